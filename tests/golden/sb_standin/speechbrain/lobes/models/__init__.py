@@ -1,0 +1,4 @@
+import os
+from ... import _REF
+__path__.append(os.path.join(_REF, "speechbrain", "lobes", "models"))
+from . import convolution  # noqa

@@ -1,0 +1,17 @@
+"""Stand-in for speechbrain.utils.dynamic_chunk_training.DynChunkTrainConfig."""
+from dataclasses import dataclass
+from typing import Optional
+
+
+@dataclass
+class DynChunkTrainConfig:
+    chunk_size: int
+    left_context_size: Optional[int] = None
+
+    def is_infinite_left_context(self) -> bool:
+        return self.left_context_size is None
+
+    def left_context_size_frames(self) -> Optional[int]:
+        if self.left_context_size is None:
+            return None
+        return self.chunk_size * self.left_context_size
