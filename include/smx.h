@@ -1,0 +1,158 @@
+/* smx.h — C-ABI of libsmx.so: the MI355X (gfx950) SummaryMixing encoder hot path.
+ *
+ * The reference (SamsungLabs/SummaryMixing @ 2024_10_08) is pure Python on torch and has NO FFI and no
+ * native kernel: every entry point below is NEW.  Each one names the reference lines whose arithmetic it
+ * replaces (paths relative to the reference root) so that a maintainer can bind it from the reference's
+ * nn.Modules (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *  - every function returns SMX_OK (0) or a negative SMX_E* code; never throws, never aborts;
+ *    smx_last_error() returns a thread-local message for the last failing call on this thread.
+ *  - all data pointers are DEVICE pointers owned by the caller; the library allocates nothing.
+ *  - matrices are row-major with an explicit leading dimension (in ELEMENTS) so column slices of a
+ *    wider buffer are addressed without copies.
+ *  - dtype is SMX_F32 or SMX_BF16 for activations/weights ("T"); biases, LayerNorm affine, conv taps,
+ *    per-utterance side inputs, statistics and all gradients of parameters are always float32.
+ *  - last argument is the hipStream_t to launch on (passed as void*); all work is stream ordered and
+ *    asynchronous; no global mutable state; safe from several host threads on different streams.
+ */
+#ifndef SMX_H_
+#define SMX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMX_VERSION 100
+
+enum { SMX_OK = 0, SMX_EINVAL = -1, SMX_EUNSUPPORTED = -2, SMX_ELAUNCH = -3 };
+enum { SMX_F32 = 0, SMX_BF16 = 1 };
+enum { SMX_ACT_NONE = 0, SMX_ACT_GELU = 1, SMX_ACT_SWISH = 2, SMX_ACT_LEAKY_RELU = 3, SMX_ACT_RELU = 4 };
+/* how the fp32 side input C0 is indexed by output row n: none | row n | row n / div | row n % div */
+enum { SMX_C0_NONE = 0, SMX_C0_ROW = 1, SMX_C0_GROUP = 2, SMX_C0_MOD = 3 };
+/* operand storage for smx_gemm: KC = reduce dimension contiguous, KS = reduce dimension strided */
+enum { SMX_GEMM_NT = 0, /* A (N,K) KC, B (M,K) KC : Y = X W^T        (torch Linear forward)            */
+       SMX_GEMM_NN = 1, /* A (N,K) KC, B (K,M) KS : dX = dZ W        (dgrad; ParallelLinear einsum)     */
+       SMX_GEMM_TN = 2  /* A (K,N) KS, B (K,M) KS : dW = dZ^T X      (wgrad)                            */ };
+enum { SMX_OUT_T = 0, SMX_OUT_F32 = 1, SMX_OUT_ATOMIC_F32 = 2 };
+enum { SMX_PAD_ZERO = 0, SMX_PAD_REFLECT = 1 };
+
+int smx_version(void);
+const char* smx_last_error(void);
+
+/* Epilogue of the fused projection GEMM:
+ *   v      = acc + bias[m] + C0[map(n), m]
+ *   Z[n,m] = v                                   (optional pre-activation store, dtype T)
+ *   a      = act(v) * row_mask[n]
+ *   C[n,m] = R[n,m] + alpha * a                  (R optional residual, dtype T)
+ * With out_mode SMX_OUT_ATOMIC_F32: C (float32) += alpha * acc and every other epilogue field must be 0. */
+typedef struct smx_epilogue {
+  const float* bias;   int64_t bias_batch_stride;       /* [M] fp32 or NULL                           */
+  const float* c0;     int64_t ldc0; int32_t c0_mode; int32_t c0_div;
+  int32_t act;         int32_t out_mode;
+  void* z;             int64_t ldz;
+  const uint8_t* row_mask;                               /* [N] 1 = valid frame, or NULL               */
+  const void* res;     int64_t ldr;
+  float alpha;         int32_t reserved;
+} smx_epilogue;
+
+/* Batched strided MFMA GEMM  C[b] (N x M) = epilogue( op(A[b]) . op(B[b]) ), reduce length K.
+ * Replaces: nn.Linear inside VanillaNN (VanillaNN.py:189-196, summary_mixing.py:207,210,237,257,282),
+ * the per-head einsum of ParallelLinear (VanillaNN.py:108-112; batch = n_split), the FFN / pointwise-conv /
+ * post-conv Linears of the Conformer layer (Conformer.py:128-157,458-472) and their autograd backward.
+ * splits > 1 partitions K over blockIdx (requires out_mode SMX_OUT_ATOMIC_F32). */
+int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb,
+             int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K, int batch, int splits,
+             const smx_epilogue* epi, void* stream);
+
+/* Y = R + alpha * act(X W^T + b [+C0]) * mask ; thin wrapper over smx_gemm(NT).
+ * Replaces summary_mixing.py:257 (global_proj * mask), :207/:210 (local/summary proj * mask),
+ * :282-284 (merge with the per-utterance summary folded in as C0 = sbar W_s^T + b, SMX_C0_GROUP, div=T). */
+int smx_linear_act_mask_fwd(int dtype, const void* X, int64_t ldx, const void* W, int64_t ldw, void* Y,
+                            int64_t ldy, int N, int M, int K, const smx_epilogue* epi, void* stream);
+
+/* dZ = dY * mask * act'(Z)  (elementwise), plus fused parameter-gradient side reductions:
+ *   dbias[m]          += sum_n dZ[n,m]                      (fp32 atomics, optional)
+ *   dgroup[n/div, m]  += sum over the rows of group n/div   (fp32 atomics, optional; the backward of a
+ *                                                            SMX_C0_GROUP side input)
+ * Backward of the epilogue above (autograd of summary_mixing.py:207-284). dY is pre-scaled by alpha. */
+int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
+                     const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
+                     float* dbias, float* dgroup, int64_t lddgroup, int group_div, void* stream);
+
+/* Masked mean over time: out[b,:] = sum_t S[b,t,:] * mask[b,t] / sum_t mask[b,t]   (fp32 out (B,D)).
+ * S is (B*T, D) with leading dimension lds.  mask NULL => all valid.  scale_by_count=0 gives the plain sum.
+ * inv_count (optional, (B) fp32) receives 1/sum_t mask[b,t].  `workspace` holds
+ * smx_masked_mean_workspace(B,T,D) bytes (split-T partial sums, combined in a fixed order => bit-reproducible).
+ * A row with zero valid frames yields NaN like the reference.  Replaces summary_mixing.py:218-220, :264-266,
+ * :305-307.  This is the HBM-roofline kernel of BASELINE config 5. */
+size_t smx_masked_mean_workspace(int B, int T, int D);
+int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const uint8_t* mask, float* out, float* inv_count,
+                        int B, int T, int D, int scale_by_count, void* workspace, void* stream);
+/* Backward / broadcast: dS[b,t,:] = g[b,:] * (inv_count ? inv_count[b] : 1) for every t (the row mask is
+ * applied by the producer's smx_act_mask_bwd).  Also the forward `repeat` (summary_mixing.py:222,267). */
+int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B, int T,
+                        int D, void* stream);
+
+/* DynChunk summary (sum_mask path, summary_mixing.py:224-235, :269-280) in O(T): frame t of chunk
+ * c = t / chunk sees frames [max(0,(c-left)*chunk), min(T,(c+1)*chunk)) (left < 0: unlimited);
+ * out[b,t,:] = sum over that window of S[b,.,:] / window length  (the denominator ignores padding, as the
+ * reference's rowsum(sum_mask) does).  bwd is the transposed operator.  workspace:
+ * smx_chunk_mean_workspace bytes (per-chunk fp32 sums). */
+size_t smx_chunk_mean_workspace(int B, int T, int D, int chunk);
+int smx_chunk_mean_fwd(int dtype, const void* S, int64_t lds, void* out, int64_t ldo, int B, int T, int D,
+                       int chunk, int left, void* workspace, void* stream);
+int smx_chunk_mean_bwd(int dtype, const void* dOut, int64_t ldo, void* dS, int64_t lds, int B, int T, int D,
+                       int chunk, int left, void* workspace, void* stream);
+
+/* LayerNorm over the last dim with an optional fused activation: Y = act(LN(X))
+ * (torch.nn.LayerNorm; Conformer.py:146,152-153,475-476,738).  stats (N,2) fp32 = (mean, rstd), optional in fwd.
+ * bwd: dX = R + LNbwd(dY * act'(LN(X))) (R optional residual-gradient, dtype T; LN(X) is recomputed from the
+ * stats); dgamma/dbeta accumulate with fp32 atomics. */
+int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const float* gamma, const float* beta, void* Y,
+                      int64_t ldy, float* stats, int N, int D, float eps, int act, void* stream);
+int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
+                      const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
+                      int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* stream);
+
+/* Fused GLU + depthwise Conv1d over time (Conformer.py:131-145,317-325):
+ *   u[b,t,c] = P[b,t,c] * sigmoid(P[b,t,D+c]);  Y[b,t,c] = bias[c] + sum_j w[c,j] u[b,t+j-(k-1)/2,c]
+ * glu=0: u = P (ldp >= D).  pad SMX_PAD_ZERO (Conformer) | SMX_PAD_REFLECT (Branchformer CSGU).
+ * chunk > 0: Dynamic Chunk Convolution (Conformer.py:190-313): inputs at or beyond the end of the output
+ * frame's own chunk read as zero.  gate != NULL: Y *= gate (CSGU x1*x2).  w (D,k) fp32, bias (D) fp32. */
+int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
+                         const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k, int glu,
+                         int pad_mode, int chunk, void* stream);
+/* dP (same shape as P), dw/dbias += (fp32 atomics); dgate optional (= dY * conv). */
+int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, const void* P, int64_t ldp, const float* w,
+                         const float* bias, const void* gate, int64_t ldg, void* dP, int64_t lddp, void* dgate,
+                         int64_t lddg, float* dw, float* dbias, int B, int T, int D, int k, int glu, int pad_mode,
+                         int chunk, void* stream);
+
+/* y = a*x (+ b*y0): generic strided elementwise helper (dtype T). */
+int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b, const void* Y0, int64_t ldy0, void* Y,
+              int64_t ldy, int N, int D, void* stream);
+/* fp32 -> T cast of a flat buffer (bf16 shadow weights). */
+int smx_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
+int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);
+
+/* Fused AdamW over a flat fp32 parameter buffer (decoupled weight decay, torch.optim.AdamW semantics;
+ * recipes/LibriSpeech/.../conformer_summarymixing_transducer.yaml:395-399).  grad_scale multiplies the
+ * gradient first (1/world_size and the global-norm clip factor); `gscale_dev` (optional, device fp32[1])
+ * is multiplied in as well so the clip factor never visits the host.  shadow (optional) receives the
+ * updated parameters cast to bf16. */
+int smx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   float grad_scale, const float* gscale_dev, void* stream);
+/* out[0] += sum(x^2) (fp32 atomics; zero it first) — global grad-norm for clipping. */
+int smx_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* out[0] = min(1, max_norm / (sqrt(sumsq[0]) * inv_scale + 1e-6)) : clip factor computed on device. */
+int smx_clip_factor(const float* sumsq, float max_norm, float inv_scale, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMX_H_ */

@@ -1,0 +1,85 @@
+"""ctypes binding of libsmx.so (include/smx.h).  The product path has NO fallback: if the HIP library is
+missing or a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmx.so")
+
+c_i, c_i64, c_f, c_vp, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# enums of include/smx.h
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SWISH, ACT_LEAKY_RELU, ACT_RELU = 0, 1, 2, 3, 4
+C0_NONE, C0_ROW, C0_GROUP, C0_MOD = 0, 1, 2, 3
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+OUT_T, OUT_F32, OUT_ATOMIC_F32 = 0, 1, 2
+PAD_ZERO, PAD_REFLECT = 0, 1
+ACTS = {"none": ACT_NONE, "identity": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH,
+        "leaky_relu": ACT_LEAKY_RELU, "relu": ACT_RELU}
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [("bias", c_vp), ("bias_batch_stride", c_i64),
+                ("c0", c_vp), ("ldc0", c_i64), ("c0_mode", ctypes.c_int32), ("c0_div", ctypes.c_int32),
+                ("act", ctypes.c_int32), ("out_mode", ctypes.c_int32),
+                ("z", c_vp), ("ldz", c_i64),
+                ("row_mask", c_vp),
+                ("res", c_vp), ("ldr", c_i64),
+                ("alpha", c_f), ("reserved", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/smx.h one to one (tests/test_abi.py checks the export list)
+SIGNATURES = {
+    "smx_version": (c_i, []),
+    "smx_last_error": (ctypes.c_char_p, []),
+    "smx_gemm": (c_i, [c_i, c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i,
+                       ctypes.POINTER(Epilogue), c_vp]),
+    "smx_linear_act_mask_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i,
+                                      ctypes.POINTER(Epilogue), c_vp]),
+    "smx_act_mask_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp,
+                               c_i64, c_i, c_vp]),
+    "smx_masked_mean_workspace": (c_sz, [c_i, c_i, c_i]),
+    "smx_masked_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "smx_masked_mean_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_vp]),
+    "smx_chunk_mean_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
+    "smx_chunk_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "smx_chunk_mean_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "smx_layernorm_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
+    "smx_layernorm_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                c_vp, c_i, c_i, c_vp]),
+    "smx_dwconv1d_glu_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i,
+                                   c_i, c_i, c_vp]),
+    "smx_dwconv1d_glu_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                   c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "smx_axpby": (c_i, [c_i, c_f, c_vp, c_i64, c_f, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
+    "smx_cast_from_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
+    "smx_cast_to_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
+    "smx_adamw_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_vp, c_vp]),
+    "smx_sumsq": (c_i, [c_vp, c_i64, c_vp, c_vp]),
+    "smx_clip_factor": (c_i, [c_vp, c_f, c_f, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libsmx.so (once).  Fails loudly: there is no CPU / eager fallback for the product path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or bash summarymixing_amd/csrc/build.sh). summarymixing_amd has no fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().smx_last_error()
+        raise RuntimeError(f"{what} failed with code {code}: {msg.decode() if msg else ''}")

@@ -1,0 +1,705 @@
+// rowwise.hip — HBM-bound row-wise kernels of the SummaryMixing path (gfx950, wave64):
+//   masked mean over time (split-T, fixed-order combine) + broadcast backward, DynChunk window mean,
+//   LayerNorm fwd/bwd, activation/mask backward with fused bias / per-utterance column sums,
+//   axpby, casts, fused AdamW, sum of squares, clip factor.
+// Every kernel moves 8-16 bytes per lane per access along the feature dim (coalesced 512 B - 1 KiB per
+// wave instruction) and accumulates in fp32.
+#include "smx_common.h"
+
+namespace smx {
+
+template <typename T> struct VT;                       // elements per 16-byte lane access
+template <> struct VT<float>  { static constexpr int N = 4; };
+template <> struct VT<bf16_t> { static constexpr int N = 8; };
+
+template <typename T, bool VEC>
+__device__ __forceinline__ void loadv(const T* p, int nvalid, float (&f)[VT<T>::N]) {
+  constexpr int N = VT<T>::N;
+  if (VEC && nvalid >= N) {
+    if constexpr (sizeof(T) == 2) {
+      uint4 r = *reinterpret_cast<const uint4*>(p);
+      const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_bits_to_f32(w[i] & 0xffffu); f[2 * i + 1] = bf16_bits_to_f32(w[i] >> 16); }
+    } else {
+      float4 r = *reinterpret_cast<const float4*>(p);
+      f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = (i < nvalid) ? to_f32(p[i]) : 0.f;
+  }
+}
+template <typename T, bool VEC>
+__device__ __forceinline__ void storev(T* p, int nvalid, const float (&f)[VT<T>::N]) {
+  constexpr int N = VT<T>::N;
+  if (VEC && nvalid >= N) {
+    if constexpr (sizeof(T) == 2) {
+      uint4 r;
+      r.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
+      r.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+      r.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16);
+      r.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+      *reinterpret_cast<uint4*>(p) = r;
+    } else {
+      *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i < nvalid) p[i] = from_f32<T>(f[i]);
+  }
+}
+
+static inline bool vec_ok(const void* p, int64_t ld, int D, int n, size_t es) {
+  return p == nullptr || (aligned16(p) && ld % n == 0 && D % n == 0 && (ld * es) % 16 == 0);
+}
+
+// =================================================================================================
+// masked mean over time.  stage 1: grid (DC, TS, B); 4 waves of a block interleave over the rows of the
+// block's time range; each lane owns VT<T>::N consecutive features (16-byte loads, 4 rows in flight).
+// =================================================================================================
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void masked_sum_stage1(const T* S, long lds, const uint8_t* mask, float* partial,
+                                                         int T_, int D, int TR, int TS) {
+  constexpr int N = VT<T>::N;
+  __shared__ float red[3][64 * N];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.z, ts = blockIdx.y;
+  const int col = (blockIdx.x * 64 + lane) * N;
+  const int nvalid = D - col;
+  const int t0 = ts * TR, t1 = min(T_, t0 + TR);
+  float acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0.f;
+  const T* base = S + ((long)b * T_) * lds + col;
+  const uint8_t* mrow = mask ? mask + (long)b * T_ : nullptr;
+  int t = t0 + w;
+  for (; t + 12 < t1; t += 16) {          // 4 independent 16-byte loads in flight per lane
+    float f0[N], f1[N], f2[N], f3[N];
+    loadv<T, VEC>(base + (long)t * lds, nvalid, f0);
+    loadv<T, VEC>(base + (long)(t + 4) * lds, nvalid, f1);
+    loadv<T, VEC>(base + (long)(t + 8) * lds, nvalid, f2);
+    loadv<T, VEC>(base + (long)(t + 12) * lds, nvalid, f3);
+    float m0 = 1.f, m1 = 1.f, m2 = 1.f, m3 = 1.f;
+    if (mrow) { m0 = mrow[t] ? 1.f : 0.f; m1 = mrow[t + 4] ? 1.f : 0.f; m2 = mrow[t + 8] ? 1.f : 0.f; m3 = mrow[t + 12] ? 1.f : 0.f; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] += (f0[i] * m0 + f1[i] * m1) + (f2[i] * m2 + f3[i] * m3);
+  }
+  for (; t < t1; t += 4) {
+    float f0[N];
+    loadv<T, VEC>(base + (long)t * lds, nvalid, f0);
+    float m0 = mrow ? (mrow[t] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] += f0[i] * m0;
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[w - 1][lane * N + i] = acc[i];
+  }
+  __syncthreads();
+  if (w == 0 && nvalid > 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = ((acc[i] + red[0][lane * N + i]) + red[1][lane * N + i]) + red[2][lane * N + i];
+    float* o = partial + ((long)b * TS + ts) * D + col;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i < nvalid) o[i] = acc[i];
+  }
+}
+
+// stage 2: fixed-order sum of the TS partials, divide by the number of valid frames.  grid (ceil(D/256), B)
+__global__ __launch_bounds__(256) void masked_sum_stage2(const float* partial, const uint8_t* mask, float* out,
+                                                         float* inv_count, int T_, int D, int TS, int scale) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+  float inv = 1.f;
+  if (scale || inv_count) {
+    float c = 0.f;
+    if (mask) {
+      for (int t = threadIdx.x; t < T_; t += 256) c += mask[(long)b * T_ + t] ? 1.f : 0.f;
+      c = wave_sum(c);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+      __syncthreads();
+      c = (red[0] + red[1]) + (red[2] + red[3]);
+    } else {
+      c = (float)T_;
+    }
+    inv = 1.f / c;   // zero valid frames -> inf, 0*inf = NaN, as the reference (summary_mixing.py:264-266)
+    if (inv_count && blockIdx.x == 0 && threadIdx.x == 0) inv_count[b] = inv;
+  }
+  if (col >= D) return;
+  float s = 0.f;
+  for (int ts = 0; ts < TS; ++ts) s += partial[((long)b * TS + ts) * D + col];
+  out[(long)b * D + col] = scale ? s * inv : s;
+}
+
+static void mm_plan(int B, int T, int D, int nvec, int& DC, int& TS, int& TR) {
+  DC = (D + 64 * nvec - 1) / (64 * nvec);
+  long want = (2048 + (long)B * DC - 1) / ((long)B * DC);   // >= 2048 blocks when the rows allow it
+  long maxts = (T + 63) / 64;                               // >= 64 rows per block
+  TS = (int)(want < 1 ? 1 : (want > maxts ? maxts : want));
+  if (TS < 1) TS = 1;
+  TR = (T + TS - 1) / TS;
+  TS = (T + TR - 1) / TR;
+  if (TS < 1) TS = 1;
+}
+
+// dS[b,t,:] = g[b,:] * inv_count[b]   (broadcast over t).  grid (DC, ceil(T/RPB), B)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const float* inv_count, T* dS, long ldds,
+                                                         int T_, int D, int RPB) {
+  constexpr int N = VT<T>::N;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
+  const int col = (blockIdx.x * 64 + lane) * N;
+  const int nvalid = D - col;
+  if (nvalid <= 0) return;
+  float v[N];
+  const float sc = inv_count ? inv_count[b] : 1.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = (i < nvalid) ? g[(long)b * D + col + i] * sc : 0.f;
+  const int t0 = blockIdx.y * RPB, t1 = min(T_, t0 + RPB);
+  for (int t = t0 + w; t < t1; t += 4) storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, v);
+}
+
+// =================================================================================================
+// DynChunk window mean (O(T)).  chunk sums -> window combine.
+// =================================================================================================
+// csum[b,c,:] = scale_c * sum_{t in chunk c} X[b,t,:]   (scale_c = 1 or 1/wlen(c)).  grid (DC, NC, B)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const T* X, long ldx, float* csum, int T_, int D, int chunk,
+                                                        int NC, int left, int scale_by_wlen) {
+  constexpr int N = VT<T>::N;
+  __shared__ float red[3][64 * N];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z, c = blockIdx.y;
+  const int col = (blockIdx.x * 64 + lane) * N;
+  const int nvalid = D - col;
+  const int t0 = c * chunk, t1 = min(T_, t0 + chunk);
+  float acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0.f;
+  for (int t = t0 + w; t < t1; t += 4) {
+    float f[N];
+    loadv<T, VEC>(X + ((long)b * T_ + t) * ldx + col, nvalid, f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] += f[i];
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[w - 1][lane * N + i] = acc[i];
+  }
+  __syncthreads();
+  if (w == 0 && nvalid > 0) {
+    float sc = 1.f;
+    if (scale_by_wlen) {
+      int lo = left < 0 ? 0 : max(0, (c - left) * chunk);
+      sc = 1.f / (float)(t1 - lo);
+    }
+    float* o = csum + ((long)b * NC + c) * D + col;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i < nvalid) o[i] = sc * (((acc[i] + red[0][lane * N + i]) + red[1][lane * N + i]) + red[2][lane * N + i]);
+  }
+}
+// fwd: out rows of chunk c = (sum_{c'=lo..c} csum[c']) / wlen(c);  bwd (reverse=1): rows of chunk c =
+// sum_{c'=c..hi} csum[c'] (csum already scaled by 1/wlen).  grid (DC, NC, B)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void chunk_window_kernel(const float* csum, T* out, long ldo, int T_, int D,
+                                                           int chunk, int NC, int left, int reverse) {
+  constexpr int N = VT<T>::N;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z, c = blockIdx.y;
+  const int col = (blockIdx.x * 64 + lane) * N;
+  const int nvalid = D - col;
+  if (nvalid <= 0) return;
+  int clo, chi;
+  if (!reverse) { clo = left < 0 ? 0 : max(0, c - left); chi = c; }
+  else { clo = c; chi = left < 0 ? NC - 1 : min(NC - 1, c + left); }
+  float acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0.f;
+  for (int cc = clo; cc <= chi; ++cc) {
+    const float* p = csum + ((long)b * NC + cc) * D + col;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i < nvalid) acc[i] += p[i];
+  }
+  const int t0 = c * chunk, t1 = min(T_, t0 + chunk);
+  if (!reverse) {
+    int lo = left < 0 ? 0 : max(0, (c - left) * chunk);
+    float sc = 1.f / (float)(t1 - lo);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] *= sc;
+  }
+  for (int t = t0 + w; t < t1; t += 4) storev<T, VEC>(out + ((long)b * T_ + t) * ldo + col, nvalid, acc);
+}
+
+// =================================================================================================
+// LayerNorm.  One wave per row, 4 rows per block; lane owns 4-element vectors at columns lane*4 + 256*i.
+// =================================================================================================
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* X, long ldx, const float* gamma, const float* beta,
+                                                            T* Y, long ldy, float* stats, int N_, int D, float eps,
+                                                            int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N_) return;
+  const T* x = X + (long)row * ldx;
+  T* y = Y + (long)row * ldy;
+  float s = 0.f;
+  if (VEC) {
+    for (int c = lane * 4; c < D; c += 256) { float f[4]; load4<T>(x + c, f); s += (f[0] + f[1]) + (f[2] + f[3]); }
+  } else {
+    for (int c = lane; c < D; c += 64) s += to_f32(x[c]);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  if (VEC) {
+    for (int c = lane * 4; c < D; c += 256) {
+      float f[4]; load4<T>(x + c, f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float d = f[i] - mean; q += d * d; }
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) { float d = to_f32(x[c]) - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (stats && lane == 0) { stats[2 * (long)row] = mean; stats[2 * (long)row + 1] = rstd; }
+  if (VEC) {
+    for (int c = lane * 4; c < D; c += 256) {
+      float f[4]; load4<T>(x + c, f);
+      float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
+      float o[4] = {(f[0] - mean) * rstd * g4.x + b4.x, (f[1] - mean) * rstd * g4.y + b4.y,
+                    (f[2] - mean) * rstd * g4.z + b4.z, (f[3] - mean) * rstd * g4.w + b4.w};
+      if (act != SMX_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = act_fwd(act, o[i]);
+      }
+      store4<T>(y + c, o);
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) y[c] = from_f32<T>(act_fwd(act, (to_f32(x[c]) - mean) * rstd * gamma[c] + beta[c]));
+  }
+}
+
+// bwd: dx = R + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma.  Blocks stride over rows and keep
+// their dgamma/dbeta partial sums in registers (columns lane*VW + 64*VW*i, i < CH), one atomic flush at the end.
+template <typename T, int VW, int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dY, long lddy, const T* X, long ldx,
+                                                            const float* gamma, const float* beta, int act,
+                                                            const float* stats, const T* R, long ldr,
+                                                            T* dX, long lddx, float* dgamma, float* dbeta, int N_, int D) {
+  __shared__ float red[3][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float dg[CH][VW], db[CH][VW];
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int j = 0; j < VW; ++j) dg[i][j] = db[i][j] = 0.f;
+  for (int row = blockIdx.x * 4 + w; row < N_; row += gridDim.x * 4) {
+    const T* dy = dY + (long)row * lddy;
+    const T* x = X + (long)row * ldx;
+    const float mean = stats[2 * (long)row], rstd = stats[2 * (long)row + 1];
+    float gv[CH][VW], xh[CH][VW];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (lane + 64 * i) * VW;
+      if (c < D) {
+        float fdy[VW], fx[VW];
+        if constexpr (VW == 4) { load4<T>(dy + c, fdy); load4<T>(x + c, fx); }
+        else { fdy[0] = to_f32(dy[c]); fx[0] = to_f32(x[c]); }
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          float xhat = (fx[j] - mean) * rstd;
+          float dyn = fdy[j];
+          if (act != SMX_ACT_NONE) dyn *= act_grad(act, xhat * gamma[c + j] + beta[c + j]);
+          float g = dyn * gamma[c + j];
+          xh[i][j] = xhat; gv[i][j] = g;
+          s1 += g; s2 += g * xhat;
+          dg[i][j] += dyn * xhat; db[i][j] += dyn;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) { xh[i][j] = 0.f; gv[i][j] = 0.f; }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (lane + 64 * i) * VW;
+      if (c < D) {
+        float o[VW];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) o[j] = rstd * (gv[i][j] - s1 - xh[i][j] * s2);
+        if (R) {
+          if constexpr (VW == 4) { float r[4]; load4<T>(R + (long)row * ldr + c, r); for (int j = 0; j < 4; ++j) o[j] += r[j]; }
+          else o[0] += to_f32(R[(long)row * ldr + c]);
+        }
+        if constexpr (VW == 4) store4<T>(dX + (long)row * lddx + c, o);
+        else dX[(long)row * lddx + c] = from_f32<T>(o[0]);
+      }
+    }
+  }
+  // flush dgamma / dbeta: reduce the 4 waves through LDS, one atomic per column per block
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        float v = pass == 0 ? dg[i][j] : db[i][j];
+        __syncthreads();
+        if (w > 0) red[w - 1][lane] = v;
+        __syncthreads();
+        if (w == 0) {
+          v = ((v + red[0][lane]) + red[1][lane]) + red[2][lane];
+          const int c = (lane + 64 * i) * VW + j;
+          if (c < D) atomicAdd((pass == 0 ? dgamma : dbeta) + c, v);
+        }
+      }
+  }
+}
+
+// =================================================================================================
+// dZ = alpha * dY * mask * act'(Z);  dbias[m] += colsum;  dgroup[n/div, m] += per-group colsum.
+// block = 64 column-vectors (4 elements each) x 4 row lanes; strip of RS rows per block.
+// =================================================================================================
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long lddy, const T* Z, long ldz,
+                                                           const uint8_t* mask, T* dZ, long lddz, int N_, int M, int act,
+                                                           float alpha, float* dbias, float* dgroup, long lddg, int gdiv,
+                                                           int RS) {
+  __shared__ float red[3][64][4];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + cx) * 4;
+  const int nvalid = M - col;
+  const int r0 = blockIdx.y * RS, r1 = min(N_, r0 + RS);
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f}, gsum[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur_g = -1;
+  if (nvalid > 0) {
+    for (int n = r0 + ry; n < r1; n += 4) {
+      float fdy[4], fz[4], o[4];
+      if (VEC && nvalid >= 4) { load4<T>(dY + (long)n * lddy + col, fdy); }
+      else { for (int q = 0; q < 4; ++q) fdy[q] = q < nvalid ? to_f32(dY[(long)n * lddy + col + q]) : 0.f; }
+      if (Z) {
+        if (VEC && nvalid >= 4) load4<T>(Z + (long)n * ldz + col, fz);
+        else { for (int q = 0; q < 4; ++q) fz[q] = q < nvalid ? to_f32(Z[(long)n * ldz + col + q]) : 0.f; }
+      }
+      const float mk = (mask ? (mask[n] ? 1.f : 0.f) : 1.f) * alpha;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = fdy[q] * mk * (Z ? act_grad(act, fz[q]) : 1.f);
+      if (dZ) {
+        if (VEC && nvalid >= 4) store4<T>(dZ + (long)n * lddz + col, o);
+        else { for (int q = 0; q < 4; ++q) if (q < nvalid) dZ[(long)n * lddz + col + q] = from_f32<T>(o[q]); }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bsum[q] += o[q];
+      if (dgroup) {
+        int g = n / gdiv;
+        if (g != cur_g) {
+          if (cur_g >= 0) { for (int q = 0; q < 4; ++q) if (q < nvalid) atomicAdd(dgroup + (long)cur_g * lddg + col + q, gsum[q]); }
+          cur_g = g;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gsum[q] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gsum[q] += o[q];
+      }
+    }
+    if (dgroup && cur_g >= 0) { for (int q = 0; q < 4; ++q) if (q < nvalid) atomicAdd(dgroup + (long)cur_g * lddg + col + q, gsum[q]); }
+  }
+  if (dbias) {
+    if (ry > 0) { for (int q = 0; q < 4; ++q) red[ry - 1][cx][q] = bsum[q]; }
+    __syncthreads();
+    if (ry == 0 && nvalid > 0) {
+      for (int q = 0; q < 4; ++q)
+        if (q < nvalid) atomicAdd(dbias + col + q, ((bsum[q] + red[0][cx][q]) + red[1][cx][q]) + red[2][cx][q]);
+    }
+  }
+}
+
+// y = a*x + b*y0
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void axpby_kernel(float a, const T* X, long ldx, float b, const T* Y0, long ldy0, T* Y,
+                                                    long ldy, int N_, int D) {
+  const int cv = (D + 3) / 4;
+  long total = (long)N_ * cv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int n = (int)(i / cv), col = (int)(i % cv) * 4, nvalid = D - col;
+    float fx[4], fy[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+    if (VEC && nvalid >= 4) load4<T>(X + (long)n * ldx + col, fx);
+    else { for (int q = 0; q < 4; ++q) fx[q] = q < nvalid ? to_f32(X[(long)n * ldx + col + q]) : 0.f; }
+    if (Y0) {
+      if (VEC && nvalid >= 4) load4<T>(Y0 + (long)n * ldy0 + col, fy);
+      else { for (int q = 0; q < 4; ++q) fy[q] = q < nvalid ? to_f32(Y0[(long)n * ldy0 + col + q]) : 0.f; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = a * fx[q] + b * fy[q];
+    if (VEC && nvalid >= 4) store4<T>(Y + (long)n * ldy + col, o);
+    else { for (int q = 0; q < 4; ++q) if (q < nvalid) Y[(long)n * ldy + col + q] = from_f32<T>(o[q]); }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* src, T* dst, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = from_f32<T>(src[i]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* src, float* dst, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = to_f32(src[i]);
+}
+
+// fused AdamW (torch.optim.AdamW semantics: p *= 1 - lr*wd; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps))
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, uint16_t* shadow, long n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, float gscale, const float* gscale_dev) {
+  const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.f);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float gi = g[i] * gs, pi = p[i], mi = m[i], vi = v[i];
+    pi *= 1.f - lr * wd;
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (shadow) shadow[i] = (uint16_t)f32_to_bf16_bits(pi);
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ void clip_factor_kernel(const float* sumsq, float max_norm, float inv_scale, float* out) {
+  float nrm = sqrtf(sumsq[0]) * inv_scale;
+  float f = max_norm / (nrm + 1e-6f);
+  out[0] = f < 1.f ? f : 1.f;
+}
+
+static inline int grid1d(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace smx
+
+using namespace smx;
+#define STREAM reinterpret_cast<hipStream_t>(stream)
+
+extern "C" size_t smx_masked_mean_workspace(int B, int T, int D) {
+  int DC, TS, TR;
+  mm_plan(B, T, D, 4, DC, TS, TR);  // fp32 plan has the most splits; bf16 needs no more
+  int DC2, TS2, TR2;
+  mm_plan(B, T, D, 8, DC2, TS2, TR2);
+  int ts = TS > TS2 ? TS : TS2;
+  return (size_t)B * ts * D * sizeof(float);
+}
+
+extern "C" int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const uint8_t* mask, float* out,
+                                   float* inv_count, int B, int T, int D, int scale_by_count, void* workspace,
+                                   void* stream) {
+  SMX_REQUIRE(S && out && workspace, "smx_masked_mean_fwd: null pointer");
+  SMX_REQUIRE(B > 0 && T > 0 && D > 0, "smx_masked_mean_fwd: bad sizes");
+  const int nvec = dtype == SMX_BF16 ? 8 : 4;
+  int DC, TS, TR;
+  mm_plan(B, T, D, nvec, DC, TS, TR);
+  dim3 g1(DC, TS, B);
+  float* partial = reinterpret_cast<float*>(workspace);
+  const bool vec = vec_ok(S, lds, D, nvec, dtype == SMX_BF16 ? 2 : 4);
+  if (dtype == SMX_BF16) {
+    if (vec) hipLaunchKernelGGL((masked_sum_stage1<bf16_t, true>), g1, dim3(256), 0, STREAM, (const bf16_t*)S, lds, mask, partial, T, D, TR, TS);
+    else hipLaunchKernelGGL((masked_sum_stage1<bf16_t, false>), g1, dim3(256), 0, STREAM, (const bf16_t*)S, lds, mask, partial, T, D, TR, TS);
+  } else if (dtype == SMX_F32) {
+    if (vec) hipLaunchKernelGGL((masked_sum_stage1<float, true>), g1, dim3(256), 0, STREAM, (const float*)S, lds, mask, partial, T, D, TR, TS);
+    else hipLaunchKernelGGL((masked_sum_stage1<float, false>), g1, dim3(256), 0, STREAM, (const float*)S, lds, mask, partial, T, D, TR, TS);
+  } else return fail(SMX_EINVAL, "smx_masked_mean_fwd: bad dtype");
+  hipLaunchKernelGGL(masked_sum_stage2, dim3((D + 255) / 256, B), dim3(256), 0, STREAM, partial, mask, out, inv_count, T, D, TS, scale_by_count);
+  return check_launch("smx_masked_mean_fwd");
+}
+
+extern "C" int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B,
+                                   int T, int D, void* stream) {
+  SMX_REQUIRE(g && dS, "smx_masked_mean_bwd: null pointer");
+  const int nvec = dtype == SMX_BF16 ? 8 : 4;
+  const int DC = (D + 64 * nvec - 1) / (64 * nvec), RPB = 64;
+  dim3 grid(DC, (T + RPB - 1) / RPB, B);
+  const bool vec = vec_ok(dS, ldds, D, nvec, dtype == SMX_BF16 ? 2 : 4);
+  if (dtype == SMX_BF16) {
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB);
+    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB);
+  } else {
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB);
+    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB);
+  }
+  return check_launch("smx_masked_mean_bwd");
+}
+
+extern "C" size_t smx_chunk_mean_workspace(int B, int T, int D, int chunk) {
+  int NC = (T + chunk - 1) / chunk;
+  return (size_t)B * NC * D * sizeof(float);
+}
+
+template <typename T>
+static int chunk_mean_impl(const void* X, int64_t ldx, void* out, int64_t ldo, int B, int T_, int D, int chunk, int left,
+                           int reverse, void* ws, hipStream_t s) {
+  const int nvec = VT<T>::N;
+  const int NC = (T_ + chunk - 1) / chunk, DC = (D + 64 * nvec - 1) / (64 * nvec);
+  dim3 grid(DC, NC, B);
+  float* csum = reinterpret_cast<float*>(ws);
+  const bool v1 = vec_ok(X, ldx, D, nvec, sizeof(T)), v2 = vec_ok(out, ldo, D, nvec, sizeof(T));
+  if (v1) hipLaunchKernelGGL((chunk_sum_kernel<T, true>), grid, dim3(256), 0, s, (const T*)X, ldx, csum, T_, D, chunk, NC, left, reverse);
+  else hipLaunchKernelGGL((chunk_sum_kernel<T, false>), grid, dim3(256), 0, s, (const T*)X, ldx, csum, T_, D, chunk, NC, left, reverse);
+  if (v2) hipLaunchKernelGGL((chunk_window_kernel<T, true>), grid, dim3(256), 0, s, csum, (T*)out, ldo, T_, D, chunk, NC, left, reverse);
+  else hipLaunchKernelGGL((chunk_window_kernel<T, false>), grid, dim3(256), 0, s, csum, (T*)out, ldo, T_, D, chunk, NC, left, reverse);
+  return check_launch("smx_chunk_mean");
+}
+
+extern "C" int smx_chunk_mean_fwd(int dtype, const void* S, int64_t lds, void* out, int64_t ldo, int B, int T, int D,
+                                  int chunk, int left, void* workspace, void* stream) {
+  SMX_REQUIRE(S && out && workspace && chunk > 0, "smx_chunk_mean_fwd: bad arguments");
+  if (dtype == SMX_BF16) return chunk_mean_impl<bf16_t>(S, lds, out, ldo, B, T, D, chunk, left, 0, workspace, STREAM);
+  return chunk_mean_impl<float>(S, lds, out, ldo, B, T, D, chunk, left, 0, workspace, STREAM);
+}
+extern "C" int smx_chunk_mean_bwd(int dtype, const void* dOut, int64_t ldo, void* dS, int64_t lds, int B, int T, int D,
+                                  int chunk, int left, void* workspace, void* stream) {
+  SMX_REQUIRE(dOut && dS && workspace && chunk > 0, "smx_chunk_mean_bwd: bad arguments");
+  if (dtype == SMX_BF16) return chunk_mean_impl<bf16_t>(dOut, ldo, dS, lds, B, T, D, chunk, left, 1, workspace, STREAM);
+  return chunk_mean_impl<float>(dOut, ldo, dS, lds, B, T, D, chunk, left, 1, workspace, STREAM);
+}
+
+extern "C" int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const float* gamma, const float* beta, void* Y,
+                                 int64_t ldy, float* stats, int N, int D, float eps, int act, void* stream) {
+  SMX_REQUIRE(X && Y && gamma && beta && N >= 0 && D > 0, "smx_layernorm_fwd: bad arguments");
+  if (N == 0) return SMX_OK;
+  const size_t es = dtype == SMX_BF16 ? 2 : 4;
+  auto ok = [&](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) % (4 * es)) == 0 && ld % 4 == 0; };
+  const bool vec = D % 4 == 0 && ok(X, ldx) && ok(Y, ldy) && aligned16(gamma) && aligned16(beta);
+  dim3 grid((N + 3) / 4);
+  if (dtype == SMX_BF16) {
+    if (vec) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, (const bf16_t*)X, ldx, gamma, beta, (bf16_t*)Y, ldy, stats, N, D, eps, act);
+    else hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, (const bf16_t*)X, ldx, gamma, beta, (bf16_t*)Y, ldy, stats, N, D, eps, act);
+  } else {
+    if (vec) hipLaunchKernelGGL((layernorm_fwd_kernel<float, true>), grid, dim3(256), 0, STREAM, (const float*)X, ldx, gamma, beta, (float*)Y, ldy, stats, N, D, eps, act);
+    else hipLaunchKernelGGL((layernorm_fwd_kernel<float, false>), grid, dim3(256), 0, STREAM, (const float*)X, ldx, gamma, beta, (float*)Y, ldy, stats, N, D, eps, act);
+  }
+  return check_launch("smx_layernorm_fwd");
+}
+
+template <typename T>
+static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma, const float* beta,
+                       int act, const float* stats,
+                       const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma, float* dbeta, int N, int D,
+                       hipStream_t s) {
+  auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % (4 * sizeof(T))) == 0 && ld % 4 == 0); };
+  const bool vec = D % 4 == 0 && ok(dY, lddy) && ok(X, ldx) && ok(R, ldr) && ok(dX, lddx);
+  int blocks = (N + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid(blocks);
+#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, dgamma, dbeta, N, D)
+  if (vec) {
+    if (D <= 256) LN_BWD(4, 1);
+    else if (D <= 512) LN_BWD(4, 2);
+    else if (D <= 1024) LN_BWD(4, 4);
+    else if (D <= 2048) LN_BWD(4, 8);
+    else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 2048", D);
+  } else {
+    if (D <= 256) LN_BWD(1, 4);
+    else if (D <= 1024) LN_BWD(1, 16);
+    else if (D <= 2048) LN_BWD(1, 32);
+    else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 2048", D);
+  }
+#undef LN_BWD
+  return check_launch("smx_layernorm_bwd");
+}
+
+extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
+                                 const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma,
+                                 float* dbeta, int N, int D, void* stream) {
+  SMX_REQUIRE(dY && X && gamma && beta && stats && dX && dgamma && dbeta && D > 0, "smx_layernorm_bwd: bad arguments");
+  if (N == 0) return SMX_OK;
+  if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, STREAM);
+  return ln_bwd_impl<float>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, STREAM);
+}
+
+extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
+                                const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
+                                float* dbias, float* dgroup, int64_t lddgroup, int group_div, void* stream) {
+  SMX_REQUIRE(dY && N >= 0 && M > 0, "smx_act_mask_bwd: bad arguments");
+  SMX_REQUIRE(!dgroup || group_div > 0, "smx_act_mask_bwd: group_div must be > 0");
+  if (N == 0) return SMX_OK;
+  const size_t es = dtype == SMX_BF16 ? 2 : 4;
+  auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % (4 * es)) == 0 && ld % 4 == 0); };
+  const bool vec = ok(dY, lddy) && ok(Z, ldz) && ok(dZ, lddz);
+  const int RS = 64;
+  dim3 grid((M + 255) / 256, (N + RS - 1) / RS);
+  if (dtype == SMX_BF16) {
+    if (vec) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
+    else hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
+  } else {
+    if (vec) hipLaunchKernelGGL((act_mask_bwd_kernel<float, true>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
+    else hipLaunchKernelGGL((act_mask_bwd_kernel<float, false>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
+  }
+  return check_launch("smx_act_mask_bwd");
+}
+
+extern "C" int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b, const void* Y0, int64_t ldy0, void* Y,
+                         int64_t ldy, int N, int D, void* stream) {
+  SMX_REQUIRE(X && Y, "smx_axpby: null pointer");
+  if (N <= 0 || D <= 0) return SMX_OK;
+  const size_t es = dtype == SMX_BF16 ? 2 : 4;
+  auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % (4 * es)) == 0 && ld % 4 == 0); };
+  const bool vec = ok(X, ldx) && ok(Y0, ldy0) && ok(Y, ldy);
+  int grid = grid1d((long)N * ((D + 3) / 4));
+  if (dtype == SMX_BF16) {
+    if (vec) hipLaunchKernelGGL((axpby_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, STREAM, a, (const bf16_t*)X, ldx, b, (const bf16_t*)Y0, ldy0, (bf16_t*)Y, ldy, N, D);
+    else hipLaunchKernelGGL((axpby_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, STREAM, a, (const bf16_t*)X, ldx, b, (const bf16_t*)Y0, ldy0, (bf16_t*)Y, ldy, N, D);
+  } else {
+    if (vec) hipLaunchKernelGGL((axpby_kernel<float, true>), dim3(grid), dim3(256), 0, STREAM, a, (const float*)X, ldx, b, (const float*)Y0, ldy0, (float*)Y, ldy, N, D);
+    else hipLaunchKernelGGL((axpby_kernel<float, false>), dim3(grid), dim3(256), 0, STREAM, a, (const float*)X, ldx, b, (const float*)Y0, ldy0, (float*)Y, ldy, N, D);
+  }
+  return check_launch("smx_axpby");
+}
+
+extern "C" int smx_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream) {
+  SMX_REQUIRE(src && dst, "smx_cast_from_f32: null pointer");
+  if (n <= 0) return SMX_OK;
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((cast_from_f32_kernel<bf16_t>), dim3(grid1d(n)), dim3(256), 0, STREAM, src, (bf16_t*)dst, n);
+  else hipLaunchKernelGGL((cast_from_f32_kernel<float>), dim3(grid1d(n)), dim3(256), 0, STREAM, src, (float*)dst, n);
+  return check_launch("smx_cast_from_f32");
+}
+extern "C" int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream) {
+  SMX_REQUIRE(src && dst, "smx_cast_to_f32: null pointer");
+  if (n <= 0) return SMX_OK;
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((cast_to_f32_kernel<bf16_t>), dim3(grid1d(n)), dim3(256), 0, STREAM, (const bf16_t*)src, dst, n);
+  else hipLaunchKernelGGL((cast_to_f32_kernel<float>), dim3(grid1d(n)), dim3(256), 0, STREAM, (const float*)src, dst, n);
+  return check_launch("smx_cast_to_f32");
+}
+
+extern "C" int smx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                              int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              float grad_scale, const float* gscale_dev, void* stream) {
+  SMX_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "smx_adamw_step: bad arguments");
+  if (n <= 0) return SMX_OK;
+  float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq,
+                     (uint16_t*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, gscale_dev);
+  return check_launch("smx_adamw_step");
+}
+extern "C" int smx_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  SMX_REQUIRE(x && out, "smx_sumsq: null pointer");
+  if (n <= 0) return SMX_OK;
+  int g = grid1d(n);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, STREAM, x, n, out);
+  return check_launch("smx_sumsq");
+}
+extern "C" int smx_clip_factor(const float* sumsq, float max_norm, float inv_scale, float* out, void* stream) {
+  SMX_REQUIRE(sumsq && out, "smx_clip_factor: null pointer");
+  hipLaunchKernelGGL(clip_factor_kernel, dim3(1), dim3(1), 0, STREAM, sumsq, max_norm, inv_scale, out);
+  return check_launch("smx_clip_factor");
+}

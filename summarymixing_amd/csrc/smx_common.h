@@ -1,0 +1,130 @@
+// smx_common.h — shared device/host helpers for the gfx950 kernels of libsmx.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/smx.h"
+
+namespace smx {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (thread-local message; never throws)
+// ---------------------------------------------------------------------------------------------
+char* last_error_buf();
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define SMX_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return ::smx::fail(SMX_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// element types
+// ---------------------------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t v;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                 // round to nearest even
+  return u >> 16;
+}
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
+template <typename T>
+__device__ __forceinline__ T from_f32(float x);
+template <>
+__device__ __forceinline__ float from_f32<float>(float x) {
+  return x;
+}
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
+  bf16_t r;
+  r.v = (uint16_t)f32_to_bf16_bits(x);
+  return r;
+}
+
+// 4 consecutive elements <-> 4 floats (vector width used by every row-wise kernel and the GEMM epilogue)
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  typedef float4 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float (&f)[4]) {
+    f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
+  }
+  static __device__ __forceinline__ raw pack(const float (&f)[4]) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <>
+struct Vec4<bf16_t> {
+  typedef uint2 raw;
+  static __device__ __forceinline__ void unpack(const raw& r, float (&f)[4]) {
+    f[0] = bf16_bits_to_f32(r.x & 0xffffu); f[1] = bf16_bits_to_f32(r.x >> 16);
+    f[2] = bf16_bits_to_f32(r.y & 0xffffu); f[3] = bf16_bits_to_f32(r.y >> 16);
+  }
+  static __device__ __forceinline__ raw pack(const float (&f)[4]) {
+    uint2 r;
+    r.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
+    r.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+    return r;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&f)[4]) {
+  typename Vec4<T>::raw r = *reinterpret_cast<const typename Vec4<T>::raw*>(p);
+  Vec4<T>::unpack(r, f);
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&f)[4]) {
+  *reinterpret_cast<typename Vec4<T>::raw*>(p) = Vec4<T>::pack(f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations (fp32 math).  gelu = exact erf GELU (torch.nn.GELU default), swish = x*sigmoid(x)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float act_fwd(int act, float v) {
+  switch (act) {
+    case SMX_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case SMX_ACT_SWISH: return v * sigmoidf_(v);
+    case SMX_ACT_LEAKY_RELU: return v >= 0.f ? v : 0.01f * v;
+    case SMX_ACT_RELU: return v > 0.f ? v : 0.f;
+    default: return v;
+  }
+}
+__device__ __forceinline__ float act_grad(int act, float v) {
+  switch (act) {
+    case SMX_ACT_GELU: {
+      float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+      float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+      return cdf + v * pdf;
+    }
+    case SMX_ACT_SWISH: {
+      float s = sigmoidf_(v);
+      return s * (1.0f + v * (1.0f - s));
+    }
+    case SMX_ACT_LEAKY_RELU: return v >= 0.f ? 1.f : 0.01f;
+    case SMX_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+    default: return 1.f;
+  }
+}
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+}  // namespace smx

@@ -1,0 +1,426 @@
+"""Host-side orchestration of the SummaryMixing encoder hot path on top of the libsmx.so kernels.
+
+Every block is a (forward, backward-closure) pair written against ``ops``; a single generic
+``torch.autograd.Function`` (``_BlockFn``) chains the blocks, so autograd only ever sees one activation in and
+one activation out per block: residual adds, gradient fan-in sums and parameter-gradient accumulation all
+happen inside the HIP kernels (GEMM epilogues, LayerNorm-backward residual input, fp32 atomics into
+``param.grad``).  Parameter gradients are therefore written by the kernels directly into ``param.grad``
+(created on demand, fp32, accumulate semantics identical to autograd's).
+
+Reference behaviour mirrored here (paths relative to the reference root):
+  cell                  speechbrain/nnet/summary_mixing.py:161-310
+  VanillaNN/ParallelLinear  speechbrain/lobes/models/VanillaNN.py:26-196
+  Conformer layer       speechbrain/lobes/models/transformer/Conformer.py:314-331,479-537
+  Branchformer layer    speechbrain/lobes/models/transformer/Branchformer.py:31-97,243-334
+"""
+import weakref
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+# ----------------------------------------------------------------------------------------------------
+# parameter plumbing: compute-dtype shadows of fp32 master weights, gradient buffers
+# ----------------------------------------------------------------------------------------------------
+_shadow = weakref.WeakKeyDictionary()   # param -> (version, ptr, bf16 tensor) or ("managed", tensor)
+
+
+def register_shadow(param, shadow):
+    """Trainer hook: `shadow` (bf16 view of a flat buffer) is kept up to date by smx_adamw_step."""
+    _shadow[param] = ("managed", None, shadow)
+
+
+def wcast(param, dtype):
+    """fp32 master parameter -> tensor in the compute dtype (bf16 shadows are cached per parameter version)."""
+    if dtype == torch.float32:
+        return param.detach()
+    ent = _shadow.get(param)
+    if ent is not None and (ent[0] == "managed" or (ent[0] == param._version and ent[1] == param.data_ptr())):
+        return ent[2]
+    sh = ops.cast(param.detach(), dtype)
+    _shadow[param] = (param._version, param.data_ptr(), sh)
+    return sh
+
+
+def gacc(param):
+    """fp32 gradient accumulator of a parameter (kernels add into it)."""
+    if param is None or not param.requires_grad:
+        return None
+    if param.grad is None:
+        param.grad = torch.zeros_like(param, dtype=torch.float32)
+    return param.grad
+
+
+def mask_u8(mask, B, T, device):
+    """(B,T) bool/float padding mask (True/1 = valid frame) -> flat uint8 (B*T) or None."""
+    if mask is None:
+        return None
+    m = mask.to(device=device)
+    if m.dtype != torch.bool:
+        m = m != 0
+    return m.reshape(B * T).contiguous().view(torch.uint8)
+
+
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, run, *params):
+        y, bwd = run(x, True)
+        ctx.bwd = bwd
+        ctx.n = len(params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = ctx.bwd(dy)
+        return (dx, None) + (None,) * ctx.n
+
+
+def block(x, run, params):
+    """Run `run(x, need_bwd) -> (y, bwd)`; hook bwd into autograd when anything upstream needs gradients."""
+    params = [p for p in params if p is not None]
+    need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    if not need:
+        return run(x, False)[0]
+    return _BlockFn.apply(x, run, *params)
+
+
+def _wgrad_splits(nrows, m, k):
+    tiles = ((m + 127) // 128) * ((k + 127) // 128)
+    if tiles < 384:
+        tiles = ((m + 63) // 64) * ((k + 63) // 64)
+    s = max(1, min(1024 // max(tiles, 1), (nrows + 511) // 512))
+    return s
+
+
+# ----------------------------------------------------------------------------------------------------
+# Linear (+bias +act +mask +residual +side input) forward / backward on 2-D row views
+# ----------------------------------------------------------------------------------------------------
+def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, c0=None, c0_mode=L.C0_NONE,
+               c0_div=0, save_z=False, out=None, out_f32=False):
+    N, K = x.shape
+    M = W.shape[0]
+    if out is None:
+        out = torch.empty((N, M), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
+    e = ops.epilogue(bias=bias, c0=c0, c0_mode=c0_mode, c0_div=c0_div, act=act, z=z, row_mask=mask, res=res,
+                     alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T)
+    ops.gemm(L.GEMM_NT, x, W, out, N, M, K, e)
+    return out, z
+
+
+def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
+               dz_is_dy=False):
+    """Backward of y = res + alpha*act(x W^T + b + c0)*mask.  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate."""
+    N, M = dy.shape
+    K = x.shape[1]
+    plain = act == L.ACT_NONE and mask is None and alpha == 1.0
+    if plain:
+        dz = dy
+        if gb is not None or dgroup is not None:
+            ops.act_mask_bwd(dy, None, None, L.ACT_NONE, 1.0, None, gb, dgroup, gdiv)
+    else:
+        dz = torch.empty((N, M), dtype=dy.dtype, device=dy.device)
+        ops.act_mask_bwd(dy, z, mask, act, alpha, dz, gb, dgroup, gdiv)
+    if gW is not None:
+        e = ops.epilogue(out_mode=L.OUT_ATOMIC_F32)
+        ops.gemm(L.GEMM_TN, dz, x, gW, M, K, N, e, splits=_wgrad_splits(N, M, K))
+    dx = None
+    if need_dx:
+        dx = dx_out if dx_out is not None else torch.empty((N, K), dtype=dy.dtype, device=dy.device)
+        ops.gemm(L.GEMM_NN, dz, W, dx, N, K, M, ops.epilogue(res=res_grad))
+    return dx, dz
+
+
+# ----------------------------------------------------------------------------------------------------
+# VanillaNN: [Linear | ParallelLinear -> act] x blocks ; mask applied in the last block's epilogue
+# ----------------------------------------------------------------------------------------------------
+def mlp_fwd(x, layers, act, mask, need_bwd, dtype):
+    """layers: list of dicts {kind: 'linear'|'parallel', W, b, H}.  x (N, F).  Returns (y, saved)."""
+    saved = []
+    n = len(layers)
+    for i, ly in enumerate(layers):
+        last = i == n - 1
+        mk = mask if last else None
+        if ly["kind"] == "linear":
+            Wc = wcast(ly["W"], dtype)
+            y, z = linear_fwd(x, Wc, ly["b"], act, mk, save_z=need_bwd)
+        else:
+            Wc = wcast(ly["W"], dtype)                     # (H, f, h)
+            H, f, h = Wc.shape
+            N = x.shape[0]
+            y = torch.empty((N, H * h), dtype=x.dtype, device=x.device)
+            z = torch.empty((N, H * h), dtype=x.dtype, device=x.device) if (need_bwd and act != L.ACT_NONE) else None
+            e = ops.epilogue(bias=ly["b"], bias_batch_stride=h, act=act, z=z, row_mask=mk)
+            ops.gemm(L.GEMM_NN, x[:, :f], Wc[0], y[:, :h], N, h, f, e, batch=H, sa=f, sb=f * h, sc=h,
+                     lda=x.stride(0), ldb=h, ldc=H * h)
+        saved.append((x, z, mk))
+        x = y
+    return x, saved
+
+
+def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None):
+    n = len(layers)
+    for i in range(n - 1, -1, -1):
+        ly = layers[i]
+        x, z, mk = saved[i]
+        first = i == 0
+        want_dx = need_dx or not first
+        if ly["kind"] == "linear":
+            Wc = wcast(ly["W"], dtype)
+            dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), gacc(ly["b"]), want_dx,
+                               res_grad if first else None, dx_out=dx_out if first else None)
+        else:
+            Wc = wcast(ly["W"], dtype)
+            H, f, h = Wc.shape
+            N = dy.shape[0]
+            gb = gacc(ly["b"])
+            if act == L.ACT_NONE and mk is None:
+                dz = dy
+                if gb is not None:
+                    ops.act_mask_bwd(dy, None, None, L.ACT_NONE, 1.0, None, gb.view(-1))
+            else:
+                dz = torch.empty_like(dy)
+                ops.act_mask_bwd(dy, z, mk, act, 1.0, dz, gb.view(-1) if gb is not None else None)
+            gW = gacc(ly["W"])
+            if gW is not None:   # dW[h] (f x h) += x_h^T dz_h
+                ops.gemm(L.GEMM_TN, x[:, :f], dz[:, :h], gW[0], f, h, N, ops.epilogue(out_mode=L.OUT_ATOMIC_F32),
+                         batch=H, sa=f, sb=h, sc=f * h, lda=x.stride(0), ldb=dz.stride(0), ldc=h)
+            if want_dx:          # dx_h = dz_h W[h]^T : NT with B = W[h] viewed (f rows, h reduce-contiguous)
+                if first and dx_out is not None:
+                    dx = dx_out
+                else:
+                    dx = torch.empty((N, H * f), dtype=dy.dtype, device=dy.device)
+                r = res_grad if first else None
+                ops.gemm(L.GEMM_NT, dz[:, :h], Wc[0], dx[:, :f], N, f, h, ops.epilogue(res=r[:, :f] if r is not None else None),
+                         batch=H, sa=h, sb=f * h, sc=f, lda=dz.stride(0), ldb=h, ldc=dx.stride(0))
+                dy = dx
+            else:
+                dy = None
+    return dy
+
+
+# ----------------------------------------------------------------------------------------------------
+# summary pooling variants: masked mean (per utterance), DynChunk window mean, dense (T,T) weights
+# ----------------------------------------------------------------------------------------------------
+class DynChunkMask:
+    """The (T,T) DynChunk summary mask in closed form (TransformerASR.py:85-110, masked_false_or_true=False):
+    frame t of chunk c sees chunks [c-left, c].  `dense()` materialises the reference's boolean matrix."""
+
+    def __init__(self, T, chunk_size, left_context=None):
+        self.T, self.chunk_size, self.left_context = T, chunk_size, left_context
+
+    def dense(self, device="cpu"):
+        t = torch.arange(self.T, device=device)
+        c = t // self.chunk_size
+        hi = (c + 1) * self.chunk_size
+        m = t[None, :] < hi[:, None]
+        if self.left_context is not None:
+            lo = (c - self.left_context) * self.chunk_size
+            m = m & (t[None, :] >= lo[:, None])
+        return m
+
+
+def _dense_pool_fwd(s, B, T, Wn):
+    """sbar[b] = Wn (T,T) @ s[b]  (Wn already row-normalised, compute dtype)."""
+    D = s.shape[1]
+    out = torch.empty((B * T, D), dtype=s.dtype, device=s.device)
+    ops.gemm(L.GEMM_NN, Wn, s, out, T, D, T, None, batch=B, sa=0, sb=T * s.stride(0), sc=T * D)
+    return out
+
+
+def _dense_pool_bwd(dsbar, B, T, Wn, ds_out):
+    """ds[b] = Wn^T @ dsbar[b]  (TN: A = Wn stored (K=T, N=T))."""
+    D = dsbar.shape[1]
+    ops.gemm(L.GEMM_TN, Wn, dsbar, ds_out, T, D, T, ops.epilogue(), batch=B, sa=0, sb=T * dsbar.stride(0),
+             sc=T * ds_out.stride(0))
+    return ds_out
+
+
+# ----------------------------------------------------------------------------------------------------
+# the SummaryMixing cell
+# ----------------------------------------------------------------------------------------------------
+def cell_run(P, cfg, B, T, mask, sum_mask, skip_is_input_res=None):
+    """Build run(x, need_bwd) for the cell.  P: parameter dict, cfg: mode/act/l.
+    Returns a closure operating on (B,T,d) tensors.  `skip_is_input_res`: optional (N,s) residual added to the
+    output (Conformer `x + skip`, Conformer.py:530) -- its gradient is returned by bwd as a second value."""
+    mode, act, l = cfg["mode"], cfg["act"], cfg["local_proj_out_dim"]
+
+    def run(x3, need_bwd, res=None):
+        dtype = x3.dtype
+        x = ops.rows2d(x3)
+        N = x.shape[0]
+        dev = x.device
+        pool_kind = "mean"
+        Wn = None
+        sm = sum_mask
+        if mode == "SummaryMixing-expdecay":
+            # Laplace weights (summary_mixing.py:316-365): M_ij = decay^|i-j| * binary_mask
+            idx = torch.arange(T, device=dev)
+            lap = torch.exp((idx[None, :] - idx[:, None]).abs().float() * torch.log(P["decay_constant"].detach().float()))
+            if isinstance(sm, DynChunkMask):
+                sm = sm.dense(dev)
+            if sm is not None:
+                lap = lap * sm.to(device=dev, dtype=torch.float32)
+            sm = lap
+        if mode == "SummaryMixing-lite":
+            sm = None                                   # the lite branch ignores sum_mask (:286-310)
+        if isinstance(sm, DynChunkMask):
+            pool_kind = "chunk"
+        elif sm is not None:
+            pool_kind = "dense"
+            w = sm.to(device=dev, dtype=torch.float32)
+            Wn = ops.cast((w / w.sum(dim=1, keepdim=True)).contiguous(), dtype)   # mask prep (T,T): plumbing
+
+        # ---- projections -------------------------------------------------------------------------
+        if mode == "SummaryMixing-fast":
+            g, sv_g = mlp_fwd(x, P["global_proj"], act, mask, need_bwd, dtype)     # (N, 2l)
+            local, s = g[:, :l], g[:, l:]
+            sv_l = sv_s = None
+        elif mode == "SummaryMixing-lite":
+            s, sv_s = mlp_fwd(x, P["summary_proj"], act, mask, need_bwd, dtype)
+            local = None
+            sv_l = sv_g = None
+        else:
+            local, sv_l = mlp_fwd(x, P["local_proj"], act, mask, need_bwd, dtype)
+            s, sv_s = mlp_fwd(x, P["summary_proj"], act, mask, need_bwd, dtype)
+            sv_g = None
+        sdim = s.shape[1]
+
+        # ---- summary ------------------------------------------------------------------------------
+        inv = None
+        if pool_kind == "mean":
+            sbar, inv = ops.masked_mean(s, mask, B, T, scale=True, want_inv=True)   # (B, sdim) fp32
+        elif pool_kind == "chunk":
+            sbar = torch.empty((N, sdim), dtype=dtype, device=dev)
+            ops.chunk_mean(s, sbar, B, T, sm.chunk_size, sm.left_context)
+        else:
+            sbar = _dense_pool_fwd(s, B, T, Wn)
+
+        if mode == "SummaryMixing-lite":
+            y3 = ops.cast(sbar, dtype).unsqueeze(1).expand(B, T, sdim)            # stride-0 view like :308
+
+            def bwd_lite(dy3):
+                dy = ops.rows2d(dy3.contiguous())
+                dsbar, _ = ops.masked_mean(dy, None, B, T, scale=False)            # sum over time
+                ds = torch.empty((N, sdim), dtype=dtype, device=dev)
+                ops.bcast_rows(dsbar, inv, ds, B, T)
+                dx = mlp_bwd(ds, P["summary_proj"], act, sv_s, dtype)
+                return dx.view(B, T, -1)
+            return y3, (bwd_lite if need_bwd else None)
+
+        # ---- merge: y = res + act(local W_l^T + sbar W_s^T + b) -------------------------------------
+        mg = P["summary_local_merging"][0]
+        Wm = wcast(mg["W"], dtype)                                              # (s_out, l + sdim)
+        lw = local.shape[1]
+        Wl, Ws = Wm[:, :lw], Wm[:, lw:]
+        if pool_kind == "mean":
+            sbar_t = ops.cast(sbar, dtype)                                         # (B, sdim) in compute dtype
+            c0, _ = linear_fwd(sbar_t, Ws, None, out_f32=True)                     # (B, s_out) fp32
+            y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_GROUP, c0_div=T,
+                               save_z=need_bwd)
+        else:
+            sbar_t = sbar
+            c0, _ = linear_fwd(sbar, Ws, None, out_f32=True)                       # (N, s_out) fp32
+            y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_ROW, save_z=need_bwd)
+        y3 = y.view(B, T, -1)
+        if not need_bwd:
+            return y3, None
+
+        def bwd(dy3):
+            dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+            s_out = dy.shape[1]
+            gWm, gbm = gacc(mg["W"]), gacc(mg["b"])
+            # buffer that receives [dlocal | ds] for the fast mode (one dg for the fused projection)
+            if mode == "SummaryMixing-fast":
+                dg = torch.empty((N, 2 * l), dtype=dtype, device=dev)
+                dlocal_out, ds_out = dg[:, :l], dg[:, l:]
+            else:
+                dlocal_out = torch.empty((N, lw), dtype=dtype, device=dev)
+                ds_out = torch.empty((N, sdim), dtype=dtype, device=dev)
+            if pool_kind == "mean":
+                dc0 = torch.zeros((B, s_out), dtype=torch.float32, device=dev)
+                _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
+                                    True, None, dgroup=dc0, gdiv=T, dx_out=dlocal_out)
+                dc0_t = ops.cast(dc0, dtype)
+                if gWm is not None:      # dW_s += dc0^T sbar
+                    ops.gemm(L.GEMM_TN, dc0_t, sbar_t, gWm[:, lw:], s_out, sdim, B, ops.epilogue(out_mode=L.OUT_ATOMIC_F32))
+                dsbar = torch.empty((B, sdim), dtype=torch.float32, device=dev)
+                ops.gemm(L.GEMM_NN, dc0_t, Ws, dsbar, B, sdim, s_out, ops.epilogue(out_mode=L.OUT_F32))
+                ops.bcast_rows(dsbar, inv, ds_out, B, T)
+            else:
+                _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
+                                    True, None, dx_out=dlocal_out)
+                if gWm is not None:      # dW_s += dzm^T sbar
+                    ops.gemm(L.GEMM_TN, dzm, sbar_t, gWm[:, lw:], s_out, sdim, N, ops.epilogue(out_mode=L.OUT_ATOMIC_F32),
+                             splits=_wgrad_splits(N, s_out, sdim))
+                dsb = torch.empty((N, sdim), dtype=dtype, device=dev)
+                ops.gemm(L.GEMM_NN, dzm, Ws, dsb, N, sdim, s_out, None)
+                if pool_kind == "chunk":
+                    ops.chunk_mean(dsb, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
+                else:
+                    _dense_pool_bwd(dsb, B, T, Wn, ds_out)
+            if mode == "SummaryMixing-fast":
+                dx = mlp_bwd(dg, P["global_proj"], act, sv_g, dtype)
+            else:
+                dx = mlp_bwd(dlocal_out, P["local_proj"], act, sv_l, dtype)
+                dx = mlp_bwd(ds_out, P["summary_proj"], act, sv_s, dtype, res_grad=dx)
+            return dx.view(B, T, -1)
+        return y3, bwd
+    return run
+
+
+# ----------------------------------------------------------------------------------------------------
+# LayerNorm block, FFN module, Conformer conv module (2-D row views in, closures out)
+# ----------------------------------------------------------------------------------------------------
+def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE):
+    """y = act(LayerNorm(x)); bwd(dy, res) = res + d/dx."""
+    y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act)
+
+    def bwd(dy, res=None):
+        return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gacc(w), gacc(b), res, act)
+    return y, (bwd if need_bwd else None)
+
+
+def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5):
+    """y = x + alpha * W2 act(W1 LN(x) + b1) + b2   (Conformer.py:458-472,507,536)."""
+    h, ln_b = ln_fwd(x, P["ln_w"], P["ln_b"], 1e-5, need_bwd)
+    W1, W2 = wcast(P["W1"], dtype), wcast(P["W2"], dtype)
+    a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd)
+    y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha)
+    if not need_bwd:
+        return y, None
+
+    def bwd(dy):
+        da, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]))
+        dh, _ = linear_bwd(da, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]))
+        return ln_b(dh, res=dy)
+    return y, bwd
+
+
+def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0):
+    """y = x + mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534)."""
+    d = x.shape[1]
+    h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd)
+    Wp = wcast(P["Wp"], dtype)                                   # (2d, d)  pointwise conv as a Linear
+    p, _ = linear_fwd(h, Wp, P["bp"])
+    k = P["wd"].shape[-1]
+    wd = P["wd"].detach().reshape(d, k)
+    c = ops.dwconv_fwd(p, wd, P["bd"].detach() if P["bd"] is not None else None, B, T, d, k, True, L.PAD_ZERO, chunk)
+    a, ln2_b = ln_fwd(c, P["ln2_w"], P["ln2_b"], 1e-5, need_bwd, act)      # LN + activation fused
+    Wo = wcast(P["Wo"], dtype)
+    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x)
+    if not need_bwd:
+        return y, None
+
+    def bwd(dy):
+        da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]))
+        dc = ln2_b(da)
+        gwd = gacc(P["wd"])
+        dp, _ = ops.dwconv_bwd(dc, p, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
+                               gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
+        dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
+        return ln1_b(dh, res=dy)
+    return y, bwd
+
+

@@ -1,0 +1,75 @@
+"""SummaryMixing cell on MI355X (reference surface: speechbrain/nnet/summary_mixing.py:76-87,161).
+
+Same constructor, same ``forward(x, sum_mask=None, src_padding_mask=None)``, same state-dict keys; the
+arithmetic runs in libsmx.so (MFMA projection GEMMs with fused bias/activation/mask epilogues, the split-T
+masked-mean kernel, the per-utterance summary folded into the merge GEMM as a side input so that neither the
+``repeat`` (:222,:267) nor the ``cat`` (:238,:283) is ever materialised).
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from ..lobes.models.VanillaNN import VanillaNN
+from .activations import act_code
+
+MODES = ("SummaryMixing", "SummaryMixing-lite", "SummaryMixing-expdecay", "SummaryMixing-fast")
+
+
+class SummaryMixing(nn.Module):
+    def __init__(self, enc_dim, nhead, local_proj_hid_dim: Optional[list] = [512],
+                 local_proj_out_dim: Optional[int] = 512, summary_hid_dim: Optional[list] = [512],
+                 summary_out_dim: Optional[int] = 512, activation: Optional[nn.Module] = nn.GELU,
+                 global_dropout: Optional[float] = 0.1, mode: Optional[str] = "SummaryMixing"):
+        super().__init__()
+        if mode not in MODES:
+            raise ValueError("The SummaryMixing mode should either be 'SummaryMixing', 'SummaryMixing-lite', "
+                             "'SummaryMixing-fast' or 'SummaryMixing-expdecay'")
+        self.enc_dim, self.mode = enc_dim, mode
+        self.local_proj_hid_dim, self.local_proj_out_dim = local_proj_hid_dim, local_proj_out_dim
+        self.summary_hid_dim, self.summary_out_dim = summary_hid_dim, summary_out_dim
+        self.act = act_code(activation)
+        self.global_dropout = float(global_dropout)
+        local_blocks = list(local_proj_hid_dim) + [local_proj_out_dim]
+        summary_blocks = list(summary_hid_dim) + [summary_out_dim]
+        shape = [None, None, enc_dim]
+        # construction order follows the reference (:112-157) so that a shared RNG seed draws the same init
+        if mode in ("SummaryMixing", "SummaryMixing-expdecay"):
+            self.local_proj = VanillaNN(shape, activation, len(local_blocks), local_blocks, n_split=nhead)
+            self.summary_local_merging = VanillaNN([None, None, local_proj_out_dim + summary_out_dim], activation, 1,
+                                                   [summary_out_dim])
+        if mode == "SummaryMixing-fast":
+            self.global_proj = VanillaNN(shape, activation, 1, local_proj_out_dim * 2, n_split=1)
+            self.summary_local_merging = VanillaNN([None, None, local_proj_out_dim * 2], activation, 1,
+                                                   [summary_out_dim])
+        else:
+            self.summary_proj = VanillaNN(shape, activation, len(summary_blocks), summary_blocks, n_split=nhead)
+        if mode == "SummaryMixing-expdecay":
+            self.decay_constant = nn.Parameter(data=torch.tensor(0.995), requires_grad=False)
+        for m in self.modules():                        # reference :159,:312-314: zero every nn.Linear bias
+            if isinstance(m, nn.Linear):
+                nn.init.zeros_(m.bias)
+
+    def _params(self):
+        P = {}
+        for name in ("local_proj", "summary_proj", "global_proj", "summary_local_merging"):
+            if hasattr(self, name):
+                P[name] = getattr(self, name).specs()
+        if hasattr(self, "decay_constant"):
+            P["decay_constant"] = self.decay_constant
+        return P
+
+    def _cfg(self):
+        return {"mode": self.mode, "act": self.act, "local_proj_out_dim": self.local_proj_out_dim}
+
+    def forward(self, x, sum_mask=None, src_padding_mask=None):
+        """x (B,T,enc_dim) on the GPU, float32 or bfloat16; src_padding_mask (B,T) True = valid frame;
+        sum_mask (T,T) tensor or functional.DynChunkMask."""
+        if self.training and self.global_dropout > 0.0:
+            raise NotImplementedError("training-mode dropout inside the cell is not implemented yet: construct with "
+                                      "global_dropout=0.0 or call .eval()")
+        B, T, _ = x.shape
+        mask = F.mask_u8(src_padding_mask, B, T, x.device)
+        run = F.cell_run(self._params(), self._cfg(), B, T, mask, sum_mask)
+        return F.block(x, run, list(self.parameters()))

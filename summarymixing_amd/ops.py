@@ -1,0 +1,218 @@
+"""Thin torch-tensor wrappers over the C-ABI of libsmx.so.
+
+torch is plumbing here: tensors own device memory, ``data_ptr()`` / strides / the current HIP stream are
+handed to the kernels.  All arithmetic happens in the hand-written gfx950 kernels.  Matrices are 2-D
+views ``(rows, cols)`` with unit stride along cols; the row stride is the leading dimension.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"summarymixing_amd supports float32 and bfloat16 activations, got {t.dtype}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _mat(t):
+    """(ptr, ld) of a 2-D view with unit inner stride."""
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), f"need a (rows, cols) view with unit col stride, got {t.shape} {t.stride()}"
+    assert t.is_cuda, "summarymixing_amd kernels run on the GPU only (no CPU fallback)"
+    return _p(t), (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def rows2d(x):
+    """(B,T,D) or (N,D) -> (N,D) view without copying (rows must be uniformly strided)."""
+    if x.dim() == 2:
+        return x
+    assert x.dim() == 3
+    B, T, D = x.shape
+    if x.stride(2) != 1 and D > 1:
+        x = x.contiguous()
+    if B > 1 and x.stride(0) != T * x.stride(1):
+        x = x.contiguous()
+    return x.as_strided((B * T, D), (x.stride(1), 1), x.storage_offset()) if T * B > 0 else x.reshape(B * T, D)
+
+
+def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, out_mode=L.OUT_T, z=None,
+             row_mask=None, res=None, alpha=1.0, bias_batch_stride=0):
+    e = L.Epilogue()
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.bias_batch_stride = bias_batch_stride
+    if c0 is not None:
+        assert c0.dtype == torch.float32
+        e.c0, e.ldc0 = _mat(c0)
+        e.c0 = c0.data_ptr()
+        e.c0_mode, e.c0_div = c0_mode, c0_div
+    e.act, e.out_mode = act, out_mode
+    if z is not None:
+        e.z, e.ldz = z.data_ptr(), _mat(z)[1]
+    if row_mask is not None:
+        assert row_mask.dtype == torch.uint8
+        e.row_mask = row_mask.data_ptr()
+    if res is not None:
+        e.res, e.ldr = res.data_ptr(), _mat(res)[1]
+    e.alpha = alpha
+    return e
+
+
+def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1, lda=None, ldb=None, ldc=None):
+    """C (N x M) = epi(op(A) op(B)); a/b/c are 2-D views of batch 0 (batch strides in elements)."""
+    pa, la = _mat(a)
+    pb, lb = _mat(b)
+    pc, lc = _mat(c)
+    if epi is None:
+        epi = epilogue()
+    assert a.dtype == b.dtype
+    L.check(L.lib().smx_gemm(layout, dt(a), pa, lda or la, sa, pb, ldb or lb, sb, pc, ldc or lc, sc, N, M, K, batch,
+                             splits, ctypes.byref(epi), _stream()), "smx_gemm")
+    return c
+
+
+def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, gdiv=0):
+    N, M = dy.shape
+    pdy, lddy = _mat(dy)
+    pz, ldz = (_mat(z) if z is not None else (None, 0))
+    pdz, lddz = (_mat(dz) if dz is not None else (None, 0))
+    pg, ldg = (_mat(dgroup) if dgroup is not None else (None, 0))
+    L.check(L.lib().smx_act_mask_bwd(dt(dy), pdy, lddy, pz, ldz, _p(mask), pdz, lddz, N, M, act, alpha, _p(dbias), pg,
+                                     ldg, gdiv, _stream()), "smx_act_mask_bwd")
+    return dz
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def masked_mean(s, mask, B, T, scale=True, want_inv=False):
+    """s: (B*T, D) view; mask: (B*T) uint8 or None -> (out (B,D) fp32, inv_count (B) fp32 | None)."""
+    D = s.shape[1]
+    ps, lds = _mat(s)
+    out = torch.empty((B, D), dtype=torch.float32, device=s.device)
+    inv = torch.empty((B,), dtype=torch.float32, device=s.device) if want_inv else None
+    ws = _workspace(L.lib().smx_masked_mean_workspace(B, T, D), s.device)
+    L.check(L.lib().smx_masked_mean_fwd(dt(s), ps, lds, _p(mask), _p(out), _p(inv), B, T, D, 1 if scale else 0, _p(ws),
+                                        _stream()), "smx_masked_mean_fwd")
+    return out, inv
+
+
+def bcast_rows(g, inv, ds, B, T):
+    """ds[b*T+t, :] = g[b,:] * inv[b]"""
+    pds, ldds = _mat(ds)
+    L.check(L.lib().smx_masked_mean_bwd(dt(ds), _p(g), _p(inv), pds, ldds, B, T, ds.shape[1], _stream()),
+            "smx_masked_mean_bwd")
+    return ds
+
+
+def chunk_mean(s, out, B, T, chunk, left, reverse=False):
+    D = s.shape[1]
+    ps, lds = _mat(s)
+    po, ldo = _mat(out)
+    ws = _workspace(L.lib().smx_chunk_mean_workspace(B, T, D, chunk), s.device)
+    fn = L.lib().smx_chunk_mean_bwd if reverse else L.lib().smx_chunk_mean_fwd
+    L.check(fn(dt(s), ps, lds, po, ldo, B, T, D, chunk, -1 if left is None else left, _p(ws), _stream()),
+            "smx_chunk_mean")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE):
+    N, D = x.shape
+    y = torch.empty((N, D), dtype=x.dtype, device=x.device)
+    stats = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    px, ldx = _mat(x)
+    L.check(L.lib().smx_layernorm_fwd(dt(x), px, ldx, _p(gamma), _p(beta), _p(y), D, _p(stats), N, D, eps, act, _stream()),
+            "smx_layernorm_fwd")
+    return y, stats
+
+
+def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE):
+    N, D = x.shape
+    dx = torch.empty((N, D), dtype=x.dtype, device=x.device)
+    pdy, lddy = _mat(dy)
+    px, ldx = _mat(x)
+    pr, ldr = (_mat(res) if res is not None else (None, 0))
+    L.check(L.lib().smx_layernorm_bwd(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), D, _p(dgamma),
+                                      _p(dbeta), N, D, _stream()), "smx_layernorm_bwd")
+    return dx
+
+
+def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None):
+    y = torch.empty((B * T, D), dtype=p.dtype, device=p.device)
+    pp, ldp = _mat(p)
+    pg, ldg = (_mat(gate) if gate is not None else (None, 0))
+    L.check(L.lib().smx_dwconv1d_glu_fwd(dt(p), pp, ldp, _p(w), _p(bias), pg, ldg, _p(y), D, B, T, D, k, 1 if glu else 0,
+                                         pad_mode, chunk, _stream()), "smx_dwconv1d_glu_fwd")
+    return y
+
+
+def dwconv_bwd(dy, p, w, bias, dw, dbias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None):
+    dp = torch.empty((B * T, p.shape[1]), dtype=p.dtype, device=p.device)
+    dgate = torch.empty((B * T, D), dtype=p.dtype, device=p.device) if gate is not None else None
+    pdy, lddy = _mat(dy)
+    pp, ldp = _mat(p)
+    pg, ldg = (_mat(gate) if gate is not None else (None, 0))
+    L.check(L.lib().smx_dwconv1d_glu_bwd(dt(p), pdy, lddy, pp, ldp, _p(w), _p(bias), pg, ldg, _p(dp), dp.shape[1],
+                                         _p(dgate), D, _p(dw), _p(dbias), B, T, D, k, 1 if glu else 0, pad_mode, chunk,
+                                         _stream()), "smx_dwconv1d_glu_bwd")
+    return dp, dgate
+
+
+def axpby(a, x, b=0.0, y0=None, out=None):
+    N, D = x.shape
+    if out is None:
+        out = torch.empty((N, D), dtype=x.dtype, device=x.device)
+    px, ldx = _mat(x)
+    py0, ldy0 = (_mat(y0) if y0 is not None else (None, 0))
+    po, ldo = _mat(out)
+    L.check(L.lib().smx_axpby(dt(x), a, px, ldx, b, py0, ldy0, po, ldo, N, D, _stream()), "smx_axpby")
+    return out
+
+
+def cast(src, dtype):
+    """fp32 <-> compute dtype through the library's cast kernels (contiguous tensors)."""
+    if src.dtype == dtype:
+        return src
+    src = src.contiguous()
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    if src.dtype == torch.float32:
+        L.check(L.lib().smx_cast_from_f32(_DT[dtype], _p(src), _p(dst), src.numel(), _stream()), "smx_cast_from_f32")
+    elif dtype == torch.float32:
+        L.check(L.lib().smx_cast_to_f32(_DT[src.dtype], _p(src), _p(dst), src.numel(), _stream()), "smx_cast_to_f32")
+    else:
+        return cast(cast(src, torch.float32), dtype)
+    return dst
+
+
+def adamw_step(param, grad, m, v, shadow, lr, b1, b2, eps, wd, step, grad_scale=1.0, gscale_dev=None):
+    L.check(L.lib().smx_adamw_step(_p(param), _p(grad), _p(m), _p(v), _p(shadow), param.numel(), lr, b1, b2, eps, wd,
+                                   step, grad_scale, _p(gscale_dev), _stream()), "smx_adamw_step")
+
+
+def sumsq(x, out):
+    L.check(L.lib().smx_sumsq(_p(x), x.numel(), _p(out), _stream()), "smx_sumsq")
+
+
+def clip_factor(sumsq_t, max_norm, inv_scale, out):
+    L.check(L.lib().smx_clip_factor(_p(sumsq_t), max_norm, inv_scale, _p(out), _stream()), "smx_clip_factor")

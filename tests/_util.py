@@ -1,0 +1,42 @@
+"""Shared helpers for the GPU parity tests."""
+import torch
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b|  (scale-relative max error; the metric the tolerances below are written in)."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    fin = torch.isfinite(b)
+    if not fin.all():
+        assert torch.equal(torch.isfinite(a), fin), "non-finite pattern differs"
+        a, b = a[fin], b[fin]
+    if b.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# north_star tolerances: 1e-3 rel fp32 / 1e-2 bf16 on forward outputs; gradients in bf16 get 3e-2
+TOL = {torch.float32: (1e-3, 1e-3), torch.bfloat16: (1e-2, 3e-2)}
+
+
+def cell_dims_from_sd(sd, meta, enc_dim):
+    """Recover the SummaryMixing constructor arguments from a reference state_dict."""
+    def blocks(prefix):
+        dims, i = [], 0
+        while True:
+            n = "linear" if i == 0 else f"linear_{i - 1}"
+            if f"{prefix}.{n}.w.weight" in sd:
+                dims.append(sd[f"{prefix}.{n}.w.weight"].shape[0])
+            elif f"{prefix}.{n}.weights" in sd:
+                w = sd[f"{prefix}.{n}.weights"]
+                dims.append(w.shape[0] * w.shape[2])
+            else:
+                return dims
+            i += 1
+    kw = dict(enc_dim=enc_dim, nhead=meta["nhead"], mode=meta["mode"], local_proj_out_dim=meta["local_proj_out_dim"])
+    lp, sp, mg = blocks("local_proj"), blocks("summary_proj"), blocks("summary_local_merging")
+    kw["local_proj_hid_dim"] = lp[:-1] if lp else [meta["local_proj_out_dim"]]
+    if sp:
+        kw["summary_hid_dim"], kw["summary_out_dim"] = sp[:-1], sp[-1]
+    else:
+        kw["summary_hid_dim"], kw["summary_out_dim"] = [8], mg[-1]
+    return kw

@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary: libsmx.so loads and exports every symbol include/smx.h declares,
+the ctypes table mirrors the header, and the product path refuses to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "smx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from summarymixing_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "libsmx.so not built (run __graft_entry__.build())"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/smx.h but not exported"
+
+
+def test_ctypes_table_matches_header():
+    from summarymixing_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_version_and_error_string_need_no_gpu():
+    from summarymixing_amd import _lib
+    L = _lib.lib()
+    assert L.smx_version() == 100
+    assert isinstance(L.smx_last_error(), bytes)
+
+
+def test_epilogue_struct_layout_matches_header():
+    from summarymixing_amd import _lib
+    assert ctypes.sizeof(_lib.Epilogue) == 96   # 12 x 8 bytes, see include/smx.h smx_epilogue
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    from summarymixing_amd.nnet.summary_mixing import SummaryMixing
+    m = SummaryMixing(8, 1, [8], 8, [8], 8, global_dropout=0.0)
+    with pytest.raises((AssertionError, RuntimeError)):
+        m(torch.randn(1, 3, 8))

@@ -1,0 +1,243 @@
+"""Kernel-level GPU tests through the C-ABI: every GEMM layout / tile / alignment path against a plain
+float64 matmul, epilogue fields, LayerNorm, depthwise conv, masked mean, chunk mean, AdamW."""
+import math
+
+import pytest
+import torch
+
+from tests._util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from summarymixing_amd import _lib as L, ops
+    return L, ops
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("N,M,K", [(300, 200, 136), (64, 64, 64), (1000, 512, 256), (37, 19, 23), (129, 257, 70),
+                                   (4000, 1024, 512)])
+def test_gemm_layouts(N, M, K, dtype, tol):
+    L, ops = _ops()
+    torch.manual_seed(N + M + K)
+    a = torch.randn(N, K, device="cuda").to(dtype)
+    # asymmetric operands (detects transposed fragments / outputs)
+    b_nt = (torch.randn(M, K, device="cuda") + torch.linspace(-1, 1, K, device="cuda")[None]).to(dtype)
+    ref = a.double() @ b_nt.double().t()
+    c = torch.empty(N, M, device="cuda", dtype=dtype)
+    ops.gemm(L.GEMM_NT, a, b_nt, c, N, M, K)
+    assert rel_err(c, ref) <= tol
+    b_nn = b_nt.t().contiguous()                       # (K, M)
+    c2 = torch.empty(N, M, device="cuda", dtype=dtype)
+    ops.gemm(L.GEMM_NN, a, b_nn, c2, N, M, K)
+    assert rel_err(c2, ref) <= tol
+    a_t = a.t().contiguous()                           # (K, N)
+    c3 = torch.zeros(N, M, device="cuda", dtype=torch.float32)
+    ops.gemm(L.GEMM_TN, a_t, b_nn, c3, N, M, K, ops.epilogue(out_mode=L.OUT_ATOMIC_F32), splits=3)
+    assert rel_err(c3, ref) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_gemm_epilogue_all_fields(dtype, tol):
+    L, ops = _ops()
+    torch.manual_seed(3)
+    N, M, K, T = 96 * 5, 160, 72, 96
+    x = torch.randn(N, K, device="cuda").to(dtype)
+    w = torch.randn(M, K, device="cuda").to(dtype) * 0.2
+    bias = torch.randn(M, device="cuda")
+    c0 = torch.randn(N // T, M, device="cuda")
+    res = torch.randn(N, M, device="cuda").to(dtype)
+    mask = (torch.rand(N, device="cuda") > 0.3)
+    z = torch.empty(N, M, device="cuda", dtype=dtype)
+    y = torch.empty(N, M, device="cuda", dtype=dtype)
+    for act, fn in [(L.ACT_GELU, torch.nn.functional.gelu), (L.ACT_SWISH, torch.nn.functional.silu),
+                    (L.ACT_LEAKY_RELU, torch.nn.functional.leaky_relu), (L.ACT_RELU, torch.relu)]:
+        e = ops.epilogue(bias=bias, c0=c0, c0_mode=L.C0_GROUP, c0_div=T, act=act, z=z, row_mask=mask.view(torch.uint8),
+                         res=res, alpha=0.5)
+        ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e)
+        v = x.double() @ w.double().t() + bias.double() + c0.double().repeat_interleave(T, 0)
+        ref = res.double() + 0.5 * fn(v) * mask.double()[:, None]
+        assert rel_err(z, v) <= tol
+        assert rel_err(y, ref) <= tol
+    pe = torch.randn(T, M, device="cuda")
+    ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(c0=pe, c0_mode=L.C0_MOD, c0_div=T))
+    assert rel_err(y, x.double() @ w.double().t() + pe.double().repeat(N // T, 1)) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+def test_gemm_strided_views_and_batch(dtype, tol):
+    """Column slices via leading dimensions + batched heads (the ParallelLinear einsum)."""
+    L, ops = _ops()
+    torch.manual_seed(4)
+    N, H, f, h = 333, 4, 24, 40
+    x = torch.randn(N, H * f, device="cuda").to(dtype)
+    w = torch.randn(H, f, h, device="cuda").to(dtype)
+    b = torch.randn(H, h, device="cuda")
+    y = torch.empty(N, H * h, device="cuda", dtype=dtype)
+    ops.gemm(L.GEMM_NN, x[:, :f], w[0], y[:, :h], N, h, f, ops.epilogue(bias=b, bias_batch_stride=h), batch=H, sa=f,
+             sb=f * h, sc=h, lda=H * f, ldb=h, ldc=H * h)
+    ref = torch.einsum("nmf,mfh->nmh", x.double().view(N, H, f), w.double()) + b.double()
+    assert rel_err(y, ref.reshape(N, H * h)) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("D", [256, 144, 30, 512])
+def test_layernorm_fwd_bwd(D, dtype, tol):
+    L, ops = _ops()
+    torch.manual_seed(D)
+    N = 777
+    x = (torch.randn(N, D, device="cuda") * 2 + 0.5).to(dtype)
+    g = torch.randn(D, device="cuda") * 0.3 + 1
+    b = torch.randn(D, device="cuda") * 0.3
+    for act, fn in [(L.ACT_NONE, lambda v: v), (L.ACT_SWISH, torch.nn.functional.silu)]:
+        y, stats = ops.layernorm_fwd(x, g, b, 1e-5, True, act)
+        xr = x.double().requires_grad_(True)
+        gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+        ref = fn(torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5))
+        assert rel_err(y, ref) <= tol
+        dy = torch.randn(N, D, device="cuda").to(dtype)
+        res = torch.randn(N, D, device="cuda").to(dtype)
+        (ref * dy.double()).sum().backward()
+        dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        dx = ops.layernorm_bwd(dy, x, g, b, stats, dg, db, res, act)
+        assert rel_err(dx, xr.grad + res.double()) <= 2 * tol
+        assert rel_err(dg, gr.grad) <= 3 * tol and rel_err(db, br.grad) <= 3 * tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("B,T,D", [(3, 1000, 256), (2, 77, 40), (8, 3000, 512), (1, 5, 8)])
+def test_masked_mean_and_broadcast(B, T, D, dtype, tol):
+    L, ops = _ops()
+    torch.manual_seed(T)
+    buf = torch.randn(B * T, 2 * D, device="cuda").to(dtype)
+    s = buf[:, D:]                                         # strided view (ld = 2D) like the fast-mode split
+    lens = torch.randint(1, T + 1, (B,), device="cuda")
+    lens[0] = T
+    mask = (torch.arange(T, device="cuda")[None] < lens[:, None])
+    out, inv = ops.masked_mean(s, mask.reshape(-1).view(torch.uint8), B, T, True, True)
+    ref = (s.double().view(B, T, D) * mask[..., None]).sum(1) / lens[:, None]
+    assert rel_err(out, ref) <= tol
+    assert rel_err(inv, 1.0 / lens.double()) <= 1e-6
+    out2, _ = ops.masked_mean(s, None, B, T, False)
+    assert rel_err(out2, s.double().view(B, T, D).sum(1)) <= tol
+    # bit-reproducible (fixed-order split-T combine)
+    out3, _ = ops.masked_mean(s, mask.reshape(-1).view(torch.uint8), B, T, True)
+    assert torch.equal(out, out3)
+    ds = torch.empty(B * T, D, device="cuda", dtype=dtype)
+    ops.bcast_rows(out, inv, ds, B, T)
+    assert rel_err(ds.view(B, T, D), (ref / lens[:, None]).unsqueeze(1).expand(B, T, D)) <= tol
+
+
+@pytest.mark.parametrize("left", [None, 0, 2])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_chunk_mean_fwd_bwd(left, dtype, tol):
+    from summarymixing_amd.functional import DynChunkMask
+    L, ops = _ops()
+    torch.manual_seed(5)
+    B, T, D, chunk = 3, 70, 48, 8
+    s = torch.randn(B * T, D, device="cuda").to(dtype)
+    Mx = DynChunkMask(T, chunk, left).dense("cuda").double()
+    out = torch.empty_like(s)
+    ops.chunk_mean(s, out, B, T, chunk, left)
+    ref = (Mx @ s.double().view(B, T, D)) / Mx.sum(1)[None, :, None]
+    assert rel_err(out.view(B, T, D), ref) <= tol
+    g = torch.randn(B * T, D, device="cuda").to(dtype)
+    ds = torch.empty_like(s)
+    ops.chunk_mean(g, ds, B, T, chunk, left, reverse=True)
+    refb = (Mx / Mx.sum(1)[:, None]).t() @ g.double().view(B, T, D)
+    assert rel_err(ds.view(B, T, D), refb) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("B,T,D,k,chunk", [(2, 150, 96, 31, 0), (3, 70, 40, 7, 0), (2, 100, 64, 31, 16), (1, 9, 8, 5, 4)])
+def test_glu_dwconv_fwd_bwd(B, T, D, k, chunk, dtype, tol):
+    from oracle import smx_oracle as O
+    L, ops = _ops()
+    torch.manual_seed(T + k)
+    p = torch.randn(B * T, 2 * D, device="cuda").to(dtype)
+    w = torch.randn(D, k, device="cuda") * 0.3
+    bias = torch.randn(D, device="cuda")
+    y = ops.dwconv_fwd(p, w, bias, B, T, D, k, True, L.PAD_ZERO, chunk)
+    pr = p.double().cpu().view(B, T, 2 * D).requires_grad_(True)
+    wr, br = w.double().cpu().requires_grad_(True), bias.double().cpu().requires_grad_(True)
+    u = pr[..., :D] * torch.sigmoid(pr[..., D:])
+    if chunk:
+        ref = O.depthwise_conv_chunked(u, wr.view(D, 1, k), br, chunk)
+    else:
+        ref = torch.nn.functional.conv1d(u.transpose(1, 2), wr.view(D, 1, k), br, padding=(k - 1) // 2, groups=D).transpose(1, 2)
+    assert rel_err(y.view(B, T, D), ref) <= tol
+    dy = torch.randn(B * T, D, device="cuda").to(dtype)
+    (ref * dy.double().cpu().view(B, T, D)).sum().backward()
+    dw, db = torch.zeros(D, k, device="cuda"), torch.zeros(D, device="cuda")
+    dp, _ = ops.dwconv_bwd(dy, p, w, bias, dw, db, B, T, D, k, True, L.PAD_ZERO, chunk)
+    assert rel_err(dp.view(B, T, 2 * D), pr.grad) <= 2 * tol
+    assert rel_err(dw, wr.grad) <= 2 * tol and rel_err(db, br.grad) <= 2 * tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+def test_gated_reflect_dwconv_fwd_bwd(dtype, tol):
+    """Branchformer CSGU form: y = gate * conv_reflect(x)."""
+    L, ops = _ops()
+    torch.manual_seed(11)
+    B, T, D, k = 2, 90, 48, 7
+    x = torch.randn(B * T, D, device="cuda").to(dtype)
+    gate = torch.randn(B * T, D, device="cuda").to(dtype)
+    w = torch.randn(D, k, device="cuda") * 0.3
+    bias = torch.randn(D, device="cuda")
+    y = ops.dwconv_fwd(x, w, bias, B, T, D, k, False, L.PAD_REFLECT, 0, gate)
+    xr = x.double().cpu().view(B, T, D).requires_grad_(True)
+    gr = gate.double().cpu().view(B, T, D).requires_grad_(True)
+    wr, br = w.double().cpu().requires_grad_(True), bias.double().cpu().requires_grad_(True)
+    xp = torch.nn.functional.pad(xr.transpose(1, 2), (k // 2, k // 2), mode="reflect")
+    ref = torch.nn.functional.conv1d(xp, wr.view(D, 1, k), br, groups=D).transpose(1, 2) * gr
+    assert rel_err(y.view(B, T, D), ref) <= tol
+    dy = torch.randn(B * T, D, device="cuda").to(dtype)
+    (ref * dy.double().cpu().view(B, T, D)).sum().backward()
+    dw, db = torch.zeros(D, k, device="cuda"), torch.zeros(D, device="cuda")
+    dx, dgate = ops.dwconv_bwd(dy, x, w, bias, dw, db, B, T, D, k, False, L.PAD_REFLECT, 0, gate)
+    assert rel_err(dx.view(B, T, D), xr.grad) <= 2 * tol
+    assert rel_err(dgate.view(B, T, D), gr.grad) <= 2 * tol
+    assert rel_err(dw, wr.grad) <= 2 * tol and rel_err(db, br.grad) <= 2 * tol
+
+
+def test_act_mask_bwd_reductions():
+    L, ops = _ops()
+    torch.manual_seed(6)
+    N, M, T = 5 * 64 + 7 * 0, 136, 64
+    dy = torch.randn(N, M, device="cuda")
+    z = torch.randn(N, M, device="cuda")
+    mask = torch.rand(N, device="cuda") > 0.4
+    dz = torch.empty_like(dy)
+    db = torch.zeros(M, device="cuda")
+    dg = torch.zeros(N // T, M, device="cuda")
+    ops.act_mask_bwd(dy, z, mask.view(torch.uint8), L.ACT_GELU, 0.5, dz, db, dg, T)
+    zr = z.double().requires_grad_(True)
+    (torch.nn.functional.gelu(zr) * mask.double()[:, None] * 0.5 * dy.double()).sum().backward()
+    assert rel_err(dz, zr.grad) <= 1e-5
+    assert rel_err(db, zr.grad.sum(0)) <= 1e-5
+    assert rel_err(dg, zr.grad.view(N // T, T, M).sum(1)) <= 1e-5
+
+
+def test_adamw_matches_torch():
+    L, ops = _ops()
+    torch.manual_seed(7)
+    n = 10007
+    p0 = torch.randn(n, device="cuda")
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=8e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sh = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for step in range(1, 4):
+        g = torch.randn(n, device="cuda")
+        ref_p.grad = g.clone()
+        opt.step()
+        ops.adamw_step(p, g, m, v, sh, 8e-4, 0.9, 0.98, 1e-9, 0.01, step)
+    assert rel_err(p, ref_p) <= 1e-6
+    assert torch.equal(sh, p.to(torch.bfloat16))
+    ss = torch.zeros(1, device="cuda")
+    ops.sumsq(p, ss)
+    assert abs(ss.item() - float((p.double() ** 2).sum())) / ss.item() < 1e-5
+    cf = torch.zeros(1, device="cuda")
+    ops.clip_factor(ss, 5.0, 1.0, cf)
+    assert abs(cf.item() - min(1.0, 5.0 / (math.sqrt(ss.item()) + 1e-6))) < 1e-6
