@@ -23,23 +23,27 @@ from . import ops
 # ----------------------------------------------------------------------------------------------------
 # parameter plumbing: compute-dtype shadows of fp32 master weights, gradient buffers
 # ----------------------------------------------------------------------------------------------------
-_shadow = weakref.WeakKeyDictionary()   # param -> (version, ptr, bf16 tensor) or ("managed", tensor)
+_shadow = {}   # id(param) -> (weakref(param), version | "managed", data_ptr, shadow tensor)
 
 
 def register_shadow(param, shadow):
     """Trainer hook: `shadow` (bf16 view of a flat buffer) is kept up to date by smx_adamw_step."""
-    _shadow[param] = ("managed", None, shadow)
+    _shadow[id(param)] = (weakref.ref(param), "managed", None, shadow)
 
 
 def wcast(param, dtype):
     """fp32 master parameter -> tensor in the compute dtype (bf16 shadows are cached per parameter version)."""
     if dtype == torch.float32:
         return param.detach()
-    ent = _shadow.get(param)
-    if ent is not None and (ent[0] == "managed" or (ent[0] == param._version and ent[1] == param.data_ptr())):
-        return ent[2]
+    ent = _shadow.get(id(param))
+    if ent is not None and ent[0]() is param and (
+            ent[1] == "managed" or (ent[1] == param._version and ent[2] == param.data_ptr())):
+        return ent[3]
     sh = ops.cast(param.detach(), dtype)
-    _shadow[param] = (param._version, param.data_ptr(), sh)
+    if len(_shadow) > 4096:                      # drop entries of dead parameters
+        for k in [k for k, v in _shadow.items() if v[0]() is None]:
+            del _shadow[k]
+    _shadow[id(param)] = (weakref.ref(param), param._version, param.data_ptr(), sh)
     return sh
 
 
@@ -398,18 +402,18 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5):
     return y, bwd
 
 
-def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0):
-    """y = x + mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534)."""
+def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True):
+    """y = [x +] mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534)."""
     d = x.shape[1]
     h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd)
-    Wp = wcast(P["Wp"], dtype)                                   # (2d, d)  pointwise conv as a Linear
+    Wp = wcast(P["Wp"], dtype).view(2 * d, d)                    # Conv1d(d,2d,1) weight viewed as a Linear
     p, _ = linear_fwd(h, Wp, P["bp"])
     k = P["wd"].shape[-1]
     wd = P["wd"].detach().reshape(d, k)
     c = ops.dwconv_fwd(p, wd, P["bd"].detach() if P["bd"] is not None else None, B, T, d, k, True, L.PAD_ZERO, chunk)
     a, ln2_b = ln_fwd(c, P["ln2_w"], P["ln2_b"], 1e-5, need_bwd, act)      # LN + activation fused
     Wo = wcast(P["Wo"], dtype)
-    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x)
+    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None)
     if not need_bwd:
         return y, None
 
@@ -420,7 +424,38 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0):
         dp, _ = ops.dwconv_bwd(dc, p, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
                                gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
         dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
-        return ln1_b(dh, res=dy)
+        return ln1_b(dh, res=dy if residual else None)
     return y, bwd
 
 
+def final_norm(x3, ln):
+    """Encoder-final LayerNorm (eps 1e-6; Conformer.py:738,784 / Branchformer.py:444,489) as one block."""
+    B, T, d = x3.shape
+
+    def run(xin, need):
+        y, b = ln_fwd(ops.rows2d(xin), ln.weight, ln.bias, ln.eps, need)
+        return y.view(B, T, d), ((lambda dy: b(ops.rows2d(dy.contiguous())).view(B, T, d)) if need else None)
+    return block(x3, run, [ln.weight, ln.bias])
+
+
+
+
+def input_proj_pe(src3, W, b, pe, T):
+    """x = src W^T + b + PE[t]  (TransformerASR.py:542,547-549): the abs-sine table enters the GEMM epilogue as
+    a per-frame side input indexed n % T, so the add costs no extra pass."""
+    B = src3.shape[0]
+
+    def run(xin, need):
+        dtype = xin.dtype
+        x = ops.rows2d(xin)
+        Wc = wcast(W, dtype)
+        y, _ = linear_fwd(x, Wc, b, c0=pe, c0_mode=L.C0_MOD, c0_div=T)
+        if not need:
+            return y.view(B, T, -1), None
+
+        def bwd(dy3):
+            dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+            dx, _ = linear_bwd(dy, x, Wc, None, L.ACT_NONE, None, 1.0, gacc(W), gacc(b), need_dx=xin.requires_grad)
+            return dx.view(xin.shape) if dx is not None else None
+        return y.view(B, T, -1), bwd
+    return block(src3, run, [W, b])

@@ -1,0 +1,182 @@
+"""Branchformer encoder with the SummaryMixing cell on MI355X.
+
+Mirrors speechbrain/lobes/models/transformer/Branchformer.py (ConvolutionBranch :31-97,
+BranchformerEncoderLayer :100-334, BranchformerEncoder :337-491) for attention_type="SummaryMixing":
+
+  layer(x) = x + merge_proj(cat[ SummaryMixing(LN(x)), cgMLP(LN(x)) ])
+  cgMLP(h) = Linear(csgu/2 -> d)( CSGU( act(Linear(d -> csgu)(h)) ) ),
+  CSGU(u)  = u1 * dwconv_reflect(LN(u2))                      (upstream ConvolutionalSpatialGatingUnit)
+The concatenation is never materialised: both branches write into the two column halves of one buffer.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .... import _lib as L
+from .... import functional as F
+from .... import ops
+from ....nnet.activations import act_code
+from ....nnet.summary_mixing import SummaryMixing
+from ...models.VanillaNN import VanillaNN
+from .Conformer import _LayerNorm, _check_dropout
+
+
+class _CSGUConv(nn.Module):
+    def __init__(self, n, k):
+        super().__init__()
+        self.conv = nn.Conv1d(n, n, k, groups=n)
+
+
+class ConvolutionalSpatialGatingUnit(nn.Module):
+    """Parameter holder with upstream's keys (norm.norm.*, conv.conv.*) and init (w ~ N(0,1e-6), bias = 1)."""
+
+    def __init__(self, input_size, kernel_size=31, dropout=0.0, use_linear_after_conv=False, activation=nn.Identity):
+        super().__init__()
+        if input_size % 2 != 0:
+            raise ValueError("Input size must be divisible by 2!")
+        if use_linear_after_conv or act_code(activation) != L.ACT_NONE:
+            raise NotImplementedError("CSGU linear-after-conv / gate activation are not used by the SummaryMixing recipes")
+        n = input_size // 2
+        self.norm = _LayerNorm(n)
+        self.conv = _CSGUConv(n, kernel_size)
+        nn.init.normal_(self.conv.conv.weight, std=1e-6)
+        nn.init.ones_(self.conv.conv.bias)
+
+
+class ConvolutionBranch(nn.Module):
+    def __init__(self, input_size, linear_units=3072, kernel_size=31, activation=nn.GELU, gate_activation=nn.Identity,
+                 dropout=0.0, use_linear_after_conv=False):
+        super().__init__()
+        self.pre_channel_proj = nn.Linear(input_size, linear_units)
+        self.post_channel_proj = nn.Linear(linear_units // 2, input_size)
+        self.act = act_code(activation)
+        self.csgu = ConvolutionalSpatialGatingUnit(linear_units, kernel_size, dropout, use_linear_after_conv,
+                                                   gate_activation)
+
+    def params(self):
+        return {"Wpre": self.pre_channel_proj.weight, "bpre": self.pre_channel_proj.bias,
+                "Wpost": self.post_channel_proj.weight, "bpost": self.post_channel_proj.bias,
+                "ln_w": self.csgu.norm.norm.weight, "ln_b": self.csgu.norm.norm.bias,
+                "wd": self.csgu.conv.conv.weight, "bd": self.csgu.conv.conv.bias}
+
+
+class BranchformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, kernel_size=31, kdim=None, vdim=None, activation=nn.GELU, dropout=0.0,
+                 attention_type="SummaryMixing", csgu_linear_units=3072, gate_activation=nn.Identity,
+                 use_linear_after_conv=False, local_proj_hid_dim=[512], local_proj_out_dim=512, summary_hid_dim=[1024],
+                 summary_out_dim=1024, mode="SummaryMixing"):
+        super().__init__()
+        if attention_type != "SummaryMixing":
+            raise NotImplementedError("summarymixing_amd implements attention_type='SummaryMixing' only")
+        self.attention_type, self.mode = attention_type, mode
+        self.act = act_code(activation)
+        self.p_drop = float(dropout)
+        self.mha_layer = SummaryMixing(enc_dim=d_model, nhead=nhead, local_proj_hid_dim=local_proj_hid_dim,
+                                       local_proj_out_dim=local_proj_out_dim, summary_hid_dim=summary_hid_dim,
+                                       summary_out_dim=summary_out_dim, activation=activation, mode=mode,
+                                       global_dropout=0.0 if dropout == 0.0 else 0.1)
+        self.merge_dnn_blocks = list(summary_hid_dim) + [d_model]
+        self.merge_proj = VanillaNN(input_shape=[None, None, local_proj_out_dim + summary_out_dim],
+                                    dnn_blocks=len(self.merge_dnn_blocks), dnn_neurons=self.merge_dnn_blocks,
+                                    activation=activation)
+        self.norm_mhsa = _LayerNorm(d_model)
+        self.convolution_branch = ConvolutionBranch(d_model, csgu_linear_units, kernel_size, activation, gate_activation,
+                                                    dropout, use_linear_after_conv)
+        self.norm_conv = _LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def make_run(self, B, T, m8, src_mask):
+        act = self.act
+        cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask)
+        Pb = self.convolution_branch.params()
+        merge = self.merge_proj.specs()
+        nm, nc = self.norm_mhsa.norm, self.norm_conv.norm
+        s_out = self.mha_layer.summary_out_dim if self.mode != "SummaryMixing-lite" else self.mha_layer.summary_out_dim
+
+        def run(x3, need):
+            dtype = x3.dtype
+            x = ops.rows2d(x3)
+            N, d = x.shape
+            dev = x.device
+            # branch 1: SummaryMixing(LN(x))
+            h1, bn1 = F.ln_fwd(x, nm.weight, nm.bias, nm.eps, need)
+            y1_3, bcell = cell(h1.view(B, T, d), need)
+            y1 = ops.rows2d(y1_3.contiguous() if y1_3.stride(1) == 0 else y1_3)
+            c1 = y1.shape[1]
+            # branch 2: cgMLP(LN(x))
+            h2, bn2 = F.ln_fwd(x, nc.weight, nc.bias, nc.eps, need)
+            Wpre, Wpost = F.wcast(Pb["Wpre"], dtype), F.wcast(Pb["Wpost"], dtype)
+            u, zu = F.linear_fwd(h2, Wpre, Pb["bpre"], act, None, save_z=need)           # (N, csgu)
+            n = u.shape[1] // 2
+            u1, u2 = u[:, :n], u[:, n:]
+            v, bnv = F.ln_fwd(u2, Pb["ln_w"], Pb["ln_b"], 1e-5, need)
+            k = Pb["wd"].shape[-1]
+            wd = Pb["wd"].detach().reshape(n, k)
+            g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1)
+            # both branches land in one (N, c1 + d) buffer = the merge input (no torch.cat)
+            cat = torch.empty((N, c1 + d), dtype=dtype, device=dev)
+            ops.axpby(1.0, y1, out=cat[:, :c1])
+            F.linear_fwd(g, Wpost, Pb["bpost"], out=cat[:, c1:])
+            m_out, sv_m = F.mlp_fwd(cat, merge, act, None, need, dtype)
+            y = ops.axpby(1.0, x, 1.0, m_out)                                          # x + merge (:279)
+            if not need:
+                return y.view(B, T, d), None
+
+            def bwd(dy3):
+                dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+                dcat = F.mlp_bwd(dy, merge, act, sv_m, dtype)
+                # branch 2 backward
+                dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]))
+                du = torch.empty_like(u)
+                dv, du1 = ops.dwconv_bwd(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T, n, k,
+                                         False, L.PAD_REFLECT, 0, gate=u1)
+                ops.axpby(1.0, du1, out=du[:, :n])
+                du2 = bnv(dv)
+                ops.axpby(1.0, du2, out=du[:, n:])
+                dh2, _ = F.linear_bwd(du, h2, Wpre, zu, act, None, 1.0, F.gacc(Pb["Wpre"]), F.gacc(Pb["bpre"]))
+                dx = bn2(dh2, res=dy)
+                # branch 1 backward
+                dh1 = ops.rows2d(bcell(dcat[:, :c1].contiguous().view(B, T, c1)))
+                dx = bn1(dh1, res=dx)
+                return dx.view(B, T, d)
+            return y.view(B, T, d), bwd
+        return run
+
+    def forward(self, x, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
+                pos_embs: Optional[torch.Tensor] = None):
+        _check_dropout(self, self.p_drop, "BranchformerEncoderLayer")
+        B, T, _ = x.shape
+        m8 = F.mask_u8(src_key_padding_mask, B, T, x.device)
+        return F.block(x, self.make_run(B, T, m8, src_mask), list(self.parameters())), None
+
+
+class BranchformerEncoder(nn.Module):
+    def __init__(self, num_layers, d_model, nhead, kernel_size=31, kdim=None, vdim=None, activation=nn.GELU, dropout=0.0,
+                 attention_type="SummaryMixing", csgu_linear_units=3072, gate_activation=nn.Identity,
+                 use_linear_after_conv=False, local_proj_hid_dim=[512], local_proj_out_dim=512, summary_hid_dim=[1024],
+                 summary_out_dim=1024, mode="SummaryMixing"):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            BranchformerEncoderLayer(nhead=nhead, d_model=d_model, kdim=kdim, vdim=vdim, dropout=dropout,
+                                     activation=activation, kernel_size=kernel_size, attention_type=attention_type,
+                                     csgu_linear_units=csgu_linear_units, gate_activation=gate_activation,
+                                     use_linear_after_conv=use_linear_after_conv, local_proj_hid_dim=local_proj_hid_dim,
+                                     local_proj_out_dim=local_proj_out_dim, summary_hid_dim=summary_hid_dim,
+                                     summary_out_dim=summary_out_dim, mode=mode) for _ in range(num_layers)])
+        self.norm = _LayerNorm(d_model, eps=1e-6)
+        self.attention_type = attention_type
+
+    def forward(self, src, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
+                pos_embs: Optional[torch.Tensor] = None, dynchunktrain_config=None):
+        if dynchunktrain_config is not None:
+            raise NotImplementedError("Dynamic chunk training is not supported for the Branchformer (as the reference)")
+        B, T, _ = src.shape
+        m8 = F.mask_u8(src_key_padding_mask, B, T, src.device)
+        out = src
+        attention_lst = []
+        for layer in self.layers:
+            _check_dropout(layer, layer.p_drop, "BranchformerEncoderLayer")
+            out = F.block(out, layer.make_run(B, T, m8, src_mask), list(layer.parameters()))
+            attention_lst.append(None)
+        return F.final_norm(out, self.norm.norm), attention_lst

@@ -1,0 +1,187 @@
+"""Conformer encoder with the SummaryMixing cell on MI355X.
+
+Mirrors the constructor / forward signatures and state-dict keys of the reference
+(speechbrain/lobes/models/transformer/Conformer.py: ConvolutionModule :72-331, ConformerEncoderLayer :334-537,
+ConformerEncoder :623-786) for attention_type="SummaryMixing".  The torch.nn sub-modules below are parameter
+HOLDERS only (same names => same keys => reference checkpoints load); all arithmetic runs in libsmx.so:
+
+  layer(x):  x1 = x  + 1/2 FFN1(x)              LN -> GEMM(+bias,act) -> GEMM(+bias, residual, alpha=1/2)
+             x2 = x1 + SummaryMixing(LN(x1))    cell with the skip fused as the merge-GEMM residual
+             x3 = x2 + mask * ConvModule(x2)    LN -> GEMM -> fused GLU+dwconv -> LN+act -> GEMM(+mask,residual)
+             y  = LN(x3 + 1/2 FFN2(x3))
+Attention types other than SummaryMixing, causal convolution and the streaming context are out of scope
+ and raise NotImplementedError.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .... import functional as F
+from .... import ops
+from ....nnet.activations import Swish, act_code
+from ....nnet.summary_mixing import SummaryMixing
+
+
+class _LayerNorm(nn.Module):
+    """Key layout of speechbrain.nnet.normalization.LayerNorm (``.norm`` is an nn.LayerNorm)."""
+
+    def __init__(self, d, eps=1e-5):
+        super().__init__()
+        self.norm = nn.LayerNorm(d, eps=eps)
+
+
+class _FFN(nn.Module):
+    """Key layout of PositionalwiseFeedForward: ``ffn.0`` Linear(d,f), ``ffn.3`` Linear(f,d)."""
+
+    def __init__(self, d_ffn, input_size, dropout, activation):
+        super().__init__()
+        self.ffn = nn.Sequential(nn.Linear(input_size, d_ffn), nn.Identity(), nn.Dropout(dropout),
+                                 nn.Linear(d_ffn, input_size))
+
+
+def _ffn_params(seq):
+    return {"ln_w": seq[0].weight, "ln_b": seq[0].bias, "W1": seq[1].ffn[0].weight, "b1": seq[1].ffn[0].bias,
+            "W2": seq[1].ffn[3].weight, "b2": seq[1].ffn[3].bias}
+
+
+def _check_dropout(module, p, what):
+    if module.training and p > 0.0:
+        raise NotImplementedError(f"{what}: training-mode dropout (p={p}) is not implemented in the HIP path yet; "
+                                  "use dropout=0.0 or .eval()")
+
+
+class ConvolutionModule(nn.Module):
+    def __init__(self, input_size, kernel_size=31, bias=True, activation=Swish, dropout=0.0, causal=False,
+                 dilation=1, masked_false_or_true=True):
+        super().__init__()
+        if causal or dilation != 1:
+            raise NotImplementedError("causal / dilated convolution is outside the SummaryMixing hot path")
+        self.kernel_size, self.causal, self.dilation = kernel_size, causal, dilation
+        self.masked_false_or_true = masked_false_or_true
+        self.padding = (kernel_size - 1) // 2
+        self.act = act_code(activation)
+        self.p_drop = float(dropout)
+        self.layer_norm = nn.LayerNorm(input_size)
+        self.bottleneck = nn.Sequential(nn.Conv1d(input_size, 2 * input_size, kernel_size=1, bias=bias), nn.Identity())
+        self.conv = nn.Conv1d(input_size, input_size, kernel_size, padding=self.padding, groups=input_size, bias=bias)
+        self.after_conv = nn.Sequential(nn.LayerNorm(input_size), nn.Identity(), nn.Linear(input_size, input_size, bias=bias),
+                                        nn.Dropout(dropout))
+
+    def params(self):
+        return {"ln1_w": self.layer_norm.weight, "ln1_b": self.layer_norm.bias, "Wp": self.bottleneck[0].weight,
+                "bp": self.bottleneck[0].bias, "wd": self.conv.weight, "bd": self.conv.bias,
+                "ln2_w": self.after_conv[0].weight, "ln2_b": self.after_conv[0].bias, "Wo": self.after_conv[2].weight,
+                "bo": self.after_conv[2].bias}
+
+    def forward(self, x, mask: Optional[torch.Tensor] = None, dynchunktrain_config=None):
+        """Returns conv_module(x) (without the residual), mask (B,T,1) multiplies the output when
+        masked_false_or_true is False (the SummaryMixing convention, Conformer.py:327-331)."""
+        _check_dropout(self, self.p_drop, "ConvolutionModule")
+        B, T, d = x.shape
+        if mask is not None and self.masked_false_or_true:
+            mask = ~mask.bool()
+        m8 = F.mask_u8(mask.reshape(B, T) if mask is not None else None, B, T, x.device)
+        P, act = self.params(), self.act
+        chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
+
+        def run(xin, need_bwd):
+            x2 = ops.rows2d(xin)
+            y, bwd = F.conv_module_fwd(x2, P, act, m8, B, T, need_bwd, xin.dtype, chunk, residual=False)
+            return y.view(B, T, d), ((lambda dy: bwd(ops.rows2d(dy.contiguous())).view(B, T, d)) if need_bwd else None)
+        return F.block(x, run, list(self.parameters()))
+
+
+class ConformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, d_ffn, nhead, kernel_size=31, kdim=None, vdim=None, activation=Swish, bias=True,
+                 dropout=0.0, causal=False, attention_type="RelPosMHAXL", local_proj_hid_dim=[512],
+                 local_proj_out_dim=512, summary_hid_dim=[1024], mode="SummaryMixing"):
+        super().__init__()
+        if attention_type != "SummaryMixing":
+            raise NotImplementedError("summarymixing_amd implements attention_type='SummaryMixing' only")
+        self.attention_type, self.mode = attention_type, mode
+        self.masked_false_or_true = False                     # Conformer.py:447
+        self.act = act_code(activation)
+        self.p_drop = float(dropout)
+        self.mha_layer = SummaryMixing(enc_dim=d_model, nhead=nhead, local_proj_hid_dim=local_proj_hid_dim,
+                                       local_proj_out_dim=local_proj_out_dim, summary_hid_dim=summary_hid_dim,
+                                       summary_out_dim=d_model, activation=activation, global_dropout=dropout, mode=mode)
+        self.convolution_module = ConvolutionModule(d_model, kernel_size, bias, activation, dropout, causal=causal,
+                                                    masked_false_or_true=False)
+        self.ffn_module1 = nn.Sequential(nn.LayerNorm(d_model), _FFN(d_ffn, d_model, dropout, activation), nn.Dropout(dropout))
+        self.ffn_module2 = nn.Sequential(nn.LayerNorm(d_model), _FFN(d_ffn, d_model, dropout, activation), nn.Dropout(dropout))
+        self.norm1 = _LayerNorm(d_model)
+        self.norm2 = _LayerNorm(d_model)
+        self.drop = nn.Dropout(dropout)
+
+    def make_run(self, B, T, m8, src_mask, chunk):
+        d_act = self.act
+        P1, P2 = _ffn_params(self.ffn_module1), _ffn_params(self.ffn_module2)
+        Pc = self.convolution_module.params()
+        n1, n2 = self.norm1.norm, self.norm2.norm
+        cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask)
+
+        def run(x3, need):
+            dtype = x3.dtype
+            x = ops.rows2d(x3)
+            y1, b1 = F.ffn_module_fwd(x, P1, d_act, need, dtype)                       # :507
+            h, bn1 = F.ln_fwd(y1, n1.weight, n1.bias, n1.eps, need)                    # :510
+            y2_3, bcell = cell(h.view(B, T, -1), need, res=y1)                        # :512-530 (skip fused)
+            y2 = ops.rows2d(y2_3)
+            y3, bconv = F.conv_module_fwd(y2, Pc, d_act, m8, B, T, need, dtype, chunk)  # :532-534
+            y4, bf2 = F.ffn_module_fwd(y3, P2, d_act, need, dtype)
+            y5, bn2 = F.ln_fwd(y4, n2.weight, n2.bias, n2.eps, need)                   # :536
+            if not need:
+                return y5.view(B, T, -1), None
+
+            def bwd(dy3):
+                dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+                d4 = bn2(dy)
+                d3 = bf2(d4)
+                d2 = bconv(d3)
+                dh = ops.rows2d(bcell(d2.view(B, T, -1)))
+                d1 = bn1(dh, res=d2)                                                   # skip gradient fused
+                return b1(d1).view(B, T, -1)
+            return y5.view(B, T, -1), bwd
+        return run
+
+    def forward(self, x, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
+                pos_embs: torch.Tensor = None, dynchunktrain_config=None):
+        _check_dropout(self, self.p_drop, "ConformerEncoderLayer")
+        B, T, _ = x.shape
+        m8 = F.mask_u8(src_key_padding_mask, B, T, x.device)
+        chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
+        run = self.make_run(B, T, m8, src_mask, chunk)
+        return F.block(x, run, list(self.parameters())), None
+
+    def forward_streaming(self, *a, **k):
+        raise NotImplementedError("streaming inference is broken for SummaryMixing in the reference (SURVEY §2 row 5)")
+
+
+class ConformerEncoder(nn.Module):
+    def __init__(self, num_layers, d_model, d_ffn, nhead, kernel_size=31, kdim=None, vdim=None, activation=Swish,
+                 bias=True, dropout=0.0, causal=False, attention_type="RelPosMHAXL", local_proj_hid_dim=[512],
+                 local_proj_out_dim=512, summary_hid_dim=[1024], mode="SummaryMixing"):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            ConformerEncoderLayer(d_ffn=d_ffn, nhead=nhead, d_model=d_model, kdim=kdim, vdim=vdim, dropout=dropout,
+                                  activation=activation, kernel_size=kernel_size, bias=bias, causal=causal,
+                                  attention_type=attention_type, local_proj_hid_dim=local_proj_hid_dim,
+                                  local_proj_out_dim=local_proj_out_dim, summary_hid_dim=summary_hid_dim, mode=mode)
+            for _ in range(num_layers)])
+        self.norm = _LayerNorm(d_model, eps=1e-6)
+        self.attention_type = attention_type
+
+    def forward(self, src, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
+                pos_embs: Optional[torch.Tensor] = None, dynchunktrain_config=None):
+        B, T, _ = src.shape
+        m8 = F.mask_u8(src_key_padding_mask, B, T, src.device)
+        chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
+        out = src
+        attention_lst = []
+        for layer in self.layers:
+            _check_dropout(layer, layer.p_drop, "ConformerEncoderLayer")
+            out = F.block(out, layer.make_run(B, T, m8, src_mask, chunk), list(layer.parameters()))
+            attention_lst.append(None)
+        out = F.final_norm(out, self.norm.norm)
+        return out, attention_lst

@@ -1,0 +1,140 @@
+"""GPU parity of the encoder layers / encoder stacks against reference-generated goldens (stand-in dependent
+for LayerNorm/FFN/CSGU, see tests/golden/make_golden.py) and against the fp64 oracle at larger shapes."""
+import pytest
+import torch
+
+from tests import _golden as G
+from tests._util import TOL, rel_err
+
+pytestmark = pytest.mark.gpu
+ACT = {"gelu": torch.nn.GELU, "swish": "swish"}
+
+
+def _conformer_layer(meta, sd):
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoderLayer
+    d = sd["norm1.norm.weight"].shape[0]
+    f = sd["ffn_module1.1.ffn.0.weight"].shape[0]
+    k = sd["convolution_module.conv.weight"].shape[-1]
+    layer = ConformerEncoderLayer(d_model=d, d_ffn=f, nhead=meta["nhead"], kernel_size=k, activation=ACT[meta["act"]],
+                                  dropout=0.0, attention_type="SummaryMixing", local_proj_hid_dim=[d],
+                                  local_proj_out_dim=d, summary_hid_dim=[d], mode=meta["mode"])
+    layer.load_state_dict(sd, strict=True)
+    return layer.cuda()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["g5_conformer_layer_swish", "g5_conformer_layer_gelu"])
+def test_conformer_layer_golden(name, dtype):
+    meta, a, sd, grads = G.load(name)
+    layer = _conformer_layer(meta, sd)
+    x = a["x"].cuda().to(dtype).requires_grad_(True)
+    y, attn = layer(x, src_key_padding_mask=a["pad_mask"].cuda())
+    assert attn is None
+    ftol, gtol = TOL[dtype]
+    if dtype == torch.bfloat16:
+        ftol, gtol = 2e-2, 5e-2        # a whole layer of bf16 storage roundings (4 LN + 8 GEMM hops)
+    assert rel_err(y, a["y"]) <= ftol, rel_err(y, a["y"])
+    (y.float() * a["r"].cuda()).sum().backward()
+    assert rel_err(x.grad, a["gx"]) <= gtol, rel_err(x.grad, a["gx"])
+    params = dict(layer.named_parameters())
+    for k, g in grads.items():
+        assert rel_err(params[k].grad, g) <= gtol, (k, rel_err(params[k].grad, g))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_branchformer_layer_golden(dtype):
+    from summarymixing_amd.lobes.models.transformer.Branchformer import BranchformerEncoderLayer
+    meta, a, sd, grads = G.load("g5_branchformer_layer")
+    d = 32
+    layer = BranchformerEncoderLayer(d_model=d, nhead=1, kernel_size=7, activation=torch.nn.GELU, dropout=0.0,
+                                     attention_type="SummaryMixing", csgu_linear_units=96, local_proj_hid_dim=[d],
+                                     local_proj_out_dim=d, summary_hid_dim=[d], summary_out_dim=d, mode="SummaryMixing")
+    layer.load_state_dict(sd, strict=True)
+    layer.cuda()
+    x = a["x"].cuda().to(dtype).requires_grad_(True)
+    y, _ = layer(x, src_key_padding_mask=a["pad_mask"].cuda())
+    ftol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (2e-2, 5e-2)
+    assert rel_err(y, a["y"]) <= ftol, rel_err(y, a["y"])
+    (y.float() * a["r"].cuda()).sum().backward()
+    assert rel_err(x.grad, a["gx"]) <= gtol, rel_err(x.grad, a["gx"])
+    params = dict(layer.named_parameters())
+    for k, g in grads.items():
+        assert rel_err(params[k].grad, g) <= gtol, (k, rel_err(params[k].grad, g))
+
+
+def _asr(meta, sd, input_size):
+    from summarymixing_amd.lobes.models.transformer.TransformerASR import EncoderWrapper, TransformerASR
+    nl = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))
+    d = sd["encoder.norm.norm.weight"].shape[0]
+    if meta["encoder_module"] == "conformer":
+        net = TransformerASR(tgt_vocab=10, input_size=input_size, d_model=d, nhead=meta["nhead"], num_encoder_layers=nl,
+                             num_decoder_layers=0, d_ffn=sd["encoder.layers.0.ffn_module1.1.ffn.0.weight"].shape[0],
+                             dropout=0.0, encoder_module="conformer", conformer_activation="swish",
+                             attention_type="SummaryMixing", mode=meta["mode"], local_proj_out_dim=d,
+                             local_proj_hid_dim=[d], summary_hid_dim=[d], causal=False,
+                             kernel_size=sd["encoder.layers.0.convolution_module.conv.weight"].shape[-1])
+    else:
+        net = TransformerASR(tgt_vocab=10, input_size=input_size, d_model=d, nhead=1, num_encoder_layers=nl,
+                             num_decoder_layers=0, dropout=0.0, encoder_module="branchformer",
+                             branchformer_activation=torch.nn.GELU, attention_type="SummaryMixing", mode=meta["mode"],
+                             local_proj_out_dim=d, local_proj_hid_dim=[d], summary_hid_dim=[d], summary_out_dim=d,
+                             csgu_linear_units=sd["encoder.layers.0.convolution_branch.pre_channel_proj.weight"].shape[0],
+                             kernel_size=sd["encoder.layers.0.convolution_branch.csgu.conv.conv.weight"].shape[-1],
+                             causal=False)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and missing == ["positional_encoding.pe"], (missing, unexpected)
+    return EncoderWrapper(net).cuda().eval()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["g5_config1_encoder", "g5_config1_encoder_dynchunk", "g5_branchformer_encoder"])
+def test_encoder_wrapper_golden(name, dtype):
+    """BASELINE config 1 (2-layer Conformer-SM d=144 through EncoderWrapper, wav_len [1.0, 0.6]) + DynChunk + Branchformer."""
+    from summarymixing_amd.utils.dynamic_chunk_training import DynChunkTrainConfig
+    meta, a, sd, _ = G.load(name)
+    if not sd:
+        sd = G.load("g5_config1_encoder")[2]
+    src = a["src"]
+    enc = _asr(meta, sd, src.shape[2] * (src.shape[3] if src.dim() == 4 else 1))
+    kw = {}
+    if meta["dynchunk"]:
+        kw["dynchunktrain_config"] = DynChunkTrainConfig(*meta["dynchunk"])
+    with torch.no_grad():
+        y = enc(src.cuda().to(dtype), a["wav_len"].cuda(), **kw)
+    tol = 1e-3 if dtype == torch.float32 else 3e-2
+    assert rel_err(y, a["y"]) <= tol, rel_err(y, a["y"])
+
+
+def test_padded_content_quirk_is_reproduced():
+    meta, a, sd, _ = G.load("g6_padded_content")
+    layer = _conformer_layer(meta, sd)
+    pad = a["pad_mask"].cuda()
+    ya, _ = layer(a["x"].cuda(), src_key_padding_mask=pad)
+    yb, _ = layer(a["xb"].cuda(), src_key_padding_mask=pad)
+    assert rel_err(ya, a["y"]) <= 1e-3 and rel_err(yb, a["yb"]) <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conformer_encoder_vs_oracle_mid_size(dtype):
+    """4 layers, d=256, ragged batch, fp64 oracle on the same weights (sizes the oracle finishes in seconds)."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(1)
+    B, T, d = 4, 190, 256
+    enc = ConformerEncoder(4, d, 512, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast")
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+            elif "bias" in n:
+                p.normal_(0, 0.05)
+    sd = {k: v.double() for k, v in enc.state_dict().items()}
+    x = torch.randn(B, T, d)
+    lens = torch.tensor([T, 60, 131, 177])
+    pad = torch.arange(T)[None] < lens[:, None]
+    ref = O.conformer_encoder(x.double(), sd, "", "swish", "SummaryMixing-fast", d, None, pad)
+    with torch.no_grad():
+        y, _ = enc.cuda()(x.cuda().to(dtype), src_key_padding_mask=pad.cuda())
+    tol = 1e-3 if dtype == torch.float32 else 3e-2
+    assert rel_err(y, ref) <= tol, rel_err(y, ref)
