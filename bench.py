@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py — encoder frames/s of the LibriSpeech Conformer-SummaryMixing training step on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3                      # default: config C2b, bf16 training step
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one synthetic padded utterance batch per GPU: encoder forward
+(input Linear + abs-sine PE + 12 Conformer-SummaryMixing layers + final LN), backward, gradient all-reduce
+(N > 1), global-norm clip and fused AdamW — all in the hand-written gfx950 kernels of libsmx.so.  Inputs are
+resident in HBM before the timed region.  Weak scaling: every rank processes its own (B, T) batch, the only
+collective is the bucketed gradient all-reduce (RCCL over xGMI).
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus
+  "roofline":     MFMA roofline of the dominant kernel (the FFN up-projection GEMM instance), timed live with
+                  HIP events on the launch stream,
+  "roofline_pool": HBM roofline of the masked-mean pool kernel at the long-utterance point (config 5),
+  "cpu_baseline": the oracle (PyTorch-CPU restatement of the reference graph) timed on this node's host cores
+                  on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: 12 layers, d_model 256 (SURVEY §8d "C2b"); saturating batch B=64, T_enc=500
+    "c2b": dict(kind="conformer", d=256, f=1024, l=256, layers=12, nhead=4, input=640, B=64, T=500,
+                name="LibriSpeech Conformer-SummaryMixing C2b (12L, d_model=256, d_ffn=1024, SummaryMixing-fast, Swish)"),
+    # recipe-faithful shapes of conformer_summarymixing_transducer.yaml:130-146 (SURVEY §8d "C2a")
+    "c2a": dict(kind="conformer", d=512, f=2048, l=512, layers=12, nhead=4, input=640, B=64, T=500,
+                name="LibriSpeech Conformer-SummaryMixing C2a (12L, d_model=512, d_ffn=2048, SummaryMixing-fast, Swish)"),
+    # plumbing config 1
+    "c1": dict(kind="conformer", d=144, f=576, l=144, layers=2, nhead=4, input=640, B=2, T=50,
+               name="config-1 plumbing (2L, d_model=144)"),
+    # Branchformer CommonVoice (config 4)
+    "c4": dict(kind="branchformer", d=512, f=0, l=512, layers=18, nhead=1, input=640, B=32, T=250, csgu=3072,
+               name="Branchformer-SummaryMixing CV (18L, d_model=512, csgu 3072)"),
+}
+FLOPS_PER_FRAME_FWD = {"c2b": 36.7e6, "c2a": 145.7e6}
+
+
+def build_encoder(cfg, device):
+    from summarymixing_amd.lobes.models.transformer.TransformerASR import EncoderWrapper, TransformerASR
+    torch.manual_seed(3407)   # recipe seed (…transducer.yaml:12)
+    kw = dict(tgt_vocab=1000, input_size=cfg["input"], d_model=cfg["d"], nhead=cfg["nhead"],
+              num_encoder_layers=cfg["layers"], num_decoder_layers=0, dropout=0.0, attention_type="SummaryMixing",
+              local_proj_hid_dim=[cfg["l"]], local_proj_out_dim=cfg["l"], summary_hid_dim=[cfg["l"]], causal=False,
+              kernel_size=31)
+    if cfg["kind"] == "conformer":
+        net = TransformerASR(encoder_module="conformer", d_ffn=cfg["f"], mode="SummaryMixing-fast", **kw)
+    else:
+        net = TransformerASR(encoder_module="branchformer", mode="SummaryMixing", summary_out_dim=cfg["d"],
+                             csgu_linear_units=cfg["csgu"], **kw)
+    return EncoderWrapper(net).to(device).train()
+
+
+def synthetic_batch(cfg, rank, device, dtype):
+    g = torch.Generator().manual_seed(1234 + rank)
+    B, T = cfg["B"], cfg["T"]
+    src = torch.randn(B, T, cfg["input"], generator=g)
+    wav_len = 0.5 + 0.5 * torch.rand(B, generator=g)
+    wav_len[0] = 1.0
+    valid = torch.arange(T)[None, :] < torch.round(wav_len * T)[:, None]
+    src = src * valid[..., None]                     # zero padded frames, as real batches
+    r = torch.randn(B, T, cfg["d"], generator=g) / (B * T)
+    return src.to(device).to(dtype), wav_len.to(device), r.to(device).to(dtype), int(valid.sum())
+
+
+def time_kernel(fn, iters=30, warm=5):
+    """Average duration (s) of one launch, HIP events on the launch stream (torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def roofline_gemm(cfg, dtype):
+    """The dominant kernel of the step: gemm_kernel<bf16, NT, 128x128> on the FFN up-projection shape."""
+    from summarymixing_amd import _lib as L, ops
+    N, K, M = cfg["B"] * cfg["T"], cfg["d"], cfg["f"] or 4 * cfg["d"]
+    x = torch.randn(N, K, device="cuda").to(dtype)
+    w = (torch.randn(M, K, device="cuda") * 0.05).to(dtype)
+    b = torch.randn(M, device="cuda")
+    y, z = torch.empty(N, M, device="cuda", dtype=dtype), torch.empty(N, M, device="cuda", dtype=dtype)
+    e = ops.epilogue(bias=b, act=L.ACT_SWISH, z=z)
+    t = time_kernel(lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e))
+    flops = 2.0 * N * K * M
+    es = 2 if dtype == torch.bfloat16 else 4
+    peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+    alg_bytes = (N * K + M * K + 2 * N * M) * es + 4 * M
+    return {"kernel": f"gemm_kernel<{'bf16' if es == 2 else 'f32'},NT,128x128> FFN up-proj ({N}x{K})x({K}x{M}) +bias+swish+Z",
+            "bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": flops / t / 1e12 / peak, "traffic": None, "launch_us": t * 1e6,
+            "hbm_GBps_algorithmic": alg_bytes / t / 1e9}
+
+
+def roofline_pool(dtype):
+    """Config 5 roofline point: masked mean over (B=8, T=30000, D=512); algorithmic bytes per launch =
+    B*T*D*sizeof + B*T (mask) + 4*B*D."""
+    from summarymixing_amd import ops
+    B, T, D = 8, 30000, 512
+    s = torch.randn(B * T, D, device="cuda").to(dtype)
+    lens = torch.randint(T // 2, T + 1, (B,), device="cuda")
+    lens[0] = T
+    mask = (torch.arange(T, device="cuda")[None] < lens[:, None]).reshape(-1).view(torch.uint8)
+    t = time_kernel(lambda: ops.masked_mean(s, mask, B, T, True, False))
+    es = 2 if dtype == torch.bfloat16 else 4
+    nbytes = B * T * D * es + B * T + 4 * B * D
+    return {"kernel": f"masked_sum_stage1+2 ({B},{T},{D}) {'bf16' if es == 2 else 'f32'}", "bound": "hbm",
+            "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
+            "traffic": None, "launch_us": t * 1e6}
+
+
+def cpu_baseline(cfg, train):
+    """The oracle (PyTorch-CPU restatement of the reference module graph) on a bounded sample of the same
+    workload: same model shapes, fp32, B=8 utterances of the same T (about 10-30 s of CPU work)."""
+    from oracle import smx_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    enc = build_encoder(cfg, "cpu")
+    sd = {k: v.detach().clone().requires_grad_(train and v.is_floating_point())
+          for k, v in enc.transformer.state_dict().items() if k != "positional_encoding.pe"}
+    small = dict(cfg, B=min(cfg["B"], 8))
+    src, wav_len, r, _ = synthetic_batch(small, 0, "cpu", torch.float32)
+    kind = "conformer" if cfg["kind"] == "conformer" else "branchformer"
+    act = "swish" if kind == "conformer" else "gelu"
+    mode = "SummaryMixing-fast" if kind == "conformer" else "SummaryMixing"
+
+    def step():
+        y = O.asr_encode(src, wav_len, sd, kind, act, mode, cfg["l"])
+        if train:
+            y.backward(r)
+            for v in sd.values():
+                v.grad = None
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 50):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    frames = small["B"] * small["T"]
+    return {"value": frames / dt, "unit": "encoder frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/smx_oracle.py asr_encode {'fwd+bwd' if train else 'fwd'}, fp32, B={small['B']} x T={small['T']} "
+                      f"of the same model, {n} steps, torch {torch.__version__}, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2b", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    if args.frames:
+        cfg["T"] = args.frames
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    train = args.mode == "train"
+
+    from summarymixing_amd.trainer import FlatAdamW
+    enc = build_encoder(cfg, dev)
+    opt = None
+    if train:
+        opt = FlatAdamW(enc, lr=8e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
+                        compute_dtype=dtype)
+        if world > 1:   # one gradient bucket per encoder layer, reduced as soon as the layer's backward is done
+            for layer in enc.transformer.encoder.layers:
+                rng = opt.param_range(list(layer.parameters()))
+                layer._on_bwd_done = (lambda r=rng: opt.reduce_bucket_async(*r))
+    else:
+        enc.eval()
+    src, wav_len, r, valid_frames = synthetic_batch(cfg, rank, dev, dtype)
+
+    def step():
+        if train:
+            opt.zero_grad()
+            y = enc(src, wav_len)
+            y.backward(r)
+            if world > 1:   # parameters outside the layer buckets (input Linear, final LN)
+                first = opt.param_range(list(enc.transformer.encoder.layers[0].parameters()))[0]
+                last = opt.param_range(list(enc.transformer.encoder.layers[-1].parameters()))[1]
+                if first > 0:
+                    opt.reduce_bucket_async(0, first)
+                if last < opt.total:
+                    opt.reduce_bucket_async(last, opt.total)
+            opt.step()
+        else:
+            with torch.no_grad():
+                enc(src, wav_len)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    frames_per_step = cfg["B"] * cfg["T"] * world
+    value = frames_per_step * args.steps / dt
+    out = {
+        "metric": "encoder frames/s (whole node), LibriSpeech Conformer-SummaryMixing",
+        "value": value, "unit": "encoder frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": cfg["name"] + (" training step (fwd+bwd+grad-clip+AdamW)" if train else " forward"),
+                   "per_gpu_batch": cfg["B"], "enc_frames_per_utt": cfg["T"], "global_batch": cfg["B"] * world,
+                   "padded_frames_per_step": frames_per_step, "valid_frames_rank0": valid_frames,
+                   "input": f"(B,T,{cfg['input']}) N(0,1), wav_len U(0.5,1), zero padded",
+                   "dropout": 0.0, "parallelism": f"dp{world}", "init": "xavier_normal seed 3407"},
+    }
+    if args.config in FLOPS_PER_FRAME_FWD:
+        fl = FLOPS_PER_FRAME_FWD[args.config] * (3.0 if train else 1.0)
+        out["model_tflops"] = value * fl / 1e12
+    if rank == 0:
+        if not args.no_roofline:
+            out["roofline"] = roofline_gemm(cfg, dtype)
+            out["roofline_pool"] = roofline_pool(dtype)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, train)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

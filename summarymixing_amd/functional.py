@@ -68,25 +68,27 @@ def mask_u8(mask, B, T, device):
 
 class _BlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, run, *params):
+    def forward(ctx, x, run, done, *params):
         y, bwd = run(x, True)
-        ctx.bwd = bwd
+        ctx.bwd, ctx.done = bwd, done
         ctx.n = len(params)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dx = ctx.bwd(dy)
-        return (dx, None) + (None,) * ctx.n
+        if ctx.done is not None:
+            ctx.done()          # e.g. launch this block's gradient-bucket all-reduce (trainer.FlatAdamW)
+        return (dx, None, None) + (None,) * ctx.n
 
 
-def block(x, run, params):
+def block(x, run, params, on_bwd_done=None):
     """Run `run(x, need_bwd) -> (y, bwd)`; hook bwd into autograd when anything upstream needs gradients."""
     params = [p for p in params if p is not None]
     need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
     if not need:
         return run(x, False)[0]
-    return _BlockFn.apply(x, run, *params)
+    return _BlockFn.apply(x, run, on_bwd_done, *params)
 
 
 def _wgrad_splits(nrows, m, k):

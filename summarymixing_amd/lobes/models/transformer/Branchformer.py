@@ -177,6 +177,7 @@ class BranchformerEncoder(nn.Module):
         attention_lst = []
         for layer in self.layers:
             _check_dropout(layer, layer.p_drop, "BranchformerEncoderLayer")
-            out = F.block(out, layer.make_run(B, T, m8, src_mask), list(layer.parameters()))
+            out = F.block(out, layer.make_run(B, T, m8, src_mask), list(layer.parameters()),
+                          getattr(layer, "_on_bwd_done", None))
             attention_lst.append(None)
         return F.final_norm(out, self.norm.norm), attention_lst

@@ -181,7 +181,8 @@ class ConformerEncoder(nn.Module):
         attention_lst = []
         for layer in self.layers:
             _check_dropout(layer, layer.p_drop, "ConformerEncoderLayer")
-            out = F.block(out, layer.make_run(B, T, m8, src_mask, chunk), list(layer.parameters()))
+            out = F.block(out, layer.make_run(B, T, m8, src_mask, chunk), list(layer.parameters()),
+                          getattr(layer, "_on_bwd_done", None))
             attention_lst.append(None)
         out = F.final_norm(out, self.norm.norm)
         return out, attention_lst

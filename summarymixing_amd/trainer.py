@@ -1,0 +1,96 @@
+"""Utterance-sharded data-parallel training harness for the encoder hot path.
+
+One process per GPU.  All parameters live in ONE flat fp32 buffer (master weights) with parallel flat buffers
+for the gradients, the two AdamW moments and the bf16 shadow weights the GEMMs read; ``param.data`` /
+``param.grad`` are views, so
+  * the HIP kernels accumulate parameter gradients straight into the flat gradient buffer,
+  * the gradient all-reduce (RCCL over xGMI, ``torch.distributed`` backend "nccl") runs on a few large
+    contiguous buckets - one per encoder layer, launched asynchronously as soon as that layer's backward has
+    finished so that it overlaps the rest of the backward pass,
+  * global-norm clipping + AdamW + the bf16 shadow refresh are three kernel launches per step
+    (smx_sumsq, smx_clip_factor, smx_adamw_step), the clip factor never visits the host.
+Forward/backward need no communication: utterances never interact.
+"""
+import torch
+import torch.distributed as dist
+
+from . import functional as F
+from . import ops
+
+ALIGN = 64   # elements; keeps every parameter view 256-byte aligned in fp32 and 128-byte in bf16
+
+
+class FlatAdamW:
+    def __init__(self, module, lr=8e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
+                 compute_dtype=torch.bfloat16, process_group=None, buckets=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total, self.offs = total, offs
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        for p, o in zip(self.params, offs):
+            n = p.numel()
+            self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[o:o + n].view(p.shape)
+            p.grad = self.flat_g[o:o + n].view(p.shape)
+        if self.shadow is not None:
+            ops.L.check(ops.L.lib().smx_cast_from_f32(ops.L.BF16, ops._p(self.flat_p), ops._p(self.shadow), total,
+                                                      ops._stream()), "smx_cast_from_f32")
+            for p, o in zip(self.params, offs):
+                F.register_shadow(p, self.shadow[o:o + p.numel()].view(p.shape))
+        self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.step_count = 0
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._clip = torch.ones(1, dtype=torch.float32, device=dev)
+        self._pending = []
+        # buckets: list of (start, end) element ranges of the flat buffers, in backward-completion order
+        self.buckets = buckets or [(0, total)]
+
+    # ---- bucket plumbing ---------------------------------------------------------------------------
+    def param_range(self, params):
+        """Element range of the flat buffers covering `params` (must be contiguous in registration order)."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        lo, hi = min(idx), max(idx)
+        assert hi - lo + 1 == len(idx), "bucket parameters must be contiguous in the flat buffer"
+        end = self.offs[hi + 1] if hi + 1 < len(self.offs) else self.total
+        return self.offs[lo], end
+
+    def reduce_bucket_async(self, start, end):
+        """Launch the all-reduce of one gradient bucket (called right after its producer's backward)."""
+        if self.world > 1:
+            self._pending.append(dist.all_reduce(self.flat_g[start:end], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def step(self, reduce_all=False):
+        if self.world > 1:
+            if reduce_all:
+                self.reduce_bucket_async(0, self.total)
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+        self.step_count += 1
+        gscale = 1.0 / self.world
+        clip = None
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            self._sumsq.zero_()
+            ops.sumsq(self.flat_g, self._sumsq)
+            ops.clip_factor(self._sumsq, self.max_grad_norm, gscale, self._clip)
+            clip = self._clip
+        ops.adamw_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.shadow, self.lr, self.betas[0],
+                       self.betas[1], self.eps, self.wd, self.step_count, gscale, clip)
+
+    def grad_norm(self):
+        """Host read of the last global gradient norm (diagnostics only)."""
+        return float(self._sumsq.sqrt().item()) / self.world
