@@ -68,6 +68,15 @@ int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64_t strideA,
              int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K, int batch, int splits,
              const smx_epilogue* epi, void* stream);
 
+/* Weight gradient of a (batched) Linear: dW[b] (M x K) += alpha * dZ[b]^T X[b], reducing over `rows` frames
+ * (dZ (rows, M), X (rows, K), both row-major).  Split-K over the frame dimension into fp32 slabs in `workspace`
+ * (smx_linear_wgrad_workspace bytes) followed by one fixed-order reduction: bit-reproducible, no atomics.
+ * Autograd backward of every nn.Linear / ParallelLinear on the path. */
+size_t smx_linear_wgrad_workspace(int rows, int M, int K, int batch);
+int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,
+                     int64_t strideX, float* dW, int64_t lddw, int64_t strideW, int rows, int M, int K, int batch,
+                     float alpha, void* workspace, void* stream);
+
 /* Y = R + alpha * act(X W^T + b [+C0]) * mask ; thin wrapper over smx_gemm(NT).
  * Replaces summary_mixing.py:257 (global_proj * mask), :207/:210 (local/summary proj * mask),
  * :282-284 (merge with the per-utterance summary folded in as C0 = sbar W_s^T + b, SMX_C0_GROUP, div=T). */
@@ -111,12 +120,14 @@ int smx_chunk_mean_bwd(int dtype, const void* dOut, int64_t ldo, void* dS, int64
 /* LayerNorm over the last dim with an optional fused activation: Y = act(LN(X))
  * (torch.nn.LayerNorm; Conformer.py:146,152-153,475-476,738).  stats (N,2) fp32 = (mean, rstd), optional in fwd.
  * bwd: dX = R + LNbwd(dY * act'(LN(X))) (R optional residual-gradient, dtype T; LN(X) is recomputed from the
- * stats); dgamma/dbeta accumulate with fp32 atomics. */
+ * stats); dgamma/dbeta += per-block partial sums (in `workspace`, smx_layernorm_bwd_workspace bytes) reduced in a
+ * fixed order: bit-reproducible, no atomics. */
 int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const float* gamma, const float* beta, void* Y,
                       int64_t ldy, float* stats, int N, int D, float eps, int act, void* stream);
+size_t smx_layernorm_bwd_workspace(int N, int D);
 int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                       const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
-                      int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* stream);
+                      int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* stream);
 
 /* Fused GLU + depthwise Conv1d over time (Conformer.py:131-145,317-325):
  *   u[b,t,c] = P[b,t,c] * sigmoid(P[b,t,D+c]);  Y[b,t,c] = bias[c] + sum_j w[c,j] u[b,t+j-(k-1)/2,c]

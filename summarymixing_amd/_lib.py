@@ -35,6 +35,9 @@ SIGNATURES = {
     "smx_last_error": (ctypes.c_char_p, []),
     "smx_gemm": (c_i, [c_i, c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i,
                        ctypes.POINTER(Epilogue), c_vp]),
+    "smx_linear_wgrad_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
+    "smx_linear_wgrad": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_f,
+                               c_vp, c_vp]),
     "smx_linear_act_mask_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i,
                                       ctypes.POINTER(Epilogue), c_vp]),
     "smx_act_mask_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp,
@@ -46,8 +49,9 @@ SIGNATURES = {
     "smx_chunk_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_chunk_mean_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_layernorm_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
+    "smx_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
     "smx_layernorm_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
-                                c_vp, c_i, c_i, c_vp]),
+                                c_vp, c_i, c_i, c_vp, c_vp]),
     "smx_dwconv1d_glu_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_vp]),
     "smx_dwconv1d_glu_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,

@@ -229,6 +229,209 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwParams p, int tiles_t
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Register-window specialisations for the production shape (compile-time K taps, zero padding, no chunking,
+// no gate, D % 8 == 0): 16-byte global accesses everywhere (a tile row of 64 channels is one 128 B line for bf16),
+// each thread pulls its 16+K-1 input frames from LDS ONCE and does all K x 16 FMAs out of registers.
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct DwVec { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T>
+__device__ __forceinline__ void ld_chunk(const T* p, float (&f)[DwVec<T>::N]) {
+  if constexpr (sizeof(T) == 2) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_bits_to_f32(w[i] & 0xffffu); f[2 * i + 1] = bf16_bits_to_f32(w[i] >> 16); }
+  } else {
+    const float4 r = *reinterpret_cast<const float4*>(p);
+    f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st_chunk(T* p, const float (&f)[DwVec<T>::N]) {
+  if constexpr (sizeof(T) == 2) {
+    uint4 r;
+    r.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16); r.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+    r.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16); r.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = r;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+}
+
+// u tile rows [t0-PAD, t0+TT+PAD) x 64 channels, GLU applied, zero padded in time; 16 B per thread per access
+template <typename T, int ROWS, int PAD>
+__device__ __forceinline__ void fill_u_vec(float (*u)[DW_CT], const DwParams& p, int b, int t0, int c0, int tid) {
+  constexpr int VW = DwVec<T>::N, LPR = DW_CT / VW, NITEM = (ROWS * LPR + 255) / 256;
+  const T* P = reinterpret_cast<const T*>(p.P);
+#pragma unroll
+  for (int k = 0; k < NITEM; ++k) {
+    const int it = tid + 256 * k;
+    if (it < ROWS * LPR) {
+      const int i = it / LPR, cc = (it % LPR) * VW;
+      const int tau = t0 - PAD + i, ch = c0 + cc;
+      float v[VW];
+#pragma unroll
+      for (int q = 0; q < VW; ++q) v[q] = 0.f;
+      if (tau >= 0 && tau < p.T && ch < p.D) {
+        const T* row = P + ((long)b * p.T + tau) * p.ldp;
+        ld_chunk<T>(row + ch, v);
+        if (p.glu) {
+          float gte[VW];
+          ld_chunk<T>(row + p.D + ch, gte);
+#pragma unroll
+          for (int q = 0; q < VW; ++q) v[q] *= sigmoidf_(gte[q]);
+        }
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < VW / 4; ++q4)
+        *reinterpret_cast<float4*>(&u[i][cc + 4 * q4]) = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+    }
+  }
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_fwd_fast(DwParams p) {
+  constexpr int PAD = (K - 1) / 2, WIN = 16 + K - 1, ROWS = DW_TT + K - 1;
+  constexpr int VW = DwVec<T>::N, LPR = DW_CT / VW;
+  __shared__ __attribute__((aligned(16))) float u[ROWS][DW_CT];
+  const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * DW_CT, ch = c0 + cl, t0 = blockIdx.y * DW_TT, b = blockIdx.z;
+  fill_u_vec<T, ROWS, PAD>(u, p, b, t0, c0, threadIdx.x);
+  float w[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = ch < p.D ? p.w[(long)ch * K + j] : 0.f;
+  const float bs = (p.bias && ch < p.D) ? p.bias[ch] : 0.f;
+  __syncthreads();
+  const int f0 = wv * 16;
+  float win[WIN];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) win[i] = u[f0 + i][cl];
+  __syncthreads();                                   // every window is in registers: the tile can be reused
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float acc = bs;
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
+    u[f0 + o][cl] = acc;
+  }
+  __syncthreads();
+  T* Y = reinterpret_cast<T*>(p.Y);
+  for (int it = threadIdx.x; it < DW_TT * LPR; it += 256) {
+    const int r = it / LPR, cc = (it % LPR) * VW;
+    const int t = t0 + r, chv = c0 + cc;
+    if (t < p.T && chv < p.D) {
+      float v[VW];
+#pragma unroll
+      for (int q = 0; q < VW; ++q) v[q] = u[r][cc + q];
+      st_chunk<T>(Y + ((long)b * p.T + t) * p.ldy + chv, v);
+    }
+  }
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t) {
+  constexpr int PAD = (K - 1) / 2, WIN = 16 + K - 1, ROWS = DW_TT + K - 1;
+  constexpr int VW = DwVec<T>::N, LPR = DW_CT / VW, NITEM = (ROWS * LPR + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float u[ROWS][DW_CT];
+  __shared__ __attribute__((aligned(16))) float g[ROWS][DW_CT];
+  __shared__ float red[3][DW_CT];
+  const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * DW_CT, ch = c0 + cl;
+  const bool cok = ch < p.D;
+  float w[K], dw[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { w[j] = cok ? p.w[(long)ch * K + j] : 0.f; dw[j] = 0.f; }
+  float dbs = 0.f;
+  const T* dY = reinterpret_cast<const T*>(p.Y);
+  const T* P = reinterpret_cast<const T*>(p.P);
+  T* dP = reinterpret_cast<T*>(p.dP);
+  const int f0 = wv * 16;
+  const long total = (long)p.B * tiles_t;
+  for (long it0 = blockIdx.y; it0 < total; it0 += gridDim.y) {
+    const int b = (int)(it0 / tiles_t), t0 = (int)(it0 % tiles_t) * DW_TT;
+    __syncthreads();
+    fill_u_vec<T, ROWS, PAD>(u, p, b, t0, c0, threadIdx.x);
+#pragma unroll
+    for (int k = 0; k < NITEM; ++k) {                // dY tile with halo, 16 B per thread
+      const int it = threadIdx.x + 256 * k;
+      if (it < ROWS * LPR) {
+        const int i = it / LPR, cc = (it % LPR) * VW;
+        const int t = t0 - PAD + i, chv = c0 + cc;
+        float v[VW];
+#pragma unroll
+        for (int q = 0; q < VW; ++q) v[q] = 0.f;
+        if (t >= 0 && t < p.T && chv < p.D) ld_chunk<T>(dY + ((long)b * p.T + t) * p.ldy + chv, v);
+#pragma unroll
+        for (int q4 = 0; q4 < VW / 4; ++q4)
+          *reinterpret_cast<float4*>(&g[i][cc + 4 * q4]) = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+      }
+    }
+    __syncthreads();
+    float uw[WIN], gw[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) { uw[i] = u[f0 + i][cl]; gw[i] = g[f0 + i][cl]; }
+    __syncthreads();                                 // windows are in registers: u can take the du tile
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) sacc += gw[PAD + o] * uw[o + j];
+      dw[j] += sacc;
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) dbs += gw[PAD + o];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      float du = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) du += w[j] * gw[o - j + 2 * PAD];
+      u[f0 + o][cl] = du;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < DW_TT * LPR; it += 256) {   // GLU backward, 16 B loads / stores
+      const int r = it / LPR, cc = (it % LPR) * VW;
+      const int t = t0 + r, chv = c0 + cc;
+      if (t < p.T && chv < p.D) {
+        float du[VW];
+#pragma unroll
+        for (int q = 0; q < VW; ++q) du[q] = u[r][cc + q];
+        T* drow = dP + ((long)b * p.T + t) * p.lddp;
+        if (p.glu) {
+          const T* row = P + ((long)b * p.T + t) * p.ldp;
+          float a[VW], gt[VW], d1[VW], d2[VW];
+          ld_chunk<T>(row + chv, a);
+          ld_chunk<T>(row + p.D + chv, gt);
+#pragma unroll
+          for (int q = 0; q < VW; ++q) {
+            const float sg = sigmoidf_(gt[q]);
+            d1[q] = du[q] * sg;
+            d2[q] = du[q] * a[q] * sg * (1.f - sg);
+          }
+          st_chunk<T>(drow + chv, d1);
+          st_chunk<T>(drow + p.D + chv, d2);
+        } else {
+          st_chunk<T>(drow + chv, du);
+        }
+      }
+    }
+  }
+  // flush dw / dbias: 4 waves -> LDS -> one atomic per (channel, tap) per block
+#pragma unroll
+  for (int j = 0; j <= K; ++j) {
+    const float v = j < K ? dw[j < K ? j : 0] : dbs;
+    __syncthreads();
+    if (wv > 0) red[wv - 1][cl] = v;
+    __syncthreads();
+    if (wv == 0 && cok) {
+      const float tot = ((v + red[0][cl]) + red[1][cl]) + red[2][cl];
+      if (j < K) atomicAdd(p.dw + (long)ch * K + j, tot);
+      else if (p.dbias) atomicAdd(p.dbias + ch, tot);
+    }
+  }
+}
+
 }  // namespace smx
 
 using namespace smx;
@@ -246,7 +449,13 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
   p.B = B; p.T = T; p.D = D; p.k = k; p.glu = glu; p.pad_mode = pad_mode; p.chunk = chunk;
   dim3 grid((D + DW_CT - 1) / DW_CT, (T + DW_TT - 1) / DW_TT, B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, p);
+  const int vw = dtype == SMX_BF16 ? 8 : 4;
+  const bool fast = k == 31 && pad_mode == SMX_PAD_ZERO && chunk <= 0 && gate == nullptr && D % vw == 0 &&
+                    ldp % vw == 0 && ldy % vw == 0 && aligned16(P) && aligned16(Y);
+  if (fast) {
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_fast<bf16_t, 31>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((dwconv_fwd_fast<float, 31>), grid, dim3(256), 0, s, p);
+  } else if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((dwconv_fwd_kernel<float>), grid, dim3(256), 0, s, p);
   return check_launch("smx_dwconv1d_glu_fwd");
 }
@@ -272,7 +481,13 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
   if (gy < 1) gy = 1;
   dim3 grid(ctiles, (unsigned)gy);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, p, tiles_t);
+  const int vw = dtype == SMX_BF16 ? 8 : 4;
+  const bool fast = k == 31 && pad_mode == SMX_PAD_ZERO && chunk <= 0 && gate == nullptr && D % vw == 0 &&
+                    ldp % vw == 0 && lddy % vw == 0 && lddp % vw == 0 && aligned16(P) && aligned16(dY) && aligned16(dP);
+  if (fast) {
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_fast<bf16_t, 31>), grid, dim3(256), 0, s, p, tiles_t);
+    else hipLaunchKernelGGL((dwconv_bwd_fast<float, 31>), grid, dim3(256), 0, s, p, tiles_t);
+  } else if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, p, tiles_t);
   else hipLaunchKernelGGL((dwconv_bwd_kernel<float>), grid, dim3(256), 0, s, p, tiles_t);
   return check_launch("smx_dwconv1d_glu_bwd");
 }

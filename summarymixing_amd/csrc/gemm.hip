@@ -21,6 +21,8 @@
 //  * blockIdx is remapped so that the M-tiles that share one A row panel land on the same XCD (same L2).
 //  * TN/wgrad reduces over the (long) frame dimension: split-K over blockIdx.y with fp32 atomics into the
 //    caller-zeroed gradient buffer.
+#include <stdlib.h>
+
 #include "smx_common.h"
 
 namespace smx {
@@ -35,6 +37,10 @@ struct GemmParams {
   int tiles_n, tiles_m;
   smx_epilogue e;
   int epi_vec;
+  int epi_lds;      // outputs are 16-byte addressable: stage the tile through LDS and store whole rows
+  long sSplit;      // element stride between split-K slabs of C (out_mode F32)
+  long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
+  int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
 };
 
 template <typename T> struct ElemTraits;
@@ -43,24 +49,32 @@ template <> struct ElemTraits<float>  { static constexpr int BK = 32; static con
 
 // ---- guarded 16-byte fetch of VPT consecutive elements -------------------------------------------------
 template <typename T, bool VEC>
-__device__ __forceinline__ uint4 ld_contig(const T* p, int nvalid) {
+__device__ __forceinline__ uint4 ld_contig(const T* p, int nvalid, const T* safe) {
   constexpr int VPT = ElemTraits<T>::VPT;
-  if (VEC && nvalid >= VPT) return *reinterpret_cast<const uint4*>(p);
-  uint4 r = make_uint4(0, 0, 0, 0);
-  if (nvalid <= 0) return r;
-  uint32_t w[4] = {0, 0, 0, 0};
-  if constexpr (sizeof(T) == 2) {
-    const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < nvalid) w[i >> 1] |= (uint32_t)q[i] << ((i & 1) * 16);
+  if constexpr (VEC) {
+    // vector mode: the host guarantees whole, aligned vectors, so a lane is either fully in or fully out.
+    // Branch-free: out-of-range lanes read a valid dummy address and are zeroed by a select, so that all the
+    // loads of a tile are issued back to back (an exec-masked branch would cost one s_waitcnt vmcnt(0) each).
+    const bool ok = nvalid >= VPT;
+    uint4 r = *reinterpret_cast<const uint4*>(ok ? p : safe);
+    return ok ? r : make_uint4(0, 0, 0, 0);
   } else {
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (nvalid <= 0) return r;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if constexpr (sizeof(T) == 2) {
+      const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < nvalid) w[i] = q[i];
+      for (int i = 0; i < 8; ++i)
+        if (i < nvalid) w[i >> 1] |= (uint32_t)q[i] << ((i & 1) * 16);
+    } else {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nvalid) w[i] = q[i];
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
   }
-  return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---- stage one operand tile (ROWS x BK) : global -> registers ------------------------------------------
@@ -77,7 +91,7 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[4], const T* base, long 
       int v = t + 256 * i, row = v >> 3, c = v & 7;
       int rg = row0 + row, kg = k0 + c * 8;
       int nv = (rg < rows_total) ? (k1 - kg) : 0;
-      reg[i] = ld_contig<T, VEC>(base + (long)rg * ld + kg, nv);
+      reg[i] = ld_contig<T, VEC>(base + (long)rg * ld + kg, nv, base);
     }
   } else if constexpr (sizeof(T) == 2 && !KC) {
     constexpr int RC = ROWS / 8;           // 16-byte row chunks per k row
@@ -89,7 +103,7 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[4], const T* base, long 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int kg = k0 + kq * 4 + j;
-        reg[j] = ld_contig<T, VEC>(base + (long)kg * ld + rg, kg < k1 ? nv : 0);
+        reg[j] = ld_contig<T, VEC>(base + (long)kg * ld + rg, kg < k1 ? nv : 0, base);
       }
     }
   } else if constexpr (sizeof(T) == 4 && KC) {
@@ -99,7 +113,7 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[4], const T* base, long 
       int v = t + 256 * i, row = v >> 3, k4 = v & 7;
       int rg = row0 + row, kg = k0 + k4 * 4;
       int nv = (rg < rows_total) ? (k1 - kg) : 0;
-      reg[i] = ld_contig<T, VEC>(base + (long)rg * ld + kg, nv);
+      reg[i] = ld_contig<T, VEC>(base + (long)rg * ld + kg, nv, base);
     }
   } else {
     constexpr int NV = ROWS / 32;
@@ -108,7 +122,7 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[4], const T* base, long 
     for (int i = 0; i < NV; ++i) {
       int v = t + 256 * i, r4 = v % R4, k = v / R4;
       int rg = row0 + r4 * 4, kg = k0 + k;
-      reg[i] = ld_contig<T, VEC>(base + (long)kg * ld + rg, kg < k1 ? rows_total - rg : 0);
+      reg[i] = ld_contig<T, VEC>(base + (long)kg * ld + rg, kg < k1 ? rows_total - rg : 0, base);
     }
   }
   (void)BK; (void)VPT;
@@ -193,26 +207,208 @@ __device__ __forceinline__ bf16x8 frag_bf16(const char* lds, int r, int kk, int 
   }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (its workgroup fence), which
+// would stall on the in-flight global prefetch of the next K tile / on the epilogue's global stores.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// activation of one accumulator quad: ONE uniform switch per 4 values (never per element)
+__device__ __forceinline__ void act4(int act, float (&y)[4]) {
+  switch (act) {
+    case SMX_ACT_GELU:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[q] = act_fwd_c<SMX_ACT_GELU>(y[q]);
+      break;
+    case SMX_ACT_SWISH:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[q] = act_fwd_c<SMX_ACT_SWISH>(y[q]);
+      break;
+    case SMX_ACT_LEAKY_RELU:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[q] = act_fwd_c<SMX_ACT_LEAKY_RELU>(y[q]);
+      break;
+    case SMX_ACT_RELU:
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[q] = act_fwd_c<SMX_ACT_RELU>(y[q]);
+      break;
+    default: break;
+  }
+}
+
 __device__ __forceinline__ long c0_row(const smx_epilogue& e, int n) {
   if (e.c0_mode == SMX_C0_GROUP) return n / e.c0_div;
   if (e.c0_mode == SMX_C0_MOD) return n % e.c0_div;
   return n;
 }
 
+// ---- one epilogue phase: WN staged fp32 rows (LDS) -> outputs.  vmcnt retires in order and counts stores too, so
+// every side input of the thread's items (bias once, C0 / residual / mask per item) is requested BEFORE the first
+// store; the stores then stream out without any wave ever waiting on them. ------------------------------------------
+template <typename T, int OSZ, int TILE_N, int TILE_M>
+__device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, int nbase, int m0, int bz, int split,
+                                               int t) {
+  constexpr int WN = TILE_N / 2;
+  constexpr int STG_LD = TILE_M * 4 + 16;
+  constexpr int CW = 16 / OSZ;                          // output columns per item (16 bytes)
+  constexpr int CPR = TILE_M / CW;                      // items per row
+  constexpr int RSTEP = 256 / CPR;                      // rows covered per pass of the 256 threads
+  constexpr int NIT = WN / RSTEP;                       // items per thread
+  const smx_epilogue& e = p.e;
+  const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
+  if (m >= p.M) return;
+  const int nv = min(CW, p.M - m);
+  const bool vec = p.epi_lds != 0 && nv == CW;
+  const float* bias = e.bias ? e.bias + (long)bz * e.bias_batch_stride : nullptr;
+  char* Cb = reinterpret_cast<char*>(p.C) + ((long)bz * p.sC + (long)split * p.sSplit) * OSZ;
+  T* Zb = e.z ? reinterpret_cast<T*>(e.z) + (long)bz * p.sC : nullptr;
+  const T* Rb = e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr;
+  // ---- loads ----
+  float bv[CW];
+#pragma unroll
+  for (int q = 0; q < CW; ++q) bv[q] = 0.f;
+  if (bias) {
+    if (vec) {
+#pragma unroll
+      for (int q4 = 0; q4 < CW / 4; ++q4) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + m + 4 * q4);
+        bv[4 * q4] = b4.x; bv[4 * q4 + 1] = b4.y; bv[4 * q4 + 2] = b4.z; bv[4 * q4 + 3] = b4.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CW; ++q) if (q < nv) bv[q] = bias[m + q];
+    }
+  }
+  float cv[NIT][CW], rv[NIT][CW], mk[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int n = nbase + r0 + k * RSTEP;
+    const bool nok = n < p.N;
+    mk[k] = ((e.row_mask && nok) ? (e.row_mask[n] ? 1.f : 0.f) : 1.f) * e.alpha;
+#pragma unroll
+    for (int q = 0; q < CW; ++q) { cv[k][q] = 0.f; rv[k][q] = 0.f; }
+    if (e.c0_mode != SMX_C0_NONE && nok) {
+      const float* c0p = e.c0 + c0_row(e, n) * e.ldc0 + m;
+      if (vec) {
+#pragma unroll
+        for (int q4 = 0; q4 < CW / 4; ++q4) {
+          const float4 c4 = *reinterpret_cast<const float4*>(c0p + 4 * q4);
+          cv[k][4 * q4] = c4.x; cv[k][4 * q4 + 1] = c4.y; cv[k][4 * q4 + 2] = c4.z; cv[k][4 * q4 + 3] = c4.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < CW; ++q) if (q < nv) cv[k][q] = c0p[q];
+      }
+    }
+    if (Rb && nok) {
+      const T* rp = Rb + (long)n * e.ldr + m;
+      if (vec) {
+        if constexpr (sizeof(T) == 2 && CW == 8) {
+          const uint4 u = *reinterpret_cast<const uint4*>(rp);
+          const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { rv[k][2 * q] = bf16_bits_to_f32(w4[q] & 0xffffu); rv[k][2 * q + 1] = bf16_bits_to_f32(w4[q] >> 16); }
+        } else {
+          load4<T>(rp, reinterpret_cast<float(&)[4]>(rv[k]));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < CW; ++q) if (q < nv) rv[k][q] = to_f32(rp[q]);
+      }
+    }
+  }
+  // ---- math + stores ----
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int r = r0 + k * RSTEP, n = nbase + r;
+    if (n >= p.N) continue;
+    float v[CW];
+#pragma unroll
+    for (int q4 = 0; q4 < CW / 4; ++q4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
+      v[4 * q4] = a4.x + bv[4 * q4] + cv[k][4 * q4]; v[4 * q4 + 1] = a4.y + bv[4 * q4 + 1] + cv[k][4 * q4 + 1];
+      v[4 * q4 + 2] = a4.z + bv[4 * q4 + 2] + cv[k][4 * q4 + 2]; v[4 * q4 + 3] = a4.w + bv[4 * q4 + 3] + cv[k][4 * q4 + 3];
+    }
+    if (Zb) {
+      T* zp = Zb + (long)n * e.ldz + m;
+      if (vec) {
+        if constexpr (sizeof(T) == 2 && CW == 8) {
+          uint4 u;
+          u.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16); u.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+          u.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16); u.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+          *reinterpret_cast<uint4*>(zp) = u;
+        } else {
+          store4<T>(zp, reinterpret_cast<const float(&)[4]>(v));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < CW; ++q) if (q < nv) zp[q] = from_f32<T>(v[q]);
+      }
+    }
+    switch (e.act) {
+      case SMX_ACT_GELU:
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<SMX_ACT_GELU>(v[q]);
+        break;
+      case SMX_ACT_SWISH:
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<SMX_ACT_SWISH>(v[q]);
+        break;
+      case SMX_ACT_LEAKY_RELU:
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<SMX_ACT_LEAKY_RELU>(v[q]);
+        break;
+      case SMX_ACT_RELU:
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<SMX_ACT_RELU>(v[q]);
+        break;
+      default: break;
+    }
+#pragma unroll
+    for (int q = 0; q < CW; ++q) v[q] = v[q] * mk[k] + rv[k][q];
+    char* dst = Cb + ((long)n * p.ldc + m) * OSZ;
+    if (vec) {
+      if constexpr (OSZ == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint4 u;
+        u.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16); u.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+        u.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16); u.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+        *reinterpret_cast<uint4*>(dst) = u;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CW; ++q) {
+        if (q < nv) {
+          if constexpr (OSZ == 4) reinterpret_cast<float*>(dst)[q] = v[q];
+          else reinterpret_cast<uint16_t*>(dst)[q] = (uint16_t)f32_to_bf16_bits(v[q]);
+        }
+      }
+    }
+  }
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------------
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
   constexpr int A_BYTES = lds_bytes<T, TILE_N>();
   constexpr int B_BYTES = lds_bytes<T, TILE_M>();
-  __shared__ __attribute__((aligned(16))) char smem[A_BYTES + B_BYTES];
+  constexpr int EPI_BYTES = (TILE_N / 2) * (TILE_M * 4 + 16);   // one half-tile of fp32 rows, 16 B row pad
+  constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > EPI_BYTES ? (A_BYTES + B_BYTES) : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   char* As = smem;
   char* Bs = smem + A_BYTES;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wn = wave >> 1, wm = wave & 1;
+  long long* dbgp = p.dbg ? p.dbg + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 : nullptr;
+#define SMX_STAMP(k) do { if (dbgp && lane == 0) dbgp[k] = clock64(); } while (0)
+  SMX_STAMP(0);
   const int l31 = lane & 31, hi = lane >> 5;
 
   // XCD-aware tile mapping: consecutive remapped ids walk the M tiles of one row panel
@@ -239,147 +435,128 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  uint4 ra[4], rb[4];
-  if (kbeg < kend) {
-    stage_load<T, A_KC, TILE_N, VEC>(ra, A, p.lda, n0, p.N, kbeg, kend, t);
-    stage_load<T, B_KC, TILE_M, VEC>(rb, B, p.ldb, m0, p.M, kbeg, kend, t);
+  // NS register stages of BK reduce-elements each are in flight (issue-early / write-late): for the K = 256..512
+  // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
+  // about one HBM/L2 round trip for its whole main loop instead of one per K tile (measured: 2.9 K cycles per
+  // K tile with a single stage, the MFMAs themselves need ~0.5 K).
+  constexpr int NS = 2;
+  uint4 ra[NS][4], rb[NS][4];
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[s_][i] = rb[s_][i] = make_uint4(0, 0, 0, 0);
+  const bool ab_nold = p.ablate & 4, ab_nomfma = p.ablate & 2, ab_nost = p.ablate & 1;
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_) {
+    const int kk = kbeg + s_ * BK;
+    if (kk < kend && !ab_nold) {
+      stage_load<T, A_KC, TILE_N, VEC>(ra[s_], A, p.lda, n0, p.N, kk, kend, t);
+      stage_load<T, B_KC, TILE_M, VEC>(rb[s_], B, p.ldb, m0, p.M, kk, kend, t);
+    }
   }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    stage_store<T, A_KC, TILE_N>(ra, As, t);
-    stage_store<T, B_KC, TILE_M>(rb, Bs, t);
-    __syncthreads();
-    if (k0 + BK < kend) {
-      stage_load<T, A_KC, TILE_N, VEC>(ra, A, p.lda, n0, p.N, k0 + BK, kend, t);
-      stage_load<T, B_KC, TILE_M, VEC>(rb, B, p.ldb, m0, p.M, k0 + BK, kend, t);
-    }
-    if constexpr (sizeof(T) == 2) {
+  SMX_STAMP(1);
+  for (int kb = kbeg; kb < kend; kb += NS * BK) {
 #pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
-        bf16x8 fa[FN], fb[FM];
-#pragma unroll
-        for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<A_KC, TILE_N>(As, wn * WN + i * 32 + l31, kk, hi);
-#pragma unroll
-        for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<B_KC, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-          for (int j = 0; j < FM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int k0 = kb + s_ * BK;
+      if (k0 >= kend) break;
+      stage_store<T, A_KC, TILE_N>(ra[s_], As, t);
+      stage_store<T, B_KC, TILE_M>(rb[s_], Bs, t);
+      lds_barrier();
+      if (k0 + NS * BK < kend && !ab_nold) {
+        stage_load<T, A_KC, TILE_N, VEC>(ra[s_], A, p.lda, n0, p.N, k0 + NS * BK, kend, t);
+        stage_load<T, B_KC, TILE_M, VEC>(rb[s_], B, p.ldb, m0, p.M, k0 + NS * BK, kend, t);
       }
-    } else {
-      const float* Af = reinterpret_cast<const float*>(As);
-      const float* Bf = reinterpret_cast<const float*>(Bs);
+      if (ab_nomfma) {
+      } else if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          bf16x8 fa[FN], fb[FM];
+#pragma unroll
+          for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<A_KC, TILE_N>(As, wn * WN + i * 32 + l31, kk, hi);
+#pragma unroll
+          for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<B_KC, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+      } else {
+        const float* Af = reinterpret_cast<const float*>(As);
+        const float* Bf = reinterpret_cast<const float*>(Bs);
 #pragma unroll 4
-      for (int s = 0; s < BK / 2; ++s) {
-        int k = 2 * s + hi;
-        float fa[FN], fb[FM];
+        for (int s2 = 0; s2 < BK / 2; ++s2) {
+          int k = 2 * s2 + hi;
+          float fa[FN], fb[FM];
 #pragma unroll
-        for (int i = 0; i < FN; ++i) fa[i] = Af[k * (TILE_N + 4) + wn * WN + i * 32 + l31];
+          for (int i = 0; i < FN; ++i) fa[i] = Af[k * (TILE_N + 4) + wn * WN + i * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < FM; ++j) fb[j] = Bf[k * (TILE_M + 4) + wm * WM + j * 32 + l31];
+          for (int j = 0; j < FM; ++j) fb[j] = Bf[k * (TILE_M + 4) + wm * WM + j * 32 + l31];
 #pragma unroll
-        for (int i = 0; i < FN; ++i)
+          for (int i = 0; i < FN; ++i)
 #pragma unroll
-          for (int j = 0; j < FM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
       }
+      lds_barrier();
     }
-    __syncthreads();
   }
 
-  // ---- epilogue: lane owns output row n, columns m .. m+3 for each accumulator quad g ------------------------
+  // ---- epilogue -------------------------------------------------------------------------------------------------
+  if (ab_nost) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += acc[i][j][q];
+    if (s == 123.456f) reinterpret_cast<float*>(p.C)[0] = s;
+    return;
+  }
+  SMX_STAMP(2);
   const smx_epilogue& e = p.e;
-  const float* bias = e.bias ? e.bias + (long)bz * e.bias_batch_stride : nullptr;
+  if (e.out_mode == SMX_OUT_ATOMIC_F32) {
 #pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    const int n = n0 + wn * WN + i * 32 + l31;
-    if (n >= p.N) continue;
-    float mk = 1.f;
-    if (e.row_mask) mk = e.row_mask[n] ? 1.f : 0.f;
-    const long c0r = (e.c0_mode != SMX_C0_NONE) ? c0_row(e, n) : 0;
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0 + wn * WN + i * 32 + l31;
 #pragma unroll
-    for (int j = 0; j < FM; ++j) {
+      for (int j = 0; j < FM; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int m = m0 + wm * WM + j * 32 + g * 8 + hi * 4;
-        if (m >= p.M) continue;
-        float v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
-        if (e.out_mode == SMX_OUT_ATOMIC_F32) {
+        for (int g = 0; g < 4; ++g) {
+          const int m = m0 + wm * WM + j * 32 + g * 8 + hi * 4;
           float* Cf = reinterpret_cast<float*>(p.C) + (long)bz * p.sC + (long)n * p.ldc + m;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (m + q < p.M) atomicAdd(Cf + q, e.alpha * v[q]);
-          continue;
+            if (n < p.N && m + q < p.M) atomicAdd(Cf + q, e.alpha * acc[i][j][g * 4 + q]);
         }
-        const bool full = p.epi_vec && (m + 3 < p.M);
-        if (bias) {
-          if (full) {
-            float4 b4 = *reinterpret_cast<const float4*>(bias + m);
-            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (m + q < p.M) v[q] += bias[m + q];
-          }
-        }
-        if (e.c0_mode != SMX_C0_NONE) {
-          const float* c0p = e.c0 + c0r * e.ldc0 + m;
-          if (full) {
-            float4 c4 = *reinterpret_cast<const float4*>(c0p);
-            v[0] += c4.x; v[1] += c4.y; v[2] += c4.z; v[3] += c4.w;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (m + q < p.M) v[q] += c0p[q];
-          }
-        }
-        if (e.z) {
-          T* zp = reinterpret_cast<T*>(e.z) + (long)bz * p.sC + (long)n * e.ldz + m;
-          if (full) store4<T>(zp, v);
-          else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (m + q < p.M) zp[q] = from_f32<T>(v[q]);
-          }
-        }
-        float y[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = e.alpha * (act_fwd(e.act, v[q]) * mk);
-        if (e.res) {
-          const T* rp = reinterpret_cast<const T*>(e.res) + (long)bz * p.sC + (long)n * e.ldr + m;
-          if (full) {
-            float r4[4];
-            load4<T>(rp, r4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) y[q] += r4[q];
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (m + q < p.M) y[q] += to_f32(rp[q]);
-          }
-        }
-        if (e.out_mode == SMX_OUT_F32) {
-          float* cp = reinterpret_cast<float*>(p.C) + (long)bz * p.sC + (long)n * p.ldc + m;
-          if (full) *reinterpret_cast<float4*>(cp) = make_float4(y[0], y[1], y[2], y[3]);
-          else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (m + q < p.M) cp[q] = y[q];
-          }
-        } else {
-          T* cp = reinterpret_cast<T*>(p.C) + (long)bz * p.sC + (long)n * p.ldc + m;
-          if (full) store4<T>(cp, y);
-          else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (m + q < p.M) cp[q] = from_f32<T>(y[q]);
-          }
-        }
-      }
     }
+    return;
   }
+  constexpr int STG_LD = TILE_M * 4 + 16;               // bytes per staged fp32 row (16 B pad: conflict-free b128)
+  const int osz = (e.out_mode == SMX_OUT_T) ? (int)sizeof(T) : 4;
+  for (int ph = 0; ph < 2; ++ph) {
+    lds_barrier();
+    if (wn == ph) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(smem + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+    }
+    lds_barrier();
+    SMX_STAMP(3 + 2 * ph);
+    if (sizeof(T) == 2 && osz == 2) epilogue_phase<T, 2, TILE_N, TILE_M>(p, smem, n0 + ph * WN, m0, bz, split, t);
+    else epilogue_phase<T, 4, TILE_N, TILE_M>(p, smem, n0 + ph * WN, m0, bz, split, t);
+    SMX_STAMP(4 + 2 * ph);
+  }
+  SMX_STAMP(7);
+#undef SMX_STAMP
 }
 
 // ---- host dispatch ------------------------------------------------------------------------------------------
@@ -397,7 +574,7 @@ template <typename T, bool A_KC, bool B_KC>
 static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // big tiles once they alone fill the chip (256 CUs x 2 resident blocks); otherwise 64x64 for more blocks
   long big = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch * p.splits;
-  if (big >= 384) return launch_tile<T, A_KC, B_KC, 128, 128>(p, vec, s);
+  if (big >= 256 && p.N >= 128 && p.M >= 128) return launch_tile<T, A_KC, B_KC, 128, 128>(p, vec, s);
   return launch_tile<T, A_KC, B_KC, 64, 64>(p, vec, s);
 }
 
@@ -415,9 +592,12 @@ static int launch_dtype(int layout, GemmParams& p, bool vec, hipStream_t s) {
 
 using namespace smx;
 
-extern "C" int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,
-                        int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K,
-                        int batch, int splits, const smx_epilogue* epi, void* stream) {
+static long long* g_dbg_stamps = nullptr;
+extern "C" void smx_debug_set_timing_buffer(void* p) { g_dbg_stamps = reinterpret_cast<long long*>(p); }
+
+static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,
+                     int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K,
+                     int batch, int splits, int64_t split_stride, const smx_epilogue* epi, void* stream) {
   SMX_REQUIRE(A && B && C, "smx_gemm: null operand");
   SMX_REQUIRE(N >= 0 && M >= 0 && K >= 0 && batch >= 1 && splits >= 1, "smx_gemm: bad sizes N=%d M=%d K=%d", N, M, K);
   SMX_REQUIRE(dtype == SMX_F32 || dtype == SMX_BF16, "smx_gemm: bad dtype %d", dtype);
@@ -430,7 +610,8 @@ extern "C" int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64
   else p.e.alpha = 1.f;
   const int BK = dtype == SMX_BF16 ? 64 : 32;
   if (splits > 1) {
-    SMX_REQUIRE(p.e.out_mode == SMX_OUT_ATOMIC_F32, "smx_gemm: splits>1 needs SMX_OUT_ATOMIC_F32");
+    SMX_REQUIRE(p.e.out_mode == SMX_OUT_ATOMIC_F32 || (p.e.out_mode == SMX_OUT_F32 && split_stride > 0),
+                "smx_gemm: splits>1 needs SMX_OUT_ATOMIC_F32, or SMX_OUT_F32 slabs (smx_linear_wgrad)");
     int kc = (K + splits - 1) / splits;
     kc = ((kc + BK - 1) / BK) * BK;
     p.kchunk = kc;
@@ -459,9 +640,103 @@ extern "C" int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64
   size_t cs = p.e.out_mode == SMX_OUT_T ? es : 4;
   p.epi_vec = ok4(C, ldc, cs) && ok4(p.e.z, p.e.ldz, es) && ok4(p.e.res, p.e.ldr, es) && ok4(p.e.bias, 4, 4) &&
               ok4(p.e.c0, p.e.ldc0, 4) && (strideC % 4 == 0) && (p.e.bias_batch_stride % 4 == 0);
+  {
+    // LDS-staged coalesced stores need 16-byte addressable output rows
+    auto ok16 = [&](const void* ptr, int64_t ld, int64_t bs, size_t esz) {
+      return ptr == nullptr || (aligned16(ptr) && (ld * (int64_t)esz) % 16 == 0 && (bs * (int64_t)esz) % 16 == 0);
+    };
+    p.epi_lds = p.e.out_mode != SMX_OUT_ATOMIC_F32 && ok16(C, ldc, strideC, cs) && ok16(p.e.z, p.e.ldz, strideC, es) &&
+                ok16(p.e.res, p.e.ldr, strideC, es) && ok16(p.e.bias, 4, p.e.bias_batch_stride, 4) &&
+                ok16(p.e.c0, p.e.ldc0, 0, 4) && (split_stride * (int64_t)cs) % 16 == 0 && M % 4 == 0;
+    p.sSplit = split_stride;
+  }
+  static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
+  p.ablate = ablate;
+  p.dbg = g_dbg_stamps;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SMX_BF16) return launch_dtype<bf16_t>(layout, p, vec, s);
   return launch_dtype<float>(layout, p, vec, s);
+}
+
+extern "C" int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,
+                        int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K,
+                        int batch, int splits, const smx_epilogue* epi, void* stream) {
+  return gemm_impl(layout, dtype, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, N, M, K, batch, splits, 0, epi,
+                   stream);
+}
+
+// ---- weight gradient: dW[b] (M x K) += alpha * dZ[b]^T X[b], reduce over `rows` frames ------------------------
+// split-K over the frame dimension into fp32 slabs (plain coalesced stores), then ONE fixed-order reduction
+// kernel adds the slabs into the gradient buffer: bit-reproducible, no atomics.
+namespace smx {
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, int nslab, long slab_stride, float* dst,
+                                                           long lddst, long sdst, int M, int K, int batch, float alpha) {
+  const int kv = K / 4;
+  const long total = (long)batch * M * kv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k4 = (int)(i % kv);
+    const long r = i / kv;
+    const int m = (int)(r % M), b = (int)(r / M);
+    const float* sp = slabs + ((long)b * M + m) * K + k4 * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nslab; ++s) {
+      float4 v = *reinterpret_cast<const float4*>(sp + s * slab_stride);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float* d = dst + (long)b * sdst + (long)m * lddst + k4 * 4;
+    d[0] += alpha * a.x; d[1] += alpha * a.y; d[2] += alpha * a.z; d[3] += alpha * a.w;
+  }
+}
+static int wgrad_splits(int rows, int M, int K, int batch) {
+  long tiles = (long)((M + 127) / 128) * ((K + 127) / 128) * batch;
+  long s = (640 + tiles - 1) / tiles;
+  long smax = (rows + 255) / 256;
+  if (s > smax) s = smax;
+  return (int)(s < 1 ? 1 : s);
+}
+}  // namespace smx
+
+static int effective_splits(int K, int splits, int BK) {
+  if (splits <= 1) return 1;
+  int kc = (K + splits - 1) / splits;
+  kc = ((kc + BK - 1) / BK) * BK;
+  int s = (K + kc - 1) / kc;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" size_t smx_linear_wgrad_workspace(int rows, int M, int K, int batch) {
+  return (size_t)wgrad_splits(rows, M, K, batch) * batch * M * K * sizeof(float) + 16;
+}
+
+extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,
+                                int64_t strideX, float* dW, int64_t lddw, int64_t strideW, int rows, int M, int K,
+                                int batch, float alpha, void* workspace, void* stream) {
+  SMX_REQUIRE(dZ && X && dW, "smx_linear_wgrad: null pointer");
+  if (M <= 0 || K <= 0 || rows <= 0) return SMX_OK;
+  smx_epilogue e;
+  memset(&e, 0, sizeof(e));
+  const int BK = dtype == SMX_BF16 ? 64 : 32;
+  const int splits = effective_splits(rows, wgrad_splits(rows, M, K, batch), BK);
+  if (K % 4 != 0 || workspace == nullptr || !aligned16(workspace)) {
+    // ragged shapes: fp32 atomics straight into the gradient (not bit-reproducible)
+    e.alpha = alpha;
+    e.out_mode = SMX_OUT_ATOMIC_F32;
+    return gemm_impl(SMX_GEMM_TN, dtype, dZ, lddz, strideZ, X, ldx, strideX, dW, lddw, strideW, M, K, rows, batch, splits,
+                     0, &e, stream);
+  }
+  e.alpha = 1.f;
+  e.out_mode = SMX_OUT_F32;
+  float* ws = reinterpret_cast<float*>(workspace);
+  const long slab = (long)batch * M * K;
+  int rc = gemm_impl(SMX_GEMM_TN, dtype, dZ, lddz, strideZ, X, ldx, strideX, ws, K, (int64_t)M * K, M, K, rows, batch,
+                     splits, slab, &e, stream);
+  if (rc != SMX_OK) return rc;
+  long total = (long)batch * M * (K / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws,
+                     splits, slab, dW, lddw, strideW, M, K, batch, alpha);
+  return check_launch("smx_linear_wgrad");
 }
 
 extern "C" int smx_linear_act_mask_fwd(int dtype, const void* X, int64_t ldx, const void* W, int64_t ldw, void* Y,

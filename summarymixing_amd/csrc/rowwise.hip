@@ -15,7 +15,8 @@ template <> struct VT<bf16_t> { static constexpr int N = 8; };
 template <typename T, bool VEC>
 __device__ __forceinline__ void loadv(const T* p, int nvalid, float (&f)[VT<T>::N]) {
   constexpr int N = VT<T>::N;
-  if (VEC && nvalid >= N) {
+  if constexpr (VEC) {
+    // whole aligned vectors only (host-checked): callers never issue this for an out-of-range column block
     if constexpr (sizeof(T) == 2) {
       uint4 r = *reinterpret_cast<const uint4*>(p);
       const uint32_t w[4] = {r.x, r.y, r.z, r.w};
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void masked_sum_stage1(const T* S, long lds, c
   float acc[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) acc[i] = 0.f;
-  const T* base = S + ((long)b * T_) * lds + col;
+  const T* base = S + ((long)b * T_) * lds + (nvalid > 0 ? col : 0);   // idle lanes re-read column 0 (discarded)
   const uint8_t* mrow = mask ? mask + (long)b * T_ : nullptr;
   int t = t0 + w;
   for (; t + 12 < t1; t += 16) {          // 4 independent 16-byte loads in flight per lane
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const T* X, long ldx, fl
   for (int i = 0; i < N; ++i) acc[i] = 0.f;
   for (int t = t0 + w; t < t1; t += 4) {
     float f[N];
-    loadv<T, VEC>(X + ((long)b * T_ + t) * ldx + col, nvalid, f);
+    loadv<T, VEC>(X + ((long)b * T_ + t) * ldx + (nvalid > 0 ? col : 0), nvalid, f);
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] += f[i];
   }
@@ -270,7 +271,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* X, long ldx
       float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
       float o[4] = {(f[0] - mean) * rstd * g4.x + b4.x, (f[1] - mean) * rstd * g4.y + b4.y,
                     (f[2] - mean) * rstd * g4.z + b4.z, (f[3] - mean) * rstd * g4.w + b4.w};
-      if (act != SMX_ACT_NONE) {
+      if (act == SMX_ACT_SWISH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = act_fwd_c<SMX_ACT_SWISH>(o[i]);
+      } else if (act == SMX_ACT_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = act_fwd_c<SMX_ACT_GELU>(o[i]);
+      } else if (act != SMX_ACT_NONE) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = act_fwd(act, o[i]);
       }
@@ -281,67 +288,98 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* X, long ldx
   }
 }
 
-// bwd: dx = R + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma.  Blocks stride over rows and keep
-// their dgamma/dbeta partial sums in registers (columns lane*VW + 64*VW*i, i < CH), one atomic flush at the end.
-template <typename T, int VW, int CH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dY, long lddy, const T* X, long ldx,
-                                                            const float* gamma, const float* beta, int act,
-                                                            const float* stats, const T* R, long ldr,
-                                                            T* dX, long lddx, float* dgamma, float* dbeta, int N_, int D) {
+// bwd: dx = R + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*act'(LN(x))*gamma.  Blocks stride over rows;
+// gamma/beta of the lane's columns live in registers for the whole kernel, U rows are in flight per wave (all
+// their loads issued before any reduction), dgamma/dbeta partial sums stay in registers until one atomic flush.
+template <typename T, int VW, int CH, int U>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ X,
+                                                            long ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int act,
+                                                            const float* __restrict__ stats, const T* __restrict__ R,
+                                                            long ldr, T* __restrict__ dX, long lddx,
+                                                            float* __restrict__ partial, int N_, int D) {
   __shared__ float red[3][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float dg[CH][VW], db[CH][VW];
+  float gam[CH][VW], bet[CH][VW], dg[CH][VW], db[CH][VW];
 #pragma unroll
   for (int i = 0; i < CH; ++i)
 #pragma unroll
-    for (int j = 0; j < VW; ++j) dg[i][j] = db[i][j] = 0.f;
-  for (int row = blockIdx.x * 4 + w; row < N_; row += gridDim.x * 4) {
-    const T* dy = dY + (long)row * lddy;
-    const T* x = X + (long)row * ldx;
-    const float mean = stats[2 * (long)row], rstd = stats[2 * (long)row + 1];
-    float gv[CH][VW], xh[CH][VW];
-    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < VW; ++j) {
+      const int c = (lane + 64 * i) * VW + j;
+      gam[i][j] = c < D ? gamma[c] : 0.f;
+      bet[i][j] = (c < D && act != SMX_ACT_NONE) ? beta[c] : 0.f;
+      dg[i][j] = db[i][j] = 0.f;
+    }
+  dispatch_act(act, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    for (int row0 = (blockIdx.x * 4 + w) * U; row0 < N_; row0 += gridDim.x * 4 * U) {
+      float fdy[U][CH][VW], fx[U][CH][VW], mean[U], rstd[U];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int c = (lane + 64 * i) * VW;
-      if (c < D) {
-        float fdy[VW], fx[VW];
-        if constexpr (VW == 4) { load4<T>(dy + c, fdy); load4<T>(x + c, fx); }
-        else { fdy[0] = to_f32(dy[c]); fx[0] = to_f32(x[c]); }
+      for (int u = 0; u < U; ++u) {
+        const int row = min(row0 + u, N_ - 1);           // tail rows re-read the last row (results discarded)
+        mean[u] = stats[2 * (long)row];
+        rstd[u] = stats[2 * (long)row + 1];
 #pragma unroll
-        for (int j = 0; j < VW; ++j) {
-          float xhat = (fx[j] - mean) * rstd;
-          float dyn = fdy[j];
-          if (act != SMX_ACT_NONE) dyn *= act_grad(act, xhat * gamma[c + j] + beta[c + j]);
-          float g = dyn * gamma[c + j];
-          xh[i][j] = xhat; gv[i][j] = g;
-          s1 += g; s2 += g * xhat;
-          dg[i][j] += dyn * xhat; db[i][j] += dyn;
+        for (int i = 0; i < CH; ++i) {
+          const int c = (lane + 64 * i) * VW;
+          const int cc = c < D ? c : 0;                  // idle lanes re-read column 0
+          if constexpr (VW == 4) { load4<T>(dY + (long)row * lddy + cc, fdy[u][i]); load4<T>(X + (long)row * ldx + cc, fx[u][i]); }
+          else { fdy[u][i][0] = to_f32(dY[(long)row * lddy + cc]); fx[u][i][0] = to_f32(X[(long)row * ldx + cc]); }
         }
-      } else {
+      }
+      float s1[U], s2[U];
 #pragma unroll
-        for (int j = 0; j < VW; ++j) { xh[i][j] = 0.f; gv[i][j] = 0.f; }
+      for (int u = 0; u < U; ++u) {
+        const bool rok = row0 + u < N_;
+        s1[u] = s2[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const bool cok = (lane + 64 * i) * VW < D;
+#pragma unroll
+          for (int j = 0; j < VW; ++j) {
+            const float xhat = (fx[u][i][j] - mean[u]) * rstd[u];
+            float dyn = (cok && rok) ? fdy[u][i][j] : 0.f;
+            if constexpr (ACT != SMX_ACT_NONE) dyn *= act_grad_c<ACT>(xhat * gam[i][j] + bet[i][j]);
+            const float g = dyn * gam[i][j];
+            fx[u][i][j] = xhat;          // reuse registers: fx <- xhat, fdy <- g
+            fdy[u][i][j] = g;
+            s1[u] += g;
+            s2[u] += g * xhat;
+            dg[i][j] += dyn * xhat;
+            db[i][j] += dyn;
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s1[u] += __shfl_xor(s1[u], off, 64); s2[u] += __shfl_xor(s2[u], off, 64); }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + u;
+        if (row >= N_) continue;
+        const float m1 = s1[u] / (float)D, m2 = s2[u] / (float)D;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int c = (lane + 64 * i) * VW;
+          if (c < D) {
+            float o[VW];
+#pragma unroll
+            for (int j = 0; j < VW; ++j) o[j] = rstd[u] * (fdy[u][i][j] - m1 - fx[u][i][j] * m2);
+            if (R) {
+              if constexpr (VW == 4) { float r[4]; load4<T>(R + (long)row * ldr + c, r); for (int j = 0; j < 4; ++j) o[j] += r[j]; }
+              else o[0] += to_f32(R[(long)row * ldr + c]);
+            }
+            if constexpr (VW == 4) store4<T>(dX + (long)row * lddx + c, o);
+            else dX[(long)row * lddx + c] = from_f32<T>(o[0]);
+          }
+        }
       }
     }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int c = (lane + 64 * i) * VW;
-      if (c < D) {
-        float o[VW];
-#pragma unroll
-        for (int j = 0; j < VW; ++j) o[j] = rstd * (gv[i][j] - s1 - xh[i][j] * s2);
-        if (R) {
-          if constexpr (VW == 4) { float r[4]; load4<T>(R + (long)row * ldr + c, r); for (int j = 0; j < 4; ++j) o[j] += r[j]; }
-          else o[0] += to_f32(R[(long)row * ldr + c]);
-        }
-        if constexpr (VW == 4) store4<T>(dX + (long)row * lddx + c, o);
-        else dX[(long)row * lddx + c] = from_f32<T>(o[0]);
-      }
-    }
-  }
-  // flush dgamma / dbeta: reduce the 4 waves through LDS, one atomic per column per block
+  });
+  // flush dgamma / dbeta: reduce the 4 waves through LDS and write ONE partial row per block (no atomics: with a
+  // few thousand blocks adding into the same D addresses the L2 atomic unit serialised, 200 us per call).
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -355,9 +393,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dY, long ld
         if (w == 0) {
           v = ((v + red[0][lane]) + red[1][lane]) + red[2][lane];
           const int c = (lane + 64 * i) * VW + j;
-          if (c < D) atomicAdd((pass == 0 ? dgamma : dbeta) + c, v);
+          if (c < D) partial[((long)blockIdx.x * 2 + pass) * D + c] = v;
         }
       }
+  }
+}
+
+// dgamma[c] += sum_b partial[b][0][c]; dbeta[c] += sum_b partial[b][1][c]   (fixed order => bit-reproducible)
+// block = 32 columns x 8 row groups; every thread sums nblocks/8 partial rows with 4 independent accumulators.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                              float* dgamma, float* dbeta) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;                 // index into the concatenated [dgamma | dbeta] row of 2*D
+  const bool ok = c < 2 * D;
+  const int pass = ok ? c / D : 0, col = ok ? c % D : 0;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = ry;
+  for (; b + 24 < nblocks; b += 32) {
+    s0 += partial[((long)b * 2 + pass) * D + col];
+    s1 += partial[((long)(b + 8) * 2 + pass) * D + col];
+    s2 += partial[((long)(b + 16) * 2 + pass) * D + col];
+    s3 += partial[((long)(b + 24) * 2 + pass) * D + col];
+  }
+  for (; b < nblocks; b += 8) s0 += partial[((long)b * 2 + pass) * D + col];
+  red[ry][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ry == 0 && ok) {
+    float tot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) tot += red[r][cx];
+    float* dst = pass == 0 ? dgamma : dbeta;
+    dst[col] += tot;
   }
 }
 
@@ -378,19 +445,22 @@ __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long ldd
   float bsum[4] = {0.f, 0.f, 0.f, 0.f}, gsum[4] = {0.f, 0.f, 0.f, 0.f};
   int cur_g = -1;
   if (nvalid > 0) {
+   dispatch_act(Z ? act : SMX_ACT_NONE, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
     for (int n = r0 + ry; n < r1; n += 4) {
       float fdy[4], fz[4], o[4];
-      if (VEC && nvalid >= 4) { load4<T>(dY + (long)n * lddy + col, fdy); }
-      else { for (int q = 0; q < 4; ++q) fdy[q] = q < nvalid ? to_f32(dY[(long)n * lddy + col + q]) : 0.f; }
-      if (Z) {
-        if (VEC && nvalid >= 4) load4<T>(Z + (long)n * ldz + col, fz);
-        else { for (int q = 0; q < 4; ++q) fz[q] = q < nvalid ? to_f32(Z[(long)n * ldz + col + q]) : 0.f; }
+      if constexpr (VEC) {
+        load4<T>(dY + (long)n * lddy + col, fdy);
+        if (Z) load4<T>(Z + (long)n * ldz + col, fz);
+      } else {
+        for (int q = 0; q < 4; ++q) fdy[q] = q < nvalid ? to_f32(dY[(long)n * lddy + col + q]) : 0.f;
+        if (Z) { for (int q = 0; q < 4; ++q) fz[q] = q < nvalid ? to_f32(Z[(long)n * ldz + col + q]) : 0.f; }
       }
       const float mk = (mask ? (mask[n] ? 1.f : 0.f) : 1.f) * alpha;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = fdy[q] * mk * (Z ? act_grad(act, fz[q]) : 1.f);
+      for (int q = 0; q < 4; ++q) o[q] = fdy[q] * mk * (ACT != SMX_ACT_NONE ? act_grad_c<ACT>(fz[q]) : 1.f);
       if (dZ) {
-        if (VEC && nvalid >= 4) store4<T>(dZ + (long)n * lddz + col, o);
+        if constexpr (VEC) store4<T>(dZ + (long)n * lddz + col, o);
         else { for (int q = 0; q < 4; ++q) if (q < nvalid) dZ[(long)n * lddz + col + q] = from_f32<T>(o[q]); }
       }
 #pragma unroll
@@ -407,6 +477,7 @@ __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long ldd
         for (int q = 0; q < 4; ++q) gsum[q] += o[q];
       }
     }
+   });
     if (dgroup && cur_g >= 0) { for (int q = 0; q < 4; ++q) if (q < nvalid) atomicAdd(dgroup + (long)cur_g * lddg + col + q, gsum[q]); }
   }
   if (dbias) {
@@ -590,17 +661,21 @@ extern "C" int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const fl
   return check_launch("smx_layernorm_fwd");
 }
 
+static int ln_bwd_blocks(int N) {
+  int blocks = (N + 7) / 8;
+  return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+}
+
 template <typename T>
 static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma, const float* beta,
                        int act, const float* stats,
                        const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma, float* dbeta, int N, int D,
-                       hipStream_t s) {
+                       float* partial, hipStream_t s) {
   auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % (4 * sizeof(T))) == 0 && ld % 4 == 0); };
   const bool vec = D % 4 == 0 && ok(dY, lddy) && ok(X, ldx) && ok(R, ldr) && ok(dX, lddx);
-  int blocks = (N + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  const int blocks = ln_bwd_blocks(N);
   dim3 grid(blocks);
-#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, dgamma, dbeta, N, D)
+#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH, (CH <= 2 ? 2 : 1)>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D)
   if (vec) {
     if (D <= 256) LN_BWD(4, 1);
     else if (D <= 512) LN_BWD(4, 2);
@@ -614,17 +689,21 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
     else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 2048", D);
   }
 #undef LN_BWD
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
   return check_launch("smx_layernorm_bwd");
 }
 
 extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                                  const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma,
-                                 float* dbeta, int N, int D, void* stream) {
-  SMX_REQUIRE(dY && X && gamma && beta && stats && dX && dgamma && dbeta && D > 0, "smx_layernorm_bwd: bad arguments");
+                                 float* dbeta, int N, int D, void* workspace, void* stream) {
+  SMX_REQUIRE(dY && X && gamma && beta && stats && dX && dgamma && dbeta && workspace && D > 0,
+              "smx_layernorm_bwd: bad arguments");
   if (N == 0) return SMX_OK;
-  if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, STREAM);
-  return ln_bwd_impl<float>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, STREAM);
+  if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM);
+  return ln_bwd_impl<float>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM);
 }
+
+extern "C" size_t smx_layernorm_bwd_workspace(int N, int D) { return (size_t)ln_bwd_blocks(N) * 2 * D * sizeof(float); }
 
 extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
                                 const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
@@ -634,8 +713,8 @@ extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const v
   if (N == 0) return SMX_OK;
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
   auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % (4 * es)) == 0 && ld % 4 == 0); };
-  const bool vec = ok(dY, lddy) && ok(Z, ldz) && ok(dZ, lddz);
-  const int RS = 64;
+  const bool vec = M % 4 == 0 && ok(dY, lddy) && ok(Z, ldz) && ok(dZ, lddz);
+  const int RS = 128;
   dim3 grid((M + 255) / 256, (N + RS - 1) / RS);
   if (dtype == SMX_BF16) {
     if (vec) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);

@@ -117,6 +117,43 @@ __device__ __forceinline__ float act_grad(int act, float v) {
   }
 }
 
+// Compile-time activation variants + a uniform dispatcher.  A run-time `switch (act)` evaluated per ELEMENT turns
+// an unrolled epilogue into thousands of branches and a code size that thrashes the instruction cache (measured:
+// 36 K lines of ISA, 2640 branches, 5x slower GEMM epilogue).  dispatch_act() hoists the switch: the body is
+// compiled once per activation and one uniform branch selects the straight-line variant.
+template <int ACT>
+__device__ __forceinline__ float act_fwd_c(float v) {
+  if constexpr (ACT == SMX_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  else if constexpr (ACT == SMX_ACT_SWISH) return v * sigmoidf_(v);
+  else if constexpr (ACT == SMX_ACT_LEAKY_RELU) return v >= 0.f ? v : 0.01f * v;
+  else if constexpr (ACT == SMX_ACT_RELU) return v > 0.f ? v : 0.f;
+  else return v;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_c(float v) {
+  if constexpr (ACT == SMX_ACT_GELU) {
+    float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+    return cdf + v * pdf;
+  } else if constexpr (ACT == SMX_ACT_SWISH) {
+    float s = sigmoidf_(v);
+    return s * (1.0f + v * (1.0f - s));
+  } else if constexpr (ACT == SMX_ACT_LEAKY_RELU) return v >= 0.f ? 1.f : 0.01f;
+  else if constexpr (ACT == SMX_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  else return 1.f;
+}
+template <int V> struct ActTag { static constexpr int value = V; };
+template <typename F>
+__device__ __forceinline__ void dispatch_act(int act, F&& f) {
+  switch (act) {
+    case SMX_ACT_GELU: f(ActTag<SMX_ACT_GELU>{}); break;
+    case SMX_ACT_SWISH: f(ActTag<SMX_ACT_SWISH>{}); break;
+    case SMX_ACT_LEAKY_RELU: f(ActTag<SMX_ACT_LEAKY_RELU>{}); break;
+    case SMX_ACT_RELU: f(ActTag<SMX_ACT_RELU>{}); break;
+    default: f(ActTag<SMX_ACT_NONE>{}); break;
+  }
+}
+
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -92,11 +92,9 @@ def block(x, run, params, on_bwd_done=None):
 
 
 def _wgrad_splits(nrows, m, k):
+    """split-K factor of the wgrad GEMM (reduce dim = frames): ~768 workgroups, >= 256 frames per split."""
     tiles = ((m + 127) // 128) * ((k + 127) // 128)
-    if tiles < 384:
-        tiles = ((m + 63) // 64) * ((k + 63) // 64)
-    s = max(1, min(1024 // max(tiles, 1), (nrows + 511) // 512))
-    return s
+    return max(1, min((768 + tiles - 1) // tiles, (nrows + 255) // 256))
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -129,8 +127,7 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
         dz = torch.empty((N, M), dtype=dy.dtype, device=dy.device)
         ops.act_mask_bwd(dy, z, mask, act, alpha, dz, gb, dgroup, gdiv)
     if gW is not None:
-        e = ops.epilogue(out_mode=L.OUT_ATOMIC_F32)
-        ops.gemm(L.GEMM_TN, dz, x, gW, M, K, N, e, splits=_wgrad_splits(N, M, K))
+        ops.wgrad(dz, x, gW, N, M, K)
     dx = None
     if need_dx:
         dx = dx_out if dx_out is not None else torch.empty((N, K), dtype=dy.dtype, device=dy.device)
@@ -190,8 +187,8 @@ def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=N
                 ops.act_mask_bwd(dy, z, mk, act, 1.0, dz, gb.view(-1) if gb is not None else None)
             gW = gacc(ly["W"])
             if gW is not None:   # dW[h] (f x h) += x_h^T dz_h
-                ops.gemm(L.GEMM_TN, x[:, :f], dz[:, :h], gW[0], f, h, N, ops.epilogue(out_mode=L.OUT_ATOMIC_F32),
-                         batch=H, sa=f, sb=h, sc=f * h, lda=x.stride(0), ldb=dz.stride(0), ldc=h)
+                ops.wgrad(x[:, :f], dz[:, :h], gW[0], N, f, h, batch=H, sz=f, sx=h, sw=f * h, lddz=x.stride(0),
+                          ldx=dz.stride(0), lddw=h)
             if want_dx:          # dx_h = dz_h W[h]^T : NT with B = W[h] viewed (f rows, h reduce-contiguous)
                 if first and dx_out is not None:
                     dx = dx_out
@@ -350,7 +347,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, skip_is_input_res=None):
                                     True, None, dgroup=dc0, gdiv=T, dx_out=dlocal_out)
                 dc0_t = ops.cast(dc0, dtype)
                 if gWm is not None:      # dW_s += dc0^T sbar
-                    ops.gemm(L.GEMM_TN, dc0_t, sbar_t, gWm[:, lw:], s_out, sdim, B, ops.epilogue(out_mode=L.OUT_ATOMIC_F32))
+                    ops.wgrad(dc0_t, sbar_t, gWm[:, lw:], B, s_out, sdim)
                 dsbar = torch.empty((B, sdim), dtype=torch.float32, device=dev)
                 ops.gemm(L.GEMM_NN, dc0_t, Ws, dsbar, B, sdim, s_out, ops.epilogue(out_mode=L.OUT_F32))
                 ops.bcast_rows(dsbar, inv, ds_out, B, T)
@@ -358,8 +355,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, skip_is_input_res=None):
                 _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
                                     True, None, dx_out=dlocal_out)
                 if gWm is not None:      # dW_s += dzm^T sbar
-                    ops.gemm(L.GEMM_TN, dzm, sbar_t, gWm[:, lw:], s_out, sdim, N, ops.epilogue(out_mode=L.OUT_ATOMIC_F32),
-                             splits=_wgrad_splits(N, s_out, sdim))
+                    ops.wgrad(dzm, sbar_t, gWm[:, lw:], N, s_out, sdim)
                 dsb = torch.empty((N, sdim), dtype=dtype, device=dev)
                 ops.gemm(L.GEMM_NN, dzm, Ws, dsb, N, sdim, s_out, None)
                 if pool_kind == "chunk":

@@ -83,6 +83,17 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
     return c
 
 
+def wgrad(dz, x, gW, rows, M, K, batch=1, sz=0, sx=0, sw=0, lddz=None, ldx=None, lddw=None, alpha=1.0):
+    """gW[b] (M x K) += alpha * dz[b]^T x[b]  (slab split-K + fixed-order reduction; see smx_linear_wgrad)."""
+    pz, lz = _mat(dz)
+    px, lx = _mat(x)
+    pw, lw = _mat(gW)
+    assert gW.dtype == torch.float32
+    ws = _workspace(L.lib().smx_linear_wgrad_workspace(rows, M, K, batch), dz.device, slot=1)
+    L.check(L.lib().smx_linear_wgrad(dt(dz), pz, lddz or lz, sz, px, ldx or lx, sx, pw, lddw or lw, sw, rows, M, K, batch,
+                                     alpha, _p(ws), _stream()), "smx_linear_wgrad")
+
+
 def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, gdiv=0):
     N, M = dy.shape
     pdy, lddy = _mat(dy)
@@ -97,8 +108,8 @@ def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, 
 _ws_cache = {}
 
 
-def _workspace(nbytes, device):
-    key = (device, torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes, device, slot=0):
+    key = (device, torch.cuda.current_stream().cuda_stream, slot)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -153,8 +164,9 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     pdy, lddy = _mat(dy)
     px, ldx = _mat(x)
     pr, ldr = (_mat(res) if res is not None else (None, 0))
+    ws = _workspace(L.lib().smx_layernorm_bwd_workspace(N, D), x.device, slot=2)
     L.check(L.lib().smx_layernorm_bwd(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), D, _p(dgamma),
-                                      _p(dbeta), N, D, _stream()), "smx_layernorm_bwd")
+                                      _p(dbeta), N, D, _p(ws), _stream()), "smx_layernorm_bwd")
     return dx
 
 

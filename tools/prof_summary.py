@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd sqlite database (kernel-trace) per kernel: calls, total, average.
+usage: prof_summary.py results.db [steps]   -> markdown-ish table on stdout (commit it under profiles/)"""
+import re, sqlite3, sys
+con = sqlite3.connect(sys.argv[1])
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rows = con.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+print(f"total kernel time {tot/1e6:.2f} ms over {steps} steps = {tot/1e6/steps:.2f} ms/step")
+print(f"{'%':>6} {'calls/step':>10} {'avg us':>9} {'min us':>8} {'max us':>8}  kernel")
+for r in rows[:28]:
+    n = re.sub(r"smx::", "", r[0]); n = re.sub(r"\(.*\)$", "", n); n = re.sub(r"^void ", "", n)
+    print(f"{r[2]/tot*100:6.1f} {r[1]/steps:10.1f} {r[3]/1e3:9.1f} {r[4]/1e3:8.1f} {r[5]/1e3:8.1f}  {n[:100]}")
