@@ -281,10 +281,14 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
       for (int q = 0; q < CW; ++q) if (q < nv) bv[q] = bias[m + q];
     }
   }
-  float cv[NIT][CW], rv[NIT][CW], mk[NIT];
+  // items are handled in batches of NB: all side-input loads of a batch precede its first store (in-order vmcnt)
+  constexpr int NB = NIT < 2 ? NIT : 2;
 #pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const int n = nbase + r0 + k * RSTEP;
+  for (int kb = 0; kb < NIT; kb += NB) {
+  float cv[NB][CW], rv[NB][CW], mk[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const int n = nbase + r0 + (kb + k) * RSTEP;
     const bool nok = n < p.N;
     mk[k] = ((e.row_mask && nok) ? (e.row_mask[n] ? 1.f : 0.f) : 1.f) * e.alpha;
 #pragma unroll
@@ -321,8 +325,8 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   }
   // ---- math + stores ----
 #pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const int r = r0 + k * RSTEP, n = nbase + r;
+  for (int k = 0; k < NB; ++k) {
+    const int r = r0 + (kb + k) * RSTEP, n = nbase + r;
     if (n >= p.N) continue;
     float v[CW];
 #pragma unroll
@@ -388,11 +392,12 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
       }
     }
   }
+  }
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
   // about one HBM/L2 round trip for its whole main loop instead of one per K tile (measured: 2.9 K cycles per
   // K tile with a single stage, the MFMAs themselves need ~0.5 K).
-  constexpr int NS = 2;
+  constexpr int NS = A_KC ? 1 : 2;
   uint4 ra[NS][4], rb[NS][4];
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_)
