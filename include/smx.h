@@ -84,13 +84,15 @@ int smx_linear_act_mask_fwd(int dtype, const void* X, int64_t ldx, const void* W
                             int64_t ldy, int N, int M, int K, const smx_epilogue* epi, void* stream);
 
 /* dZ = dY * mask * act'(Z)  (elementwise), plus fused parameter-gradient side reductions:
- *   dbias[m]          += sum_n dZ[n,m]                      (fp32 atomics, optional)
+ *   dbias[m]          += sum_n dZ[n,m]                      (optional; per-strip partials in `workspace`,
+ *                                                            smx_act_mask_bwd_workspace bytes, fixed-order reduce)
  *   dgroup[n/div, m]  += sum over the rows of group n/div   (fp32 atomics, optional; the backward of a
  *                                                            SMX_C0_GROUP side input)
  * Backward of the epilogue above (autograd of summary_mixing.py:207-284). dY is pre-scaled by alpha. */
+size_t smx_act_mask_bwd_workspace(int N, int M);
 int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
                      const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
-                     float* dbias, float* dgroup, int64_t lddgroup, int group_div, void* stream);
+                     float* dbias, float* dgroup, int64_t lddgroup, int group_div, void* workspace, void* stream);
 
 /* Masked mean over time: out[b,:] = sum_t S[b,t,:] * mask[b,t] / sum_t mask[b,t]   (fp32 out (B,D)).
  * S is (B*T, D) with leading dimension lds.  mask NULL => all valid.  scale_by_count=0 gives the plain sum.
@@ -137,11 +139,13 @@ int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, in
 int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
                          const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k, int glu,
                          int pad_mode, int chunk, void* stream);
-/* dP (same shape as P), dw/dbias += (fp32 atomics); dgate optional (= dY * conv). */
+/* dP (same shape as P), dw/dbias += ; dgate optional (= dY * conv).  workspace: smx_dwconv1d_glu_bwd_workspace bytes
+ * (per-block partial tap gradients of the fast path, reduced in a fixed order; NULL selects the generic kernel). */
+size_t smx_dwconv1d_glu_bwd_workspace(int B, int T, int D, int k);
 int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, const void* P, int64_t ldp, const float* w,
                          const float* bias, const void* gate, int64_t ldg, void* dP, int64_t lddp, void* dgate,
                          int64_t lddg, float* dw, float* dbias, int B, int T, int D, int k, int glu, int pad_mode,
-                         int chunk, void* stream);
+                         int chunk, void* workspace, void* stream);
 
 /* y = a*x (+ b*y0): generic strided elementwise helper (dtype T). */
 int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b, const void* Y0, int64_t ldy0, void* Y,

@@ -40,8 +40,9 @@ SIGNATURES = {
                                c_vp, c_vp]),
     "smx_linear_act_mask_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i,
                                       ctypes.POINTER(Epilogue), c_vp]),
+    "smx_act_mask_bwd_workspace": (c_sz, [c_i, c_i]),
     "smx_act_mask_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp,
-                               c_i64, c_i, c_vp]),
+                               c_i64, c_i, c_vp, c_vp]),
     "smx_masked_mean_workspace": (c_sz, [c_i, c_i, c_i]),
     "smx_masked_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_masked_mean_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_vp]),
@@ -54,8 +55,9 @@ SIGNATURES = {
                                 c_vp, c_i, c_i, c_vp, c_vp]),
     "smx_dwconv1d_glu_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_vp]),
+    "smx_dwconv1d_glu_bwd_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_dwconv1d_glu_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
-                                   c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+                                   c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_axpby": (c_i, [c_i, c_f, c_vp, c_i64, c_f, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
     "smx_cast_from_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
     "smx_cast_to_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),

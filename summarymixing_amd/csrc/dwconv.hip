@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_fast(DwParams p) {
 }
 
 template <typename T, int K>
-__global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t) {
+__global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, float* __restrict__ partial) {
   constexpr int PAD = (K - 1) / 2, WIN = 16 + K - 1, ROWS = DW_TT + K - 1;
   constexpr int VW = DwVec<T>::N, LPR = DW_CT / VW, NITEM = (ROWS * LPR + 255) / 256;
   __shared__ __attribute__((aligned(16))) float u[ROWS][DW_CT];
@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t) 
       }
     }
   }
-  // flush dw / dbias: 4 waves -> LDS -> one atomic per (channel, tap) per block
+  // flush dw / dbias: 4 waves -> LDS -> one partial row per block (reduced in a fixed order by
+  // dw_partials_reduce_kernel; same-address fp32 atomics from ~1000 blocks cost ~100 ns each)
 #pragma unroll
   for (int j = 0; j <= K; ++j) {
     const float v = j < K ? dw[j < K ? j : 0] : dbs;
@@ -426,10 +427,28 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t) 
     __syncthreads();
     if (wv == 0 && cok) {
       const float tot = ((v + red[0][cl]) + red[1][cl]) + red[2][cl];
-      if (j < K) atomicAdd(p.dw + (long)ch * K + j, tot);
-      else if (p.dbias) atomicAdd(p.dbias + ch, tot);
+      partial[((long)blockIdx.y * p.D + ch) * (K + 1) + j] = tot;
     }
   }
+}
+
+// dw[ch][j] += sum_y partial[y][ch][j] (j < K); dbias[ch] += sum_y partial[y][ch][K]
+__global__ __launch_bounds__(256) void dw_partials_reduce_kernel(const float* __restrict__ partial, int ny, int D, int K,
+                                                                 float* dw, float* dbias) {
+  const long W = (long)D * (K + 1);
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  if (idx >= W) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int y = 0;
+  for (; y + 3 < ny; y += 4) {
+    s0 += partial[(long)y * W + idx]; s1 += partial[(long)(y + 1) * W + idx];
+    s2 += partial[(long)(y + 2) * W + idx]; s3 += partial[(long)(y + 3) * W + idx];
+  }
+  for (; y < ny; ++y) s0 += partial[(long)y * W + idx];
+  const int ch = (int)(idx / (K + 1)), j = (int)(idx % (K + 1));
+  const float tot = (s0 + s1) + (s2 + s3);
+  if (j < K) dw[(long)ch * K + j] += tot;
+  else if (dbias) dbias[ch] += tot;
 }
 
 }  // namespace smx
@@ -460,10 +479,18 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
   return check_launch("smx_dwconv1d_glu_fwd");
 }
 
+extern "C" size_t smx_dwconv1d_glu_bwd_workspace(int B, int T, int D, int k) {
+  const int tiles_t = (T + DW_TT - 1) / DW_TT, ctiles = (D + DW_CT - 1) / DW_CT;
+  long total = (long)B * tiles_t, gy = (1024 + ctiles - 1) / ctiles;
+  if (gy > total) gy = total;
+  if (gy < 1) gy = 1;
+  return (size_t)gy * D * (k + 1) * sizeof(float);
+}
+
 extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, const void* P, int64_t ldp, const float* w,
                                     const float* bias, const void* gate, int64_t ldg, void* dP, int64_t lddp,
                                     void* dgate, int64_t lddg, float* dw, float* dbias, int B, int T, int D, int k,
-                                    int glu, int pad_mode, int chunk, void* stream) {
+                                    int glu, int pad_mode, int chunk, void* workspace, void* stream) {
   SMX_REQUIRE(dY && P && w && dP && dw, "smx_dwconv1d_glu_bwd: null pointer");
   SMX_REQUIRE(k >= 1 && k <= DW_KMAX && (k & 1), "smx_dwconv1d_glu_bwd: k=%d must be odd and <= %d", k, DW_KMAX);
   SMX_REQUIRE((gate == nullptr) == (dgate == nullptr), "smx_dwconv1d_glu_bwd: gate and dgate go together");
@@ -483,10 +510,14 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int vw = dtype == SMX_BF16 ? 8 : 4;
   const bool fast = k == 31 && pad_mode == SMX_PAD_ZERO && chunk <= 0 && gate == nullptr && D % vw == 0 &&
-                    ldp % vw == 0 && lddy % vw == 0 && lddp % vw == 0 && aligned16(P) && aligned16(dY) && aligned16(dP);
+                    ldp % vw == 0 && lddy % vw == 0 && lddp % vw == 0 && aligned16(P) && aligned16(dY) && aligned16(dP) &&
+                    workspace != nullptr;
   if (fast) {
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_fast<bf16_t, 31>), grid, dim3(256), 0, s, p, tiles_t);
-    else hipLaunchKernelGGL((dwconv_bwd_fast<float, 31>), grid, dim3(256), 0, s, p, tiles_t);
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_fast<bf16_t, 31>), grid, dim3(256), 0, s, p, tiles_t, partial);
+    else hipLaunchKernelGGL((dwconv_bwd_fast<float, 31>), grid, dim3(256), 0, s, p, tiles_t, partial);
+    const long W = (long)D * (k + 1);
+    hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, (int)gy, D, k, dw, dbias);
   } else if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, p, tiles_t);
   else hipLaunchKernelGGL((dwconv_bwd_kernel<float>), grid, dim3(256), 0, s, p, tiles_t);
   return check_launch("smx_dwconv1d_glu_bwd");

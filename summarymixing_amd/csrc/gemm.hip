@@ -674,8 +674,9 @@ extern "C" int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64
 // split-K over the frame dimension into fp32 slabs (plain coalesced stores), then ONE fixed-order reduction
 // kernel adds the slabs into the gradient buffer: bit-reproducible, no atomics.
 namespace smx {
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, int nslab, long slab_stride, float* dst,
-                                                           long lddst, long sdst, int M, int K, int batch, float alpha) {
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, long slab_stride,
+                                                           float* dst, long lddst, long sdst, int M, int K, int batch,
+                                                           float alpha) {
   const int kv = K / 4;
   const long total = (long)batch * M * kv;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -683,13 +684,25 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, i
     const long r = i / kv;
     const int m = (int)(r % M), b = (int)(r / M);
     const float* sp = slabs + ((long)b * M + m) * K + k4 * 4;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nslab; ++s) {
-      float4 v = *reinterpret_cast<const float4*>(sp + s * slab_stride);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;   // 4 loads in flight, fixed order
+    int s = 0;
+    for (; s + 3 < nslab; s += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(sp + (long)s * slab_stride);
+      const float4 v1 = *reinterpret_cast<const float4*>(sp + (long)(s + 1) * slab_stride);
+      const float4 v2 = *reinterpret_cast<const float4*>(sp + (long)(s + 2) * slab_stride);
+      const float4 v3 = *reinterpret_cast<const float4*>(sp + (long)(s + 3) * slab_stride);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; s < nslab; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(sp + (long)s * slab_stride);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
     }
     float* d = dst + (long)b * sdst + (long)m * lddst + k4 * 4;
-    d[0] += alpha * a.x; d[1] += alpha * a.y; d[2] += alpha * a.z; d[3] += alpha * a.w;
+    d[0] += alpha * ((a0.x + a1.x) + (a2.x + a3.x)); d[1] += alpha * ((a0.y + a1.y) + (a2.y + a3.y));
+    d[2] += alpha * ((a0.z + a1.z) + (a2.z + a3.z)); d[3] += alpha * ((a0.w + a1.w) + (a2.w + a3.w));
   }
 }
 static int wgrad_splits(int rows, int M, int K, int batch) {

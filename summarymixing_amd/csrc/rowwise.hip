@@ -403,26 +403,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // block = 32 columns x 8 row groups; every thread sums nblocks/8 partial rows with 4 independent accumulators.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int D,
                                                               float* dgamma, float* dbeta) {
-  __shared__ float red[8][32];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;                 // index into the concatenated [dgamma | dbeta] row of 2*D
+  __shared__ float red[16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;                 // index into the concatenated [dgamma | dbeta] row of 2*D
   const bool ok = c < 2 * D;
   const int pass = ok ? c / D : 0, col = ok ? c % D : 0;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int b = ry;
-  for (; b + 24 < nblocks; b += 32) {
+  for (; b + 48 < nblocks; b += 64) {
     s0 += partial[((long)b * 2 + pass) * D + col];
-    s1 += partial[((long)(b + 8) * 2 + pass) * D + col];
-    s2 += partial[((long)(b + 16) * 2 + pass) * D + col];
-    s3 += partial[((long)(b + 24) * 2 + pass) * D + col];
+    s1 += partial[((long)(b + 16) * 2 + pass) * D + col];
+    s2 += partial[((long)(b + 32) * 2 + pass) * D + col];
+    s3 += partial[((long)(b + 48) * 2 + pass) * D + col];
   }
-  for (; b < nblocks; b += 8) s0 += partial[((long)b * 2 + pass) * D + col];
+  for (; b < nblocks; b += 16) s0 += partial[((long)b * 2 + pass) * D + col];
   red[ry][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ry == 0 && ok) {
     float tot = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) tot += red[r][cx];
+    for (int r = 0; r < 16; ++r) tot += red[r][cx];
     float* dst = pass == 0 ? dgamma : dbeta;
     dst[col] += tot;
   }
@@ -430,9 +430,110 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
 
 // =================================================================================================
 // dZ = alpha * dY * mask * act'(Z);  dbias[m] += colsum;  dgroup[n/div, m] += per-group colsum.
-// block = 64 column-vectors (4 elements each) x 4 row lanes; strip of RS rows per block.
+// VEC kernel: a lane owns VT<T>::N consecutive columns (16-byte accesses); LPR lanes span a row chunk of up to
+// 64*N columns, the remaining 64/LPR lanes of a wave take further rows; 4 rows are in flight per lane.
 // =================================================================================================
-template <typename T, bool VEC>
+template <typename T>
+__global__ __launch_bounds__(256) void act_mask_bwd_vec_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ Z,
+                                                               long ldz, const uint8_t* __restrict__ mask, T* __restrict__ dZ,
+                                                               long lddz, int N_, int M, int act, float alpha, float* dbias,
+                                                               float* dgroup, long lddg, int gdiv, int RS, int LPR,
+                                                               float* __restrict__ partial) {
+  constexpr int N = VT<T>::N;
+  __shared__ float red[256][N];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lc = lane % LPR, lr = lane / LPR;          // column chunk / row slot inside the wave
+  const int RPW = 64 / LPR;                            // rows per wave instruction
+  const int col = (blockIdx.x * LPR + lc) * N;
+  const bool cok = col < M;
+  const int colc = cok ? col : 0;
+  const int r0 = blockIdx.y * RS, r1 = min(N_, r0 + RS);
+  float bsum[N], gsum[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) bsum[q] = gsum[q] = 0.f;
+  int cur_g = -1;
+  const int rstep = 4 * RPW;                           // rows advanced per pass of the block's 4 waves
+  dispatch_act(Z ? act : SMX_ACT_NONE, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    for (int nb = r0 + w * RPW + lr; nb < r1; nb += 4 * rstep) {
+      float fdy[4][N], fz[4][N];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = min(nb + u * rstep, N_ - 1);
+        loadv<T, true>(dY + (long)n * lddy + colc, N, fdy[u]);
+        if (ACT != SMX_ACT_NONE) loadv<T, true>(Z + (long)n * ldz + colc, N, fz[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = nb + u * rstep;
+        if (n >= r1 || !cok) continue;
+        const float mk = (mask ? (mask[n] ? 1.f : 0.f) : 1.f) * alpha;
+        float o[N];
+#pragma unroll
+        for (int q = 0; q < N; ++q) o[q] = fdy[u][q] * mk * (ACT != SMX_ACT_NONE ? act_grad_c<ACT>(fz[u][q]) : 1.f);
+        if (dZ) storev<T, true>(dZ + (long)n * lddz + col, N, o);
+#pragma unroll
+        for (int q = 0; q < N; ++q) bsum[q] += o[q];
+        if (dgroup) {
+          const int g = n / gdiv;
+          if (g != cur_g) {
+            if (cur_g >= 0) { for (int q = 0; q < N; ++q) atomicAdd(dgroup + (long)cur_g * lddg + col + q, gsum[q]); }
+            cur_g = g;
+#pragma unroll
+            for (int q = 0; q < N; ++q) gsum[q] = 0.f;
+          }
+#pragma unroll
+          for (int q = 0; q < N; ++q) gsum[q] += o[q];
+        }
+      }
+    }
+  });
+  if (dgroup && cur_g >= 0 && cok) { for (int q = 0; q < N; ++q) atomicAdd(dgroup + (long)cur_g * lddg + col + q, gsum[q]); }
+  if (dbias) {                                         // fold the 256 threads that share a column chunk
+#pragma unroll
+    for (int q = 0; q < N; ++q) red[threadIdx.x][q] = bsum[q];
+    __syncthreads();
+    if (threadIdx.x < LPR && cok) {
+      float tot[N];
+#pragma unroll
+      for (int q = 0; q < N; ++q) tot[q] = 0.f;
+      for (int k = threadIdx.x; k < 256; k += LPR) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) tot[q] += red[k][q];
+      }
+      // one partial row per row strip (no atomics: ~100 ns each when thousands of blocks hit the same address)
+#pragma unroll
+      for (int q = 0; q < N; ++q) partial[(long)blockIdx.y * M + col + q] = tot[q];
+    }
+  }
+}
+
+// dst[c] += sum_b partial[b][c]  (fixed order).  block = 32 columns x 8 row groups
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, int nrows, int W, float* dst) {
+  __shared__ float red[16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
+  const bool ok = c < W;
+  const int col = ok ? c : 0;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = ry;
+  for (; b + 48 < nrows; b += 64) {
+    s0 += partial[(long)b * W + col]; s1 += partial[(long)(b + 16) * W + col];
+    s2 += partial[(long)(b + 32) * W + col]; s3 += partial[(long)(b + 48) * W + col];
+  }
+  for (; b < nrows; b += 16) s0 += partial[(long)b * W + col];
+  red[ry][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ry == 0 && ok) {
+    float tot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot += red[r][cx];
+    dst[col] += tot;
+  }
+}
+
+// generic (ragged / unaligned) variant: 4 columns per thread, scalar accesses
+template <typename T>
 __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long lddy, const T* Z, long ldz,
                                                            const uint8_t* mask, T* dZ, long lddz, int N_, int M, int act,
                                                            float alpha, float* dbias, float* dgroup, long lddg, int gdiv,
@@ -445,39 +546,24 @@ __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long ldd
   float bsum[4] = {0.f, 0.f, 0.f, 0.f}, gsum[4] = {0.f, 0.f, 0.f, 0.f};
   int cur_g = -1;
   if (nvalid > 0) {
-   dispatch_act(Z ? act : SMX_ACT_NONE, [&](auto act_tag) {
-    constexpr int ACT = decltype(act_tag)::value;
     for (int n = r0 + ry; n < r1; n += 4) {
-      float fdy[4], fz[4], o[4];
-      if constexpr (VEC) {
-        load4<T>(dY + (long)n * lddy + col, fdy);
-        if (Z) load4<T>(Z + (long)n * ldz + col, fz);
-      } else {
-        for (int q = 0; q < 4; ++q) fdy[q] = q < nvalid ? to_f32(dY[(long)n * lddy + col + q]) : 0.f;
-        if (Z) { for (int q = 0; q < 4; ++q) fz[q] = q < nvalid ? to_f32(Z[(long)n * ldz + col + q]) : 0.f; }
-      }
+      float fdy[4], fz[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+      for (int q = 0; q < 4; ++q) fdy[q] = q < nvalid ? to_f32(dY[(long)n * lddy + col + q]) : 0.f;
+      if (Z) { for (int q = 0; q < 4; ++q) fz[q] = q < nvalid ? to_f32(Z[(long)n * ldz + col + q]) : 0.f; }
       const float mk = (mask ? (mask[n] ? 1.f : 0.f) : 1.f) * alpha;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = fdy[q] * mk * (ACT != SMX_ACT_NONE ? act_grad_c<ACT>(fz[q]) : 1.f);
-      if (dZ) {
-        if constexpr (VEC) store4<T>(dZ + (long)n * lddz + col, o);
-        else { for (int q = 0; q < 4; ++q) if (q < nvalid) dZ[(long)n * lddz + col + q] = from_f32<T>(o[q]); }
-      }
-#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = fdy[q] * mk * (Z ? act_grad(act, fz[q]) : 1.f);
+      if (dZ) { for (int q = 0; q < 4; ++q) if (q < nvalid) dZ[(long)n * lddz + col + q] = from_f32<T>(o[q]); }
       for (int q = 0; q < 4; ++q) bsum[q] += o[q];
       if (dgroup) {
         int g = n / gdiv;
         if (g != cur_g) {
           if (cur_g >= 0) { for (int q = 0; q < 4; ++q) if (q < nvalid) atomicAdd(dgroup + (long)cur_g * lddg + col + q, gsum[q]); }
           cur_g = g;
-#pragma unroll
           for (int q = 0; q < 4; ++q) gsum[q] = 0.f;
         }
-#pragma unroll
         for (int q = 0; q < 4; ++q) gsum[q] += o[q];
       }
     }
-   });
     if (dgroup && cur_g >= 0) { for (int q = 0; q < 4; ++q) if (q < nvalid) atomicAdd(dgroup + (long)cur_g * lddg + col + q, gsum[q]); }
   }
   if (dbias) {
@@ -689,7 +775,7 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
     else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 2048", D);
   }
 #undef LN_BWD
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
   return check_launch("smx_layernorm_bwd");
 }
 
@@ -705,23 +791,34 @@ extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const 
 
 extern "C" size_t smx_layernorm_bwd_workspace(int N, int D) { return (size_t)ln_bwd_blocks(N) * 2 * D * sizeof(float); }
 
+static const int ACT_BWD_RS = 32;
+extern "C" size_t smx_act_mask_bwd_workspace(int N, int M) { return (size_t)((N + ACT_BWD_RS - 1) / ACT_BWD_RS) * M * sizeof(float); }
+
 extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
                                 const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
-                                float* dbias, float* dgroup, int64_t lddgroup, int group_div, void* stream) {
+                                float* dbias, float* dgroup, int64_t lddgroup, int group_div, void* workspace,
+                                void* stream) {
   SMX_REQUIRE(dY && N >= 0 && M > 0, "smx_act_mask_bwd: bad arguments");
   SMX_REQUIRE(!dgroup || group_div > 0, "smx_act_mask_bwd: group_div must be > 0");
   if (N == 0) return SMX_OK;
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
-  auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % (4 * es)) == 0 && ld % 4 == 0); };
-  const bool vec = M % 4 == 0 && ok(dY, lddy) && ok(Z, ldz) && ok(dZ, lddz);
-  const int RS = 128;
-  dim3 grid((M + 255) / 256, (N + RS - 1) / RS);
-  if (dtype == SMX_BF16) {
-    if (vec) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
-    else hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
+  const int nv = dtype == SMX_BF16 ? 8 : 4;
+  auto ok = [&](const void* p, int64_t ld) { return p == nullptr || (aligned16(p) && (ld * (int64_t)es) % 16 == 0); };
+  const bool vec = M % nv == 0 && ok(dY, lddy) && ok(Z, ldz) && ok(dZ, lddz) && (!dbias || workspace);
+  if (vec) {
+    int chunks = M / nv, LPR = 1;
+    while (LPR < 64 && LPR < chunks) LPR <<= 1;       // lanes per row chunk (power of two <= 64)
+    const int RS = ACT_BWD_RS;
+    float* partial = reinterpret_cast<float*>(workspace);
+    dim3 grid((chunks + LPR - 1) / LPR, (N + RS - 1) / RS);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial);
+    else hipLaunchKernelGGL((act_mask_bwd_vec_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial);
+    if (dbias) hipLaunchKernelGGL(colsum_partials_kernel, dim3((M + 15) / 16), dim3(256), 0, STREAM, partial, (N + RS - 1) / RS, M, dbias);
   } else {
-    if (vec) hipLaunchKernelGGL((act_mask_bwd_kernel<float, true>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
-    else hipLaunchKernelGGL((act_mask_bwd_kernel<float, false>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
+    const int RS = 128;
+    dim3 grid((M + 255) / 256, (N + RS - 1) / RS);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
+    else hipLaunchKernelGGL((act_mask_bwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
   }
   return check_launch("smx_act_mask_bwd");
 }

@@ -100,8 +100,9 @@ def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, 
     pz, ldz = (_mat(z) if z is not None else (None, 0))
     pdz, lddz = (_mat(dz) if dz is not None else (None, 0))
     pg, ldg = (_mat(dgroup) if dgroup is not None else (None, 0))
+    ws = _workspace(L.lib().smx_act_mask_bwd_workspace(N, M), dy.device, slot=3) if dbias is not None else None
     L.check(L.lib().smx_act_mask_bwd(dt(dy), pdy, lddy, pz, ldz, _p(mask), pdz, lddz, N, M, act, alpha, _p(dbias), pg,
-                                     ldg, gdiv, _stream()), "smx_act_mask_bwd")
+                                     ldg, gdiv, _p(ws), _stream()), "smx_act_mask_bwd")
     return dz
 
 
@@ -185,9 +186,10 @@ def dwconv_bwd(dy, p, w, bias, dw, dbias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, 
     pdy, lddy = _mat(dy)
     pp, ldp = _mat(p)
     pg, ldg = (_mat(gate) if gate is not None else (None, 0))
+    ws = _workspace(L.lib().smx_dwconv1d_glu_bwd_workspace(B, T, D, k), p.device, slot=4)
     L.check(L.lib().smx_dwconv1d_glu_bwd(dt(p), pdy, lddy, pp, ldp, _p(w), _p(bias), pg, ldg, _p(dp), dp.shape[1],
                                          _p(dgate), D, _p(dw), _p(dbias), B, T, D, k, 1 if glu else 0, pad_mode, chunk,
-                                         _stream()), "smx_dwconv1d_glu_bwd")
+                                         _p(ws), _stream()), "smx_dwconv1d_glu_bwd")
     return dp, dgate
 
 
