@@ -4,6 +4,8 @@
 //   axpby, casts, fused AdamW, sum of squares, clip factor.
 // Every kernel moves 8-16 bytes per lane per access along the feature dim (coalesced 512 B - 1 KiB per
 // wave instruction) and accumulates in fp32.
+#include <stdlib.h>
+
 #include "smx_common.h"
 
 namespace smx {
@@ -62,7 +64,7 @@ static inline bool vec_ok(const void* p, int64_t ld, int D, int n, size_t es) {
 // =================================================================================================
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void masked_sum_stage1(const T* S, long lds, const uint8_t* mask, float* partial,
-                                                         int T_, int D, int TR, int TS) {
+                                                         float* pcount, int T_, int D, int TR, int TS) {
   constexpr int N = VT<T>::N;
   __shared__ float red[3][64 * N];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -71,29 +73,31 @@ __global__ __launch_bounds__(256) void masked_sum_stage1(const T* S, long lds, c
   const int nvalid = D - col;
   const int t0 = ts * TR, t1 = min(T_, t0 + TR);
   float acc[N];
+  float cnt = 0.f;
 #pragma unroll
   for (int i = 0; i < N; ++i) acc[i] = 0.f;
   const T* base = S + ((long)b * T_) * lds + (nvalid > 0 ? col : 0);   // idle lanes re-read column 0 (discarded)
   const uint8_t* mrow = mask ? mask + (long)b * T_ : nullptr;
-  int t = t0 + w;
-  for (; t + 12 < t1; t += 16) {          // 4 independent 16-byte loads in flight per lane
-    float f0[N], f1[N], f2[N], f3[N];
-    loadv<T, VEC>(base + (long)t * lds, nvalid, f0);
-    loadv<T, VEC>(base + (long)(t + 4) * lds, nvalid, f1);
-    loadv<T, VEC>(base + (long)(t + 8) * lds, nvalid, f2);
-    loadv<T, VEC>(base + (long)(t + 12) * lds, nvalid, f3);
-    float m0 = 1.f, m1 = 1.f, m2 = 1.f, m3 = 1.f;
-    if (mrow) { m0 = mrow[t] ? 1.f : 0.f; m1 = mrow[t + 4] ? 1.f : 0.f; m2 = mrow[t + 8] ? 1.f : 0.f; m3 = mrow[t + 12] ? 1.f : 0.f; }
+  // every pass keeps 8 independent 16-byte loads in flight per lane (128 B/lane, 8 KiB/wave); rows past the end of
+  // the block's range re-read its last row with weight 0, so there is no scalar tail
+  const int tlast = t1 - 1;
+  for (int t = t0 + w; t < t1; t += 32) {
+    float f[8][N], m[8];
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] += (f0[i] * m0 + f1[i] * m1) + (f2[i] * m2 + f3[i] * m3);
-  }
-  for (; t < t1; t += 4) {
-    float f0[N];
-    loadv<T, VEC>(base + (long)t * lds, nvalid, f0);
-    float m0 = mrow ? (mrow[t] ? 1.f : 0.f) : 1.f;
+    for (int u = 0; u < 8; ++u) loadv<T, VEC>(base + (long)min(t + 4 * u, tlast) * lds, nvalid, f[u]);
+    {
+      const int tt = t + 4 * (lane & 7);                 // lane u (0..7) fetches the mask byte of row slot u
+      const float mv = tt < t1 ? (mrow ? (mrow[tt] ? 1.f : 0.f) : 1.f) : 0.f;
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] += f0[i] * m0;
+      for (int u = 0; u < 8; ++u) { m[u] = __shfl(mv, u, 64); cnt += m[u]; }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      acc[i] += ((f[0][i] * m[0] + f[1][i] * m[1]) + (f[2][i] * m[2] + f[3][i] * m[3])) +
+                ((f[4][i] * m[4] + f[5][i] * m[5]) + (f[6][i] * m[6] + f[7][i] * m[7]));
   }
+  __shared__ float cred[4];
+  if (lane == 0) cred[w] = cnt;
   if (w > 0) {
 #pragma unroll
     for (int i = 0; i < N; ++i) red[w - 1][lane * N + i] = acc[i];
@@ -107,38 +111,34 @@ __global__ __launch_bounds__(256) void masked_sum_stage1(const T* S, long lds, c
     for (int i = 0; i < N; ++i)
       if (i < nvalid) o[i] = acc[i];
   }
+  if (threadIdx.x == 0 && blockIdx.x == 0) pcount[(long)b * TS + ts] = (cred[0] + cred[1]) + (cred[2] + cred[3]);
 }
 
 // stage 2: fixed-order sum of the TS partials, divide by the number of valid frames.  grid (ceil(D/256), B)
-__global__ __launch_bounds__(256) void masked_sum_stage2(const float* partial, const uint8_t* mask, float* out,
+__global__ __launch_bounds__(256) void masked_sum_stage2(const float* partial, const float* pcount, float* out,
                                                          float* inv_count, int T_, int D, int TS, int scale) {
-  __shared__ float red[4];
   const int b = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
-  float inv = 1.f;
-  if (scale || inv_count) {
-    float c = 0.f;
-    if (mask) {
-      for (int t = threadIdx.x; t < T_; t += 256) c += mask[(long)b * T_ + t] ? 1.f : 0.f;
-      c = wave_sum(c);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-      __syncthreads();
-      c = (red[0] + red[1]) + (red[2] + red[3]);
-    } else {
-      c = (float)T_;
-    }
-    inv = 1.f / c;   // zero valid frames -> inf, 0*inf = NaN, as the reference (summary_mixing.py:264-266)
-    if (inv_count && blockIdx.x == 0 && threadIdx.x == 0) inv_count[b] = inv;
-  }
+  float c = 0.f;
+  for (int ts = 0; ts < TS; ++ts) c += pcount[(long)b * TS + ts];   // every thread sums the same TS counts (L1 hits)
+  const float inv = 1.f / c;   // zero valid frames -> inf, 0*inf = NaN, as the reference (summary_mixing.py:264-266)
+  if (inv_count && blockIdx.x == 0 && threadIdx.x == 0) inv_count[b] = inv;
   if (col >= D) return;
-  float s = 0.f;
-  for (int ts = 0; ts < TS; ++ts) s += partial[((long)b * TS + ts) * D + col];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int ts = 0;
+  for (; ts + 3 < TS; ts += 4) {
+    s0 += partial[((long)b * TS + ts) * D + col]; s1 += partial[((long)b * TS + ts + 1) * D + col];
+    s2 += partial[((long)b * TS + ts + 2) * D + col]; s3 += partial[((long)b * TS + ts + 3) * D + col];
+  }
+  for (; ts < TS; ++ts) s0 += partial[((long)b * TS + ts) * D + col];
+  const float s = (s0 + s1) + (s2 + s3);
   out[(long)b * D + col] = scale ? s * inv : s;
 }
 
 static void mm_plan(int B, int T, int D, int nvec, int& DC, int& TS, int& TR) {
   DC = (D + 64 * nvec - 1) / (64 * nvec);
-  long want = (2048 + (long)B * DC - 1) / ((long)B * DC);   // >= 2048 blocks when the rows allow it
-  long maxts = (T + 63) / 64;                               // >= 64 rows per block
+  static const long target = getenv("SMX_POOL_BLOCKS") ? atol(getenv("SMX_POOL_BLOCKS")) : 512;
+  long want = (target + (long)B * DC - 1) / ((long)B * DC);   // ~1024 workgroups (4 per CU) when the rows allow it
+  long maxts = (T + 127) / 128;                             // >= 128 rows per block (32 per wave)
   TS = (int)(want < 1 ? 1 : (want > maxts ? maxts : want));
   if (TS < 1) TS = 1;
   TR = (T + TS - 1) / TS;
@@ -654,7 +654,7 @@ extern "C" size_t smx_masked_mean_workspace(int B, int T, int D) {
   int DC2, TS2, TR2;
   mm_plan(B, T, D, 8, DC2, TS2, TR2);
   int ts = TS > TS2 ? TS : TS2;
-  return (size_t)B * ts * D * sizeof(float);
+  return (size_t)B * ts * (D + 1) * sizeof(float);
 }
 
 extern "C" int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const uint8_t* mask, float* out,
@@ -667,15 +667,16 @@ extern "C" int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const 
   mm_plan(B, T, D, nvec, DC, TS, TR);
   dim3 g1(DC, TS, B);
   float* partial = reinterpret_cast<float*>(workspace);
+  float* pcount = partial + (size_t)B * TS * D;
   const bool vec = vec_ok(S, lds, D, nvec, dtype == SMX_BF16 ? 2 : 4);
   if (dtype == SMX_BF16) {
-    if (vec) hipLaunchKernelGGL((masked_sum_stage1<bf16_t, true>), g1, dim3(256), 0, STREAM, (const bf16_t*)S, lds, mask, partial, T, D, TR, TS);
-    else hipLaunchKernelGGL((masked_sum_stage1<bf16_t, false>), g1, dim3(256), 0, STREAM, (const bf16_t*)S, lds, mask, partial, T, D, TR, TS);
+    if (vec) hipLaunchKernelGGL((masked_sum_stage1<bf16_t, true>), g1, dim3(256), 0, STREAM, (const bf16_t*)S, lds, mask, partial, pcount, T, D, TR, TS);
+    else hipLaunchKernelGGL((masked_sum_stage1<bf16_t, false>), g1, dim3(256), 0, STREAM, (const bf16_t*)S, lds, mask, partial, pcount, T, D, TR, TS);
   } else if (dtype == SMX_F32) {
-    if (vec) hipLaunchKernelGGL((masked_sum_stage1<float, true>), g1, dim3(256), 0, STREAM, (const float*)S, lds, mask, partial, T, D, TR, TS);
-    else hipLaunchKernelGGL((masked_sum_stage1<float, false>), g1, dim3(256), 0, STREAM, (const float*)S, lds, mask, partial, T, D, TR, TS);
+    if (vec) hipLaunchKernelGGL((masked_sum_stage1<float, true>), g1, dim3(256), 0, STREAM, (const float*)S, lds, mask, partial, pcount, T, D, TR, TS);
+    else hipLaunchKernelGGL((masked_sum_stage1<float, false>), g1, dim3(256), 0, STREAM, (const float*)S, lds, mask, partial, pcount, T, D, TR, TS);
   } else return fail(SMX_EINVAL, "smx_masked_mean_fwd: bad dtype");
-  hipLaunchKernelGGL(masked_sum_stage2, dim3((D + 255) / 256, B), dim3(256), 0, STREAM, partial, mask, out, inv_count, T, D, TS, scale_by_count);
+  hipLaunchKernelGGL(masked_sum_stage2, dim3((D + 255) / 256, B), dim3(256), 0, STREAM, partial, pcount, out, inv_count, T, D, TS, scale_by_count);
   return check_launch("smx_masked_mean_fwd");
 }
 
