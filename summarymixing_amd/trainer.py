@@ -40,7 +40,7 @@ class FlatAdamW:
             self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
             p.data = self.flat_p[o:o + n].view(p.shape)
             p.grad = self.flat_g[o:o + n].view(p.shape)
-        if self.shadow is not None:
+        if self.shadow is not None and dev.type == "cuda":
             ops.L.check(ops.L.lib().smx_cast_from_f32(ops.L.BF16, ops._p(self.flat_p), ops._p(self.shadow), total,
                                                       ops._stream()), "smx_cast_from_f32")
             for p, o in zip(self.params, offs):
@@ -81,7 +81,10 @@ class FlatAdamW:
                 w.wait()
             self._pending = []
         self.step_count += 1
-        gscale = 1.0 / self.world
+        self._apply_update(1.0 / self.world)
+
+    def _apply_update(self, gscale):
+        """Global-norm clip + AdamW + bf16 shadow refresh: three HIP kernel launches, nothing visits the host."""
         clip = None
         if self.max_grad_norm is not None and self.max_grad_norm > 0:
             self._sumsq.zero_()
