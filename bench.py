@@ -45,11 +45,11 @@ CONFIGS = {
 FLOPS_PER_FRAME_FWD = {"c2b": 36.7e6, "c2a": 145.7e6}
 
 
-def build_encoder(cfg, device):
+def build_encoder(cfg, device, dropout=0.0):
     from summarymixing_amd.lobes.models.transformer.TransformerASR import EncoderWrapper, TransformerASR
     torch.manual_seed(3407)   # recipe seed (…transducer.yaml:12)
     kw = dict(tgt_vocab=1000, input_size=cfg["input"], d_model=cfg["d"], nhead=cfg["nhead"],
-              num_encoder_layers=cfg["layers"], num_decoder_layers=0, dropout=0.0, attention_type="SummaryMixing",
+              num_encoder_layers=cfg["layers"], num_decoder_layers=0, dropout=dropout, attention_type="SummaryMixing",
               local_proj_hid_dim=[cfg["l"]], local_proj_out_dim=cfg["l"], summary_hid_dim=[cfg["l"]], causal=False,
               kernel_size=31)
     if cfg["kind"] == "conformer":
@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--dropout", type=float, default=0.15, help="training-mode dropout (recipe: 0.15)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -194,7 +195,7 @@ def main():
     train = args.mode == "train"
 
     from summarymixing_amd.trainer import FlatAdamW
-    enc = build_encoder(cfg, dev)
+    enc = build_encoder(cfg, dev, args.dropout if train else 0.0)
     opt = None
     if train:
         opt = FlatAdamW(enc, lr=8e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
@@ -253,7 +254,7 @@ def main():
                    "per_gpu_batch": cfg["B"], "enc_frames_per_utt": cfg["T"], "global_batch": cfg["B"] * world,
                    "padded_frames_per_step": frames_per_step, "valid_frames_rank0": valid_frames,
                    "input": f"(B,T,{cfg['input']}) N(0,1), wav_len U(0.5,1), zero padded",
-                   "dropout": 0.0, "parallelism": f"dp{world}", "init": "xavier_normal seed 3407"},
+                   "dropout": (args.dropout if train else 0.0), "parallelism": f"dp{world}", "init": "xavier_normal seed 3407"},
     }
     if args.config in FLOPS_PER_FRAME_FWD:
         fl = FLOPS_PER_FRAME_FWD[args.config] * (3.0 if train else 1.0)

@@ -150,6 +150,14 @@ int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, const void* P,
 /* y = a*x (+ b*y0): generic strided elementwise helper (dtype T). */
 int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b, const void* Y0, int64_t ldy0, void* Y,
               int64_t ldy, int N, int D, void* stream);
+/* Inverted dropout with a counter-based generator: Y[n,c] = keep(seed, n*D+c) ? X[n,c]/(1-p) : 0 (in place allowed).
+ * The mask is a pure function of (seed, element index): calling it again on the gradient with the same seed is the
+ * backward.  Replaces nn.Dropout at summary_mixing.py:238,283, Conformer.py:157,461-472, TransformerASR.py:353. */
+int smx_dropout(int dtype, const void* X, int64_t ldx, void* Y, int64_t ldy, int N, int D, float p, uint64_t seed,
+                void* stream);
+/* Y[n,:] += table[n % R,:] (fp32 table): abs-sine positional encoding added after the input dropout
+ * (TransformerASR.py:547-549). */
+int smx_add_rowtable(int dtype, void* Y, int64_t ldy, const float* table, int R, int N, int D, void* stream);
 /* fp32 -> T cast of a flat buffer (bf16 shadow weights). */
 int smx_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream);
 int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* stream);

@@ -59,6 +59,8 @@ SIGNATURES = {
     "smx_dwconv1d_glu_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                    c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_axpby": (c_i, [c_i, c_f, c_vp, c_i64, c_f, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
+    "smx_dropout": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_f, ctypes.c_uint64, c_vp]),
+    "smx_add_rowtable": (c_i, [c_i, c_vp, c_i64, c_vp, c_i, c_i, c_i, c_vp]),
     "smx_cast_from_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
     "smx_cast_to_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
     "smx_adamw_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_vp, c_vp]),

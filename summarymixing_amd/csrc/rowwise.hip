@@ -638,6 +638,45 @@ __global__ void clip_factor_kernel(const float* sumsq, float max_norm, float inv
   out[0] = f < 1.f ? f : 1.f;
 }
 
+// counter-based dropout: keep(n, c) is a pure function of (seed, n * D + c), so the backward pass regenerates the
+// forward mask from the seed instead of storing it.  Two rounds of a 32-bit multiply/xorshift mix (lowbias32) on the
+// element index, XORed with a second mix of the seed for the high index bits.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+  const uint32_t h = mix32((uint32_t)idx ^ mix32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  return h >= thresh;                                  // P(drop) = thresh / 2^32
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* X, long ldx, T* Y, long ldy, int N_, int D, uint32_t thresh,
+                                                      float scale, uint64_t seed) {
+  const int cv = (D + 3) / 4;
+  const long total = (long)N_ * cv;
+  const bool vec = (D & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ((uintptr_t)X % (4 * sizeof(T))) == 0 &&
+                   ((uintptr_t)Y % (4 * sizeof(T))) == 0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / cv), col = (int)(i % cv) * 4, nvalid = D - col;
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) load4<T>(X + (long)n * ldx + col, f);
+    else { for (int q = 0; q < 4; ++q) if (q < nvalid) f[q] = to_f32(X[(long)n * ldx + col + q]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[q] = dropout_keep(seed, (uint64_t)n * D + col + q, thresh) ? f[q] * scale : 0.f;
+    if (vec) store4<T>(Y + (long)n * ldy + col, f);
+    else { for (int q = 0; q < 4; ++q) if (q < nvalid) Y[(long)n * ldy + col + q] = from_f32<T>(f[q]); }
+  }
+}
+// Y[n, :] += table[n % R, :]   (fp32 table; the abs-sine positional encoding added after the input dropout)
+template <typename T>
+__global__ __launch_bounds__(256) void add_rowtable_kernel(T* Y, long ldy, const float* table, int R, int N_, int D) {
+  const long total = (long)N_ * D;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / D), c = (int)(i % D);
+    Y[(long)n * ldy + c] = from_f32<T>(to_f32(Y[(long)n * ldy + c]) + table[(long)(n % R) * D + c]);
+  }
+}
+
 static inline int grid1d(long n) {
   long b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -840,6 +879,27 @@ extern "C" int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b
     else hipLaunchKernelGGL((axpby_kernel<float, false>), dim3(grid), dim3(256), 0, STREAM, a, (const float*)X, ldx, b, (const float*)Y0, ldy0, (float*)Y, ldy, N, D);
   }
   return check_launch("smx_axpby");
+}
+
+extern "C" int smx_dropout(int dtype, const void* X, int64_t ldx, void* Y, int64_t ldy, int N, int D, float p,
+                           uint64_t seed, void* stream) {
+  SMX_REQUIRE(X && Y && p >= 0.f && p < 1.f, "smx_dropout: bad arguments (0 <= p < 1)");
+  if (N <= 0 || D <= 0) return SMX_OK;
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  const float scale = 1.f / (1.f - p);
+  int grid = grid1d((long)N * ((D + 3) / 4));
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)X, ldx, (bf16_t*)Y, ldy, N, D, thresh, scale, seed);
+  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, STREAM, (const float*)X, ldx, (float*)Y, ldy, N, D, thresh, scale, seed);
+  return check_launch("smx_dropout");
+}
+
+extern "C" int smx_add_rowtable(int dtype, void* Y, int64_t ldy, const float* table, int R, int N, int D, void* stream) {
+  SMX_REQUIRE(Y && table && R > 0, "smx_add_rowtable: bad arguments");
+  if (N <= 0 || D <= 0) return SMX_OK;
+  int grid = grid1d((long)N * D);
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((add_rowtable_kernel<bf16_t>), dim3(grid), dim3(256), 0, STREAM, (bf16_t*)Y, ldy, table, R, N, D);
+  else hipLaunchKernelGGL((add_rowtable_kernel<float>), dim3(grid), dim3(256), 0, STREAM, (float*)Y, ldy, table, R, N, D);
+  return check_launch("smx_add_rowtable");
 }
 
 extern "C" int smx_cast_from_f32(int dtype, const float* src, void* dst, int64_t n, void* stream) {

@@ -243,7 +243,7 @@ def _dense_pool_bwd(dsbar, B, T, Wn, ds_out):
 # ----------------------------------------------------------------------------------------------------
 # the SummaryMixing cell
 # ----------------------------------------------------------------------------------------------------
-def cell_run(P, cfg, B, T, mask, sum_mask, skip_is_input_res=None):
+def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
     """Build run(x, need_bwd) for the cell.  P: parameter dict, cfg: mode/act/l.
     Returns a closure operating on (B,T,d) tensors.  `skip_is_input_res`: optional (N,s) residual added to the
     output (Conformer `x + skip`, Conformer.py:530) -- its gradient is returned by bwd as a second value."""
@@ -317,7 +317,21 @@ def cell_run(P, cfg, B, T, mask, sum_mask, skip_is_input_res=None):
         Wm = wcast(mg["W"], dtype)                                              # (s_out, l + sdim)
         lw = local.shape[1]
         Wl, Ws = Wm[:, :lw], Wm[:, lw:]
-        if pool_kind == "mean":
+        cat = s1 = s2 = None
+        if p_drop > 0.0:
+            # training: dropout acts on cat[local, repeat(sbar)] per FRAME (summary_mixing.py:237-239,282-284), which
+            # breaks the per-utterance factorisation -> materialise the dropped concatenation once and run K = l + s
+            s1, s2 = ops.new_dropout_seed(), ops.new_dropout_seed()
+            cat = torch.empty((N, lw + sdim), dtype=dtype, device=dev)
+            ops.dropout(local, p_drop, s1, out=cat[:, :lw])
+            if pool_kind == "mean":
+                ops.bcast_rows(sbar, None, cat[:, lw:], B, T)
+                ops.dropout(cat[:, lw:], p_drop, s2, out=cat[:, lw:])
+            else:
+                ops.dropout(sbar, p_drop, s2, out=cat[:, lw:])
+            sbar_t = None
+            y, zm = linear_fwd(cat, Wm, mg["b"], act, None, res=res, save_z=need_bwd)
+        elif pool_kind == "mean":
             sbar_t = ops.cast(sbar, dtype)                                         # (B, sdim) in compute dtype
             c0, _ = linear_fwd(sbar_t, Ws, None, out_f32=True)                     # (B, s_out) fp32
             y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_GROUP, c0_div=T,
@@ -341,7 +355,18 @@ def cell_run(P, cfg, B, T, mask, sum_mask, skip_is_input_res=None):
             else:
                 dlocal_out = torch.empty((N, lw), dtype=dtype, device=dev)
                 ds_out = torch.empty((N, sdim), dtype=dtype, device=dev)
-            if pool_kind == "mean":
+            if p_drop > 0.0:
+                dcat, _ = linear_bwd(dy, cat, Wm, zm, act, None, 1.0, gWm, gbm, True, None)
+                ops.dropout(dcat[:, :lw], p_drop, s1, out=dlocal_out)
+                ops.dropout(dcat[:, lw:], p_drop, s2, out=dcat[:, lw:])
+                if pool_kind == "mean":
+                    dsbar, _ = ops.masked_mean(dcat[:, lw:], None, B, T, scale=False)      # sum over time
+                    ops.bcast_rows(dsbar, inv, ds_out, B, T)
+                elif pool_kind == "chunk":
+                    ops.chunk_mean(dcat[:, lw:], ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
+                else:
+                    _dense_pool_bwd(dcat[:, lw:], B, T, Wn, ds_out)
+            elif pool_kind == "mean":
                 dc0 = torch.zeros((B, s_out), dtype=torch.float32, device=dev)
                 _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
                                     True, None, dgroup=dc0, gdiv=T, dx_out=dlocal_out)
@@ -384,42 +409,74 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE):
     return y, (bwd if need_bwd else None)
 
 
-def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5):
-    """y = x + alpha * W2 act(W1 LN(x) + b1) + b2   (Conformer.py:458-472,507,536)."""
+def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
+    """y = x + alpha * D2(W2 D1(act(W1 LN(x) + b1)) + b2)   (Conformer.py:458-472,507,536; D = dropout, p = 0 in eval).
+    With p == 0 the second Linear's epilogue carries the residual and alpha (no extra pass)."""
     h, ln_b = ln_fwd(x, P["ln_w"], P["ln_b"], 1e-5, need_bwd)
     W1, W2 = wcast(P["W1"], dtype), wcast(P["W2"], dtype)
     a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd)
-    y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha)
+    if p == 0.0:
+        y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha)
+        if not need_bwd:
+            return y, None
+
+        def bwd(dy):
+            da, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]))
+            dh, _ = linear_bwd(da, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]))
+            return ln_b(dh, res=dy)
+        return y, bwd
+    s1, s2 = ops.new_dropout_seed(), ops.new_dropout_seed()
+    ops.dropout(a, p, s1, out=a)
+    t, _ = linear_fwd(a, W2, P["b2"])
+    ops.dropout(t, p, s2, out=t)
+    y = ops.axpby(alpha, t, 1.0, x)
     if not need_bwd:
         return y, None
 
-    def bwd(dy):
-        da, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]))
+    def bwd_d(dy):
+        dt = ops.dropout(dy, p, s2)
+        da, _ = linear_bwd(dt, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]))
+        ops.dropout(da, p, s1, out=da)
         dh, _ = linear_bwd(da, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]))
         return ln_b(dh, res=dy)
-    return y, bwd
+    return y, bwd_d
 
 
-def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True):
+def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True, p=0.0):
     """y = [x +] mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534)."""
     d = x.shape[1]
     h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd)
     Wp = wcast(P["Wp"], dtype).view(2 * d, d)                    # Conv1d(d,2d,1) weight viewed as a Linear
-    p, _ = linear_fwd(h, Wp, P["bp"])
+    p_, _ = linear_fwd(h, Wp, P["bp"])
     k = P["wd"].shape[-1]
     wd = P["wd"].detach().reshape(d, k)
-    c = ops.dwconv_fwd(p, wd, P["bd"].detach() if P["bd"] is not None else None, B, T, d, k, True, L.PAD_ZERO, chunk)
+    c = ops.dwconv_fwd(p_, wd, P["bd"].detach() if P["bd"] is not None else None, B, T, d, k, True, L.PAD_ZERO, chunk)
     a, ln2_b = ln_fwd(c, P["ln2_w"], P["ln2_b"], 1e-5, need_bwd, act)      # LN + activation fused
     Wo = wcast(P["Wo"], dtype)
-    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None)
+    seed = None
+    if p == 0.0:
+        y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None)
+    else:                                            # Linear -> Dropout -> * mask (+ x)   (Conformer.py:156-157,327-331)
+        seed = ops.new_dropout_seed()
+        t, _ = linear_fwd(a, Wo, P["bo"])
+        ops.dropout(t, p, seed, out=t)
+        if mask is not None:
+            ops.act_mask_bwd(t, None, mask, L.ACT_NONE, 1.0, t)       # elementwise row-mask multiply, in place
+        y = ops.axpby(1.0, t, 1.0, x) if residual else t
     if not need_bwd:
         return y, None
 
     def bwd(dy):
-        da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]))
+        if p == 0.0:
+            da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]))
+        else:
+            dt = torch.empty_like(dy)
+            ops.act_mask_bwd(dy, None, mask, L.ACT_NONE, 1.0, dt)
+            ops.dropout(dt, p, seed, out=dt)
+            da, _ = linear_bwd(dt, a, Wo, None, L.ACT_NONE, None, 1.0, gacc(P["Wo"]), gacc(P["bo"]))
         dc = ln2_b(da)
         gwd = gacc(P["wd"])
-        dp, _ = ops.dwconv_bwd(dc, p, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
+        dp, _ = ops.dwconv_bwd(dc, p_, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
                                gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
         dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
         return ln1_b(dh, res=dy if residual else None)
@@ -438,21 +495,30 @@ def final_norm(x3, ln):
 
 
 
-def input_proj_pe(src3, W, b, pe, T):
-    """x = src W^T + b + PE[t]  (TransformerASR.py:542,547-549): the abs-sine table enters the GEMM epilogue as
-    a per-frame side input indexed n % T, so the add costs no extra pass."""
+def input_proj_pe(src3, W, b, pe, T, p=0.0):
+    """x = D(src W^T + b) + PE[t]  (TransformerASR.py:349-354,542,547-549).  Without dropout the abs-sine table enters
+    the GEMM epilogue as a per-frame side input indexed n % T, so the add costs no extra pass."""
     B = src3.shape[0]
 
     def run(xin, need):
         dtype = xin.dtype
         x = ops.rows2d(xin)
         Wc = wcast(W, dtype)
-        y, _ = linear_fwd(x, Wc, b, c0=pe, c0_mode=L.C0_MOD, c0_div=T)
+        seed = None
+        if p == 0.0:
+            y, _ = linear_fwd(x, Wc, b, c0=pe, c0_mode=L.C0_MOD, c0_div=T)
+        else:
+            seed = ops.new_dropout_seed()
+            y, _ = linear_fwd(x, Wc, b)
+            ops.dropout(y, p, seed, out=y)
+            ops.add_rowtable(y, pe, T)
         if not need:
             return y.view(B, T, -1), None
 
         def bwd(dy3):
             dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+            if p != 0.0:
+                dy = ops.dropout(dy, p, seed)
             dx, _ = linear_bwd(dy, x, Wc, None, L.ACT_NONE, None, 1.0, gacc(W), gacc(b), need_dx=xin.requires_grad)
             return dx.view(xin.shape) if dx is not None else None
         return y.view(B, T, -1), bwd

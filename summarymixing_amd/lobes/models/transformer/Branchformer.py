@@ -88,7 +88,9 @@ class BranchformerEncoderLayer(nn.Module):
 
     def make_run(self, B, T, m8, src_mask):
         act = self.act
-        cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask)
+        pd = self.p_drop if self.training else 0.0
+        cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask,
+                          self.mha_layer.global_dropout if self.training else 0.0)
         Pb = self.convolution_branch.params()
         merge = self.merge_proj.specs()
         nm, nc = self.norm_mhsa.norm, self.norm_conv.norm
@@ -116,16 +118,28 @@ class BranchformerEncoderLayer(nn.Module):
             g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1)
             # both branches land in one (N, c1 + d) buffer = the merge input (no torch.cat)
             cat = torch.empty((N, c1 + d), dtype=dtype, device=dev)
-            ops.axpby(1.0, y1, out=cat[:, :c1])
+            sd1 = sd2 = sd3 = None
+            if pd > 0.0:                                    # dropout on both branches and on the merge (:279,295,334)
+                sd1, sd2, sd3 = ops.new_dropout_seed(), ops.new_dropout_seed(), ops.new_dropout_seed()
+                ops.dropout(y1, pd, sd1, out=cat[:, :c1])
+            else:
+                ops.axpby(1.0, y1, out=cat[:, :c1])
             F.linear_fwd(g, Wpost, Pb["bpost"], out=cat[:, c1:])
+            if pd > 0.0:
+                ops.dropout(cat[:, c1:], pd, sd2, out=cat[:, c1:])
             m_out, sv_m = F.mlp_fwd(cat, merge, act, None, need, dtype)
+            if pd > 0.0:
+                ops.dropout(m_out, pd, sd3, out=m_out)
             y = ops.axpby(1.0, x, 1.0, m_out)                                          # x + merge (:279)
             if not need:
                 return y.view(B, T, d), None
 
             def bwd(dy3):
                 dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
-                dcat = F.mlp_bwd(dy, merge, act, sv_m, dtype)
+                dcat = F.mlp_bwd(ops.dropout(dy, pd, sd3) if pd > 0.0 else dy, merge, act, sv_m, dtype)
+                if pd > 0.0:
+                    ops.dropout(dcat[:, :c1], pd, sd1, out=dcat[:, :c1])
+                    ops.dropout(dcat[:, c1:], pd, sd2, out=dcat[:, c1:])
                 # branch 2 backward
                 dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]))
                 du = torch.empty_like(u)

@@ -46,9 +46,8 @@ def _ffn_params(seq):
 
 
 def _check_dropout(module, p, what):
-    if module.training and p > 0.0:
-        raise NotImplementedError(f"{what}: training-mode dropout (p={p}) is not implemented in the HIP path yet; "
-                                  "use dropout=0.0 or .eval()")
+    """Kept for API stability: training-mode dropout is implemented (counter-based smx_dropout)."""
+    return None
 
 
 class ConvolutionModule(nn.Module):
@@ -84,10 +83,11 @@ class ConvolutionModule(nn.Module):
         m8 = F.mask_u8(mask.reshape(B, T) if mask is not None else None, B, T, x.device)
         P, act = self.params(), self.act
         chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
+        pd = self.p_drop if self.training else 0.0
 
         def run(xin, need_bwd):
             x2 = ops.rows2d(xin)
-            y, bwd = F.conv_module_fwd(x2, P, act, m8, B, T, need_bwd, xin.dtype, chunk, residual=False)
+            y, bwd = F.conv_module_fwd(x2, P, act, m8, B, T, need_bwd, xin.dtype, chunk, residual=False, p=pd)
             return y.view(B, T, d), ((lambda dy: bwd(ops.rows2d(dy.contiguous())).view(B, T, d)) if need_bwd else None)
         return F.block(x, run, list(self.parameters()))
 
@@ -119,17 +119,19 @@ class ConformerEncoderLayer(nn.Module):
         P1, P2 = _ffn_params(self.ffn_module1), _ffn_params(self.ffn_module2)
         Pc = self.convolution_module.params()
         n1, n2 = self.norm1.norm, self.norm2.norm
-        cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask)
+        pd = self.p_drop if self.training else 0.0
+        cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask,
+                          self.mha_layer.global_dropout if self.training else 0.0)
 
         def run(x3, need):
             dtype = x3.dtype
             x = ops.rows2d(x3)
-            y1, b1 = F.ffn_module_fwd(x, P1, d_act, need, dtype)                       # :507
+            y1, b1 = F.ffn_module_fwd(x, P1, d_act, need, dtype, p=pd)                 # :507
             h, bn1 = F.ln_fwd(y1, n1.weight, n1.bias, n1.eps, need)                    # :510
             y2_3, bcell = cell(h.view(B, T, -1), need, res=y1)                        # :512-530 (skip fused)
             y2 = ops.rows2d(y2_3)
-            y3, bconv = F.conv_module_fwd(y2, Pc, d_act, m8, B, T, need, dtype, chunk)  # :532-534
-            y4, bf2 = F.ffn_module_fwd(y3, P2, d_act, need, dtype)
+            y3, bconv = F.conv_module_fwd(y2, Pc, d_act, m8, B, T, need, dtype, chunk, p=pd)  # :532-534
+            y4, bf2 = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd)
             y5, bn2 = F.ln_fwd(y4, n2.weight, n2.bias, n2.eps, need)                   # :536
             if not need:
                 return y5.view(B, T, -1), None

@@ -135,8 +135,6 @@ class TransformerASR(nn.Module):
         raise NotImplementedError("the seq2seq decoder is outside the SummaryMixing hot path; call .encode()")
 
     def encode(self, src, wav_len=None, pad_idx=0, dynchunktrain_config=None, masked_false_or_true: Optional[bool] = True):
-        if self.training and self.p_drop > 0.0:
-            raise NotImplementedError("training-mode dropout is not implemented in the HIP path yet")
         if src.dim() == 4:
             bz, t, ch1, ch2 = src.shape
             src = src.reshape(bz, t, ch1 * ch2)
@@ -151,7 +149,7 @@ class TransformerASR(nn.Module):
             pe = self.positional_encoding.pe[0, :T]
         else:
             pe = torch.zeros((T, lin.weight.shape[0]), device=src.device)
-        x = F.input_proj_pe(src, lin.weight, lin.bias, pe, T)
+        x = F.input_proj_pe(src, lin.weight, lin.bias, pe, T, self.p_drop if self.training else 0.0)
         out, _ = self.encoder(src=x, src_mask=src_mask, src_key_padding_mask=key_padding_mask, pos_embs=None,
                               dynchunktrain_config=dynchunktrain_config)
         return out

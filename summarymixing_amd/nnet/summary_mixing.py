@@ -60,16 +60,17 @@ class SummaryMixing(nn.Module):
             P["decay_constant"] = self.decay_constant
         return P
 
+    def drop_p(self):
+        """Dropout probability in effect (reference: nn.Dropout(global_dropout), active in train() only)."""
+        return self.global_dropout if self.training else 0.0
+
     def _cfg(self):
         return {"mode": self.mode, "act": self.act, "local_proj_out_dim": self.local_proj_out_dim}
 
     def forward(self, x, sum_mask=None, src_padding_mask=None):
         """x (B,T,enc_dim) on the GPU, float32 or bfloat16; src_padding_mask (B,T) True = valid frame;
         sum_mask (T,T) tensor or functional.DynChunkMask."""
-        if self.training and self.global_dropout > 0.0:
-            raise NotImplementedError("training-mode dropout inside the cell is not implemented yet: construct with "
-                                      "global_dropout=0.0 or call .eval()")
         B, T, _ = x.shape
         mask = F.mask_u8(src_padding_mask, B, T, x.device)
-        run = F.cell_run(self._params(), self._cfg(), B, T, mask, sum_mask)
+        run = F.cell_run(self._params(), self._cfg(), B, T, mask, sum_mask, self.drop_p())
         return F.block(x, run, list(self.parameters()))

@@ -204,6 +204,34 @@ def axpby(a, x, b=0.0, y0=None, out=None):
     return out
 
 
+_drop_state = {"counter": 0}
+
+
+def new_dropout_seed():
+    """A fresh 64-bit seed per dropout site and call, derived from torch's global seed and a call counter (no
+    device sync)."""
+    _drop_state["counter"] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _drop_state["counter"] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout(x, p, seed, out=None):
+    """out = dropout(x) with the counter-based mask of `seed` (call again on the gradient for the backward)."""
+    N, D = x.shape
+    if out is None:
+        out = torch.empty((N, D), dtype=x.dtype, device=x.device)
+    px, ldx = _mat(x)
+    po, ldo = _mat(out)
+    L.check(L.lib().smx_dropout(dt(x), px, ldx, po, ldo, N, D, p, seed, _stream()), "smx_dropout")
+    return out
+
+
+def add_rowtable(y, table, R):
+    N, D = y.shape
+    py, ldy = _mat(y)
+    L.check(L.lib().smx_add_rowtable(dt(y), py, ldy, _p(table), R, N, D, _stream()), "smx_add_rowtable")
+    return y
+
+
 def cast(src, dtype):
     """fp32 <-> compute dtype through the library's cast kernels (contiguous tensors)."""
     if src.dtype == dtype:

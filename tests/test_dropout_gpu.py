@@ -1,0 +1,85 @@
+"""Training-mode dropout on the HIP path: keep rate / scaling, mask determinism per seed, backward uses the forward
+mask (gradient consistency), eval() == dropout-free, and the reference's placement (per-frame dropout of the
+concatenated [local, summary], summary_mixing.py:237-239,282-284)."""
+import pytest
+import torch
+
+from tests._util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dropout_kernel_statistics_and_determinism():
+    from summarymixing_amd import ops
+    x = torch.ones(4096, 512, device="cuda", dtype=torch.bfloat16)
+    for p in (0.1, 0.15, 0.5):
+        y = ops.dropout(x, p, 1234)
+        keep = (y != 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 3e-3
+        assert abs(y.float().mean().item() - 1.0) < 1e-2                    # inverted dropout preserves the mean
+        assert torch.equal(y, ops.dropout(x, p, 1234))                      # same seed -> same mask
+        assert not torch.equal(y, ops.dropout(x, p, 1235))
+    # strided views address the same mask by (row, col)
+    big = torch.ones(100, 64, device="cuda")
+    a = ops.dropout(big[:, :32], 0.3, 7)
+    b = torch.empty(100, 64, device="cuda")
+    ops.dropout(big[:, :32], 0.3, 7, out=b[:, 32:])
+    assert torch.equal(a, b[:, 32:])
+    # no obvious structure along rows / columns
+    m = (ops.dropout(torch.ones(2048, 256, device="cuda"), 0.5, 99) != 0).float()
+    assert (m.mean(0) - 0.5).abs().max() < 0.06 and (m.mean(1) - 0.5).abs().max() < 0.15
+
+
+@pytest.mark.parametrize("mode", ["SummaryMixing-fast", "SummaryMixing"])
+def test_cell_dropout_backward_uses_forward_mask(mode):
+    """y is piecewise linear in x for relu; with a fixed seed stream the directional derivative must equal <dx, v>."""
+    from summarymixing_amd import ops
+    from summarymixing_amd.nnet.summary_mixing import SummaryMixing
+    torch.manual_seed(0)
+    m = SummaryMixing(32, 2, [32], 32, [32], 32, activation="swish", global_dropout=0.3, mode=mode).cuda().train()
+    x = torch.randn(3, 40, 32, device="cuda", requires_grad=True)
+    pad = (torch.arange(40, device="cuda")[None] < torch.tensor([40, 23, 31], device="cuda")[:, None])
+    r = torch.randn(3, 40, 32, device="cuda")
+
+    def f(xx):
+        ops._drop_state["counter"] = 1000          # replay the same seed stream -> same masks
+        return (m(xx, src_padding_mask=pad) * r).sum()
+    y = f(x)
+    y.backward()
+    v = torch.randn_like(x)
+    eps = 1e-3
+    with torch.no_grad():
+        num = (f(x + eps * v) - f(x - eps * v)) / (2 * eps)
+    ana = (x.grad * v).sum()
+    assert abs(num.item() - ana.item()) <= 2e-2 * max(1.0, abs(ana.item())), (num.item(), ana.item())
+    # eval() disables it and matches the dropout-free module
+    m.eval()
+    m2 = SummaryMixing(32, 2, [32], 32, [32], 32, activation="swish", global_dropout=0.0, mode=mode).cuda()
+    m2.load_state_dict(m.state_dict())
+    assert rel_err(m(x.detach(), src_padding_mask=pad), m2(x.detach(), src_padding_mask=pad)) < 1e-6
+
+
+def test_conformer_layer_trains_with_dropout():
+    from summarymixing_amd import ops
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoderLayer
+    torch.manual_seed(1)
+    d = 64
+    layer = ConformerEncoderLayer(d_model=d, d_ffn=128, nhead=4, kernel_size=31, activation="swish", dropout=0.15,
+                                  attention_type="SummaryMixing", local_proj_hid_dim=[d], local_proj_out_dim=d,
+                                  summary_hid_dim=[d], mode="SummaryMixing-fast").cuda().train()
+    x = torch.randn(4, 70, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    pad = (torch.arange(70, device="cuda")[None] < torch.tensor([70, 33, 51, 64], device="cuda")[:, None])
+    ops._drop_state["counter"] = 5
+    y1, _ = layer(x, src_key_padding_mask=pad)
+    y1.float().sum().backward()
+    assert torch.isfinite(y1).all() and torch.isfinite(x.grad).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
+    ops._drop_state["counter"] = 5
+    y2, _ = layer(x, src_key_padding_mask=pad)
+    assert torch.equal(y1, y2)                                             # same seeds -> bit-identical
+    y3, _ = layer(x, src_key_padding_mask=pad)
+    assert not torch.equal(y1, y3)                                         # fresh seeds -> different masks
+    layer.eval()
+    ye1, _ = layer(x, src_key_padding_mask=pad)
+    ye2, _ = layer(x, src_key_padding_mask=pad)
+    assert torch.equal(ye1, ye2)
