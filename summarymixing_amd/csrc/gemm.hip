@@ -340,8 +340,8 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
       if (vec) {
         if constexpr (sizeof(T) == 2 && CW == 8) {
           uint4 u;
-          u.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16); u.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
-          u.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16); u.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+          u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+          u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
           *reinterpret_cast<uint4*>(zp) = u;
         } else {
           store4<T>(zp, reinterpret_cast<const float(&)[4]>(v));
@@ -378,8 +378,8 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         uint4 u;
-        u.x = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16); u.y = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
-        u.z = f32_to_bf16_bits(v[4]) | (f32_to_bf16_bits(v[5]) << 16); u.w = f32_to_bf16_bits(v[6]) | (f32_to_bf16_bits(v[7]) << 16);
+        u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+        u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>(dst) = u;
       }
     } else {
@@ -416,16 +416,32 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
   SMX_STAMP(0);
   const int l31 = lane & 31, hi = lane >> 5;
 
-  // XCD-aware tile mapping: consecutive remapped ids walk the M tiles of one row panel
-  int ntiles = p.tiles_n * p.tiles_m;
-  int bid = blockIdx.x;
+  // XCD-aware work mapping (workgroup b runs on XCD b % 8, each XCD has its own L2):
+  //  * splits == 1: consecutive remapped ids walk the M tiles of one A row panel, so a panel is fetched into ONE L2;
+  //  * split-K (wgrad): all tiles of one K-range read the same operand rows, so a whole split is given to one XCD
+  //    (XCD x owns splits x, x+8, ...).  With the naive (tile, split) grid every XCD streamed every input row:
+  //    8x the HBM/fabric traffic.
+  int tile_n, tile_m, bz, split;
   {
-    int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int ntiles = p.tiles_n * p.tiles_m;
+    if (p.splits == 1) {
+      int bid = blockIdx.x;
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      tile_n = bid / p.tiles_m; tile_m = bid % p.tiles_m;
+      bz = blockIdx.y; split = 0;
+    } else {
+      const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+      const int per = ntiles * p.batch;                 // work items of one split
+      const int item = idx % per;
+      split = (idx / per) * 8 + xcd;
+      if (split >= p.splits) return;
+      bz = item / ntiles;
+      const int tl = item % ntiles;
+      tile_n = tl / p.tiles_m; tile_m = tl % p.tiles_m;
+    }
   }
-  const int tile_n = bid / p.tiles_m, tile_m = bid % p.tiles_m;
   const int n0 = tile_n * TILE_N, m0 = tile_m * TILE_M;
-  const int bz = blockIdx.y / p.splits, split = blockIdx.y % p.splits;
   const int kbeg = split * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
 
@@ -569,7 +585,8 @@ template <typename T, bool A_KC, bool B_KC, int TN, int TM>
 static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
   p.tiles_n = (p.N + TN - 1) / TN;
   p.tiles_m = (p.M + TM - 1) / TM;
-  dim3 grid(p.tiles_n * p.tiles_m, p.batch * p.splits);
+  dim3 grid(p.tiles_n * p.tiles_m, p.batch);
+  if (p.splits > 1) grid = dim3(8 * p.tiles_n * p.tiles_m * p.batch * ((p.splits + 7) / 8), 1);
   if (vec) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, TN, TM, true>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, TN, TM, false>), grid, dim3(256), 0, s, p);
   return check_launch("smx_gemm");

@@ -39,10 +39,10 @@ __device__ __forceinline__ void storev(T* p, int nvalid, const float (&f)[VT<T>:
   if (VEC && nvalid >= N) {
     if constexpr (sizeof(T) == 2) {
       uint4 r;
-      r.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
-      r.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
-      r.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16);
-      r.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+      r.x = pack_bf16x2(f[0], f[1]);
+      r.y = pack_bf16x2(f[2], f[3]);
+      r.z = pack_bf16x2(f[4], f[5]);
+      r.w = pack_bf16x2(f[6], f[7]);
       *reinterpret_cast<uint4*>(p) = r;
     } else {
       *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);

@@ -29,12 +29,16 @@ struct bf16_t {
 };
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                 // round to nearest even
-  return u >> 16;
+// fp32 -> bf16 goes through the hardware converter (v_cvt_pk_bf16_f32: round to nearest even, NaN preserving, two
+// values per instruction) instead of a ~7-instruction integer sequence: the conversions were a large share of the
+// VALU work of the GEMM epilogue and of every bf16 row-wise kernel.
+typedef __bf16 smx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float smx_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  smx_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, smx_bf16x2));
 }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) { return pack_bf16x2(f, 0.f) & 0xffffu; }
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return bf16_bits_to_f32(x.v); }
 template <typename T>
@@ -70,8 +74,8 @@ struct Vec4<bf16_t> {
   }
   static __device__ __forceinline__ raw pack(const float (&f)[4]) {
     uint2 r;
-    r.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
-    r.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+    r.x = pack_bf16x2(f[0], f[1]);
+    r.y = pack_bf16x2(f[2], f[3]);
     return r;
   }
 };
