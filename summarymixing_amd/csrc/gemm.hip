@@ -95,16 +95,12 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[4], const T* base, long 
     }
   } else if constexpr (sizeof(T) == 2 && !KC) {
     constexpr int RC = ROWS / 8;           // 16-byte row chunks per k row
-    constexpr int ITEMS = 16 * RC;         // (k quad, row chunk)
-    if (t < ITEMS) {
-      int rc = t % RC, kq = t / RC;
-      int rg = row0 + rc * 8;
-      int nv = rows_total - rg;
+    constexpr int NV = ROWS / 32;          // vectors per thread (64 k rows x RC chunks / 256 threads)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int kg = k0 + kq * 4 + j;
-        reg[j] = ld_contig<T, VEC>(base + (long)kg * ld + rg, kg < k1 ? nv : 0, base);
-      }
+    for (int i = 0; i < NV; ++i) {
+      const int v = t + 256 * i, rc = v % RC, k = v / RC;
+      const int rg = row0 + rc * 8, kg = k0 + k;
+      reg[i] = ld_contig<T, VEC>(base + (long)kg * ld + rg, kg < k1 ? rows_total - rg : 0, base);
     }
   } else if constexpr (sizeof(T) == 4 && KC) {
     constexpr int NV = ROWS / 32;
@@ -139,27 +135,14 @@ __device__ __forceinline__ void stage_store(const uint4 (&reg)[4], char* lds, in
       *reinterpret_cast<uint4*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = reg[i];
     }
   } else if constexpr (sizeof(T) == 2 && !KC) {
+    // plain copy into a [k][ROWS (+32 pad)] image: the transposition is done by ds_read_b64_tr_b16 on the way out
     constexpr int RC = ROWS / 8;
-    constexpr int ITEMS = 16 * RC;
-    if (t < ITEMS) {
-      int rc = t % RC, kq = t / RC;
-      const uint32_t* g0 = reinterpret_cast<const uint32_t*>(&reg[0]);
-      const uint32_t* g1 = reinterpret_cast<const uint32_t*>(&reg[1]);
-      const uint32_t* g2 = reinterpret_cast<const uint32_t*>(&reg[2]);
-      const uint32_t* g3 = reinterpret_cast<const uint32_t*>(&reg[3]);
-      int sw = (rc >> 1) & 3;
-      char* basep = lds + kq * (ROWS * 8) + (rc >> 2) * 256;
+    constexpr int NV = ROWS / 32;
+    constexpr int KSTRB = (ROWS + 32) * 2;
 #pragma unroll
-      for (int gr = 0; gr < 4; ++gr) {  // granule = rows (2gr, 2gr+1) of this 8-row chunk, 4 k each
-        uint32_t w0 = g0[gr], w1 = g1[gr], w2 = g2[gr], w3 = g3[gr];
-        uint4 o;
-        o.x = (w0 & 0xffffu) | (w1 << 16);          // even row: k0,k1
-        o.y = (w2 & 0xffffu) | (w3 << 16);          //           k2,k3
-        o.z = (w0 >> 16) | (w1 & 0xffff0000u);      // odd row:  k0,k1
-        o.w = (w2 >> 16) | (w3 & 0xffff0000u);      //           k2,k3
-        int pg = ((rc & 3) << 2) | (gr ^ sw);
-        *reinterpret_cast<uint4*>(basep + (pg << 4)) = o;
-      }
+    for (int i = 0; i < NV; ++i) {
+      const int v = t + 256 * i, rc = v % RC, k = v / RC;
+      *reinterpret_cast<uint4*>(lds + k * KSTRB + rc * 16) = reg[i];
     }
   } else if constexpr (sizeof(T) == 4 && KC) {
     constexpr int NV = ROWS / 32;
@@ -185,9 +168,9 @@ __device__ __forceinline__ void stage_store(const uint4 (&reg)[4], char* lds, in
   }
 }
 
-template <typename T, int ROWS>
+template <typename T, int ROWS, bool KC>
 constexpr int lds_bytes() {
-  return sizeof(T) == 2 ? ROWS * 128 : 32 * (ROWS + 4) * 4;
+  return sizeof(T) == 2 ? (KC ? ROWS * 128 : 64 * (ROWS + 32) * 2) : 32 * (ROWS + 4) * 4;
 }
 
 // ---- fragment reads ---------------------------------------------------------------------------------------
@@ -198,17 +181,26 @@ __device__ __forceinline__ bf16x8 frag_bf16(const char* lds, int r, int kk, int 
     uint4 v = *reinterpret_cast<const uint4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
     return __builtin_bit_cast(bf16x8, v);
   } else {
-    int kq = kk * 4 + hi * 2;
-    const char* p = lds + kq * (ROWS * 8) + (r >> 5) * 256 + ((((r & 31) >> 1) ^ ((r >> 4) & 3)) << 4) + (r & 1) * 8;
-    uint2 lo = *reinterpret_cast<const uint2*>(p);
-    uint2 hi2 = *reinterpret_cast<const uint2*>(p + ROWS * 8);
-    uint4 v = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+    // reduce-strided operand: LDS holds [k][ROWS+32] (k rows of the tile, row index contiguous).  One
+    // ds_read_b64_tr_b16 hands every lane of a 16-lane group the 4 consecutive k of ITS row (hardware 4x16
+    // transpose; verified by tools/tr_probe.hip); two of them make the 8-k MFMA fragment.  Row stride +64 B keeps the
+    // four k rows of a group and the neighbouring group on distinct banks.
+    constexpr int KSTR = ROWS + 32;
+    typedef short short4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) short4_t* lds_s4;
+    const int lane = (r & 31) | (hi << 5);              // r carries the lane's row; rebuild the lane id
+    const int li = lane & 15, g1 = (lane >> 4) & 1;
+    const int rbase = r - (r & 31);                     // fragment row base
+    const uint16_t* l16 = reinterpret_cast<const uint16_t*>(lds);
+    const uint16_t* p0 = l16 + (kk * 16 + hi * 8 + (li >> 2)) * KSTR + rbase + g1 * 16 + (li & 3) * 4;
+    const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
+    const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * KSTR));
+    const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+    uint4 v = make_uint4(ua.x, ua.y, ub.x, ub.y);
     return __builtin_bit_cast(bf16x8, v);
   }
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (its workgroup fence), which
-// would stall on the in-flight global prefetch of the next K tile / on the epilogue's global stores.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -401,8 +393,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
-  constexpr int A_BYTES = lds_bytes<T, TILE_N>();
-  constexpr int B_BYTES = lds_bytes<T, TILE_M>();
+  constexpr int A_BYTES = lds_bytes<T, TILE_N, A_KC>();
+  constexpr int B_BYTES = lds_bytes<T, TILE_M, B_KC>();
   constexpr int EPI_BYTES = (TILE_N / 2) * (TILE_M * 4 + 16);   // one half-tile of fp32 rows, 16 B row pad
   constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > EPI_BYTES ? (A_BYTES + B_BYTES) : EPI_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
