@@ -46,7 +46,7 @@ const char* smx_last_error(void);
 /* Epilogue of the fused projection GEMM:
  *   v      = acc + bias[m] + C0[map(n), m]
  *   Z[n,m] = v                                   (optional pre-activation store, dtype T)
- *   a      = act(v) * row_mask[n]
+ *   a      = dropout(act(v)) * row_mask[n]        (dropout: keep(seed, n*M+m) ? x/(1-p) : 0; off when drop_p == 0)
  *   C[n,m] = R[n,m] + alpha * a                  (R optional residual, dtype T)
  * With out_mode SMX_OUT_ATOMIC_F32: C (float32) += alpha * acc and every other epilogue field must be 0. */
 typedef struct smx_epilogue {
@@ -56,8 +56,11 @@ typedef struct smx_epilogue {
   void* z;             int64_t ldz;
   const uint8_t* row_mask;                               /* [N] 1 = valid frame, or NULL               */
   const void* res;     int64_t ldr;
-  float alpha;         int32_t reserved;
+  float alpha;         int32_t flags;                     /* SMX_EPI_C0_POST: add C0 after dropout/mask/alpha      */
+  float drop_p;        int32_t drop_pad;                  /* fused inverted dropout (0 = off), applied after act()  */
+  uint64_t drop_seed;                                     /* counter-based mask, same indexing as smx_dropout       */
 } smx_epilogue;
+enum { SMX_EPI_C0_POST = 1 };
 
 /* Batched strided MFMA GEMM  C[b] (N x M) = epilogue( op(A[b]) . op(B[b]) ), reduce length K.
  * Replaces: nn.Linear inside VanillaNN (VanillaNN.py:189-196, summary_mixing.py:207,210,237,257,282),
@@ -83,7 +86,8 @@ int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, c
 int smx_linear_act_mask_fwd(int dtype, const void* X, int64_t ldx, const void* W, int64_t ldw, void* Y,
                             int64_t ldy, int N, int M, int K, const smx_epilogue* epi, void* stream);
 
-/* dZ = dY * mask * act'(Z)  (elementwise), plus fused parameter-gradient side reductions:
+/* dZ = dropout_mask(seed) * dY * mask * act'(Z)  (elementwise; the mask of the forward's fused dropout is regenerated
+ * from the seed), plus fused parameter-gradient side reductions:
  *   dbias[m]          += sum_n dZ[n,m]                      (optional; per-strip partials in `workspace`,
  *                                                            smx_act_mask_bwd_workspace bytes, fixed-order reduce)
  *   dgroup[n/div, m]  += sum over the rows of group n/div   (fp32 atomics, optional; the backward of a
@@ -92,7 +96,8 @@ int smx_linear_act_mask_fwd(int dtype, const void* X, int64_t ldx, const void* W
 size_t smx_act_mask_bwd_workspace(int N, int M);
 int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
                      const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
-                     float* dbias, float* dgroup, int64_t lddgroup, int group_div, void* workspace, void* stream);
+                     float* dbias, float* dgroup, int64_t lddgroup, int group_div, float drop_p, uint64_t drop_seed,
+                     void* workspace, void* stream);
 
 /* Masked mean over time: out[b,:] = sum_t S[b,t,:] * mask[b,t] / sum_t mask[b,t]   (fp32 out (B,D)).
  * S is (B*T, D) with leading dimension lds.  mask NULL => all valid.  scale_by_count=0 gives the plain sum.

@@ -14,6 +14,7 @@ ACT_NONE, ACT_GELU, ACT_SWISH, ACT_LEAKY_RELU, ACT_RELU = 0, 1, 2, 3, 4
 C0_NONE, C0_ROW, C0_GROUP, C0_MOD = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_T, OUT_F32, OUT_ATOMIC_F32 = 0, 1, 2
+EPI_C0_POST = 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACTS = {"none": ACT_NONE, "identity": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH,
         "leaky_relu": ACT_LEAKY_RELU, "relu": ACT_RELU}
@@ -26,7 +27,8 @@ class Epilogue(ctypes.Structure):
                 ("z", c_vp), ("ldz", c_i64),
                 ("row_mask", c_vp),
                 ("res", c_vp), ("ldr", c_i64),
-                ("alpha", c_f), ("reserved", ctypes.c_int32)]
+                ("alpha", c_f), ("flags", ctypes.c_int32),
+                ("drop_p", c_f), ("drop_pad", ctypes.c_int32), ("drop_seed", ctypes.c_uint64)]
 
 
 # name -> (restype, argtypes); mirrors include/smx.h one to one (tests/test_abi.py checks the export list)
@@ -42,7 +44,7 @@ SIGNATURES = {
                                       ctypes.POINTER(Epilogue), c_vp]),
     "smx_act_mask_bwd_workspace": (c_sz, [c_i, c_i]),
     "smx_act_mask_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp,
-                               c_i64, c_i, c_vp, c_vp]),
+                               c_i64, c_i, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_masked_mean_workspace": (c_sz, [c_i, c_i, c_i]),
     "smx_masked_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_masked_mean_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_vp]),

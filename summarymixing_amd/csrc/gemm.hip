@@ -39,6 +39,7 @@ struct GemmParams {
   int epi_vec;
   int epi_lds;      // outputs are 16-byte addressable: stage the tile through LDS and store whole rows
   long sSplit;      // element stride between split-K slabs of C (out_mode F32)
+  unsigned dthresh; float dscale;   // fused dropout: drop if hash16 < dthresh>>16, survivors * dscale
   long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
   int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
 };
@@ -249,6 +250,8 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   constexpr int RSTEP = 256 / CPR;                      // rows covered per pass of the 256 threads
   constexpr int NIT = WN / RSTEP;                       // items per thread
   const smx_epilogue& e = p.e;
+  const uint32_t dthresh = p.dthresh;
+  const float dscale = p.dscale;
   const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
   if (m >= p.M) return;
   const int nv = min(CW, p.M - m);
@@ -285,7 +288,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
     mk[k] = ((e.row_mask && nok) ? (e.row_mask[n] ? 1.f : 0.f) : 1.f) * e.alpha;
 #pragma unroll
     for (int q = 0; q < CW; ++q) { cv[k][q] = 0.f; rv[k][q] = 0.f; }
-    if (e.c0_mode != SMX_C0_NONE && nok) {
+    if (e.c0_mode != SMX_C0_NONE && nok) {   // (added before the activation, or after everything with SMX_EPI_C0_POST)
       const float* c0p = e.c0 + c0_row(e, n) * e.ldc0 + m;
       if (vec) {
 #pragma unroll
@@ -324,8 +327,13 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
 #pragma unroll
     for (int q4 = 0; q4 < CW / 4; ++q4) {
       const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
-      v[4 * q4] = a4.x + bv[4 * q4] + cv[k][4 * q4]; v[4 * q4 + 1] = a4.y + bv[4 * q4 + 1] + cv[k][4 * q4 + 1];
-      v[4 * q4 + 2] = a4.z + bv[4 * q4 + 2] + cv[k][4 * q4 + 2]; v[4 * q4 + 3] = a4.w + bv[4 * q4 + 3] + cv[k][4 * q4 + 3];
+      v[4 * q4] = a4.x + bv[4 * q4]; v[4 * q4 + 1] = a4.y + bv[4 * q4 + 1];
+      v[4 * q4 + 2] = a4.z + bv[4 * q4 + 2]; v[4 * q4 + 3] = a4.w + bv[4 * q4 + 3];
+    }
+    const bool c0post = (e.flags & SMX_EPI_C0_POST) != 0;
+    if (!c0post) {
+#pragma unroll
+      for (int q = 0; q < CW; ++q) v[q] += cv[k][q];
     }
     if (Zb) {
       T* zp = Zb + (long)n * e.ldz + m;
@@ -362,8 +370,12 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
         break;
       default: break;
     }
+    if (dthresh) {                                       // fused inverted dropout, mask = f(seed, n * M + m)
 #pragma unroll
-    for (int q = 0; q < CW; ++q) v[q] = v[q] * mk[k] + rv[k][q];
+      for (int q = 0; q < CW; ++q) v[q] = dropout_keep(e.drop_seed, (uint64_t)n * p.M + m + q, dthresh) ? v[q] * dscale : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < CW; ++q) v[q] = v[q] * mk[k] + rv[k][q] + (c0post ? cv[k][q] : 0.f);
     char* dst = Cb + ((long)n * p.ldc + m) * OSZ;
     if (vec) {
       if constexpr (OSZ == 4) {
@@ -636,8 +648,9 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   }
   p.splits = splits;
   if (p.e.out_mode == SMX_OUT_ATOMIC_F32)
-    SMX_REQUIRE(!p.e.bias && !p.e.c0 && !p.e.z && !p.e.res && !p.e.row_mask && p.e.act == SMX_ACT_NONE,
+    SMX_REQUIRE(!p.e.bias && !p.e.c0 && !p.e.z && !p.e.res && !p.e.row_mask && p.e.act == SMX_ACT_NONE && p.e.drop_p == 0.f,
                 "smx_gemm: atomic output takes no epilogue");
+  SMX_REQUIRE(p.e.drop_p >= 0.f && p.e.drop_p < 1.f, "smx_gemm: 0 <= drop_p < 1");
   SMX_REQUIRE(p.e.c0_mode == SMX_C0_NONE || (p.e.c0 && (p.e.c0_mode == SMX_C0_ROW || p.e.c0_div > 0)),
               "smx_gemm: bad C0 spec");
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
@@ -667,6 +680,8 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
   p.ablate = ablate;
   p.dbg = g_dbg_stamps;
+  p.dthresh = (unsigned)((double)p.e.drop_p * 4294967296.0);
+  p.dscale = 1.f / (1.f - p.e.drop_p);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SMX_BF16) return launch_dtype<bf16_t>(layout, p, vec, s);
   return launch_dtype<float>(layout, p, vec, s);

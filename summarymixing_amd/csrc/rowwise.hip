@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void act_mask_bwd_vec_kernel(const T* __restri
                                                                long ldz, const uint8_t* __restrict__ mask, T* __restrict__ dZ,
                                                                long lddz, int N_, int M, int act, float alpha, float* dbias,
                                                                float* dgroup, long lddg, int gdiv, int RS, int LPR,
-                                                               float* __restrict__ partial) {
+                                                               float* __restrict__ partial, uint32_t dthresh, float dscale,
+                                                               uint64_t dseed) {
   constexpr int N = VT<T>::N;
   __shared__ float red[256][N];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -471,6 +472,10 @@ __global__ __launch_bounds__(256) void act_mask_bwd_vec_kernel(const T* __restri
         float o[N];
 #pragma unroll
         for (int q = 0; q < N; ++q) o[q] = fdy[u][q] * mk * (ACT != SMX_ACT_NONE ? act_grad_c<ACT>(fz[u][q]) : 1.f);
+        if (dthresh) {
+#pragma unroll
+          for (int q = 0; q < N; ++q) o[q] = dropout_keep(dseed, (uint64_t)n * M + col + q, dthresh) ? o[q] * dscale : 0.f;
+        }
         if (dZ) storev<T, true>(dZ + (long)n * lddz + col, N, o);
 #pragma unroll
         for (int q = 0; q < N; ++q) bsum[q] += o[q];
@@ -537,7 +542,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long lddy, const T* Z, long ldz,
                                                            const uint8_t* mask, T* dZ, long lddz, int N_, int M, int act,
                                                            float alpha, float* dbias, float* dgroup, long lddg, int gdiv,
-                                                           int RS) {
+                                                           int RS, uint32_t dthresh, float dscale, uint64_t dseed) {
   __shared__ float red[3][64][4];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + cx) * 4;
@@ -552,6 +557,7 @@ __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long ldd
       if (Z) { for (int q = 0; q < 4; ++q) fz[q] = q < nvalid ? to_f32(Z[(long)n * ldz + col + q]) : 0.f; }
       const float mk = (mask ? (mask[n] ? 1.f : 0.f) : 1.f) * alpha;
       for (int q = 0; q < 4; ++q) o[q] = fdy[q] * mk * (Z ? act_grad(act, fz[q]) : 1.f);
+      if (dthresh) { for (int q = 0; q < 4; ++q) o[q] = dropout_keep(dseed, (uint64_t)n * M + col + q, dthresh) ? o[q] * dscale : 0.f; }
       if (dZ) { for (int q = 0; q < 4; ++q) if (q < nvalid) dZ[(long)n * lddz + col + q] = from_f32<T>(o[q]); }
       for (int q = 0; q < 4; ++q) bsum[q] += o[q];
       if (dgroup) {
@@ -638,17 +644,6 @@ __global__ void clip_factor_kernel(const float* sumsq, float max_norm, float inv
   out[0] = f < 1.f ? f : 1.f;
 }
 
-// counter-based dropout: keep(n, c) is a pure function of (seed, n * D + c), so the backward pass regenerates the
-// forward mask from the seed instead of storing it.  Two rounds of a 32-bit multiply/xorshift mix (lowbias32) on the
-// element index, XORed with a second mix of the seed for the high index bits.
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
-  return x;
-}
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  const uint32_t h = mix32((uint32_t)idx ^ mix32((uint32_t)(idx >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
-  return h >= thresh;                                  // P(drop) = thresh / 2^32
-}
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* X, long ldx, T* Y, long ldy, int N_, int D, uint32_t thresh,
                                                       float scale, uint64_t seed) {
@@ -836,9 +831,12 @@ extern "C" size_t smx_act_mask_bwd_workspace(int N, int M) { return (size_t)((N 
 
 extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
                                 const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
-                                float* dbias, float* dgroup, int64_t lddgroup, int group_div, void* workspace,
-                                void* stream) {
+                                float* dbias, float* dgroup, int64_t lddgroup, int group_div, float drop_p,
+                                uint64_t drop_seed, void* workspace, void* stream) {
   SMX_REQUIRE(dY && N >= 0 && M > 0, "smx_act_mask_bwd: bad arguments");
+  SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_act_mask_bwd: 0 <= drop_p < 1");
+  const uint32_t dthresh = (uint32_t)((double)drop_p * 4294967296.0);
+  const float dscale = 1.f / (1.f - drop_p);
   SMX_REQUIRE(!dgroup || group_div > 0, "smx_act_mask_bwd: group_div must be > 0");
   if (N == 0) return SMX_OK;
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
@@ -851,14 +849,14 @@ extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const v
     const int RS = ACT_BWD_RS;
     float* partial = reinterpret_cast<float*>(workspace);
     dim3 grid((chunks + LPR - 1) / LPR, (N + RS - 1) / RS);
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial);
-    else hipLaunchKernelGGL((act_mask_bwd_vec_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed);
+    else hipLaunchKernelGGL((act_mask_bwd_vec_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed);
     if (dbias) hipLaunchKernelGGL(colsum_partials_kernel, dim3((M + 15) / 16), dim3(256), 0, STREAM, partial, (N + RS - 1) / RS, M, dbias);
   } else {
     const int RS = 128;
     dim3 grid((M + 255) / 256, (N + RS - 1) / RS);
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
-    else hipLaunchKernelGGL((act_mask_bwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed);
+    else hipLaunchKernelGGL((act_mask_bwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed);
   }
   return check_launch("smx_act_mask_bwd");
 }

@@ -158,6 +158,20 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
   }
 }
 
+// counter-based dropout: keep(n, c) is a pure function of (seed, n * D + c), so the backward pass regenerates the
+// forward mask from the seed instead of storing it.  Two rounds of a 32-bit multiply/xorshift mix (lowbias32) on the
+// element index, XORed with a second mix of the seed for the high index bits.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+  // one 32-bit hash serves the two elements of an (even, odd) index pair, 16 bits each: P(drop) = (thresh>>16)/65536
+  const uint64_t pair = idx >> 1;
+  const uint32_t h = mix32((uint32_t)pair ^ mix32((uint32_t)(pair >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return r >= (thresh >> 16);
+}
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -101,31 +101,34 @@ def _wgrad_splits(nrows, m, k):
 # Linear (+bias +act +mask +residual +side input) forward / backward on 2-D row views
 # ----------------------------------------------------------------------------------------------------
 def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, c0=None, c0_mode=L.C0_NONE,
-               c0_div=0, save_z=False, out=None, out_f32=False):
+               c0_div=0, save_z=False, out=None, out_f32=False, drop=None, c0_post=False):
     N, K = x.shape
     M = W.shape[0]
     if out is None:
         out = torch.empty((N, M), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
     e = ops.epilogue(bias=bias, c0=c0, c0_mode=c0_mode, c0_div=c0_div, act=act, z=z, row_mask=mask, res=res,
-                     alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T)
+                     alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post)
     ops.gemm(L.GEMM_NT, x, W, out, N, M, K, e)
     return out, z
 
 
 def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
-               dz_is_dy=False):
-    """Backward of y = res + alpha*act(x W^T + b + c0)*mask.  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate."""
+               drop=None):
+    """Backward of y = res + alpha*D(act(x W^T + b + c0))*mask (D = the forward's fused dropout, regenerated from its
+    seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate."""
     N, M = dy.shape
     K = x.shape[1]
-    plain = act == L.ACT_NONE and mask is None and alpha == 1.0
+    if drop is not None and drop[0] <= 0.0:
+        drop = None
+    plain = act == L.ACT_NONE and mask is None and alpha == 1.0 and drop is None
     if plain:
         dz = dy
         if gb is not None or dgroup is not None:
             ops.act_mask_bwd(dy, None, None, L.ACT_NONE, 1.0, None, gb, dgroup, gdiv)
     else:
         dz = torch.empty((N, M), dtype=dy.dtype, device=dy.device)
-        ops.act_mask_bwd(dy, z, mask, act, alpha, dz, gb, dgroup, gdiv)
+        ops.act_mask_bwd(dy, z, mask, act, alpha, dz, gb, dgroup, gdiv, drop)
     if gW is not None:
         ops.wgrad(dz, x, gW, N, M, K)
     dx = None
@@ -414,33 +417,18 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
     With p == 0 the second Linear's epilogue carries the residual and alpha (no extra pass)."""
     h, ln_b = ln_fwd(x, P["ln_w"], P["ln_b"], 1e-5, need_bwd)
     W1, W2 = wcast(P["W1"], dtype), wcast(P["W2"], dtype)
-    a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd)
-    if p == 0.0:
-        y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha)
-        if not need_bwd:
-            return y, None
-
-        def bwd(dy):
-            da, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]))
-            dh, _ = linear_bwd(da, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]))
-            return ln_b(dh, res=dy)
-        return y, bwd
-    s1, s2 = ops.new_dropout_seed(), ops.new_dropout_seed()
-    ops.dropout(a, p, s1, out=a)
-    t, _ = linear_fwd(a, W2, P["b2"])
-    ops.dropout(t, p, s2, out=t)
-    y = ops.axpby(alpha, t, 1.0, x)
+    d1 = (p, ops.new_dropout_seed()) if p > 0.0 else None       # both dropouts are fused into the GEMM epilogues
+    d2 = (p, ops.new_dropout_seed()) if p > 0.0 else None
+    a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1)
+    y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2)
     if not need_bwd:
         return y, None
 
-    def bwd_d(dy):
-        dt = ops.dropout(dy, p, s2)
-        da, _ = linear_bwd(dt, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]))
-        ops.dropout(da, p, s1, out=da)
-        dh, _ = linear_bwd(da, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]))
+    def bwd(dy):
+        da, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2)
+        dh, _ = linear_bwd(da, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), drop=d1)
         return ln_b(dh, res=dy)
-    return y, bwd_d
-
+    return y, bwd
 
 def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True, p=0.0):
     """y = [x +] mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534)."""
@@ -453,27 +441,13 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
     c = ops.dwconv_fwd(p_, wd, P["bd"].detach() if P["bd"] is not None else None, B, T, d, k, True, L.PAD_ZERO, chunk)
     a, ln2_b = ln_fwd(c, P["ln2_w"], P["ln2_b"], 1e-5, need_bwd, act)      # LN + activation fused
     Wo = wcast(P["Wo"], dtype)
-    seed = None
-    if p == 0.0:
-        y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None)
-    else:                                            # Linear -> Dropout -> * mask (+ x)   (Conformer.py:156-157,327-331)
-        seed = ops.new_dropout_seed()
-        t, _ = linear_fwd(a, Wo, P["bo"])
-        ops.dropout(t, p, seed, out=t)
-        if mask is not None:
-            ops.act_mask_bwd(t, None, mask, L.ACT_NONE, 1.0, t)       # elementwise row-mask multiply, in place
-        y = ops.axpby(1.0, t, 1.0, x) if residual else t
+    dr = (p, ops.new_dropout_seed()) if p > 0.0 else None   # Linear -> Dropout -> * mask (+ x): one epilogue
+    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None, drop=dr)
     if not need_bwd:
         return y, None
 
     def bwd(dy):
-        if p == 0.0:
-            da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]))
-        else:
-            dt = torch.empty_like(dy)
-            ops.act_mask_bwd(dy, None, mask, L.ACT_NONE, 1.0, dt)
-            ops.dropout(dt, p, seed, out=dt)
-            da, _ = linear_bwd(dt, a, Wo, None, L.ACT_NONE, None, 1.0, gacc(P["Wo"]), gacc(P["bo"]))
+        da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr)
         dc = ln2_b(da)
         gwd = gacc(P["wd"])
         dp, _ = ops.dwconv_bwd(dc, p_, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
@@ -504,22 +478,14 @@ def input_proj_pe(src3, W, b, pe, T, p=0.0):
         dtype = xin.dtype
         x = ops.rows2d(xin)
         Wc = wcast(W, dtype)
-        seed = None
-        if p == 0.0:
-            y, _ = linear_fwd(x, Wc, b, c0=pe, c0_mode=L.C0_MOD, c0_div=T)
-        else:
-            seed = ops.new_dropout_seed()
-            y, _ = linear_fwd(x, Wc, b)
-            ops.dropout(y, p, seed, out=y)
-            ops.add_rowtable(y, pe, T)
+        dr = (p, ops.new_dropout_seed()) if p > 0.0 else None
+        y, _ = linear_fwd(x, Wc, b, c0=pe, c0_mode=L.C0_MOD, c0_div=T, drop=dr, c0_post=True)
         if not need:
             return y.view(B, T, -1), None
 
         def bwd(dy3):
             dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
-            if p != 0.0:
-                dy = ops.dropout(dy, p, seed)
-            dx, _ = linear_bwd(dy, x, Wc, None, L.ACT_NONE, None, 1.0, gacc(W), gacc(b), need_dx=xin.requires_grad)
+            dx, _ = linear_bwd(dy, x, Wc, None, L.ACT_NONE, None, 1.0, gacc(W), gacc(b), need_dx=xin.requires_grad, drop=dr)
             return dx.view(xin.shape) if dx is not None else None
         return y.view(B, T, -1), bwd
     return block(src3, run, [W, b])

@@ -49,7 +49,7 @@ def rows2d(x):
 
 
 def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, out_mode=L.OUT_T, z=None,
-             row_mask=None, res=None, alpha=1.0, bias_batch_stride=0):
+             row_mask=None, res=None, alpha=1.0, bias_batch_stride=0, drop=None, c0_post=False):
     e = L.Epilogue()
     e.bias = bias.data_ptr() if bias is not None else None
     e.bias_batch_stride = bias_batch_stride
@@ -67,6 +67,9 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
     if res is not None:
         e.res, e.ldr = res.data_ptr(), _mat(res)[1]
     e.alpha = alpha
+    e.flags = L.EPI_C0_POST if c0_post else 0
+    if drop is not None and drop[0] > 0.0:
+        e.drop_p, e.drop_seed = drop
     return e
 
 
@@ -94,15 +97,16 @@ def wgrad(dz, x, gW, rows, M, K, batch=1, sz=0, sx=0, sw=0, lddz=None, ldx=None,
                                      alpha, _p(ws), _stream()), "smx_linear_wgrad")
 
 
-def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, gdiv=0):
+def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, gdiv=0, drop=None):
     N, M = dy.shape
     pdy, lddy = _mat(dy)
     pz, ldz = (_mat(z) if z is not None else (None, 0))
     pdz, lddz = (_mat(dz) if dz is not None else (None, 0))
     pg, ldg = (_mat(dgroup) if dgroup is not None else (None, 0))
     ws = _workspace(L.lib().smx_act_mask_bwd_workspace(N, M), dy.device, slot=3) if dbias is not None else None
+    dp, ds = (drop if drop is not None else (0.0, 0))
     L.check(L.lib().smx_act_mask_bwd(dt(dy), pdy, lddy, pz, ldz, _p(mask), pdz, lddz, N, M, act, alpha, _p(dbias), pg,
-                                     ldg, gdiv, _p(ws), _stream()), "smx_act_mask_bwd")
+                                     ldg, gdiv, dp, ds, _p(ws), _stream()), "smx_act_mask_bwd")
     return dz
 
 

@@ -83,3 +83,32 @@ def test_conformer_layer_trains_with_dropout():
     ye1, _ = layer(x, src_key_padding_mask=pad)
     ye2, _ = layer(x, src_key_padding_mask=pad)
     assert torch.equal(ye1, ye2)
+
+
+def test_fused_epilogue_dropout_equals_standalone_kernel():
+    """The GEMM epilogue's fused dropout and smx_act_mask_bwd's regenerated mask index elements exactly like
+    smx_dropout (n*M + m), so fused and unfused paths are interchangeable (checked in fp32: no rounding in between)."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(2)
+    N, M, K = 300, 136, 72
+    x = torch.randn(N, K, device="cuda")
+    w = torch.randn(M, K, device="cuda") * 0.2
+    b = torch.randn(M, device="cuda")
+    res = torch.randn(N, M, device="cuda")
+    mask = (torch.rand(N, device="cuda") > 0.3).view(torch.uint8)
+    seed, p = 0xABCDEF0123, 0.25
+    y = torch.empty(N, M, device="cuda")
+    ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, row_mask=mask, res=res, alpha=0.5,
+                                                        drop=(p, seed)))
+    a = torch.empty(N, M, device="cuda")
+    ops.gemm(L.GEMM_NT, x, w, a, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH))
+    ops.dropout(a, p, seed, out=a)
+    ref = res + 0.5 * a * mask.bool()[:, None]
+    assert rel_err(y, ref) < 1e-6
+    dy = torch.randn(N, M, device="cuda")
+    z = torch.randn(N, M, device="cuda")
+    dz = torch.empty_like(dy)
+    ops.act_mask_bwd(dy, z, mask, L.ACT_GELU, 0.5, dz, drop=(p, seed))
+    dz2 = torch.empty_like(dy)
+    ops.act_mask_bwd(ops.dropout(dy, p, seed), z, mask, L.ACT_GELU, 0.5, dz2)
+    assert rel_err(dz, dz2) < 1e-6
