@@ -152,6 +152,24 @@ int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, const void* P,
                          int64_t lddg, float* dw, float* dbias, int B, int T, int D, int k, int glu, int pad_mode,
                          int chunk, void* workspace, void* stream);
 
+/* ---- front-end (arithmetic lives in un-vendored SpeechBrain: parity unpinned, spec = oracle) ----
+ * Log-mel filterbank (speechbrain.lobes.features.Fbank, ...transducer.yaml:171-175):
+ *   smx_frame_window : frames[b*T+t, j] = window[j] * wav[b, t*hop + j - n_fft/2]  (center=True, zero pad), fp32
+ *   DFT              : smx_gemm(NT, F32) of the frames with a [cos | -sin] basis (exact-fp32 MFMA)
+ *   smx_mel_db       : power spectrum -> mel filterbank (n_mels x n_bins fp32) -> 10 log10(max(., amin)) -> per-utterance
+ *                      top_db clamp; spec (B*T, lds) holds re at column f and im at column im_off + f.
+ * Conv subsampling (ConvolutionFrontEnd, ...yaml:247-254): 3x3 / stride 2 / reflect pad 1, channels-last:
+ *   smx_im2col_s2 : x (B,T,F,C) -> col (B*ceil(T/2)*ceil(F/2), Kp), column (dt*3+df)*C + c, zero beyond 9*C
+ *   conv          : smx_gemm(NT) col x W^T + bias, then smx_layernorm_fwd over (F2*Cout) with fused LeakyReLU
+ *   smx_col2im_s2 : backward of im2col (gather form, no atomics). */
+int smx_frame_window(const float* wav, int64_t ldw, const float* window, float* frames, int B, int L, int T, int n_fft,
+                     int hop, void* stream);
+size_t smx_fbank_workspace(int B, int T, int n_mels);
+int smx_mel_db(int out_dtype, const float* spec, int64_t lds, int im_off, const float* fb, int n_bins, int n_mels,
+               float amin, float top_db, void* out, int B, int T, void* workspace, void* stream);
+int smx_im2col_s2(int dtype, const void* x, void* col, int B, int T, int F, int C, int Kp, void* stream);
+int smx_col2im_s2(int dtype, const void* dcol, void* dx, int B, int T, int F, int C, int Kp, void* stream);
+
 /* y = a*x (+ b*y0): generic strided elementwise helper (dtype T). */
 int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b, const void* Y0, int64_t ldy0, void* Y,
               int64_t ldy, int N, int D, void* stream);

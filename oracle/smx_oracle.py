@@ -329,3 +329,55 @@ def asr_encode(src: Tensor, wav_len: Optional[Tensor], sd: SD, encoder_module: s
         return conformer_encoder(x, sd, "encoder.", act, mode, local_proj_out_dim, src_mask, pad_mask,
                                  dynchunk[0] if dynchunk is not None else None)
     return branchformer_encoder(x, sd, "encoder.", act, mode, local_proj_out_dim, src_mask, pad_mask)
+
+
+# ----------------------------------------------------------------------------------------------
+# Front-end.  PARITY UNPINNED: this arithmetic lives in un-vendored SpeechBrain
+# (speechbrain.lobes.features.Fbank, speechbrain.lobes.models.convolution.ConvolutionFrontEnd; call sites
+# recipes/LibriSpeech/ASR/transducer/hparams/conformer_summarymixing_transducer.yaml:167-175,247-254) and no
+# reference test touches it.  The functions below are this repo's own CPU definition (SURVEY §2.1 formulas).
+# ----------------------------------------------------------------------------------------------
+def mel_filterbank(n_mels: int = 80, n_fft: int = 512, sample_rate: int = 16000, f_min: float = 0.0,
+                   f_max: Optional[float] = None) -> Tensor:
+    """Triangular HTK-mel filters (n_mels, n_fft//2+1): mel = 2595 log10(1 + f/700)."""
+    f_max = sample_rate / 2 if f_max is None else f_max
+    to_mel = lambda hz: 2595.0 * math.log10(1.0 + hz / 700.0)
+    mel = torch.linspace(to_mel(f_min), to_mel(f_max), n_mels + 2, dtype=torch.float64)
+    hz = 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+    band = hz[1:] - hz[:-1]
+    f_central, band = hz[1:-1], band[:-1]
+    all_freqs = torch.linspace(0, sample_rate // 2, n_fft // 2 + 1, dtype=torch.float64)
+    slope = (all_freqs[None, :] - f_central[:, None]) / band[:, None]
+    return torch.clamp(torch.minimum(slope + 1.0, -slope + 1.0), min=0.0).float()
+
+
+def fbank(wav: Tensor, sample_rate: int = 16000, n_fft: int = 512, win_length_ms: float = 32, hop_length_ms: float = 10,
+          n_mels: int = 80, amin: float = 1e-10, top_db: float = 80.0) -> Tensor:
+    """wav (B, L) -> log-mel (B, T, n_mels), T = 1 + L // hop: STFT(hamming, center, zero pad) -> |X|^2 -> mel ->
+    10 log10(max(., amin)) -> clamp at (per-utterance max - top_db)."""
+    win = int(round(sample_rate / 1000.0 * win_length_ms))
+    hop = int(round(sample_rate / 1000.0 * hop_length_ms))
+    window = torch.hamming_window(win, dtype=wav.dtype)
+    X = torch.stft(wav, n_fft, hop, win, window, center=True, pad_mode="constant", normalized=False, onesided=True,
+                   return_complex=True)
+    power = (X.real ** 2 + X.imag ** 2).transpose(1, 2)                 # (B, T, n_bins)
+    mel = power @ mel_filterbank(n_mels, n_fft, sample_rate).to(wav.dtype).t()
+    db = 10.0 * torch.log10(torch.clamp(mel, min=amin))
+    return torch.maximum(db, db.amax(dim=(-2, -1), keepdim=True) - top_db)
+
+
+def conv_frontend(x: Tensor, sd: SD, prefix: str = "") -> Tensor:
+    """x (B, T, F) -> (B, ceil(T/4), ceil(F/4) * C_last): per block Conv2d(3x3, stride 2, reflect pad 1) over (time, freq)
+    -> LayerNorm over (F', C) -> LeakyReLU(0.01).  Weights: {prefix}convblock_i.conv.weight (Cout, Cin, 3, 3), .bias,
+    {prefix}convblock_i.norm.weight/.bias (F', Cout)."""
+    h = x.unsqueeze(1)                                                   # (B, C=1, T, F)
+    i = 0
+    while f"{prefix}convblock_{i}.conv.weight" in sd:
+        p = f"{prefix}convblock_{i}."
+        h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"), sd[p + "conv.weight"], sd[p + "conv.bias"], stride=2)
+        hl = h.permute(0, 2, 3, 1)                                       # (B, T', F', C)
+        hl = F.layer_norm(hl, hl.shape[2:], sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
+        h = F.leaky_relu(hl, 0.01).permute(0, 3, 1, 2)
+        i += 1
+    h = h.permute(0, 2, 3, 1)
+    return h.reshape(h.shape[0], h.shape[1], -1)

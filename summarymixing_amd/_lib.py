@@ -60,6 +60,11 @@ SIGNATURES = {
     "smx_dwconv1d_glu_bwd_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_dwconv1d_glu_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                    c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "smx_frame_window": (c_i, [c_vp, c_i64, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "smx_fbank_workspace": (c_sz, [c_i, c_i, c_i]),
+    "smx_mel_db": (c_i, [c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_f, c_f, c_vp, c_i, c_i, c_vp, c_vp]),
+    "smx_im2col_s2": (c_i, [c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "smx_col2im_s2": (c_i, [c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_axpby": (c_i, [c_i, c_f, c_vp, c_i64, c_f, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
     "smx_dropout": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_f, ctypes.c_uint64, c_vp]),
     "smx_add_rowtable": (c_i, [c_i, c_vp, c_i64, c_vp, c_i, c_i, c_i, c_vp]),

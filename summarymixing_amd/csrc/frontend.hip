@@ -1,0 +1,204 @@
+// frontend.hip — the step in front of the encoder, gfx950:
+//   log-mel filterbank  : frame+window -> [DFT as an exact-fp32 MFMA GEMM, smx_gemm] -> power + mel + dB -> top_db clamp
+//   conv subsampling    : im2col (3x3, stride 2, reflect pad 1, channels-last) -> [smx_gemm + bias] -> LayerNorm over
+//                         (F, C) + LeakyReLU (smx_layernorm_fwd with fused activation); col2im for the backward.
+// The arithmetic of these stages lives in un-vendored SpeechBrain (Fbank / ConvolutionFrontEnd, recipes/LibriSpeech/
+// ASR/transducer/hparams/conformer_summarymixing_transducer.yaml:167-175,247-254): the reference pins nothing here, the
+// spec is oracle/smx_oracle.py::fbank / conv_frontend ("parity unpinned").
+#include "smx_common.h"
+
+namespace smx {
+
+// frames[b*T + t, j] = window[j] * wav[b, t*hop + j - n_fft/2]   (center=True, zero padding), fp32
+__global__ __launch_bounds__(256) void frame_window_kernel(const float* __restrict__ wav, long ldw, const float* __restrict__ win,
+                                                           float* __restrict__ out, int B, int L, int T, int n_fft, int hop) {
+  const long total = (long)B * T * (n_fft / 4);
+  const int half = n_fft / 2, q4 = n_fft / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int j = (int)(i % q4) * 4;
+    const long row = i / q4;
+    const int t = (int)(row % T), b = (int)(row / T);
+    const long s0 = (long)t * hop + j - half;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long s = s0 + q;
+      v[q] = (s >= 0 && s < L) ? wav[(long)b * ldw + s] * win[j + q] : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + row * n_fft + j) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// One wave per frame: P[f] = re^2 + im^2 (LDS), mel[m] = sum_f P[f] * fb[m][f], db = 10 log10(max(mel, amin)).
+// spec layout: S (N, lds) with re at column f and im at column im_off + f.  Per-block max -> bmax[block].
+__global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S, long lds, int im_off, const float* __restrict__ fb,
+                                                     int n_bins, int n_mels, float amin, float* __restrict__ db,
+                                                     float* __restrict__ bmax, int N_) {
+  extern __shared__ float pw[];                        // 4 x n_bins
+  __shared__ float wmax[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + w;
+  float* P = pw + w * n_bins;
+  float mx = -3.0e38f;
+  if (n < N_) {
+    const float* s = S + (long)n * lds;
+    for (int f = lane; f < n_bins; f += 64) { const float re = s[f], im = s[im_off + f]; P[f] = re * re + im * im; }
+  }
+  __syncthreads();
+  if (n < N_) {
+    for (int m = lane; m < n_mels; m += 64) {
+      const float* fr = fb + (long)m * n_bins;
+      float a0 = 0.f, a1 = 0.f;
+      int f = 0;
+      for (; f + 1 < n_bins; f += 2) { a0 += P[f] * fr[f]; a1 += P[f + 1] * fr[f + 1]; }
+      if (f < n_bins) a0 += P[f] * fr[f];
+      const float d = 10.f * log10f(fmaxf(a0 + a1, amin));
+      db[(long)n * n_mels + m] = d;
+      mx = fmaxf(mx, d);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) wmax[w] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+}
+
+// umax[b] = max over the blocks of utterance b (blocks never straddle utterances when T % 4 == 0; otherwise the
+// per-frame fallback below is used).  One block per utterance.
+__global__ __launch_bounds__(256) void utt_max_kernel(const float* __restrict__ db, int T, int n_mels, float* __restrict__ umax) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float mx = -3.0e38f;
+  const long base = (long)b * T * n_mels, cnt = (long)T * n_mels;
+  for (long i = threadIdx.x; i < cnt; i += 256) mx = fmaxf(mx, db[base + i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) umax[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void topdb_clamp_kernel(const float* __restrict__ db, const float* __restrict__ umax, float top_db,
+                                                          T* __restrict__ out, long per_utt, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / per_utt);
+    out[i] = from_f32<T>(fmaxf(db[i], umax[b] - top_db));
+  }
+}
+
+__device__ __forceinline__ int reflect1(int i, int L) { return i < 0 ? -i : (i >= L ? 2 * (L - 1) - i : i); }
+
+// im2col for a 3x3 / stride 2 / reflect-pad-1 convolution over (time, freq), channels-last.
+//   x (B, T, F, C) -> col (B*T2*F2, Kp), column = (dt*3 + df)*C + c, columns >= 9*C are zero.  T2 = ceil(T/2).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_s2_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int T_, int F, int C,
+                                                        int T2, int F2, int Kp) {
+  const long total = (long)B * T2 * F2 * Kp;
+  const int K = 9 * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    const long row = i / Kp;
+    T v = from_f32<T>(0.f);
+    if (k < K) {
+      const int c = k % C, tap = k / C, dt = tap / 3, df = tap % 3;
+      const int f2 = (int)(row % F2);
+      const long r2 = row / F2;
+      const int t2 = (int)(r2 % T2), b = (int)(r2 / T2);
+      const int t = reflect1(2 * t2 + dt - 1, T_), f = reflect1(2 * f2 + df - 1, F);
+      v = x[(((long)b * T_ + t) * F + f) * C + c];
+    }
+    col[i] = v;
+  }
+}
+
+// col2im: dx[b,t,f,c] = sum over (t2,dt,f2,df) whose reflected source is (t,f) of dcol[(b,t2,f2), (dt*3+df)*C + c]
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_s2_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int B, int T_, int F, int C,
+                                                        int T2, int F2, int Kp) {
+  const long total = (long)B * T_ * F * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int f = (int)(r % F);
+    r /= F;
+    const int t = (int)(r % T_), b = (int)(r / T_);
+    float acc = 0.f;
+    // candidate output rows: those whose 3-tap window [2*t2-1, 2*t2+1] touches t directly, plus the reflected edges
+    for (int t2 = max(0, (t - 1) / 2 - 1); t2 <= min(T2 - 1, (t + 1) / 2 + 1); ++t2) {
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        if (reflect1(2 * t2 + dt - 1, T_) != t) continue;
+        for (int f2 = max(0, (f - 1) / 2 - 1); f2 <= min(F2 - 1, (f + 1) / 2 + 1); ++f2) {
+#pragma unroll
+          for (int df = 0; df < 3; ++df) {
+            if (reflect1(2 * f2 + df - 1, F) != f) continue;
+            acc += to_f32(dcol[(((long)b * T2 + t2) * F2 + f2) * Kp + (dt * 3 + df) * C + c]);
+          }
+        }
+      }
+    }
+    dx[i] = from_f32<T>(acc);
+  }
+}
+
+static inline int fgrid(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace smx
+
+using namespace smx;
+#define STREAM reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int smx_frame_window(const float* wav, int64_t ldw, const float* window, float* frames, int B, int L, int T,
+                                int n_fft, int hop, void* stream) {
+  SMX_REQUIRE(wav && window && frames && n_fft % 4 == 0 && hop > 0, "smx_frame_window: bad arguments (n_fft % 4 == 0)");
+  if (B <= 0 || T <= 0) return SMX_OK;
+  hipLaunchKernelGGL(frame_window_kernel, dim3(fgrid((long)B * T * (n_fft / 4))), dim3(256), 0, STREAM, wav, ldw, window, frames,
+                     B, L, T, n_fft, hop);
+  return check_launch("smx_frame_window");
+}
+
+extern "C" size_t smx_fbank_workspace(int B, int T, int n_mels) {
+  return ((size_t)B * T * n_mels + (size_t)(B * (long)T + 3) / 4 + B + 16) * sizeof(float);
+}
+
+extern "C" int smx_mel_db(int out_dtype, const float* spec, int64_t lds, int im_off, const float* fb, int n_bins, int n_mels,
+                          float amin, float top_db, void* out, int B, int T, void* workspace, void* stream) {
+  SMX_REQUIRE(spec && fb && out && workspace && n_bins > 0 && n_mels > 0, "smx_mel_db: bad arguments");
+  if (B <= 0 || T <= 0) return SMX_OK;
+  const int N = B * T;
+  float* db = reinterpret_cast<float*>(workspace);
+  float* bmax = db + (size_t)N * n_mels;
+  float* umax = bmax + (N + 3) / 4;
+  hipLaunchKernelGGL(mel_db_kernel, dim3((N + 3) / 4), dim3(256), 4 * n_bins * sizeof(float), STREAM, spec, lds, im_off, fb, n_bins,
+                     n_mels, amin, db, bmax, N);
+  hipLaunchKernelGGL(utt_max_kernel, dim3(B), dim3(256), 0, STREAM, db, T, n_mels, umax);
+  const long total = (long)N * n_mels;
+  if (out_dtype == SMX_BF16) hipLaunchKernelGGL((topdb_clamp_kernel<bf16_t>), dim3(fgrid(total)), dim3(256), 0, STREAM, db, umax, top_db, (bf16_t*)out, (long)T * n_mels, total);
+  else hipLaunchKernelGGL((topdb_clamp_kernel<float>), dim3(fgrid(total)), dim3(256), 0, STREAM, db, umax, top_db, (float*)out, (long)T * n_mels, total);
+  return check_launch("smx_mel_db");
+}
+
+extern "C" int smx_im2col_s2(int dtype, const void* x, void* col, int B, int T, int F, int C, int Kp, void* stream) {
+  SMX_REQUIRE(x && col && Kp >= 9 * C && T >= 2 && F >= 2, "smx_im2col_s2: bad arguments");
+  const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
+  const long total = (long)B * T2 * F2 * Kp;
+  if (total <= 0) return SMX_OK;
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((im2col_s2_kernel<bf16_t>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const bf16_t*)x, (bf16_t*)col, B, T, F, C, T2, F2, Kp);
+  else hipLaunchKernelGGL((im2col_s2_kernel<float>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const float*)x, (float*)col, B, T, F, C, T2, F2, Kp);
+  return check_launch("smx_im2col_s2");
+}
+
+extern "C" int smx_col2im_s2(int dtype, const void* dcol, void* dx, int B, int T, int F, int C, int Kp, void* stream) {
+  SMX_REQUIRE(dcol && dx && Kp >= 9 * C && T >= 2 && F >= 2, "smx_col2im_s2: bad arguments");
+  const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
+  const long total = (long)B * T * F * C;
+  if (total <= 0) return SMX_OK;
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((col2im_s2_kernel<bf16_t>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const bf16_t*)dcol, (bf16_t*)dx, B, T, F, C, T2, F2, Kp);
+  else hipLaunchKernelGGL((col2im_s2_kernel<float>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const float*)dcol, (float*)dx, B, T, F, C, T2, F2, Kp);
+  return check_launch("smx_col2im_s2");
+}

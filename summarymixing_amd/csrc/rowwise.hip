@@ -399,6 +399,64 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+// wide rows (2048 < D <= 4096, e.g. the (F,C) = 40x64 LayerNorm of the conv front-end): one WORKGROUP per row at a
+// time, thread t owns columns t + 256*i; row statistics through an LDS reduction; same partial-row flush as above.
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ X,
+                                                                 long ldx, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int act,
+                                                                 const float* __restrict__ stats, const T* __restrict__ R,
+                                                                 long ldr, T* __restrict__ dX, long lddx,
+                                                                 float* __restrict__ partial, int N_, int D) {
+  __shared__ float red[2][4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  float gam[CH], bet[CH], dg[CH], db[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = t + 256 * i;
+    gam[i] = c < D ? gamma[c] : 0.f;
+    bet[i] = (c < D && act != SMX_ACT_NONE) ? beta[c] : 0.f;
+    dg[i] = db[i] = 0.f;
+  }
+  for (int row = blockIdx.x; row < N_; row += gridDim.x) {
+    const float mean = stats[2 * (long)row], rstd = stats[2 * (long)row + 1];
+    float g[CH], xh[CH], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = t + 256 * i;
+      g[i] = xh[i] = 0.f;
+      if (c < D) {
+        const float xhat = (to_f32(X[(long)row * ldx + c]) - mean) * rstd;
+        float dyn = to_f32(dY[(long)row * lddy + c]);
+        if (act != SMX_ACT_NONE) dyn *= act_grad(act, xhat * gam[i] + bet[i]);
+        g[i] = dyn * gam[i]; xh[i] = xhat;
+        s1 += g[i]; s2 += g[i] * xhat;
+        dg[i] += dyn * xhat; db[i] += dyn;
+      }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    __syncthreads();
+    if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    const float m1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D;
+    const float m2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)D;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = t + 256 * i;
+      if (c < D) {
+        float o = rstd * (g[i] - m1 - xh[i] * m2);
+        if (R) o += to_f32(R[(long)row * ldr + c]);
+        dX[(long)row * lddx + c] = from_f32<T>(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = t + 256 * i;
+    if (c < D) { partial[((long)blockIdx.x * 2) * D + c] = dg[i]; partial[((long)blockIdx.x * 2 + 1) * D + c] = db[i]; }
+  }
+}
+
 // dgamma[c] += sum_b partial[b][0][c]; dbeta[c] += sum_b partial[b][1][c]   (fixed order => bit-reproducible)
 // block = 32 columns x 8 row groups; every thread sums nblocks/8 partial rows with 4 independent accumulators.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int D,
@@ -802,12 +860,14 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
     else if (D <= 512) LN_BWD(4, 2);
     else if (D <= 1024) LN_BWD(4, 4);
     else if (D <= 2048) LN_BWD(4, 8);
-    else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 2048", D);
+    else if (D <= 4096) hipLaunchKernelGGL((layernorm_bwd_wide_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D);
+    else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 4096", D);
   } else {
     if (D <= 256) LN_BWD(1, 4);
     else if (D <= 1024) LN_BWD(1, 16);
     else if (D <= 2048) LN_BWD(1, 32);
-    else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 2048", D);
+    else if (D <= 4096) hipLaunchKernelGGL((layernorm_bwd_wide_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D);
+    else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 4096", D);
   }
 #undef LN_BWD
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);

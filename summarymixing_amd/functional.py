@@ -403,12 +403,15 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
 # ----------------------------------------------------------------------------------------------------
 # LayerNorm block, FFN module, Conformer conv module (2-D row views in, closures out)
 # ----------------------------------------------------------------------------------------------------
-def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE):
-    """y = act(LayerNorm(x)); bwd(dy, res) = res + d/dx."""
+def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None):
+    """y = act(LayerNorm(x)); bwd(dy, res) = res + d/dx.  w/b are flat (D) views; wp/bp name the owning parameters
+    when those are multi-dimensional (the (F', C) affine of the conv front-end)."""
     y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act)
 
     def bwd(dy, res=None):
-        return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gacc(w), gacc(b), res, act)
+        gw = gacc(wp).view(-1) if wp is not None else gacc(w)
+        gb = gacc(bp).view(-1) if bp is not None else gacc(b)
+        return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act)
     return y, (bwd if need_bwd else None)
 
 

@@ -1,0 +1,103 @@
+"""Conv2d subsampling front-end on MI355X (surface of speechbrain.lobes.models.convolution.ConvolutionFrontEnd as the
+recipes use it: 2 blocks, out_channels (64, 32), 3x3 kernels, strides (2, 2), ...transducer.yaml:247-254):
+
+    block:  Conv2d(3x3, stride 2, reflect pad 1) -> LayerNorm over (F', C) -> LeakyReLU(0.01) -> Dropout
+
+Each conv is im2col (channels-last gather kernel) + the MFMA GEMM with bias epilogue; LayerNorm+LeakyReLU is one
+kernel; the backward runs wgrad / dgrad GEMMs and a gather-form col2im.  Output (B, ceil(T/4), 20, 32) feeds
+TransformerASR.encode, which flattens it to 640 features (TransformerASR.py:528-530).  Arithmetic spec:
+oracle/smx_oracle.py::conv_frontend (parity unpinned: upstream SpeechBrain code)."""
+import torch
+from torch import nn
+
+from ... import _lib as L
+from ... import functional as F
+from ... import ops
+
+
+class _ConvBlock(nn.Module):
+    def __init__(self, c_in, c_out, f_in):
+        super().__init__()
+        self.conv = nn.Conv2d(c_in, c_out, 3, stride=2)            # parameter holder (Cout, Cin, 3, 3)
+        self.f_out = (f_in + 1) // 2
+        self.norm = nn.LayerNorm((self.f_out, c_out))               # affine over (F', C) like upstream's LayerNorm
+        self.c_in, self.c_out = c_in, c_out
+        self.kp = (9 * c_in + 7) // 8 * 8
+
+
+class ConvolutionFrontEnd(nn.Module):
+    def __init__(self, input_shape, num_blocks=2, num_layers_per_block=1, out_channels=(64, 32), kernel_sizes=(3, 3),
+                 strides=(2, 2), dilations=(1, 1), residuals=(False, False), conv_module=None, activation=nn.LeakyReLU,
+                 norm=None, dropout=0.1, conv_bias=True, padding="same", conv_init=None):
+        super().__init__()
+        if (num_layers_per_block != 1 or tuple(kernel_sizes) != (3,) * num_blocks or tuple(strides) != (2,) * num_blocks or
+                any(residuals) or any(d != 1 for d in dilations)):
+            raise NotImplementedError("only the recipes' configuration is built: 3x3 kernels, stride 2, one layer per block")
+        f, c = input_shape[-1], 1
+        blocks = []
+        for i in range(num_blocks):
+            blocks.append(_ConvBlock(c, out_channels[i], f))
+            f, c = blocks[-1].f_out, out_channels[i]
+        self.blocks = nn.ModuleList(blocks)
+        self.p_drop = float(dropout)
+
+    def state_dict_for_oracle(self):
+        sd = {}
+        for i, b in enumerate(self.blocks):
+            sd[f"convblock_{i}.conv.weight"], sd[f"convblock_{i}.conv.bias"] = b.conv.weight.detach(), b.conv.bias.detach()
+            sd[f"convblock_{i}.norm.weight"], sd[f"convblock_{i}.norm.bias"] = b.norm.weight.detach(), b.norm.bias.detach()
+        return sd
+
+    def forward(self, x):
+        """x (B, T, F) log-mel features (GPU, float32 or bfloat16) -> (B, ceil(T/4), F/4, C_last)."""
+        B = x.shape[0]
+        pd = self.p_drop if self.training else 0.0
+        blocks = list(self.blocks)
+
+        def run(xin, need):
+            dtype = xin.dtype
+            h = xin.reshape(B, xin.shape[1], xin.shape[2], 1).contiguous()
+            saved = []
+            for bi, blk in enumerate(blocks):
+                _, T_, F_, C = h.shape
+                T2, F2 = (T_ + 1) // 2, (F_ + 1) // 2
+                col = ops.im2col_s2(h, blk.kp)
+                # GEMM-layout weight (Cout, Kp): column (dt*3+df)*Cin + c  <- conv.weight (Cout, Cin, 3, 3)
+                wg = torch.zeros((blk.c_out, blk.kp), dtype=torch.float32, device=h.device)
+                wg[:, :9 * C] = blk.conv.weight.detach().permute(0, 2, 3, 1).reshape(blk.c_out, 9 * C)
+                wgc = ops.cast(wg, dtype)
+                y, _ = F.linear_fwd(col, wgc, blk.conv.bias.detach())                         # (B*T2*F2, Cout)
+                yr = y.view(B * T2, F2 * blk.c_out)
+                a, ln_b = F.ln_fwd(yr, blk.norm.weight.view(-1), blk.norm.bias.view(-1), blk.norm.eps, need,
+                                   L.ACT_LEAKY_RELU, wp=blk.norm.weight, bp=blk.norm.bias)
+                seed = None
+                if pd > 0.0:
+                    seed = ops.new_dropout_seed()
+                    ops.dropout(a, pd, seed, out=a)
+                saved.append((h.shape, col, wgc, ln_b, seed, blk, bi))
+                h = a.view(B, T2, F2, blk.c_out)
+            if not need:
+                return h, None
+
+            def bwd(dout):
+                d = dout.contiguous()
+                for shape, col, wgc, ln_b, seed, blk, bi in reversed(saved):
+                    _, T_, F_, C = shape
+                    T2, F2 = (T_ + 1) // 2, (F_ + 1) // 2
+                    da = d.reshape(B * T2, F2 * blk.c_out)
+                    if seed is not None:
+                        da = ops.dropout(da, pd, seed)
+                    dy = ln_b(da).view(B * T2 * F2, blk.c_out)
+                    gw = torch.zeros((blk.c_out, blk.kp), dtype=torch.float32, device=dy.device)
+                    first = bi == 0
+                    dcol, _ = F.linear_bwd(dy, col, wgc, None, L.ACT_NONE, None, 1.0, gw, F.gacc(blk.conv.bias),
+                                           need_dx=not first)
+                    g = F.gacc(blk.conv.weight)                       # fold the GEMM-layout gradient back (9*Cin*Cout values)
+                    if g is not None:
+                        g.add_(gw[:, :9 * C].view(blk.c_out, 3, 3, C).permute(0, 3, 1, 2))
+                    if first:
+                        return None
+                    d = ops.col2im_s2(dcol, B, T_, F_, C)
+                return None
+            return h, bwd
+        return F.block(x, run, list(self.parameters()))

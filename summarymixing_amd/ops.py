@@ -262,3 +262,35 @@ def sumsq(x, out):
 
 def clip_factor(sumsq_t, max_norm, inv_scale, out):
     L.check(L.lib().smx_clip_factor(_p(sumsq_t), max_norm, inv_scale, _p(out), _stream()), "smx_clip_factor")
+
+
+# ---- front-end -----------------------------------------------------------------------------------------
+def frame_window(wav, window, T, n_fft, hop):
+    B, Lw = wav.shape
+    out = torch.empty((B * T, n_fft), dtype=torch.float32, device=wav.device)
+    L.check(L.lib().smx_frame_window(_p(wav), wav.stride(0), _p(window), _p(out), B, Lw, T, n_fft, hop, _stream()),
+            "smx_frame_window")
+    return out
+
+
+def mel_db(spec, im_off, fb, B, T, amin, top_db, out_dtype):
+    n_mels, n_bins = fb.shape
+    out = torch.empty((B, T, n_mels), dtype=out_dtype, device=spec.device)
+    ws = _workspace(L.lib().smx_fbank_workspace(B, T, n_mels), spec.device, slot=5)
+    L.check(L.lib().smx_mel_db(_DT[out_dtype], _p(spec), spec.stride(0), im_off, _p(fb), n_bins, n_mels, amin, top_db, _p(out),
+                               B, T, _p(ws), _stream()), "smx_mel_db")
+    return out
+
+
+def im2col_s2(x, Kp):
+    B, T, F_, C = x.shape
+    T2, F2 = (T + 1) // 2, (F_ + 1) // 2
+    col = torch.empty((B * T2 * F2, Kp), dtype=x.dtype, device=x.device)
+    L.check(L.lib().smx_im2col_s2(dt(x), _p(x), _p(col), B, T, F_, C, Kp, _stream()), "smx_im2col_s2")
+    return col
+
+
+def col2im_s2(dcol, B, T, F_, C):
+    dx = torch.empty((B, T, F_, C), dtype=dcol.dtype, device=dcol.device)
+    L.check(L.lib().smx_col2im_s2(dt(dcol), _p(dcol), _p(dx), B, T, F_, C, dcol.shape[1], _stream()), "smx_col2im_s2")
+    return dx

@@ -1,0 +1,93 @@
+"""Front-end kernels against this repo's CPU spec in oracle/smx_oracle.py (the reference pins
+nothing here: the arithmetic is un-vendored SpeechBrain code -> 'parity unpinned', self-consistency tests)."""
+import pytest
+import torch
+
+from tests._util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fbank_matches_cpu_spec():
+    from oracle import smx_oracle as O
+    from summarymixing_amd.lobes.features import Fbank
+    torch.manual_seed(0)
+    B, Lw = 3, 16000
+    t = torch.arange(Lw) / 16000.0
+    wav = 0.3 * torch.sin(2 * torch.pi * 440 * t)[None] * torch.tensor([1.0, 0.5, 0.1])[:, None] + 0.01 * torch.randn(B, Lw)
+    wav[2, 9000:] = 0.0                                         # trailing silence -> exercises amin / top_db clamp
+    ref = O.fbank(wav.double(), n_fft=512, win_length_ms=32, n_mels=80).float()
+    fb = Fbank(sample_rate=16000, n_fft=512, n_mels=80, win_length=32).cuda()
+    out = fb(wav.cuda())
+    assert out.shape == ref.shape == (B, 101, 80)
+    assert (out.cpu() - ref).abs().max() < 2e-2                 # dB; fp32 DFT vs float64 reference
+    assert (out[2].amax() - out[2].amin()).item() <= 80.0 + 1e-3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 4e-2)])
+def test_conv_frontend_fwd_bwd(dtype, tol):
+    from oracle import smx_oracle as O
+    from summarymixing_amd.lobes.models.convolution import ConvolutionFrontEnd
+    torch.manual_seed(1)
+    B, T, Fm = 3, 37, 80                                         # odd T: ceil division + reflect at both edges
+    fe = ConvolutionFrontEnd((None, None, Fm), out_channels=(64, 32), dropout=0.0).cuda()
+    with torch.no_grad():
+        for blk in fe.blocks:
+            blk.norm.weight.normal_(1.0, 0.1)
+            blk.norm.bias.normal_(0.0, 0.1)
+    x = torch.randn(B, T, Fm)
+    sd = {k: v.double().cpu().requires_grad_(True) for k, v in fe.state_dict_for_oracle().items()}
+    xr = x.double().requires_grad_(True)
+    ref = O.conv_frontend(xr, sd)
+    xg = x.cuda().to(dtype).requires_grad_(True)
+    y = fe(xg)
+    assert y.shape == (B, 10, 20, 32)
+    assert rel_err(y.reshape(B, 10, -1), ref) <= tol
+    r = torch.randn(ref.shape)
+    (ref * r.double()).sum().backward()
+    (y.reshape(B, 10, -1).float() * r.cuda()).sum().backward()
+    # gradients: relative Frobenius error (bf16 activations are stored rounded between the two conv blocks; single
+    # elements of a 9-tap gradient that nearly cancel are not a meaningful max-norm target)
+    def fro(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return float((a - b).norm() / b.norm())
+    gtol = 3 * tol
+    assert fro(fe.blocks[0].conv.weight.grad, sd["convblock_0.conv.weight"].grad) <= gtol
+    assert fro(fe.blocks[1].conv.weight.grad, sd["convblock_1.conv.weight"].grad) <= gtol
+    assert fro(fe.blocks[1].conv.bias.grad, sd["convblock_1.conv.bias"].grad) <= gtol
+    assert fro(fe.blocks[0].norm.weight.grad, sd["convblock_0.norm.weight"].grad) <= gtol
+    assert fro(fe.blocks[1].norm.bias.grad, sd["convblock_1.norm.bias"].grad) <= gtol
+
+
+def test_im2col_col2im_are_adjoint():
+    """<im2col(x), c> == <x, col2im(c)> (exact adjoint incl. the reflected edges)."""
+    from summarymixing_amd import ops
+    torch.manual_seed(2)
+    B, T, F_, C, Kp = 2, 9, 7, 4, 40
+    x = torch.randn(B, T, F_, C, device="cuda")
+    c = torch.randn(B * 5 * 4, Kp, device="cuda")
+    c[:, 9 * C:] = 0
+    lhs = (ops.im2col_s2(x, Kp) * c).sum()
+    rhs = (x * ops.col2im_s2(c, B, T, F_, C)).sum()
+    assert abs(lhs.item() - rhs.item()) <= 1e-3 * abs(lhs.item()) + 1e-3
+
+
+def test_fbank_conv_encoder_chain_runs():
+    """wav -> fbank -> conv subsampling -> EncoderWrapper: shapes of the recipe (T_fb/4 frames x 640 features)."""
+    from summarymixing_amd.lobes.features import Fbank
+    from summarymixing_amd.lobes.models.convolution import ConvolutionFrontEnd
+    from summarymixing_amd.lobes.models.transformer.TransformerASR import EncoderWrapper, TransformerASR
+    torch.manual_seed(3)
+    wav = torch.randn(2, 16000 * 2).cuda() * 0.1
+    feats = Fbank(sample_rate=16000, n_fft=512, n_mels=80, win_length=32).cuda()(wav)            # (2, 201, 80)
+    cnn = ConvolutionFrontEnd((None, None, 80), dropout=0.0).cuda()
+    h = cnn(feats.bfloat16())
+    assert h.shape == (2, 51, 20, 32)
+    net = TransformerASR(tgt_vocab=10, input_size=640, d_model=64, nhead=4, num_encoder_layers=1, num_decoder_layers=0,
+                         d_ffn=128, dropout=0.0, encoder_module="conformer", attention_type="SummaryMixing",
+                         mode="SummaryMixing-fast", local_proj_hid_dim=[64], local_proj_out_dim=64, summary_hid_dim=[64],
+                         causal=False).cuda()
+    y = EncoderWrapper(net)(h, torch.tensor([1.0, 0.7]).cuda())
+    assert y.shape == (2, 51, 64) and torch.isfinite(y).all()
+    y.float().sum().backward()
+    assert cnn.blocks[0].conv.weight.grad is not None and torch.isfinite(cnn.blocks[0].conv.weight.grad).all()
