@@ -270,11 +270,11 @@ __device__ __forceinline__ void fill_u_vec(float (*u)[DW_CT], const DwParams& p,
     const int it = tid + 256 * k;
     if (it < ROWS * LPR) {
       const int i = it / LPR, cc = (it % LPR) * VW;
-      const int tau = t0 - PAD + i, ch = c0 + cc;
+      const int tau = map_frame(t0 - PAD + i, p.T, p.pad_mode), ch = c0 + cc;   // zero pad -> -1, reflect -> mirrored
       float v[VW];
 #pragma unroll
       for (int q = 0; q < VW; ++q) v[q] = 0.f;
-      if (tau >= 0 && tau < p.T && ch < p.D) {
+      if (tau >= 0 && ch < p.D) {
         const T* row = P + ((long)b * p.T + tau) * p.ldp;
         ld_chunk<T>(row + ch, v);
         if (p.glu) {
@@ -325,6 +325,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_fast(DwParams p) {
       float v[VW];
 #pragma unroll
       for (int q = 0; q < VW; ++q) v[q] = u[r][cc + q];
+      if (p.gate) {                                    // CSGU: y = conv(x2) * x1
+        float gt[VW];
+        ld_chunk<T>(reinterpret_cast<const T*>(p.gate) + ((long)b * p.T + t) * p.ldg + chv, gt);
+#pragma unroll
+        for (int q = 0; q < VW; ++q) v[q] *= gt[q];
+      }
       st_chunk<T>(Y + ((long)b * p.T + t) * p.ldy + chv, v);
     }
   }
@@ -362,7 +368,15 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
         float v[VW];
 #pragma unroll
         for (int q = 0; q < VW; ++q) v[q] = 0.f;
-        if (t >= 0 && t < p.T && chv < p.D) ld_chunk<T>(dY + ((long)b * p.T + t) * p.ldy + chv, v);
+        if (t >= 0 && t < p.T && chv < p.D) {
+          ld_chunk<T>(dY + ((long)b * p.T + t) * p.ldy + chv, v);
+          if (p.gate) {                                // gradient w.r.t. the conv output: dY * gate
+            float gt[VW];
+            ld_chunk<T>(reinterpret_cast<const T*>(p.gate) + ((long)b * p.T + t) * p.ldg + chv, gt);
+#pragma unroll
+            for (int q = 0; q < VW; ++q) v[q] *= gt[q];
+          }
+        }
 #pragma unroll
         for (int q4 = 0; q4 < VW / 4; ++q4)
           *reinterpret_cast<float4*>(&g[i][cc + 4 * q4]) = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
@@ -373,6 +387,30 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
 #pragma unroll
     for (int i = 0; i < WIN; ++i) { uw[i] = u[f0 + i][cl]; gw[i] = g[f0 + i][cl]; }
     __syncthreads();                                 // windows are in registers: u can take the du tile
+    if (p.gate) {                                    // dgate = dY * conv(x2)  (forward recompute out of the window)
+      const float bsv = (p.bias && cok) ? p.bias[ch] : 0.f;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) {
+        float acc = bsv;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc += w[j] * uw[o + j];
+        u[f0 + o][cl] = acc;
+      }
+      __syncthreads();
+      T* dG = reinterpret_cast<T*>(p.dgate);
+      for (int it = threadIdx.x; it < DW_TT * LPR; it += 256) {
+        const int r = it / LPR, cc = (it % LPR) * VW;
+        const int t = t0 + r, chv = c0 + cc;
+        if (t < p.T && chv < p.D) {
+          float dyv[VW], o8[VW];
+          ld_chunk<T>(dY + ((long)b * p.T + t) * p.ldy + chv, dyv);
+#pragma unroll
+          for (int q = 0; q < VW; ++q) o8[q] = dyv[q] * u[r][cc + q];
+          st_chunk<T>(dG + ((long)b * p.T + t) * p.lddg + chv, o8);
+        }
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       float sacc = 0.f;
@@ -387,6 +425,21 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
       float du = 0.f;
 #pragma unroll
       for (int j = 0; j < K; ++j) du += w[j] * gw[o - j + 2 * PAD];
+      if (p.pad_mode == SMX_PAD_REFLECT) {           // fold the gradient of the mirrored virtual frames (edge tiles only)
+        const int tau = t0 + f0 + o;
+        if (tau >= 1 && tau <= PAD) {                // virtual frame -tau mirrors frame tau
+          for (int j = 0; j < K; ++j) {
+            const int tt = -tau - j + PAD, r = tt - (t0 - PAD);
+            if (tt >= 0 && tt < p.T && r >= 0 && r < ROWS) du += w[j] * g[r][cl];
+          }
+        }
+        if (tau <= p.T - 2 && tau >= p.T - 1 - PAD) {   // virtual frame 2(T-1)-tau mirrors frame tau
+          for (int j = 0; j < K; ++j) {
+            const int tt = 2 * (p.T - 1) - tau - j + PAD, r = tt - (t0 - PAD);
+            if (tt >= 0 && tt < p.T && r >= 0 && r < ROWS) du += w[j] * g[r][cl];
+          }
+        }
+      }
       u[f0 + o][cl] = du;
     }
     __syncthreads();
@@ -469,8 +522,8 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
   dim3 grid((D + DW_CT - 1) / DW_CT, (T + DW_TT - 1) / DW_TT, B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int vw = dtype == SMX_BF16 ? 8 : 4;
-  const bool fast = k == 31 && pad_mode == SMX_PAD_ZERO && chunk <= 0 && gate == nullptr && D % vw == 0 &&
-                    ldp % vw == 0 && ldy % vw == 0 && aligned16(P) && aligned16(Y);
+  const bool fast = k == 31 && chunk <= 0 && D % vw == 0 && ldp % vw == 0 && ldy % vw == 0 && aligned16(P) && aligned16(Y) &&
+                    (gate == nullptr || (ldg % vw == 0 && aligned16(gate))) && (pad_mode == SMX_PAD_ZERO || T > 15);
   if (fast) {
     if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_fast<bf16_t, 31>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((dwconv_fwd_fast<float, 31>), grid, dim3(256), 0, s, p);
@@ -509,9 +562,10 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
   dim3 grid(ctiles, (unsigned)gy);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int vw = dtype == SMX_BF16 ? 8 : 4;
-  const bool fast = k == 31 && pad_mode == SMX_PAD_ZERO && chunk <= 0 && gate == nullptr && D % vw == 0 &&
-                    ldp % vw == 0 && lddy % vw == 0 && lddp % vw == 0 && aligned16(P) && aligned16(dY) && aligned16(dP) &&
-                    workspace != nullptr;
+  const bool fast = k == 31 && chunk <= 0 && D % vw == 0 && ldp % vw == 0 && lddy % vw == 0 && lddp % vw == 0 &&
+                    aligned16(P) && aligned16(dY) && aligned16(dP) && workspace != nullptr &&
+                    (gate == nullptr || (ldg % vw == 0 && lddg % vw == 0 && aligned16(gate) && aligned16(dgate))) &&
+                    (pad_mode == SMX_PAD_ZERO || T > 15);
   if (fast) {
     float* partial = reinterpret_cast<float*>(workspace);
     if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_fast<bf16_t, 31>), grid, dim3(256), 0, s, p, tiles_t, partial);

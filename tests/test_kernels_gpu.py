@@ -176,11 +176,11 @@ def test_glu_dwconv_fwd_bwd(B, T, D, k, chunk, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
-def test_gated_reflect_dwconv_fwd_bwd(dtype, tol):
-    """Branchformer CSGU form: y = gate * conv_reflect(x)."""
+@pytest.mark.parametrize("B,T,D,k", [(2, 90, 48, 7), (2, 150, 64, 31), (1, 40, 16, 31), (3, 129, 72, 31)])
+def test_gated_reflect_dwconv_fwd_bwd(B, T, D, k, dtype, tol):
+    """Branchformer CSGU form: y = gate * conv_reflect(x)  (k=31 takes the register-window fast path)."""
     L, ops = _ops()
-    torch.manual_seed(11)
-    B, T, D, k = 2, 90, 48, 7
+    torch.manual_seed(11 + T)
     x = torch.randn(B * T, D, device="cuda").to(dtype)
     gate = torch.randn(B * T, D, device="cuda").to(dtype)
     w = torch.randn(D, k, device="cuda") * 0.3
