@@ -190,7 +190,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("SMX_FORCE_ALLREDUCE") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -210,7 +211,7 @@ def main():
     if train:
         opt = FlatAdamW(enc, lr=8e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
                         compute_dtype=dtype)
-        if world > 1:   # one gradient bucket per encoder layer, reduced as soon as the layer's backward is done
+        if world > 1 or force_dist:   # one gradient bucket per encoder layer, reduced as soon as its backward is done
             for layer in enc.transformer.encoder.layers:
                 rng = opt.param_range(list(layer.parameters()))
                 layer._on_bwd_done = (lambda r=rng: opt.reduce_bucket_async(*r))
@@ -223,7 +224,7 @@ def main():
             opt.zero_grad()
             y = enc(src, wav_len)
             y.backward(r)
-            if world > 1:   # parameters outside the layer buckets (input Linear, final LN)
+            if world > 1 or force_dist:   # parameters outside the layer buckets (input Linear, final LN)
                 first = opt.param_range(list(enc.transformer.encoder.layers[0].parameters()))[0]
                 last = opt.param_range(list(enc.transformer.encoder.layers[-1].parameters()))[1]
                 if first > 0:
@@ -236,7 +237,7 @@ def main():
                 enc(src, wav_len)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -248,7 +249,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -256,7 +257,8 @@ def main():
     frames_per_step = cfg["B"] * cfg["T"] * world
     value = frames_per_step * args.steps / dt
     out = {
-        "metric": "encoder frames/s (whole node), LibriSpeech Conformer-SummaryMixing",
+        "metric": "encoder frames/s (whole node), " + ("LibriSpeech Conformer-SummaryMixing" if cfg["kind"] == "conformer"
+                                                       else "CommonVoice Branchformer-SummaryMixing"),
         "value": value, "unit": "encoder frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
@@ -276,7 +278,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, train)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

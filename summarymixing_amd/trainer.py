@@ -11,6 +11,8 @@ for the gradients, the two AdamW moments and the bf16 shadow weights the GEMMs r
     (smx_sumsq, smx_clip_factor, smx_adamw_step), the clip factor never visits the host.
 Forward/backward need no communication: utterances never interact.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -49,6 +51,8 @@ class FlatAdamW:
         self.step_count = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        # SMX_FORCE_ALLREDUCE=1 exercises the collective path on a single rank (identity all-reduce) for smoke tests
+        self._collective = self.world > 1 or (os.environ.get("SMX_FORCE_ALLREDUCE") == "1" and dist.is_initialized())
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._clip = torch.ones(1, dtype=torch.float32, device=dev)
         self._pending = []
@@ -67,14 +71,14 @@ class FlatAdamW:
 
     def reduce_bucket_async(self, start, end):
         """Launch the all-reduce of one gradient bucket (called right after its producer's backward)."""
-        if self.world > 1:
+        if self._collective:
             self._pending.append(dist.all_reduce(self.flat_g[start:end], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def zero_grad(self):
         self.flat_g.zero_()
 
     def step(self, reduce_all=False):
-        if self.world > 1:
+        if self._collective:
             if reduce_all:
                 self.reduce_bucket_async(0, self.total)
             for w in self._pending:
