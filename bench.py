@@ -31,11 +31,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # BASELINE.json configs[1]: 12 layers, d_model 256 (SURVEY §8d "C2b"); saturating batch B=64, T_enc=500
-    "c2b": dict(kind="conformer", d=256, f=1024, l=256, layers=12, nhead=4, input=640, B=64, T=500,
+    # BASELINE.json configs[1]: 12 layers, d_model 256 (SURVEY §8d "C2b").  Batch: 128 utterances x 500 encoder frames
+    # (20 s each): the recipe sizes 150 s of audio per batch for a 24 GB card (...transducer.yaml:112-116), the same
+    # rule gives ~1800-2600 s on 288 GB.  --batch 64 reproduces SURVEY's "saturating batch".
+    "c2b": dict(kind="conformer", d=256, f=1024, l=256, layers=12, nhead=4, input=640, B=128, T=500,
                 name="LibriSpeech Conformer-SummaryMixing C2b (12L, d_model=256, d_ffn=1024, SummaryMixing-fast, Swish)"),
     # recipe-faithful shapes of conformer_summarymixing_transducer.yaml:130-146 (SURVEY §8d "C2a")
-    "c2a": dict(kind="conformer", d=512, f=2048, l=512, layers=12, nhead=4, input=640, B=64, T=500,
+    "c2a": dict(kind="conformer", d=512, f=2048, l=512, layers=12, nhead=4, input=640, B=128, T=500,
                 name="LibriSpeech Conformer-SummaryMixing C2a (12L, d_model=512, d_ffn=2048, SummaryMixing-fast, Swish)"),
     # plumbing config 1
     "c1": dict(kind="conformer", d=144, f=576, l=144, layers=2, nhead=4, input=640, B=2, T=50,
