@@ -291,7 +291,7 @@ __device__ __forceinline__ void fill_u_vec(float (*u)[DW_CT], const DwParams& p,
   }
 }
 
-template <typename T, int K>
+template <typename T, int K, bool GATE>
 __global__ __launch_bounds__(256) void dwconv_fwd_fast(DwParams p) {
   constexpr int PAD = (K - 1) / 2, WIN = 16 + K - 1, ROWS = DW_TT + K - 1;
   constexpr int VW = DwVec<T>::N, LPR = DW_CT / VW;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_fast(DwParams p) {
       float v[VW];
 #pragma unroll
       for (int q = 0; q < VW; ++q) v[q] = u[r][cc + q];
-      if (p.gate) {                                    // CSGU: y = conv(x2) * x1
+      if constexpr (GATE) {                            // CSGU: y = conv(x2) * x1
         float gt[VW];
         ld_chunk<T>(reinterpret_cast<const T*>(p.gate) + ((long)b * p.T + t) * p.ldg + chv, gt);
 #pragma unroll
@@ -336,15 +336,21 @@ __global__ __launch_bounds__(256) void dwconv_fwd_fast(DwParams p) {
   }
 }
 
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, float* __restrict__ partial) {
+template <typename T, int K, bool REFLECT, bool GATE>
+__global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, float* __restrict__ partial, int gy) {
   constexpr int PAD = (K - 1) / 2, WIN = 16 + K - 1, ROWS = DW_TT + K - 1;
   constexpr int VW = DwVec<T>::N, LPR = DW_CT / VW, NITEM = (ROWS * LPR + 255) / 256;
   __shared__ __attribute__((aligned(16))) float u[ROWS][DW_CT];
   __shared__ __attribute__((aligned(16))) float g[ROWS][DW_CT];
   __shared__ float red[3][DW_CT];
   const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c0 = blockIdx.x * DW_CT, ch = c0 + cl;
+  // workgroup b runs on XCD b % 8: keep the channel tiles of one frame-tile sequence on ONE XCD and adjacent in
+  // dispatch order, so the 128-byte pieces of a feature row are fetched by neighbours at the same time
+  const int ctiles = (p.D + DW_CT - 1) / DW_CT;
+  const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+  const int by = (widx / ctiles) * 8 + xcd, bx = widx % ctiles;
+  if (by >= gy) return;
+  const int c0 = bx * DW_CT, ch = c0 + cl;
   const bool cok = ch < p.D;
   float w[K], dw[K];
 #pragma unroll
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
   T* dP = reinterpret_cast<T*>(p.dP);
   const int f0 = wv * 16;
   const long total = (long)p.B * tiles_t;
-  for (long it0 = blockIdx.y; it0 < total; it0 += gridDim.y) {
+  for (long it0 = by; it0 < total; it0 += gy) {
     const int b = (int)(it0 / tiles_t), t0 = (int)(it0 % tiles_t) * DW_TT;
     __syncthreads();
     fill_u_vec<T, ROWS, PAD>(u, p, b, t0, c0, threadIdx.x);
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
         for (int q = 0; q < VW; ++q) v[q] = 0.f;
         if (t >= 0 && t < p.T && chv < p.D) {
           ld_chunk<T>(dY + ((long)b * p.T + t) * p.ldy + chv, v);
-          if (p.gate) {                                // gradient w.r.t. the conv output: dY * gate
+          if constexpr (GATE) {                        // gradient w.r.t. the conv output: dY * gate
             float gt[VW];
             ld_chunk<T>(reinterpret_cast<const T*>(p.gate) + ((long)b * p.T + t) * p.ldg + chv, gt);
 #pragma unroll
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
 #pragma unroll
     for (int i = 0; i < WIN; ++i) { uw[i] = u[f0 + i][cl]; gw[i] = g[f0 + i][cl]; }
     __syncthreads();                                 // windows are in registers: u can take the du tile
-    if (p.gate) {                                    // dgate = dY * conv(x2)  (forward recompute out of the window)
+    if constexpr (GATE) {                            // dgate = dY * conv(x2)  (forward recompute out of the window)
       const float bsv = (p.bias && cok) ? p.bias[ch] : 0.f;
 #pragma unroll
       for (int o = 0; o < 16; ++o) {
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
       float du = 0.f;
 #pragma unroll
       for (int j = 0; j < K; ++j) du += w[j] * gw[o - j + 2 * PAD];
-      if (p.pad_mode == SMX_PAD_REFLECT) {           // fold the gradient of the mirrored virtual frames (edge tiles only)
+      if constexpr (REFLECT) {                       // fold the gradient of the mirrored virtual frames (edge tiles only)
         const int tau = t0 + f0 + o;
         if (tau >= 1 && tau <= PAD) {                // virtual frame -tau mirrors frame tau
           for (int j = 0; j < K; ++j) {
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
     __syncthreads();
     if (wv == 0 && cok) {
       const float tot = ((v + red[0][cl]) + red[1][cl]) + red[2][cl];
-      partial[((long)blockIdx.y * p.D + ch) * (K + 1) + j] = tot;
+      partial[((long)by * p.D + ch) * (K + 1) + j] = tot;
     }
   }
 }
@@ -525,8 +531,13 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
   const bool fast = k == 31 && chunk <= 0 && D % vw == 0 && ldp % vw == 0 && ldy % vw == 0 && aligned16(P) && aligned16(Y) &&
                     (gate == nullptr || (ldg % vw == 0 && aligned16(gate))) && (pad_mode == SMX_PAD_ZERO || T > 15);
   if (fast) {
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_fast<bf16_t, 31>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((dwconv_fwd_fast<float, 31>), grid, dim3(256), 0, s, p);
+    if (gate) {
+      if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_fast<bf16_t, 31, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((dwconv_fwd_fast<float, 31, true>), grid, dim3(256), 0, s, p);
+    } else {
+      if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_fast<bf16_t, 31, false>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((dwconv_fwd_fast<float, 31, false>), grid, dim3(256), 0, s, p);
+    }
   } else if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((dwconv_fwd_kernel<float>), grid, dim3(256), 0, s, p);
   return check_launch("smx_dwconv1d_glu_fwd");
@@ -568,8 +579,17 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
                     (pad_mode == SMX_PAD_ZERO || T > 15);
   if (fast) {
     float* partial = reinterpret_cast<float*>(workspace);
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_fast<bf16_t, 31>), grid, dim3(256), 0, s, p, tiles_t, partial);
-    else hipLaunchKernelGGL((dwconv_bwd_fast<float, 31>), grid, dim3(256), 0, s, p, tiles_t, partial);
+    dim3 g1((unsigned)(8 * ctiles * ((gy + 7) / 8)));
+    const bool refl = pad_mode == SMX_PAD_REFLECT, gt = gate != nullptr;
+#define DW_BWD(TT, R, G) hipLaunchKernelGGL((dwconv_bwd_fast<TT, 31, R, G>), g1, dim3(256), 0, s, p, tiles_t, partial, (int)gy)
+    if (dtype == SMX_BF16) {
+      if (refl && gt) DW_BWD(bf16_t, true, true); else if (refl) DW_BWD(bf16_t, true, false);
+      else if (gt) DW_BWD(bf16_t, false, true); else DW_BWD(bf16_t, false, false);
+    } else {
+      if (refl && gt) DW_BWD(float, true, true); else if (refl) DW_BWD(float, true, false);
+      else if (gt) DW_BWD(float, false, true); else DW_BWD(float, false, false);
+    }
+#undef DW_BWD
     const long W = (long)D * (k + 1);
     hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, (int)gy, D, k, dw, dbias);
   } else if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, p, tiles_t);
