@@ -59,8 +59,16 @@ typedef struct smx_epilogue {
   float alpha;         int32_t flags;                     /* SMX_EPI_C0_POST: add C0 after dropout/mask/alpha      */
   float drop_p;        int32_t drop_pad;                  /* fused inverted dropout (0 = off), applied after act()  */
   uint64_t drop_seed;                                     /* counter-based mask, same indexing as smx_dropout       */
+  float* colsum;                                          /* [M] fp32 or NULL: colsum[m] += sum_n C[n,m] (fixed order) */
+  void* workspace;                                        /* smx_gemm_colsum_workspace(N, M) bytes when colsum is set  */
 } smx_epilogue;
-enum { SMX_EPI_C0_POST = 1 };
+/* flags.  SMX_EPI_ACT_GRAD turns the epilogue into the BACKWARD of an upstream activation layer: z is then a
+ * read-only INPUT (the pre-activation the forward saved) and
+ *   C[n,m] = alpha * dropout(v * act'(z[n,m])) * row_mask[n]
+ * so a dgrad GEMM dX = dZ W emits the upstream layer's dZ directly (act/dropout/mask backward fused; `res` must be
+ * NULL); with `colsum` the upstream bias gradient comes out of the same launch.  batch == 1, splits == 1. */
+enum { SMX_EPI_C0_POST = 1, SMX_EPI_ACT_GRAD = 2 };
+size_t smx_gemm_colsum_workspace(int N, int M);
 
 /* Batched strided MFMA GEMM  C[b] (N x M) = epilogue( op(A[b]) . op(B[b]) ), reduce length K.
  * Replaces: nn.Linear inside VanillaNN (VanillaNN.py:189-196, summary_mixing.py:207,210,237,257,282),

@@ -15,6 +15,7 @@ C0_NONE, C0_ROW, C0_GROUP, C0_MOD = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_T, OUT_F32, OUT_ATOMIC_F32 = 0, 1, 2
 EPI_C0_POST = 1
+EPI_ACT_GRAD = 2
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACTS = {"none": ACT_NONE, "identity": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH,
         "leaky_relu": ACT_LEAKY_RELU, "relu": ACT_RELU}
@@ -28,7 +29,8 @@ class Epilogue(ctypes.Structure):
                 ("row_mask", c_vp),
                 ("res", c_vp), ("ldr", c_i64),
                 ("alpha", c_f), ("flags", ctypes.c_int32),
-                ("drop_p", c_f), ("drop_pad", ctypes.c_int32), ("drop_seed", ctypes.c_uint64)]
+                ("drop_p", c_f), ("drop_pad", ctypes.c_int32), ("drop_seed", ctypes.c_uint64),
+                ("colsum", c_vp), ("workspace", c_vp)]
 
 
 # name -> (restype, argtypes); mirrors include/smx.h one to one (tests/test_abi.py checks the export list)
@@ -37,6 +39,7 @@ SIGNATURES = {
     "smx_last_error": (ctypes.c_char_p, []),
     "smx_gemm": (c_i, [c_i, c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i,
                        ctypes.POINTER(Epilogue), c_vp]),
+    "smx_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
     "smx_linear_wgrad_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_linear_wgrad": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_f,
                                c_vp, c_vp]),

@@ -22,6 +22,7 @@
 //  * TN/wgrad reduces over the (long) frame dimension: split-K over blockIdx.y with fp32 atomics into the
 //    caller-zeroed gradient buffer.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "smx_common.h"
 
@@ -238,164 +239,235 @@ __device__ __forceinline__ long c0_row(const smx_epilogue& e, int n) {
 }
 
 // ---- one epilogue phase: WN staged fp32 rows (LDS) -> outputs.  vmcnt retires in order and counts stores too, so
-// every side input of the thread's items (bias once, C0 / residual / mask per item) is requested BEFORE the first
-// store; the stores then stream out without any wave ever waiting on them. ------------------------------------------
-template <typename T, int OSZ, int TILE_N, int TILE_M>
-__device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, int nbase, int m0, int bz, int split,
-                                               int t) {
+// every side input of a batch of items (C0 / residual or saved pre-activation / mask) is requested BEFORE the
+// batch's first store; the stores then stream out without any wave waiting on them.
+// Every optional feature sits behind ONE wave-uniform branch per item (never per element), so an absent feature
+// costs no VALU work: the epilogue is VALU-issue bound when the three resident workgroups of a CU reach it together.
+// EVEC: whole, 16-byte aligned items (host-checked) -> no per-element guards at all. -------------------------------
+template <int ACT, int CW>
+__device__ __forceinline__ void act_fwd_n(float (&v)[CW]) {
+#pragma unroll
+  for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<ACT>(v[q]);
+}
+template <int ACT, int CW>
+__device__ __forceinline__ void act_grad_mul_n(float (&v)[CW], const float (&z)[CW]) {
+#pragma unroll
+  for (int q = 0; q < CW; ++q) v[q] *= act_grad_c<ACT>(z[q]);
+}
+// CW elements of type T held as raw 32-bit words -> floats
+template <typename T, int CW>
+__device__ __forceinline__ void unpack_words(const uint32_t (&w)[CW * sizeof(T) / 4], float (&f)[CW]) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int q = 0; q < CW / 2; ++q) { f[2 * q] = bf16_bits_to_f32(w[q] & 0xffffu); f[2 * q + 1] = bf16_bits_to_f32(w[q] >> 16); }
+  } else {
+#pragma unroll
+    for (int q = 0; q < CW; ++q) f[q] = __uint_as_float(w[q]);
+  }
+}
+template <int NW>
+__device__ __forceinline__ void ld_words(const void* p, uint32_t (&w)[NW]) {
+  if constexpr (NW == 4) { const uint4 u = *reinterpret_cast<const uint4*>(p); w[0] = u.x; w[1] = u.y; w[2] = u.z; w[3] = u.w; }
+  else { const uint2 u = *reinterpret_cast<const uint2*>(p); w[0] = u.x; w[1] = u.y; }
+}
+template <typename T, int CW>
+__device__ __forceinline__ void st_elems(void* p, const float (&v)[CW]) {   // CW elements of type T, one store
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (CW == 8) {
+    uint4 u;
+    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+  } else {
+    uint2 u;
+    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = u;
+  }
+}
+
+// "consume" a loaded register: the compiler places the load's s_waitcnt HERE (zero instructions otherwise)
+__device__ __forceinline__ void settle(uint32_t& w) { asm volatile("" : "+v"(w)); }
+__device__ __forceinline__ void settle(float& w) { asm volatile("" : "+v"(w)); }
+
+// side = [TILE_M] bias (0 when absent) followed by [TILE_N] row factors (row_mask * alpha), staged in LDS by the
+// kernel prologue: reading them costs LDS (lgkmcnt) traffic only, never a vmcnt wait behind in-flight stores.
+template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC>
+__device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, const float* side, int ph, int nbase,
+                                               int m0, int bz, int split, int t) {
   constexpr int WN = TILE_N / 2;
   constexpr int STG_LD = TILE_M * 4 + 16;
   constexpr int CW = 16 / OSZ;                          // output columns per item (16 bytes)
   constexpr int CPR = TILE_M / CW;                      // items per row
   constexpr int RSTEP = 256 / CPR;                      // rows covered per pass of the 256 threads
   constexpr int NIT = WN / RSTEP;                       // items per thread
+  constexpr int SW = CW * (int)sizeof(T) / 4;           // 32-bit words of one side-input item (type T)
+  typedef typename std::conditional<OSZ == 4, float, T>::type OutT;
   const smx_epilogue& e = p.e;
   const uint32_t dthresh = p.dthresh;
   const float dscale = p.dscale;
   const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
   if (m >= p.M) return;
-  const int nv = min(CW, p.M - m);
-  const bool vec = p.epi_lds != 0 && nv == CW;
-  const float* bias = e.bias ? e.bias + (long)bz * e.bias_batch_stride : nullptr;
+  const float* mkrow = side + TILE_M + ph * WN;
   char* Cb = reinterpret_cast<char*>(p.C) + ((long)bz * p.sC + (long)split * p.sSplit) * OSZ;
-  T* Zb = e.z ? reinterpret_cast<T*>(e.z) + (long)bz * p.sC : nullptr;
-  const T* Rb = e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr;
-  // ---- loads ----
-  float bv[CW];
+  const bool ag = (e.flags & SMX_EPI_ACT_GRAD) != 0;     // z is an input: multiply by act'(z)
+  const bool c0post = (e.flags & SMX_EPI_C0_POST) != 0;
+  const bool has_c0 = e.c0_mode != SMX_C0_NONE;
+  const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
+  T* Zb = (e.z && !ag) ? reinterpret_cast<T*>(e.z) + (long)bz * p.sC : nullptr;
+  // the one side input of element type: the residual, or (ACT_GRAD) the saved pre-activation
+  const T* Sb = ag ? reinterpret_cast<const T*>(e.z) : (e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr);
+  const long lds_ = ag ? e.ldz : e.ldr;
+
+  if constexpr (EVEC) {
+    // ---- the element-type side input (residual / saved pre-activation) of ALL the phase's items is requested and
+    // waited for before the phase's first store; the (rarer, fp32, twice as wide) C0 rows go in batches of NB items.
+    // vmcnt retires in order and counts stores: a load issued after stores can only be consumed once those stores
+    // have drained, so every such point is a full write-latency bubble - none of them sits between two stores of a
+    // kernel without side inputs, one per phase with a residual, one per batch with C0. ----
+    constexpr int NB = NIT < 2 ? NIT : 2;
+    uint32_t sw[NIT][SW];
+    if (Sb) {
 #pragma unroll
-  for (int q = 0; q < CW; ++q) bv[q] = 0.f;
-  if (bias) {
-    if (vec) {
-#pragma unroll
-      for (int q4 = 0; q4 < CW / 4; ++q4) {
-        const float4 b4 = *reinterpret_cast<const float4*>(bias + m + 4 * q4);
-        bv[4 * q4] = b4.x; bv[4 * q4 + 1] = b4.y; bv[4 * q4 + 2] = b4.z; bv[4 * q4 + 3] = b4.w;
+      for (int k = 0; k < NIT; ++k) {
+        const int n = min(nbase + r0 + k * RSTEP, p.N - 1);
+        ld_words<SW>(Sb + (long)n * lds_ + m, sw[k]);
       }
+      // settle INSIDE the branch that loads: afterwards no register is a pending load in the compiler's scoreboard on
+      // any path, so it cannot place a (conservative) vmcnt wait between the stores below
+#pragma unroll
+      for (int k = 0; k < NIT; ++k)
+#pragma unroll
+        for (int q = 0; q < SW; ++q) settle(sw[k][q]);
     } else {
 #pragma unroll
-      for (int q = 0; q < CW; ++q) if (q < nv) bv[q] = bias[m + q];
+      for (int k = 0; k < NIT; ++k)
+#pragma unroll
+        for (int q = 0; q < SW; ++q) sw[k][q] = 0u;
     }
-  }
-  // items are handled in batches of NB: all side-input loads of a batch precede its first store (in-order vmcnt)
-  constexpr int NB = NIT < 2 ? NIT : 2;
 #pragma unroll
-  for (int kb = 0; kb < NIT; kb += NB) {
-  float cv[NB][CW], rv[NB][CW], mk[NB];
+    for (int kb = 0; kb < NIT; kb += NB) {
+    float cv[NB][CW];
+    if (has_c0) {
 #pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const int n = nbase + r0 + (kb + k) * RSTEP;
-    const bool nok = n < p.N;
-    mk[k] = ((e.row_mask && nok) ? (e.row_mask[n] ? 1.f : 0.f) : 1.f) * e.alpha;
-#pragma unroll
-    for (int q = 0; q < CW; ++q) { cv[k][q] = 0.f; rv[k][q] = 0.f; }
-    if (e.c0_mode != SMX_C0_NONE && nok) {   // (added before the activation, or after everything with SMX_EPI_C0_POST)
-      const float* c0p = e.c0 + c0_row(e, n) * e.ldc0 + m;
-      if (vec) {
+      for (int k = 0; k < NB; ++k) {
+        const int n = min(nbase + r0 + (kb + k) * RSTEP, p.N - 1);
+        const float* c0p = e.c0 + c0_row(e, n) * e.ldc0 + m;
 #pragma unroll
         for (int q4 = 0; q4 < CW / 4; ++q4) {
           const float4 c4 = *reinterpret_cast<const float4*>(c0p + 4 * q4);
           cv[k][4 * q4] = c4.x; cv[k][4 * q4 + 1] = c4.y; cv[k][4 * q4 + 2] = c4.z; cv[k][4 * q4 + 3] = c4.w;
         }
-      } else {
-#pragma unroll
-        for (int q = 0; q < CW; ++q) if (q < nv) cv[k][q] = c0p[q];
       }
-    }
-    if (Rb && nok) {
-      const T* rp = Rb + (long)n * e.ldr + m;
-      if (vec) {
-        if constexpr (sizeof(T) == 2 && CW == 8) {
-          const uint4 u = *reinterpret_cast<const uint4*>(rp);
-          const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { rv[k][2 * q] = bf16_bits_to_f32(w4[q] & 0xffffu); rv[k][2 * q + 1] = bf16_bits_to_f32(w4[q] >> 16); }
-        } else {
-          load4<T>(rp, reinterpret_cast<float(&)[4]>(rv[k]));
-        }
-      } else {
+      for (int k = 0; k < NB; ++k)
 #pragma unroll
-        for (int q = 0; q < CW; ++q) if (q < nv) rv[k][q] = to_f32(rp[q]);
-      }
-    }
-  }
-  // ---- math + stores ----
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const int r = r0 + (kb + k) * RSTEP, n = nbase + r;
-    if (n >= p.N) continue;
-    float v[CW];
-#pragma unroll
-    for (int q4 = 0; q4 < CW / 4; ++q4) {
-      const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
-      v[4 * q4] = a4.x + bv[4 * q4]; v[4 * q4 + 1] = a4.y + bv[4 * q4 + 1];
-      v[4 * q4 + 2] = a4.z + bv[4 * q4 + 2]; v[4 * q4 + 3] = a4.w + bv[4 * q4 + 3];
-    }
-    const bool c0post = (e.flags & SMX_EPI_C0_POST) != 0;
-    if (!c0post) {
-#pragma unroll
-      for (int q = 0; q < CW; ++q) v[q] += cv[k][q];
-    }
-    if (Zb) {
-      T* zp = Zb + (long)n * e.ldz + m;
-      if (vec) {
-        if constexpr (sizeof(T) == 2 && CW == 8) {
-          uint4 u;
-          u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
-          u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
-          *reinterpret_cast<uint4*>(zp) = u;
-        } else {
-          store4<T>(zp, reinterpret_cast<const float(&)[4]>(v));
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < CW; ++q) if (q < nv) zp[q] = from_f32<T>(v[q]);
-      }
-    }
-    switch (e.act) {
-      case SMX_ACT_GELU:
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<SMX_ACT_GELU>(v[q]);
-        break;
-      case SMX_ACT_SWISH:
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<SMX_ACT_SWISH>(v[q]);
-        break;
-      case SMX_ACT_LEAKY_RELU:
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<SMX_ACT_LEAKY_RELU>(v[q]);
-        break;
-      case SMX_ACT_RELU:
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<SMX_ACT_RELU>(v[q]);
-        break;
-      default: break;
-    }
-    if (dthresh) {                                       // fused inverted dropout, mask = f(seed, n * M + m)
-#pragma unroll
-      for (int q = 0; q < CW; ++q) v[q] = dropout_keep(e.drop_seed, (uint64_t)n * p.M + m + q, dthresh) ? v[q] * dscale : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < CW; ++q) v[q] = v[q] * mk[k] + rv[k][q] + (c0post ? cv[k][q] : 0.f);
-    char* dst = Cb + ((long)n * p.ldc + m) * OSZ;
-    if (vec) {
-      if constexpr (OSZ == 4) {
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint4 u;
-        u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
-        u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(dst) = u;
-      }
+        for (int q = 0; q < CW; ++q) settle(cv[k][q]);
     } else {
 #pragma unroll
-      for (int q = 0; q < CW; ++q) {
-        if (q < nv) {
-          if constexpr (OSZ == 4) reinterpret_cast<float*>(dst)[q] = v[q];
-          else reinterpret_cast<uint16_t*>(dst)[q] = (uint16_t)f32_to_bf16_bits(v[q]);
+      for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int q = 0; q < CW; ++q) cv[k][q] = 0.f;
+    }
+    // ---- math + stores: no global load inside, the stores stream out back to back ----
+#pragma unroll
+    for (int kk = 0; kk < NB; ++kk) {
+      const int k = kb + kk;
+      const int r = r0 + k * RSTEP, n = nbase + r;
+      if (n >= p.N) continue;
+      float v[CW];
+#pragma unroll
+      for (int q4 = 0; q4 < CW / 4; ++q4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
+        v[4 * q4] = a4.x; v[4 * q4 + 1] = a4.y; v[4 * q4 + 2] = a4.z; v[4 * q4 + 3] = a4.w;
+      }
+      if (e.bias) {
+#pragma unroll
+        for (int q4 = 0; q4 < CW / 4; ++q4) {
+          const float4 b4 = *reinterpret_cast<const float4*>(side + c + 4 * q4);
+          v[4 * q4] += b4.x; v[4 * q4 + 1] += b4.y; v[4 * q4 + 2] += b4.z; v[4 * q4 + 3] += b4.w;
         }
       }
+      if (has_c0 && !c0post) {
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] += cv[kk][q];
+      }
+      if (ag) {
+        float zf[CW];
+        unpack_words<T, CW>(sw[k], zf);
+        switch (e.act) {
+          case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, CW>(v, zf); break;
+          case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, CW>(v, zf); break;
+          case SMX_ACT_LEAKY_RELU: act_grad_mul_n<SMX_ACT_LEAKY_RELU, CW>(v, zf); break;
+          case SMX_ACT_RELU: act_grad_mul_n<SMX_ACT_RELU, CW>(v, zf); break;
+          default: break;
+        }
+      } else {
+        if (Zb) st_elems<T, CW>(Zb + (long)n * e.ldz + m, v);
+        switch (e.act) {
+          case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, CW>(v); break;
+          case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, CW>(v); break;
+          case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, CW>(v); break;
+          case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, CW>(v); break;
+          default: break;
+        }
+      }
+      if (dthresh) {                                     // fused inverted dropout, mask = f(seed, n * M + m)
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] = dropout_keep(e.drop_seed, (uint64_t)n * p.M + m + q, dthresh) ? v[q] * dscale : 0.f;
+      }
+      if (has_mk) {
+        const float mk = mkrow[r];
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] *= mk;
+      }
+      if (Sb && !ag) {
+        float rf[CW];
+        unpack_words<T, CW>(sw[k], rf);
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] += rf[q];
+      }
+      if (has_c0 && c0post) {
+#pragma unroll
+        for (int q = 0; q < CW; ++q) v[q] += cv[kk][q];
+      }
+      if (e.colsum) {                                    // final values back into the item's own staged slot
+#pragma unroll
+        for (int q4 = 0; q4 < CW / 4; ++q4)
+          *reinterpret_cast<float4*>(const_cast<char*>(smem) + r * STG_LD + (c + 4 * q4) * 4) =
+              make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+      }
+      st_elems<OutT, CW>(Cb + ((long)n * p.ldc + m) * OSZ, v);
     }
-  }
+    }
+  } else {
+    // ragged / unaligned shapes: one element at a time (rolled loops, run-time activation)
+    const int nv = min(CW, p.M - m);
+    const float* sf = reinterpret_cast<const float*>(smem);
+#pragma unroll 1
+    for (int k = 0; k < NIT; ++k) {
+      const int r = r0 + k * RSTEP, n = nbase + r;
+      if (n >= p.N) continue;
+      const float mkv = mkrow[r];
+      const float* c0p = has_c0 ? e.c0 + c0_row(e, n) * e.ldc0 + m : nullptr;
+#pragma unroll 1
+      for (int q = 0; q < nv; ++q) {
+        float v = sf[r * (STG_LD / 4) + c + q] + side[c + q];
+        if (c0p && !c0post) v += c0p[q];
+        if (ag) {
+          v *= act_grad(e.act, to_f32(Sb[(long)n * lds_ + m + q]));
+        } else {
+          if (Zb) Zb[(long)n * e.ldz + m + q] = from_f32<T>(v);
+          v = act_fwd(e.act, v);
+        }
+        if (dthresh) v = dropout_keep(e.drop_seed, (uint64_t)n * p.M + m + q, dthresh) ? v * dscale : 0.f;
+        v *= mkv;
+        if (Sb && !ag) v += to_f32(Sb[(long)n * lds_ + m + q]);
+        if (c0p && c0post) v += c0p[q];
+        if (e.colsum) const_cast<float*>(sf)[r * (STG_LD / 4) + c + q] = v;
+        if constexpr (OSZ == 4) reinterpret_cast<float*>(Cb)[(long)n * p.ldc + m + q] = v;
+        else reinterpret_cast<uint16_t*>(Cb)[(long)n * p.ldc + m + q] = (uint16_t)f32_to_bf16_bits(v);
+      }
+    }
   }
 }
 
@@ -409,7 +481,11 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
   constexpr int B_BYTES = lds_bytes<T, TILE_M, B_KC>();
   constexpr int EPI_BYTES = (TILE_N / 2) * (TILE_M * 4 + 16);   // one half-tile of fp32 rows, 16 B row pad
   constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > EPI_BYTES ? (A_BYTES + B_BYTES) : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
+  constexpr int SIDE_BYTES = (TILE_M + TILE_N) * 4;              // bias[TILE_M] | row factors[TILE_N] (mask * alpha)
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES + RED_BYTES + SIDE_BYTES];
+  float* red = reinterpret_cast<float*>(smem + SMEM_BYTES);
+  float* side = red + TILE_M;
   char* As = smem;
   char* Bs = smem + A_BYTES;
 
@@ -451,6 +527,18 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
 
   const T* A = reinterpret_cast<const T*>(p.A) + (long)bz * p.sA;
   const T* B = reinterpret_cast<const T*>(p.B) + (long)bz * p.sB;
+
+  // epilogue side vector of this thread (requested first, parked in ONE register across the main loop, published to
+  // LDS before the epilogue): t < TILE_M -> bias[m0 + t], then TILE_N row factors row_mask[n] * alpha
+  float side_v = 0.f;
+  if (p.e.out_mode != SMX_OUT_ATOMIC_F32) {
+    if (t < TILE_M) {
+      if (p.e.bias && m0 + t < p.M) side_v = p.e.bias[(long)bz * p.e.bias_batch_stride + m0 + t];
+    } else if (t < TILE_M + TILE_N) {
+      const int n = n0 + t - TILE_M;
+      side_v = ((p.e.row_mask && n < p.N) ? (p.e.row_mask[n] ? 1.f : 0.f) : 1.f) * p.e.alpha;
+    }
+  }
 
   f32x16 acc[FN][FM];
 #pragma unroll
@@ -562,6 +650,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
   }
   constexpr int STG_LD = TILE_M * 4 + 16;               // bytes per staged fp32 row (16 B pad: conflict-free b128)
   const int osz = (e.out_mode == SMX_OUT_T) ? (int)sizeof(T) : 4;
+  if (t < TILE_M + TILE_N) side[t] = side_v;             // (visible after the first barrier below)
+#pragma unroll 1
   for (int ph = 0; ph < 2; ++ph) {
     lds_barrier();
     if (wn == ph) {
@@ -576,8 +666,20 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
     }
     lds_barrier();
     SMX_STAMP(3 + 2 * ph);
-    if (sizeof(T) == 2 && osz == 2) epilogue_phase<T, 2, TILE_N, TILE_M>(p, smem, n0 + ph * WN, m0, bz, split, t);
-    else epilogue_phase<T, 4, TILE_N, TILE_M>(p, smem, n0 + ph * WN, m0, bz, split, t);
+    if (sizeof(T) == 2 && osz == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + ph * WN, m0, bz, split, t);
+    else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + ph * WN, m0, bz, split, t);
+    if (e.colsum) {
+      // column sums of this phase's outputs (the bias gradient of a fused backward): every item was written back to
+      // its staged slot; thread t < TILE_M adds column t over the valid rows in a fixed order
+      lds_barrier();
+      if (t < TILE_M) {
+        const int rows = min(WN, p.N - (n0 + ph * WN));
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += *reinterpret_cast<const float*>(smem + r * STG_LD + t * 4);
+        if (ph == 0) red[t] = s;
+        else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = red[t] + s;
+      }
+    }
     SMX_STAMP(4 + 2 * ph);
   }
   SMX_STAMP(7);
@@ -593,6 +695,7 @@ static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
   if (p.splits > 1) grid = dim3(8 * p.tiles_n * p.tiles_m * p.batch * ((p.splits + 7) / 8), 1);
   if (vec) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, TN, TM, true>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, TN, TM, false>), grid, dim3(256), 0, s, p);
+  if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
   return check_launch("smx_gemm");
 }
 
@@ -600,7 +703,8 @@ template <typename T, bool A_KC, bool B_KC>
 static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // big tiles once they alone fill the chip (256 CUs x 2 resident blocks); otherwise 64x64 for more blocks
   long big = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch * p.splits;
-  if (big >= 256 && p.N >= 128 && p.M >= 128) return launch_tile<T, A_KC, B_KC, 128, 128>(p, vec, s);
+  static const int force_small = getenv("SMX_GEMM_TILE64") ? 1 : 0;   // experiment knob
+  if (!force_small && big >= 256 && p.N >= 128 && p.M >= 128) return launch_tile<T, A_KC, B_KC, 128, 128>(p, vec, s);
   return launch_tile<T, A_KC, B_KC, 64, 64>(p, vec, s);
 }
 
@@ -677,6 +781,14 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
                 ok16(p.e.c0, p.e.ldc0, 0, 4) && (split_stride * (int64_t)cs) % 16 == 0 && M % 4 == 0;
     p.sSplit = split_stride;
   }
+  // the vector kernels take whole 16-byte items in the epilogue as well (no per-element guards anywhere)
+  vec = vec && p.epi_lds && M % (int)(16 / cs) == 0;
+  if (p.e.flags & SMX_EPI_ACT_GRAD)
+    SMX_REQUIRE(p.e.z && !p.e.res && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
+                "smx_gemm: SMX_EPI_ACT_GRAD needs z (input), no residual, batch == 1, splits == 1");
+  if (p.e.colsum)
+    SMX_REQUIRE(p.e.workspace && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
+                "smx_gemm: colsum needs a workspace (smx_gemm_colsum_workspace), batch == 1, splits == 1");
   static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
   p.ablate = ablate;
   p.dbg = g_dbg_stamps;
@@ -685,6 +797,11 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SMX_BF16) return launch_dtype<bf16_t>(layout, p, vec, s);
   return launch_dtype<float>(layout, p, vec, s);
+}
+
+extern "C" size_t smx_gemm_colsum_workspace(int N, int M) {
+  if (N <= 0 || M <= 0) return 0;
+  return (size_t)((N + 63) / 64) * (size_t)M * sizeof(float);   // one partial row per N tile (64 = the small tile)
 }
 
 extern "C" int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,

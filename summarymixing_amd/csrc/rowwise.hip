@@ -595,6 +595,10 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
   }
 }
 
+void launch_colsum_partials(const float* partial, int nrows, int W, float* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((W + 15) / 16), dim3(256), 0, stream, partial, nrows, W, dst);
+}
+
 // generic (ragged / unaligned) variant: 4 columns per thread, scalar accesses
 template <typename T>
 __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long lddy, const T* Z, long ldz,

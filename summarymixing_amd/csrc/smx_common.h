@@ -15,6 +15,8 @@ namespace smx {
 char* last_error_buf();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+// dst[c] += sum_r partial[r][c], fixed order (rowwise.hip); shared by the act/mask backward and the GEMM colsum epilogue
+void launch_colsum_partials(const float* partial, int nrows, int W, float* dst, hipStream_t stream);
 
 #define SMX_REQUIRE(cond, ...) \
   do {                         \

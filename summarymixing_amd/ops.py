@@ -49,7 +49,11 @@ def rows2d(x):
 
 
 def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, out_mode=L.OUT_T, z=None,
-             row_mask=None, res=None, alpha=1.0, bias_batch_stride=0, drop=None, c0_post=False):
+             row_mask=None, res=None, alpha=1.0, bias_batch_stride=0, drop=None, c0_post=False, act_grad_z=None,
+             colsum=None):
+    """Build an smx_epilogue.  act_grad_z: the saved pre-activation of the UPSTREAM layer (SMX_EPI_ACT_GRAD: the GEMM
+    then emits alpha * D(acc * act'(z)) * mask, i.e. the upstream dZ); colsum: fp32 [M] accumulator of the output's
+    column sums (the upstream bias gradient), workspace attached by gemm()."""
     e = L.Epilogue()
     e.bias = bias.data_ptr() if bias is not None else None
     e.bias_batch_stride = bias_batch_stride
@@ -68,6 +72,13 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         e.res, e.ldr = res.data_ptr(), _mat(res)[1]
     e.alpha = alpha
     e.flags = L.EPI_C0_POST if c0_post else 0
+    if act_grad_z is not None:
+        assert z is None and res is None
+        e.z, e.ldz = act_grad_z.data_ptr(), _mat(act_grad_z)[1]
+        e.flags |= L.EPI_ACT_GRAD
+    if colsum is not None:
+        assert colsum.dtype == torch.float32 and colsum.is_contiguous()
+        e.colsum = colsum.data_ptr()
     if drop is not None and drop[0] > 0.0:
         e.drop_p, e.drop_seed = drop
     return e
@@ -81,6 +92,8 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
     if epi is None:
         epi = epilogue()
     assert a.dtype == b.dtype
+    if epi.colsum:
+        epi.workspace = _workspace(L.lib().smx_gemm_colsum_workspace(N, M), c.device, "gemm_colsum").data_ptr()
     L.check(L.lib().smx_gemm(layout, dt(a), pa, lda or la, sa, pb, ldb or lb, sb, pc, ldc or lc, sc, N, M, K, batch,
                              splits, ctypes.byref(epi), _stream()), "smx_gemm")
     return c

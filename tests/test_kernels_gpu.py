@@ -201,6 +201,31 @@ def test_gated_reflect_dwconv_fwd_bwd(B, T, D, k, dtype, tol):
     assert rel_err(dw, wr.grad) <= 2 * tol and rel_err(db, br.grad) <= 2 * tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("N,M,K", [(700, 256, 136), (333, 72, 40), (1500, 1024, 256), (130, 67, 24)])
+def test_gemm_act_grad_epilogue(N, M, K, dtype, tol):
+    """SMX_EPI_ACT_GRAD + colsum: the dgrad GEMM emits the UPSTREAM layer's dZ = alpha * D(dX * act'(Z)) * mask and
+    its bias gradient in one launch; must equal the unfused act_mask_bwd path (same dropout seed)."""
+    L, ops = _ops()
+    torch.manual_seed(N + K)
+    dz2 = torch.randn(N, K, device="cuda").to(dtype)
+    w = (torch.randn(K, M, device="cuda") * 0.2).to(dtype)            # NN: dX (N,M) = dZ2 (N,K) W (K,M)
+    z = torch.randn(N, M, device="cuda").to(dtype)
+    mask = (torch.rand(N, device="cuda") > 0.3).view(torch.uint8)
+    for act, drop, mk, alpha in [(L.ACT_SWISH, None, None, 1.0), (L.ACT_GELU, (0.2, 1234567), mask, 0.5),
+                                 (L.ACT_RELU, (0.1, 99), None, 1.0), (L.ACT_NONE, None, mask, 1.0)]:
+        out = torch.empty(N, M, device="cuda", dtype=dtype)
+        gb = torch.full((M,), 0.25, device="cuda")
+        e = ops.epilogue(act=act, act_grad_z=z, drop=drop, row_mask=mk, alpha=alpha, colsum=gb)
+        ops.gemm(L.GEMM_NN, dz2, w, out, N, M, K, e)
+        dx = (dz2.double() @ w.double()).float()                       # unfused reference on the fp32 product
+        ref = torch.empty(N, M, device="cuda")
+        gb_ref = torch.full((M,), 0.25, device="cuda")
+        ops.act_mask_bwd(dx, z.float(), mk, act, alpha, ref, gb_ref, drop=drop)
+        assert rel_err(out, ref) <= tol
+        assert rel_err(gb, gb_ref) <= tol
+
+
 def test_act_mask_bwd_reductions():
     L, ops = _ops()
     torch.manual_seed(6)

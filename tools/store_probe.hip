@@ -14,8 +14,10 @@ __global__ __launch_bounds__(256) void tile_store(char* out, long rowbytes, int 
     *reinterpret_cast<uint4*>(out + ((long)tn * rows + r) * rowbytes + (long)tm * seg + c * 16) = v;
   }
 }
-int main() {
-  const long R = 32000, rowbytes = 4096;   // 131 MB  (= Y and Z of the FFN up-projection side by side)
+int main(int argc, char** argv) {
+  // default 131 MB (= Y and Z of the FFN up-projection at 32000 frames: fits the 256 MB MALL); pass a larger row count
+  // (e.g. 256000 -> 1 GB) for the HBM-resident write rate
+  const long R = argc > 1 ? atol(argv[1]) : 32000, rowbytes = 4096;
   char* d; hipMalloc(&d, R * rowbytes);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   struct { int rows, seg, swz; } cfg[] = {{128, 256, 1}, {128, 256, 0}, {128, 512, 1}, {64, 1024, 1}, {32, 4096, 1}, {8, 4096, 0}, {128, 4096, 0}};
@@ -26,7 +28,7 @@ int main() {
     for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(tile_store, dim3(tiles_m * tiles_n), dim3(256), 0, 0, d, rowbytes, c.rows, c.seg, tiles_m, c.swz);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("tile %4d rows x %5d B  swz=%d  blocks=%6d : %8.1f us  %7.1f GB/s\n", c.rows, c.seg, c.swz, tiles_m * tiles_n, ms * 1e3 / 20, R * rowbytes / (ms * 1e-3 / 20) / 1e9);
+    printf("R=%ld tile %4d rows x %5d B  swz=%d  blocks=%6d : %8.1f us  %7.1f GB/s\n", R, c.rows, c.seg, c.swz, tiles_m * tiles_n, ms * 1e3 / 20, R * rowbytes / (ms * 1e-3 / 20) / 1e9);
   }
   return 0;
 }
