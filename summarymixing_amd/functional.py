@@ -114,15 +114,22 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
 
 
 def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
-               drop=None):
+               drop=None, dz_ready=False, up=None):
     """Backward of y = res + alpha*D(act(x W^T + b + c0))*mask (D = the forward's fused dropout, regenerated from its
-    seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate."""
+    seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate.
+    dz_ready: dy already IS dZ (a downstream dgrad epilogue fused this layer's act/dropout/mask backward and its bias
+    gradient, see `up`).
+    up = (z_up, act_up, mask_up, alpha_up, drop_up, gb_up): x is the output alpha_up*D(act_up(z_up))*mask_up of an
+    upstream activation layer; the dgrad GEMM's epilogue then emits THAT layer's dZ (SMX_EPI_ACT_GRAD) and its bias
+    gradient (colsum) instead of dX, so the (N x K) gradient never makes a separate elementwise pass."""
     N, M = dy.shape
     K = x.shape[1]
     if drop is not None and drop[0] <= 0.0:
         drop = None
     plain = act == L.ACT_NONE and mask is None and alpha == 1.0 and drop is None
-    if plain:
+    if dz_ready:
+        dz = dy
+    elif plain:
         dz = dy
         if gb is not None or dgroup is not None:
             ops.act_mask_bwd(dy, None, None, L.ACT_NONE, 1.0, None, gb, dgroup, gdiv)
@@ -134,7 +141,13 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
     dx = None
     if need_dx:
         dx = dx_out if dx_out is not None else torch.empty((N, K), dtype=dy.dtype, device=dy.device)
-        ops.gemm(L.GEMM_NN, dz, W, dx, N, K, M, ops.epilogue(res=res_grad))
+        if up is not None:
+            assert res_grad is None
+            z_up, act_up, mask_up, alpha_up, drop_up, gb_up = up
+            e = ops.epilogue(act=act_up, act_grad_z=z_up, row_mask=mask_up, alpha=alpha_up, drop=drop_up, colsum=gb_up)
+        else:
+            e = ops.epilogue(res=res_grad)
+        ops.gemm(L.GEMM_NN, dz, W, dx, N, K, M, e)
     return dx, dz
 
 
@@ -167,6 +180,7 @@ def mlp_fwd(x, layers, act, mask, need_bwd, dtype):
 
 def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None):
     n = len(layers)
+    dz_ready = False
     for i in range(n - 1, -1, -1):
         ly = layers[i]
         x, z, mk = saved[i]
@@ -174,8 +188,13 @@ def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=N
         want_dx = need_dx or not first
         if ly["kind"] == "linear":
             Wc = wcast(ly["W"], dtype)
-            dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), gacc(ly["b"]), want_dx,
-                               res_grad if first else None, dx_out=dx_out if first else None)
+            # a Linear below an activated Linear: this layer's dgrad epilogue emits the lower layer's dZ and db
+            up = None
+            if not first and layers[i - 1]["kind"] == "linear" and act != L.ACT_NONE:
+                up = (saved[i - 1][1], act, saved[i - 1][2], 1.0, None, gacc(layers[i - 1]["b"]))
+            dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), None if dz_ready else gacc(ly["b"]), want_dx,
+                               res_grad if first else None, dx_out=dx_out if first else None, dz_ready=dz_ready, up=up)
+            dz_ready = up is not None
         else:
             Wc = wcast(ly["W"], dtype)
             H, f, h = Wc.shape
@@ -428,8 +447,10 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
         return y, None
 
     def bwd(dy):
-        da, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2)
-        dh, _ = linear_bwd(da, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), drop=d1)
+        # the second Linear's dgrad epilogue applies D1 and act'(z1) and sums the columns: it emits dZ1 and db1 directly
+        dz1, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2,
+                            up=(z1, act, None, 1.0, d1, gacc(P["b1"])))
+        dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), None, dz_ready=True)
         return ln_b(dh, res=dy)
     return y, bwd
 
