@@ -288,6 +288,89 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* X, long ldx
   }
 }
 
+// Single-read forward for D <= 256 * CH (D % 4 == 0, aligned rows): the row lives in registers (one 4-element vector
+// per lane and chunk), U rows are in flight per wave (all their loads issued before the first reduction), workgroups
+// stride over the rows.  The generic kernel above re-reads the row three times behind three dependent latencies.
+template <typename T, int CH, int U>
+__global__ __launch_bounds__(256) void layernorm_fwd_fast(const T* __restrict__ X, long ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ Y, long ldy,
+                                                          float* __restrict__ stats, int N_, int D, float eps, int act) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float gam[CH][4], bet[CH][4];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
+      gam[i][0] = g4.x; gam[i][1] = g4.y; gam[i][2] = g4.z; gam[i][3] = g4.w;
+      bet[i][0] = b4.x; bet[i][1] = b4.y; bet[i][2] = b4.z; bet[i][3] = b4.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gam[i][j] = bet[i][j] = 0.f;
+    }
+  }
+  const float invD = 1.f / (float)D;
+  dispatch_act(act, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    for (int row0 = (blockIdx.x * 4 + w) * U; row0 < N_; row0 += gridDim.x * 4 * U) {
+      float f[U][CH][4], s[U], q[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = min(row0 + u, N_ - 1);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int c = (lane + 64 * i) * 4;
+          if (c < D) load4<T>(X + (long)row * ldx + c, f[u][i]);
+          else f[u][i][0] = f[u][i][1] = f[u][i][2] = f[u][i][3] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        s[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) s[u] += (f[u][i][0] + f[u][i][1]) + (f[u][i][2] + f[u][i][3]);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[u] += __shfl_xor(s[u], off, 64);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        s[u] *= invD;                                      // mean
+        q[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          if ((lane + 64 * i) * 4 < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = f[u][i][j] - s[u]; q[u] += d * d; }
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int u = 0; u < U; ++u) q[u] += __shfl_xor(q[u], off, 64);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + u;
+        if (row >= N_) break;
+        const float rstd = rsqrtf(q[u] * invD + eps);
+        if (stats && lane == 0) *reinterpret_cast<float2*>(stats + 2 * (long)row) = make_float2(s[u], rstd);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int c = (lane + 64 * i) * 4;
+          if (c < D) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = act_fwd_c<ACT>((f[u][i][j] - s[u]) * rstd * gam[i][j] + bet[i][j]);
+            store4<T>(Y + (long)row * ldy + c, o);
+          }
+        }
+      }
+    }
+  });
+}
+
 // bwd: dx = R + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*act'(LN(x))*gamma.  Blocks stride over rows;
 // gamma/beta of the lane's columns live in registers for the whole kernel, U rows are in flight per wave (all
 // their loads issued before any reduction), dgamma/dbeta partial sums stay in registers until one atomic flush.
@@ -833,6 +916,18 @@ extern "C" int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const fl
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
   auto ok = [&](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) % (4 * es)) == 0 && ld % 4 == 0; };
   const bool vec = D % 4 == 0 && ok(X, ldx) && ok(Y, ldy) && aligned16(gamma) && aligned16(beta);
+  if (vec && D <= 2048) {
+    const int ch = (D + 255) / 256;
+    const int U = ch <= 1 ? 4 : (ch <= 2 ? 2 : 1);
+    int blocks = (N + 4 * U - 1) / (4 * U);
+    if (blocks > 2048) blocks = 2048;
+#define LN_FWD(TT, CH_, U_) hipLaunchKernelGGL((layernorm_fwd_fast<TT, CH_, U_>), dim3(blocks), dim3(256), 0, STREAM, (const TT*)X, ldx, gamma, beta, (TT*)Y, ldy, stats, N, D, eps, act)
+#define LN_FWD_T(TT) do { if (ch <= 1) LN_FWD(TT, 1, 4); else if (ch <= 2) LN_FWD(TT, 2, 2); else if (ch <= 4) LN_FWD(TT, 4, 1); else LN_FWD(TT, 8, 1); } while (0)
+    if (dtype == SMX_BF16) LN_FWD_T(bf16_t); else LN_FWD_T(float);
+#undef LN_FWD_T
+#undef LN_FWD
+    return check_launch("smx_layernorm_fwd");
+  }
   dim3 grid((N + 3) / 4);
   if (dtype == SMX_BF16) {
     if (vec) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, (const bf16_t*)X, ldx, gamma, beta, (bf16_t*)Y, ldy, stats, N, D, eps, act);
