@@ -117,9 +117,11 @@ size_t smx_masked_mean_workspace(int B, int T, int D);
 int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const uint8_t* mask, float* out, float* inv_count,
                         int B, int T, int D, int scale_by_count, void* workspace, void* stream);
 /* Backward / broadcast: dS[b,t,:] = g[b,:] * (inv_count ? inv_count[b] : 1) for every t (the row mask is
- * applied by the producer's smx_act_mask_bwd).  Also the forward `repeat` (summary_mixing.py:222,267). */
+ * applied by the producer's smx_act_mask_bwd).  Also the forward `repeat` (summary_mixing.py:222,267), there with the
+ * training dropout of the concatenated merge input fused in (drop_p > 0: mask = f(seed, row * D + col), the
+ * smx_dropout indexing; summary_mixing.py:237-239). */
 int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B, int T,
-                        int D, void* stream);
+                        int D, float drop_p, uint64_t drop_seed, void* stream);
 
 /* DynChunk summary (sum_mask path, summary_mixing.py:224-235, :269-280) in O(T): frame t of chunk
  * c = t / chunk sees frames [max(0,(c-left)*chunk), min(T,(c+1)*chunk)) (left < 0: unlimited);

@@ -149,7 +149,8 @@ static void mm_plan(int B, int T, int D, int nvec, int& DC, int& TS, int& TR) {
 // dS[b,t,:] = g[b,:] * inv_count[b]   (broadcast over t).  grid (DC, ceil(T/RPB), B)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const float* inv_count, T* dS, long ldds,
-                                                         int T_, int D, int RPB) {
+                                                         int T_, int D, int RPB, uint32_t dthresh, float dscale,
+                                                         uint64_t dseed) {
   constexpr int N = VT<T>::N;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
   const int col = (blockIdx.x * 64 + lane) * N;
@@ -160,7 +161,17 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const f
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = (i < nvalid) ? g[(long)b * D + col + i] * sc : 0.f;
   const int t0 = blockIdx.y * RPB, t1 = min(T_, t0 + RPB);
-  for (int t = t0 + w; t < t1; t += 4) storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, v);
+  if (dthresh == 0) {
+    for (int t = t0 + w; t < t1; t += 4) storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, v);
+  } else {                                               // fused inverted dropout, mask = f(seed, row * D + col)
+    for (int t = t0 + w; t < t1; t += 4) {
+      const uint64_t base = ((uint64_t)b * T_ + t) * (uint64_t)D + col;
+      float o[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) o[i] = dropout_keep(dseed, base + i, dthresh) ? v[i] * dscale : 0.f;
+      storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, o);
+    }
+  }
 }
 
 // =================================================================================================
@@ -860,18 +871,21 @@ extern "C" int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const 
 }
 
 extern "C" int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B,
-                                   int T, int D, void* stream) {
+                                   int T, int D, float drop_p, uint64_t drop_seed, void* stream) {
   SMX_REQUIRE(g && dS, "smx_masked_mean_bwd: null pointer");
+  SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_masked_mean_bwd: 0 <= drop_p < 1");
+  const uint32_t dthresh = (uint32_t)((double)drop_p * 4294967296.0);
+  const float dscale = 1.f / (1.f - drop_p);
   const int nvec = dtype == SMX_BF16 ? 8 : 4;
   const int DC = (D + 64 * nvec - 1) / (64 * nvec), RPB = 64;
   dim3 grid(DC, (T + RPB - 1) / RPB, B);
   const bool vec = vec_ok(dS, ldds, D, nvec, dtype == SMX_BF16 ? 2 : 4);
   if (dtype == SMX_BF16) {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB);
-    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed);
+    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed);
   } else {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB);
-    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed);
+    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed);
   }
   return check_launch("smx_masked_mean_bwd");
 }

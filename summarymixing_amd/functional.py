@@ -178,9 +178,9 @@ def mlp_fwd(x, layers, act, mask, need_bwd, dtype):
     return x, saved
 
 
-def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None):
+def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None, dz_ready=False):
+    """dz_ready: dy already is the LAST layer's dZ and its bias gradient is done (fused upstream, see linear_bwd `up`)."""
     n = len(layers)
-    dz_ready = False
     for i in range(n - 1, -1, -1):
         ly = layers[i]
         x, z, mk = saved[i]
@@ -347,8 +347,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             cat = torch.empty((N, lw + sdim), dtype=dtype, device=dev)
             ops.dropout(local, p_drop, s1, out=cat[:, :lw])
             if pool_kind == "mean":
-                ops.bcast_rows(sbar, None, cat[:, lw:], B, T)
-                ops.dropout(cat[:, lw:], p_drop, s2, out=cat[:, lw:])
+                ops.bcast_rows(sbar, None, cat[:, lw:], B, T, drop=(p_drop, s2))   # repeat + dropout in one pass
             else:
                 ops.dropout(sbar, p_drop, s2, out=cat[:, lw:])
             sbar_t = None
@@ -377,21 +376,49 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             else:
                 dlocal_out = torch.empty((N, lw), dtype=dtype, device=dev)
                 ds_out = torch.empty((N, sdim), dtype=dtype, device=dev)
+            # the projections whose outputs are `local` (and, fused, `s`): their act/mask backward for the LOCAL columns is
+            # fused into the merge dgrad's epilogue (SMX_EPI_ACT_GRAD), which then emits dZ and the bias gradient
+            if mode == "SummaryMixing-fast":
+                lproj, sv_lp = P["global_proj"], sv_g
+            else:
+                lproj, sv_lp = P["local_proj"], sv_l
+            fuse_local = lproj[-1]["kind"] == "linear"
+            up_local = None
+            if fuse_local:
+                z_lp, mk_lp = sv_lp[-1][1], sv_lp[-1][2]
+                gb_lp = gacc(lproj[-1]["b"])
+                up_local = (z_lp[:, :lw] if z_lp is not None else None, act if z_lp is not None else L.ACT_NONE, mk_lp, 1.0,
+                            None, gb_lp[:lw] if gb_lp is not None else None)
+                if z_lp is None and mk_lp is None and gb_lp is None:
+                    up_local = None
+                    fuse_local = False
             if p_drop > 0.0:
-                dcat, _ = linear_bwd(dy, cat, Wm, zm, act, None, 1.0, gWm, gbm, True, None)
-                ops.dropout(dcat[:, :lw], p_drop, s1, out=dlocal_out)
-                ops.dropout(dcat[:, lw:], p_drop, s2, out=dcat[:, lw:])
+                # dgrad of the K = l + s merge as two GEMMs over the column halves of W: the dropout backward of each half
+                # (and the local half's act/mask backward) rides in the epilogue instead of separate passes
+                dzm = torch.empty((N, s_out), dtype=dtype, device=dev)
+                ops.act_mask_bwd(dy, zm, None, act, 1.0, dzm, gbm)
+                if gWm is not None:
+                    ops.wgrad(dzm, cat, gWm, N, s_out, lw + sdim)
+                if fuse_local:
+                    e = ops.epilogue(act=up_local[1], act_grad_z=up_local[0], row_mask=up_local[2], drop=(p_drop, s1),
+                                     colsum=up_local[5]) if up_local[0] is not None else \
+                        ops.epilogue(row_mask=up_local[2], drop=(p_drop, s1), colsum=up_local[5])
+                else:
+                    e = ops.epilogue(drop=(p_drop, s1))
+                ops.gemm(L.GEMM_NN, dzm, Wm[:, :lw], dlocal_out, N, lw, s_out, e)
+                dsd = torch.empty((N, sdim), dtype=dtype, device=dev)
+                ops.gemm(L.GEMM_NN, dzm, Wm[:, lw:], dsd, N, sdim, s_out, ops.epilogue(drop=(p_drop, s2)))
                 if pool_kind == "mean":
-                    dsbar, _ = ops.masked_mean(dcat[:, lw:], None, B, T, scale=False)      # sum over time
+                    dsbar, _ = ops.masked_mean(dsd, None, B, T, scale=False)               # sum over time
                     ops.bcast_rows(dsbar, inv, ds_out, B, T)
                 elif pool_kind == "chunk":
-                    ops.chunk_mean(dcat[:, lw:], ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
+                    ops.chunk_mean(dsd, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
                 else:
-                    _dense_pool_bwd(dcat[:, lw:], B, T, Wn, ds_out)
+                    _dense_pool_bwd(dsd, B, T, Wn, ds_out)
             elif pool_kind == "mean":
                 dc0 = torch.zeros((B, s_out), dtype=torch.float32, device=dev)
                 _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
-                                    True, None, dgroup=dc0, gdiv=T, dx_out=dlocal_out)
+                                    True, None, dgroup=dc0, gdiv=T, dx_out=dlocal_out, up=up_local)
                 dc0_t = ops.cast(dc0, dtype)
                 if gWm is not None:      # dW_s += dc0^T sbar
                     ops.wgrad(dc0_t, sbar_t, gWm[:, lw:], B, s_out, sdim)
@@ -400,7 +427,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 ops.bcast_rows(dsbar, inv, ds_out, B, T)
             else:
                 _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
-                                    True, None, dx_out=dlocal_out)
+                                    True, None, dx_out=dlocal_out, up=up_local)
                 if gWm is not None:      # dW_s += dzm^T sbar
                     ops.wgrad(dzm, sbar_t, gWm[:, lw:], N, s_out, sdim)
                 dsb = torch.empty((N, sdim), dtype=dtype, device=dev)
@@ -410,9 +437,18 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 else:
                     _dense_pool_bwd(dsb, B, T, Wn, ds_out)
             if mode == "SummaryMixing-fast":
-                dx = mlp_bwd(dg, P["global_proj"], act, sv_g, dtype)
+                if fuse_local:
+                    # dg[:, :l] already holds dZ (and db[:l] is done): finish the summary columns in place
+                    z_g, mk_g = sv_g[-1][1], sv_g[-1][2]
+                    gb_g = gacc(P["global_proj"][-1]["b"])
+                    if z_g is not None or mk_g is not None or gb_g is not None:
+                        ops.act_mask_bwd(ds_out, z_g[:, l:] if z_g is not None else None, mk_g,
+                                         act if z_g is not None else L.ACT_NONE, 1.0,
+                                         ds_out if (z_g is not None or mk_g is not None) else None,
+                                         gb_g[l:] if gb_g is not None else None)
+                dx = mlp_bwd(dg, P["global_proj"], act, sv_g, dtype, dz_ready=fuse_local)
             else:
-                dx = mlp_bwd(dlocal_out, P["local_proj"], act, sv_l, dtype)
+                dx = mlp_bwd(dlocal_out, P["local_proj"], act, sv_l, dtype, dz_ready=fuse_local)
                 dx = mlp_bwd(ds_out, P["summary_proj"], act, sv_s, dtype, res_grad=dx)
             return dx.view(B, T, -1)
         return y3, bwd

@@ -147,10 +147,11 @@ def masked_mean(s, mask, B, T, scale=True, want_inv=False):
     return out, inv
 
 
-def bcast_rows(g, inv, ds, B, T):
-    """ds[b*T+t, :] = g[b,:] * inv[b]"""
+def bcast_rows(g, inv, ds, B, T, drop=None):
+    """ds[b*T+t, :] = D(g[b,:] * inv[b])   (D: optional fused dropout (p, seed), index row * D + col)"""
     pds, ldds = _mat(ds)
-    L.check(L.lib().smx_masked_mean_bwd(dt(ds), _p(g), _p(inv), pds, ldds, B, T, ds.shape[1], _stream()),
+    dp, dseed = drop if drop is not None else (0.0, 0)
+    L.check(L.lib().smx_masked_mean_bwd(dt(ds), _p(g), _p(inv), pds, ldds, B, T, ds.shape[1], dp, dseed, _stream()),
             "smx_masked_mean_bwd")
     return ds
 
