@@ -42,6 +42,7 @@ struct GemmParams {
   long sSplit;      // element stride between split-K slabs of C (out_mode F32)
   unsigned dthresh; float dscale;   // fused dropout: drop if hash16 < dthresh>>16, survivors * dscale
   long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
+  int nt;       // non-temporal store hints: 1 = saved pre-activation Z, 2 = the output C
   int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
 };
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint4 ld_contig(const T* p, int nvalid, const T* safe
 // ---- stage one operand tile (ROWS x BK) : global -> registers ------------------------------------------
 // KC: element (row r, reduce k) at base[r*ld + k];  KS: at base[k*ld + r]
 template <typename T, bool KC, int ROWS, bool VEC>
-__device__ __forceinline__ void stage_load(uint4 (&reg)[4], const T* base, long ld, int row0, int rows_total,
+__device__ __forceinline__ void stage_load(uint4 (&reg)[ROWS / 32], const T* base, long ld, int row0, int rows_total,
                                            int k0, int k1, int t) {
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int VPT = ElemTraits<T>::VPT;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[4], const T* base, long 
 
 // ---- registers -> LDS image -----------------------------------------------------------------------------
 template <typename T, bool KC, int ROWS>
-__device__ __forceinline__ void stage_store(const uint4 (&reg)[4], char* lds, int t) {
+__device__ __forceinline__ void stage_store(const uint4 (&reg)[ROWS / 32], char* lds, int t) {
   if constexpr (sizeof(T) == 2 && KC) {
     constexpr int NV = ROWS / 32;
 #pragma unroll
@@ -291,10 +292,27 @@ __device__ __forceinline__ void settle(float& w) { asm volatile("" : "+v"(w)); }
 
 // side = [TILE_M] bias (0 when absent) followed by [TILE_N] row factors (row_mask * alpha), staged in LDS by the
 // kernel prologue: reading them costs LDS (lgkmcnt) traffic only, never a vmcnt wait behind in-flight stores.
+// same, with the non-temporal hint: a saved pre-activation is not read again before the backward pass
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <typename T, int CW>
+__device__ __forceinline__ void st_elems_nt(void* p, const float (&v)[CW]) {
+  if constexpr (sizeof(T) == 4) {
+    u32x4_t u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    __builtin_nontemporal_store(u, reinterpret_cast<u32x4_t*>(p));
+  } else if constexpr (CW == 8) {
+    u32x4_t u = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    __builtin_nontemporal_store(u, reinterpret_cast<u32x4_t*>(p));
+  } else {
+    u32x2_t u = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    __builtin_nontemporal_store(u, reinterpret_cast<u32x2_t*>(p));
+  }
+}
+
 template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC>
 __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, const float* side, int ph, int nbase,
                                                int m0, int bz, int split, int t) {
-  constexpr int WN = TILE_N / 2;
+  constexpr int WN = TILE_M > 128 ? 32 : TILE_N / 2;    // rows staged per phase (phase_rows() of the kernel)
   constexpr int STG_LD = TILE_M * 4 + 16;
   constexpr int CW = 16 / OSZ;                          // output columns per item (16 bytes)
   constexpr int CPR = TILE_M / CW;                      // items per row
@@ -402,7 +420,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
           default: break;
         }
       } else {
-        if (Zb) st_elems<T, CW>(Zb + (long)n * e.ldz + m, v);
+        if (Zb) { if (p.nt & 1) st_elems_nt<T, CW>(Zb + (long)n * e.ldz + m, v); else st_elems<T, CW>(Zb + (long)n * e.ldz + m, v); }
         switch (e.act) {
           case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, CW>(v); break;
           case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, CW>(v); break;
@@ -436,7 +454,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
           *reinterpret_cast<float4*>(const_cast<char*>(smem) + r * STG_LD + (c + 4 * q4) * 4) =
               make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
       }
-      st_elems<OutT, CW>(Cb + ((long)n * p.ldc + m) * OSZ, v);
+      if (p.nt & 2) st_elems_nt<OutT, CW>(Cb + ((long)n * p.ldc + m) * OSZ, v); else st_elems<OutT, CW>(Cb + ((long)n * p.ldc + m) * OSZ, v);
     }
     }
   } else {
@@ -473,13 +491,24 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC>
-__global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
+#ifndef SMX_OCC
+#define SMX_OCC 3
+#endif
+#ifndef SMX_NS_KC
+#define SMX_NS_KC 1
+#endif
+__global__ __launch_bounds__(256, (TILE_M > 128 ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
   constexpr int A_BYTES = lds_bytes<T, TILE_N, A_KC>();
   constexpr int B_BYTES = lds_bytes<T, TILE_M, B_KC>();
-  constexpr int EPI_BYTES = (TILE_N / 2) * (TILE_M * 4 + 16);   // one half-tile of fp32 rows, 16 B row pad
+  // the epilogue stages PH_ROWS fp32 rows at a time: half a tile, or 32 rows for the wide (TILE_M = 256) tile so that
+  // the block stays under 64 KB of LDS
+  constexpr int PH_FRAGS = TILE_M > 128 ? 1 : FN;                // 32-row accumulator fragments per phase
+  constexpr int PH_ROWS = 32 * PH_FRAGS;
+  constexpr int NPH = TILE_N / PH_ROWS;
+  constexpr int EPI_BYTES = PH_ROWS * (TILE_M * 4 + 16);         // fp32 rows, 16 B row pad
   constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > EPI_BYTES ? (A_BYTES + B_BYTES) : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N) * 4;              // bias[TILE_M] | row factors[TILE_N] (mask * alpha)
@@ -530,13 +559,19 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
 
   // epilogue side vector of this thread (requested first, parked in ONE register across the main loop, published to
   // LDS before the epilogue): t < TILE_M -> bias[m0 + t], then TILE_N row factors row_mask[n] * alpha
-  float side_v = 0.f;
-  if (p.e.out_mode != SMX_OUT_ATOMIC_F32) {
-    if (t < TILE_M) {
-      if (p.e.bias && m0 + t < p.M) side_v = p.e.bias[(long)bz * p.e.bias_batch_stride + m0 + t];
-    } else if (t < TILE_M + TILE_N) {
-      const int n = n0 + t - TILE_M;
-      side_v = ((p.e.row_mask && n < p.N) ? (p.e.row_mask[n] ? 1.f : 0.f) : 1.f) * p.e.alpha;
+  constexpr int NSIDE = (TILE_M + TILE_N + 255) / 256;
+  float side_v[NSIDE];
+#pragma unroll
+  for (int i = 0; i < NSIDE; ++i) {
+    const int si = t + 256 * i;
+    side_v[i] = 0.f;
+    if (p.e.out_mode != SMX_OUT_ATOMIC_F32) {
+      if (si < TILE_M) {
+        if (p.e.bias && m0 + si < p.M) side_v[i] = p.e.bias[(long)bz * p.e.bias_batch_stride + m0 + si];
+      } else if (si < TILE_M + TILE_N) {
+        const int n = n0 + si - TILE_M;
+        side_v[i] = ((p.e.row_mask && n < p.N) ? (p.e.row_mask[n] ? 1.f : 0.f) : 1.f) * p.e.alpha;
+      }
     }
   }
 
@@ -552,8 +587,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
   // about one HBM/L2 round trip for its whole main loop instead of one per K tile (measured: 2.9 K cycles per
   // K tile with a single stage, the MFMAs themselves need ~0.5 K).
-  constexpr int NS = A_KC ? 1 : 2;
-  uint4 ra[NS][4], rb[NS][4];
+  constexpr int NS = A_KC ? SMX_NS_KC : 2;
+  uint4 ra[NS][TILE_N / 32], rb[NS][TILE_M / 32];
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_)
 #pragma unroll
@@ -650,37 +685,45 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
   }
   constexpr int STG_LD = TILE_M * 4 + 16;               // bytes per staged fp32 row (16 B pad: conflict-free b128)
   const int osz = (e.out_mode == SMX_OUT_T) ? (int)sizeof(T) : 4;
-  if (t < TILE_M + TILE_N) side[t] = side_v;             // (visible after the first barrier below)
+#pragma unroll
+  for (int i = 0; i < NSIDE; ++i)
+    if (t + 256 * i < TILE_M + TILE_N) side[t + 256 * i] = side_v[i];   // (visible after the first barrier below)
 #pragma unroll 1
-  for (int ph = 0; ph < 2; ++ph) {
+  for (int ph = 0; ph < NPH; ++ph) {
     lds_barrier();
-    if (wn == ph) {
+    const int row_in_tile = ph * PH_ROWS;
+    if (wn == row_in_tile / WN) {                         // the wave row that owns these accumulator rows
+      const int i0 = (row_in_tile % WN) / 32;              // first 32-row fragment of the phase
 #pragma unroll
-      for (int i = 0; i < FN; ++i)
+      for (int i = 0; i < FN; ++i) {
+        if (PH_FRAGS == FN || (i >= i0 && i < i0 + PH_FRAGS)) {
 #pragma unroll
-        for (int j = 0; j < FM; ++j)
+          for (int j = 0; j < FM; ++j)
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(smem + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
-                make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(smem + ((i - (PH_FRAGS == FN ? 0 : i0)) * 32 + l31) * STG_LD +
+                                         (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                  make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        }
+      }
     }
     lds_barrier();
-    SMX_STAMP(3 + 2 * ph);
-    if (sizeof(T) == 2 && osz == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + ph * WN, m0, bz, split, t);
-    else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + ph * WN, m0, bz, split, t);
+    if (ph < 2) SMX_STAMP(3 + 2 * ph);
+    if (sizeof(T) == 2 && osz == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+    else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     if (e.colsum) {
       // column sums of this phase's outputs (the bias gradient of a fused backward): every item was written back to
       // its staged slot; thread t < TILE_M adds column t over the valid rows in a fixed order
       lds_barrier();
       if (t < TILE_M) {
-        const int rows = min(WN, p.N - (n0 + ph * WN));
-        float s = 0.f;
+        const int rows = min(PH_ROWS, p.N - (n0 + row_in_tile));
+        float s = ph == 0 ? 0.f : red[t];
         for (int r = 0; r < rows; ++r) s += *reinterpret_cast<const float*>(smem + r * STG_LD + t * 4);
-        if (ph == 0) red[t] = s;
-        else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = red[t] + s;
+        if (ph < NPH - 1) red[t] = s;
+        else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = s;
       }
     }
-    SMX_STAMP(4 + 2 * ph);
+    if (ph < 2) SMX_STAMP(4 + 2 * ph);
   }
   SMX_STAMP(7);
 #undef SMX_STAMP
@@ -704,6 +747,15 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // big tiles once they alone fill the chip (256 CUs x 2 resident blocks); otherwise 64x64 for more blocks
   long big = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch * p.splits;
   static const int force_small = getenv("SMX_GEMM_TILE64") ? 1 : 0;   // experiment knob
+  // wide 128 x 256 tile (2 workgroups per CU, 128 accumulator registers per lane): when it covers the whole output
+  // width (M == 256: the activation panel is fetched exactly once and 500 tiles fill the 512 slots in one round at
+  // 64000 frames) or when the reduction is long enough for the doubled MFMA-per-LDS-read ratio to matter.
+  // Measured at 64000 frames: (K=1024, M=256) NT 77 -> 59 us, NN 65 -> 55 us; (K=256, M=1024) 99 -> 103 us (not used).
+  static const int wide_env = getenv("SMX_GEMM_WIDE") ? atoi(getenv("SMX_GEMM_WIDE")) : -1;
+  const bool wide = wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 512 && p.M <= 512));
+  if (wide && !force_small && p.N >= 128 && p.M >= 256 && p.M % 256 == 0 && p.splits == 1 &&
+      (long)((p.N + 127) / 128) * (p.M / 256) * p.batch >= 256)
+    return launch_tile<T, A_KC, B_KC, 128, 256>(p, vec, s);
   if (!force_small && big >= 256 && p.N >= 128 && p.M >= 128) return launch_tile<T, A_KC, B_KC, 128, 128>(p, vec, s);
   return launch_tile<T, A_KC, B_KC, 64, 64>(p, vec, s);
 }
@@ -789,6 +841,12 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   if (p.e.colsum)
     SMX_REQUIRE(p.e.workspace && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
                 "smx_gemm: colsum needs a workspace (smx_gemm_colsum_workspace), batch == 1, splits == 1");
+  // Store policy.  Z (the pre-activation saved for the backward pass) is not read again for a long time: always
+  // streamed past the caches.  The output C is consumed by the next kernel: streamed only when it is too large to
+  // survive in the 256 MB MALL anyway (measured: FFN up-projection at 64000 frames 118 -> 96 us, no change at 32000).
+  static const long nt_bytes = getenv("SMX_NT_BYTES") ? atol(getenv("SMX_NT_BYTES")) : (96L << 20);
+  static const int nt_z = getenv("SMX_NT_Z") ? atoi(getenv("SMX_NT_Z")) : 1;
+  p.nt = (nt_z ? 1 : 0) | (((long)N * M * (long)cs * batch >= nt_bytes) ? 2 : 0);
   static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
   p.ablate = ablate;
   p.dbg = g_dbg_stamps;
