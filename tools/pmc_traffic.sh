@@ -28,5 +28,6 @@ PY
 }
 run "pool bf16 (8,30000,512) masked_sum_stage1 [algorithmic 246.0 MB]" masked_sum_stage1 python3 "$ROOT/tools/one_pool.py" bf16
 run "pool f32  (8,30000,512) masked_sum_stage1 [algorithmic 491.8 MB]" masked_sum_stage1 python3 "$ROOT/tools/one_pool.py" f32
+run "gemm NT bf16 (64000x256)x(256x1024)+bias+swish+Z = bench.py roofline kernel [algorithmic 295.4 MB: 33.3 read, 262.1 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NT 64000 256 1024
 run "gemm NT bf16 (32000x256)x(256x1024)+bias+swish+Z [algorithmic 147.9 MB: 16.9 read, 131.1 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NT 32000 256 1024
 run "gemm NT bf16 (32000x512)x(512x2048)+bias+swish+Z [algorithmic 297.0 MB: 34.9 read, 262.1 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NT 32000 512 2048
