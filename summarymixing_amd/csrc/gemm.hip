@@ -906,7 +906,12 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 static int wgrad_splits(int rows, int M, int K, int batch) {
   long tiles = (long)((M + 127) / 128) * ((K + 127) / 128) * batch;
-  long s = (640 + tiles - 1) / tiles;
+  // workgroups to aim for: exactly two per CU.  640 (2.5 per CU) leaves half the CUs with a third workgroup and the
+  // launch takes as long as those; measured at 64000 frames: 71 -> 66 us (1024x256), 42 -> 35 us (256x256).
+  // (The wide 128x256 tile is 2.5x SLOWER here: two register stages of both operands + 128 accumulators spill.)
+  static const int target_env = getenv("SMX_WGRAD_BLOCKS") ? atoi(getenv("SMX_WGRAD_BLOCKS")) : 0;
+  const long target = target_env > 0 ? target_env : 512;
+  long s = (target + tiles - 1) / tiles;
   long smax = (rows + 255) / 256;
   if (s > smax) s = smax;
   return (int)(s < 1 ? 1 : s);
