@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256, (TILE_M > 128 ? 2 : SMX_OCC)) void gemm_kernel
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
   // about one HBM/L2 round trip for its whole main loop instead of one per K tile (measured: 2.9 K cycles per
   // K tile with a single stage, the MFMAs themselves need ~0.5 K).
-  constexpr int NS = A_KC ? SMX_NS_KC : 2;
+  constexpr int NS = A_KC ? SMX_NS_KC : (TILE_M > 128 ? 1 : 2);   // (two stages of a 128x256 tile pair would spill)
   uint4 ra[NS][TILE_N / 32], rb[NS][TILE_M / 32];
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_)
@@ -908,7 +908,7 @@ static int wgrad_splits(int rows, int M, int K, int batch) {
   long tiles = (long)((M + 127) / 128) * ((K + 127) / 128) * batch;
   // workgroups to aim for: exactly two per CU.  640 (2.5 per CU) leaves half the CUs with a third workgroup and the
   // launch takes as long as those; measured at 64000 frames: 71 -> 66 us (1024x256), 42 -> 35 us (256x256).
-  // (The wide 128x256 tile is 2.5x SLOWER here: two register stages of both operands + 128 accumulators spill.)
+  // (The wide 128x256 tile does not help here: 2.5x slower with two register stages (spills), 71 vs 66 us with one.)
   static const int target_env = getenv("SMX_WGRAD_BLOCKS") ? atoi(getenv("SMX_WGRAD_BLOCKS")) : 0;
   const long target = target_env > 0 ? target_env : 512;
   long s = (target + tiles - 1) / tiles;

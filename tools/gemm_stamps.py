@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from summarymixing_amd import _lib as L, ops
 layout = sys.argv[1] if len(sys.argv) > 1 else "NT"
-N, K, M = 32000, int(sys.argv[2]) if len(sys.argv) > 2 else 256, int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+N, K, M = int(os.environ.get("N", 32000)), int(sys.argv[2]) if len(sys.argv) > 2 else 256, int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 x = torch.randn(N, K, device="cuda").bfloat16()
 if layout == "NT":
     w = (torch.randn(M, K, device="cuda") * 0.05).bfloat16()
