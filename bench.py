@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--dropout", type=float, default=0.15, help="training-mode dropout (recipe: 0.15)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="capture the step once in a hipGraph and replay it (auto: single-GPU runs below 40000 frames per step, "
+                         "where the host launch path is the bottleneck; neutral above)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -246,9 +249,36 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # hipGraph: the ~1100 kernel launches of a step cost ~14 ms of host time - hidden behind the GPU at 64000 frames per
+    # step, the bottleneck below ~30000.  One capture (after the eager warm-up has created gradients, shadows and
+    # workspaces), then every timed step is one graph launch.  The step count (AdamW bias correction) and the dropout
+    # epoch live in a device counter, so replays still advance them (include/smx.h: smx_set_step_counter).
+    run, graph_note = step, "eager"
+    if args.graph == "on" or (args.graph == "auto" and world == 1 and not force_dist and cfg["B"] * cfg["T"] < 40000):
+        try:
+            if train:
+                opt.use_device_step_counter(True)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                   # (untimed) allocate this stream's workspaces before capture
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            run, graph_note = graph.replay, "hipGraph replay (one capture of the whole step)"
+        except Exception as ex:                          # noqa: BLE001 - report and time the eager path instead
+            if args.graph == "on":
+                raise
+            if train:
+                opt.use_device_step_counter(False)
+            torch.cuda.synchronize()
+            run, graph_note = step, f"eager (hipGraph capture failed: {type(ex).__name__})"
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1 or force_dist:
@@ -268,7 +298,8 @@ def main():
                    "per_gpu_batch": cfg["B"], "enc_frames_per_utt": cfg["T"], "global_batch": cfg["B"] * world,
                    "padded_frames_per_step": frames_per_step, "valid_frames_rank0": valid_frames,
                    "input": f"(B,T,{cfg['input']}) N(0,1), wav_len U(0.5,1), zero padded",
-                   "dropout": (args.dropout if train else 0.0), "parallelism": f"dp{world}", "init": "xavier_normal seed 3407"},
+                   "dropout": (args.dropout if train else 0.0), "parallelism": f"dp{world}", "init": "xavier_normal seed 3407",
+                   "launch": graph_note},
     }
     if args.config in FLOPS_PER_FRAME_FWD:
         fl = FLOPS_PER_FRAME_FWD[args.config] * (3.0 if train else 1.0)

@@ -203,6 +203,14 @@ int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* str
 int smx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, const float* gscale_dev, void* stream);
+/* step <= 0: the bias-correction step is read from the device step counter (smx_set_step_counter) instead. */
+/* Optional device step counter (one uint64 in device memory), the only process-global of the library.  While set
+ * (non-NULL), every fused / standalone dropout mixes the counter's current value into its seed and smx_adamw_step with
+ * step <= 0 takes its step from it: a whole training step can then be captured ONCE in a hipGraph (all kernel
+ * arguments constant) and replayed - masks and bias correction still advance, because the counter does
+ * (smx_step_counter_add is itself a captured kernel).  NULL restores the plain by-value behaviour. */
+int smx_set_step_counter(const uint64_t* dev_counter);
+int smx_step_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream);
 /* out[0] += sum(x^2) (fp32 atomics; zero it first) — global grad-norm for clipping. */
 int smx_sumsq(const float* x, int64_t n, float* out, void* stream);
 /* out[0] = min(1, max_norm / (sqrt(sumsq[0]) * inv_scale + 1e-6)) : clip factor computed on device. */

@@ -74,6 +74,8 @@ SIGNATURES = {
     "smx_cast_from_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
     "smx_cast_to_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
     "smx_adamw_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_vp, c_vp]),
+    "smx_set_step_counter": (c_i, [c_vp]),
+    "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
     "smx_sumsq": (c_i, [c_vp, c_i64, c_vp, c_vp]),
     "smx_clip_factor": (c_i, [c_vp, c_f, c_f, c_vp, c_vp]),
 }

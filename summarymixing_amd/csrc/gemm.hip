@@ -40,6 +40,7 @@ struct GemmParams {
   int epi_vec;
   int epi_lds;      // outputs are 16-byte addressable: stage the tile through LDS and store whole rows
   long sSplit;      // element stride between split-K slabs of C (out_mode F32)
+  const uint64_t* epoch;            // device step counter mixed into the dropout seed (or null)
   unsigned dthresh; float dscale;   // fused dropout: drop if hash16 < dthresh>>16, survivors * dscale
   long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
   int nt;       // non-temporal store hints: 1 = saved pre-activation Z, 2 = the output C
@@ -323,6 +324,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   const smx_epilogue& e = p.e;
   const uint32_t dthresh = p.dthresh;
   const float dscale = p.dscale;
+  const uint64_t dseed = dthresh ? epoch_seed(p.e.drop_seed, p.epoch) : 0;
   const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
   if (m >= p.M) return;
   const float* mkrow = side + TILE_M + ph * WN;
@@ -431,7 +433,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
       }
       if (dthresh) {                                     // fused inverted dropout, mask = f(seed, n * M + m)
 #pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] = dropout_keep(e.drop_seed, (uint64_t)n * p.M + m + q, dthresh) ? v[q] * dscale : 0.f;
+        for (int q = 0; q < CW; ++q) v[q] = dropout_keep(dseed, (uint64_t)n * p.M + m + q, dthresh) ? v[q] * dscale : 0.f;
       }
       if (has_mk) {
         const float mk = mkrow[r];
@@ -477,7 +479,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
           if (Zb) Zb[(long)n * e.ldz + m + q] = from_f32<T>(v);
           v = act_fwd(e.act, v);
         }
-        if (dthresh) v = dropout_keep(e.drop_seed, (uint64_t)n * p.M + m + q, dthresh) ? v * dscale : 0.f;
+        if (dthresh) v = dropout_keep(dseed, (uint64_t)n * p.M + m + q, dthresh) ? v * dscale : 0.f;
         v *= mkv;
         if (Sb && !ag) v += to_f32(Sb[(long)n * lds_ + m + q]);
         if (c0p && c0post) v += c0p[q];
@@ -850,6 +852,7 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
   p.ablate = ablate;
   p.dbg = g_dbg_stamps;
+  p.epoch = g_step_counter;
   p.dthresh = (unsigned)((double)p.e.drop_p * 4294967296.0);
   p.dscale = 1.f / (1.f - p.e.drop_p);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -150,7 +150,8 @@ static void mm_plan(int B, int T, int D, int nvec, int& DC, int& TS, int& TR) {
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const float* inv_count, T* dS, long ldds,
                                                          int T_, int D, int RPB, uint32_t dthresh, float dscale,
-                                                         uint64_t dseed) {
+                                                         uint64_t dseed_, const uint64_t* ep) {
+  const uint64_t dseed = dthresh ? epoch_seed(dseed_, ep) : 0;
   constexpr int N = VT<T>::N;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
   const int col = (blockIdx.x * 64 + lane) * N;
@@ -591,8 +592,9 @@ __global__ __launch_bounds__(256) void act_mask_bwd_vec_kernel(const T* __restri
                                                                long lddz, int N_, int M, int act, float alpha, float* dbias,
                                                                float* dgroup, long lddg, int gdiv, int RS, int LPR,
                                                                float* __restrict__ partial, uint32_t dthresh, float dscale,
-                                                               uint64_t dseed) {
+                                                               uint64_t dseed_, const uint64_t* ep) {
   constexpr int N = VT<T>::N;
+  const uint64_t dseed = dthresh ? epoch_seed(dseed_, ep) : 0;
   __shared__ float red[256][N];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int lc = lane % LPR, lr = lane / LPR;          // column chunk / row slot inside the wave
@@ -698,7 +700,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long lddy, const T* Z, long ldz,
                                                            const uint8_t* mask, T* dZ, long lddz, int N_, int M, int act,
                                                            float alpha, float* dbias, float* dgroup, long lddg, int gdiv,
-                                                           int RS, uint32_t dthresh, float dscale, uint64_t dseed) {
+                                                           int RS, uint32_t dthresh, float dscale, uint64_t dseed_,
+                                                           const uint64_t* ep) {
+  const uint64_t dseed = dthresh ? epoch_seed(dseed_, ep) : 0;
   __shared__ float red[3][64][4];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + cx) * 4;
@@ -772,8 +776,14 @@ __global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* src, float* d
 // fused AdamW (torch.optim.AdamW semantics: p *= 1 - lr*wd; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps))
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, uint16_t* shadow, long n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt, float gscale, const float* gscale_dev) {
+                                                    float bc2_sqrt, float gscale, const float* gscale_dev,
+                                                    const uint64_t* step_dev) {
   const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.f);
+  if (step_dev) {                                        // bias correction from the device step counter (graph replay)
+    const float t = (float)step_dev[0];
+    bc1 = 1.f - powf(b1, t);
+    bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  }
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float gi = g[i] * gs, pi = p[i], mi = m[i], vi = v[i];
     pi *= 1.f - lr * wd;
@@ -802,7 +812,8 @@ __global__ void clip_factor_kernel(const float* sumsq, float max_norm, float inv
 
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* X, long ldx, T* Y, long ldy, int N_, int D, uint32_t thresh,
-                                                      float scale, uint64_t seed) {
+                                                      float scale, uint64_t seed_, const uint64_t* ep) {
+  const uint64_t seed = epoch_seed(seed_, ep);
   const int cv = (D + 3) / 4;
   const long total = (long)N_ * cv;
   const bool vec = (D & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && ((uintptr_t)X % (4 * sizeof(T))) == 0 &&
@@ -881,11 +892,11 @@ extern "C" int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_c
   dim3 grid(DC, (T + RPB - 1) / RPB, B);
   const bool vec = vec_ok(dS, ldds, D, nvec, dtype == SMX_BF16 ? 2 : 4);
   if (dtype == SMX_BF16) {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed);
-    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter);
+    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter);
   } else {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed);
-    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter);
+    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter);
   }
   return check_launch("smx_masked_mean_bwd");
 }
@@ -1022,14 +1033,14 @@ extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const v
     const int RS = ACT_BWD_RS;
     float* partial = reinterpret_cast<float*>(workspace);
     dim3 grid((chunks + LPR - 1) / LPR, (N + RS - 1) / RS);
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed);
-    else hipLaunchKernelGGL((act_mask_bwd_vec_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed, g_step_counter);
+    else hipLaunchKernelGGL((act_mask_bwd_vec_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed, g_step_counter);
     if (dbias) hipLaunchKernelGGL(colsum_partials_kernel, dim3((M + 15) / 16), dim3(256), 0, STREAM, partial, (N + RS - 1) / RS, M, dbias);
   } else {
     const int RS = 128;
     dim3 grid((M + 255) / 256, (N + RS - 1) / RS);
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed);
-    else hipLaunchKernelGGL((act_mask_bwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed, g_step_counter);
+    else hipLaunchKernelGGL((act_mask_bwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed, g_step_counter);
   }
   return check_launch("smx_act_mask_bwd");
 }
@@ -1059,8 +1070,8 @@ extern "C" int smx_dropout(int dtype, const void* X, int64_t ldx, void* Y, int64
   const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
   const float scale = 1.f / (1.f - p);
   int grid = grid1d((long)N * ((D + 3) / 4));
-  if (dtype == SMX_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)X, ldx, (bf16_t*)Y, ldy, N, D, thresh, scale, seed);
-  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, STREAM, (const float*)X, ldx, (float*)Y, ldy, N, D, thresh, scale, seed);
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)X, ldx, (bf16_t*)Y, ldy, N, D, thresh, scale, seed, g_step_counter);
+  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, STREAM, (const float*)X, ldx, (float*)Y, ldy, N, D, thresh, scale, seed, g_step_counter);
   return check_launch("smx_dropout");
 }
 
@@ -1091,11 +1102,13 @@ extern "C" int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n
 extern "C" int smx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                               int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                               float grad_scale, const float* gscale_dev, void* stream) {
-  SMX_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "smx_adamw_step: bad arguments");
+  SMX_REQUIRE(param && grad && exp_avg && exp_avg_sq, "smx_adamw_step: bad arguments");
   if (n <= 0) return SMX_OK;
+  SMX_REQUIRE(step > 0 || g_step_counter, "smx_adamw_step: step <= 0 needs smx_set_step_counter()");
   float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq,
-                     (uint16_t*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, gscale_dev);
+                     (uint16_t*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, gscale_dev,
+                     step > 0 ? nullptr : g_step_counter);
   return check_launch("smx_adamw_step");
 }
 extern "C" int smx_sumsq(const float* x, int64_t n, float* out, void* stream) {

@@ -174,6 +174,12 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32
   const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
   return r >= (thresh >> 16);
 }
+// Optional device step counter (smx_set_step_counter): when set, every dropout seed is mixed with its current value,
+// so a training step captured once in a hipGraph (constant kernel arguments) still draws fresh masks at every replay.
+extern const uint64_t* g_step_counter;
+__device__ __forceinline__ uint64_t epoch_seed(uint64_t seed, const uint64_t* ep) {
+  return ep ? seed ^ (ep[0] * 0x9E3779B97F4A7C15ull) : seed;
+}
 // 64-lane wave reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -48,7 +48,9 @@ def make_transformer_src_tgt_masks(src, tgt=None, wav_len=None, pad_idx=0, causa
     src_key_padding_mask = None
     if wav_len is not None:
         abs_len = torch.round(wav_len * src.shape[1])
-        valid = length_to_mask(abs_len)
+        # the reference sizes the mask by abs_len.max() (a host sync) and only works when that equals T (the longest
+        # utterance of a batch has wav_len == 1); max_len = T gives the same mask without the sync (hipGraph-capturable)
+        valid = length_to_mask(abs_len, src.shape[1])
         src_key_padding_mask = ~valid if masked_false_or_true else valid
     src_mask = make_transformer_src_mask(src, causal, masked_false_or_true, dynchunktrain_config)
     return src_key_padding_mask, None, src_mask, None

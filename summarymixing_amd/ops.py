@@ -270,6 +270,17 @@ def adamw_step(param, grad, m, v, shadow, lr, b1, b2, eps, wd, step, grad_scale=
                                    step, grad_scale, _p(gscale_dev), _stream()), "smx_adamw_step")
 
 
+def set_step_counter(counter):
+    """Register (or clear, with None) the device step counter: an int64 tensor of one element (see include/smx.h)."""
+    if counter is not None:
+        assert counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1
+    L.check(L.lib().smx_set_step_counter(_p(counter)), "smx_set_step_counter")
+
+
+def step_counter_add(counter, inc=1):
+    L.check(L.lib().smx_step_counter_add(_p(counter), inc, _stream()), "smx_step_counter_add")
+
+
 def sumsq(x, out):
     L.check(L.lib().smx_sumsq(_p(x), x.numel(), _p(out), _stream()), "smx_sumsq")
 

@@ -56,6 +56,7 @@ class FlatAdamW:
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._clip = torch.ones(1, dtype=torch.float32, device=dev)
         self._pending = []
+        self._dev_step = None
         # buckets: list of (start, end) element ranges of the flat buffers, in backward-completion order
         self.buckets = buckets or [(0, total)]
 
@@ -77,6 +78,18 @@ class FlatAdamW:
     def zero_grad(self):
         self.flat_g.zero_()
 
+    def use_device_step_counter(self, enable=True):
+        """Keep the step count (AdamW bias correction, dropout epoch) in device memory so that a whole training step
+        can be captured once in a hipGraph (``torch.cuda.graph``) and replayed: no kernel argument changes between
+        steps, the counter does (include/smx.h: smx_set_step_counter)."""
+        if enable:
+            if self._dev_step is None:
+                self._dev_step = torch.full((1,), self.step_count, dtype=torch.int64, device=self.flat_p.device)
+            ops.set_step_counter(self._dev_step)
+        else:
+            ops.set_step_counter(None)
+            self._dev_step = None
+
     def step(self, reduce_all=False):
         if self._collective:
             if reduce_all:
@@ -85,6 +98,8 @@ class FlatAdamW:
                 w.wait()
             self._pending = []
         self.step_count += 1
+        if self._dev_step is not None:
+            ops.step_counter_add(self._dev_step, 1)
         self._apply_update(1.0 / self.world)
 
     def _apply_update(self, gscale):
@@ -96,7 +111,7 @@ class FlatAdamW:
             ops.clip_factor(self._sumsq, self.max_grad_norm, gscale, self._clip)
             clip = self._clip
         ops.adamw_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.shadow, self.lr, self.betas[0],
-                       self.betas[1], self.eps, self.wd, self.step_count, gscale, clip)
+                       self.betas[1], self.eps, self.wd, 0 if self._dev_step is not None else self.step_count, gscale, clip)
 
     def grad_norm(self):
         """Host read of the last global gradient norm (diagnostics only)."""
