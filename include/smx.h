@@ -82,11 +82,13 @@ int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64_t strideA,
 /* Weight gradient of a (batched) Linear: dW[b] (M x K) += alpha * dZ[b]^T X[b], reducing over `rows` frames
  * (dZ (rows, M), X (rows, K), both row-major).  Split-K over the frame dimension into fp32 slabs in `workspace`
  * (smx_linear_wgrad_workspace bytes) followed by one fixed-order reduction: bit-reproducible, no atomics.
+ * dbias (optional, fp32 [batch][M]): dbias += alpha * column sums of dZ - the bias gradient comes out of the same
+ * launch (the kernel sums the dZ tiles it stages anyway), so no separate pass over dZ is needed for it.
  * Autograd backward of every nn.Linear / ParallelLinear on the path. */
 size_t smx_linear_wgrad_workspace(int rows, int M, int K, int batch);
 int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,
-                     int64_t strideX, float* dW, int64_t lddw, int64_t strideW, int rows, int M, int K, int batch,
-                     float alpha, void* workspace, void* stream);
+                     int64_t strideX, float* dW, int64_t lddw, int64_t strideW, float* dbias, int rows, int M, int K,
+                     int batch, float alpha, void* workspace, void* stream);
 
 /* Y = R + alpha * act(X W^T + b [+C0]) * mask ; thin wrapper over smx_gemm(NT).
  * Replaces summary_mixing.py:257 (global_proj * mask), :207/:210 (local/summary proj * mask),

@@ -41,8 +41,8 @@ SIGNATURES = {
                        ctypes.POINTER(Epilogue), c_vp]),
     "smx_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
     "smx_linear_wgrad_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
-    "smx_linear_wgrad": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_f,
-                               c_vp, c_vp]),
+    "smx_linear_wgrad": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i, c_i,
+                               c_f, c_vp, c_vp]),
     "smx_linear_act_mask_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i,
                                       ctypes.POINTER(Epilogue), c_vp]),
     "smx_act_mask_bwd_workspace": (c_sz, [c_i, c_i]),

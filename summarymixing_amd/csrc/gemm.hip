@@ -40,6 +40,7 @@ struct GemmParams {
   int epi_vec;
   int epi_lds;      // outputs are 16-byte addressable: stage the tile through LDS and store whole rows
   long sSplit;      // element stride between split-K slabs of C (out_mode F32)
+  float* acolsum;                   // TN only: [splits][batch][N] partial column sums of the A operand (bias gradient)
   const uint64_t* epoch;            // device step counter mixed into the dropout seed (or null)
   unsigned dthresh; float dscale;   // fused dropout: drop if hash16 < dthresh>>16, survivors * dscale
   long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
@@ -491,6 +492,24 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   }
 }
 
+// column sums of a reduce-strided (KS) operand stage: a thread's vectors all cover the SAME columns (256 threads are
+// a multiple of the chunks per k row), so it keeps one partial sum per column it owns.  Used by the wgrad GEMM: the
+// column sums of dZ are the bias gradient, a by-product of tiles the kernel stages anyway.
+template <typename T, int ROWS>
+__device__ __forceinline__ void stage_colsum(const uint4 (&reg)[ROWS / 32], float (&cs)[16 / sizeof(T)]) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const uint32_t w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { cs[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu); cs[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16); }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cs[q] += __uint_as_float(w[q]);
+    }
+  }
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------------
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC>
 #ifndef SMX_OCC
@@ -499,7 +518,9 @@ template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC>
 #ifndef SMX_NS_KC
 #define SMX_NS_KC 1
 #endif
-__global__ __launch_bounds__(256, (TILE_M > 128 ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
+// wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
+// the bias-gradient column sums and two register stages of both operands
+__global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
@@ -605,11 +626,19 @@ __global__ __launch_bounds__(256, (TILE_M > 128 ? 2 : SMX_OCC)) void gemm_kernel
     }
   }
   SMX_STAMP(1);
+  constexpr int CSN = 16 / (int)sizeof(T);
+  float cs[CSN];
+#pragma unroll
+  for (int q = 0; q < CSN; ++q) cs[q] = 0.f;
+  const bool do_cs = !A_KC && p.acolsum != nullptr && tile_m == 0;
   for (int kb = kbeg; kb < kend; kb += NS * BK) {
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
       const int k0 = kb + s_ * BK;
       if (k0 >= kend) break;
+      if constexpr (!A_KC) {
+        if (do_cs) stage_colsum<T, TILE_N>(ra[s_], cs);
+      }
       stage_store<T, A_KC, TILE_N>(ra[s_], As, t);
       stage_store<T, B_KC, TILE_M>(rb[s_], Bs, t);
       lds_barrier();
@@ -651,6 +680,23 @@ __global__ __launch_bounds__(256, (TILE_M > 128 ? 2 : SMX_OCC)) void gemm_kernel
         }
       }
       lds_barrier();
+    }
+  }
+
+  if constexpr (!A_KC) {
+    if (do_cs) {                                          // (uniform per workgroup)
+      constexpr int CPK = TILE_N / CSN;                   // column chunks per k row of the stage = threads per group
+      float* redc = reinterpret_cast<float*>(smem);       // [256 / CPK groups][TILE_N]
+      lds_barrier();                                      // every wave is done reading As / Bs
+#pragma unroll
+      for (int q = 0; q < CSN; ++q) redc[(t / CPK) * TILE_N + (t % CPK) * CSN + q] = cs[q];
+      lds_barrier();
+      if (t < TILE_N && n0 + t < p.N) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 256 / CPK; ++g) sum += redc[g * TILE_N + t];
+        p.acolsum[((long)split * p.batch + bz) * p.N + n0 + t] = sum;
+      }
     }
   }
 
@@ -781,7 +827,8 @@ extern "C" void smx_debug_set_timing_buffer(void* p) { g_dbg_stamps = reinterpre
 
 static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,
                      int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K,
-                     int batch, int splits, int64_t split_stride, const smx_epilogue* epi, void* stream) {
+                     int batch, int splits, int64_t split_stride, const smx_epilogue* epi, void* stream,
+                     float* acolsum = nullptr) {
   SMX_REQUIRE(A && B && C, "smx_gemm: null operand");
   SMX_REQUIRE(N >= 0 && M >= 0 && K >= 0 && batch >= 1 && splits >= 1, "smx_gemm: bad sizes N=%d M=%d K=%d", N, M, K);
   SMX_REQUIRE(dtype == SMX_F32 || dtype == SMX_BF16, "smx_gemm: bad dtype %d", dtype);
@@ -853,6 +900,7 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   p.ablate = ablate;
   p.dbg = g_dbg_stamps;
   p.epoch = g_step_counter;
+  p.acolsum = acolsum;
   p.dthresh = (unsigned)((double)p.e.drop_p * 4294967296.0);
   p.dscale = 1.f / (1.f - p.e.drop_p);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -878,7 +926,16 @@ extern "C" int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64
 namespace smx {
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, long slab_stride,
                                                            float* dst, long lddst, long sdst, int M, int K, int batch,
-                                                           float alpha) {
+                                                           float alpha, const float* __restrict__ bpart, float* dbias) {
+  // bias gradient: dbias[b*M + m] += alpha * sum_s bpart[s][b*M + m]  (column sums of dZ collected by the wgrad GEMM)
+  if (dbias) {
+    const long nb = (long)batch * M;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nb; i += (long)gridDim.x * 256) {
+      float a = 0.f;
+      for (int sidx = 0; sidx < nslab; ++sidx) a += bpart[(long)sidx * nb + i];
+      dbias[i] += alpha * a;
+    }
+  }
   const int kv = K / 4;
   const long total = (long)batch * M * kv;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -930,13 +987,15 @@ static int effective_splits(int K, int splits, int BK) {
 }
 
 extern "C" size_t smx_linear_wgrad_workspace(int rows, int M, int K, int batch) {
-  return (size_t)wgrad_splits(rows, M, K, batch) * batch * M * K * sizeof(float) + 16;
+  return (size_t)wgrad_splits(rows, M, K, batch) * batch * ((size_t)M * K + M) * sizeof(float) + 16;
 }
 
 extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,
-                                int64_t strideX, float* dW, int64_t lddw, int64_t strideW, int rows, int M, int K,
-                                int batch, float alpha, void* workspace, void* stream) {
+                                int64_t strideX, float* dW, int64_t lddw, int64_t strideW, float* dbias, int rows, int M,
+                                int K, int batch, float alpha, void* workspace, void* stream) {
   SMX_REQUIRE(dZ && X && dW, "smx_linear_wgrad: null pointer");
+  SMX_REQUIRE(!dbias || (K % 4 == 0 && workspace && aligned16(workspace)),
+              "smx_linear_wgrad: dbias needs the slab path (K %% 4 == 0 and an aligned workspace)");
   if (M <= 0 || K <= 0 || rows <= 0) return SMX_OK;
   smx_epilogue e;
   memset(&e, 0, sizeof(e));
@@ -953,14 +1012,15 @@ extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t
   e.out_mode = SMX_OUT_F32;
   float* ws = reinterpret_cast<float*>(workspace);
   const long slab = (long)batch * M * K;
+  float* bpart = dbias ? ws + (long)splits * slab : nullptr;   // [splits][batch][M] behind the slabs
   int rc = gemm_impl(SMX_GEMM_TN, dtype, dZ, lddz, strideZ, X, ldx, strideX, ws, K, (int64_t)M * K, M, K, rows, batch,
-                     splits, slab, &e, stream);
+                     splits, slab, &e, stream, bpart);
   if (rc != SMX_OK) return rc;
   long total = (long)batch * M * (K / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws,
-                     splits, slab, dW, lddw, strideW, M, K, batch, alpha);
+                     splits, slab, dW, lddw, strideW, M, K, batch, alpha, bpart, dbias);
   return check_launch("smx_linear_wgrad");
 }
 

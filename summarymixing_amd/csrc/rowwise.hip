@@ -602,7 +602,6 @@ __global__ __launch_bounds__(256) void act_mask_bwd_vec_kernel(const T* __restri
   const int col = (blockIdx.x * LPR + lc) * N;
   const bool cok = col < M;
   const int colc = cok ? col : 0;
-  const int r0 = blockIdx.y * RS, r1 = min(N_, r0 + RS);
   float bsum[N], gsum[N];
 #pragma unroll
   for (int q = 0; q < N; ++q) bsum[q] = gsum[q] = 0.f;
@@ -610,6 +609,9 @@ __global__ __launch_bounds__(256) void act_mask_bwd_vec_kernel(const T* __restri
   const int rstep = 4 * RPW;                           // rows advanced per pass of the block's 4 waves
   dispatch_act(Z ? act : SMX_ACT_NONE, [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
+    // a workgroup strides over row strips: gridDim.y (<= ACT_BWD_YMAX) partial rows for the bias reduction however long N is
+    for (int r0 = blockIdx.y * RS; r0 < N_; r0 += gridDim.y * RS) {
+    const int r1 = min(N_, r0 + RS);
     for (int nb = r0 + w * RPW + lr; nb < r1; nb += 4 * rstep) {
       float fdy[4][N], fz[4][N];
 #pragma unroll
@@ -645,6 +647,7 @@ __global__ __launch_bounds__(256) void act_mask_bwd_vec_kernel(const T* __restri
           for (int q = 0; q < N; ++q) gsum[q] += o[q];
         }
       }
+    }
     }
   });
   if (dgroup && cur_g >= 0 && cok) { for (int q = 0; q < N; ++q) atomicAdd(dgroup + (long)cur_g * lddg + col + q, gsum[q]); }
@@ -1011,6 +1014,7 @@ extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const 
 extern "C" size_t smx_layernorm_bwd_workspace(int N, int D) { return (size_t)ln_bwd_blocks(N) * 2 * D * sizeof(float); }
 
 static const int ACT_BWD_RS = 32;
+static const int ACT_BWD_YMAX = 512;   // row-strip workgroups per column block (= partial rows of the bias reduction)
 extern "C" size_t smx_act_mask_bwd_workspace(int N, int M) { return (size_t)((N + ACT_BWD_RS - 1) / ACT_BWD_RS) * M * sizeof(float); }
 
 extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
@@ -1032,10 +1036,11 @@ extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const v
     while (LPR < 64 && LPR < chunks) LPR <<= 1;       // lanes per row chunk (power of two <= 64)
     const int RS = ACT_BWD_RS;
     float* partial = reinterpret_cast<float*>(workspace);
-    dim3 grid((chunks + LPR - 1) / LPR, (N + RS - 1) / RS);
+    const int ny = min((N + RS - 1) / RS, ACT_BWD_YMAX);
+    dim3 grid((chunks + LPR - 1) / LPR, ny);
     if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed, g_step_counter);
     else hipLaunchKernelGGL((act_mask_bwd_vec_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed, g_step_counter);
-    if (dbias) hipLaunchKernelGGL(colsum_partials_kernel, dim3((M + 15) / 16), dim3(256), 0, STREAM, partial, (N + RS - 1) / RS, M, dbias);
+    if (dbias) hipLaunchKernelGGL(colsum_partials_kernel, dim3((M + 15) / 16), dim3(256), 0, STREAM, partial, ny, M, dbias);
   } else {
     const int RS = 128;
     dim3 grid((M + 255) / 256, (N + RS - 1) / RS);

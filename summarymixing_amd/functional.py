@@ -15,6 +15,8 @@ Reference behaviour mirrored here (paths relative to the reference root):
 """
 import weakref
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -45,6 +47,9 @@ def wcast(param, dtype):
             del _shadow[k]
     _shadow[id(param)] = (weakref.ref(param), param._version, param.data_ptr(), sh)
     return sh
+
+
+_WGRAD_BIAS = os.environ.get("SMX_NO_WGRAD_BIAS") != "1"     # A/B knob: bias gradients as a by-product of the wgrad GEMM
 
 
 def gacc(param):
@@ -117,27 +122,28 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
                drop=None, dz_ready=False, up=None):
     """Backward of y = res + alpha*D(act(x W^T + b + c0))*mask (D = the forward's fused dropout, regenerated from its
     seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate.
-    dz_ready: dy already IS dZ (a downstream dgrad epilogue fused this layer's act/dropout/mask backward and its bias
-    gradient, see `up`).
+    dz_ready: dy already IS dZ (a downstream dgrad epilogue fused this layer's act/dropout/mask backward, see `up`).
     up = (z_up, act_up, mask_up, alpha_up, drop_up, gb_up): x is the output alpha_up*D(act_up(z_up))*mask_up of an
-    upstream activation layer; the dgrad GEMM's epilogue then emits THAT layer's dZ (SMX_EPI_ACT_GRAD) and its bias
-    gradient (colsum) instead of dX, so the (N x K) gradient never makes a separate elementwise pass."""
+    upstream activation layer; the dgrad GEMM's epilogue then emits THAT layer's dZ (SMX_EPI_ACT_GRAD) instead of dX,
+    so the (N x K) gradient never makes a separate elementwise pass (gb_up: optional colsum output; normally None,
+    the upstream layer's own wgrad yields its bias gradient)."""
     N, M = dy.shape
     K = x.shape[1]
     if drop is not None and drop[0] <= 0.0:
         drop = None
     plain = act == L.ACT_NONE and mask is None and alpha == 1.0 and drop is None
-    if dz_ready:
+    # the bias gradient (column sums of dZ) is a by-product of the wgrad GEMM, which stages the dZ tiles anyway
+    wb = gb is not None and gW is not None and K % 4 == 0 and _WGRAD_BIAS
+    gb_pass = None if wb else gb
+    if dz_ready or plain:
         dz = dy
-    elif plain:
-        dz = dy
-        if gb is not None or dgroup is not None:
-            ops.act_mask_bwd(dy, None, None, L.ACT_NONE, 1.0, None, gb, dgroup, gdiv)
+        if gb_pass is not None or (dgroup is not None and not dz_ready):
+            ops.act_mask_bwd(dy, None, None, L.ACT_NONE, 1.0, None, gb_pass, None if dz_ready else dgroup, gdiv)
     else:
         dz = torch.empty((N, M), dtype=dy.dtype, device=dy.device)
-        ops.act_mask_bwd(dy, z, mask, act, alpha, dz, gb, dgroup, gdiv, drop)
+        ops.act_mask_bwd(dy, z, mask, act, alpha, dz, gb_pass, dgroup, gdiv, drop)
     if gW is not None:
-        ops.wgrad(dz, x, gW, N, M, K)
+        ops.wgrad(dz, x, gW, N, M, K, dbias=gb if wb else None)
     dx = None
     if need_dx:
         dx = dx_out if dx_out is not None else torch.empty((N, K), dtype=dy.dtype, device=dy.device)
@@ -191,8 +197,8 @@ def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=N
             # a Linear below an activated Linear: this layer's dgrad epilogue emits the lower layer's dZ and db
             up = None
             if not first and layers[i - 1]["kind"] == "linear" and act != L.ACT_NONE:
-                up = (saved[i - 1][1], act, saved[i - 1][2], 1.0, None, gacc(layers[i - 1]["b"]))
-            dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), None if dz_ready else gacc(ly["b"]), want_dx,
+                up = (saved[i - 1][1], act, saved[i - 1][2], 1.0, None, None)
+            dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), gacc(ly["b"]), want_dx,
                                res_grad if first else None, dx_out=dx_out if first else None, dz_ready=dz_ready, up=up)
             dz_ready = up is not None
         else:
@@ -386,19 +392,19 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             up_local = None
             if fuse_local:
                 z_lp, mk_lp = sv_lp[-1][1], sv_lp[-1][2]
-                gb_lp = gacc(lproj[-1]["b"])
                 up_local = (z_lp[:, :lw] if z_lp is not None else None, act if z_lp is not None else L.ACT_NONE, mk_lp, 1.0,
-                            None, gb_lp[:lw] if gb_lp is not None else None)
-                if z_lp is None and mk_lp is None and gb_lp is None:
+                            None, None)                   # (the bias gradient comes out of the projection's own wgrad)
+                if z_lp is None and mk_lp is None:
                     up_local = None
                     fuse_local = False
             if p_drop > 0.0:
                 # dgrad of the K = l + s merge as two GEMMs over the column halves of W: the dropout backward of each half
                 # (and the local half's act/mask backward) rides in the epilogue instead of separate passes
                 dzm = torch.empty((N, s_out), dtype=dtype, device=dev)
-                ops.act_mask_bwd(dy, zm, None, act, 1.0, dzm, gbm)
+                wb = gbm is not None and gWm is not None and (lw + sdim) % 4 == 0 and _WGRAD_BIAS
+                ops.act_mask_bwd(dy, zm, None, act, 1.0, dzm, None if wb else gbm)
                 if gWm is not None:
-                    ops.wgrad(dzm, cat, gWm, N, s_out, lw + sdim)
+                    ops.wgrad(dzm, cat, gWm, N, s_out, lw + sdim, dbias=gbm if wb else None)
                 if fuse_local:
                     e = ops.epilogue(act=up_local[1], act_grad_z=up_local[0], row_mask=up_local[2], drop=(p_drop, s1),
                                      colsum=up_local[5]) if up_local[0] is not None else \
@@ -440,12 +446,9 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 if fuse_local:
                     # dg[:, :l] already holds dZ (and db[:l] is done): finish the summary columns in place
                     z_g, mk_g = sv_g[-1][1], sv_g[-1][2]
-                    gb_g = gacc(P["global_proj"][-1]["b"])
-                    if z_g is not None or mk_g is not None or gb_g is not None:
+                    if z_g is not None or mk_g is not None:
                         ops.act_mask_bwd(ds_out, z_g[:, l:] if z_g is not None else None, mk_g,
-                                         act if z_g is not None else L.ACT_NONE, 1.0,
-                                         ds_out if (z_g is not None or mk_g is not None) else None,
-                                         gb_g[l:] if gb_g is not None else None)
+                                         act if z_g is not None else L.ACT_NONE, 1.0, ds_out, None)
                 dx = mlp_bwd(dg, P["global_proj"], act, sv_g, dtype, dz_ready=fuse_local)
             else:
                 dx = mlp_bwd(dlocal_out, P["local_proj"], act, sv_l, dtype, dz_ready=fuse_local)
@@ -483,10 +486,10 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
         return y, None
 
     def bwd(dy):
-        # the second Linear's dgrad epilogue applies D1 and act'(z1) and sums the columns: it emits dZ1 and db1 directly
+        # the second Linear's dgrad epilogue applies D1 and act'(z1): it emits dZ1 directly; db1 comes out of W1's wgrad
         dz1, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2,
-                            up=(z1, act, None, 1.0, d1, gacc(P["b1"])))
-        dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), None, dz_ready=True)
+                            up=(z1, act, None, 1.0, d1, None))
+        dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True)
         return ln_b(dh, res=dy)
     return y, bwd
 

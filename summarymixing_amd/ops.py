@@ -99,15 +99,18 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
     return c
 
 
-def wgrad(dz, x, gW, rows, M, K, batch=1, sz=0, sx=0, sw=0, lddz=None, ldx=None, lddw=None, alpha=1.0):
-    """gW[b] (M x K) += alpha * dz[b]^T x[b]  (slab split-K + fixed-order reduction; see smx_linear_wgrad)."""
+def wgrad(dz, x, gW, rows, M, K, batch=1, sz=0, sx=0, sw=0, lddz=None, ldx=None, lddw=None, alpha=1.0, dbias=None):
+    """gW[b] (M x K) += alpha * dz[b]^T x[b]  (slab split-K + fixed-order reduction; see smx_linear_wgrad).
+    dbias (fp32 (batch, M), contiguous): += alpha * column sums of dz from the same launch (needs K % 4 == 0)."""
     pz, lz = _mat(dz)
     px, lx = _mat(x)
     pw, lw = _mat(gW)
     assert gW.dtype == torch.float32
+    if dbias is not None:
+        assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == batch * M and K % 4 == 0
     ws = _workspace(L.lib().smx_linear_wgrad_workspace(rows, M, K, batch), dz.device, slot=1)
-    L.check(L.lib().smx_linear_wgrad(dt(dz), pz, lddz or lz, sz, px, ldx or lx, sx, pw, lddw or lw, sw, rows, M, K, batch,
-                                     alpha, _p(ws), _stream()), "smx_linear_wgrad")
+    L.check(L.lib().smx_linear_wgrad(dt(dz), pz, lddz or lz, sz, px, ldx or lx, sx, pw, lddw or lw, sw, _p(dbias), rows, M, K,
+                                     batch, alpha, _p(ws), _stream()), "smx_linear_wgrad")
 
 
 def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, gdiv=0, drop=None):

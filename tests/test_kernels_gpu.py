@@ -226,6 +226,23 @@ def test_gemm_act_grad_epilogue(N, M, K, dtype, tol):
         assert rel_err(gb, gb_ref) <= tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("rows,M,K,batch", [(3000, 256, 128, 1), (777, 72, 40, 1), (5000, 1024, 256, 1), (900, 48, 32, 3)])
+def test_wgrad_with_bias_gradient(rows, M, K, batch, dtype, tol):
+    """smx_linear_wgrad(dbias=): the column sums of dZ (the bias gradient) come out of the wgrad launch itself."""
+    L, ops = _ops()
+    torch.manual_seed(rows + M)
+    dz = torch.randn(rows, batch * M, device="cuda").to(dtype)
+    x = torch.randn(rows, batch * K, device="cuda").to(dtype)
+    gW = torch.full((batch, M, K), 0.5, device="cuda")
+    gb = torch.full((batch, M), -0.25, device="cuda")
+    ops.wgrad(dz[:, :M], x[:, :K], gW[0], rows, M, K, batch=batch, sz=M, sx=K, sw=M * K, lddz=batch * M, ldx=batch * K,
+              lddw=K, alpha=0.5, dbias=gb)
+    dz3, x3 = dz.double().view(rows, batch, M), x.double().view(rows, batch, K)
+    assert rel_err(gW, 0.5 + 0.5 * torch.einsum("rbm,rbk->bmk", dz3, x3)) <= tol
+    assert rel_err(gb, -0.25 + 0.5 * dz3.sum(0)) <= tol
+
+
 def test_act_mask_bwd_reductions():
     L, ops = _ops()
     torch.manual_seed(6)
