@@ -21,6 +21,21 @@ def run(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
         e = ops.epilogue(bias=b, act=L.ACT_SWISH, z=z) if epi == "swishz" else ops.epilogue(bias=b)
         fn = lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e)
         nbytes = (N * K + M * K + (2 if epi == "swishz" else 1) * N * M) * es
+    elif layout == "NNag":  # dgrad with the fused activation backward: dZ_up (N,M) = (dZ (N,K) W (K,M)) * act'(Z_up), Z read
+        w = (torch.randn(K, M, device="cuda") * 0.05).to(dtype)
+        y = torch.empty(N, M, device="cuda", dtype=dtype)
+        zin = torch.randn(N, M, device="cuda").to(dtype)
+        e = ops.epilogue(act=L.ACT_SWISH, act_grad_z=zin, drop=(0.15, 1234))
+        fn = lambda: ops.gemm(L.GEMM_NN, x, w, y, N, M, K, e)
+        nbytes = (N * K + M * K + 2 * N * M) * es
+    elif layout == "NTres":  # forward Linear with residual + dropout + alpha (FFN down-projection)
+        w = (torch.randn(M, K, device="cuda") * 0.05).to(dtype)
+        y = torch.empty(N, M, device="cuda", dtype=dtype)
+        r = torch.randn(N, M, device="cuda").to(dtype)
+        b = torch.randn(M, device="cuda")
+        e = ops.epilogue(bias=b, res=r, alpha=0.5, drop=(0.15, 99))
+        fn = lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e)
+        nbytes = (N * K + M * K + 2 * N * M) * es
     elif layout == "NN":    # dgrad: dX (N,M) = dZ (N,K) W (K,M)
         w = (torch.randn(K, M, device="cuda") * 0.05).to(dtype)
         y = torch.empty(N, M, device="cuda", dtype=dtype)
@@ -43,3 +58,4 @@ if __name__ == "__main__":
         run(N, d, f, "NT"); run(N, f, d, "NT", epi="plain"); run(N, d, 2 * d, "NT"); run(N, d, d, "NT", epi="plain")
         run(N, f, d, "NN"); run(N, d, f, "NN"); run(N, d, d, "NN")
         run(N, f, d, "TN"); run(N, d, f, "TN"); run(N, d, d, "TN")
+        run(N, d, f, "NNag"); run(N, f, d, "NTres")
