@@ -927,13 +927,27 @@ namespace smx {
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, long slab_stride,
                                                            float* dst, long lddst, long sdst, int M, int K, int batch,
                                                            float alpha, const float* __restrict__ bpart, float* dbias) {
-  // bias gradient: dbias[b*M + m] += alpha * sum_s bpart[s][b*M + m]  (column sums of dZ collected by the wgrad GEMM)
+  // bias gradient: dbias[b*M + m] += alpha * sum_s bpart[s][b*M + m]  (column sums of dZ collected by the wgrad GEMM).
+  // 8 lanes share one element (slabs s = part, part+8, ..; 4 loads in flight each) and are folded in a fixed order:
+  // a single thread walking up to 128 slabs is a 128-deep chain of dependent L2 round trips.
   if (dbias) {
     const long nb = (long)batch * M;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < nb; i += (long)gridDim.x * 256) {
-      float a = 0.f;
-      for (int sidx = 0; sidx < nslab; ++sidx) a += bpart[(long)sidx * nb + i];
-      dbias[i] += alpha * a;
+    const long nb8 = (nb * 8 + 255) / 256 * 256;          // whole wave iterations (shuffles need all 8 lanes present)
+    for (long g = blockIdx.x * 256L + threadIdx.x; g < nb8; g += (long)gridDim.x * 256) {
+      const long i = g >> 3;
+      const int part = (int)(g & 7);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (i < nb) {
+        int sidx = part;
+        for (; sidx + 24 < nslab; sidx += 32) {
+          a0 += bpart[(long)sidx * nb + i]; a1 += bpart[(long)(sidx + 8) * nb + i];
+          a2 += bpart[(long)(sidx + 16) * nb + i]; a3 += bpart[(long)(sidx + 24) * nb + i];
+        }
+        for (; sidx < nslab; sidx += 8) a0 += bpart[(long)sidx * nb + i];
+      }
+      float a = (a0 + a1) + (a2 + a3);
+      a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+      if (part == 0 && i < nb) dbias[i] += alpha * a;
     }
   }
   const int kv = K / 4;
