@@ -950,32 +950,53 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
       if (part == 0 && i < nb) dbias[i] += alpha * a;
     }
   }
+  // weights: P lanes share one float4 of dW (slabs s = part, part+P, ..; 4 loads in flight each) and are folded by
+  // shuffles in a fixed order - one thread walking all the slabs of a small weight (128 of them for a 256x256 matrix)
+  // is a long chain of dependent L2 round trips.  P = 8 when there are many slabs, 1 for a handful.
   const int kv = K / 4;
   const long total = (long)batch * M * kv;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int k4 = (int)(i % kv);
-    const long r = i / kv;
+  const int P = nslab >= 16 ? 8 : 1, pshift = nslab >= 16 ? 3 : 0;
+  const long totalp = ((total << pshift) + 255) / 256 * 256;   // whole wave iterations (shuffles need every lane)
+  for (long g = blockIdx.x * 256L + threadIdx.x; g < totalp; g += (long)gridDim.x * 256) {
+    const long i = g >> pshift;
+    const int part = (int)(g & (P - 1));
+    const bool ok = i < total;
+    const long ic = ok ? i : 0;
+    const int k4 = (int)(ic % kv);
+    const long r = ic / kv;
     const int m = (int)(r % M), b = (int)(r / M);
     const float* sp = slabs + ((long)b * M + m) * K + k4 * 4;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;   // 4 loads in flight, fixed order
-    int s = 0;
-    for (; s + 3 < nslab; s += 4) {
-      const float4 v0 = *reinterpret_cast<const float4*>(sp + (long)s * slab_stride);
-      const float4 v1 = *reinterpret_cast<const float4*>(sp + (long)(s + 1) * slab_stride);
-      const float4 v2 = *reinterpret_cast<const float4*>(sp + (long)(s + 2) * slab_stride);
-      const float4 v3 = *reinterpret_cast<const float4*>(sp + (long)(s + 3) * slab_stride);
-      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-      a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-      a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    if (ok) {
+      int sidx = part;
+      for (; sidx + 3 * P < nslab; sidx += 4 * P) {
+        const float4 v0 = *reinterpret_cast<const float4*>(sp + (long)sidx * slab_stride);
+        const float4 v1 = *reinterpret_cast<const float4*>(sp + (long)(sidx + P) * slab_stride);
+        const float4 v2 = *reinterpret_cast<const float4*>(sp + (long)(sidx + 2 * P) * slab_stride);
+        const float4 v3 = *reinterpret_cast<const float4*>(sp + (long)(sidx + 3 * P) * slab_stride);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+      }
+      for (; sidx < nslab; sidx += P) {
+        const float4 v0 = *reinterpret_cast<const float4*>(sp + (long)sidx * slab_stride);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      }
     }
-    for (; s < nslab; ++s) {
-      const float4 v0 = *reinterpret_cast<const float4*>(sp + (long)s * slab_stride);
-      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    float sx = (a0.x + a1.x) + (a2.x + a3.x), sy = (a0.y + a1.y) + (a2.y + a3.y);
+    float sz = (a0.z + a1.z) + (a2.z + a3.z), sw = (a0.w + a1.w) + (a2.w + a3.w);
+    if (P == 8) {
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) {
+        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64);
+        sz += __shfl_xor(sz, off, 64); sw += __shfl_xor(sw, off, 64);
+      }
     }
-    float* d = dst + (long)b * sdst + (long)m * lddst + k4 * 4;
-    d[0] += alpha * ((a0.x + a1.x) + (a2.x + a3.x)); d[1] += alpha * ((a0.y + a1.y) + (a2.y + a3.y));
-    d[2] += alpha * ((a0.z + a1.z) + (a2.z + a3.z)); d[3] += alpha * ((a0.w + a1.w) + (a2.w + a3.w));
+    if (ok && part == 0) {
+      float* d = dst + (long)b * sdst + (long)m * lddst + k4 * 4;
+      d[0] += alpha * sx; d[1] += alpha * sy; d[2] += alpha * sz; d[3] += alpha * sw;
+    }
   }
 }
 static int wgrad_splits(int rows, int M, int K, int batch) {
@@ -1030,9 +1051,9 @@ extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t
   int rc = gemm_impl(SMX_GEMM_TN, dtype, dZ, lddz, strideZ, X, ldx, strideX, ws, K, (int64_t)M * K, M, K, rows, batch,
                      splits, slab, &e, stream, bpart);
   if (rc != SMX_OK) return rc;
-  long total = (long)batch * M * (K / 4);
+  long total = (long)batch * M * (K / 4) * (splits >= 16 ? 8 : 1);
   long blocks = (total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws,
                      splits, slab, dW, lddw, strideW, M, K, batch, alpha, bpart, dbias);
   return check_launch("smx_linear_wgrad");
