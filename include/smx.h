@@ -205,6 +205,30 @@ int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* str
 int smx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, const float* gscale_dev, void* stream);
+/* ---- CTC head after the encoder (recipe keys `log_softmax`, `ctc_cost`:
+ * …/LibriSpeech/ASR/transducer/hparams/conformer_summarymixing_transducer.yaml:297-298,331). ----
+ * Y = log_softmax(X) over the last dim (N rows of V); bwd: dX = dY - exp(Y) * rowsum(dY).
+ * Replaces speechbrain.nnet.activations.Softmax(apply_log=True). */
+int smx_log_softmax_fwd(int dtype, const void* X, int64_t ldx, void* Y, int64_t ldy, int N, int V, void* stream);
+int smx_log_softmax_bwd(int dtype, const void* dY, int64_t lddy, const void* Y, int64_t ldy, void* dX, int64_t lddx, int N,
+                        int V, void* stream);
+/* CTC negative log-likelihood per utterance and its gradient; replaces torch.nn.functional.ctc_loss(...,
+ * zero_infinity=True) as called by speechbrain.nnet.losses.ctc_loss.
+ *   log_probs (B, T, V) row-major with leading dimension ldlp (rows b*T + t), dtype T (log-softmax outputs);
+ *   targets int32 (B, Smax) padded, in_len / tgt_len int32 (B) absolute lengths, blank < V;
+ *   fwd: nll[b] = -log p(targets_b | x_b)  (+inf when no alignment exists); keeps the forward variables in `workspace`
+ *        (smx_ctc_workspace bytes) for the backward;
+ *   bwd: grad[b,t,v] = gscale[b] * (exp(lp) - exp(log sum_{s: l'_s = v} alpha*beta/y + nll[b])), zero for t >= in_len[b]
+ *        and for utterances with infinite nll (the convention of torch's ctc_loss backward: the gradient w.r.t. the
+ *        unnormalised logits; pushing it through smx_log_softmax_bwd leaves it unchanged).  gscale[b] carries the
+ *        reduction (1/B, 1/tgt_len, ...) times the upstream gradient.  Must follow smx_ctc_loss_fwd on the same workspace. */
+size_t smx_ctc_workspace(int B, int T, int Smax);
+int smx_ctc_loss_fwd(int dtype, const void* log_probs, int64_t ldlp, const int32_t* targets, const int32_t* in_len,
+                     const int32_t* tgt_len, int B, int T, int V, int Smax, int blank, float* nll, void* workspace, void* stream);
+int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, const int32_t* targets, const int32_t* in_len,
+                     const int32_t* tgt_len, int B, int T, int V, int Smax, int blank, const float* nll, const float* gscale,
+                     void* grad, int64_t ldg, void* workspace, void* stream);
+
 /* step <= 0: the bias-correction step is read from the device step counter (smx_set_step_counter) instead. */
 /* Optional device step counter (one uint64 in device memory), the only process-global of the library.  While set
  * (non-NULL), every fused / standalone dropout mixes the counter's current value into its seed and smx_adamw_step with

@@ -381,3 +381,28 @@ def conv_frontend(x: Tensor, sd: SD, prefix: str = "") -> Tensor:
         i += 1
     h = h.permute(0, 2, 3, 1)
     return h.reshape(h.shape[0], h.shape[1], -1)
+
+
+# ----------------------------------------------------------------------------------------------------
+# CTC head.  Arithmetic is upstream-only (SpeechBrain v1.0 `speechbrain.nnet.losses.ctc_loss`
+# -> torch.nn.functional.ctc_loss, and `speechbrain.nnet.activations.Softmax(apply_log=True)`; call sites
+# …/LibriSpeech/ASR/transducer/hparams/conformer_summarymixing_transducer.yaml:297-298,331): **parity unpinned** by the
+# reference tree, pinned here against torch's own CPU implementation, which is what the recipes execute.
+# ----------------------------------------------------------------------------------------------------
+def log_softmax(x):
+    return torch.log_softmax(x, dim=-1)
+
+
+def ctc_loss(log_probs, targets, input_lens, target_lens, blank_index, reduction="mean"):
+    """speechbrain.nnet.losses.ctc_loss restated: relative lengths -> absolute, (B,T,V) -> (T,B,V), zero_infinity."""
+    B, T, _ = log_probs.shape
+    in_len = (input_lens * T).round().int()
+    tgt_len = (target_lens * targets.shape[1]).round().int()
+    red = {"batchmean": "sum", "batch": "none"}.get(reduction, reduction)
+    loss = torch.nn.functional.ctc_loss(log_probs.transpose(0, 1), targets, in_len, tgt_len, blank_index,
+                                        zero_infinity=True, reduction=red)
+    if reduction == "batchmean":
+        return loss / B
+    if reduction == "batch":
+        return loss / tgt_len.to(loss.dtype)
+    return loss

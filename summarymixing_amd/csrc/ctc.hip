@@ -1,0 +1,245 @@
+// ctc.hip — the CTC head that follows the encoder in the reference recipes, gfx950 only:
+//   log-softmax over the vocabulary (speechbrain.nnet.activations.Softmax(apply_log=True), recipe `log_softmax`) and
+//   the CTC negative log-likelihood + its gradient (speechbrain.nnet.losses.ctc_loss -> torch.nn.functional.ctc_loss
+//   with zero_infinity=True; recipe `ctc_cost`, …transducer.yaml:297-298,331).
+// Three kernels for the loss: alpha (forward variable, one workgroup per utterance, states across the threads, one
+// LDS-resident time step at a time), beta (backward variable; turns the stored alphas into log occupancies
+// log(alpha*beta/y) in place) and a fully parallel gradient pass (one workgroup per (utterance, frame) row).
+#include "smx_common.h"
+
+namespace smx {
+
+static constexpr float NEG_INF = -__builtin_inff();
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  const float m = fmaxf(a, fmaxf(b, c));
+  if (m == NEG_INF) return NEG_INF;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+// ---- log-softmax over the last dimension: one wave per row, row read twice (max+sum, then write) -------------
+template <typename T>
+__global__ __launch_bounds__(256) void log_softmax_fwd_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
+                                                              int N_, int V) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N_) return;
+  const T* x = X + (long)row * ldx;
+  float m = NEG_INF;
+  for (int c = lane; c < V; c += 64) m = fmaxf(m, to_f32(x[c]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += expf(to_f32(x[c]) - m);
+  s = wave_sum(s);
+  const float lz = m + logf(s);
+  T* y = Y + (long)row * ldy;
+  for (int c = lane; c < V; c += 64) y[c] = from_f32<T>(to_f32(x[c]) - lz);
+}
+
+// dX = dY - exp(Y) * sum_v dY   (Y = the log-probabilities the forward produced)
+template <typename T>
+__global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ Y,
+                                                              long ldy, T* __restrict__ dX, long lddx, int N_, int V) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N_) return;
+  const T* dy = dY + (long)row * lddy;
+  const T* y = Y + (long)row * ldy;
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += to_f32(dy[c]);
+  s = wave_sum(s);
+  T* dx = dX + (long)row * lddx;
+  for (int c = lane; c < V; c += 64) dx[c] = from_f32<T>(to_f32(dy[c]) - expf(to_f32(y[c])) * s);
+}
+
+// ---- CTC ---------------------------------------------------------------------------------------------------
+// extended label sequence l' of utterance b: state s is the blank for even s, target (s >> 1) for odd s
+__device__ __forceinline__ int state_label(const int* tg, int s, int blank) { return (s & 1) ? tg[s >> 1] : blank; }
+
+// alpha[b, t, s] (log domain, includes the emission at t); nll[b] = -log p(l | x).  grid = B, block = 256.
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_alpha_kernel(const T* __restrict__ LP, long ldlp, int Tmax, int V,
+                                                        const int* __restrict__ targets, int Smax,
+                                                        const int* __restrict__ in_len, const int* __restrict__ tgt_len,
+                                                        int blank, float* __restrict__ alpha, int Lmax, float* __restrict__ nll) {
+  extern __shared__ float sh[];                          // 2 * Lmax floats
+  const int b = blockIdx.x;
+  const int Tb = min(in_len[b], Tmax), S = min(tgt_len[b], Smax), L = 2 * S + 1;
+  const int* tg = targets + (long)b * Smax;
+  float* prev = sh;
+  float* cur = sh + Lmax;
+  float* ab = alpha + (long)b * Tmax * Lmax;
+  for (int t = 0; t < Tb; ++t) {
+    const T* lp = LP + ((long)b * Tmax + t) * ldlp;
+    for (int s = threadIdx.x; s < L; s += 256) {
+      const int lab = state_label(tg, s, blank);
+      const float y = to_f32(lp[lab]);
+      float a;
+      if (t == 0) {
+        a = s < 2 ? y : NEG_INF;
+      } else {
+        const float a0 = prev[s];
+        const float a1 = s >= 1 ? prev[s - 1] : NEG_INF;
+        const float a2 = (s >= 2 && (s & 1) && tg[s >> 1] != tg[(s >> 1) - 1]) ? prev[s - 2] : NEG_INF;
+        a = lse3(a0, a1, a2) + y;
+      }
+      cur[s] = a;
+      ab[(long)t * Lmax + s] = a;
+    }
+    __syncthreads();
+    float* tmp = prev; prev = cur; cur = tmp;
+  }
+  if (threadIdx.x == 0) {
+    float ll = NEG_INF;
+    if (Tb > 0) ll = lse3(prev[L - 1], L > 1 ? prev[L - 2] : NEG_INF, NEG_INF);
+    nll[b] = -ll;                                        // +inf when no alignment exists (zero_infinity handled by the caller)
+  }
+}
+
+// beta recursion; overwrites alpha[b,t,s] with the log occupancy  alpha + beta - y  ( = log(alpha*beta / y) ).
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_beta_kernel(const T* __restrict__ LP, long ldlp, int Tmax, int V,
+                                                       const int* __restrict__ targets, int Smax,
+                                                       const int* __restrict__ in_len, const int* __restrict__ tgt_len,
+                                                       int blank, float* __restrict__ alpha, int Lmax) {
+  extern __shared__ float sh[];
+  const int b = blockIdx.x;
+  const int Tb = min(in_len[b], Tmax), S = min(tgt_len[b], Smax), L = 2 * S + 1;
+  const int* tg = targets + (long)b * Smax;
+  float* nxt = sh;
+  float* cur = sh + Lmax;
+  float* ab = alpha + (long)b * Tmax * Lmax;
+  for (int t = Tb - 1; t >= 0; --t) {
+    const T* lp = LP + ((long)b * Tmax + t) * ldlp;
+    for (int s = threadIdx.x; s < L; s += 256) {
+      const int lab = state_label(tg, s, blank);
+      const float y = to_f32(lp[lab]);
+      float bt;
+      if (t == Tb - 1) {
+        bt = s >= L - 2 ? y : NEG_INF;
+      } else {
+        const float b0 = nxt[s];
+        const float b1 = s + 1 < L ? nxt[s + 1] : NEG_INF;
+        const float b2 = (s + 2 < L && (s & 1) && tg[s >> 1] != tg[(s >> 1) + 1]) ? nxt[s + 2] : NEG_INF;
+        bt = lse3(b0, b1, b2) + y;
+      }
+      cur[s] = bt;
+      const float a = ab[(long)t * Lmax + s];
+      ab[(long)t * Lmax + s] = (a == NEG_INF || bt == NEG_INF) ? NEG_INF : a + bt - y;
+    }
+    __syncthreads();
+    float* tmp = nxt; nxt = cur; cur = tmp;
+  }
+}
+
+// gradient w.r.t. the (log-softmax-normalised) inputs, torch.nn.functional.ctc_loss convention (Graves eq. 16):
+//   G[b,t,v] = gscale[b] * ( exp(lp[b,t,v]) - exp( log sum_{s: l'_s = v} occ[b,t,s] + nll[b] ) )
+// and 0 for t >= in_len[b] or when nll[b] is infinite (zero_infinity).  grid = B*Tmax rows, block = 256.
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ LP, long ldlp, int Tmax, int V,
+                                                       const int* __restrict__ targets, int Smax,
+                                                       const int* __restrict__ in_len, const int* __restrict__ tgt_len,
+                                                       int blank, const float* __restrict__ occ, int Lmax,
+                                                       const float* __restrict__ nll, const float* __restrict__ gscale,
+                                                       T* __restrict__ G, long ldg) {
+  extern __shared__ float acc[];                         // V floats + 4 (block max)
+  __shared__ float redm[4];
+  const int row = blockIdx.x, b = row / Tmax, t = row % Tmax;
+  T* g = G + (long)row * ldg;
+  const float nl = nll[b];
+  const int Tb = min(in_len[b], Tmax);
+  if (t >= Tb || !(nl < __builtin_inff())) {
+    for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
+    return;
+  }
+  const int S = min(tgt_len[b], Smax), L = 2 * S + 1;
+  const int* tg = targets + (long)b * Smax;
+  const float* oc = occ + ((long)b * Tmax + t) * Lmax;
+  for (int v = threadIdx.x; v < V; v += 256) acc[v] = 0.f;
+  float m = NEG_INF;
+  for (int s = threadIdx.x; s < L; s += 256) m = fmaxf(m, oc[s]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  if (m > NEG_INF) {
+    for (int s = threadIdx.x; s < L; s += 256) {
+      const float o = oc[s];
+      if (o > NEG_INF) atomicAdd(&acc[state_label(tg, s, blank)], expf(o - m));
+    }
+  }
+  __syncthreads();
+  const float sc = gscale[b];
+  const T* lp = LP + (long)row * ldlp;
+  const float shift = m + nl;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float a = acc[v];
+    const float lab = a > 0.f ? expf(logf(a) + shift) : 0.f;
+    g[v] = from_f32<T>(sc * (expf(to_f32(lp[v])) - lab));
+  }
+}
+
+}  // namespace smx
+
+using namespace smx;
+#define STREAM reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int smx_log_softmax_fwd(int dtype, const void* X, int64_t ldx, void* Y, int64_t ldy, int N, int V, void* stream) {
+  SMX_REQUIRE(X && Y && V > 0, "smx_log_softmax_fwd: bad arguments");
+  if (N <= 0) return SMX_OK;
+  dim3 grid((N + 3) / 4);
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((log_softmax_fwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)X, ldx, (bf16_t*)Y, ldy, N, V);
+  else hipLaunchKernelGGL((log_softmax_fwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)X, ldx, (float*)Y, ldy, N, V);
+  return check_launch("smx_log_softmax_fwd");
+}
+
+extern "C" int smx_log_softmax_bwd(int dtype, const void* dY, int64_t lddy, const void* Y, int64_t ldy, void* dX, int64_t lddx,
+                                   int N, int V, void* stream) {
+  SMX_REQUIRE(dY && Y && dX && V > 0, "smx_log_softmax_bwd: bad arguments");
+  if (N <= 0) return SMX_OK;
+  dim3 grid((N + 3) / 4);
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((log_softmax_bwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Y, ldy, (bf16_t*)dX, lddx, N, V);
+  else hipLaunchKernelGGL((log_softmax_bwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Y, ldy, (float*)dX, lddx, N, V);
+  return check_launch("smx_log_softmax_bwd");
+}
+
+static int ctc_lmax(int Smax) { return 2 * Smax + 1; }
+
+extern "C" size_t smx_ctc_workspace(int B, int T, int Smax) { return (size_t)B * T * ctc_lmax(Smax) * sizeof(float); }
+
+extern "C" int smx_ctc_loss_fwd(int dtype, const void* log_probs, int64_t ldlp, const int32_t* targets, const int32_t* in_len,
+                                const int32_t* tgt_len, int B, int T, int V, int Smax, int blank, float* nll, void* workspace,
+                                void* stream) {
+  SMX_REQUIRE(log_probs && targets && in_len && tgt_len && nll && workspace, "smx_ctc_loss_fwd: null pointer");
+  SMX_REQUIRE(B >= 0 && T > 0 && V > 0 && Smax >= 0 && blank >= 0 && blank < V, "smx_ctc_loss_fwd: bad sizes");
+  const int Lmax = ctc_lmax(Smax);
+  SMX_REQUIRE(2 * Lmax * sizeof(float) <= 64 * 1024, "smx_ctc_loss_fwd: target length %d too long (max 4095)", Smax);
+  if (B == 0) return SMX_OK;
+  const size_t shm = 2 * (size_t)Lmax * sizeof(float);
+  float* alpha = reinterpret_cast<float*>(workspace);
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((ctc_alpha_kernel<bf16_t>), dim3(B), dim3(256), shm, STREAM, (const bf16_t*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll);
+  else hipLaunchKernelGGL((ctc_alpha_kernel<float>), dim3(B), dim3(256), shm, STREAM, (const float*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll);
+  return check_launch("smx_ctc_loss_fwd");
+}
+
+extern "C" int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, const int32_t* targets, const int32_t* in_len,
+                                const int32_t* tgt_len, int B, int T, int V, int Smax, int blank, const float* nll,
+                                const float* gscale, void* grad, int64_t ldg, void* workspace, void* stream) {
+  SMX_REQUIRE(log_probs && targets && in_len && tgt_len && nll && gscale && grad && workspace, "smx_ctc_loss_bwd: null pointer");
+  SMX_REQUIRE(B >= 0 && T > 0 && V > 0 && V <= 12288 && Smax >= 0 && blank >= 0 && blank < V, "smx_ctc_loss_bwd: bad sizes");
+  const int Lmax = ctc_lmax(Smax);
+  SMX_REQUIRE(2 * Lmax * sizeof(float) <= 64 * 1024, "smx_ctc_loss_bwd: target length %d too long (max 4095)", Smax);
+  if (B == 0) return SMX_OK;
+  const size_t shm = 2 * (size_t)Lmax * sizeof(float);
+  float* alpha = reinterpret_cast<float*>(workspace);
+  if (dtype == SMX_BF16) {
+    hipLaunchKernelGGL((ctc_beta_kernel<bf16_t>), dim3(B), dim3(256), shm, STREAM, (const bf16_t*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax);
+    hipLaunchKernelGGL((ctc_grad_kernel<bf16_t>), dim3(B * T), dim3(256), (size_t)V * sizeof(float), STREAM, (const bf16_t*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll, gscale, (bf16_t*)grad, ldg);
+  } else {
+    hipLaunchKernelGGL((ctc_beta_kernel<float>), dim3(B), dim3(256), shm, STREAM, (const float*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax);
+    hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(B * T), dim3(256), (size_t)V * sizeof(float), STREAM, (const float*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll, gscale, (float*)grad, ldg);
+  }
+  return check_launch("smx_ctc_loss_bwd");
+}

@@ -17,6 +17,38 @@ class Swish(torch.nn.Module):
         raise RuntimeError("activations are fused into the HIP kernels; this module is a marker")
 
 
+class _LogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        from .. import ops
+        x2 = ops.rows2d(x if x.is_contiguous() else x.contiguous())
+        y = ops.log_softmax_fwd(x2)
+        ctx.save_for_backward(y)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import ops
+        (y,) = ctx.saved_tensors
+        dy2 = ops.rows2d(dy if dy.is_contiguous() else dy.contiguous())
+        return ops.log_softmax_bwd(dy2, y).view(dy.shape)
+
+
+class Softmax(torch.nn.Module):
+    """speechbrain.nnet.activations.Softmax as the recipes instantiate it (``apply_log: True``, last dim): the
+    log-softmax in front of the CTC loss (…transducer.yaml:331).  HIP kernels, GPU only."""
+
+    def __init__(self, apply_log=False, dim=-1, reshape=True, dtype=torch.float32):
+        super().__init__()
+        if not apply_log or dim != -1:
+            raise NotImplementedError("only the log-softmax over the last dim used by the CTC head is implemented")
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("summarymixing_amd kernels run on the GPU only (no CPU fallback)")
+        return _LogSoftmax.apply(x)
+
+
 _BY_NAME = {"gelu": L.ACT_GELU, "swish": L.ACT_SWISH, "silu": L.ACT_SWISH, "leakyrelu": L.ACT_LEAKY_RELU,
             "leaky_relu": L.ACT_LEAKY_RELU, "relu": L.ACT_RELU, "identity": L.ACT_NONE, "none": L.ACT_NONE}
 

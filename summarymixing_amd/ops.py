@@ -273,6 +273,46 @@ def adamw_step(param, grad, m, v, shadow, lr, b1, b2, eps, wd, step, grad_scale=
                                    step, grad_scale, _p(gscale_dev), _stream()), "smx_adamw_step")
 
 
+def log_softmax_fwd(x):
+    """log_softmax over the last dim of a (N, V) view."""
+    N, V = x.shape
+    y = torch.empty((N, V), dtype=x.dtype, device=x.device)
+    px, ldx = _mat(x)
+    L.check(L.lib().smx_log_softmax_fwd(dt(x), px, ldx, _p(y), V, N, V, _stream()), "smx_log_softmax_fwd")
+    return y
+
+
+def log_softmax_bwd(dy, y):
+    N, V = y.shape
+    dx = torch.empty((N, V), dtype=y.dtype, device=y.device)
+    pdy, lddy = _mat(dy)
+    py, ldy = _mat(y)
+    L.check(L.lib().smx_log_softmax_bwd(dt(y), pdy, lddy, py, ldy, _p(dx), V, N, V, _stream()), "smx_log_softmax_bwd")
+    return dx
+
+
+def ctc_fwd(lp2, targets, in_len, tgt_len, B, T, blank):
+    """lp2: (B*T, V) log-probabilities; targets int32 (B, Smax); lengths int32 (B).  -> (nll (B) fp32, workspace)."""
+    V, Smax = lp2.shape[1], targets.shape[1]
+    assert targets.dtype == torch.int32 and in_len.dtype == torch.int32 and tgt_len.dtype == torch.int32
+    assert targets.is_contiguous()
+    nll = torch.empty((B,), dtype=torch.float32, device=lp2.device)
+    ws = torch.empty(max(L.lib().smx_ctc_workspace(B, T, Smax), 16), dtype=torch.uint8, device=lp2.device)  # kept for the bwd
+    plp, ldlp = _mat(lp2)
+    L.check(L.lib().smx_ctc_loss_fwd(dt(lp2), plp, ldlp, _p(targets), _p(in_len), _p(tgt_len), B, T, V, Smax, blank, _p(nll),
+                                     _p(ws), _stream()), "smx_ctc_loss_fwd")
+    return nll, ws
+
+
+def ctc_bwd(lp2, targets, in_len, tgt_len, B, T, blank, nll, gscale, ws):
+    V, Smax = lp2.shape[1], targets.shape[1]
+    g = torch.empty((B * T, V), dtype=lp2.dtype, device=lp2.device)
+    plp, ldlp = _mat(lp2)
+    L.check(L.lib().smx_ctc_loss_bwd(dt(lp2), plp, ldlp, _p(targets), _p(in_len), _p(tgt_len), B, T, V, Smax, blank, _p(nll),
+                                     _p(gscale), _p(g), V, _p(ws), _stream()), "smx_ctc_loss_bwd")
+    return g
+
+
 def set_step_counter(counter):
     """Register (or clear, with None) the device step counter: an int64 tensor of one element (see include/smx.h)."""
     if counter is not None:
