@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const T* __restric
 __device__ __forceinline__ int state_label(const int* tg, int s, int blank) { return (s & 1) ? tg[s >> 1] : blank; }
 
 // alpha[b, t, s] (log domain, includes the emission at t); nll[b] = -log p(l | x).  grid = B, block = 256.
-template <typename T>
+// A thread owns the states s = tid + 256 k (k < KS): their labels and skip permissions live in registers for the whole
+// utterance and the emissions of frame t+1 are requested before frame t is combined, so the gather latency is off the
+// T-step critical path (one barrier + one LDS exchange per frame remain).
+template <typename T, int KS>
 __global__ __launch_bounds__(256) void ctc_alpha_kernel(const T* __restrict__ LP, long ldlp, int Tmax, int V,
                                                         const int* __restrict__ targets, int Smax,
                                                         const int* __restrict__ in_len, const int* __restrict__ tgt_len,
@@ -70,25 +73,48 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(const T* __restrict__ LP
   float* prev = sh;
   float* cur = sh + Lmax;
   float* ab = alpha + (long)b * Tmax * Lmax;
+  int lab[KS];
+  bool skip[KS];
+  float y[KS], yn[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int s = threadIdx.x + 256 * k;
+    lab[k] = s < L ? state_label(tg, s, blank) : blank;
+    skip[k] = s < L && s >= 2 && (s & 1) && tg[s >> 1] != tg[(s >> 1) - 1];
+    y[k] = yn[k] = 0.f;
+  }
+  const T* lp0 = LP + (long)b * Tmax * ldlp;
+  if (Tb > 0) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) y[k] = to_f32(lp0[lab[k]]);
+  }
   for (int t = 0; t < Tb; ++t) {
-    const T* lp = LP + ((long)b * Tmax + t) * ldlp;
-    for (int s = threadIdx.x; s < L; s += 256) {
-      const int lab = state_label(tg, s, blank);
-      const float y = to_f32(lp[lab]);
-      float a;
-      if (t == 0) {
-        a = s < 2 ? y : NEG_INF;
-      } else {
-        const float a0 = prev[s];
-        const float a1 = s >= 1 ? prev[s - 1] : NEG_INF;
-        const float a2 = (s >= 2 && (s & 1) && tg[s >> 1] != tg[(s >> 1) - 1]) ? prev[s - 2] : NEG_INF;
-        a = lse3(a0, a1, a2) + y;
+    if (t + 1 < Tb) {
+      const T* lpn = lp0 + (long)(t + 1) * ldlp;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) yn[k] = to_f32(lpn[lab[k]]);
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int s = threadIdx.x + 256 * k;
+      if (s < L) {
+        float a;
+        if (t == 0) {
+          a = s < 2 ? y[k] : NEG_INF;
+        } else {
+          const float a0 = prev[s];
+          const float a1 = s >= 1 ? prev[s - 1] : NEG_INF;
+          const float a2 = skip[k] ? prev[s - 2] : NEG_INF;
+          a = lse3(a0, a1, a2) + y[k];
+        }
+        cur[s] = a;
+        ab[(long)t * Lmax + s] = a;
       }
-      cur[s] = a;
-      ab[(long)t * Lmax + s] = a;
     }
     __syncthreads();
     float* tmp = prev; prev = cur; cur = tmp;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) y[k] = yn[k];
   }
   if (threadIdx.x == 0) {
     float ll = NEG_INF;
@@ -98,7 +124,7 @@ __global__ __launch_bounds__(256) void ctc_alpha_kernel(const T* __restrict__ LP
 }
 
 // beta recursion; overwrites alpha[b,t,s] with the log occupancy  alpha + beta - y  ( = log(alpha*beta / y) ).
-template <typename T>
+template <typename T, int KS>
 __global__ __launch_bounds__(256) void ctc_beta_kernel(const T* __restrict__ LP, long ldlp, int Tmax, int V,
                                                        const int* __restrict__ targets, int Smax,
                                                        const int* __restrict__ in_len, const int* __restrict__ tgt_len,
@@ -110,26 +136,55 @@ __global__ __launch_bounds__(256) void ctc_beta_kernel(const T* __restrict__ LP,
   float* nxt = sh;
   float* cur = sh + Lmax;
   float* ab = alpha + (long)b * Tmax * Lmax;
+  int lab[KS];
+  bool skip[KS];
+  float y[KS], yn[KS], av[KS], avn[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    const int s = threadIdx.x + 256 * k;
+    lab[k] = s < L ? state_label(tg, s, blank) : blank;
+    skip[k] = s + 2 < L && (s & 1) && tg[s >> 1] != tg[(s >> 1) + 1];
+    y[k] = yn[k] = av[k] = avn[k] = 0.f;
+  }
+  const T* lp0 = LP + (long)b * Tmax * ldlp;
+  if (Tb > 0) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int s = threadIdx.x + 256 * k;
+      y[k] = to_f32(lp0[(long)(Tb - 1) * ldlp + lab[k]]);
+      av[k] = s < L ? ab[(long)(Tb - 1) * Lmax + s] : NEG_INF;
+    }
+  }
   for (int t = Tb - 1; t >= 0; --t) {
-    const T* lp = LP + ((long)b * Tmax + t) * ldlp;
-    for (int s = threadIdx.x; s < L; s += 256) {
-      const int lab = state_label(tg, s, blank);
-      const float y = to_f32(lp[lab]);
-      float bt;
-      if (t == Tb - 1) {
-        bt = s >= L - 2 ? y : NEG_INF;
-      } else {
-        const float b0 = nxt[s];
-        const float b1 = s + 1 < L ? nxt[s + 1] : NEG_INF;
-        const float b2 = (s + 2 < L && (s & 1) && tg[s >> 1] != tg[(s >> 1) + 1]) ? nxt[s + 2] : NEG_INF;
-        bt = lse3(b0, b1, b2) + y;
+    if (t > 0) {                                         // frame t-1: emissions and alphas, one step ahead
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        const int s = threadIdx.x + 256 * k;
+        yn[k] = to_f32(lp0[(long)(t - 1) * ldlp + lab[k]]);
+        avn[k] = s < L ? ab[(long)(t - 1) * Lmax + s] : NEG_INF;
       }
-      cur[s] = bt;
-      const float a = ab[(long)t * Lmax + s];
-      ab[(long)t * Lmax + s] = (a == NEG_INF || bt == NEG_INF) ? NEG_INF : a + bt - y;
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int s = threadIdx.x + 256 * k;
+      if (s < L) {
+        float bt;
+        if (t == Tb - 1) {
+          bt = s >= L - 2 ? y[k] : NEG_INF;
+        } else {
+          const float b0 = nxt[s];
+          const float b1 = s + 1 < L ? nxt[s + 1] : NEG_INF;
+          const float b2 = skip[k] ? nxt[s + 2] : NEG_INF;
+          bt = lse3(b0, b1, b2) + y[k];
+        }
+        cur[s] = bt;
+        ab[(long)t * Lmax + s] = (av[k] == NEG_INF || bt == NEG_INF) ? NEG_INF : av[k] + bt - y[k];
+      }
     }
     __syncthreads();
     float* tmp = nxt; nxt = cur; cur = tmp;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { y[k] = yn[k]; av[k] = avn[k]; }
   }
 }
 
@@ -219,8 +274,11 @@ extern "C" int smx_ctc_loss_fwd(int dtype, const void* log_probs, int64_t ldlp, 
   if (B == 0) return SMX_OK;
   const size_t shm = 2 * (size_t)Lmax * sizeof(float);
   float* alpha = reinterpret_cast<float*>(workspace);
-  if (dtype == SMX_BF16) hipLaunchKernelGGL((ctc_alpha_kernel<bf16_t>), dim3(B), dim3(256), shm, STREAM, (const bf16_t*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll);
-  else hipLaunchKernelGGL((ctc_alpha_kernel<float>), dim3(B), dim3(256), shm, STREAM, (const float*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll);
+#define CTC_ALPHA(TT, KS_) hipLaunchKernelGGL((ctc_alpha_kernel<TT, KS_>), dim3(B), dim3(256), shm, STREAM, (const TT*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll)
+#define CTC_ALPHA_T(TT) do { if (Lmax <= 256) CTC_ALPHA(TT, 1); else if (Lmax <= 512) CTC_ALPHA(TT, 2); else if (Lmax <= 1024) CTC_ALPHA(TT, 4); else if (Lmax <= 2048) CTC_ALPHA(TT, 8); else if (Lmax <= 4096) CTC_ALPHA(TT, 16); else CTC_ALPHA(TT, 32); } while (0)
+  if (dtype == SMX_BF16) CTC_ALPHA_T(bf16_t); else CTC_ALPHA_T(float);
+#undef CTC_ALPHA_T
+#undef CTC_ALPHA
   return check_launch("smx_ctc_loss_fwd");
 }
 
@@ -234,12 +292,16 @@ extern "C" int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, 
   if (B == 0) return SMX_OK;
   const size_t shm = 2 * (size_t)Lmax * sizeof(float);
   float* alpha = reinterpret_cast<float*>(workspace);
+#define CTC_BETA(TT, KS_) hipLaunchKernelGGL((ctc_beta_kernel<TT, KS_>), dim3(B), dim3(256), shm, STREAM, (const TT*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax)
+#define CTC_BETA_T(TT) do { if (Lmax <= 256) CTC_BETA(TT, 1); else if (Lmax <= 512) CTC_BETA(TT, 2); else if (Lmax <= 1024) CTC_BETA(TT, 4); else if (Lmax <= 2048) CTC_BETA(TT, 8); else if (Lmax <= 4096) CTC_BETA(TT, 16); else CTC_BETA(TT, 32); } while (0)
   if (dtype == SMX_BF16) {
-    hipLaunchKernelGGL((ctc_beta_kernel<bf16_t>), dim3(B), dim3(256), shm, STREAM, (const bf16_t*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax);
+    CTC_BETA_T(bf16_t);
     hipLaunchKernelGGL((ctc_grad_kernel<bf16_t>), dim3(B * T), dim3(256), (size_t)V * sizeof(float), STREAM, (const bf16_t*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll, gscale, (bf16_t*)grad, ldg);
   } else {
-    hipLaunchKernelGGL((ctc_beta_kernel<float>), dim3(B), dim3(256), shm, STREAM, (const float*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax);
+    CTC_BETA_T(float);
     hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(B * T), dim3(256), (size_t)V * sizeof(float), STREAM, (const float*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll, gscale, (float*)grad, ldg);
   }
+#undef CTC_BETA_T
+#undef CTC_BETA
   return check_launch("smx_ctc_loss_bwd");
 }
