@@ -1007,7 +1007,9 @@ static int wgrad_splits(int rows, int M, int K, int batch) {
   static const int target_env = getenv("SMX_WGRAD_BLOCKS") ? atoi(getenv("SMX_WGRAD_BLOCKS")) : 0;
   const long target = target_env > 0 ? target_env : 512;
   long s = (target + tiles - 1) / tiles;
-  long smax = (rows + 255) / 256;
+  static const int min_rows_env = getenv("SMX_WGRAD_MIN_ROWS") ? atoi(getenv("SMX_WGRAD_MIN_ROWS")) : 0;
+  const int min_rows = min_rows_env > 0 ? min_rows_env : 512;   // frames per split: fewer, longer splits when the batch is small (slab traffic)
+  long smax = (rows + min_rows - 1) / min_rows;
   if (s > smax) s = smax;
   return (int)(s < 1 ? 1 : s);
 }
