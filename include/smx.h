@@ -90,6 +90,27 @@ int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, c
                      int64_t strideX, float* dW, int64_t lddw, int64_t strideW, float* dbias, int rows, int M, int K,
                      int batch, float alpha, void* workspace, void* stream);
 
+/* Deferred variant: only the split-K GEMM; the slabs (and, with want_bias, the bias partials behind them) stay in
+ * `workspace` (same size query) for a later smx_reduce_jobs.  Outputs: *nslabs, *slab_stride (floats between slabs of
+ * the [batch][M][K] weight image), *bias_offset (floats from the workspace start to the [nslabs][batch][M] bias
+ * partials).  Returns SMX_EUNSUPPORTED for shapes the slab path cannot take (K % 4 != 0): use smx_linear_wgrad. */
+int smx_linear_wgrad_partial(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,
+                             int64_t strideX, int rows, int M, int K, int batch, int want_bias, void* workspace,
+                             int32_t* nslabs, int64_t* slab_stride, int64_t* bias_offset, void* stream);
+
+/* One launch for many small fixed-order reductions
+ *   dst[i*ldd + j] += alpha * sum_{s < nsrc} src[s*src_stride + i*src_ld + j]      (i < rows, j < cols; src_ld 0 = cols)
+ * : weight-gradient slabs, bias partials, LayerNorm dgamma/dbeta partial rows.  `vec` = 1
+ * when cols, ldd, src_ld, src_stride are multiples of 4 and src / dst are 16-byte aligned.  jobs and block_starts (njobs + 1 entries,
+ * prefix sums of smx_reduce_job_blocks) live in device memory; tables can be cached while the pointers stay valid. */
+typedef struct smx_reduce_job {
+  const float* src; float* dst; int64_t src_stride; int64_t ldd; int32_t nsrc; int32_t rows; int32_t cols; float alpha;
+  int32_t vec; int32_t src_ld;
+} smx_reduce_job;
+int smx_reduce_job_blocks(const smx_reduce_job* job_host);
+int smx_reduce_jobs(const smx_reduce_job* jobs_dev, const int32_t* block_starts_dev, int njobs, int total_blocks,
+                    void* stream);
+
 /* Y = R + alpha * act(X W^T + b [+C0]) * mask ; thin wrapper over smx_gemm(NT).
  * Replaces summary_mixing.py:257 (global_proj * mask), :207/:210 (local/summary proj * mask),
  * :282-284 (merge with the per-utterance summary folded in as C0 = sbar W_s^T + b, SMX_C0_GROUP, div=T). */
@@ -136,6 +157,9 @@ int smx_chunk_mean_fwd(int dtype, const void* S, int64_t lds, void* out, int64_t
 int smx_chunk_mean_bwd(int dtype, const void* dOut, int64_t ldo, void* dS, int64_t lds, int B, int T, int D,
                        int chunk, int left, void* workspace, void* stream);
 
+/* (smx_layernorm_bwd with dgamma == dbeta == NULL leaves its partial rows [smx_layernorm_bwd_blocks(N)][2][D] in the
+ *  workspace for smx_reduce_jobs: two jobs, src = ws (dgamma) and ws + D (dbeta), src_stride 2*D, rows 1, cols D.) */
+int smx_layernorm_bwd_blocks(int N);
 /* LayerNorm over the last dim with an optional fused activation: Y = act(LN(X))
  * (torch.nn.LayerNorm; Conformer.py:146,152-153,475-476,738).  stats (N,2) fp32 = (mean, rstd), optional in fwd.
  * bwd: dX = R + LNbwd(dY * act'(LN(X))) (R optional residual-gradient, dtype T; LN(X) is recomputed from the

@@ -21,6 +21,12 @@ ACTS = {"none": ACT_NONE, "identity": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_S
         "leaky_relu": ACT_LEAKY_RELU, "relu": ACT_RELU}
 
 
+class ReduceJob(ctypes.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("src_stride", c_i64), ("ldd", c_i64), ("nsrc", ctypes.c_int32),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("alpha", c_f), ("vec", ctypes.c_int32),
+                ("src_ld", ctypes.c_int32)]
+
+
 class Epilogue(ctypes.Structure):
     _fields_ = [("bias", c_vp), ("bias_batch_stride", c_i64),
                 ("c0", c_vp), ("ldc0", c_i64), ("c0_mode", ctypes.c_int32), ("c0_div", ctypes.c_int32),
@@ -43,6 +49,11 @@ SIGNATURES = {
     "smx_linear_wgrad_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_linear_wgrad": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i, c_i,
                                c_f, c_vp, c_vp]),
+    "smx_linear_wgrad_partial": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp,
+                                       ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_vp]),
+    "smx_reduce_job_blocks": (c_i, [ctypes.POINTER(ReduceJob)]),
+    "smx_reduce_jobs": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
+    "smx_layernorm_bwd_blocks": (c_i, [c_i]),
     "smx_linear_act_mask_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i,
                                       ctypes.POINTER(Epilogue), c_vp]),
     "smx_act_mask_bwd_workspace": (c_sz, [c_i, c_i]),

@@ -1027,6 +1027,22 @@ extern "C" size_t smx_linear_wgrad_workspace(int rows, int M, int K, int batch) 
   return (size_t)wgrad_splits(rows, M, K, batch) * batch * ((size_t)M * K + M) * sizeof(float) + 16;
 }
 
+// slabs (+ bias partials) only; shared by the immediate and the deferred entry point
+static int wgrad_slabs(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx, int64_t strideX,
+                       int rows, int M, int K, int batch, bool want_bias, float* ws, int* splits_out, void* stream) {
+  smx_epilogue e;
+  memset(&e, 0, sizeof(e));
+  const int BK = dtype == SMX_BF16 ? 64 : 32;
+  const int splits = effective_splits(rows, wgrad_splits(rows, M, K, batch), BK);
+  e.alpha = 1.f;
+  e.out_mode = SMX_OUT_F32;
+  const long slab = (long)batch * M * K;
+  float* bpart = want_bias ? ws + (long)splits * slab : nullptr;   // [splits][batch][M] behind the slabs
+  *splits_out = splits;
+  return gemm_impl(SMX_GEMM_TN, dtype, dZ, lddz, strideZ, X, ldx, strideX, ws, K, (int64_t)M * K, M, K, rows, batch, splits,
+                   slab, &e, stream, bpart);
+}
+
 extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,
                                 int64_t strideX, float* dW, int64_t lddw, int64_t strideW, float* dbias, int rows, int M,
                                 int K, int batch, float alpha, void* workspace, void* stream) {
@@ -1034,31 +1050,45 @@ extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t
   SMX_REQUIRE(!dbias || (K % 4 == 0 && workspace && aligned16(workspace)),
               "smx_linear_wgrad: dbias needs the slab path (K %% 4 == 0 and an aligned workspace)");
   if (M <= 0 || K <= 0 || rows <= 0) return SMX_OK;
-  smx_epilogue e;
-  memset(&e, 0, sizeof(e));
-  const int BK = dtype == SMX_BF16 ? 64 : 32;
-  const int splits = effective_splits(rows, wgrad_splits(rows, M, K, batch), BK);
   if (K % 4 != 0 || workspace == nullptr || !aligned16(workspace)) {
     // ragged shapes: fp32 atomics straight into the gradient (not bit-reproducible)
+    smx_epilogue e;
+    memset(&e, 0, sizeof(e));
+    const int BK = dtype == SMX_BF16 ? 64 : 32;
+    const int splits = effective_splits(rows, wgrad_splits(rows, M, K, batch), BK);
     e.alpha = alpha;
     e.out_mode = SMX_OUT_ATOMIC_F32;
     return gemm_impl(SMX_GEMM_TN, dtype, dZ, lddz, strideZ, X, ldx, strideX, dW, lddw, strideW, M, K, rows, batch, splits,
                      0, &e, stream);
   }
-  e.alpha = 1.f;
-  e.out_mode = SMX_OUT_F32;
   float* ws = reinterpret_cast<float*>(workspace);
-  const long slab = (long)batch * M * K;
-  float* bpart = dbias ? ws + (long)splits * slab : nullptr;   // [splits][batch][M] behind the slabs
-  int rc = gemm_impl(SMX_GEMM_TN, dtype, dZ, lddz, strideZ, X, ldx, strideX, ws, K, (int64_t)M * K, M, K, rows, batch,
-                     splits, slab, &e, stream, bpart);
+  int splits = 1;
+  int rc = wgrad_slabs(dtype, dZ, lddz, strideZ, X, ldx, strideX, rows, M, K, batch, dbias != nullptr, ws, &splits, stream);
   if (rc != SMX_OK) return rc;
+  const long slab = (long)batch * M * K;
+  float* bpart = dbias ? ws + (long)splits * slab : nullptr;
   long total = (long)batch * M * (K / 4) * (splits >= 16 ? 8 : 1);
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws,
                      splits, slab, dW, lddw, strideW, M, K, batch, alpha, bpart, dbias);
   return check_launch("smx_linear_wgrad");
+}
+
+extern "C" int smx_linear_wgrad_partial(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,
+                                        int64_t strideX, int rows, int M, int K, int batch, int want_bias, void* workspace,
+                                        int32_t* nslabs, int64_t* slab_stride, int64_t* bias_offset, void* stream) {
+  SMX_REQUIRE(dZ && X && workspace && nslabs && slab_stride && bias_offset, "smx_linear_wgrad_partial: null pointer");
+  if (K % 4 != 0 || !aligned16(workspace) || M <= 0 || K <= 0 || rows <= 0)
+    return fail(SMX_EUNSUPPORTED, "smx_linear_wgrad_partial: needs K %% 4 == 0, positive sizes and an aligned workspace");
+  int splits = 1;
+  int rc = wgrad_slabs(dtype, dZ, lddz, strideZ, X, ldx, strideX, rows, M, K, batch, want_bias != 0,
+                       reinterpret_cast<float*>(workspace), &splits, stream);
+  if (rc != SMX_OK) return rc;
+  *nslabs = splits;
+  *slab_stride = (int64_t)batch * M * K;
+  *bias_offset = (int64_t)splits * batch * M * K;
+  return SMX_OK;
 }
 
 extern "C" int smx_linear_act_mask_fwd(int dtype, const void* X, int64_t ldx, const void* W, int64_t ldw, void* Y,

@@ -997,20 +997,22 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
     else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 4096", D);
   }
 #undef LN_BWD
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
+  if (dgamma)   // (NULL dgamma/dbeta: the partial rows stay in the workspace for a deferred smx_reduce_jobs)
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
   return check_launch("smx_layernorm_bwd");
 }
 
 extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                                  const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma,
                                  float* dbeta, int N, int D, void* workspace, void* stream) {
-  SMX_REQUIRE(dY && X && gamma && beta && stats && dX && dgamma && dbeta && workspace && D > 0,
+  SMX_REQUIRE(dY && X && gamma && beta && stats && dX && workspace && D > 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
               "smx_layernorm_bwd: bad arguments");
   if (N == 0) return SMX_OK;
   if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM);
   return ln_bwd_impl<float>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM);
 }
 
+extern "C" int smx_layernorm_bwd_blocks(int N) { return ln_bwd_blocks(N); }
 extern "C" size_t smx_layernorm_bwd_workspace(int N, int D) { return (size_t)ln_bwd_blocks(N) * 2 * D * sizeof(float); }
 
 static const int ACT_BWD_RS = 32;

@@ -15,6 +15,7 @@ Reference behaviour mirrored here (paths relative to the reference root):
 """
 import weakref
 
+import ctypes
 import os
 
 import torch
@@ -71,6 +72,74 @@ def mask_u8(mask, B, T, device):
     return m.reshape(B * T).contiguous().view(torch.uint8)
 
 
+# ----------------------------------------------------------------------------------------------------
+# Deferred parameter-gradient reductions: wgrad slabs, bias partials and LayerNorm dgamma/dbeta partial rows stay in
+# persistent per-parameter workspaces and ONE smx_reduce_jobs launch per block backward (= per encoder layer) folds
+# them into the gradients - instead of ~300 tiny latency-bound launches per step.  The job tables are cached on the
+# device (workspace and gradient addresses are stable), so steady-state steps - and hipGraph capture - copy nothing.
+# ----------------------------------------------------------------------------------------------------
+class _Deferred:
+    enabled = os.environ.get("SMX_DEFER_REDUCE", "1") != "0"
+    jobs = []        # (src_ptr, dst_ptr, src_stride, ldd, nsrc, rows, cols, alpha)
+    pending = set()  # workspace keys written since the last flush
+    ws = {}          # key -> persistent uint8 workspace
+    cache = {}       # tuple(jobs) -> (jobs_dev, starts_dev, njobs, total_blocks)
+
+
+def deferred_ws(key, nbytes, device):
+    """Persistent workspace of one producer call site (keyed by the gradient buffer it feeds)."""
+    if key in _Deferred.pending:
+        flush_deferred()                       # the same parameter twice inside one block: reduce the first use now
+    t = _Deferred.ws.get(key)
+    if t is None or t.numel() < nbytes or t.device != device:
+        t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _Deferred.ws[key] = t
+    _Deferred.pending.add(key)
+    return t
+
+
+def defer(src_ptr, dst, src_stride, nsrc, rows, cols, alpha=1.0):
+    """dst (a (rows, cols) fp32 view or a flat (cols,) one) += alpha * sum_s src[s*src_stride + i*cols + j]."""
+    ldd = dst.stride(0) if dst.dim() == 2 else cols
+    _Deferred.jobs.append((src_ptr, dst.data_ptr(), src_stride, ldd, nsrc, rows, cols, alpha))
+
+
+def flush_deferred():
+    if not _Deferred.jobs:
+        _Deferred.pending.clear()
+        return
+    key = tuple(_Deferred.jobs)
+    ent = _Deferred.cache.get(key)
+    if ent is None:
+        arr = (L.ReduceJob * len(key))()
+        starts = [0]
+        for i, (src, dstp, st, ldd, nsrc, rows, cols, alpha) in enumerate(key):
+            vec = int(cols % 4 == 0 and ldd % 4 == 0 and st % 4 == 0 and src % 16 == 0 and dstp % 16 == 0)
+            arr[i] = L.ReduceJob(src, dstp, st, ldd, nsrc, rows, cols, alpha, vec, 0)
+            starts.append(starts[-1] + L.lib().smx_reduce_job_blocks(ctypes.byref(arr[i])))
+        dev = next(iter(_Deferred.ws.values())).device
+        jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        starts_dev = torch.tensor(starts, dtype=torch.int32).to(dev)
+        ent = (jobs_dev, starts_dev, len(key), starts[-1])
+        _Deferred.cache[key] = ent
+    ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
+    _Deferred.jobs = []
+    _Deferred.pending.clear()
+
+
+def _wgrad(dz, x, gW, N, M, K, dbias):
+    """gW (M, K) += dz^T x (and dbias += column sums of dz): immediately, or as slabs + a deferred reduction job."""
+    if not _Deferred.enabled or K % 4 != 0:
+        ops.wgrad(dz, x, gW, N, M, K, dbias=dbias)
+        return
+    key = gW.data_ptr()
+    ws = deferred_ws(key, L.lib().smx_linear_wgrad_workspace(N, M, K, 1), dz.device)
+    nslabs, stride, boff = ops.wgrad_partial(dz, x, N, M, K, ws, want_bias=dbias is not None)
+    defer(ws.data_ptr(), gW, stride, nslabs, M, K)
+    if dbias is not None:
+        defer(ws.data_ptr() + 4 * boff, dbias, M, nslabs, 1, M)
+
+
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, run, done, *params):
@@ -82,6 +151,7 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         dx = ctx.bwd(dy)
+        flush_deferred()        # the block's parameter gradients are final before its bucket is all-reduced
         if ctx.done is not None:
             ctx.done()          # e.g. launch this block's gradient-bucket all-reduce (trainer.FlatAdamW)
         return (dx, None, None) + (None,) * ctx.n
@@ -143,7 +213,7 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
         dz = torch.empty((N, M), dtype=dy.dtype, device=dy.device)
         ops.act_mask_bwd(dy, z, mask, act, alpha, dz, gb_pass, dgroup, gdiv, drop)
     if gW is not None:
-        ops.wgrad(dz, x, gW, N, M, K, dbias=gb if wb else None)
+        _wgrad(dz, x, gW, N, M, K, gb if wb else None)
     dx = None
     if need_dx:
         dx = dx_out if dx_out is not None else torch.empty((N, K), dtype=dy.dtype, device=dy.device)
@@ -404,7 +474,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 wb = gbm is not None and gWm is not None and (lw + sdim) % 4 == 0 and _WGRAD_BIAS
                 ops.act_mask_bwd(dy, zm, None, act, 1.0, dzm, None if wb else gbm)
                 if gWm is not None:
-                    ops.wgrad(dzm, cat, gWm, N, s_out, lw + sdim, dbias=gbm if wb else None)
+                    _wgrad(dzm, cat, gWm, N, s_out, lw + sdim, gbm if wb else None)
                 if fuse_local:
                     e = ops.epilogue(act=up_local[1], act_grad_z=up_local[0], row_mask=up_local[2], drop=(p_drop, s1),
                                      colsum=up_local[5]) if up_local[0] is not None else \
@@ -469,6 +539,14 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None):
     def bwd(dy, res=None):
         gw = gacc(wp).view(-1) if wp is not None else gacc(w)
         gb = gacc(bp).view(-1) if bp is not None else gacc(b)
+        if _Deferred.enabled and gw is not None and gb is not None:
+            N, D = x.shape
+            ws = deferred_ws(gw.data_ptr(), L.lib().smx_layernorm_bwd_workspace(N, D), x.device)
+            dx = ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, None, None, res, act, ws=ws)
+            nb = L.lib().smx_layernorm_bwd_blocks(N)
+            defer(ws.data_ptr(), gw, 2 * D, nb, 1, D)
+            defer(ws.data_ptr() + 4 * D, gb, 2 * D, nb, 1, D)
+            return dx
         return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act)
     return y, (bwd if need_bwd else None)
 

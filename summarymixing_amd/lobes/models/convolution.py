@@ -93,6 +93,7 @@ class ConvolutionFrontEnd(nn.Module):
                     dcol, _ = F.linear_bwd(dy, col, wgc, None, L.ACT_NONE, None, 1.0, gw, F.gacc(blk.conv.bias),
                                            need_dx=not first)
                     g = F.gacc(blk.conv.weight)                       # fold the GEMM-layout gradient back (9*Cin*Cout values)
+                    F.flush_deferred()                                # gw is a temporary: its slab reduction must have run
                     if g is not None:
                         g.add_(gw[:, :9 * C].view(blk.c_out, 3, 3, C).permute(0, 3, 1, 2))
                     if first:

@@ -113,6 +113,22 @@ def wgrad(dz, x, gW, rows, M, K, batch=1, sz=0, sx=0, sw=0, lddz=None, ldx=None,
                                      batch, alpha, _p(ws), _stream()), "smx_linear_wgrad")
 
 
+def wgrad_partial(dz, x, rows, M, K, ws, batch=1, sz=0, sx=0, lddz=None, ldx=None, want_bias=False):
+    """Only the split-K slabs of a wgrad (and the bias partials behind them) into the caller-owned workspace `ws`.
+    -> (nslabs, slab_stride, bias_offset) in floats; reduce later with reduce_jobs."""
+    pz, lz = _mat(dz)
+    px, lx = _mat(x)
+    n, st, bo = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    L.check(L.lib().smx_linear_wgrad_partial(dt(dz), pz, lddz or lz, sz, px, ldx or lx, sx, rows, M, K, batch,
+                                             1 if want_bias else 0, _p(ws), ctypes.byref(n), ctypes.byref(st),
+                                             ctypes.byref(bo), _stream()), "smx_linear_wgrad_partial")
+    return n.value, st.value, bo.value
+
+
+def reduce_jobs(jobs_dev, starts_dev, njobs, total_blocks):
+    L.check(L.lib().smx_reduce_jobs(_p(jobs_dev), _p(starts_dev), njobs, total_blocks, _stream()), "smx_reduce_jobs")
+
+
 def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, gdiv=0, drop=None):
     N, M = dy.shape
     pdy, lddy = _mat(dy)
@@ -180,13 +196,15 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE):
     return y, stats
 
 
-def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE):
+def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE, ws=None):
+    """ws: caller-owned workspace; with dgamma = dbeta = None the partial rows stay in it for a deferred reduce_jobs."""
     N, D = x.shape
     dx = torch.empty((N, D), dtype=x.dtype, device=x.device)
     pdy, lddy = _mat(dy)
     px, ldx = _mat(x)
     pr, ldr = (_mat(res) if res is not None else (None, 0))
-    ws = _workspace(L.lib().smx_layernorm_bwd_workspace(N, D), x.device, slot=2)
+    if ws is None:
+        ws = _workspace(L.lib().smx_layernorm_bwd_workspace(N, D), x.device, slot=2)
     L.check(L.lib().smx_layernorm_bwd(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), D, _p(dgamma),
                                       _p(dbeta), N, D, _p(ws), _stream()), "smx_layernorm_bwd")
     return dx

@@ -91,6 +91,7 @@ class FlatAdamW:
             self._dev_step = None
 
     def step(self, reduce_all=False):
+        F.flush_deferred()          # (no-op unless a backward ran outside functional.block)
         if self._collective:
             if reduce_all:
                 self.reduce_bucket_async(0, self.total)

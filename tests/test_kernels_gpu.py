@@ -283,3 +283,26 @@ def test_adamw_matches_torch():
     cf = torch.zeros(1, device="cuda")
     ops.clip_factor(ss, 5.0, 1.0, cf)
     assert abs(cf.item() - min(1.0, 5.0 / (math.sqrt(ss.item()) + 1e-6))) < 1e-6
+
+
+def test_reduce_jobs_batched():
+    """smx_reduce_jobs: several fixed-order reductions (vector / scalar paths, strided destinations, few / many sources)
+    in one launch, with a cached job table."""
+    import ctypes
+    L, ops = _ops()
+    from summarymixing_amd import functional as F
+    torch.manual_seed(9)
+    cases = [(40, 64, 128, 128), (3, 5, 31, 40), (130, 1, 256, 256), (17, 8, 12, 20)]      # nsrc, rows, cols, ldd
+    srcs, dsts, refs = [], [], []
+    F._Deferred.jobs, F._Deferred.pending = [], set()
+    for nsrc, rows, cols, ldd in cases:
+        src = torch.randn(nsrc, rows, cols, device="cuda")
+        dst = torch.randn(rows, ldd, device="cuda")
+        refs.append(dst[:, :cols].double() + 0.5 * src.double().sum(0))
+        F._Deferred.ws[len(srcs)] = src.view(-1).view(torch.uint8)          # (flush looks up the device there)
+        F.defer(src.data_ptr(), dst[:, :cols], rows * cols, nsrc, rows, cols, alpha=0.5)
+        srcs.append(src); dsts.append(dst)
+    F.flush_deferred()
+    for (nsrc, rows, cols, ldd), dst, ref in zip(cases, dsts, refs):
+        assert rel_err(dst[:, :cols], ref) <= 1e-6
+    assert not F._Deferred.jobs
