@@ -157,6 +157,17 @@ int smx_chunk_mean_fwd(int dtype, const void* S, int64_t lds, void* out, int64_t
 int smx_chunk_mean_bwd(int dtype, const void* dOut, int64_t ldo, void* dS, int64_t lds, int B, int T, int D,
                        int chunk, int left, void* workspace, void* stream);
 
+/* SummaryMixing-expdecay summary in O(T) (the reference materialises the (T,T) Laplace matrix gamma^|i-j|,
+ * summary_mixing.py:316-365, and computes (M s) / rowsum(M), :233-235 - O(T^2)):
+ *   fwd: out[b,t,:] = sum_j decay^|t-j| S[b,j,:] / sum_j decay^|t-j|   (j over ALL T frames: padding is ignored in the
+ *        denominator exactly like the reference; padded frames of S are zero because the projection is masked);
+ *   bwd: dS = M (dOut / rowsum(M))  (M is symmetric).  Two-sided exponential recurrences, chunked scan over T.
+ * Only for sum_mask == None; with a DynChunk mask the reference's dense path is kept. */
+size_t smx_expdecay_mean_workspace(int B, int T, int D);
+int smx_expdecay_mean_fwd(int dtype, const void* S, int64_t lds, void* out, int64_t ldo, int B, int T, int D, float decay,
+                          void* workspace, void* stream);
+int smx_expdecay_mean_bwd(int dtype, const void* dOut, int64_t ldo, void* dS, int64_t lds, int B, int T, int D, float decay,
+                          void* workspace, void* stream);
 /* (smx_layernorm_bwd with dgamma == dbeta == NULL leaves its partial rows [smx_layernorm_bwd_blocks(N)][2][D] in the
  *  workspace for smx_reduce_jobs: two jobs, src = ws (dgamma) and ws + D (dbeta), src_stride 2*D, rows 1, cols D.) */
 int smx_layernorm_bwd_blocks(int N);

@@ -65,6 +65,9 @@ SIGNATURES = {
     "smx_chunk_mean_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_chunk_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_chunk_mean_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "smx_expdecay_mean_workspace": (c_sz, [c_i, c_i, c_i]),
+    "smx_expdecay_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp]),
+    "smx_expdecay_mean_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp]),
     "smx_layernorm_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "smx_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
     "smx_layernorm_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,

@@ -247,6 +247,138 @@ __global__ __launch_bounds__(256) void chunk_window_kernel(const float* csum, T*
 }
 
 // =================================================================================================
+// SummaryMixing-expdecay in O(T).  The reference builds the (T,T) Laplace matrix
+// M_ij = gamma^|i-j| (summary_mixing.py:316-365) and evaluates (M s) / rowsum(M) (:233-235): O(T^2).  M s is a two-sided
+// exponential filter:  f_t = s_t + gamma f_{t-1},  g_t = s_t + gamma g_{t+1},  (M s)_t = f_t + g_t - s_t,  and
+// rowsum(M)_t = (2 - gamma^(t+1) - gamma^(T-t)) / (1 - gamma) - 1 in closed form (the denominator ignores padding like
+// the reference's).  Chunked scan over T: (1) per 16-row chunk the local end values of both recurrences, (2) carries
+// across the chunks (a short sequential loop per column), (3) per chunk both local scans out of registers + carries.
+// mode 0 (forward):  out = (M s) / rowsum(M);   mode 1 (backward, M symmetric): out = M (s / rowsum(M)).
+// =================================================================================================
+constexpr int ED_CH = 16;                                // rows per chunk
+
+__device__ __forceinline__ float ed_inv_den(int t, int T_, float lng, float inv1mg) {
+  const float den = (2.f - expf((float)(t + 1) * lng) - expf((float)(T_ - t) * lng)) * inv1mg - 1.f;
+  return 1.f / den;
+}
+
+// grid (DC, ceil(NC/4), B); a wave owns one chunk; lane owns 4 columns.  ws[b][c][0][D] = F_c, ws[b][c][1][D] = G_c
+template <typename T>
+__global__ __launch_bounds__(256) void expdecay_chunk_kernel(const T* __restrict__ X, long ldx, float* __restrict__ ws,
+                                                             int T_, int D, int NC, float gamma, int mode) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
+  const int c = blockIdx.y * 4 + w, col = (blockIdx.x * 64 + lane) * 4;
+  if (c >= NC || col >= D) return;
+  const float lng = logf(gamma), inv1mg = 1.f / (1.f - gamma);
+  const int t0 = c * ED_CH;
+  float F[4] = {0.f, 0.f, 0.f, 0.f}, G[4] = {0.f, 0.f, 0.f, 0.f};
+  float v[ED_CH][4];
+#pragma unroll
+  for (int i = 0; i < ED_CH; ++i) {
+    const int t = t0 + i;
+    if (t < T_) load4<T>(X + ((long)b * T_ + t) * ldx + col, v[i]);
+    else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+  }
+  float pw = 1.f;
+#pragma unroll
+  for (int i = 0; i < ED_CH; ++i) {
+    const int t = t0 + i;
+    const float sc = (mode == 1 && t < T_) ? ed_inv_den(t, T_, lng, inv1mg) : 1.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float x = v[i][q] * sc;
+      F[q] = x + gamma * F[q];                           // = sum_t gamma^(last - t) x_t  (rows past T count as zeros)
+      G[q] += pw * x;                                    // = sum_t gamma^(t - first) x_t
+    }
+    pw *= gamma;
+  }
+  float* o = ws + (((long)b * NC + c) * 2) * D + col;
+  *reinterpret_cast<float4*>(o) = make_float4(F[0], F[1], F[2], F[3]);
+  *reinterpret_cast<float4*>(o + D) = make_float4(G[0], G[1], G[2], G[3]);
+}
+
+// in place: ws[b][c][0] <- f entering chunk c from the left, ws[b][c][1] <- g entering chunk c from the right.
+// One thread per (b, column); the chunk values are independent of the recurrence, so 8 are fetched ahead.
+__global__ __launch_bounds__(256) void expdecay_carry_kernel(float* __restrict__ ws, int D, int NC, int B, float gamma) {
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  if (idx >= (long)B * D) return;
+  const int b = (int)(idx / D), col = (int)(idx % D);
+  float* base = ws + (long)b * NC * 2 * D + col;
+  const float gch = expf((float)ED_CH * logf(gamma));    // every chunk is ED_CH rows long (the tail is zero padded)
+  // both directions advance in the same loop (two independent chains), 16 chunk values of each fetched ahead
+  float cf = 0.f, cg = 0.f;
+  for (int c0 = 0; c0 < NC; c0 += 16) {
+    float f[16], g[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int c = c0 + u;
+      f[u] = c < NC ? base[(long)c * 2 * D] : 0.f;
+      g[u] = c < NC ? base[(long)(NC - 1 - c) * 2 * D + D] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int c = c0 + u;
+      if (c < NC) {
+        base[(long)c * 2 * D] = cf;
+        cf = f[u] + gch * cf;
+        base[(long)(NC - 1 - c) * 2 * D + D] = cg;
+        cg = g[u] + gch * cg;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void expdecay_apply_kernel(const T* __restrict__ X, long ldx, const float* __restrict__ ws,
+                                                             T* __restrict__ Y, long ldy, int T_, int D, int NC, float gamma,
+                                                             int mode) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
+  const int c = blockIdx.y * 4 + w, col = (blockIdx.x * 64 + lane) * 4;
+  if (c >= NC || col >= D) return;
+  const float lng = logf(gamma), inv1mg = 1.f / (1.f - gamma);
+  const int t0 = c * ED_CH;
+  float v[ED_CH][4], a[ED_CH][4];
+#pragma unroll
+  for (int i = 0; i < ED_CH; ++i) {
+    const int t = t0 + i;
+    if (t < T_) load4<T>(X + ((long)b * T_ + t) * ldx + col, v[i]);
+    else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+  }
+  const float* cw = ws + (((long)b * NC + c) * 2) * D + col;
+  const float4 cf4 = *reinterpret_cast<const float4*>(cw), cg4 = *reinterpret_cast<const float4*>(cw + D);
+  float f[4] = {cf4.x, cf4.y, cf4.z, cf4.w}, g[4] = {cg4.x, cg4.y, cg4.z, cg4.w};
+#pragma unroll
+  for (int i = 0; i < ED_CH; ++i) {                      // ascending: a_t = gamma f_{t-1}  (= f_t - x_t)
+    const int t = t0 + i;
+    const float sc = (mode == 1 && t < T_) ? ed_inv_den(t, T_, lng, inv1mg) : 1.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[i][q] *= sc;
+      a[i][q] = gamma * f[q];
+      f[q] = v[i][q] + a[i][q];
+    }
+  }
+#pragma unroll
+  for (int i = ED_CH - 1; i >= 0; --i) {                 // descending: g_t = x_t + gamma g_{t+1};  out = a_t + g_t
+    const int t = t0 + i;
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      g[q] = v[i][q] + gamma * g[q];
+      o[q] = a[i][q] + g[q];
+    }
+    if (t < T_) {
+      if (mode == 0) {
+        const float sc = ed_inv_den(t, T_, lng, inv1mg);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] *= sc;
+      }
+      store4<T>(Y + ((long)b * T_ + t) * ldy + col, o);
+    }
+  }
+}
+
+// =================================================================================================
 // LayerNorm.  One wave per row, 4 rows per block; lane owns 4-element vectors at columns lane*4 + 256*i.
 // =================================================================================================
 template <typename T, bool VEC>
@@ -935,6 +1067,48 @@ extern "C" int smx_chunk_mean_bwd(int dtype, const void* dOut, int64_t ldo, void
   SMX_REQUIRE(dOut && dS && workspace && chunk > 0, "smx_chunk_mean_bwd: bad arguments");
   if (dtype == SMX_BF16) return chunk_mean_impl<bf16_t>(dOut, ldo, dS, lds, B, T, D, chunk, left, 1, workspace, STREAM);
   return chunk_mean_impl<float>(dOut, ldo, dS, lds, B, T, D, chunk, left, 1, workspace, STREAM);
+}
+
+extern "C" size_t smx_expdecay_mean_workspace(int B, int T, int D) {
+  return (size_t)B * ((T + ED_CH - 1) / ED_CH) * 2 * D * sizeof(float);
+}
+
+template <typename T>
+static int expdecay_impl(const void* X, int64_t ldx, void* Y, int64_t ldy, int B, int T_, int D, float gamma, int mode,
+                         void* ws, hipStream_t s) {
+  const int NC = (T_ + ED_CH - 1) / ED_CH;
+  dim3 grid((D + 255) / 256, (NC + 3) / 4, B);
+  float* w = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL((expdecay_chunk_kernel<T>), grid, dim3(256), 0, s, (const T*)X, ldx, w, T_, D, NC, gamma, mode);
+  hipLaunchKernelGGL(expdecay_carry_kernel, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, s, w, D, NC, B, gamma);
+  hipLaunchKernelGGL((expdecay_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)X, ldx, w, (T*)Y, ldy, T_, D, NC, gamma, mode);
+  return check_launch("smx_expdecay_mean");
+}
+
+static int expdecay_check(const void* X, int64_t ldx, const void* Y, int64_t ldy, int D, float gamma, const void* ws, size_t es) {
+  SMX_REQUIRE(X && Y && ws, "smx_expdecay_mean: null pointer");
+  SMX_REQUIRE(gamma > 0.f && gamma < 1.f, "smx_expdecay_mean: 0 < decay < 1 (got %f)", (double)gamma);
+  SMX_REQUIRE(D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(X) % (4 * es)) == 0 &&
+                  (reinterpret_cast<uintptr_t>(Y) % (4 * es)) == 0 && aligned16(ws),
+              "smx_expdecay_mean: needs D, leading dimensions multiples of 4 and aligned pointers");
+  return SMX_OK;
+}
+
+extern "C" int smx_expdecay_mean_fwd(int dtype, const void* S, int64_t lds, void* out, int64_t ldo, int B, int T, int D,
+                                     float decay, void* workspace, void* stream) {
+  int rc = expdecay_check(S, lds, out, ldo, D, decay, workspace, dtype == SMX_BF16 ? 2 : 4);
+  if (rc != SMX_OK) return rc;
+  if (B <= 0 || T <= 0 || D <= 0) return SMX_OK;
+  if (dtype == SMX_BF16) return expdecay_impl<bf16_t>(S, lds, out, ldo, B, T, D, decay, 0, workspace, STREAM);
+  return expdecay_impl<float>(S, lds, out, ldo, B, T, D, decay, 0, workspace, STREAM);
+}
+extern "C" int smx_expdecay_mean_bwd(int dtype, const void* dOut, int64_t ldo, void* dS, int64_t lds, int B, int T, int D,
+                                     float decay, void* workspace, void* stream) {
+  int rc = expdecay_check(dOut, ldo, dS, lds, D, decay, workspace, dtype == SMX_BF16 ? 2 : 4);
+  if (rc != SMX_OK) return rc;
+  if (B <= 0 || T <= 0 || D <= 0) return SMX_OK;
+  if (dtype == SMX_BF16) return expdecay_impl<bf16_t>(dOut, ldo, dS, lds, B, T, D, decay, 1, workspace, STREAM);
+  return expdecay_impl<float>(dOut, ldo, dS, lds, B, T, D, decay, 1, workspace, STREAM);
 }
 
 extern "C" int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const float* gamma, const float* beta, void* Y,

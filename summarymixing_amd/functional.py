@@ -355,7 +355,18 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         pool_kind = "mean"
         Wn = None
         sm = sum_mask
-        if mode == "SummaryMixing-expdecay":
+        decay = None
+        def _sdim():
+            ly = P["summary_proj"][-1]
+            return ly["W"].shape[0] if ly["kind"] == "linear" else ly["W"].shape[0] * ly["W"].shape[2]
+        if mode == "SummaryMixing-expdecay" and sm is None and _sdim() % 8 == 0:
+            # no sum_mask: (M s)/rowsum(M) with M_ij = decay^|i-j| is a two-sided exponential filter -> O(T) kernels
+            # (smx_expdecay_mean_*); the frozen decay constant (summary_mixing.py:154-157) is read once
+            if "_decay" not in cfg:
+                cfg["_decay"] = float(P["decay_constant"].detach().float().cpu())
+            decay = cfg["_decay"]
+            pool_kind = "expdecay"
+        elif mode == "SummaryMixing-expdecay":
             # Laplace weights (summary_mixing.py:316-365): M_ij = decay^|i-j| * binary_mask
             idx = torch.arange(T, device=dev)
             lap = torch.exp((idx[None, :] - idx[:, None]).abs().float() * torch.log(P["decay_constant"].detach().float()))
@@ -395,6 +406,9 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         elif pool_kind == "chunk":
             sbar = torch.empty((N, sdim), dtype=dtype, device=dev)
             ops.chunk_mean(s, sbar, B, T, sm.chunk_size, sm.left_context)
+        elif pool_kind == "expdecay":
+            sbar = torch.empty((N, sdim), dtype=dtype, device=dev)
+            ops.expdecay_mean(s, sbar, B, T, decay)
         else:
             sbar = _dense_pool_fwd(s, B, T, Wn)
 
@@ -489,6 +503,8 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                     ops.bcast_rows(dsbar, inv, ds_out, B, T)
                 elif pool_kind == "chunk":
                     ops.chunk_mean(dsd, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
+                elif pool_kind == "expdecay":
+                    ops.expdecay_mean(dsd, ds_out, B, T, decay, reverse=True)
                 else:
                     _dense_pool_bwd(dsd, B, T, Wn, ds_out)
             elif pool_kind == "mean":
@@ -510,6 +526,8 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 ops.gemm(L.GEMM_NN, dzm, Ws, dsb, N, sdim, s_out, None)
                 if pool_kind == "chunk":
                     ops.chunk_mean(dsb, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
+                elif pool_kind == "expdecay":
+                    ops.expdecay_mean(dsb, ds_out, B, T, decay, reverse=True)
                 else:
                     _dense_pool_bwd(dsb, B, T, Wn, ds_out)
             if mode == "SummaryMixing-fast":

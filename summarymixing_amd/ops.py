@@ -186,6 +186,17 @@ def chunk_mean(s, out, B, T, chunk, left, reverse=False):
     return out
 
 
+def expdecay_mean(s, out, B, T, decay, reverse=False):
+    """out = (M s)/rowsum(M) with M_ij = decay^|i-j| (reverse: the transposed operator M (s/rowsum(M))); O(T)."""
+    D = s.shape[1]
+    ps, lds = _mat(s)
+    po, ldo = _mat(out)
+    ws = _workspace(L.lib().smx_expdecay_mean_workspace(B, T, D), s.device, slot=5)
+    fn = L.lib().smx_expdecay_mean_bwd if reverse else L.lib().smx_expdecay_mean_fwd
+    L.check(fn(dt(s), ps, lds, po, ldo, B, T, D, float(decay), _p(ws), _stream()), "smx_expdecay_mean")
+    return out
+
+
 def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE):
     N, D = x.shape
     y = torch.empty((N, D), dtype=x.dtype, device=x.device)

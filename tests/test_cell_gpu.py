@@ -95,3 +95,37 @@ def test_cell_fast_vs_oracle_random_shapes(dtype):
     ref = O.summary_mixing(x.double(), sd, "", "SummaryMixing-fast", "swish", l, None, pad)
     y = m.cuda()(x.cuda().to(dtype), src_padding_mask=pad.cuda())
     assert rel_err(y, ref) <= TOL[dtype][0]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_expdecay_cell_uses_the_linear_time_kernels(dtype, monkeypatch):
+    """SummaryMixing-expdecay without sum_mask runs on the O(T) recurrence kernels and still matches
+    the oracle's dense (T,T) Laplace evaluation, forward and backward, at a ragged mid-size shape."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd import ops
+    from summarymixing_amd.nnet.summary_mixing import SummaryMixing
+    torch.manual_seed(4)
+    B, T, d = 3, 301, 64
+    m = SummaryMixing(d, 1, [d], d, [d], d, activation="gelu", global_dropout=0.0, mode="SummaryMixing-expdecay")
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                p.normal_(0, 0.1)
+    sd = {k: v.double().clone().requires_grad_(v.requires_grad) for k, v in m.state_dict().items()}
+    for k, p in m.named_parameters():
+        sd[k].requires_grad_(p.requires_grad)
+    x = torch.randn(B, T, d)
+    pad = torch.arange(T)[None] < torch.tensor([T, 120, 250])[:, None]
+    r = torch.randn(B, T, d)
+    xo = x.double().requires_grad_(True)
+    ref = O.summary_mixing(xo, sd, "", "SummaryMixing-expdecay", "gelu", d, None, pad)
+    (ref * r.double()).sum().backward()
+    calls = []
+    real = ops.expdecay_mean
+    monkeypatch.setattr(ops, "expdecay_mean", lambda *a, **k: (calls.append(k.get("reverse", False)), real(*a, **k))[1])
+    xg = x.cuda().to(dtype).requires_grad_(True)
+    y = m.cuda()(xg, src_padding_mask=pad.cuda())
+    (y.float() * r.cuda()).sum().backward()
+    assert calls == [False, True]                      # one forward filter, one transposed filter in the backward
+    assert rel_err(y, ref) <= TOL[dtype][0]
+    assert rel_err(xg.grad, xo.grad) <= TOL[dtype][1]

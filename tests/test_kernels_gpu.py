@@ -306,3 +306,23 @@ def test_reduce_jobs_batched():
     for (nsrc, rows, cols, ldd), dst, ref in zip(cases, dsts, refs):
         assert rel_err(dst[:, :cols], ref) <= 1e-6
     assert not F._Deferred.jobs
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("B,T,D", [(2, 50, 64), (3, 333, 256), (1, 2000, 32), (2, 16, 8)])
+def test_expdecay_mean_matches_dense_laplace(B, T, D, dtype, tol):
+    """O(T) two-sided exponential filter == the reference's dense (T,T) Laplace path (summary_mixing.py:316-365,233-235),
+    forward and transposed (backward) operator."""
+    L, ops = _ops()
+    torch.manual_seed(T + D)
+    decay = 0.995 if T > 100 else 0.9
+    s = torch.randn(B * T, D, device="cuda").to(dtype)
+    idx = torch.arange(T, device="cuda")
+    M = torch.pow(torch.tensor(decay, dtype=torch.float64, device="cuda"), (idx[None] - idx[:, None]).abs().double())
+    Wn = M / M.sum(1, keepdim=True)
+    s3 = s.double().view(B, T, D)
+    out = torch.empty_like(s)
+    ops.expdecay_mean(s, out, B, T, decay)
+    assert rel_err(out.view(B, T, D), torch.einsum("ij,bjd->bid", Wn, s3)) <= tol
+    ops.expdecay_mean(s, out, B, T, decay, reverse=True)
+    assert rel_err(out.view(B, T, D), torch.einsum("ji,bjd->bid", Wn, s3)) <= tol
