@@ -91,6 +91,11 @@ def deferred_ws(key, nbytes, device):
     if key in _Deferred.pending:
         flush_deferred()                       # the same parameter twice inside one block: reduce the first use now
     t = _Deferred.ws.get(key)
+    if t is None and len(_Deferred.ws) >= 2048:           # gradient buffers keep being re-allocated at new addresses:
+        flush_deferred()                                   # drop the stale workspaces (and the tables that name them)
+        _Deferred.ws.clear()
+        _Deferred.cache.clear()
+        _Deferred.pending.add(key)
     if t is None or t.numel() < nbytes or t.device != device:
         t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         _Deferred.ws[key] = t
