@@ -146,6 +146,12 @@ int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const uint8_t* ma
 int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B, int T,
                         int D, float drop_p, uint64_t drop_seed, void* stream);
 
+/* Same broadcast with the activation / mask backward of the projection that produced the summary columns fused in:
+ *   dS[b,t,:] = g[b,:] * inv_count[b] * act'(Z[b,t,:]) * row_mask[b,t]      (Z and/or row_mask given)
+ * i.e. the dZ of `s = act(x W_s^T + b) * mask` (summary_mixing.py:210,257) without writing and re-reading the broadcast. */
+int smx_masked_mean_bwd_act(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, const void* Z,
+                            int64_t ldz, const uint8_t* row_mask, int act, int B, int T, int D, void* stream);
+
 /* DynChunk summary (sum_mask path, summary_mixing.py:224-235, :269-280) in O(T): frame t of chunk
  * c = t / chunk sees frames [max(0,(c-left)*chunk), min(T,(c+1)*chunk)) (left < 0: unlimited);
  * out[b,t,:] = sum over that window of S[b,.,:] / window length  (the denominator ignores padding, as the

@@ -62,6 +62,7 @@ SIGNATURES = {
     "smx_masked_mean_workspace": (c_sz, [c_i, c_i, c_i]),
     "smx_masked_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_masked_mean_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, ctypes.c_uint64, c_vp]),
+    "smx_masked_mean_bwd_act": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "smx_chunk_mean_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_chunk_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_chunk_mean_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),

@@ -147,10 +147,14 @@ static void mm_plan(int B, int T, int D, int nvec, int& DC, int& TS, int& TR) {
 }
 
 // dS[b,t,:] = g[b,:] * inv_count[b]   (broadcast over t).  grid (DC, ceil(T/RPB), B)
+// Optional fusions: the dropout of the merge input (forward `repeat`), or - in the backward - the activation / mask
+// backward of the projection that produced the summary columns: dS = g * inv * act'(Z[b,t,:]) * mask[b,t], so that the
+// broadcast gradient is never written and re-read by a separate act_mask_bwd pass.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const float* inv_count, T* dS, long ldds,
                                                          int T_, int D, int RPB, uint32_t dthresh, float dscale,
-                                                         uint64_t dseed_, const uint64_t* ep) {
+                                                         uint64_t dseed_, const uint64_t* ep, const T* __restrict__ Z, long ldz,
+                                                         const uint8_t* __restrict__ mask, int act) {
   const uint64_t dseed = dthresh ? epoch_seed(dseed_, ep) : 0;
   constexpr int N = VT<T>::N;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
@@ -162,7 +166,26 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const f
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = (i < nvalid) ? g[(long)b * D + col + i] * sc : 0.f;
   const int t0 = blockIdx.y * RPB, t1 = min(T_, t0 + RPB);
-  if (dthresh == 0) {
+  if (Z || mask) {                                       // backward through act(.) * mask of the producing projection
+    dispatch_act(Z ? act : SMX_ACT_NONE, [&](auto act_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+      for (int t = t0 + w; t < t1; t += 4) {
+        const long n = (long)b * T_ + t;
+        const float mk = mask ? (mask[n] ? 1.f : 0.f) : 1.f;
+        float o[N];
+        if (ACT != SMX_ACT_NONE) {
+          float z[N];
+          loadv<T, VEC>(Z + n * ldz + col, nvalid, z);
+#pragma unroll
+          for (int i = 0; i < N; ++i) o[i] = v[i] * mk * act_grad_c<ACT>(z[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < N; ++i) o[i] = v[i] * mk;
+        }
+        storev<T, VEC>(dS + n * ldds + col, nvalid, o);
+      }
+    });
+  } else if (dthresh == 0) {
     for (int t = t0 + w; t < t1; t += 4) storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, v);
   } else {                                               // fused inverted dropout, mask = f(seed, row * D + col)
     for (int t = t0 + w; t < t1; t += 4) {
@@ -1016,24 +1039,40 @@ extern "C" int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const 
   return check_launch("smx_masked_mean_fwd");
 }
 
-extern "C" int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B,
-                                   int T, int D, float drop_p, uint64_t drop_seed, void* stream) {
-  SMX_REQUIRE(g && dS, "smx_masked_mean_bwd: null pointer");
-  SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_masked_mean_bwd: 0 <= drop_p < 1");
+static int bcast_impl(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B, int T, int D,
+                      float drop_p, uint64_t drop_seed, const void* Z, int64_t ldz, const uint8_t* mask, int act, void* stream,
+                      const char* what) {
   const uint32_t dthresh = (uint32_t)((double)drop_p * 4294967296.0);
   const float dscale = 1.f / (1.f - drop_p);
   const int nvec = dtype == SMX_BF16 ? 8 : 4;
   const int DC = (D + 64 * nvec - 1) / (64 * nvec), RPB = 64;
   dim3 grid(DC, (T + RPB - 1) / RPB, B);
-  const bool vec = vec_ok(dS, ldds, D, nvec, dtype == SMX_BF16 ? 2 : 4);
+  const size_t es = dtype == SMX_BF16 ? 2 : 4;
+  const bool vec = vec_ok(dS, ldds, D, nvec, es) && (Z == nullptr || vec_ok(Z, ldz, D, nvec, es));
   if (dtype == SMX_BF16) {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter);
-    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const bf16_t*)Z, ldz, mask, act);
+    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const bf16_t*)Z, ldz, mask, act);
   } else {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter);
-    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const float*)Z, ldz, mask, act);
+    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const float*)Z, ldz, mask, act);
   }
-  return check_launch("smx_masked_mean_bwd");
+  return check_launch(what);
+}
+
+extern "C" int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B,
+                                   int T, int D, float drop_p, uint64_t drop_seed, void* stream) {
+  SMX_REQUIRE(g && dS, "smx_masked_mean_bwd: null pointer");
+  SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_masked_mean_bwd: 0 <= drop_p < 1");
+  return bcast_impl(dtype, g, inv_count, dS, ldds, B, T, D, drop_p, drop_seed, nullptr, 0, nullptr, SMX_ACT_NONE, stream,
+                    "smx_masked_mean_bwd");
+}
+
+extern "C" int smx_masked_mean_bwd_act(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds,
+                                       const void* Z, int64_t ldz, const uint8_t* row_mask, int act, int B, int T, int D,
+                                       void* stream) {
+  SMX_REQUIRE(g && dS && (Z || row_mask), "smx_masked_mean_bwd_act: null pointer");
+  return bcast_impl(dtype, g, inv_count, dS, ldds, B, T, D, 0.f, 0, Z, ldz, row_mask, Z ? act : SMX_ACT_NONE, stream,
+                    "smx_masked_mean_bwd_act");
 }
 
 extern "C" size_t smx_chunk_mean_workspace(int B, int T, int D, int chunk) {

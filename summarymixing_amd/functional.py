@@ -486,6 +486,19 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 if z_lp is None and mk_lp is None:
                     up_local = None
                     fuse_local = False
+            # fast mode + per-utterance mean: the broadcast of the summary gradient applies the act/mask backward of the
+            # summary columns of global_proj itself (smx_masked_mean_bwd_act) - no separate act_mask_bwd pass over ds
+            sum_done = False
+
+            def bcast_ds(dsbar_):
+                nonlocal sum_done
+                if mode == "SummaryMixing-fast" and fuse_local:
+                    z_g, mk_g = sv_g[-1][1], sv_g[-1][2]
+                    if z_g is not None or mk_g is not None:
+                        ops.bcast_rows_act_bwd(dsbar_, inv, ds_out, B, T, z_g[:, l:] if z_g is not None else None, mk_g, act)
+                        sum_done = True
+                        return
+                ops.bcast_rows(dsbar_, inv, ds_out, B, T)
             if p_drop > 0.0:
                 # dgrad of the K = l + s merge as two GEMMs over the column halves of W: the dropout backward of each half
                 # (and the local half's act/mask backward) rides in the epilogue instead of separate passes
@@ -505,7 +518,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 ops.gemm(L.GEMM_NN, dzm, Wm[:, lw:], dsd, N, sdim, s_out, ops.epilogue(drop=(p_drop, s2)))
                 if pool_kind == "mean":
                     dsbar, _ = ops.masked_mean(dsd, None, B, T, scale=False)               # sum over time
-                    ops.bcast_rows(dsbar, inv, ds_out, B, T)
+                    bcast_ds(dsbar)
                 elif pool_kind == "chunk":
                     ops.chunk_mean(dsd, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
                 elif pool_kind == "expdecay":
@@ -521,7 +534,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                     ops.wgrad(dc0_t, sbar_t, gWm[:, lw:], B, s_out, sdim)
                 dsbar = torch.empty((B, sdim), dtype=torch.float32, device=dev)
                 ops.gemm(L.GEMM_NN, dc0_t, Ws, dsbar, B, sdim, s_out, ops.epilogue(out_mode=L.OUT_F32))
-                ops.bcast_rows(dsbar, inv, ds_out, B, T)
+                bcast_ds(dsbar)
             else:
                 _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
                                     True, None, dx_out=dlocal_out, up=up_local)
@@ -539,7 +552,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 if fuse_local:
                     # dg[:, :l] already holds dZ (and db[:l] is done): finish the summary columns in place
                     z_g, mk_g = sv_g[-1][1], sv_g[-1][2]
-                    if z_g is not None or mk_g is not None:
+                    if (z_g is not None or mk_g is not None) and not sum_done:
                         ops.act_mask_bwd(ds_out, z_g[:, l:] if z_g is not None else None, mk_g,
                                          act if z_g is not None else L.ACT_NONE, 1.0, ds_out, None)
                 dx = mlp_bwd(dg, P["global_proj"], act, sv_g, dtype, dz_ready=fuse_local)

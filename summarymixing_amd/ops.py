@@ -175,6 +175,15 @@ def bcast_rows(g, inv, ds, B, T, drop=None):
     return ds
 
 
+def bcast_rows_act_bwd(g, inv, ds, B, T, z, mask, act):
+    """ds[b*T+t, :] = g[b,:] * inv[b] * act'(z[b*T+t, :]) * mask[b*T+t]   (z and / or mask may be None)"""
+    pds, ldds = _mat(ds)
+    pz, ldz = (_mat(z) if z is not None else (None, 0))
+    L.check(L.lib().smx_masked_mean_bwd_act(dt(ds), _p(g), _p(inv), pds, ldds, pz, ldz, _p(mask), act, B, T, ds.shape[1],
+                                            _stream()), "smx_masked_mean_bwd_act")
+    return ds
+
+
 def chunk_mean(s, out, B, T, chunk, left, reverse=False):
     D = s.shape[1]
     ps, lds = _mat(s)
