@@ -246,6 +246,19 @@ int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* str
 int smx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, const float* gscale_dev, void* stream);
+/* ---- InputNormalization between the filterbank and the CNN front-end (recipe key `normalize`:
+ * speechbrain.processing.features.InputNormalization, …transducer.yaml:167-169; upstream-only arithmetic). ----
+ * smx_utt_meanstd: mean[b,f] and unbiased std[b,f] over the frames t < len[b] (std clamped below by eps; 0 / 1 when the
+ * respective normalisation is off).  smx_stats_combine: glob = (1-w)*glob + w*mean_b(cur) (w = 1 replaces: the first
+ * batch / norm_type "batch").  smx_colnorm: Y = (X - mean[b*stat_stride + f]) / std[...] over (B, T, F) rows b*T + t
+ * (stat_stride 0 = shared statistics: "global" / "batch"; F = per-utterance: "sentence"). */
+int smx_utt_meanstd(int dtype, const void* X, int64_t ldx, const int32_t* len, float* mean, float* std, int B, int T, int F,
+                    int mean_norm, int std_norm, float eps, void* stream);
+int smx_stats_combine(const float* cur_mean, const float* cur_std, int B, int F, float* glob_mean, float* glob_std, float weight,
+                      void* stream);
+int smx_colnorm(int dtype, const void* X, int64_t ldx, const float* mean, const float* std, int64_t stat_stride, void* Y,
+                int64_t ldy, int B, int T, int F, void* stream);
+
 /* ---- CTC head after the encoder (recipe keys `log_softmax`, `ctc_cost`:
  * …/LibriSpeech/ASR/transducer/hparams/conformer_summarymixing_transducer.yaml:297-298,331). ----
  * Y = log_softmax(X) over the last dim (N rows of V); bwd: dX = dY - exp(Y) * rowsum(dY).

@@ -406,3 +406,41 @@ def ctc_loss(log_probs, targets, input_lens, target_lens, blank_index, reduction
     if reduction == "batch":
         return loss / tgt_len.to(loss.dtype)
     return loss
+
+
+# ----------------------------------------------------------------------------------------------------
+# InputNormalization (speechbrain.processing.features.InputNormalization v1.0, recipe key `normalize`,
+# …transducer.yaml:167-169).  Upstream-only arithmetic: **parity unpinned**; restated from the SpeechBrain semantics:
+# per-utterance statistics over the valid frames (torch.mean / unbiased torch.std, std clamped at eps=1e-10), the
+# "global" mode keeps a running average of the per-batch averages while training and epoch < update_until_epoch.
+# ----------------------------------------------------------------------------------------------------
+class InputNormalizationState:
+    def __init__(self):
+        self.count, self.glob_mean, self.glob_std = 0, None, None
+
+
+def input_normalization(x, lengths, state, norm_type="global", mean_norm=True, std_norm=True, avg_factor=None,
+                        update_until_epoch=3, epoch=0, training=True, eps=1e-10):
+    B, T, _ = x.shape
+    means, stds = [], []
+    for b in range(B):
+        n = int(torch.round(lengths[b] * T))
+        seg = x[b, :n]
+        m = seg.mean(0) if mean_norm else torch.zeros(1, dtype=x.dtype)
+        s = seg.std(0) if std_norm else torch.ones(1, dtype=x.dtype)
+        means.append(m)
+        stds.append(torch.max(s, eps * torch.ones_like(s)))
+    if norm_type == "sentence":
+        return torch.stack([(x[b] - means[b]) / stds[b] for b in range(B)])
+    cm, cs = torch.stack(means).mean(0), torch.stack(stds).mean(0)
+    if norm_type == "batch":
+        return (x - cm) / cs
+    if training:
+        if state.count == 0:
+            state.glob_mean, state.glob_std = cm, cs
+        elif epoch < update_until_epoch:
+            w = 1.0 / (state.count + 1) if avg_factor is None else avg_factor
+            state.glob_mean = (1 - w) * state.glob_mean + w * cm
+            state.glob_std = (1 - w) * state.glob_std + w * cs
+        state.count += 1
+    return (x - state.glob_mean) / state.glob_std

@@ -89,6 +89,9 @@ SIGNATURES = {
     "smx_cast_from_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
     "smx_cast_to_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
     "smx_adamw_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_vp, c_vp]),
+    "smx_utt_meanstd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_vp]),
+    "smx_stats_combine": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_vp, c_f, c_vp]),
+    "smx_colnorm": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_vp]),
     "smx_log_softmax_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
     "smx_log_softmax_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
     "smx_ctc_workspace": (c_sz, [c_i, c_i, c_i]),

@@ -143,6 +143,60 @@ __global__ __launch_bounds__(256) void col2im_s2_kernel(const T* __restrict__ dc
   }
 }
 
+// ---- InputNormalization (speechbrain.processing.features.InputNormalization, recipe key `normalize`) ---------------
+// per-utterance mean and unbiased std over the valid frames t < len[b] of every feature; grid (ceil(F/64), B), 256
+// threads = 64 features x 4 time groups; two passes over the (small) feature block for a stable variance
+template <typename T>
+__global__ __launch_bounds__(256) void utt_meanstd_kernel(const T* __restrict__ X, long ldx, int Tmax, int F,
+                                                          const int* __restrict__ len, float* __restrict__ mean,
+                                                          float* __restrict__ sd, int mean_norm, int std_norm, float eps) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, tg = threadIdx.x >> 6, b = blockIdx.y;
+  const int c = blockIdx.x * 64 + cl;
+  const int n = min(max(len[b], 0), Tmax);
+  const T* x = X + (long)b * Tmax * ldx + c;
+  float s = 0.f;
+  if (c < F) for (int t = tg; t < n; t += 4) s += to_f32(x[(long)t * ldx]);
+  red[tg][cl] = s;
+  __syncthreads();
+  const float m = n > 0 ? ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)n : 0.f;
+  __syncthreads();
+  float q = 0.f;
+  if (c < F) for (int t = tg; t < n; t += 4) { const float d = to_f32(x[(long)t * ldx]) - m; q += d * d; }
+  red[tg][cl] = q;
+  __syncthreads();
+  if (tg == 0 && c < F) {
+    const float var = n > 1 ? ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)(n - 1) : __builtin_nanf("");
+    mean[(long)b * F + c] = mean_norm ? m : 0.f;
+    sd[(long)b * F + c] = std_norm ? fmaxf(sqrtf(var), eps) : 1.f;    // torch.max(std, eps): NaN (one frame) propagates
+  }
+}
+
+// glob = (1 - w) * glob + w * mean_b(cur)   (w = 1: replace).  One thread per feature, fixed order over the batch.
+__global__ void stats_combine_kernel(const float* __restrict__ cur_mean, const float* __restrict__ cur_std, int B, int F,
+                                     float* glob_mean, float* glob_std, float w) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= F) return;
+  float m = 0.f, s = 0.f;
+  for (int b = 0; b < B; ++b) { m += cur_mean[(long)b * F + c]; s += cur_std[(long)b * F + c]; }
+  m /= (float)B; s /= (float)B;
+  glob_mean[c] = w >= 1.f ? m : (1.f - w) * glob_mean[c] + w * m;
+  glob_std[c] = w >= 1.f ? s : (1.f - w) * glob_std[c] + w * s;
+}
+
+// Y[b,t,c] = (X[b,t,c] - mean[b*stride + c]) / std[b*stride + c]   (stride 0: shared statistics)
+template <typename T>
+__global__ __launch_bounds__(256) void colnorm_kernel(const T* __restrict__ X, long ldx, const float* __restrict__ mean,
+                                                      const float* __restrict__ sd, long sstride, T* __restrict__ Y, long ldy,
+                                                      int Tmax, int F, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % F);
+    const long row = i / F;
+    const long b = row / Tmax;
+    Y[row * ldy + c] = from_f32<T>((to_f32(X[row * ldx + c]) - mean[b * sstride + c]) / sd[b * sstride + c]);
+  }
+}
+
 static inline int fgrid(long n) {
   long b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -201,4 +255,32 @@ extern "C" int smx_col2im_s2(int dtype, const void* dcol, void* dx, int B, int T
   if (dtype == SMX_BF16) hipLaunchKernelGGL((col2im_s2_kernel<bf16_t>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const bf16_t*)dcol, (bf16_t*)dx, B, T, F, C, T2, F2, Kp);
   else hipLaunchKernelGGL((col2im_s2_kernel<float>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const float*)dcol, (float*)dx, B, T, F, C, T2, F2, Kp);
   return check_launch("smx_col2im_s2");
+}
+
+extern "C" int smx_utt_meanstd(int dtype, const void* X, int64_t ldx, const int32_t* len, float* mean, float* std, int B, int T,
+                               int F, int mean_norm, int std_norm, float eps, void* stream) {
+  SMX_REQUIRE(X && len && mean && std && T > 0 && F > 0, "smx_utt_meanstd: bad arguments");
+  if (B <= 0) return SMX_OK;
+  dim3 grid((F + 63) / 64, B);
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((utt_meanstd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)X, ldx, T, F, len, mean, std, mean_norm, std_norm, eps);
+  else hipLaunchKernelGGL((utt_meanstd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)X, ldx, T, F, len, mean, std, mean_norm, std_norm, eps);
+  return check_launch("smx_utt_meanstd");
+}
+
+extern "C" int smx_stats_combine(const float* cur_mean, const float* cur_std, int B, int F, float* glob_mean, float* glob_std,
+                                 float weight, void* stream) {
+  SMX_REQUIRE(cur_mean && cur_std && glob_mean && glob_std && B > 0 && F > 0 && weight > 0.f, "smx_stats_combine: bad arguments");
+  hipLaunchKernelGGL(stats_combine_kernel, dim3((F + 255) / 256), dim3(256), 0, STREAM, cur_mean, cur_std, B, F, glob_mean,
+                     glob_std, weight);
+  return check_launch("smx_stats_combine");
+}
+
+extern "C" int smx_colnorm(int dtype, const void* X, int64_t ldx, const float* mean, const float* std, int64_t stat_stride,
+                           void* Y, int64_t ldy, int B, int T, int F, void* stream) {
+  SMX_REQUIRE(X && mean && std && Y && T > 0 && F > 0, "smx_colnorm: bad arguments");
+  if (B <= 0) return SMX_OK;
+  const long total = (long)B * T * F;
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((colnorm_kernel<bf16_t>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const bf16_t*)X, ldx, mean, std, stat_stride, (bf16_t*)Y, ldy, T, F, total);
+  else hipLaunchKernelGGL((colnorm_kernel<float>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const float*)X, ldx, mean, std, stat_stride, (float*)Y, ldy, T, F, total);
+  return check_launch("smx_colnorm");
 }

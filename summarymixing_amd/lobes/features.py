@@ -55,3 +55,56 @@ class Fbank(nn.Module):
         spec = torch.empty((B * T, self.basis.shape[0]), dtype=torch.float32, device=wav.device)
         ops.gemm(L.GEMM_NT, frames, self.basis, spec, B * T, self.basis.shape[0], self.n_fft)
         return ops.mel_db(spec, self.im_off, self.fb, B, T, self.amin, self.top_db, out_dtype)
+
+
+class InputNormalization(nn.Module):
+    """Mean / variance normalisation of the filterbank features (speechbrain.processing.features.InputNormalization as the
+    recipes instantiate it: ``norm_type: global, update_until_epoch: 4``, ...transducer.yaml:167-169).  Statistics per
+    utterance over its valid frames (unbiased std, clamped at eps); "sentence" normalises each utterance by its own,
+    "batch" by the batch average, "global" by a running average over all training batches seen while
+    ``epoch < update_until_epoch`` (weight 1/(count+1), or ``avg_factor``).  Padded frames are normalised too, like the
+    reference.  HIP kernels (smx_utt_meanstd / smx_stats_combine / smx_colnorm); arithmetic spec:
+    oracle/smx_oracle.py::input_normalization (upstream-only code: parity unpinned)."""
+
+    def __init__(self, mean_norm=True, std_norm=True, norm_type="global", avg_factor=None, requires_grad=False,
+                 update_until_epoch=3):
+        super().__init__()
+        if norm_type not in ("global", "batch", "sentence"):
+            raise NotImplementedError("norm_type 'speaker' keeps per-speaker dictionaries on the host: not built")
+        self.mean_norm, self.std_norm, self.norm_type = mean_norm, std_norm, norm_type
+        self.avg_factor, self.update_until_epoch = avg_factor, update_until_epoch
+        self.eps = 1e-10
+        self.count = 0
+        self.glob_mean = None
+        self.glob_std = None
+
+    def forward(self, x, lengths, spk_ids=None, epoch=0):
+        if not x.is_cuda:
+            raise RuntimeError("summarymixing_amd kernels run on the GPU only (no CPU fallback)")
+        B, T, F = x.shape
+        x = x if x.is_contiguous() else x.contiguous()
+        x2 = x.view(B * T, F)
+        lens = torch.round(lengths.to(x.device) * T).to(torch.int32)
+        mean = torch.empty((B, F), dtype=torch.float32, device=x.device)
+        std = torch.empty((B, F), dtype=torch.float32, device=x.device)
+        ops.utt_meanstd(x2, lens, mean, std, B, T, self.mean_norm, self.std_norm, self.eps)
+        out = torch.empty_like(x2)
+        if self.norm_type == "sentence":
+            ops.colnorm(x2, mean, std, F, out, B, T)
+            return out.view(B, T, F)
+        if self.norm_type == "batch":
+            gm, gs = torch.empty(F, device=x.device), torch.empty(F, device=x.device)
+            ops.stats_combine(mean, std, gm, gs, 1.0)
+        else:
+            if self.glob_mean is None:
+                self.glob_mean, self.glob_std = torch.zeros(F, device=x.device), torch.ones(F, device=x.device)
+            if self.training:
+                if self.count == 0:
+                    ops.stats_combine(mean, std, self.glob_mean, self.glob_std, 1.0)
+                elif epoch < self.update_until_epoch:
+                    w = 1.0 / (self.count + 1) if self.avg_factor is None else self.avg_factor
+                    ops.stats_combine(mean, std, self.glob_mean, self.glob_std, w)
+                self.count += 1
+            gm, gs = self.glob_mean, self.glob_std
+        ops.colnorm(x2, gm, gs, 0, out, B, T)
+        return out.view(B, T, F)

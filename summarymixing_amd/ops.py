@@ -311,6 +311,25 @@ def adamw_step(param, grad, m, v, shadow, lr, b1, b2, eps, wd, step, grad_scale=
                                    step, grad_scale, _p(gscale_dev), _stream()), "smx_adamw_step")
 
 
+def utt_meanstd(x2, lens, mean, std, B, T, mean_norm=True, std_norm=True, eps=1e-10):
+    px, ldx = _mat(x2)
+    L.check(L.lib().smx_utt_meanstd(dt(x2), px, ldx, _p(lens), _p(mean), _p(std), B, T, x2.shape[1], int(mean_norm),
+                                    int(std_norm), eps, _stream()), "smx_utt_meanstd")
+
+
+def stats_combine(cur_mean, cur_std, glob_mean, glob_std, weight):
+    B, F = cur_mean.shape
+    L.check(L.lib().smx_stats_combine(_p(cur_mean), _p(cur_std), B, F, _p(glob_mean), _p(glob_std), float(weight), _stream()),
+            "smx_stats_combine")
+
+
+def colnorm(x2, mean, std, stat_stride, out, B, T):
+    px, ldx = _mat(x2)
+    po, ldo = _mat(out)
+    L.check(L.lib().smx_colnorm(dt(x2), px, ldx, _p(mean), _p(std), stat_stride, po, ldo, B, T, x2.shape[1], _stream()),
+            "smx_colnorm")
+
+
 def log_softmax_fwd(x):
     """log_softmax over the last dim of a (N, V) view."""
     N, V = x.shape

@@ -91,3 +91,29 @@ def test_fbank_conv_encoder_chain_runs():
     assert y.shape == (2, 51, 64) and torch.isfinite(y).all()
     y.float().sum().backward()
     assert cnn.blocks[0].conv.weight.grad is not None and torch.isfinite(cnn.blocks[0].conv.weight.grad).all()
+
+
+@pytest.mark.parametrize("norm_type", ["global", "batch", "sentence"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+def test_input_normalization_matches_spec(norm_type, dtype, tol):
+    """InputNormalization (recipe key `normalize`) against the oracle restatement of the SpeechBrain semantics: ragged
+    lengths, running global statistics over three training batches, frozen statistics in eval / past update_until_epoch."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd.lobes.features import InputNormalization
+    torch.manual_seed(7)
+    mod = InputNormalization(norm_type=norm_type, update_until_epoch=2).cuda().train()
+    st = O.InputNormalizationState()
+    B, T, F = 4, 57, 80
+    for step, epoch in enumerate([0, 0, 1, 5]):
+        x = (torch.randn(B, T, F) * 7.0 - 20.0).to(dtype)
+        lens = torch.tensor([1.0, 0.53, 0.8, 0.31])
+        ref = O.input_normalization(x.double(), lens, st, norm_type=norm_type, update_until_epoch=2, epoch=epoch)
+        y = mod(x.cuda(), lens.cuda(), epoch=epoch)
+        assert rel_err(y, ref) <= tol, (step, rel_err(y, ref))
+    if norm_type == "global":
+        assert mod.count == 4 and st.count == 4
+        assert rel_err(mod.glob_mean, st.glob_mean) <= 1e-4 and rel_err(mod.glob_std, st.glob_std) <= 1e-3
+        mod.eval()
+        x = (torch.randn(B, T, F) * 3.0).to(dtype)
+        ref = O.input_normalization(x.double(), lens, st, norm_type="global", training=False)
+        assert rel_err(mod(x.cuda(), lens.cuda()), ref) <= tol and mod.count == 4
