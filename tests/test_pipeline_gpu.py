@@ -60,3 +60,42 @@ def test_waveform_to_ctc_loss_matches_oracle_chain():
         assert fro(params[k].grad, sd[k].grad) <= 2e-2, k
     assert fro(cnn.blocks[1].conv.weight.grad, sd_cnn["convblock_1.conv.weight"].grad) <= 2e-2
     assert fro(cnn.blocks[0].norm.weight.grad, sd_cnn["convblock_0.norm.weight"].grad) <= 2e-2
+
+
+def test_training_steps_reduce_the_ctc_loss():
+    """40 optimizer steps (FlatAdamW: HIP clip + AdamW) on one fixed batch, bf16 compute, dropout on: the multitask CTC
+    loss of the encoder + heads must go down substantially and every parameter must stay finite."""
+    from summarymixing_amd.lobes.models.transformer.TransformerASR import EncoderWrapper, TransformerASR
+    from summarymixing_amd.nnet.activations import Softmax
+    from summarymixing_amd.nnet.linear import Linear
+    from summarymixing_amd.nnet.losses import ctc_loss
+    from summarymixing_amd.trainer import FlatAdamW
+    torch.manual_seed(5)
+    B, T, Fin, d, V, S = 8, 64, 80, 64, 20, 6
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            net = TransformerASR(tgt_vocab=V, input_size=Fin, d_model=d, nhead=4, num_encoder_layers=2, num_decoder_layers=0,
+                                 d_ffn=128, dropout=0.1, encoder_module="conformer", conformer_activation="swish",
+                                 attention_type="SummaryMixing", mode="SummaryMixing-fast", local_proj_out_dim=d,
+                                 local_proj_hid_dim=[d], summary_hid_dim=[d], summary_out_dim=d, causal=False, kernel_size=15)
+            self.enc = EncoderWrapper(net)
+            self.proj_ctc = Linear(V, input_size=d)
+    m = Model().cuda().train()
+    opt = FlatAdamW(m, lr=2e-3, compute_dtype=torch.bfloat16)
+    src = torch.randn(B, T, Fin).cuda().bfloat16()
+    wav_len = torch.linspace(1.0, 0.6, B).cuda()
+    targets = torch.randint(1, V, (B, S)).cuda()
+    tg_rel = torch.ones(B).cuda()
+    log_softmax = Softmax(apply_log=True)
+    losses = []
+    for _ in range(40):
+        opt.zero_grad()
+        loss = ctc_loss(log_softmax(m.proj_ctc(m.enc(src, wav_len)).float()), targets, wav_len, tg_rel, 0)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert torch.isfinite(opt.flat_p).all()
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
