@@ -84,6 +84,9 @@ class _Deferred:
     pending = set()  # workspace keys written since the last flush
     ws = {}          # key -> persistent uint8 workspace
     cache = {}       # tuple(jobs) -> (jobs_dev, starts_dev, njobs, total_blocks)
+    side_enabled = os.environ.get("SMX_WGRAD_STREAM", "1") != "0"
+    side = {}        # device -> side stream of the slab GEMMs
+    side_used = False
 
 
 def deferred_ws(key, nbytes, device):
@@ -113,6 +116,10 @@ def flush_deferred():
     if not _Deferred.jobs:
         _Deferred.pending.clear()
         return
+    if _Deferred.side_used:                    # the slab GEMMs of this block ran on the side stream: join it
+        for st in _Deferred.side.values():
+            torch.cuda.current_stream().wait_stream(st)
+        _Deferred.side_used = False
     key = tuple(_Deferred.jobs)
     ent = _Deferred.cache.get(key)
     if ent is None:
@@ -139,7 +146,21 @@ def _wgrad(dz, x, gW, N, M, K, dbias):
         return
     key = gW.data_ptr()
     ws = deferred_ws(key, L.lib().smx_linear_wgrad_workspace(N, M, K, 1), dz.device)
-    nslabs, stride, boff = ops.wgrad_partial(dz, x, N, M, K, ws, want_bias=dbias is not None)
+    if _Deferred.side_enabled and not torch.cuda.is_current_stream_capturing():
+        # the slab GEMM only feeds the deferred reduction: run it on a side stream next to the dgrad chain (its reads
+        # overlap the dgrad's epilogue writes instead of queueing behind them)
+        main = torch.cuda.current_stream()
+        side = _Deferred.side.get(dz.device)
+        if side is None:
+            side = _Deferred.side[dz.device] = torch.cuda.Stream(device=dz.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            nslabs, stride, boff = ops.wgrad_partial(dz, x, N, M, K, ws, want_bias=dbias is not None)
+        dz.record_stream(side)
+        x.record_stream(side)
+        _Deferred.side_used = True
+    else:
+        nslabs, stride, boff = ops.wgrad_partial(dz, x, N, M, K, ws, want_bias=dbias is not None)
     defer(ws.data_ptr(), gW, stride, nslabs, M, K)
     if dbias is not None:
         defer(ws.data_ptr() + 4 * boff, dbias, M, nslabs, 1, M)
