@@ -89,6 +89,22 @@ def time_kernel(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def pmc_traffic_bytes(tag):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.txt: TCC FETCH_SIZE x2-corrected +
+    WRITE_SIZE, separate --pmc passes of tools/pmc_traffic.sh on this exact shape), or None when no matching line."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.txt")
+    try:
+        for line in open(path):
+            if tag in line:
+                m = re.search(r"traffic\(corrected\)=([0-9.]+) MB", line)
+                if m:
+                    return float(m.group(1)) * 1e6
+    except OSError:
+        pass
+    return None
+
+
 def roofline_gemm(cfg, dtype):
     """The dominant kernel of the step: gemm_kernel<bf16, NT, 128x128> on the FFN up-projection shape."""
     from summarymixing_amd import _lib as L, ops
@@ -108,8 +124,11 @@ def roofline_gemm(cfg, dtype):
     name = (f"gemm_kernel<{'bf16' if es == 2 else 'f32'},NT,128x128> FFN up-proj ({N}x{K})x({K}x{M}) +bias+swish+Z")
     common = {"kernel": name, "launch_us": t * 1e6, "arithmetic_intensity_flop_per_byte": intensity,
               "mfma_TFLOPs": flops / t / 1e12, "mfma_frac": flops / t / 1e12 / mfma_peak,
-              "hbm_GBps_algorithmic": alg_bytes / t / 1e9, "traffic": None,
-              "traffic_note": "PMC FETCH_SIZE/WRITE_SIZE per launch: profiles/r01_pmc_traffic.txt"}
+              "hbm_GBps_algorithmic": alg_bytes / t / 1e9,
+              "traffic": pmc_traffic_bytes(f"gemm NT bf16 ({N}x{K})x({K}x{M})") if es == 2 else None,
+              "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE (x2 corrected) + WRITE_SIZE from separate --pmc passes "
+                              "on this shape (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.txt); algorithmic bytes "
+                              f"{alg_bytes / 1e6:.1f} MB"}
     if intensity < ridge:
         return dict(common, bound="hbm", achieved=alg_bytes / t / 1e9, peak=8000.0, unit="GB/s",
                     frac=alg_bytes / t / 1e9 / 8000.0)
@@ -131,7 +150,7 @@ def roofline_pool(dtype):
     nbytes = B * T * D * es + B * T + 4 * B * D
     return {"kernel": f"masked_sum_stage1+2 ({B},{T},{D}) {'bf16' if es == 2 else 'f32'}", "bound": "hbm",
             "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
-            "traffic": None, "launch_us": t * 1e6}
+            "traffic": pmc_traffic_bytes(f"pool {'bf16' if es == 2 else 'f32 '} ({B},{T},{D})"), "launch_us": t * 1e6}
 
 
 def cpu_baseline(cfg, train):
