@@ -511,16 +511,26 @@ __device__ __forceinline__ void stage_colsum(const uint4 (&reg)[ROWS / 32], floa
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
-template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC>
 #ifndef SMX_OCC
 #define SMX_OCC 3
 #endif
 #ifndef SMX_NS_KC
 #define SMX_NS_KC 1
 #endif
+// LDS-DMA issue of one 1 KB piece (global_load_lds_dwordx4: lane i lands at lds_dst + 16 i; M0 carries the wave-uniform
+// LDS base and is compiler-reserved, so it is saved / restored inside the statement).  hipcc does not count this
+// load: the kernel waits for it with explicit s_waitcnt vmcnt(N).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
-// the bias-gradient column sums and two register stages of both operands
-__global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
+// the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
+template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, bool DMA = false>
+__global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC || DMA) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
+  static_assert(!DMA || (sizeof(T) == 2 && A_KC && B_KC && VEC), "LDS-DMA staging: bf16, both operands reduce-contiguous");
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
@@ -532,11 +542,17 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   constexpr int PH_ROWS = 32 * PH_FRAGS;
   constexpr int NPH = TILE_N / PH_ROWS;
   constexpr int EPI_BYTES = PH_ROWS * (TILE_M * 4 + 16);         // fp32 rows, 16 B row pad
-  constexpr int SMEM_BYTES = (A_BYTES + B_BYTES) > EPI_BYTES ? (A_BYTES + B_BYTES) : EPI_BYTES;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;                 // one K tile of both operands
+  constexpr int RING = DMA ? 2 : 1;                              // LDS-DMA: two stages, one landing while one is multiplied
+  constexpr int SMEM_BYTES = (RING * STAGE_BYTES) > EPI_BYTES ? (RING * STAGE_BYTES) : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N) * 4;              // bias[TILE_M] | row factors[TILE_N] (mask * alpha)
-  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES + RED_BYTES + SIDE_BYTES];
-  float* red = reinterpret_cast<float*>(smem + SMEM_BYTES);
+  // the DMA ring fills the 64 KB static LDS limit: its small epilogue arrays live behind the epilogue staging rows
+  // inside the (by then dead) ring, fenced by one extra barrier
+  constexpr bool ALIAS_SIDE = (SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536);
+  static_assert(!ALIAS_SIDE || EPI_BYTES + RED_BYTES + SIDE_BYTES + 64 <= SMEM_BYTES, "epilogue arrays do not fit");
+  __shared__ __attribute__((aligned(16))) char smem[ALIAS_SIDE ? SMEM_BYTES : SMEM_BYTES + RED_BYTES + SIDE_BYTES];
+  float* red = reinterpret_cast<float*>(smem + (ALIAS_SIDE ? (EPI_BYTES + 63) / 64 * 64 : SMEM_BYTES));
   float* side = red + TILE_M;
   char* As = smem;
   char* Bs = smem + A_BYTES;
@@ -606,6 +622,68 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  const bool ab_nold = p.ablate & 4, ab_nomfma = p.ablate & 2, ab_nost = p.ablate & 1;
+  constexpr int CSN = 16 / (int)sizeof(T);
+  float cs[CSN];
+#pragma unroll
+  for (int q = 0; q < CSN; ++q) cs[q] = 0.f;
+  const bool do_cs = !A_KC && p.acolsum != nullptr && tile_m == 0;
+  if constexpr (DMA) {
+    // ---- LDS-DMA main loop (NT, bf16, K % 64 == 0): the K tiles go HBM -> LDS without touching a VGPR.  Measured
+    // (tools/glds_probe.hip, 1 GB panel): this path streams 6.1 TB/s where global -> register -> ds_write tops out at
+    // 2.9 TB/s.  Same LDS image as the register path (128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7):
+    // the swizzle is applied to the SOURCE address, because lane i of a piece always lands at +16 i.
+    const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+    const int niter = (kend - kbeg) / BK;
+    auto issue = [&](int it) {
+      const int buf = it & 1, k0 = kbeg + it * BK;
+#pragma unroll
+      for (int j = 0; j < TILE_N / 32; ++j) {              // A: TILE_N / 8 pieces of 8 rows, 4 waves
+        const int ins = wave + 4 * j, row = ins * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        const long gr = min(n0 + row, p.N - 1);
+        glds16(A + gr * p.lda + k0 + lc * 8, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + ins * 1024));
+      }
+#pragma unroll
+      for (int j = 0; j < TILE_M / 32; ++j) {
+        const int ins = wave + 4 * j, row = ins * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        const long gr = min(m0 + row, p.M - 1);
+        glds16(B + gr * p.ldb + k0 + lc * 8,
+               __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + A_BYTES + ins * 1024));
+      }
+    };
+    constexpr int PIECES = TILE_N / 32 + TILE_M / 32;     // DMA instructions per wave and stage
+    if (niter > 0) issue(0);
+    SMX_STAMP(1);
+    for (int it = 0; it < niter; ++it) {
+      if (it + 1 < niter) {
+        issue(it + 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");   // stage `it` has landed, `it + 1` is in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      As = smem + (it & 1) * STAGE_BYTES;
+      Bs = As + A_BYTES;
+      if (!ab_nomfma) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          bf16x8 fa[FN], fb[FM];
+#pragma unroll
+          for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<true, TILE_N>(As, wn * WN + i * 32 + l31, kk, hi);
+#pragma unroll
+          for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<true, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      lds_barrier();                                       // buffer (it & 1) is free for stage it + 2
+    }
+  } else {
   // NS register stages of BK reduce-elements each are in flight (issue-early / write-late): for the K = 256..512
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
   // about one HBM/L2 round trip for its whole main loop instead of one per K tile (measured: 2.9 K cycles per
@@ -616,7 +694,6 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   for (int s_ = 0; s_ < NS; ++s_)
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[s_][i] = rb[s_][i] = make_uint4(0, 0, 0, 0);
-  const bool ab_nold = p.ablate & 4, ab_nomfma = p.ablate & 2, ab_nost = p.ablate & 1;
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_) {
     const int kk = kbeg + s_ * BK;
@@ -626,11 +703,6 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     }
   }
   SMX_STAMP(1);
-  constexpr int CSN = 16 / (int)sizeof(T);
-  float cs[CSN];
-#pragma unroll
-  for (int q = 0; q < CSN; ++q) cs[q] = 0.f;
-  const bool do_cs = !A_KC && p.acolsum != nullptr && tile_m == 0;
   for (int kb = kbeg; kb < kend; kb += NS * BK) {
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
@@ -683,6 +755,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     }
   }
 
+  }   // (register-staged main loop)
   if constexpr (!A_KC) {
     if (do_cs) {                                          // (uniform per workgroup)
       constexpr int CPK = TILE_N / CSN;                   // column chunks per k row of the stage = threads per group
@@ -733,6 +806,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   }
   constexpr int STG_LD = TILE_M * 4 + 16;               // bytes per staged fp32 row (16 B pad: conflict-free b128)
   const int osz = (e.out_mode == SMX_OUT_T) ? (int)sizeof(T) : 4;
+  if constexpr (ALIAS_SIDE) lds_barrier();               // every wave is done reading the operand ring
 #pragma unroll
   for (int i = 0; i < NSIDE; ++i)
     if (t + 256 * i < TILE_M + TILE_N) side[t + 256 * i] = side_v[i];   // (visible after the first barrier below)
@@ -801,6 +875,17 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // Measured at 64000 frames: (K=1024, M=256) NT 77 -> 59 us, NN 65 -> 55 us; (K=256, M=1024) 99 -> 103 us (not used).
   static const int wide_env = getenv("SMX_GEMM_WIDE") ? atoi(getenv("SMX_GEMM_WIDE")) : -1;
   const bool wide = wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 512 && p.M <= 512));
+  static const int dma_env = getenv("SMX_GEMM_DMA") ? atoi(getenv("SMX_GEMM_DMA")) : 0;
+  if constexpr (sizeof(T) == 2 && A_KC && B_KC) {
+    if (dma_env && vec && !force_small && p.splits == 1 && p.K % 64 == 0 && p.K >= 64 && p.N >= 128 && p.M >= 128 &&
+        (reinterpret_cast<uintptr_t>(p.A) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.B) % 16 == 0)) {
+      p.tiles_n = (p.N + 127) / 128;
+      p.tiles_m = (p.M + 127) / 128;
+      hipLaunchKernelGGL((gemm_kernel<T, true, true, 128, 128, true, true>), dim3(p.tiles_n * p.tiles_m, p.batch), dim3(256), 0, s, p);
+      if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
+      return check_launch("smx_gemm");
+    }
+  }
   if (wide && !force_small && p.N >= 128 && p.M >= 256 && p.M % 256 == 0 && p.splits == 1 &&
       (long)((p.N + 127) / 128) * (p.M / 256) * p.batch >= 256)
     return launch_tile<T, A_KC, B_KC, 128, 256>(p, vec, s);

@@ -326,3 +326,17 @@ def test_expdecay_mean_matches_dense_laplace(B, T, D, dtype, tol):
     assert rel_err(out.view(B, T, D), torch.einsum("ij,bjd->bid", Wn, s3)) <= tol
     ops.expdecay_mean(s, out, B, T, decay, reverse=True)
     assert rel_err(out.view(B, T, D), torch.einsum("ji,bjd->bid", Wn, s3)) <= tol
+
+
+def test_gemm_lds_dma_variant_in_subprocess():
+    """The opt-in LDS-DMA main loop (SMX_GEMM_DMA=1: global_load_lds ring instead of register staging for the NT bf16
+    kernels) must pass the same GEMM tests; the knob is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SMX_GEMM_DMA="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "-m", "gpu", "-q", "-x", "-k",
+                        "test_gemm_layouts or test_gemm_epilogue_all_fields or test_gemm_act_grad_epilogue"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
