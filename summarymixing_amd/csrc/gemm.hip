@@ -529,8 +529,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, bool DMA = false>
-__global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC || DMA) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
-  static_assert(!DMA || (sizeof(T) == 2 && A_KC && B_KC && VEC), "LDS-DMA staging: bf16, both operands reduce-contiguous");
+__global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
+  static_assert(!DMA || (sizeof(T) == 2 && A_KC && VEC), "LDS-DMA staging of A: bf16, reduce-contiguous, aligned");
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
@@ -542,20 +542,20 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC || DMA) ? 2 : SMX_OCC)
   constexpr int PH_ROWS = 32 * PH_FRAGS;
   constexpr int NPH = TILE_N / PH_ROWS;
   constexpr int EPI_BYTES = PH_ROWS * (TILE_M * 4 + 16);         // fp32 rows, 16 B row pad
-  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;                 // one K tile of both operands
-  constexpr int RING = DMA ? 2 : 1;                              // LDS-DMA: two stages, one landing while one is multiplied
-  constexpr int SMEM_BYTES = (RING * STAGE_BYTES) > EPI_BYTES ? (RING * STAGE_BYTES) : EPI_BYTES;
+  constexpr int RING = DMA ? 2 : 1;                              // LDS-DMA: two A stages, one landing while one is multiplied
+  constexpr int AB_BYTES = RING * A_BYTES + B_BYTES;
+  constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N) * 4;              // bias[TILE_M] | row factors[TILE_N] (mask * alpha)
   // the DMA ring fills the 64 KB static LDS limit: its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) ring, fenced by one extra barrier
-  constexpr bool ALIAS_SIDE = (SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536);
+  constexpr bool ALIAS_SIDE = DMA || (SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536);
   static_assert(!ALIAS_SIDE || EPI_BYTES + RED_BYTES + SIDE_BYTES + 64 <= SMEM_BYTES, "epilogue arrays do not fit");
   __shared__ __attribute__((aligned(16))) char smem[ALIAS_SIDE ? SMEM_BYTES : SMEM_BYTES + RED_BYTES + SIDE_BYTES];
   float* red = reinterpret_cast<float*>(smem + (ALIAS_SIDE ? (EPI_BYTES + 63) / 64 * 64 : SMEM_BYTES));
   float* side = red + TILE_M;
   char* As = smem;
-  char* Bs = smem + A_BYTES;
+  char* Bs = smem + RING * A_BYTES;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wn = wave >> 1, wm = wave & 1;
@@ -629,43 +629,40 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC || DMA) ? 2 : SMX_OCC)
   for (int q = 0; q < CSN; ++q) cs[q] = 0.f;
   const bool do_cs = !A_KC && p.acolsum != nullptr && tile_m == 0;
   if constexpr (DMA) {
-    // ---- LDS-DMA main loop (NT, bf16, K % 64 == 0): the K tiles go HBM -> LDS without touching a VGPR.  Measured
-    // (tools/glds_probe.hip, 1 GB panel): this path streams 6.1 TB/s where global -> register -> ds_write tops out at
-    // 2.9 TB/s.  Same LDS image as the register path (128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7):
+    // ---- LDS-DMA main loop: the A tiles (the activation stream, the operand that comes from HBM) go HBM -> LDS
+    // without touching a VGPR, into a ring of two stages; the weights (L2 resident) keep the register path.  Measured
+    // (tools/glds_probe.hip, 1 GB panel): the DMA path streams 6.1 TB/s where global -> register -> ds_write tops out
+    // at 2.9 TB/s.  Same LDS image as the register path (128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7):
     // the swizzle is applied to the SOURCE address, because lane i of a piece always lands at +16 i.
+    // Waits: hipcc does not count the DMA.  Stage it+1 of A is issued BEFORE the register loads of B's stage it+1, so
+    // the wait hipcc emits for those registers (vmcnt retires in order) also covers the older DMA pieces.
     const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
     const int niter = (kend - kbeg) / BK;
-    auto issue = [&](int it) {
+    uint4 rb[TILE_M / 32];
+    auto issue_a = [&](int it) {
       const int buf = it & 1, k0 = kbeg + it * BK;
 #pragma unroll
-      for (int j = 0; j < TILE_N / 32; ++j) {              // A: TILE_N / 8 pieces of 8 rows, 4 waves
+      for (int j = 0; j < TILE_N / 32; ++j) {              // TILE_N / 8 pieces of 8 rows (1 KB each), 4 waves
         const int ins = wave + 4 * j, row = ins * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         const long gr = min(n0 + row, p.N - 1);
-        glds16(A + gr * p.lda + k0 + lc * 8, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + ins * 1024));
-      }
-#pragma unroll
-      for (int j = 0; j < TILE_M / 32; ++j) {
-        const int ins = wave + 4 * j, row = ins * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        const long gr = min(m0 + row, p.M - 1);
-        glds16(B + gr * p.ldb + k0 + lc * 8,
-               __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + A_BYTES + ins * 1024));
+        glds16(A + gr * p.lda + k0 + lc * 8, __builtin_amdgcn_readfirstlane(lds_base + buf * A_BYTES + ins * 1024));
       }
     };
-    constexpr int PIECES = TILE_N / 32 + TILE_M / 32;     // DMA instructions per wave and stage
-    if (niter > 0) issue(0);
+    if (niter > 0) {
+      issue_a(0);
+      stage_load<T, B_KC, TILE_M, VEC>(rb, B, p.ldb, m0, p.M, kbeg, kend, t);
+    }
     SMX_STAMP(1);
     for (int it = 0; it < niter; ++it) {
+      stage_store<T, B_KC, TILE_M>(rb, Bs, t);             // (waits for B's registers and therefore for A's stage `it`)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // explicit: nothing of this wave is in flight at the barrier
+      lds_barrier();
       if (it + 1 < niter) {
-        issue(it + 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");   // stage `it` has landed, `it + 1` is in flight
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_a(it + 1);
+        stage_load<T, B_KC, TILE_M, VEC>(rb, B, p.ldb, m0, p.M, kbeg + (it + 1) * BK, kend, t);
       }
-      __builtin_amdgcn_s_barrier();
-      As = smem + (it & 1) * STAGE_BYTES;
-      Bs = As + A_BYTES;
+      As = smem + (it & 1) * A_BYTES;
       if (!ab_nomfma) {
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -673,7 +670,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC || DMA) ? 2 : SMX_OCC)
 #pragma unroll
           for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<true, TILE_N>(As, wn * WN + i * 32 + l31, kk, hi);
 #pragma unroll
-          for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<true, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
+          for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<B_KC, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
 #pragma unroll
           for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -681,7 +678,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC || DMA) ? 2 : SMX_OCC)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
       }
-      lds_barrier();                                       // buffer (it & 1) is free for stage it + 2
+      lds_barrier();                                       // Bs and A buffer (it & 1) are free again
     }
   } else {
   // NS register stages of BK reduce-elements each are in flight (issue-early / write-late): for the K = 256..512
@@ -876,12 +873,12 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   static const int wide_env = getenv("SMX_GEMM_WIDE") ? atoi(getenv("SMX_GEMM_WIDE")) : -1;
   const bool wide = wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 512 && p.M <= 512));
   static const int dma_env = getenv("SMX_GEMM_DMA") ? atoi(getenv("SMX_GEMM_DMA")) : 0;
-  if constexpr (sizeof(T) == 2 && A_KC && B_KC) {
+  if constexpr (sizeof(T) == 2 && A_KC) {
     if (dma_env && vec && !force_small && p.splits == 1 && p.K % 64 == 0 && p.K >= 64 && p.N >= 128 && p.M >= 128 &&
-        (reinterpret_cast<uintptr_t>(p.A) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.B) % 16 == 0)) {
+        big >= 256 && (reinterpret_cast<uintptr_t>(p.A) % 16 == 0) && (dma_env != 2 || !wide)) {
       p.tiles_n = (p.N + 127) / 128;
       p.tiles_m = (p.M + 127) / 128;
-      hipLaunchKernelGGL((gemm_kernel<T, true, true, 128, 128, true, true>), dim3(p.tiles_n * p.tiles_m, p.batch), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((gemm_kernel<T, true, B_KC, 128, 128, true, true>), dim3(p.tiles_n * p.tiles_m, p.batch), dim3(256), 0, s, p);
       if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
       return check_launch("smx_gemm");
     }
