@@ -192,12 +192,6 @@ def block(x, run, params, on_bwd_done=None):
     return _BlockFn.apply(x, run, on_bwd_done, *params)
 
 
-def _wgrad_splits(nrows, m, k):
-    """split-K factor of the wgrad GEMM (reduce dim = frames): ~768 workgroups, >= 256 frames per split."""
-    tiles = ((m + 127) // 128) * ((k + 127) // 128)
-    return max(1, min((768 + tiles - 1) // tiles, (nrows + 255) // 256))
-
-
 # ----------------------------------------------------------------------------------------------------
 # Linear (+bias +act +mask +residual +side input) forward / backward on 2-D row views
 # ----------------------------------------------------------------------------------------------------
