@@ -129,3 +129,22 @@ def test_expdecay_cell_uses_the_linear_time_kernels(dtype, monkeypatch):
     assert calls == [False, True]                      # one forward filter, one transposed filter in the backward
     assert rel_err(y, ref) <= TOL[dtype][0]
     assert rel_err(xg.grad, xo.grad) <= TOL[dtype][1]
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 3), (1, 130), (7, 2)])
+@pytest.mark.parametrize("mode", ["SummaryMixing", "SummaryMixing-fast", "SummaryMixing-lite"])
+def test_cell_degenerate_shapes_vs_oracle(B, T, mode):
+    """Tiny and odd shapes (single frame, single utterance, T < chunk sizes of every kernel), no padding mask."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd.nnet.summary_mixing import SummaryMixing
+    torch.manual_seed(B * 100 + T)
+    d = 32
+    m = SummaryMixing(d, 2, [d], d, [d], d, activation="gelu", global_dropout=0.0, mode=mode)
+    sd = {k: v.double() for k, v in m.state_dict().items()}
+    x = torch.randn(B, T, d)
+    ref = O.summary_mixing(x.double(), sd, "", mode, "gelu", d, None, None)
+    xg = x.cuda().requires_grad_(True)
+    y = m.cuda()(xg)
+    assert y.shape == ref.shape and rel_err(y, ref) <= 1e-3
+    y.sum().backward()
+    assert torch.isfinite(xg.grad).all()
