@@ -43,7 +43,7 @@ CONFIGS = {
     "c1": dict(kind="conformer", d=144, f=576, l=144, layers=2, nhead=4, input=640, B=2, T=50,
                name="config-1 plumbing (2L, d_model=144)"),
     # Branchformer CommonVoice (config 4)
-    "c4": dict(kind="branchformer", d=512, f=0, l=512, layers=18, nhead=1, input=640, B=32, T=250, csgu=3072,
+    "c4": dict(kind="branchformer", d=512, f=0, l=512, layers=18, nhead=1, input=640, B=128, T=250, csgu=3072,
                name="Branchformer-SummaryMixing CV (18L, d_model=512, csgu 3072)"),
 }
 FLOPS_PER_FRAME_FWD = {"c2b": 36.7e6, "c2a": 145.7e6}

@@ -431,22 +431,34 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
       float du = 0.f;
 #pragma unroll
       for (int j = 0; j < K; ++j) du += w[j] * gw[o - j + 2 * PAD];
-      if constexpr (REFLECT) {                       // fold the gradient of the mirrored virtual frames (edge tiles only)
-        const int tau = t0 + f0 + o;
-        if (tau >= 1 && tau <= PAD) {                // virtual frame -tau mirrors frame tau
-          for (int j = 0; j < K; ++j) {
-            const int tt = -tau - j + PAD, r = tt - (t0 - PAD);
-            if (tt >= 0 && tt < p.T && r >= 0 && r < ROWS) du += w[j] * g[r][cl];
+      u[f0 + o][cl] = du;
+    }
+    if constexpr (REFLECT) {
+      // fold the gradient of the mirrored virtual frames into the edge frames.  Kept OUT of the unrolled FMA block above
+      // (a rolled loop over this thread's own 16 rows of the du tile, entered only by tiles that touch an utterance edge)
+      // and with the taps re-read from memory: branches inside the unrolled block and a run-time index into the
+      // register array w[] made every tile of the reflect variant 3.3x slower.
+      if (t0 <= PAD || t0 + DW_TT + PAD >= p.T - 1) {
+        const float* wg = p.w + (long)(cok ? ch : 0) * K;
+        __syncthreads();                               // every du row of the tile is in LDS
+        for (int o = wv; o < DW_TT; o += 4) {          // the (at most 2 * PAD) edge rows are shared among the 4 waves
+          const int tau = t0 + o;
+          float add = 0.f;
+          if (tau >= 1 && tau <= PAD) {                // virtual frame -tau mirrors frame tau: taps j <= PAD - tau
+            for (int j = 0; j <= PAD - tau; ++j) {
+              const int tt = PAD - tau - j, r = tt - (t0 - PAD);
+              if (tt < p.T && r >= 0 && r < ROWS) add += wg[j] * g[r][cl];
+            }
           }
-        }
-        if (tau <= p.T - 2 && tau >= p.T - 1 - PAD) {   // virtual frame 2(T-1)-tau mirrors frame tau
-          for (int j = 0; j < K; ++j) {
-            const int tt = 2 * (p.T - 1) - tau - j + PAD, r = tt - (t0 - PAD);
-            if (tt >= 0 && tt < p.T && r >= 0 && r < ROWS) du += w[j] * g[r][cl];
+          if (tau <= p.T - 2 && tau >= p.T - 1 - PAD) {   // virtual frame 2(T-1)-tau mirrors frame tau: taps j >= T-1-tau+PAD
+            for (int j = max(0, p.T - 1 - tau + PAD); j < K; ++j) {
+              const int tt = 2 * (p.T - 1) - tau - j + PAD, r = tt - (t0 - PAD);
+              if (tt >= 0 && r >= 0 && r < ROWS) add += wg[j] * g[r][cl];
+            }
           }
+          if (add != 0.f) u[o][cl] += add;
         }
       }
-      u[f0 + o][cl] = du;
     }
     __syncthreads();
     for (int it = threadIdx.x; it < DW_TT * LPR; it += 256) {   // GLU backward, 16 B loads / stores
