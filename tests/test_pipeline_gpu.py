@@ -99,3 +99,28 @@ def test_training_steps_reduce_the_ctc_loss():
     assert all(torch.isfinite(torch.tensor(losses)))
     assert torch.isfinite(opt.flat_p).all()
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+def test_gradient_accumulation_over_two_backward_passes():
+    """Parameter gradients accumulate across backward passes (kernels add into param.grad; the deferred reductions are
+    flushed per block): two passes on the same batch give twice the gradient of one."""
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(2)
+    d = 64
+    enc = ConformerEncoder(2, d, 128, 4, kernel_size=15, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d],
+                           mode="SummaryMixing-fast").cuda()
+    x = torch.randn(3, 50, d, device="cuda")
+    pad = (torch.arange(50, device="cuda")[None] < torch.tensor([50, 31, 44], device="cuda")[:, None])
+    r = torch.randn(3, 50, d, device="cuda")
+
+    def run():
+        y, _ = enc(x, src_key_padding_mask=pad)
+        (y * r).sum().backward()
+    run()
+    g1 = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    run()
+    assert len(g1) > 20
+    for n, p in enc.named_parameters():
+        if n in g1:
+            assert rel_err(p.grad, 2.0 * g1[n]) <= 1e-5, n
