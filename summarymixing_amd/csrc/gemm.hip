@@ -1089,6 +1089,9 @@ static int wgrad_splits(int rows, int M, int K, int batch) {
   static const int target_env = getenv("SMX_WGRAD_BLOCKS") ? atoi(getenv("SMX_WGRAD_BLOCKS")) : 0;
   const long target = target_env > 0 ? target_env : 512;
   long s = (target + tiles - 1) / tiles;
+  // a whole split lives on one XCD (XCD x owns splits x, x + 8, ..): a split count that is not a multiple of 8 leaves
+  // XCDs idle (6 splits of a 3072 x 512 weight: 236 us; 8 splits: 199 us)
+  if (s >= 4) s = (s + 7) / 8 * 8;
   static const int min_rows_env = getenv("SMX_WGRAD_MIN_ROWS") ? atoi(getenv("SMX_WGRAD_MIN_ROWS")) : 0;
   const int min_rows = min_rows_env > 0 ? min_rows_env : 512;   // frames per split: fewer, longer splits when the batch is small (slab traffic)
   long smax = (rows + min_rows - 1) / min_rows;
