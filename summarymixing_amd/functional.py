@@ -250,8 +250,10 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
 # ----------------------------------------------------------------------------------------------------
 # VanillaNN: [Linear | ParallelLinear -> act] x blocks ; mask applied in the last block's epilogue
 # ----------------------------------------------------------------------------------------------------
-def mlp_fwd(x, layers, act, mask, need_bwd, dtype):
-    """layers: list of dicts {kind: 'linear'|'parallel', W, b, H}.  x (N, F).  Returns (y, saved)."""
+def mlp_fwd(x, layers, act, mask, need_bwd, dtype, last_res=None, last_drop=None):
+    """layers: list of dicts {kind: 'linear'|'parallel', W, b, H}.  x (N, F).  Returns (y, saved).
+    last_res / last_drop: the last (Linear) layer's epilogue also applies dropout and adds a residual,
+    y = last_res + D(act(z)) (hand the same last_drop to mlp_bwd)."""
     saved = []
     n = len(layers)
     for i, ly in enumerate(layers):
@@ -259,7 +261,8 @@ def mlp_fwd(x, layers, act, mask, need_bwd, dtype):
         mk = mask if last else None
         if ly["kind"] == "linear":
             Wc = wcast(ly["W"], dtype)
-            y, z = linear_fwd(x, Wc, ly["b"], act, mk, save_z=need_bwd)
+            y, z = linear_fwd(x, Wc, ly["b"], act, mk, save_z=need_bwd, res=last_res if last else None,
+                              drop=last_drop if last else None)
         else:
             Wc = wcast(ly["W"], dtype)                     # (H, f, h)
             H, f, h = Wc.shape
@@ -274,8 +277,9 @@ def mlp_fwd(x, layers, act, mask, need_bwd, dtype):
     return x, saved
 
 
-def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None, dz_ready=False):
-    """dz_ready: dy already is the LAST layer's dZ and its bias gradient is done (fused upstream, see linear_bwd `up`)."""
+def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None, dz_ready=False, last_drop=None):
+    """dz_ready: dy already is the LAST layer's dZ and its bias gradient is done (fused upstream, see linear_bwd `up`).
+    last_drop: the dropout mlp_fwd fused into the last layer."""
     n = len(layers)
     for i in range(n - 1, -1, -1):
         ly = layers[i]
@@ -289,7 +293,8 @@ def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=N
             if not first and layers[i - 1]["kind"] == "linear" and act != L.ACT_NONE:
                 up = (saved[i - 1][1], act, saved[i - 1][2], 1.0, None, None)
             dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), gacc(ly["b"]), want_dx,
-                               res_grad if first else None, dx_out=dx_out if first else None, dz_ready=dz_ready, up=up)
+                               res_grad if first else None, dx_out=dx_out if first else None, dz_ready=dz_ready, up=up,
+                               drop=last_drop if i == n - 1 else None)
             dz_ready = up is not None
         else:
             Wc = wcast(ly["W"], dtype)
@@ -587,18 +592,18 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None):
     when those are multi-dimensional (the (F', C) affine of the conv front-end)."""
     y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act)
 
-    def bwd(dy, res=None):
+    def bwd(dy, res=None, out=None):
         gw = gacc(wp).view(-1) if wp is not None else gacc(w)
         gb = gacc(bp).view(-1) if bp is not None else gacc(b)
         if _Deferred.enabled and gw is not None and gb is not None:
             N, D = x.shape
             ws = deferred_ws(gw.data_ptr(), L.lib().smx_layernorm_bwd_workspace(N, D), x.device)
-            dx = ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, None, None, res, act, ws=ws)
+            dx = ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, None, None, res, act, ws=ws, dx_out=out)
             nb = L.lib().smx_layernorm_bwd_blocks(N)
             defer(ws.data_ptr(), gw, 2 * D, nb, 1, D)
             defer(ws.data_ptr() + 4 * D, gb, 2 * D, nb, 1, D)
             return dx
-        return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act)
+        return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act, dx_out=out)
     return y, (bwd if need_bwd else None)
 
 

@@ -124,34 +124,37 @@ class BranchformerEncoderLayer(nn.Module):
                 ops.dropout(y1, pd, sd1, out=cat[:, :c1])
             else:
                 ops.axpby(1.0, y1, out=cat[:, :c1])
-            F.linear_fwd(g, Wpost, Pb["bpost"], out=cat[:, c1:])
-            if pd > 0.0:
-                ops.dropout(cat[:, c1:], pd, sd2, out=cat[:, c1:])
-            m_out, sv_m = F.mlp_fwd(cat, merge, act, None, need, dtype)
-            if pd > 0.0:
-                ops.dropout(m_out, pd, sd3, out=m_out)
-            y = ops.axpby(1.0, x, 1.0, m_out)                                          # x + merge (:279)
+            F.linear_fwd(g, Wpost, Pb["bpost"], out=cat[:, c1:], drop=(pd, sd2) if pd > 0.0 else None)   # Linear + dropout
+            mdrop = (pd, sd3) if pd > 0.0 else None
+            if merge[-1]["kind"] == "linear":              # x + dropout(merge(cat)) (:279) in the last Linear's epilogue
+                y, sv_m = F.mlp_fwd(cat, merge, act, None, need, dtype, last_res=x, last_drop=mdrop)
+            else:
+                m_out, sv_m = F.mlp_fwd(cat, merge, act, None, need, dtype)
+                if pd > 0.0:
+                    ops.dropout(m_out, pd, sd3, out=m_out)
+                y = ops.axpby(1.0, x, 1.0, m_out)
             if not need:
                 return y.view(B, T, d), None
 
             def bwd(dy3):
                 dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
-                dcat = F.mlp_bwd(ops.dropout(dy, pd, sd3) if pd > 0.0 else dy, merge, act, sv_m, dtype)
-                if pd > 0.0:
-                    ops.dropout(dcat[:, :c1], pd, sd1, out=dcat[:, :c1])
-                    ops.dropout(dcat[:, c1:], pd, sd2, out=dcat[:, c1:])
-                # branch 2 backward
-                dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]))
-                du = torch.empty_like(u)
-                dv, du1 = ops.dwconv_bwd(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T, n, k,
-                                         False, L.PAD_REFLECT, 0, gate=u1)
-                ops.axpby(1.0, du1, out=du[:, :n])
-                du2 = bnv(dv)
-                ops.axpby(1.0, du2, out=du[:, n:])
+                if merge[-1]["kind"] == "linear":
+                    dcat = F.mlp_bwd(dy, merge, act, sv_m, dtype, last_drop=mdrop)
+                else:
+                    dcat = F.mlp_bwd(ops.dropout(dy, pd, sd3) if pd > 0.0 else dy, merge, act, sv_m, dtype)
+                # the cell's gradient: a contiguous (N, c1) copy either way, the dropout backward rides in it
+                d1 = ops.dropout(dcat[:, :c1], pd, sd1) if pd > 0.0 else dcat[:, :c1].contiguous()
+                # branch 2 backward (the dropout backward of its half rides in linear_bwd's activation/mask pass)
+                dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
+                                     drop=(pd, sd2) if pd > 0.0 else None)
+                du = torch.empty_like(u)                   # [d gate | d LN input]: both kernels write their half directly
+                dv, _ = ops.dwconv_bwd(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T, n, k,
+                                       False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])
+                bnv(dv, out=du[:, n:])
                 dh2, _ = F.linear_bwd(du, h2, Wpre, zu, act, None, 1.0, F.gacc(Pb["Wpre"]), F.gacc(Pb["bpre"]))
                 dx = bn2(dh2, res=dy)
                 # branch 1 backward
-                dh1 = ops.rows2d(bcell(dcat[:, :c1].contiguous().view(B, T, c1)))
+                dh1 = ops.rows2d(bcell(d1.view(B, T, c1)))
                 dx = bn1(dh1, res=dx)
                 return dx.view(B, T, d)
             return y.view(B, T, d), bwd

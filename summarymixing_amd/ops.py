@@ -216,16 +216,17 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE):
     return y, stats
 
 
-def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE, ws=None):
-    """ws: caller-owned workspace; with dgamma = dbeta = None the partial rows stay in it for a deferred reduce_jobs."""
+def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE, ws=None, dx_out=None):
+    """ws: caller-owned workspace; with dgamma = dbeta = None the partial rows stay in it for a deferred reduce_jobs.
+    dx_out: optional (N, D) destination view (e.g. a column slice of a wider buffer)."""
     N, D = x.shape
-    dx = torch.empty((N, D), dtype=x.dtype, device=x.device)
+    dx = dx_out if dx_out is not None else torch.empty((N, D), dtype=x.dtype, device=x.device)
     pdy, lddy = _mat(dy)
     px, ldx = _mat(x)
     pr, ldr = (_mat(res) if res is not None else (None, 0))
     if ws is None:
         ws = _workspace(L.lib().smx_layernorm_bwd_workspace(N, D), x.device, slot=2)
-    L.check(L.lib().smx_layernorm_bwd(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), D, _p(dgamma),
+    L.check(L.lib().smx_layernorm_bwd(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), _mat(dx)[1], _p(dgamma),
                                       _p(dbeta), N, D, _p(ws), _stream()), "smx_layernorm_bwd")
     return dx
 
@@ -239,15 +240,18 @@ def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=N
     return y
 
 
-def dwconv_bwd(dy, p, w, bias, dw, dbias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None):
+def dwconv_bwd(dy, p, w, bias, dw, dbias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None, dgate_out=None):
     dp = torch.empty((B * T, p.shape[1]), dtype=p.dtype, device=p.device)
-    dgate = torch.empty((B * T, D), dtype=p.dtype, device=p.device) if gate is not None else None
+    dgate = None
+    if gate is not None:
+        dgate = dgate_out if dgate_out is not None else torch.empty((B * T, D), dtype=p.dtype, device=p.device)
     pdy, lddy = _mat(dy)
     pp, ldp = _mat(p)
     pg, ldg = (_mat(gate) if gate is not None else (None, 0))
     ws = _workspace(L.lib().smx_dwconv1d_glu_bwd_workspace(B, T, D, k), p.device, slot=4)
     L.check(L.lib().smx_dwconv1d_glu_bwd(dt(p), pdy, lddy, pp, ldp, _p(w), _p(bias), pg, ldg, _p(dp), dp.shape[1],
-                                         _p(dgate), D, _p(dw), _p(dbias), B, T, D, k, 1 if glu else 0, pad_mode, chunk,
+                                         _p(dgate), (_mat(dgate)[1] if dgate is not None else 0), _p(dw), _p(dbias), B, T, D, k,
+                                         1 if glu else 0, pad_mode, chunk,
                                          _p(ws), _stream()), "smx_dwconv1d_glu_bwd")
     return dp, dgate
 
