@@ -45,8 +45,13 @@ CONFIGS = {
     # Branchformer CommonVoice (config 4)
     "c4": dict(kind="branchformer", d=512, f=0, l=512, layers=18, nhead=1, input=640, B=128, T=250, csgu=3072,
                name="Branchformer-SummaryMixing CV (18L, d_model=512, csgu 3072)"),
+    # BASELINE.json configs[4] / SURVEY §8d "C5": long-utterance stress, x (8, 30000, 512) N(0,1) straight into the
+    # 12-layer encoder stack (no input Linear / PE: the reference's PE table ends at 2500 frames), forward only, ragged
+    # lengths U(0.5,1).  With --seq-parallel under torchrun the TIME axis is sharded over the ranks (strong scaling).
+    "c5": dict(kind="conformer", stack_only=True, d=512, f=2048, l=512, layers=12, nhead=4, input=512, B=8, T=30000,
+               name="Long-utterance stress C5 (12L Conformer-SummaryMixing stack, d_model=512, d_ffn=2048, fast)"),
 }
-FLOPS_PER_FRAME_FWD = {"c2b": 36.7e6, "c2a": 145.7e6}
+FLOPS_PER_FRAME_FWD = {"c2b": 36.7e6, "c2a": 145.7e6, "c5": 145.0e6}   # SURVEY §8(a) A12 (c5: without the input Linear)
 
 
 def build_encoder(cfg, device, dropout=0.0):
@@ -62,6 +67,20 @@ def build_encoder(cfg, device, dropout=0.0):
         net = TransformerASR(encoder_module="branchformer", mode="SummaryMixing", summary_out_dim=cfg["d"],
                              csgu_linear_units=cfg["csgu"], **kw)
     return EncoderWrapper(net).to(device).train()
+
+
+def build_stack(cfg, device):
+    """Config 5: the bare ConformerEncoder stack (eval)."""
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(3407)
+    enc = ConformerEncoder(cfg["layers"], cfg["d"], cfg["f"], cfg["nhead"], kernel_size=31, activation="swish", dropout=0.0,
+                           attention_type="SummaryMixing", local_proj_hid_dim=[cfg["l"]], local_proj_out_dim=cfg["l"],
+                           summary_hid_dim=[cfg["l"]], mode="SummaryMixing-fast")
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+    return enc.to(device).eval()
 
 
 def synthetic_batch(cfg, rank, device, dtype):
@@ -159,6 +178,8 @@ def cpu_baseline(cfg, train):
     from oracle import smx_oracle as O
     cores = min(os.cpu_count() or 1, 32)   # torch CPU scales poorly past ~32 threads on these small GEMMs
     torch.set_num_threads(cores)
+    if cfg.get("stack_only"):
+        return cpu_baseline_stack(cfg, cores)
     enc = build_encoder(cfg, "cpu")
     sd = {k: v.detach().clone().requires_grad_(train and v.is_floating_point())
           for k, v in enc.transformer.state_dict().items() if k != "positional_encoding.pe"}
@@ -189,6 +210,30 @@ def cpu_baseline(cfg, train):
                       f"of the same model, {n} steps, torch {torch.__version__}, {cores} threads"}
 
 
+def cpu_baseline_stack(cfg, cores):
+    """Config 5 on the host: the oracle's ConformerEncoder forward on ONE utterance of 3000 frames of the same model."""
+    from oracle import smx_oracle as O
+    enc = build_stack(cfg, "cpu")
+    sd = {k: v.detach() for k, v in enc.state_dict().items()}
+    T = 3000
+    x = torch.randn(1, T, cfg["d"], generator=torch.Generator().manual_seed(1234))
+    pad = torch.ones(1, T, dtype=torch.bool)
+
+    def step():
+        with torch.no_grad():
+            O.conformer_encoder(x, sd, "", "swish", "SummaryMixing-fast", cfg["l"], None, pad)
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 1 or (n < 20 and time.perf_counter() - t0 < 12.0):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": T / dt, "unit": "encoder frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/smx_oracle.py conformer_encoder fwd, fp32, 1 x {T} frames of the same stack, {n} passes, "
+                      f"torch {torch.__version__}, {cores} threads"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +248,9 @@ def main():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="capture the step once in a hipGraph and replay it (auto: single-GPU runs below 40000 frames per step, "
                          "where the host launch path is the bottleneck; neutral above)")
+    ap.add_argument("--seq-parallel", action="store_true",
+                    help="config c5 under torchrun: shard the TIME axis over the ranks (summarymixing_amd/sequence_parallel.py) "
+                         "instead of the utterances; the job then processes ONE batch (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -228,6 +276,10 @@ def main():
         cfg["T"] = args.frames
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     train = args.mode == "train"
+    if cfg.get("stack_only"):
+        return main_stack(args, cfg, dtype, dev, rank, world)
+    if args.seq_parallel:
+        raise SystemExit("--seq-parallel is the long-utterance mode of --config c5")
 
     from summarymixing_amd.trainer import FlatAdamW
     enc = build_encoder(cfg, dev, args.dropout if train else 0.0)
@@ -331,6 +383,68 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, train)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def main_stack(args, cfg, dtype, dev, rank, world):
+    """Config 5: encoder-stack forward on (B, T, d).  Default: every rank runs its own batch (weak scaling, no
+    collective).  --seq-parallel: one batch, time axis sharded, two small exchanges per layer."""
+    import contextlib
+    from summarymixing_amd import sequence_parallel as SP
+    enc = build_stack(cfg, dev)
+    sp = args.seq_parallel and world > 1
+    B, T = cfg["B"], cfg["T"]
+    g = torch.Generator().manual_seed(1234 + (0 if sp else rank))
+    x = torch.randn(B, T, cfg["d"], generator=g)
+    lens = torch.round((0.5 + 0.5 * torch.rand(B, generator=g)) * T).long()
+    lens[0] = T
+    pad = torch.arange(T)[None, :] < lens[:, None]
+    x = (x * pad[..., None]).to(dev).to(dtype)
+    pad = pad.to(dev)
+    ctx = SP.sequence_parallel() if sp else contextlib.nullcontext()
+    with ctx:
+        if sp:
+            x, pad = SP.shard(x), SP.shard(pad)
+
+        def step():
+            with torch.no_grad():
+                enc(x, src_key_padding_mask=pad)
+
+        def barrier():
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    frames_per_step = B * T * (1 if sp else world)
+    value = frames_per_step * args.steps / dt
+    out = {"metric": "encoder frames/s (whole node), long-utterance Conformer-SummaryMixing encoder stack forward",
+           "value": value, "unit": "encoder frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sp else "weak",
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": cfg["name"] + " forward", "per_gpu_batch": B, "enc_frames_per_utt": T if not sp else T // world,
+                      "padded_frames_per_step": frames_per_step, "valid_frames": int(lens.sum()),
+                      "input": f"(B,T,{cfg['d']}) N(0,1) into the encoder stack, lengths U(0.5,1), zero padded",
+                      "parallelism": (f"sp{world} (time axis sharded)" if sp else f"dp{world}"), "launch": "eager"},
+           "model_tflops": value * FLOPS_PER_FRAME_FWD["c5"] / 1e12}
+    if rank == 0:
+        if not args.no_roofline:
+            out["roofline"] = roofline_pool(dtype)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, False)
+        print(json.dumps(out), flush=True)
+    if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

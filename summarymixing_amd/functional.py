@@ -22,6 +22,7 @@ import torch
 
 from . import _lib as L
 from . import ops
+from . import sequence_parallel as SP
 
 # ----------------------------------------------------------------------------------------------------
 # parameter plumbing: compute-dtype shadows of fp32 master weights, gradient buffers
@@ -426,7 +427,19 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
 
         # ---- summary ------------------------------------------------------------------------------
         inv = None
-        if pool_kind == "mean":
+        sp = SP.enabled()
+        if sp and pool_kind != "mean":
+            raise NotImplementedError("sequence-parallel mode supports the per-utterance mean only (no sum_mask / expdecay)")
+        if sp:
+            # time axis sharded over the group: local partial sums + valid-frame counts, ONE all-reduce, then the mean
+            ssum, _ = ops.masked_mean(s, mask, B, T, scale=False)
+            cnt = (mask.view(B, T).sum(1, dtype=torch.float32) if mask is not None
+                   else torch.full((B,), float(T), dtype=torch.float32, device=dev))
+            buf = torch.cat([ssum, cnt[:, None]], 1)
+            SP.all_reduce_sum(buf)
+            inv = (1.0 / buf[:, sdim]).contiguous()
+            sbar = (buf[:, :sdim] * inv[:, None]).contiguous()
+        elif pool_kind == "mean":
             sbar, inv = ops.masked_mean(s, mask, B, T, scale=True, want_inv=True)   # (B, sdim) fp32
         elif pool_kind == "chunk":
             sbar = torch.empty((N, sdim), dtype=dtype, device=dev)
@@ -443,6 +456,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             def bwd_lite(dy3):
                 dy = ops.rows2d(dy3.contiguous())
                 dsbar, _ = ops.masked_mean(dy, None, B, T, scale=False)            # sum over time
+                SP.all_reduce_sum(dsbar)                                           # (sequence-parallel: over all shards)
                 ds = torch.empty((N, sdim), dtype=dtype, device=dev)
                 ops.bcast_rows(dsbar, inv, ds, B, T)
                 dx = mlp_bwd(ds, P["summary_proj"], act, sv_s, dtype)
@@ -512,6 +526,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
 
             def bcast_ds(dsbar_):
                 nonlocal sum_done
+                SP.all_reduce_sum(dsbar_)                  # sequence-parallel: the mean's gradient sums over every shard
                 if mode == "SummaryMixing-fast" and fuse_local:
                     z_g, mk_g = sv_g[-1][1], sv_g[-1][2]
                     if z_g is not None or mk_g is not None:
@@ -630,6 +645,8 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
 def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True, p=0.0):
     """y = [x +] mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534)."""
     d = x.shape[1]
+    if SP.enabled():
+        return _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual, p)
     h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd)
     Wp = wcast(P["Wp"], dtype).view(2 * d, d)                    # Conv1d(d,2d,1) weight viewed as a Linear
     p_, _ = linear_fwd(h, Wp, P["bp"])
@@ -651,6 +668,66 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
                                gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
         dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
         return ln1_b(dh, res=dy if residual else None)
+    return y, bwd
+
+
+def _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual, p):
+    """conv_module_fwd with the time axis sharded (sequence_parallel.py): the (k-1)/2 frames either side come from the
+    neighbour ranks as halos of the module INPUT; LN / pointwise conv / GLU are recomputed on them, the depthwise conv
+    runs on the extended sequence and only the centre T frames go on.  At the two ends of the whole sequence the halo
+    must act as the conv's zero padding, i.e. zero AFTER the GLU: the pointwise output rows there are cleared."""
+    if chunk:
+        raise NotImplementedError("sequence-parallel mode does not support the Dynamic Chunk Convolution")
+    d = x.shape[1]
+    k = P["wd"].shape[-1]
+    H = (k - 1) // 2
+    if T < H:
+        raise ValueError(f"sequence-parallel shards need at least {H} frames per rank (got {T})")
+    Te = T + 2 * H
+    first_rank, last_rank = SP.rank() == 0, SP.rank() == SP.world() - 1
+    x3 = x.view(B, T, d)
+    lh, rh = SP.exchange_halos(x3[:, :H], x3[:, T - H:])
+    xe = torch.cat([lh, x3, rh], 1).view(B * Te, d)
+    h, ln1_b = ln_fwd(xe, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd)
+    Wp = wcast(P["Wp"], dtype).view(2 * d, d)
+    p_, _ = linear_fwd(h, Wp, P["bp"])
+
+    def clear_ends(t2, width):
+        t3 = t2.view(B, Te, width)
+        if first_rank:
+            t3[:, :H].zero_()
+        if last_rank:
+            t3[:, Te - H:].zero_()
+    clear_ends(p_, 2 * d)
+    wd = P["wd"].detach().reshape(d, k)
+    ce = ops.dwconv_fwd(p_, wd, P["bd"].detach() if P["bd"] is not None else None, B, Te, d, k, True, L.PAD_ZERO, 0)
+    c = ce.view(B, Te, d)[:, H:H + T].contiguous().view(B * T, d)
+    a, ln2_b = ln_fwd(c, P["ln2_w"], P["ln2_b"], 1e-5, need_bwd, act)
+    Wo = wcast(P["Wo"], dtype)
+    dr = (p, ops.new_dropout_seed()) if p > 0.0 else None
+    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None, drop=dr)
+    if not need_bwd:
+        return y, None
+
+    def bwd(dy):
+        da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr)
+        dc = ln2_b(da)
+        dce = torch.zeros((B, Te, d), dtype=dtype, device=x.device)       # the halo outputs were dropped: zero gradient
+        dce[:, H:H + T] = dc.view(B, T, d)
+        gwd = gacc(P["wd"])
+        dp, _ = ops.dwconv_bwd(dce.view(B * Te, d), p_, wd, P["bd"].detach() if P["bd"] is not None else None,
+                               gwd.view(d, k), gacc(P["bd"]), B, Te, d, k, True, L.PAD_ZERO, 0)
+        clear_ends(dp, 2 * d)                                             # nothing flows into the zero padding
+        dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
+        dxe = ln1_b(dh).view(B, Te, d)
+        g_first, g_last = SP.return_halo_grads(dxe[:, :H], dxe[:, Te - H:])
+        dx = dxe[:, H:H + T].contiguous()
+        dx[:, :H] += g_first
+        dx[:, T - H:] += g_last
+        dx = dx.view(B * T, d)
+        if residual:
+            dx = ops.axpby(1.0, dx, 1.0, dy)
+        return dx
     return y, bwd
 
 

@@ -1,0 +1,108 @@
+"""Sequence-parallel mode (summarymixing_amd/sequence_parallel.py): the time axis of one batch sharded
+over 2 ranks must reproduce the unsharded encoder - outputs, input gradients and (summed) parameter gradients.
+
+The GPU box has ONE device, so the two ranks share cuda:0 and talk over gloo (host-staged); on a multi-GPU node the same
+code runs one rank per GPU over RCCL.  Every rank first runs the unsharded encoder itself as the reference."""
+import os
+import subprocess
+import sys
+import socket
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SMX_ROOT"])
+from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+from summarymixing_amd import sequence_parallel as SP
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+mode, drop_ok = os.environ["SMX_MODE"], True
+d, B, T = 64, 3, 96
+torch.manual_seed(5)
+enc = ConformerEncoder(2, d, 128, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                       local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode=mode)
+with torch.no_grad():
+    for n, p in enc.named_parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_normal_(p)
+        elif "bias" in n:
+            p.normal_(0, 0.05)
+enc = enc.cuda()
+x = torch.randn(B, T, d).cuda()
+r = torch.randn(B, T, d).cuda()
+lens = torch.tensor([T, 70, 40])                    # utterance 2 ends inside shard 0: shard 1 holds only its padding
+pad = (torch.arange(T)[None] < lens[:, None]).cuda()
+if os.environ.get("SMX_NOMASK") == "1":
+    pad = None
+
+xf = x.clone().requires_grad_(True)
+y, _ = enc(xf, src_key_padding_mask=pad)
+(y * r).sum().backward()
+gfull = {n: p.grad.clone() for n, p in enc.named_parameters()}
+dxf = xf.grad.clone()
+for p in enc.parameters():
+    p.grad = None
+
+with SP.sequence_parallel():
+    xl = SP.shard(x).requires_grad_(True)
+    pl = SP.shard(pad) if pad is not None else None
+    yl, _ = enc(xl, src_key_padding_mask=pl)
+    (yl * SP.shard(r)).sum().backward()
+    SP.reduce_gradients(list(enc.parameters()))
+    y_ref, dx_ref = SP.shard(y.detach()), SP.shard(dxf)
+
+def close(a, b, what, tol=2e-4):
+    err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-6)
+    assert err < tol, f"rank {rank} {what}: rel err {err:.3e}"
+
+close(yl.detach(), y_ref, "output")
+close(xl.grad, dx_ref, "input gradient")
+for n, p in enc.named_parameters():
+    close(p.grad, gfull[n], "grad " + n, 5e-4)
+dist.barrier()
+print(f"rank {rank} OK")
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(mode, nomask=False):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SMX_ROOT=ROOT, SMX_MODE=mode, SMX_NOMASK="1" if nomask else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+            out += "\n[timeout]"
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {rank} OK" in out, f"rank {rank} failed:\n{out[-3000:]}"
+
+
+@pytest.mark.parametrize("mode", ["SummaryMixing-fast", "SummaryMixing", "SummaryMixing-lite"])
+def test_sequence_parallel_matches_unsharded(mode):
+    _run(mode)
+
+
+def test_sequence_parallel_no_padding_mask():
+    _run("SummaryMixing-fast", nomask=True)

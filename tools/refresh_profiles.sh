@@ -11,6 +11,7 @@ python bench.py --batch 64 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/r01_b
 python bench.py --config c2a --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/r01_bench_c2a.json"
 python bench.py --mode forward --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/r01_bench_fwd.json"
 python bench.py --config c4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/r01_bench_c4.json"
+python bench.py --config c5 --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/r01_bench_c5.json"
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_refresh && rocprofv3 --kernel-trace --stats -d /tmp/prof_refresh -o p -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1)
 DB=$(find /tmp/prof_refresh -name '*.db' | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (7 steps incl. warmup; C2b, B=128 x T=500, bf16, dropout 0.15)"; python tools/prof_summary.py "$DB" 7; echo; echo "## GEMM launches by grid (shape)"; python tools/prof_by_grid.py "$DB" 7; } > "$OUT/r01_step_c2b_${TAG}.txt"
