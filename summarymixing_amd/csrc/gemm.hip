@@ -848,6 +848,249 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 #undef SMX_STAMP
 }
 
+
+// ---- row-panel kernel: output-heavy GEMMs with a short reduction (bf16, K <= 256, M >= 512) ---------------------------
+// The FFN up-projection shape (K = 256 -> M = 1024) writes 8x the bytes it reads, and in gemm_kernel the stores of one
+// workgroup's epilogue sit in front of the operand loads of its CU neighbours (the vector-memory pipeline is in order):
+// main loop and epilogue ablate to 45 + 64 us but run in 91-118 us.  Here ONE workgroup per CU owns a 128-row panel of A,
+// keeps all of it in LDS (<= 64 KB) and walks the column tiles of the output:
+//   * A is fetched once per panel instead of once per column tile;
+//   * the (L2-resident) weight tile of column tile c+1 is requested into registers DURING the main loop of tile c, one
+//     K step at a time right after that step's registers were written to LDS, and waited for BEFORE the first store of
+//     tile c's epilogue - so no load is ever queued behind this workgroup's own stores (vmcnt retires in order and
+//     counts stores), and the stores of tile c drain while tile c+1 multiplies;
+//   * the epilogue staging rows have their own LDS, so the next B stage can be written while slow waves still store.
+// LDS: A panel 64 KB + two B stages + 33 KB staging = 131-140 KB (dynamic), 1 workgroup (4 waves) per CU.
+// unconditional 16-byte operand loads for the panel kernel (rows clamped instead of predicated: K % 64 == 0, and the
+// columns / rows past the edge are never stored) - a predicated load costs a branch and a conservative vmcnt(0)
+template <bool KC, int ROWS>
+__device__ __forceinline__ void panel_load(uint4 (&reg)[ROWS / 32], const bf16_t* base, long ld, int row0, int rows_total,
+                                           int k0, int t) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int v = t + 256 * i;
+    if constexpr (KC) {
+      const int rg = min(row0 + (v >> 3), rows_total - 1);
+      reg[i] = *reinterpret_cast<const uint4*>(base + (long)rg * ld + k0 + (v & 7) * 8);
+    } else {
+      constexpr int RC = ROWS / 8;
+      const int rg = min(row0 + (v % RC) * 8, rows_total - 8);
+      reg[i] = *reinterpret_cast<const uint4*>(base + (long)(k0 + v / RC) * ld + rg);
+    }
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void settle_regs(uint4 (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) { settle(r[i].x); settle(r[i].y); settle(r[i].z); settle(r[i].w); }
+}
+
+// LDS plan of the panel kernel: [A panel: 4 K steps][B stage(s)][epilogue staging (aliases the B stage when it is single)]
+template <bool B_KC, int TN>
+struct PanelLds {
+  static constexpr int A_BYTES = lds_bytes<bf16_t, TN, true>();
+  static constexpr int B_BYTES = lds_bytes<bf16_t, 128, B_KC>();
+  static constexpr int NBUF = TN == 128 ? 2 : 1;
+  static constexpr int EPI_BYTES = ((TN / 2) * (128 * 4 + 16) + 63) / 64 * 64;
+  static constexpr bool ALIAS = NBUF == 1;
+  static constexpr int BS_BYTES = ALIAS ? (B_BYTES > EPI_BYTES ? B_BYTES : EPI_BYTES) : NBUF * B_BYTES;
+  static constexpr int STG_OFF = 4 * A_BYTES + (ALIAS ? 0 : BS_BYTES);
+  static constexpr int RED_OFF = 4 * A_BYTES + BS_BYTES + (ALIAS ? 0 : EPI_BYTES);
+  static constexpr int TOTAL = RED_OFF + (128 + 128 + TN) * 4;
+  static constexpr int OCC = TN == 128 ? 1 : (3 * TOTAL <= 160 * 1024 ? 3 : 2);
+};
+
+// ---- row-panel kernel: output-heavy GEMMs with a short reduction (bf16, K <= 256, M >= 512) ---------------------------
+// The FFN up-projection shape (K = 256 -> M = 1024) writes 8x the bytes it reads.  In gemm_kernel every 128 x 128 output
+// tile is a workgroup of its own: it pays a full operand round trip (nothing to multiply until the tile's A and B rows have
+// arrived) and its loads queue behind the epilogue stores of the CU's other workgroups (the vector-memory pipeline is
+// in order) - main loop and epilogue ablate to 45 + 64 us but run in 91-118 us.  Here a workgroup owns a TN-row panel
+// of A, keeps ALL of it in LDS (TN x K <= 64 KB) and walks the column tiles of the output:
+//   * A is fetched once per panel instead of once per column tile;
+//   * the (L2-resident) weight tile of column tile c+1 is requested into registers DURING the main loop of tile c - each
+//     K step's registers are re-loaded right after they were written to LDS - and waited for BEFORE the first store of
+//     tile c's epilogue: no load is ever queued behind this workgroup's own stores (vmcnt retires in order and counts
+//     stores), and the stores of tile c drain while tile c+1 multiplies;
+//   * all loads are unconditional (clamped rows) and nothing is pending at the loop head, so the compiler places no
+//     vmcnt wait inside the main loop.
+// Status: correct (tests/test_kernels_gpu.py::test_gemm_row_panel_variant_in_subprocess) but SLOWER than the tiled kernel
+// (FFN up-projection at 64000 frames: 152 us vs 98 us) and therefore opt-in (SMX_GEMM_PANEL=1).  Per-wave clock stamps
+// (tools/panel_stamps.py): with ONE workgroup (4 waves) per CU - the 131 KB of LDS allow no more - every phase is
+// latency-bound: main loop 6.3 K cycles per column tile (the 64 MFMAs need 2 K), each 64-row epilogue phase 6.3 K, and
+// even the skeleton without MFMA and epilogue (4 x [LDS write of a B stage + its reload + barrier]) takes 3.6 K: one
+// wave per SIMD hides nothing.  A TN = 64 build (51 KB, three workgroups per CU) spilled at the 168-register budget
+// and was slower still.  What the experiment settles: pure stores in this pattern run at 6.8 TB/s even from one
+// workgroup per CU that drains after every tile (tools/store_probe2.hip), so the tiled kernel's epilogue is not bound
+// by store bandwidth; the next attempt should keep >= 2 waves per SIMD (a 512-thread workgroup whose wave groups
+// work on different column tiles of the same LDS-resident panel).
+template <bool B_KC, int TN>
+__global__ __launch_bounds__(256, (PanelLds<B_KC, TN>::OCC)) void gemm_panel_kernel(GemmParams p) {
+  typedef bf16_t T;
+  typedef PanelLds<B_KC, TN> PL;
+  constexpr int BK = 64, TM = 128, KS_MAX = 4, WN = TN / 2, WM = 64, FN = WN / 32, FM = 2;
+  constexpr int A_BYTES = PL::A_BYTES, B_BYTES = PL::B_BYTES;
+  constexpr int PH_ROWS = TN / 2, NPH = 2, STG_LD = TM * 4 + 16;
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  char* Ap = dsm;
+  char* Bs = dsm + KS_MAX * A_BYTES;
+  char* stg = dsm + PL::STG_OFF;
+  float* red = reinterpret_cast<float*>(dsm + PL::RED_OFF);
+  float* side = red + TM;                                // bias[TM] | row factors[TN]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  const int tile_n = blockIdx.x, n0 = tile_n * TN;
+  const int ksteps = p.K / BK;
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B);
+  const smx_epilogue& e = p.e;
+  long long* dbgp = p.dbg ? p.dbg + ((long)blockIdx.x * 4 + wave) * 8 : nullptr;
+#define SMX_PSTAMP(k) do { if (dbgp && lane == 0) dbgp[k] = clock64(); } while (0)
+  SMX_PSTAMP(0);
+
+  uint4 rb[KS_MAX][TM / 32];
+#pragma unroll
+  for (int ks = 0; ks < KS_MAX; ++ks)
+#pragma unroll
+    for (int i = 0; i < TM / 32; ++i) rb[ks][i] = make_uint4(0, 0, 0, 0);
+  {
+    uint4 ra[KS_MAX][TN / 32];
+#pragma unroll
+    for (int ks = 0; ks < KS_MAX; ++ks)
+      if (ks < ksteps) panel_load<true, TN>(ra[ks], A, p.lda, n0, p.N, ks * BK, t);
+#pragma unroll
+    for (int ks = 0; ks < KS_MAX; ++ks)
+      if (ks < ksteps) panel_load<B_KC, TM>(rb[ks], B, p.ldb, 0, p.M, ks * BK, t);
+#pragma unroll
+    for (int ks = 0; ks < KS_MAX; ++ks)
+      if (ks < ksteps) stage_store<T, true, TN>(ra[ks], Ap + ks * A_BYTES, t);
+  }
+  // (one-time) nothing is pending at the loop head
+#pragma unroll
+  for (int ks = 0; ks < KS_MAX; ++ks) settle_regs(rb[ks]);
+  float bias_v = (t < TM && e.bias && t < p.M) ? e.bias[t] : 0.f;
+  if (t >= TM && t < TM + TN) {
+    const int n = n0 + t - TM;
+    side[t] = ((e.row_mask && n < p.N) ? (e.row_mask[n] ? 1.f : 0.f) : 1.f) * e.alpha;
+  }
+  const int osz = (e.out_mode == SMX_OUT_T) ? 2 : 4;
+  SMX_PSTAMP(1);
+
+#pragma unroll 1
+  for (int tm = 0; tm < p.tiles_m; ++tm) {
+    const int m0 = tm * TM;
+    const bool more = tm + 1 < p.tiles_m;
+    if (tm == 1) SMX_PSTAMP(2);
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS_MAX; ++ks) {
+      if (ks < ksteps) {
+        char* Bb = Bs + (PL::NBUF == 2 ? (ks & 1) * B_BYTES : 0);
+        stage_store<T, B_KC, TM>(rb[ks], Bb, t);
+        if (more) panel_load<B_KC, TM>(rb[ks], B, p.ldb, m0 + TM, p.M, ks * BK, t);   // the next column tile's K step
+        lds_barrier();
+        const char* As = Ap + ks * A_BYTES;
+        if (!(p.ablate & 2)) {
+#pragma unroll
+          for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 fa[FN], fb[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<true, TN>(As, wn * WN + i * 32 + l31, kk, hi);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<B_KC, TM>(Bb, wm * WM + j * 32 + l31, kk, hi);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+              for (int j = 0; j < FM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          }
+        }
+        if (PL::NBUF == 1) lds_barrier();                // single B stage: every wave is done reading it
+      }
+    }
+    if (tm == 1) SMX_PSTAMP(3);
+    if (t < TM) side[t] = bias_v;                        // (visible after the first epilogue barrier)
+    float bias_n = 0.f;
+    if (more) {
+      if (t < TM && e.bias && m0 + TM + t < p.M) bias_n = e.bias[m0 + TM + t];
+      // the next tile's operands have landed before this tile's first store: nothing waits behind the stores
+#pragma unroll
+      for (int ks = 0; ks < KS_MAX; ++ks) settle_regs(rb[ks]);
+      settle(bias_n);
+    }
+    if (tm == 1) SMX_PSTAMP(4);
+    if (p.ablate & 1) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sacc += acc[i][j][q];
+      if (sacc == 123.456f) reinterpret_cast<float*>(p.C)[0] = sacc;
+      lds_barrier();
+      bias_v = bias_n;
+      continue;
+    }
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      lds_barrier();
+      if (wn == ph) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(stg + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                  make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+      }
+      lds_barrier();
+      if (osz == 2) epilogue_phase<T, 2, TN, TM, true>(p, stg, side, ph, n0 + ph * PH_ROWS, m0, 0, 0, t);
+      else epilogue_phase<T, 4, TN, TM, true>(p, stg, side, ph, n0 + ph * PH_ROWS, m0, 0, 0, t);
+      if (e.colsum) {
+        lds_barrier();
+        if (t < TM) {
+          const int rows = min(PH_ROWS, p.N - (n0 + ph * PH_ROWS));
+          float sum = ph == 0 ? 0.f : red[t];
+          for (int r = 0; r < rows; ++r) sum += *reinterpret_cast<const float*>(stg + r * STG_LD + t * 4);
+          if (ph < NPH - 1) red[t] = sum;
+          else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = sum;
+        }
+      }
+      if (tm == 1) SMX_PSTAMP(5 + ph);
+    }
+    if (PL::ALIAS) lds_barrier();                        // the staging rows are the next tile's B stage
+    bias_v = bias_n;
+  }
+  SMX_PSTAMP(7);
+#undef SMX_PSTAMP
+}
+
+template <bool B_KC, int TN>
+static int launch_panel(GemmParams& p, hipStream_t s) {
+  constexpr int LDS = PanelLds<B_KC, TN>::TOTAL;
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<B_KC, TN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return fail(SMX_ELAUNCH, "smx_gemm: cannot reserve %d bytes of LDS for the panel kernel", LDS);
+    once = true;
+  }
+  p.tiles_n = (p.N + TN - 1) / TN;
+  p.tiles_m = (p.M + 127) / 128;
+  hipLaunchKernelGGL((gemm_panel_kernel<B_KC, TN>), dim3(p.tiles_n), dim3(256), LDS, s, p);
+  if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
+  return check_launch("smx_gemm");
+}
+
 // ---- host dispatch ------------------------------------------------------------------------------------------
 template <typename T, bool A_KC, bool B_KC, int TN, int TM>
 static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
@@ -873,6 +1116,16 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   static const int wide_env = getenv("SMX_GEMM_WIDE") ? atoi(getenv("SMX_GEMM_WIDE")) : -1;
   const bool wide = wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 512 && p.M <= 512));
   static const int dma_env = getenv("SMX_GEMM_DMA") ? atoi(getenv("SMX_GEMM_DMA")) : 0;
+  // row-panel kernel (see gemm_panel_kernel; experimental, opt-in - measured slower than the tiled kernel):
+  // short reduction, wide output, enough panels to fill the chip.
+  // SMX_GEMM_PANEL: 0 off (default), 1 epilogues without a per-element side input, 2 every eligible epilogue
+  static const int panel_env = getenv("SMX_GEMM_PANEL") ? atoi(getenv("SMX_GEMM_PANEL")) : 0;
+  if constexpr (sizeof(T) == 2 && A_KC) {
+    const bool side_in = p.e.res || p.e.c0 || (p.e.flags & SMX_EPI_ACT_GRAD);
+    if (panel_env && vec && p.splits == 1 && p.batch == 1 && p.K % 64 == 0 && p.K >= 64 && p.K <= 256 && p.M >= 512 &&
+        (p.N + 127) / 128 >= 256 && p.e.out_mode != SMX_OUT_ATOMIC_F32 && (panel_env >= 2 || !side_in))
+      return launch_panel<B_KC, 128>(p, s);
+  }
   if constexpr (sizeof(T) == 2 && A_KC) {
     if (dma_env && vec && !force_small && p.splits == 1 && p.K % 64 == 0 && p.K >= 64 && p.N >= 128 && p.M >= 128 &&
         big >= 256 && (reinterpret_cast<uintptr_t>(p.A) % 16 == 0) && (dma_env != 2 || !wide)) {
