@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   dispatch_act(act, [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
     for (int row0 = (blockIdx.x * 4 + w) * U; row0 < N_; row0 += gridDim.x * 4 * U) {
-      float fdy[U][CH][VW], fx[U][CH][VW], mean[U], rstd[U];
+      float fdy[U][CH][VW], fx[U][CH][VW], fr[U][CH][VW == 4 ? 4 : 1], mean[U], rstd[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int row = min(row0 + u, N_ - 1);           // tail rows re-read the last row (results discarded)
@@ -575,6 +575,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
           const int cc = c < D ? c : 0;                  // idle lanes re-read column 0
           if constexpr (VW == 4) { load4<T>(dY + (long)row * lddy + cc, fdy[u][i]); load4<T>(X + (long)row * ldx + cc, fx[u][i]); }
           else { fdy[u][i][0] = to_f32(dY[(long)row * lddy + cc]); fx[u][i][0] = to_f32(X[(long)row * ldx + cc]); }
+          // the residual gradient is requested with the operands: loaded after the reductions it was a second dependent
+          // round trip per row group
+          if constexpr (VW == 4) {
+            if (R) load4<T>(R + (long)row * ldr + cc, fr[u][i]);
+            else fr[u][i][0] = fr[u][i][1] = fr[u][i][2] = fr[u][i][3] = 0.f;
+          }
         }
       }
       float s1[U], s2[U];
@@ -617,9 +623,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             float o[VW];
 #pragma unroll
             for (int j = 0; j < VW; ++j) o[j] = rstd[u] * (fdy[u][i][j] - m1 - fx[u][i][j] * m2);
-            if (R) {
-              if constexpr (VW == 4) { float r[4]; load4<T>(R + (long)row * ldr + c, r); for (int j = 0; j < 4; ++j) o[j] += r[j]; }
-              else o[0] += to_f32(R[(long)row * ldr + c]);
+            if constexpr (VW == 4) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] += fr[u][i][j];
+            } else {
+              if (R) o[0] += to_f32(R[(long)row * ldr + c]);
             }
             if constexpr (VW == 4) store4<T>(dX + (long)row * lddx + c, o);
             else dX[(long)row * lddx + c] = from_f32<T>(o[0]);
@@ -1185,6 +1193,9 @@ static int ln_bwd_blocks(int N) {
   return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
 }
 
+#ifndef SMX_LNB_U1
+#define SMX_LNB_U1 2      // rows in flight per wave for D <= 256
+#endif
 template <typename T>
 static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma, const float* beta,
                        int act, const float* stats,
@@ -1194,7 +1205,7 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
   const bool vec = D % 4 == 0 && ok(dY, lddy) && ok(X, ldx) && ok(R, ldr) && ok(dX, lddx);
   const int blocks = ln_bwd_blocks(N);
   dim3 grid(blocks);
-#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH, (CH <= 2 ? 2 : 1)>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D)
+#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH, (VW == 4 && CH == 1 ? SMX_LNB_U1 : (CH <= 2 ? 2 : 1))>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D)
   if (vec) {
     if (D <= 256) LN_BWD(4, 1);
     else if (D <= 512) LN_BWD(4, 2);
