@@ -342,7 +342,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
   constexpr int VW = DwVec<T>::N, LPR = DW_CT / VW, NITEM = (ROWS * LPR + 255) / 256;
   __shared__ __attribute__((aligned(16))) float u[ROWS][DW_CT];
   __shared__ __attribute__((aligned(16))) float g[ROWS][DW_CT];
+  // CSGU: the tile's own dY rows, kept for dgate = dY * conv (re-reading them from memory after the conv recompute was
+  // one more exposed round trip per tile)
+  __shared__ __attribute__((aligned(16))) float dyc[GATE ? DW_TT : 1][DW_CT];
   __shared__ float red[3][DW_CT];
+  __shared__ float wl[REFLECT ? K : 1][DW_CT];         // the taps once more, indexable at run time by the edge fold
   const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // workgroup b runs on XCD b % 8: keep the channel tiles of one frame-tile sequence on ONE XCD and adjacent in
   // dispatch order, so the 128-byte pieces of a feature row are fetched by neighbours at the same time
@@ -355,6 +359,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
   float w[K], dw[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) { w[j] = cok ? p.w[(long)ch * K + j] : 0.f; dw[j] = 0.f; }
+  if constexpr (REFLECT) {
+    for (int j = wv; j < K; j += 4) wl[j][cl] = cok ? p.w[(long)ch * K + j] : 0.f;   // (first use is behind barriers)
+  }
   float dbs = 0.f;
   const T* dY = reinterpret_cast<const T*>(p.Y);
   const T* P = reinterpret_cast<const T*>(p.P);
@@ -379,6 +386,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
           if constexpr (GATE) {                        // gradient w.r.t. the conv output: dY * gate
             float gt[VW];
             ld_chunk<T>(reinterpret_cast<const T*>(p.gate) + ((long)b * p.T + t) * p.ldg + chv, gt);
+            if (i >= PAD && i < PAD + DW_TT) {
+#pragma unroll
+              for (int q4 = 0; q4 < VW / 4; ++q4)
+                *reinterpret_cast<float4*>(&dyc[i - PAD][cc + 4 * q4]) = make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+            }
 #pragma unroll
             for (int q = 0; q < VW; ++q) v[q] *= gt[q];
           }
@@ -408,10 +420,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
         const int r = it / LPR, cc = (it % LPR) * VW;
         const int t = t0 + r, chv = c0 + cc;
         if (t < p.T && chv < p.D) {
-          float dyv[VW], o8[VW];
-          ld_chunk<T>(dY + ((long)b * p.T + t) * p.ldy + chv, dyv);
+          float o8[VW];
 #pragma unroll
-          for (int q = 0; q < VW; ++q) o8[q] = dyv[q] * u[r][cc + q];
+          for (int q = 0; q < VW; ++q) o8[q] = dyc[r][cc + q] * u[r][cc + q];
           st_chunk<T>(dG + ((long)b * p.T + t) * p.lddg + chv, o8);
         }
       }
@@ -436,27 +447,35 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
     if constexpr (REFLECT) {
       // fold the gradient of the mirrored virtual frames into the edge frames.  Kept OUT of the unrolled FMA block above
       // (a rolled loop over this thread's own 16 rows of the du tile, entered only by tiles that touch an utterance edge)
-      // and with the taps re-read from memory: branches inside the unrolled block and a run-time index into the
-      // register array w[] made every tile of the reflect variant 3.3x slower.
+      // and with the taps read from an LDS copy: branches inside the unrolled block and a run-time index into the
+      // register array w[] made every tile of the reflect variant 3.3x slower; taps re-read from global memory cost a
+      // dependent L2 round trip per tap (T = 250: half the tiles touch an edge, 451 us vs 322 us for zero padding).
       if (t0 <= PAD || t0 + DW_TT + PAD >= p.T - 1) {
-        const float* wg = p.w + (long)(cok ? ch : 0) * K;
         __syncthreads();                               // every du row of the tile is in LDS
-        for (int o = wv; o < DW_TT; o += 4) {          // the (at most 2 * PAD) edge rows are shared among the 4 waves
-          const int tau = t0 + o;
+        // the PAD rows next to either edge are shared among the 4 waves.  The wave index is made explicitly uniform: row,
+        // tap range and LDS row addresses are then scalar arithmetic, the tap loops are plain counted loops (no per-lane
+        // predication) and unroll by 4 so that their LDS reads overlap
+        const int wvs = __builtin_amdgcn_readfirstlane(wv);
+        for (int idx = wvs; idx < 2 * PAD; idx += 4) {
+          const bool top = idx < PAD;
+          const int tau = top ? 1 + idx : p.T - 1 - PAD + (idx - PAD);
+          const int o = tau - t0;
+          if (o < 0 || o >= DW_TT || tau < 1 || tau > p.T - 2) continue;
           float add = 0.f;
-          if (tau >= 1 && tau <= PAD) {                // virtual frame -tau mirrors frame tau: taps j <= PAD - tau
-            for (int j = 0; j <= PAD - tau; ++j) {
-              const int tt = PAD - tau - j, r = tt - (t0 - PAD);
-              if (tt < p.T && r >= 0 && r < ROWS) add += wg[j] * g[r][cl];
-            }
+          if (top) {                                   // virtual frame -tau mirrors frame tau: taps j <= PAD - tau
+            const int r0 = 2 * PAD - tau - t0;         // g row of tap 0; tap j reads row r0 - j (frame PAD - tau - j)
+            const int jlo = max(max(0, r0 - (ROWS - 1)), PAD - tau - p.T + 1), jhi = min(PAD - tau, r0);
+#pragma unroll 4
+            for (int j = jlo; j <= jhi; ++j) add += wl[j][cl] * g[r0 - j][cl];
           }
-          if (tau <= p.T - 2 && tau >= p.T - 1 - PAD) {   // virtual frame 2(T-1)-tau mirrors frame tau: taps j >= T-1-tau+PAD
-            for (int j = max(0, p.T - 1 - tau + PAD); j < K; ++j) {
-              const int tt = 2 * (p.T - 1) - tau - j + PAD, r = tt - (t0 - PAD);
-              if (tt >= 0 && r >= 0 && r < ROWS) add += wg[j] * g[r][cl];
-            }
+          if (tau >= p.T - 1 - PAD) {                   // virtual frame 2(T-1)-tau mirrors frame tau: taps j >= T-1-tau+PAD
+            const int r0 = 2 * (p.T - 1) - tau + 2 * PAD - t0;   // tap j reads row r0 - j (frame 2(T-1) - tau - j + PAD)
+            const int jlo = max(max(0, p.T - 1 - tau + PAD), r0 - (ROWS - 1));
+            const int jhi = min(min(K - 1, r0), 2 * (p.T - 1) - tau + PAD);
+#pragma unroll 4
+            for (int j = jlo; j <= jhi; ++j) add += wl[j][cl] * g[r0 - j][cl];
           }
-          if (add != 0.f) u[o][cl] += add;
+          u[o][cl] += add;
         }
       }
     }

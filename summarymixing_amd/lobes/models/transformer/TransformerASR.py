@@ -12,7 +12,6 @@ import torch
 from torch import nn
 
 from .... import functional as F
-from .... import ops
 from ....nnet.activations import Swish
 from ....utils.dynamic_chunk_training import DynChunkTrainConfig  # noqa: F401
 from ...models.VanillaNN import Linear

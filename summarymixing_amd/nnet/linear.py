@@ -4,7 +4,6 @@
 MFMA GEMM of libsmx.so; GPU only."""
 from typing import Optional
 
-import torch
 from torch import nn
 
 from .. import functional as F
