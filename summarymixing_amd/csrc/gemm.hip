@@ -1091,6 +1091,159 @@ static int launch_panel(GemmParams& p, hipStream_t s) {
   return check_launch("smx_gemm");
 }
 
+// ---- wgrad (TN) with both operands on the LDS-DMA path ---------------------------------------------------------------
+// dW = dZ^T X reduces over the frames: both operands are reduce-strided (a k row = 128 contiguous columns = 256 B), the
+// loop is long (rows / splits / 64 steps) and has no epilogue work inside - the shape the LDS-DMA ring fits best.  Per
+// K step the register-staged kernel spends ~850 cycles writing the stage to LDS and on its two barriers, ~950 waiting for
+// the loads and ~800 in MFMAs, one after the other (tools/gemm_stamps.py: 2.6 K cycles per step at two waves per SIMD).
+// Here a stage (64 k rows x 128 columns of dZ and of X, 32 KB) goes HBM/L2 -> LDS by global_load_lds_dwordx4, two stages
+// form a ring, ONE barrier per K step, no operand ever touches a VGPR (two workgroups per CU as before).
+// LDS image of an operand stage: element (k, c) at  k * 256 + (((c >> 3) ^ ((k & 3) << 1)) << 4) + (c & 7) * 2.
+// The DMA writes a piece linearly (lane i -> +16 i; a 1 KB piece = 4 k rows), so the XOR is applied to the SOURCE column
+// granule; it replaces the +64 B row pad of the register-staged image: the four k rows a 16-lane group of
+// ds_read_b64_tr_b16 touches land on four different 32-byte bank groups.
+// Bias gradient (column sums of dZ): one extra MFMA per fragment against a constant all-ones B fragment in the waves
+// that own output columns 0..63 of the first column tile - no LDS reads, no VALU.
+__device__ __forceinline__ bf16x8 frag_tr_swz(const char* lds, int r, int kk, int hi) {
+  typedef short short4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) short4_t* lds_s4;
+  const int lane = (r & 31) | (hi << 5);
+  const int li = lane & 15, g1 = (lane >> 4) & 1;
+  const int k = kk * 16 + hi * 8 + (li >> 2);           // (k & 3) == li >> 2; row k + 4 has the same swizzle
+  const int c = (r - (r & 31)) + g1 * 16 + (li & 3) * 4;
+  const char* p0 = lds + k * 256 + ((((c >> 3) ^ ((li >> 2) << 1)) << 4) + (c & 7) * 2);
+  const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
+  const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * 256));
+  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
+  typedef bf16_t T;
+  constexpr int BK = 64, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
+  constexpr int OP_BYTES = BK * TILE * 2, STAGE_BYTES = 2 * OP_BYTES;
+  constexpr int PH_ROWS = 64, NPH = 2, STG_LD = TILE * 4 + 16, EPI_BYTES = (PH_ROWS * STG_LD + 63) / 64 * 64;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];      // the ring; the epilogue rows alias it
+  float* side = reinterpret_cast<float*>(smem + EPI_BYTES);                   // (written after the main loop)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  int tile_n, tile_m, bz, split;
+  {
+    const int ntiles = p.tiles_n * p.tiles_m;
+    if (p.splits == 1) {
+      int bid = blockIdx.x;
+      const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      tile_n = bid / p.tiles_m; tile_m = bid % p.tiles_m;
+      bz = blockIdx.y; split = 0;
+    } else {                                             // a whole split lives on one XCD (see gemm_kernel)
+      const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+      const int per = ntiles * p.batch;
+      const int item = idx % per;
+      split = (idx / per) * 8 + xcd;
+      if (split >= p.splits) return;
+      bz = item / ntiles;
+      const int tl = item % ntiles;
+      tile_n = tl / p.tiles_m; tile_m = tl % p.tiles_m;
+    }
+  }
+  const int n0 = tile_n * TILE, m0 = tile_m * TILE;
+  const int kbeg = split * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  const int niter = (kend - kbeg) / BK;
+  const T* A = reinterpret_cast<const T*>(p.A) + (long)bz * p.sA;
+  const T* B = reinterpret_cast<const T*>(p.B) + (long)bz * p.sB;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+  const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 1)) * 8;      // this lane's k row in a piece, source column
+  auto issue = [&](int it) {
+    const int buf = it & 1;
+    const long k0 = kbeg + (long)it * BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                        // 16 pieces of 4 k rows per operand, 4 per wave
+      const int pc = wave + 4 * j;
+      const long kr = k0 + 4 * pc + prow;
+      glds16(A + kr * p.lda + n0 + gsrc, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + pc * 1024));
+      glds16(B + kr * p.ldb + m0 + gsrc, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + OP_BYTES + pc * 1024));
+    }
+  };
+  f32x16 acc[FN][FM], accb[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accb[i][q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  }
+  const bool do_cs = p.acolsum != nullptr && tile_m == 0 && wm == 0;      // (uniform per wave)
+  const uint32_t one2 = 0x3F803F80u;
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2));
+  if (niter > 0) issue(0);
+  for (int it = 0; it < niter; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage `it` (issued a whole step ago)
+    lds_barrier();                                       // ... and everybody's; buffer (it + 1) & 1 is no longer read
+    if (it + 1 < niter) issue(it + 1);
+    const char* As = smem + (it & 1) * STAGE_BYTES;
+    const char* Bs = As + OP_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fa[FN], fb[FM];
+#pragma unroll
+      for (int i = 0; i < FN; ++i) fa[i] = frag_tr_swz(As, wn * WN + i * 32 + l31, kk, hi);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) fb[j] = frag_tr_swz(Bs, wm * WM + j * 32 + l31, kk, hi);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[i], accb[i], 0, 0, 0);
+      }
+    }
+  }
+  if (do_cs && hi == 0) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0 + wn * WN + i * 32 + l31;
+      if (n < p.N) p.acolsum[((long)split * p.batch + bz) * p.N + n] = accb[i][0];
+    }
+  }
+  // ---- epilogue (fp32 slabs or the final output) through the staged rows, as in gemm_kernel -------------------------
+  const smx_epilogue& e = p.e;
+  lds_barrier();                                         // every wave is done reading the ring
+  if (t < TILE) side[t] = (e.bias && m0 + t < p.M) ? e.bias[(long)bz * e.bias_batch_stride + m0 + t] : 0.f;
+  else side[t] = ((e.row_mask && n0 + t - TILE < p.N) ? (e.row_mask[n0 + t - TILE] ? 1.f : 0.f) : 1.f) * e.alpha;
+  const int osz = (e.out_mode == SMX_OUT_T) ? 2 : 4;
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph) {
+    lds_barrier();
+    if (wn == ph) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(smem + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+    }
+    lds_barrier();
+    if (osz == 2) epilogue_phase<T, 2, TILE, TILE, true>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, split, t);
+    else epilogue_phase<T, 4, TILE, TILE, true>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, split, t);
+  }
+}
+
+static int launch_tn_dma(GemmParams& p, hipStream_t s) {
+  p.tiles_n = p.N / 128;
+  p.tiles_m = p.M / 128;
+  dim3 grid(p.tiles_n * p.tiles_m, p.batch);
+  if (p.splits > 1) grid = dim3(8 * p.tiles_n * p.tiles_m * p.batch * ((p.splits + 7) / 8), 1);
+  hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(256), 0, s, p);
+  return check_launch("smx_gemm");
+}
+
 // ---- host dispatch ------------------------------------------------------------------------------------------
 template <typename T, bool A_KC, bool B_KC, int TN, int TM>
 static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
@@ -1120,6 +1273,14 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // short reduction, wide output, enough panels to fill the chip.
   // SMX_GEMM_PANEL: 0 off (default), 1 epilogues without a per-element side input, 2 every eligible epilogue
   static const int panel_env = getenv("SMX_GEMM_PANEL") ? atoi(getenv("SMX_GEMM_PANEL")) : 0;
+  // wgrad-shaped TN GEMMs with both operands on the LDS-DMA ring (gemm_tn_dma_kernel).  SMX_TN_DMA=0 disables it.
+  static const int tn_dma_env = getenv("SMX_TN_DMA") ? atoi(getenv("SMX_TN_DMA")) : 1;
+  if constexpr (sizeof(T) == 2 && !A_KC && !B_KC) {
+    if (tn_dma_env && vec && p.N % 128 == 0 && p.M % 128 == 0 && p.K % 64 == 0 && p.kchunk % 64 == 0 && p.K >= 64 &&
+        p.e.out_mode != SMX_OUT_ATOMIC_F32 && !p.e.colsum && !p.e.res && !p.e.c0 && !p.e.z && !p.ablate &&
+        (long)(p.N / 128) * (p.M / 128) * p.batch * p.splits >= 256)
+      return launch_tn_dma(p, s);
+  }
   if constexpr (sizeof(T) == 2 && A_KC) {
     const bool side_in = p.e.res || p.e.c0 || (p.e.flags & SMX_EPI_ACT_GRAD);
     if (panel_env && vec && p.splits == 1 && p.batch == 1 && p.K % 64 == 0 && p.K >= 64 && p.K <= 256 && p.M >= 512 &&

@@ -389,3 +389,30 @@ def test_gemm_row_panel_variant_in_subprocess():
     env = dict(os.environ, SMX_GEMM_PANEL="2", SMX_ROOT=root)
     r = subprocess.run([sys.executable, "-c", _PANEL_WORKER], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PANEL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("N,M,K", [(32768, 512, 256), (32768, 256, 1024), (16384, 1536, 512)])
+def test_wgrad_lds_dma_kernel(N, M, K):
+    """Shapes that take the LDS-DMA TN kernel (gemm_tn_dma_kernel: M, K multiples of 128, frames a multiple of 64, at least
+    256 workgroups): dW += dZ^T X accumulates into a non-zero gradient, the bias gradient comes out of the extra
+    all-ones MFMA; fp32 torch reference."""
+    from summarymixing_amd import ops
+    torch.manual_seed(N + M)
+    dz = torch.randn(N, M, device="cuda").bfloat16()
+    x = torch.randn(N, K, device="cuda").bfloat16()
+    gw0 = torch.randn(M, K, device="cuda")
+    gb0 = torch.randn(M, device="cuda")
+    gw, gb = gw0.clone(), gb0.clone()
+    ops.wgrad(dz, x, gw, N, M, K, dbias=gb)
+    ref = gw0 + dz.float().t() @ x.float()
+    refb = gb0 + dz.float().sum(0)
+    assert (gw - ref).abs().max().item() / ref.abs().max().item() < 1e-4
+    assert (gb - refb).abs().max().item() / refb.abs().max().item() < 1e-4
+    # strided operands (column slices of wider buffers), no bias
+    wide_z = torch.randn(N, M + 128, device="cuda").bfloat16()
+    wide_x = torch.randn(N, K + 256, device="cuda").bfloat16()
+    dzs, xs = wide_z[:, 128:], wide_x[:, 128:128 + K]
+    gw2 = torch.zeros(M, K, device="cuda")
+    ops.wgrad(dzs, xs, gw2, N, M, K, lddz=wide_z.stride(0), ldx=wide_x.stride(0))
+    ref2 = dzs.float().t() @ xs.float()
+    assert (gw2 - ref2).abs().max().item() / ref2.abs().max().item() < 1e-4
