@@ -1244,6 +1244,137 @@ static int launch_tn_dma(GemmParams& p, hipStream_t s) {
   return check_launch("smx_gemm");
 }
 
+// ---- NT / NN GEMM with BOTH operands on the LDS-DMA ring (128 x 128 tile, two 32 KB stages, one barrier per K step) ---
+// gemm_kernel<..., DMA = true> streams only A through the ring and keeps B on the register path (two barriers per step,
+// B's registers live across the MFMAs).  With the reduce-strided swizzle of gemm_tn_dma_kernel the weights of the dgrad
+// (NN) layout can take the DMA path as well; in the NT layout B uses A's row image.  No operand VGPRs at all.
+template <bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_dma2_kernel(GemmParams p) {
+  typedef bf16_t T;
+  constexpr int BK = 64, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
+  constexpr int OP_BYTES = BK * TILE * 2, STAGE_BYTES = 2 * OP_BYTES;
+  constexpr int PH_ROWS = 64, NPH = 2, STG_LD = TILE * 4 + 16, EPI_BYTES = (PH_ROWS * STG_LD + 63) / 64 * 64;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];      // the ring; the epilogue rows alias it
+  float* red = reinterpret_cast<float*>(smem + EPI_BYTES);                    // (both used after the main loop only)
+  float* side = red + TILE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  int tile_n, tile_m;
+  {
+    const int ntiles = p.tiles_n * p.tiles_m;
+    int bid = blockIdx.x;
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_n = bid / p.tiles_m; tile_m = bid % p.tiles_m;
+  }
+  const int bz = blockIdx.y;
+  const int n0 = tile_n * TILE, m0 = tile_m * TILE;
+  const int niter = p.K / BK;
+  const T* A = reinterpret_cast<const T*>(p.A) + (long)bz * p.sA;
+  const T* B = reinterpret_cast<const T*>(p.B) + (long)bz * p.sB;
+  const smx_epilogue& e = p.e;
+  // epilogue side vector, requested before the main loop (bias[TILE] | row factors[TILE])
+  float side_v = 0.f;
+  if (t < TILE) { if (e.bias && m0 + t < p.M) side_v = e.bias[(long)bz * e.bias_batch_stride + m0 + t]; }
+  else { const int n = n0 + t - TILE; side_v = ((e.row_mask && n < p.N) ? (e.row_mask[n] ? 1.f : 0.f) : 1.f) * e.alpha; }
+
+  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+  // row-image pieces (reduce-contiguous operand): 8 rows of 128 B per piece, chunk XOR (row >> 1) & 7 on the source
+  const int rrow = lane >> 3;
+  // k-image pieces (reduce-strided operand): 4 k rows of 256 B per piece, granule XOR (k & 3) << 1 on the source
+  const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 1)) * 8;
+  auto issue = [&](int it) {
+    const int buf = it & 1;
+    const long k0 = (long)it * BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pc = wave + 4 * j;
+      const int row = pc * 8 + rrow;
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      const long ga = min(n0 + row, p.N - 1);
+      glds16(A + ga * p.lda + k0 + lc * 8, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + pc * 1024));
+      if constexpr (B_KC) {
+        const long gb = min(m0 + row, p.M - 1);
+        glds16(B + gb * p.ldb + k0 + lc * 8, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + OP_BYTES + pc * 1024));
+      } else {
+        const long kr = k0 + 4 * pc + prow;
+        const int mc = min(m0 + gsrc, p.M - 8);
+        glds16(B + kr * p.ldb + mc, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + OP_BYTES + pc * 1024));
+      }
+    }
+  };
+  f32x16 acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  if (niter > 0) issue(0);
+  for (int it = 0; it < niter; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (it + 1 < niter) issue(it + 1);
+    const char* As = smem + (it & 1) * STAGE_BYTES;
+    const char* Bs = As + OP_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fa[FN], fb[FM];
+#pragma unroll
+      for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<true, TILE>(As, wn * WN + i * 32 + l31, kk, hi);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        if constexpr (B_KC) fb[j] = frag_bf16<true, TILE>(Bs, wm * WM + j * 32 + l31, kk, hi);
+        else fb[j] = frag_tr_swz(Bs, wm * WM + j * 32 + l31, kk, hi);
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  lds_barrier();                                         // every wave is done reading the ring
+  side[t] = side_v;
+  const int osz = (e.out_mode == SMX_OUT_T) ? 2 : 4;
+#pragma unroll 1
+  for (int ph = 0; ph < NPH; ++ph) {
+    lds_barrier();
+    if (wn == ph) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(smem + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+    }
+    lds_barrier();
+    if (osz == 2) epilogue_phase<T, 2, TILE, TILE, true>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, 0, t);
+    else epilogue_phase<T, 4, TILE, TILE, true>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, 0, t);
+    if (e.colsum) {
+      lds_barrier();
+      if (t < TILE) {
+        const int rows = min(PH_ROWS, p.N - (n0 + ph * PH_ROWS));
+        float sum = ph == 0 ? 0.f : red[t];
+        for (int r = 0; r < rows; ++r) sum += *reinterpret_cast<const float*>(smem + r * STG_LD + t * 4);
+        if (ph < NPH - 1) red[t] = sum;
+        else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = sum;
+      }
+    }
+  }
+}
+
+template <bool B_KC>
+static int launch_dma2(GemmParams& p, hipStream_t s) {
+  p.tiles_n = (p.N + 127) / 128;
+  p.tiles_m = (p.M + 127) / 128;
+  hipLaunchKernelGGL((gemm_dma2_kernel<B_KC>), dim3(p.tiles_n * p.tiles_m, p.batch), dim3(256), 0, s, p);
+  if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
+  return check_launch("smx_gemm");
+}
+
 // ---- host dispatch ------------------------------------------------------------------------------------------
 template <typename T, bool A_KC, bool B_KC, int TN, int TM>
 static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
@@ -1280,6 +1411,15 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
         p.e.out_mode != SMX_OUT_ATOMIC_F32 && !p.e.colsum && !p.e.res && !p.e.c0 && !p.e.z && !p.ablate &&
         (long)(p.N / 128) * (p.M / 128) * p.batch * p.splits >= 256)
       return launch_tn_dma(p, s);
+  }
+  // NT / NN with both operands on the LDS-DMA ring (gemm_dma2_kernel).  SMX_GEMM_DMA2: 0 off, 1 on for every eligible
+  // shape, 2 only where the wide tile is not chosen
+  static const int dma2_env = getenv("SMX_GEMM_DMA2") ? atoi(getenv("SMX_GEMM_DMA2")) : 0;
+  if constexpr (sizeof(T) == 2 && A_KC) {
+    if (dma2_env && vec && p.splits == 1 && p.K % 64 == 0 && p.K >= 64 && p.N >= 128 && p.M >= 128 && p.M % 8 == 0 &&
+        p.e.out_mode != SMX_OUT_ATOMIC_F32 && !p.ablate && (dma2_env != 2 || !wide) &&
+        (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch >= 256)
+      return launch_dma2<B_KC>(p, s);
   }
   if constexpr (sizeof(T) == 2 && A_KC) {
     const bool side_in = p.e.res || p.e.c0 || (p.e.flags & SMX_EPI_ACT_GRAD);

@@ -378,6 +378,18 @@ print("PANEL OK")
 '''
 
 
+def test_gemm_all_dma_variant_in_subprocess():
+    """The opt-in all-DMA NT / NN GEMM (SMX_GEMM_DMA2=1: both operands through the LDS-DMA ring, gemm_dma2_kernel) on the
+    same large ragged shapes and epilogues as the row-panel test."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMX_GEMM_DMA2="1", SMX_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", _PANEL_WORKER], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PANEL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_gemm_row_panel_variant_in_subprocess():
     """The opt-in row-panel GEMM (SMX_GEMM_PANEL=2: one workgroup keeps a 128-row panel of A in LDS and walks the column
     tiles; K <= 256, M >= 512, >= 256 panels) against fp32 torch references on panel-eligible shapes (ragged N, M, K);
