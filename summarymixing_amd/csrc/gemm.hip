@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256, (PanelLds<B_KC, TN>::OCC)) void gemm_panel_ker
       bias_v = bias_n;
       continue;
     }
-#pragma unroll
+#pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
       lds_barrier();
       if (wn == ph) {
@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
   if (t < TILE) side[t] = (e.bias && m0 + t < p.M) ? e.bias[(long)bz * e.bias_batch_stride + m0 + t] : 0.f;
   else side[t] = ((e.row_mask && n0 + t - TILE < p.N) ? (e.row_mask[n0 + t - TILE] ? 1.f : 0.f) : 1.f) * e.alpha;
   const int osz = (e.out_mode == SMX_OUT_T) ? 2 : 4;
-#pragma unroll
+#pragma unroll 1
   for (int ph = 0; ph < NPH; ++ph) {
     lds_barrier();
     if (wn == ph) {
