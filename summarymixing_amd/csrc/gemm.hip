@@ -45,6 +45,7 @@ struct GemmParams {
   unsigned dthresh; float dscale;   // fused dropout: drop if hash16 < dthresh>>16, survivors * dscale
   long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
   int nt;       // non-temporal store hints: 1 = saved pre-activation Z, 2 = the output C
+  int reg_epi;  // epilogue without element-wise side inputs: math on the accumulator fragments, bf16 staging (gemm_kernel)
   int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
 };
 
@@ -801,6 +802,94 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     }
     return;
   }
+  if constexpr (sizeof(T) == 2 && TILE_N == 128 && TILE_M == 128 && VEC && !DMA) {
+    if (p.reg_epi) {
+      // ---- register-domain epilogue (bias / activation / row mask / dropout / saved Z only; bf16 output) -------------
+      // The math runs on the accumulator fragments of all four waves at once; what goes through LDS is the finished bf16
+      // tile (128 x 128 x 2 B, ONE phase per output instead of two fp32 half-tile phases), and the copy-out loop is a
+      // plain 16-byte LDS -> global copy.  Lane (l31, hi) of wave (wn, wm) owns rows wn*64 + i*32 + l31 and, per
+      // (j, g), the 4 columns wm*64 + j*32 + g*8 + hi*4 .. +3.
+      constexpr int SB = TILE_M * 2 + 8;                  // staged bf16 row: 264 B (66 dwords: 2-way conflicts at worst)
+      lds_barrier();                                      // every wave is done reading the operand stage
+      if (t < TILE_M + TILE_N) side[t] = side_v[0];
+      lds_barrier();
+      const uint32_t dthresh = p.dthresh;
+      const float dscale = p.dscale;
+      const uint64_t dseed = dthresh ? epoch_seed(e.drop_seed, p.epoch) : 0;
+      const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
+      T* Cb = reinterpret_cast<T*>(p.C) + (long)bz * p.sC;
+      T* Zb = e.z ? reinterpret_cast<T*>(e.z) + (long)bz * p.sC : nullptr;
+      auto copy_out = [&](T* dst, long ld, bool nt) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int it = t + 256 * k, r = it >> 4, c = (it & 15) * 8;
+          const uint2 lo = *reinterpret_cast<const uint2*>(smem + r * SB + c * 2);
+          const uint2 hi2 = *reinterpret_cast<const uint2*>(smem + r * SB + c * 2 + 8);
+          if (n0 + r < p.N && m0 + c < p.M) {
+            u32x4_t u = {lo.x, lo.y, hi2.x, hi2.y};
+            u32x4_t* gp = reinterpret_cast<u32x4_t*>(dst + (long)(n0 + r) * ld + m0 + c);
+            if (nt) __builtin_nontemporal_store(u, gp); else *gp = u;
+          }
+        }
+      };
+      // z = acc + bias (in place)
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(side + wm * WM + j * 32 + g * 8 + hi * 4);
+#pragma unroll
+          for (int i = 0; i < FN; ++i) {
+            acc[i][j][g * 4] += b4.x; acc[i][j][g * 4 + 1] += b4.y; acc[i][j][g * 4 + 2] += b4.z; acc[i][j][g * 4 + 3] += b4.w;
+          }
+        }
+      if (Zb) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<uint2*>(smem + (wn * WN + i * 32 + l31) * SB + (wm * WM + j * 32 + g * 8 + hi * 4) * 2) =
+                  make_uint2(pack_bf16x2(acc[i][j][g * 4], acc[i][j][g * 4 + 1]), pack_bf16x2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]));
+        lds_barrier();
+        copy_out(Zb, e.ldz, p.nt & 1);
+        lds_barrier();
+      }
+      float mk[FN];
+#pragma unroll
+      for (int i = 0; i < FN; ++i) mk[i] = has_mk ? side[TILE_M + wn * WN + i * 32 + l31] : 1.f;
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const int n = n0 + wn * WN + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v[4] = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+            switch (e.act) {
+              case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 4>(v); break;
+              case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 4>(v); break;
+              case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 4>(v); break;
+              case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 4>(v); break;
+              default: break;
+            }
+            const int m = m0 + wm * WM + j * 32 + g * 8 + hi * 4;
+            if (dthresh) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = dropout_keep(dseed, (uint64_t)n * p.M + m + q, dthresh) ? v[q] * dscale : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] *= mk[i];
+            *reinterpret_cast<uint2*>(smem + (wn * WN + i * 32 + l31) * SB + (wm * WM + j * 32 + g * 8 + hi * 4) * 2) =
+                make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          }
+      }
+      lds_barrier();
+      copy_out(Cb, p.ldc, p.nt & 2);
+      return;
+    }
+  }
   constexpr int STG_LD = TILE_M * 4 + 16;               // bytes per staged fp32 row (16 B pad: conflict-free b128)
   const int osz = (e.out_mode == SMX_OUT_T) ? (int)sizeof(T) : 4;
   if constexpr (ALIAS_SIDE) lds_barrier();               // every wave is done reading the operand ring
@@ -1532,6 +1621,13 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   static const long nt_bytes = getenv("SMX_NT_BYTES") ? atol(getenv("SMX_NT_BYTES")) : (96L << 20);
   static const int nt_z = getenv("SMX_NT_Z") ? atoi(getenv("SMX_NT_Z")) : 1;
   p.nt = (nt_z ? 1 : 0) | (((long)N * M * (long)cs * batch >= nt_bytes) ? 2 : 0);
+  // register-domain epilogue (gemm_kernel): 0 off, 1 every eligible epilogue, 2 (default) only without a saved Z - measured
+  // at 64000 frames: bias-only K=256 -> M=1024 102 -> 77 us, NN+bias 91 -> 71 us, but bias+Swish+Z 99 -> 99 us; training
+  // steps unchanged with either setting, forward-only steps -2 % (C2b) / -4 % (C5)
+  static const int reg_epi_env = getenv("SMX_REG_EPI") ? atoi(getenv("SMX_REG_EPI")) : 2;
+  p.reg_epi = reg_epi_env && (reg_epi_env != 2 || p.e.z == nullptr) && dtype == SMX_BF16 && p.e.out_mode == SMX_OUT_T && !p.e.res && !p.e.c0 && !p.e.colsum &&
+              !(p.e.flags & SMX_EPI_ACT_GRAD) && splits == 1 && p.epi_lds && M % 8 == 0 &&
+              (p.e.z == nullptr || (aligned16(p.e.z) && p.e.ldz % 8 == 0)) && aligned16(C) && ldc % 8 == 0 && strideC % 8 == 0;
   static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
   p.ablate = ablate;
   p.dbg = g_dbg_stamps;
