@@ -1274,21 +1274,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
     if (it + 1 < niter) issue(it + 1);
     const char* As = smem + (it & 1) * STAGE_BYTES;
     const char* Bs = As + OP_BYTES;
+    // fragments double-buffered in registers: the transposing LDS reads of sub-step kk + 1 are in flight under the
+    // MFMAs of sub-step kk
+    bf16x8 fa[2][FN], fb[2][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) fa[0][i] = frag_tr_swz(As, wn * WN + i * 32 + l31, 0, hi);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) fb[0][j] = frag_tr_swz(Bs, wm * WM + j * 32 + l31, 0, hi);
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 fa[FN], fb[FM];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 16) {
 #pragma unroll
-      for (int i = 0; i < FN; ++i) fa[i] = frag_tr_swz(As, wn * WN + i * 32 + l31, kk, hi);
+        for (int i = 0; i < FN; ++i) fa[nxt][i] = frag_tr_swz(As, wn * WN + i * 32 + l31, kk + 1, hi);
 #pragma unroll
-      for (int j = 0; j < FM; ++j) fb[j] = frag_tr_swz(Bs, wm * WM + j * 32 + l31, kk, hi);
+        for (int j = 0; j < FM; ++j) fb[nxt][j] = frag_tr_swz(Bs, wm * WM + j * 32 + l31, kk + 1, hi);
+      }
 #pragma unroll
       for (int i = 0; i < FN; ++i)
 #pragma unroll
         for (int j = 0; j < FM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
       if (do_cs) {
 #pragma unroll
-        for (int i = 0; i < FN; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[i], accb[i], 0, 0, 0);
+        for (int i = 0; i < FN; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[cur][i], accb[i], 0, 0, 0);
       }
     }
   }
