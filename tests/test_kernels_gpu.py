@@ -428,3 +428,34 @@ def test_wgrad_lds_dma_kernel(N, M, K):
     ops.wgrad(dzs, xs, gw2, N, M, K, lddz=wide_z.stride(0), ldx=wide_x.stride(0))
     ref2 = dzs.float().t() @ xs.float()
     assert (gw2 - ref2).abs().max().item() / ref2.abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("N,K,M", [(40000 + 33, 256, 1024), (33000, 192, 520)])
+def test_gemm_register_domain_epilogue(N, K, M):
+    """Epilogues without a saved Z take the register-domain path of the 128 x 128 kernel (math on the accumulator fragments,
+    bf16 staging of the finished tile); with a saved Z the fp32-staged path runs.  Both must agree with an fp32 torch
+    reference, and - the dropout index is a function of (row, column) only - with each other bit for bit under dropout."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(N)
+    x = torch.randn(N, K, device="cuda").bfloat16()
+    w = (torch.randn(M, K, device="cuda") * 0.05).bfloat16()
+    b = torch.randn(M, device="cuda")
+    mask = (torch.rand(N, device="cuda") > 0.2).to(torch.uint8)
+    zr = x.float() @ w.float().t() + b
+    yr = torch.nn.functional.gelu(zr) * mask[:, None] * 0.5
+    y1 = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(L.GEMM_NT, x, w, y1, N, M, K, ops.epilogue(bias=b, act=L.ACT_GELU, row_mask=mask, alpha=0.5))
+    assert rel_err(y1.float(), yr) < 1e-2
+    # NN layout (dgrad shaped), bias only, strided output (a column slice of a wider buffer)
+    wide = torch.zeros(N, M + 64, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(L.GEMM_NN, x, w.t().contiguous(), wide[:, 64:], N, M, K, ops.epilogue(bias=b))
+    assert rel_err(wide[:, 64:].float(), zr) < 1e-2 and float(wide[:, :64].abs().max()) == 0.0
+    # dropout: register-domain path (no Z) vs fp32-staged path (Z requested) with the same seed
+    ya, yb = torch.empty_like(y1), torch.empty_like(y1)
+    z = torch.empty_like(y1)
+    ops.gemm(L.GEMM_NT, x, w, ya, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, row_mask=mask, drop=(0.15, 4242)))
+    ops.gemm(L.GEMM_NT, x, w, yb, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, row_mask=mask, drop=(0.15, 4242), z=z))
+    assert torch.equal(ya == 0, yb == 0)
+    assert rel_err(ya.float(), yb.float()) < 1e-6
+    keep = (ya != 0).float().mean().item() / mask.float().mean().item()
+    assert abs(keep - 0.85) < 0.01
