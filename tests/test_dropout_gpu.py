@@ -112,3 +112,64 @@ def test_fused_epilogue_dropout_equals_standalone_kernel():
     dz2 = torch.empty_like(dy)
     ops.act_mask_bwd(ops.dropout(dy, p, seed), z, mask, L.ACT_GELU, 0.5, dz2)
     assert rel_err(dz, dz2) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["conformer", "branchformer"])
+def test_training_mode_gradients_match_finite_differences(kind):
+    """With the dropout seeds pinned (counter reset before every call) a training-mode layer is a deterministic, piecewise
+    smooth function: the analytic input gradient (which regenerates every fused dropout mask in the backward kernels) must
+    match central finite differences along random directions, and so must the gradient of a weight deep in the layer."""
+    from summarymixing_amd import ops
+    torch.manual_seed(3)
+    d = 32
+    if kind == "conformer":
+        from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoderLayer
+        layer = ConformerEncoderLayer(d_model=d, d_ffn=64, nhead=2, kernel_size=31, activation="swish", dropout=0.15,
+                                      attention_type="SummaryMixing", local_proj_hid_dim=[d], local_proj_out_dim=d,
+                                      summary_hid_dim=[d], mode="SummaryMixing-fast")
+        wname = "ffn_module1.ffn.1.w_1.weight" if any("w_1" in n for n, _ in layer.named_parameters()) else None
+    else:
+        from summarymixing_amd.lobes.models.transformer.Branchformer import BranchformerEncoderLayer
+        layer = BranchformerEncoderLayer(d_model=d, nhead=1, kernel_size=31, activation="gelu", dropout=0.15,
+                                         csgu_linear_units=64, local_proj_hid_dim=[d], local_proj_out_dim=d,
+                                         summary_hid_dim=[2 * d], summary_out_dim=d, mode="SummaryMixing")
+        wname = "convolution_branch.pre_channel_proj.weight"
+    with torch.no_grad():
+        for n, p in layer.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+        if kind == "branchformer":                        # upstream inits the CSGU conv to ~0 / 1: give it real taps
+            layer.convolution_branch.csgu.conv.conv.weight.normal_(0, 0.2)
+    layer = layer.cuda().train()
+    names = dict(layer.named_parameters())
+    wpar = names[wname] if wname in names else next(p for n, p in names.items() if p.dim() == 2)
+    B, T = 3, 40
+    x = torch.randn(B, T, d, device="cuda")
+    pad = (torch.arange(T, device="cuda")[None] < torch.tensor([T, 25, 33], device="cuda")[:, None])
+    r = torch.randn(B, T, d, device="cuda")
+
+    def f(xx):
+        ops._drop_state["counter"] = 11
+        y, _ = layer(xx, src_key_padding_mask=pad)
+        return (y * r).sum()
+
+    xg = x.clone().requires_grad_(True)
+    for p in layer.parameters():
+        p.grad = None
+    f(xg).backward()
+    gx, gw = xg.grad.clone(), wpar.grad.clone()
+    eps = 1e-2
+    for trial in range(3):
+        v = torch.randn_like(x)
+        with torch.no_grad():
+            fd = (f(x + eps * v) - f(x - eps * v)) / (2 * eps)
+        an = (gx * v).sum()
+        assert abs(float(fd - an)) <= 3e-2 * max(1.0, abs(float(an))), (kind, "dx", float(fd), float(an))
+    u = torch.randn_like(wpar)
+    with torch.no_grad():
+        w0 = wpar.detach().clone()
+        wpar.copy_(w0 + eps * u); fp = f(x)
+        wpar.copy_(w0 - eps * u); fm = f(x)
+        wpar.copy_(w0)
+    fd, an = (fp - fm) / (2 * eps), (gw * u).sum()
+    assert abs(float(fd - an)) <= 3e-2 * max(1.0, abs(float(an))), (kind, "dW", float(fd), float(an))
