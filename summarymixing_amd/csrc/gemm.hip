@@ -130,6 +130,50 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[ROWS / 32], const T* bas
   (void)BK; (void)VPT;
 }
 
+// ---- the same stage through buffer loads (bf16, aligned shapes) ---------------------------------------------------------
+// PMC (profiles/r01_pmc_sq.txt): a bias-only K=256 tile executed ~1270 VALU instructions per wave next to its 64 MFMAs,
+// about half of them in the main loop - per-load 64-bit address arithmetic and bounds predicates that the compiler
+// re-materialises every K step at the 168-register budget.  With a buffer resource the per-thread byte offsets of a
+// stage are computed ONCE (one 32-bit VGPR per vector), the K step advances through the scalar offset, and the bounds
+// check is the hardware's (out-of-range rows / k rows return zeros): the main loop's loads need no VALU at all.
+// Requirements (checked on the host, else the generic path): operand span < 2 GB; for a reduce-contiguous operand
+// K % 64 == 0 (a k tail inside a row would read the next row instead of zeros).
+#ifndef SMX_BUFLD_WIDE
+#define SMX_BUFLD_WIDE 1
+#endif
+template <typename T, bool KC, int ROWS>
+struct BufStage {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff[ROWS / 32];
+  uint32_t kbytes;                                       // bytes per unit k
+  __device__ __forceinline__ void init(const T* base, long ld, int row0, int rows_total, int K, int t) {
+    const long span = KC ? ((long)(rows_total - 1) * ld + K) : ((long)(K - 1) * ld + rows_total);
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), (short)0, (int)(span * (long)sizeof(T)), 0x00020000);
+    kbytes = KC ? (uint32_t)sizeof(T) : (uint32_t)(ld * (long)sizeof(T));
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int v = t + 256 * i;
+      if constexpr (KC) {
+        const int rg = row0 + (v >> 3);
+        voff[i] = rg < rows_total ? (uint32_t)(((long)rg * ld + (v & 7) * 8) * (long)sizeof(T)) : 0x80000000u;
+      } else {
+        constexpr int RC = ROWS / 8;
+        const int rg = row0 + (v % RC) * 8;
+        voff[i] = rg < rows_total ? (uint32_t)(((long)(v / RC) * ld + rg) * (long)sizeof(T)) : 0x80000000u;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(uint4 (&reg)[ROWS / 32], int k0) const {
+    const uint32_t soff = (uint32_t)k0 * kbytes;         // (uniform)
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+      const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0);
+      reg[i] = make_uint4(r.x, r.y, r.z, r.w);
+    }
+  }
+};
+
 // ---- registers -> LDS image -----------------------------------------------------------------------------
 template <typename T, bool KC, int ROWS>
 __device__ __forceinline__ void stage_store(const uint4 (&reg)[ROWS / 32], char* lds, int t) {
@@ -596,6 +640,23 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 
   const T* A = reinterpret_cast<const T*>(p.A) + (long)bz * p.sA;
   const T* B = reinterpret_cast<const T*>(p.B) + (long)bz * p.sB;
+  // operand stage loads: buffer loads with once-computed offsets for the aligned bf16 kernels (BufStage), else the
+  // generic guarded loads
+  constexpr bool BUFLD = sizeof(T) == 2 && VEC && (SMX_BUFLD_WIDE || TILE_M <= 128);
+  BufStage<T, A_KC, TILE_N> bufa;
+  BufStage<T, B_KC, TILE_M> bufb;
+  if constexpr (BUFLD) {
+    bufa.init(A, p.lda, n0, p.N, p.K, t);
+    bufb.init(B, p.ldb, m0, p.M, p.K, t);
+  }
+  auto load_a = [&](uint4 (&reg)[TILE_N / 32], int k0) {
+    if constexpr (BUFLD) bufa.load(reg, k0);
+    else stage_load<T, A_KC, TILE_N, VEC>(reg, A, p.lda, n0, p.N, k0, kend, t);
+  };
+  auto load_b = [&](uint4 (&reg)[TILE_M / 32], int k0) {
+    if constexpr (BUFLD) bufb.load(reg, k0);
+    else stage_load<T, B_KC, TILE_M, VEC>(reg, B, p.ldb, m0, p.M, k0, kend, t);
+  };
 
   // epilogue side vector of this thread (requested first, parked in ONE register across the main loop, published to
   // LDS before the epilogue): t < TILE_M -> bias[m0 + t], then TILE_N row factors row_mask[n] * alpha
@@ -652,7 +713,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     };
     if (niter > 0) {
       issue_a(0);
-      stage_load<T, B_KC, TILE_M, VEC>(rb, B, p.ldb, m0, p.M, kbeg, kend, t);
+      load_b(rb, kbeg);
     }
     SMX_STAMP(1);
     for (int it = 0; it < niter; ++it) {
@@ -661,7 +722,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
       lds_barrier();
       if (it + 1 < niter) {
         issue_a(it + 1);
-        stage_load<T, B_KC, TILE_M, VEC>(rb, B, p.ldb, m0, p.M, kbeg + (it + 1) * BK, kend, t);
+        load_b(rb, kbeg + (it + 1) * BK);
       }
       As = smem + (it & 1) * A_BYTES;
       if (!ab_nomfma) {
@@ -696,8 +757,8 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   for (int s_ = 0; s_ < NS; ++s_) {
     const int kk = kbeg + s_ * BK;
     if (kk < kend && !ab_nold) {
-      stage_load<T, A_KC, TILE_N, VEC>(ra[s_], A, p.lda, n0, p.N, kk, kend, t);
-      stage_load<T, B_KC, TILE_M, VEC>(rb[s_], B, p.ldb, m0, p.M, kk, kend, t);
+      load_a(ra[s_], kk);
+      load_b(rb[s_], kk);
     }
   }
   SMX_STAMP(1);
@@ -713,8 +774,8 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
       stage_store<T, B_KC, TILE_M>(rb[s_], Bs, t);
       lds_barrier();
       if (k0 + NS * BK < kend && !ab_nold) {
-        stage_load<T, A_KC, TILE_N, VEC>(ra[s_], A, p.lda, n0, p.N, k0 + NS * BK, kend, t);
-        stage_load<T, B_KC, TILE_M, VEC>(rb[s_], B, p.ldb, m0, p.M, k0 + NS * BK, kend, t);
+        load_a(ra[s_], k0 + NS * BK);
+        load_b(rb[s_], k0 + NS * BK);
       }
       if (ab_nomfma) {
       } else if constexpr (sizeof(T) == 2) {
@@ -1599,6 +1660,12 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   bool vec = aligned16(A) && aligned16(B) && lda % vpt == 0 && ldb % vpt == 0 && (strideA * es) % 16 == 0 &&
              (strideB * es) % 16 == 0;
   vec = vec && (a_kc ? K % vpt == 0 : N % vpt == 0) && (b_kc ? K % vpt == 0 : M % vpt == 0);
+  // bf16 vector kernels fetch their operand stages with buffer loads (BufStage): a reduce-contiguous operand then needs
+  // whole 64-element K steps, and every operand must span less than 2 GB
+  if (dtype == SMX_BF16 && vec) {
+    const long span_a = a_kc ? (long)N * lda : (long)K * lda, span_b = b_kc ? (long)M * ldb : (long)K * ldb;
+    if (((a_kc || b_kc) && K % 64 != 0) || span_a * 2 >= (1L << 31) || span_b * 2 >= (1L << 31)) vec = false;
+  }
   // 4-wide epilogue accesses
   auto ok4 = [&](const void* ptr, int64_t ld, size_t esz) {
     return ptr == nullptr || ((reinterpret_cast<uintptr_t>(ptr) % (4 * esz)) == 0 && ld % 4 == 0);
