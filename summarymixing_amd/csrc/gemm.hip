@@ -45,6 +45,7 @@ struct GemmParams {
   unsigned dthresh; float dscale;   // fused dropout: drop if hash16 < dthresh>>16, survivors * dscale
   long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
   int nt;       // non-temporal store hints: 1 = saved pre-activation Z, 2 = the output C
+  int epi_simple;  // no element-wise side input, no column sums: the SIMPLE instantiation of epilogue_phase
   int reg_epi;  // epilogue without element-wise side inputs: math on the accumulator fragments, bf16 staging (gemm_kernel)
   int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
 };
@@ -251,6 +252,14 @@ __device__ __forceinline__ bf16x8 frag_bf16(const char* lds, int r, int kk, int 
   }
 }
 
+// reduce-contiguous fragments with the loop-invariant part of the swizzled address precomputed: chunk kk*2 + hi of row r
+// sits at r*128 + (((kk*2 + hi) ^ ((r >> 1) & 7)) << 4) = frag_pre(r, hi) ^ (kk << 5)  (r*128 has no bits below 128, and
+// kk*2 only touches bits 1-2 of the chunk index) - one v_xor with an immediate per fragment and sub-step
+__device__ __forceinline__ uint32_t frag_pre(int r, int hi) { return (uint32_t)(r * 128 + ((hi ^ ((r >> 1) & 7)) << 4)); }
+__device__ __forceinline__ bf16x8 frag_kc(const char* lds, uint32_t pre, int kk) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (pre ^ (uint32_t)(kk << 5))));
+}
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -356,7 +365,10 @@ __device__ __forceinline__ void st_elems_nt(void* p, const float (&v)[CW]) {
   }
 }
 
-template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC>
+// SIMPLE: the epilogue has no element-wise side input and no column sums (bias / activation / saved Z / row factors /
+// dropout only) - known at compile time, so the side-input registers, their zero fills and the feature selects vanish
+// (PMC: 113 VALU instructions per 8-element item in the general instantiation of a bias+Swish+Z epilogue).
+template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC, bool SIMPLE = false>
 __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, const float* side, int ph, int nbase,
                                                int m0, int bz, int split, int t) {
   constexpr int WN = TILE_M > 128 ? 32 : TILE_N / 2;    // rows staged per phase (phase_rows() of the kernel)
@@ -375,13 +387,14 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   if (m >= p.M) return;
   const float* mkrow = side + TILE_M + ph * WN;
   char* Cb = reinterpret_cast<char*>(p.C) + ((long)bz * p.sC + (long)split * p.sSplit) * OSZ;
-  const bool ag = (e.flags & SMX_EPI_ACT_GRAD) != 0;     // z is an input: multiply by act'(z)
-  const bool c0post = (e.flags & SMX_EPI_C0_POST) != 0;
-  const bool has_c0 = e.c0_mode != SMX_C0_NONE;
+  const bool ag = !SIMPLE && (e.flags & SMX_EPI_ACT_GRAD) != 0;     // z is an input: multiply by act'(z)
+  const bool c0post = !SIMPLE && (e.flags & SMX_EPI_C0_POST) != 0;
+  const bool has_c0 = !SIMPLE && e.c0_mode != SMX_C0_NONE;
   const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
   T* Zb = (e.z && !ag) ? reinterpret_cast<T*>(e.z) + (long)bz * p.sC : nullptr;
   // the one side input of element type: the residual, or (ACT_GRAD) the saved pre-activation
-  const T* Sb = ag ? reinterpret_cast<const T*>(e.z) : (e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr);
+  const T* Sb = SIMPLE ? nullptr
+                       : (ag ? reinterpret_cast<const T*>(e.z) : (e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr));
   const long lds_ = ag ? e.ldz : e.ldr;
 
   if constexpr (EVEC) {
@@ -496,7 +509,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
 #pragma unroll
         for (int q = 0; q < CW; ++q) v[q] += cv[kk][q];
       }
-      if (e.colsum) {                                    // final values back into the item's own staged slot
+      if (!SIMPLE && e.colsum) {                         // final values back into the item's own staged slot
 #pragma unroll
         for (int q4 = 0; q4 < CW / 4; ++q4)
           *reinterpret_cast<float4*>(const_cast<char*>(smem) + r * STG_LD + (c + 4 * q4) * 4) =
@@ -684,6 +697,11 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  uint32_t fpa[FN], fpb[FM];                             // loop-invariant fragment addresses (reduce-contiguous images)
+#pragma unroll
+  for (int i = 0; i < FN; ++i) fpa[i] = frag_pre(wn * WN + i * 32 + l31, hi);
+#pragma unroll
+  for (int j = 0; j < FM; ++j) fpb[j] = frag_pre(wm * WM + j * 32 + l31, hi);
   const bool ab_nold = p.ablate & 4, ab_nomfma = p.ablate & 2, ab_nost = p.ablate & 1;
   constexpr int CSN = 16 / (int)sizeof(T);
   float cs[CSN];
@@ -730,9 +748,12 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
         for (int kk = 0; kk < BK / 16; ++kk) {
           bf16x8 fa[FN], fb[FM];
 #pragma unroll
-          for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<true, TILE_N>(As, wn * WN + i * 32 + l31, kk, hi);
+          for (int i = 0; i < FN; ++i) fa[i] = frag_kc(As, fpa[i], kk);
 #pragma unroll
-          for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<B_KC, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
+          for (int j = 0; j < FM; ++j) {
+            if constexpr (B_KC) fb[j] = frag_kc(Bs, fpb[j], kk);
+            else fb[j] = frag_bf16<B_KC, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
+          }
 #pragma unroll
           for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -783,9 +804,15 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
         for (int kk = 0; kk < BK / 16; ++kk) {
           bf16x8 fa[FN], fb[FM];
 #pragma unroll
-          for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<A_KC, TILE_N>(As, wn * WN + i * 32 + l31, kk, hi);
+          for (int i = 0; i < FN; ++i) {
+            if constexpr (A_KC) fa[i] = frag_kc(As, fpa[i], kk);
+            else fa[i] = frag_bf16<A_KC, TILE_N>(As, wn * WN + i * 32 + l31, kk, hi);
+          }
 #pragma unroll
-          for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<B_KC, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
+          for (int j = 0; j < FM; ++j) {
+            if constexpr (B_KC) fb[j] = frag_kc(Bs, fpb[j], kk);
+            else fb[j] = frag_bf16<B_KC, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
+          }
 #pragma unroll
           for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -978,8 +1005,10 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     }
     lds_barrier();
     if (ph < 2) SMX_STAMP(3 + 2 * ph);
-    if (sizeof(T) == 2 && osz == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
-    else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+    if (sizeof(T) == 2 && osz == 2) {
+      if (VEC && p.epi_simple) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, true>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+      else epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+    } else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     if (e.colsum) {
       // column sums of this phase's outputs (the bias gradient of a fused backward): every item was written back to
       // its staged slot; thread t < TILE_M adds column t over the valid rows in a fixed order
@@ -1704,6 +1733,8 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   p.reg_epi = reg_epi_env && (reg_epi_env != 2 || p.e.z == nullptr) && dtype == SMX_BF16 && p.e.out_mode == SMX_OUT_T && !p.e.res && !p.e.c0 && !p.e.colsum &&
               !(p.e.flags & SMX_EPI_ACT_GRAD) && splits == 1 && p.epi_lds && M % 8 == 0 &&
               (p.e.z == nullptr || (aligned16(p.e.z) && p.e.ldz % 8 == 0)) && aligned16(C) && ldc % 8 == 0 && strideC % 8 == 0;
+  static const int simple_env = getenv("SMX_EPI_SIMPLE") ? atoi(getenv("SMX_EPI_SIMPLE")) : 1;
+  p.epi_simple = simple_env && !p.e.res && !p.e.c0 && !p.e.colsum && !(p.e.flags & SMX_EPI_ACT_GRAD);
   static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
   p.ablate = ablate;
   p.dbg = g_dbg_stamps;
