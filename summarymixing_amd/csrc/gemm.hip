@@ -365,10 +365,11 @@ __device__ __forceinline__ void st_elems_nt(void* p, const float (&v)[CW]) {
   }
 }
 
-// SIMPLE: the epilogue has no element-wise side input and no column sums (bias / activation / saved Z / row factors /
-// dropout only) - known at compile time, so the side-input registers, their zero fills and the feature selects vanish
+// SIMPLE = 1: the epilogue has no element-wise side input and no column sums (bias / activation / saved Z / row factors /
+// dropout only); SIMPLE = 2: one element-type side input (residual, or the saved pre-activation of a fused act-grad),
+// still no C0 rows and no column sums - known at compile time, so the side-input registers, their zero fills and the feature selects vanish
 // (PMC: 113 VALU instructions per 8-element item in the general instantiation of a bias+Swish+Z epilogue).
-template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC, bool SIMPLE = false>
+template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC, int SIMPLE = 0>
 __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, const float* side, int ph, int nbase,
                                                int m0, int bz, int split, int t) {
   constexpr int WN = TILE_M > 128 ? 32 : TILE_N / 2;    // rows staged per phase (phase_rows() of the kernel)
@@ -387,13 +388,13 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   if (m >= p.M) return;
   const float* mkrow = side + TILE_M + ph * WN;
   char* Cb = reinterpret_cast<char*>(p.C) + ((long)bz * p.sC + (long)split * p.sSplit) * OSZ;
-  const bool ag = !SIMPLE && (e.flags & SMX_EPI_ACT_GRAD) != 0;     // z is an input: multiply by act'(z)
+  const bool ag = SIMPLE != 1 && (e.flags & SMX_EPI_ACT_GRAD) != 0;     // z is an input: multiply by act'(z)
   const bool c0post = !SIMPLE && (e.flags & SMX_EPI_C0_POST) != 0;
   const bool has_c0 = !SIMPLE && e.c0_mode != SMX_C0_NONE;
   const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
   T* Zb = (e.z && !ag) ? reinterpret_cast<T*>(e.z) + (long)bz * p.sC : nullptr;
   // the one side input of element type: the residual, or (ACT_GRAD) the saved pre-activation
-  const T* Sb = SIMPLE ? nullptr
+  const T* Sb = SIMPLE == 1 ? nullptr
                        : (ag ? reinterpret_cast<const T*>(e.z) : (e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr));
   const long lds_ = ag ? e.ldz : e.ldr;
 
@@ -1006,7 +1007,8 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     lds_barrier();
     if (ph < 2) SMX_STAMP(3 + 2 * ph);
     if (sizeof(T) == 2 && osz == 2) {
-      if (VEC && p.epi_simple) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, true>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+      if (VEC && p.epi_simple == 1) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+      else if (VEC && p.epi_simple == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
       else epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     } else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     if (e.colsum) {
@@ -1733,8 +1735,9 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   p.reg_epi = reg_epi_env && (reg_epi_env != 2 || p.e.z == nullptr) && dtype == SMX_BF16 && p.e.out_mode == SMX_OUT_T && !p.e.res && !p.e.c0 && !p.e.colsum &&
               !(p.e.flags & SMX_EPI_ACT_GRAD) && splits == 1 && p.epi_lds && M % 8 == 0 &&
               (p.e.z == nullptr || (aligned16(p.e.z) && p.e.ldz % 8 == 0)) && aligned16(C) && ldc % 8 == 0 && strideC % 8 == 0;
-  static const int simple_env = getenv("SMX_EPI_SIMPLE") ? atoi(getenv("SMX_EPI_SIMPLE")) : 1;
-  p.epi_simple = simple_env && !p.e.res && !p.e.c0 && !p.e.colsum && !(p.e.flags & SMX_EPI_ACT_GRAD);
+  static const int simple_env = getenv("SMX_EPI_SIMPLE") ? atoi(getenv("SMX_EPI_SIMPLE")) : 2;
+  p.epi_simple = 0;
+  if (simple_env && !p.e.c0 && !p.e.colsum) p.epi_simple = (p.e.res || (p.e.flags & SMX_EPI_ACT_GRAD)) ? (simple_env >= 2 ? 2 : 0) : 1;
   static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
   p.ablate = ablate;
   p.dbg = g_dbg_stamps;
