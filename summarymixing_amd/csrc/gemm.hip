@@ -1010,7 +1010,8 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
       if (VEC && p.epi_simple == 1) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
       else if (VEC && p.epi_simple == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
       else epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
-    } else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+    } else if (VEC && p.epi_simple == 1) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+    else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     if (e.colsum) {
       // column sums of this phase's outputs (the bias gradient of a fused backward): every item was written back to
       // its staged slot; thread t < TILE_M adds column t over the valid rows in a fixed order
@@ -1420,8 +1421,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
                 make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
     }
     lds_barrier();
-    if (osz == 2) epilogue_phase<T, 2, TILE, TILE, true>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, split, t);
-    else epilogue_phase<T, 4, TILE, TILE, true>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, split, t);
+    // (the dispatch admits no element-wise side input here: the SIMPLE instantiation)
+    if (osz == 2) epilogue_phase<T, 2, TILE, TILE, true, 1>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, split, t);
+    else epilogue_phase<T, 4, TILE, TILE, true, 1>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, split, t);
   }
 }
 
