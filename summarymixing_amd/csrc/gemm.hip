@@ -1336,15 +1336,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
   const T* B = reinterpret_cast<const T*>(p.B) + (long)bz * p.sB;
   const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
   const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 1)) * 8;      // this lane's k row in a piece, source column
-  auto issue = [&](int it) {
-    const int buf = it & 1;
-    const long k0 = kbeg + (long)it * BK;
+  // source pointers of this lane's 4 + 4 pieces, advanced by one K step per issue (no per-step address arithmetic
+  // beyond eight 64-bit adds)
+  const T* pa[4];
+  const T* pb[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                        // 16 pieces of 4 k rows per operand, 4 per wave
-      const int pc = wave + 4 * j;
-      const long kr = k0 + 4 * pc + prow;
-      glds16(A + kr * p.lda + n0 + gsrc, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + pc * 1024));
-      glds16(B + kr * p.ldb + m0 + gsrc, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + OP_BYTES + pc * 1024));
+  for (int j = 0; j < 4; ++j) {                          // 16 pieces of 4 k rows per operand, 4 per wave
+    const long kr = kbeg + 4 * (wave + 4 * j) + prow;
+    pa[j] = A + kr * p.lda + n0 + gsrc;
+    pb[j] = B + kr * p.ldb + m0 + gsrc;
+  }
+  const long stepa = (long)BK * p.lda, stepb = (long)BK * p.ldb;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
+  auto issue = [&](int it) {
+    const uint32_t dst = wave_lds + (it & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      glds16(pa[j], dst + j * 4096);
+      glds16(pb[j], dst + OP_BYTES + j * 4096);
+      pa[j] += stepa;
+      pb[j] += stepb;
     }
   };
   f32x16 acc[FN][FM], accb[FN];
