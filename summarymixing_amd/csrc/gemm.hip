@@ -1860,7 +1860,9 @@ static int wgrad_splits(int rows, int M, int K, int batch) {
   // launch takes as long as those; measured at 64000 frames: 71 -> 66 us (1024x256), 42 -> 35 us (256x256).
   // (The wide 128x256 tile does not help here: 2.5x slower with two register stages (spills), 71 vs 66 us with one.)
   static const int target_env = getenv("SMX_WGRAD_BLOCKS") ? atoi(getenv("SMX_WGRAD_BLOCKS")) : 0;
-  const long target = target_env > 0 ? target_env : 512;
+  // (with the LDS-DMA kernel and the wgrads on a side stream next to the dgrad chain, 384 = 1.5 per CU is the better
+  // target for the step: C2b 27.04 -> 26.56 ms; fewer, longer splits also mean less slab traffic for the reduction)
+  const long target = target_env > 0 ? target_env : 384;
   long s = (target + tiles - 1) / tiles;
   // a whole split lives on one XCD (XCD x owns splits x, x + 8, ..): a split count that is not a multiple of 8 leaves
   // XCDs idle (6 splits of a 3072 x 512 weight: 236 us; 8 splits: 199 us)
