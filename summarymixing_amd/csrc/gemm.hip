@@ -492,8 +492,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
         }
       }
       if (dthresh) {                                     // fused inverted dropout, mask = f(seed, n * M + m)
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] = dropout_keep(dseed, (uint64_t)n * p.M + m + q, dthresh) ? v[q] * dscale : 0.f;
+        dropout_apply<CW>(v, dseed, (uint64_t)n * p.M + m, dthresh, dscale);   // (m and M are multiples of CW here)
       }
       if (has_mk) {
         const float mk = mkrow[r];
@@ -965,8 +964,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
             }
             const int m = m0 + wm * WM + j * 32 + g * 8 + hi * 4;
             if (dthresh) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = dropout_keep(dseed, (uint64_t)n * p.M + m + q, dthresh) ? v[q] * dscale : 0.f;
+              dropout_apply<4>(v, dseed, (uint64_t)n * p.M + m, dthresh, dscale);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] *= mk[i];
