@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const f
       const uint64_t base = ((uint64_t)b * T_ + t) * (uint64_t)D + col;
       float o[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) o[i] = dropout_keep(dseed, base + i, dthresh) ? v[i] * dscale : 0.f;
+      for (int i = 0; i < N; ++i) o[i] = v[i];
+      dropout_apply_any<N>(o, dseed, base, dthresh, dscale);
       storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, o);
     }
   }
@@ -791,10 +792,7 @@ __global__ __launch_bounds__(256) void act_mask_bwd_vec_kernel(const T* __restri
         float o[N];
 #pragma unroll
         for (int q = 0; q < N; ++q) o[q] = fdy[u][q] * mk * (ACT != SMX_ACT_NONE ? act_grad_c<ACT>(fz[u][q]) : 1.f);
-        if (dthresh) {
-#pragma unroll
-          for (int q = 0; q < N; ++q) o[q] = dropout_keep(dseed, (uint64_t)n * M + col + q, dthresh) ? o[q] * dscale : 0.f;
-        }
+        if (dthresh) dropout_apply_any<N>(o, dseed, (uint64_t)n * M + col, dthresh, dscale);
         if (dZ) storev<T, true>(dZ + (long)n * lddz + col, N, o);
 #pragma unroll
         for (int q = 0; q < N; ++q) bsum[q] += o[q];
@@ -883,7 +881,7 @@ __global__ __launch_bounds__(256) void act_mask_bwd_kernel(const T* dY, long ldd
       if (Z) { for (int q = 0; q < 4; ++q) fz[q] = q < nvalid ? to_f32(Z[(long)n * ldz + col + q]) : 0.f; }
       const float mk = (mask ? (mask[n] ? 1.f : 0.f) : 1.f) * alpha;
       for (int q = 0; q < 4; ++q) o[q] = fdy[q] * mk * (Z ? act_grad(act, fz[q]) : 1.f);
-      if (dthresh) { for (int q = 0; q < 4; ++q) o[q] = dropout_keep(dseed, (uint64_t)n * M + col + q, dthresh) ? o[q] * dscale : 0.f; }
+      if (dthresh) dropout_apply_any<4>(o, dseed, (uint64_t)n * M + col, dthresh, dscale);
       if (dZ) { for (int q = 0; q < 4; ++q) if (q < nvalid) dZ[(long)n * lddz + col + q] = from_f32<T>(o[q]); }
       for (int q = 0; q < 4; ++q) bsum[q] += o[q];
       if (dgroup) {
@@ -989,8 +987,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* X, long ldx, T* Y
     float f[4] = {0.f, 0.f, 0.f, 0.f};
     if (vec) load4<T>(X + (long)n * ldx + col, f);
     else { for (int q = 0; q < 4; ++q) if (q < nvalid) f[q] = to_f32(X[(long)n * ldx + col + q]); }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) f[q] = dropout_keep(seed, (uint64_t)n * D + col + q, thresh) ? f[q] * scale : 0.f;
+    dropout_apply_any<4>(f, seed, (uint64_t)n * D + col, thresh, scale);
     if (vec) store4<T>(Y + (long)n * ldy + col, f);
     else { for (int q = 0; q < 4; ++q) if (q < nvalid) Y[(long)n * ldy + col + q] = from_f32<T>(f[q]); }
   }

@@ -190,6 +190,16 @@ __device__ __forceinline__ void dropout_apply(float (&v)[NV], uint64_t seed, uin
     v[2 * q2 + 1] = (h >> 16) >= t16 ? v[2 * q2 + 1] * scale : 0.f;
   }
 }
+// group form with a run-time alignment check (rows whose length is not a multiple of NV): falls back element by element
+template <int NV>
+__device__ __forceinline__ void dropout_apply_any(float (&v)[NV], uint64_t seed, uint64_t idx0, uint32_t thresh, float scale) {
+  if ((NV % 2 == 0) && (idx0 & (uint64_t)(NV - 1)) == 0) {
+    if constexpr (NV % 2 == 0) dropout_apply<NV>(v, seed, idx0, thresh, scale);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = dropout_keep(seed, idx0 + q, thresh) ? v[q] * scale : 0.f;
+  }
+}
 // Optional device step counter (smx_set_step_counter): when set, every dropout seed is mixed with its current value,
 // so a training step captured once in a hipGraph (constant kernel arguments) still draws fresh masks at every replay.
 extern const uint64_t* g_step_counter;
