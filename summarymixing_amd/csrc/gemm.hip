@@ -1278,10 +1278,12 @@ static int launch_panel(GemmParams& p, hipStream_t s) {
 // the loads and ~800 in MFMAs, one after the other (tools/gemm_stamps.py: 2.6 K cycles per step at two waves per SIMD).
 // Here a stage (64 k rows x 128 columns of dZ and of X, 32 KB) goes HBM/L2 -> LDS by global_load_lds_dwordx4, two stages
 // form a ring, ONE barrier per K step, no operand ever touches a VGPR (two workgroups per CU as before).
-// LDS image of an operand stage: element (k, c) at  k * 256 + (((c >> 3) ^ ((k & 3) << 1)) << 4) + (c & 7) * 2.
+// LDS image of an operand stage: element (k, c) at  k * 256 + (((c >> 3) ^ ((k & 3) << 2)) << 4) + (c & 7) * 2.
 // The DMA writes a piece linearly (lane i -> +16 i; a 1 KB piece = 4 k rows), so the XOR is applied to the SOURCE column
-// granule; it replaces the +64 B row pad of the register-staged image: the four k rows a 16-lane group of
-// ds_read_b64_tr_b16 touches land on four different 32-byte bank groups.
+// granule; it replaces the +64 B row pad of the register-staged image.  A 256-byte k row covers all 64 LDS banks once, so
+// the bank of an access is its granule index: the 32 lanes served together by ds_read_b64_tr_b16 touch 4 k rows x 4
+// granules, and XOR-ing the granule with 4 * (k & 3) sends the four rows to four disjoint granule quadruples (with
+// 2 * (k & 3) rows 0/1 and 2/3 collided: SQ_LDS_BANK_CONFLICT = 2 cycles per read).
 // Bias gradient (column sums of dZ): one extra MFMA per fragment against a constant all-ones B fragment in the waves
 // that own output columns 0..63 of the first column tile - no LDS reads, no VALU.
 __device__ __forceinline__ bf16x8 frag_tr_swz(const char* lds, int r, int kk, int hi) {
@@ -1291,7 +1293,7 @@ __device__ __forceinline__ bf16x8 frag_tr_swz(const char* lds, int r, int kk, in
   const int li = lane & 15, g1 = (lane >> 4) & 1;
   const int k = kk * 16 + hi * 8 + (li >> 2);           // (k & 3) == li >> 2; row k + 4 has the same swizzle
   const int c = (r - (r & 31)) + g1 * 16 + (li & 3) * 4;
-  const char* p0 = lds + k * 256 + ((((c >> 3) ^ ((li >> 2) << 1)) << 4) + (c & 7) * 2);
+  const char* p0 = lds + k * 256 + ((((c >> 3) ^ ((li >> 2) << 2)) << 4) + (c & 7) * 2);
   const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
   const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * 256));
   const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
@@ -1333,7 +1335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
   const T* A = reinterpret_cast<const T*>(p.A) + (long)bz * p.sA;
   const T* B = reinterpret_cast<const T*>(p.B) + (long)bz * p.sB;
   const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
-  const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 1)) * 8;      // this lane's k row in a piece, source column
+  const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 2)) * 8;      // this lane's k row in a piece, source column
   // source pointers of this lane's 4 + 4 pieces, advanced by one K step per issue (no per-step address arithmetic
   // beyond eight 64-bit adds)
   const T* pa[4];
@@ -1482,8 +1484,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma2_kernel(GemmParams p) {
   const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
   // row-image pieces (reduce-contiguous operand): 8 rows of 128 B per piece, chunk XOR (row >> 1) & 7 on the source
   const int rrow = lane >> 3;
-  // k-image pieces (reduce-strided operand): 4 k rows of 256 B per piece, granule XOR (k & 3) << 1 on the source
-  const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 1)) * 8;
+  // k-image pieces (reduce-strided operand): 4 k rows of 256 B per piece, granule XOR (k & 3) << 2 on the source
+  const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 2)) * 8;
   auto issue = [&](int it) {
     const int buf = it & 1;
     const long k0 = (long)it * BK;

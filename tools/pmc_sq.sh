@@ -15,7 +15,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for fn in glob.glob("/tmp/sq_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        if "gemm_kernel" in r["Kernel_Name"]:
+        if "gemm_" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print(f"{k:32s} {sum(v)/len(v):16.0f}  (n={len(v)})")
