@@ -1300,12 +1300,19 @@ __device__ __forceinline__ bf16x8 frag_tr_swz(const char* lds, int r, int kk, in
   return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
 }
 
+#ifndef SMX_TN_BK
+#define SMX_TN_BK 64      // k rows per LDS-DMA stage of the wgrad kernel (64: ring of 2; 32: ring of 4 - measured 3-5 % slower)
+#endif
 __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
   typedef bf16_t T;
-  constexpr int BK = 64, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
+  // ring of NST thin stages (BK k rows each): the DMA of stage it + NST - 1 is issued while stage it is multiplied, i.e.
+  // a prefetch distance of (NST - 1) * BK frames in the same 64 KB of LDS
+  constexpr int BK = SMX_TN_BK, NST = 128 / BK, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
   constexpr int OP_BYTES = BK * TILE * 2, STAGE_BYTES = 2 * OP_BYTES;
+  constexpr int NPC = BK / 16;                          // 1 KB pieces per wave, operand and stage
+  static_assert(BK == 64 || BK == 32, "ring of 2 x 64 or 4 x 32 k rows");
   constexpr int PH_ROWS = 64, NPH = 2, STG_LD = TILE * 4 + 16, EPI_BYTES = (PH_ROWS * STG_LD + 63) / 64 * 64;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];      // the ring; the epilogue rows alias it
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE_BYTES];      // the ring; the epilogue rows alias it
   float* side = reinterpret_cast<float*>(smem + EPI_BYTES);                   // (written after the main loop)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi = lane >> 5;
@@ -1338,10 +1345,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
   const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 2)) * 8;      // this lane's k row in a piece, source column
   // source pointers of this lane's 4 + 4 pieces, advanced by one K step per issue (no per-step address arithmetic
   // beyond eight 64-bit adds)
-  const T* pa[4];
-  const T* pb[4];
+  const T* pa[NPC];
+  const T* pb[NPC];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {                          // 16 pieces of 4 k rows per operand, 4 per wave
+  for (int j = 0; j < NPC; ++j) {                        // BK / 4 pieces of 4 k rows per operand and stage, NPC per wave
     const long kr = kbeg + 4 * (wave + 4 * j) + prow;
     pa[j] = A + kr * p.lda + n0 + gsrc;
     pb[j] = B + kr * p.ldb + m0 + gsrc;
@@ -1349,9 +1356,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
   const long stepa = (long)BK * p.lda, stepb = (long)BK * p.ldb;
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
   auto issue = [&](int it) {
-    const uint32_t dst = wave_lds + (it & 1) * STAGE_BYTES;
+    const uint32_t dst = wave_lds + (it % NST) * STAGE_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPC; ++j) {
       glds16(pa[j], dst + j * 4096);
       glds16(pb[j], dst + OP_BYTES + j * 4096);
       pa[j] += stepa;
@@ -1371,12 +1378,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
   const bool do_cs = p.acolsum != nullptr && tile_m == 0 && wm == 0;      // (uniform per wave)
   const uint32_t one2 = 0x3F803F80u;
   const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2));
-  if (niter > 0) issue(0);
+  for (int s_ = 0; s_ < NST - 1 && s_ < niter; ++s_) issue(s_);
   for (int it = 0; it < niter; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage `it` (issued a whole step ago)
-    lds_barrier();                                       // ... and everybody's; buffer (it + 1) & 1 is no longer read
-    if (it + 1 < niter) issue(it + 1);
-    const char* As = smem + (it & 1) * STAGE_BYTES;
+    // this wave's pieces of stage `it` have landed when at most the (2 NPC each) DMA instructions of the younger stages in
+    // flight are outstanding (vmcnt retires in order; nothing else uses vector memory in this loop)
+    const int ahead = min(NST - 2, niter - 1 - it);
+    if (ahead >= 2 && NST >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
+    else if (ahead >= 1 && NST >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();                                       // ... and everybody's; the stage read last step is free again
+    if (it + NST - 1 < niter) issue(it + NST - 1);
+    const char* As = smem + (it % NST) * STAGE_BYTES;
     const char* Bs = As + OP_BYTES;
     // fragments double-buffered in registers: the transposing LDS reads of sub-step kk + 1 are in flight under the
     // MFMAs of sub-step kk
