@@ -983,6 +983,8 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 #pragma unroll
   for (int i = 0; i < NSIDE; ++i)
     if (t + 256 * i < TILE_M + TILE_N) side[t + 256 * i] = side_v[i];   // (visible after the first barrier below)
+  if constexpr (TILE_M > 128) {
+  // (wide tile: 128 accumulator registers - duplicating the loop per variant spills there; the choice stays inside)
 #pragma unroll 1
   for (int ph = 0; ph < NPH; ++ph) {
     lds_barrier();
@@ -1023,6 +1025,58 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
       }
     }
     if (ph < 2) SMX_STAMP(4 + 2 * ph);
+  }
+  } else {
+  // The epilogue variant is chosen ONCE, outside the phase loop: with the choice inside, the loop carried the hoisted
+  // invariants (output / side-input row pointers, masks) of all the instantiations at the same time and spilled ~90 B
+  // per thread to scratch at the 168-register budget - 90 MB of extra HBM writes per launch of an output-bound kernel
+  // (PMC WRITE_SIZE 350 MB for 262 MB of output).
+  auto run_phases = [&](auto osz_tag, auto lvl_tag) {
+    constexpr int OSZ_ = decltype(osz_tag)::value, LVL_ = decltype(lvl_tag)::value;
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+      lds_barrier();
+      const int row_in_tile = ph * PH_ROWS;
+      if (wn == row_in_tile / WN) {                         // the wave row that owns these accumulator rows
+        const int i0 = (row_in_tile % WN) / 32;              // first 32-row fragment of the phase
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          if (PH_FRAGS == FN || (i >= i0 && i < i0 + PH_FRAGS)) {
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(smem + ((i - (PH_FRAGS == FN ? 0 : i0)) * 32 + l31) * STG_LD +
+                                           (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                    make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+          }
+        }
+      }
+      lds_barrier();
+      if (ph < 2) SMX_STAMP(3 + 2 * ph);
+      epilogue_phase<T, OSZ_, TILE_N, TILE_M, VEC, LVL_>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+      if (LVL_ == 0 && e.colsum) {
+        // column sums of this phase's outputs (the bias gradient of a fused backward): every item was written back to
+        // its staged slot; thread t < TILE_M adds column t over the valid rows in a fixed order
+        lds_barrier();
+        if (t < TILE_M) {
+          const int rows = min(PH_ROWS, p.N - (n0 + row_in_tile));
+          float s = ph == 0 ? 0.f : red[t];
+          for (int r = 0; r < rows; ++r) s += *reinterpret_cast<const float*>(smem + r * STG_LD + t * 4);
+          if (ph < NPH - 1) red[t] = s;
+          else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = s;
+        }
+      }
+      if (ph < 2) SMX_STAMP(4 + 2 * ph);
+    }
+  };
+  const int lvl = VEC ? p.epi_simple : 0;
+  if (sizeof(T) == 2 && osz == 2) {
+    if (lvl == 1) run_phases(ActTag<2>{}, ActTag<1>{});
+    else if (lvl == 2) run_phases(ActTag<2>{}, ActTag<2>{});
+    else run_phases(ActTag<2>{}, ActTag<0>{});
+  } else if (lvl == 1) run_phases(ActTag<4>{}, ActTag<1>{});
+  else run_phases(ActTag<4>{}, ActTag<0>{});
   }
   SMX_STAMP(7);
 #undef SMX_STAMP
