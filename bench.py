@@ -10,11 +10,18 @@ A "step" = one pass of the hot path over one synthetic padded utterance batch pe
 resident in HBM before the timed region.  Weak scaling: every rank processes its own (B, T) batch, the only
 collective is the bucketed gradient all-reduce (RCCL over xGMI).
 
+`python bench.py --gpus N` without a torchrun environment re-launches itself under torch.distributed.run with N ranks
+(and fails loudly when fewer than N GPUs are visible).  --scaling strong keeps the GLOBAL batch fixed (B / N per rank).
+
 Prints ONE JSON line (rank 0) with the driver contract fields plus
-  "roofline":     roofline of the dominant kernel (the FFN up-projection GEMM instance), timed live with HIP events on
-                  the launch stream; at d_model <= 512 its arithmetic intensity (114-226 flop/B) is below the bf16
-                  ridge (~312 flop/B), so the bound that applies - and the one reported - is HBM; the MFMA fraction is
-                  given alongside,
+  "roofline":     roofline of the DOMINANT kernel family of the step (largest share of the in-step kernel time; the
+                  wgrad slab GEMM at the default config), aggregated over its launches inside one instrumented step:
+                  algorithmic bytes / HIP-event time on the stream each launch ran on.  At d_model <= 512 every GEMM of
+                  this model sits below the bf16 ridge (~312 flop/B), so the bound reported is HBM; the MFMA fraction
+                  is given alongside,
+  "roofline_kernels": the top kernels (family + shape) of that instrumented step: calls/step, in-step avg us,
+                  algorithmic bytes per launch, fraction of the HBM roof, share of the step's kernel time,
+  "roofline_isolated": the FFN up-projection GEMM and the dominant wgrad shape timed back to back in isolation,
   "roofline_pool": HBM roofline of the masked-mean pool kernel at the long-utterance point (config 5),
   "cpu_baseline": the oracle (PyTorch-CPU restatement of the reference graph) timed on this node's host cores
                   on a bounded sample of the same workload.
@@ -108,13 +115,23 @@ def time_kernel(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+PMC_FILES = ("r02_pmc_traffic.txt", "r01_pmc_traffic.txt")
+PMC_NOTE = ("HBM bytes per launch read from the COMMITTED PMC passes under profiles/ (TCC FETCH_SIZE x2-corrected + "
+            "WRITE_SIZE, separate --pmc passes of tools/pmc_traffic.sh on this exact shape) - a constant of the build, "
+            "not measured in this run; null when no pass exists for the shape")
+
+
 def pmc_traffic_bytes(tag):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.txt: TCC FETCH_SIZE x2-corrected +
-    WRITE_SIZE, separate --pmc passes of tools/pmc_traffic.sh on this exact shape), or None when no matching line."""
+    """HBM bytes per launch from the committed PMC passes (profiles/r0N_pmc_traffic.txt), or None when no matching line."""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.txt")
+    lines = []
+    for fn in PMC_FILES:
+        try:
+            lines += open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fn)).readlines()
+        except OSError:
+            pass
     try:
-        for line in open(path):
+        for line in lines:
             if tag in line:
                 m = re.search(r"traffic\(corrected\)=([0-9.]+) MB", line)
                 if m:
@@ -124,8 +141,67 @@ def pmc_traffic_bytes(tag):
     return None
 
 
+def roofline_step_kernels(step, dtype, top=6):
+    """One instrumented (eager) step: every libsmx launch bracketed by HIP events on its own stream (ops._PROF).
+    -> (roofline of the dominant kernel family, top kernels by in-step time)."""
+    from summarymixing_amd import ops
+    step()                                   # settle allocations of the eager path
+    torch.cuda.synchronize()
+    ops.prof_start()
+    step()
+    recs = ops.prof_stop()
+    es = 2 if dtype == torch.bfloat16 else 4
+    mfma_peak = 2500.0 if es == 2 else 157.3
+    total_ms = sum(r[3] for r in recs) or 1e-9
+    by_name, by_fam = {}, {}
+    for name, nb, fl, ms in recs:
+        fam = name.split(" (")[0].split(" dW")[0]
+        for d, k in ((by_name, name), (by_fam, fam)):
+            e = d.setdefault(k, [0, 0.0, 0.0, 0.0])
+            e[0] += 1; e[1] += nb; e[2] += fl; e[3] += ms
+
+    def entry(k, e):
+        calls, nb, fl, ms = e
+        t = ms * 1e-3
+        return {"kernel": k, "calls_per_step": calls, "in_step_avg_us": ms * 1e3 / calls, "algorithmic_bytes_per_launch": nb / calls,
+                "hbm_GBps_algorithmic": nb / t / 1e9, "frac_hbm": nb / t / 1e9 / 8000.0, "mfma_TFLOPs": fl / t / 1e12,
+                "frac_mfma": fl / t / 1e12 / mfma_peak, "share_of_step_kernel_time": ms / total_ms}
+    kernels = [entry(k, e) for k, e in sorted(by_name.items(), key=lambda kv: -kv[1][3])[:top]]
+    fam, e = max(by_fam.items(), key=lambda kv: kv[1][3])
+    d = entry(fam, e)
+    intensity = e[2] / max(e[1], 1.0)
+    bound = "hbm" if intensity < mfma_peak * 1e12 / 8000e9 else "mfma"
+    roof = {"kernel": f"{fam} (all {e[0]} in-step launches of the family, HIP events on their launch streams)",
+            "bound": bound, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+            "achieved": d["hbm_GBps_algorithmic"] if bound == "hbm" else d["mfma_TFLOPs"],
+            "peak": 8000.0 if bound == "hbm" else mfma_peak,
+            "frac": d["frac_hbm"] if bound == "hbm" else d["frac_mfma"],
+            "launch_us": d["in_step_avg_us"], "calls_per_step": e[0], "share_of_step_kernel_time": d["share_of_step_kernel_time"],
+            "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "arithmetic_intensity_flop_per_byte": intensity,
+            "mfma_TFLOPs": d["mfma_TFLOPs"], "mfma_frac": d["frac_mfma"],
+            "step_kernel_time_ms": total_ms, "traffic": None, "traffic_note": PMC_NOTE}
+    return roof, kernels
+
+
+def roofline_wgrad(cfg, dtype):
+    """The dominant wgrad shape (FFN weights, M x K = d_ffn x d) in isolation: slabs + fixed-order reduction."""
+    from summarymixing_amd import ops
+    N, K, M = cfg["B"] * cfg["T"], cfg["d"], cfg["f"] or 4 * cfg["d"]
+    dz = torch.randn(N, M, device="cuda").to(dtype)
+    x = torch.randn(N, K, device="cuda").to(dtype)
+    gw = torch.zeros(M, K, device="cuda")
+    gb = torch.zeros(M, device="cuda")
+    t = time_kernel(lambda: ops.wgrad(dz, x, gw, N, M, K, dbias=gb))
+    es = 2 if dtype == torch.bfloat16 else 4
+    nb, fl = (M + K) * N * es + 4 * M * K, 2.0 * N * M * K
+    return {"kernel": f"wgrad slabs + reduction dW({M}x{K}) over {N} frames (isolated, back to back)", "bound": "hbm",
+            "launch_us": t * 1e6, "achieved": nb / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nb / t / 1e9 / 8000.0,
+            "algorithmic_bytes_per_launch": nb, "mfma_TFLOPs": fl / t / 1e12,
+            "traffic": pmc_traffic_bytes(f"wgrad bf16 dW({M}x{K}) over {N}") if es == 2 else None, "traffic_note": PMC_NOTE}
+
+
 def roofline_gemm(cfg, dtype):
-    """The dominant kernel of the step: gemm_kernel<bf16, NT, 128x128> on the FFN up-projection shape."""
+    """The FFN up-projection GEMM (gemm_kernel<bf16, NT, 128x128> +bias+Swish+Z) in isolation, back to back."""
     from summarymixing_amd import _lib as L, ops
     N, K, M = cfg["B"] * cfg["T"], cfg["d"], cfg["f"] or 4 * cfg["d"]
     x = torch.randn(N, K, device="cuda").to(dtype)
@@ -145,9 +221,7 @@ def roofline_gemm(cfg, dtype):
               "mfma_TFLOPs": flops / t / 1e12, "mfma_frac": flops / t / 1e12 / mfma_peak,
               "hbm_GBps_algorithmic": alg_bytes / t / 1e9,
               "traffic": pmc_traffic_bytes(f"gemm NT bf16 ({N}x{K})x({K}x{M})") if es == 2 else None,
-              "traffic_note": "HBM bytes per launch, PMC FETCH_SIZE (x2 corrected) + WRITE_SIZE from separate --pmc passes "
-                              "on this shape (tools/pmc_traffic.sh -> profiles/r01_pmc_traffic.txt); algorithmic bytes "
-                              f"{alg_bytes / 1e6:.1f} MB"}
+              "traffic_note": PMC_NOTE + f"; algorithmic bytes {alg_bytes / 1e6:.1f} MB"}
     if intensity < ridge:
         return dict(common, bound="hbm", achieved=alg_bytes / t / 1e9, peak=8000.0, unit="GB/s",
                     frac=alg_bytes / t / 1e9 / 8000.0)
@@ -172,9 +246,20 @@ def roofline_pool(dtype):
             "traffic": pmc_traffic_bytes(f"pool {'bf16' if es == 2 else 'f32 '} ({B},{T},{D})"), "launch_us": t * 1e6}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, train):
     """The oracle (PyTorch-CPU restatement of the reference module graph) on a bounded sample of the same
-    workload: same model shapes, fp32, B=4 utterances of the same T (about 10-30 s of CPU work)."""
+    workload: same model shapes, fp32, B=4 utterances of the same T (about 10-30 s of CPU work).  Timed at
+    min(all cores, 32) threads (the reported value) and at 8 threads."""
     from oracle import smx_oracle as O
     cores = min(os.cpu_count() or 1, 32)   # torch CPU scales poorly past ~32 threads on these small GEMMs
     torch.set_num_threads(cores)
@@ -195,19 +280,29 @@ def cpu_baseline(cfg, train):
             y.backward(r)
             for v in sd.values():
                 v.grad = None
-    t0 = time.perf_counter()
-    step()                                   # warm-up, also bounds the sample
-    first = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    n = 0
-    while n < 1 or (n < 20 and time.perf_counter() - t0 + first < 12.0):
-        step()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
+    def timed(budget):
+        t0 = time.perf_counter()
+        step()                                   # warm-up, also bounds the sample
+        first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        n = 0
+        while n < 1 or (n < 20 and time.perf_counter() - t0 + first < budget):
+            step()
+            n += 1
+        return (time.perf_counter() - t0) / n, n
+    dt, n = timed(12.0)
     frames = small["B"] * small["T"]
-    return {"value": frames / dt, "unit": "encoder frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/smx_oracle.py asr_encode {'fwd+bwd' if train else 'fwd'}, fp32, B={small['B']} x T={small['T']} "
-                      f"of the same model, {n} steps, torch {torch.__version__}, {cores} threads"}
+    out = {"value": frames / dt, "unit": "encoder frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+           "host_cpus": os.cpu_count(),
+           "sample": f"oracle/smx_oracle.py asr_encode {'fwd+bwd' if train else 'fwd'}, fp32, B={small['B']} x T={small['T']} "
+                     f"of the same model, {n} steps, torch {torch.__version__}, {cores} threads"}
+    if cores > 8:
+        torch.set_num_threads(8)
+        dt8, n8 = timed(6.0)
+        out["value_8_threads"] = frames / dt8
+        out["sample_8_threads"] = f"same sample, {n8} steps, 8 threads"
+        torch.set_num_threads(cores)
+    return out
 
 
 def cpu_baseline_stack(cfg, cores):
@@ -251,9 +346,28 @@ def main():
     ap.add_argument("--seq-parallel", action="store_true",
                     help="config c5 under torchrun: shard the TIME axis over the ranks (summarymixing_amd/sequence_parallel.py) "
                          "instead of the utterances; the job then processes ONE batch (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank runs the config's batch (default); strong: the GLOBAL batch is the config's batch, "
+                         "each of the N ranks gets B / N utterances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks (one process per GPU) under torch.distributed.run
+        import socket
+        import subprocess
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node - refusing to run fewer ranks "
+                             "than asked for")
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -267,13 +381,22 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1 or force_dist:
+        world = torch.distributed.get_world_size()          # n_gpus = the ranks that really joined the RCCL group
 
     cfg = dict(CONFIGS[args.config])
     if args.batch:
         cfg["B"] = args.batch
     if args.frames:
         cfg["T"] = args.frames
+    global_B = cfg["B"] * world
+    if args.scaling == "strong":
+        if cfg["B"] % world:
+            raise SystemExit(f"--scaling strong: the global batch {cfg['B']} does not divide over {world} ranks")
+        global_B = cfg["B"]
+        cfg["B"] //= world
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     train = args.mode == "train"
     if cfg.get("stack_only"):
@@ -363,10 +486,10 @@ def main():
         "metric": "encoder frames/s (whole node), " + ("LibriSpeech Conformer-SummaryMixing" if cfg["kind"] == "conformer"
                                                        else "CommonVoice Branchformer-SummaryMixing"),
         "value": value, "unit": "encoder frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": cfg["name"] + (" training step (fwd+bwd+grad-clip+AdamW)" if train else " forward"),
-                   "per_gpu_batch": cfg["B"], "enc_frames_per_utt": cfg["T"], "global_batch": cfg["B"] * world,
+                   "per_gpu_batch": cfg["B"], "enc_frames_per_utt": cfg["T"], "global_batch": global_B,
                    "padded_frames_per_step": frames_per_step, "valid_frames_rank0": valid_frames,
                    "input": f"(B,T,{cfg['input']}) N(0,1), wav_len U(0.5,1), zero padded",
                    "dropout": (args.dropout if train else 0.0), "parallelism": f"dp{world}", "init": "xavier_normal seed 3407",
@@ -377,7 +500,11 @@ def main():
         out["model_tflops"] = value * fl / 1e12
     if rank == 0:
         if not args.no_roofline:
-            out["roofline"] = roofline_gemm(cfg, dtype)
+            if train and world == 1 and not force_dist:
+                out["roofline"], out["roofline_kernels"] = roofline_step_kernels(step, dtype)
+                out["roofline_isolated"] = [roofline_wgrad(cfg, dtype), roofline_gemm(cfg, dtype)]
+            else:
+                out["roofline"] = roofline_gemm(cfg, dtype)
             out["roofline_pool"] = roofline_pool(dtype)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, train)

@@ -293,7 +293,10 @@ int smx_set_step_counter(const uint64_t* dev_counter);
 int smx_step_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream);
 /* out[0] += sum(x^2) (fp32 atomics; zero it first) — global grad-norm for clipping. */
 int smx_sumsq(const float* x, int64_t n, float* out, void* stream);
-/* out[0] = min(1, max_norm / (sqrt(sumsq[0]) * inv_scale + 1e-6)) : clip factor computed on device. */
+/* out[0] = min(1, max_norm / (sqrt(sumsq[0]) * inv_scale + 1e-6)) : clip factor computed on device.  `out` is fp32[2]:
+ * when sumsq[0] is NaN / Inf (a bad batch: bf16 overflow, a zero-length utterance) out[0] = 0 and out[1] += 1 (skipped-step
+ * counter); smx_adamw_step treats a device factor of exactly 0 as "skip the update" (no decay, no moments, no shadow
+ * refresh) - the behaviour of SpeechBrain's Brain.check_gradients for non-finite gradients. */
 int smx_clip_factor(const float* sumsq, float max_norm, float inv_scale, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -942,6 +942,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
                                                     float lr, float b1, float b2, float eps, float wd, float bc1,
                                                     float bc2_sqrt, float gscale, const float* gscale_dev,
                                                     const uint64_t* step_dev) {
+  // a clip factor of exactly 0 is smx_clip_factor's "non-finite gradient norm" verdict: skip the whole update
+  // (no weight decay, no moment update, shadows untouched) like SpeechBrain's check_gradients does
+  if (gscale_dev && gscale_dev[0] == 0.f) return;
   const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.f);
   if (step_dev) {                                        // bias correction from the device step counter (graph replay)
     const float t = (float)step_dev[0];
@@ -969,7 +972,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, floa
   if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
 }
 __global__ void clip_factor_kernel(const float* sumsq, float max_norm, float inv_scale, float* out) {
-  float nrm = sqrtf(sumsq[0]) * inv_scale;
+  const float ss = sumsq[0];
+  if (!(ss >= 0.f && ss < __builtin_inff())) {           // NaN or Inf gradient norm: factor 0 = "skip this step"
+    out[0] = 0.f;
+    out[1] += 1.f;                                        // skipped-step counter
+    return;
+  }
+  float nrm = sqrtf(ss) * inv_scale;
   float f = max_norm / (nrm + 1e-6f);
   out[0] = f < 1.f ? f : 1.f;
 }

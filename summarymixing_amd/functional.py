@@ -3,9 +3,11 @@
 Every block is a (forward, backward-closure) pair written against ``ops``; a single generic
 ``torch.autograd.Function`` (``_BlockFn``) chains the blocks, so autograd only ever sees one activation in and
 one activation out per block: residual adds, gradient fan-in sums and parameter-gradient accumulation all
-happen inside the HIP kernels (GEMM epilogues, LayerNorm-backward residual input, fp32 atomics into
-``param.grad``).  Parameter gradients are therefore written by the kernels directly into ``param.grad``
-(created on demand, fp32, accumulate semantics identical to autograd's).
+happen inside the HIP kernels (GEMM epilogues, LayerNorm-backward residual input, split-K slabs / partial rows
+folded into ``param.grad`` by a fixed-order reduction - no atomics).  Parameter gradients are therefore written by
+the kernels directly into ``param.grad`` (created on demand, fp32, accumulate semantics identical to autograd's);
+autograd itself never sees them: AccumulateGrad hooks do not fire, so torch DistributedDataParallel must NOT wrap
+these modules (trainer.FlatAdamW buckets, or an explicit all-reduce of the ``.grad`` tensors, do the reduction).
 
 Reference behaviour mirrored here (paths relative to the reference root):
   cell                  speechbrain/nnet/summary_mixing.py:161-310
@@ -210,14 +212,15 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
 
 
 def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
-               drop=None, dz_ready=False, up=None):
+               drop=None, dz_ready=False, up=None, dx_drop=None):
     """Backward of y = res + alpha*D(act(x W^T + b + c0))*mask (D = the forward's fused dropout, regenerated from its
     seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate.
     dz_ready: dy already IS dZ (a downstream dgrad epilogue fused this layer's act/dropout/mask backward, see `up`).
     up = (z_up, act_up, mask_up, alpha_up, drop_up, gb_up): x is the output alpha_up*D(act_up(z_up))*mask_up of an
     upstream activation layer; the dgrad GEMM's epilogue then emits THAT layer's dZ (SMX_EPI_ACT_GRAD) instead of dX,
     so the (N x K) gradient never makes a separate elementwise pass (gb_up: optional colsum output; normally None,
-    the upstream layer's own wgrad yields its bias gradient)."""
+    the upstream layer's own wgrad yields its bias gradient).
+    dx_drop = (p, seed): x is the output of a dropout of that seed; its backward rides in the dgrad epilogue."""
     N, M = dy.shape
     K = x.shape[1]
     if drop is not None and drop[0] <= 0.0:
@@ -243,7 +246,8 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
             z_up, act_up, mask_up, alpha_up, drop_up, gb_up = up
             e = ops.epilogue(act=act_up, act_grad_z=z_up, row_mask=mask_up, alpha=alpha_up, drop=drop_up, colsum=gb_up)
         else:
-            e = ops.epilogue(res=res_grad)
+            assert dx_drop is None or res_grad is None
+            e = ops.epilogue(res=res_grad, drop=dx_drop)
         ops.gemm(L.GEMM_NN, dz, W, dx, N, K, M, e)
     return dx, dz
 

@@ -74,8 +74,9 @@ class BranchformerEncoderLayer(nn.Module):
         self.p_drop = float(dropout)
         self.mha_layer = SummaryMixing(enc_dim=d_model, nhead=nhead, local_proj_hid_dim=local_proj_hid_dim,
                                        local_proj_out_dim=local_proj_out_dim, summary_hid_dim=summary_hid_dim,
-                                       summary_out_dim=summary_out_dim, activation=activation, mode=mode,
-                                       global_dropout=0.0 if dropout == 0.0 else 0.1)
+                                       summary_out_dim=summary_out_dim, activation=activation, mode=mode)
+        # (global_dropout stays at the cell's default 0.1 whatever the layer dropout is, as in the reference:
+        #  Branchformer.py:209-218 does not pass it)
         self.merge_dnn_blocks = list(summary_hid_dim) + [d_model]
         self.merge_proj = VanillaNN(input_shape=[None, None, local_proj_out_dim + summary_out_dim],
                                     dnn_blocks=len(self.merge_dnn_blocks), dnn_neurons=self.merge_dnn_blocks,
@@ -118,9 +119,10 @@ class BranchformerEncoderLayer(nn.Module):
             g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1)
             # both branches land in one (N, c1 + d) buffer = the merge input (no torch.cat)
             cat = torch.empty((N, c1 + d), dtype=dtype, device=dev)
-            sd1 = sd2 = sd3 = None
+            sd1 = sd2 = sd3 = sd4 = None
             if pd > 0.0:                                    # dropout on both branches and on the merge (:279,295,334)
-                sd1, sd2, sd3 = ops.new_dropout_seed(), ops.new_dropout_seed(), ops.new_dropout_seed()
+                sd1, sd2, sd3, sd4 = (ops.new_dropout_seed() for _ in range(4))
+                ops.dropout(g, pd, sd4, out=g)              # the CSGU's own dropout on x1 * conv(x2) (upstream CSGU.forward)
                 ops.dropout(y1, pd, sd1, out=cat[:, :c1])
             else:
                 ops.axpby(1.0, y1, out=cat[:, :c1])
@@ -146,7 +148,7 @@ class BranchformerEncoderLayer(nn.Module):
                 d1 = ops.dropout(dcat[:, :c1], pd, sd1) if pd > 0.0 else dcat[:, :c1].contiguous()
                 # branch 2 backward (the dropout backward of its half rides in linear_bwd's activation/mask pass)
                 dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
-                                     drop=(pd, sd2) if pd > 0.0 else None)
+                                     drop=(pd, sd2) if pd > 0.0 else None, dx_drop=(pd, sd4) if pd > 0.0 else None)
                 du = torch.empty_like(u)                   # [d gate | d LN input]: both kernels write their half directly
                 dv, _ = ops.dwconv_bwd(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T, n, k,
                                        False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])

@@ -28,6 +28,45 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# ---- in-step kernel timing (bench.py's roofline_kernels): while `_PROF` is a list every wrapper below brackets its
+# launch with two HIP events on the stream it launches on (the wgrad slabs run on a side stream) and appends
+# (kernel family + shape, algorithmic bytes, flops, start, end).  Off (None) in normal operation: one `is None` test.
+_PROF = None
+
+
+def prof_start():
+    global _PROF
+    _PROF = []
+
+
+def prof_stop():
+    """-> list of (name, algorithmic bytes, flops, milliseconds); synchronises the device."""
+    global _PROF
+    recs, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    return [(n, b, f, e0.elapsed_time(e1)) for n, b, f, e0, e1 in recs]
+
+
+def _pb(name, nbytes, flops=0.0):
+    if _PROF is None:
+        return None
+    st = torch.cuda.current_stream()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    return (name, float(nbytes), float(flops), e0, st)
+
+
+def _pe(tok):
+    if tok is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(tok[4])
+        _PROF.append(tok[:4] + (e1,))
+
+
+def _es(t):
+    return 2 if t.dtype == torch.bfloat16 else 4
+
+
 def _mat(t):
     """(ptr, ld) of a 2-D view with unit inner stride."""
     assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), f"need a (rows, cols) view with unit col stride, got {t.shape} {t.stride()}"
@@ -94,8 +133,19 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
     assert a.dtype == b.dtype
     if epi.colsum:
         epi.workspace = _workspace(L.lib().smx_gemm_colsum_workspace(N, M), c.device, "gemm_colsum").data_ptr()
+    tok = None
+    if _PROF is not None:
+        es, osz = _es(a), (4 if epi.out_mode == L.OUT_F32 else _es(c))
+        side = (1 if epi.res else 0) + (1 if epi.z else 0)            # residual / saved or re-read pre-activation
+        nb = batch * ((N * K + M * K + side * N * M) * es + N * M * osz)
+        tag = "".join(t for t, on in (("+bias", epi.bias), ("+act", epi.act != L.ACT_NONE and not (epi.flags & L.EPI_ACT_GRAD)),
+                                      ("+Z", epi.z and not (epi.flags & L.EPI_ACT_GRAD)), ("+actgrad(z)", epi.flags & L.EPI_ACT_GRAD),
+                                      ("+res", epi.res), ("+c0", epi.c0), ("+mask", epi.row_mask), ("+drop", epi.drop_p > 0)) if on)
+        tok = _pb(f"gemm {('NT', 'NN', 'TN')[layout]} {'bf16' if es == 2 else 'f32'} ({N}x{K})x({K}x{M}){'' if batch == 1 else ' x%d' % batch} {tag}",
+                  nb, 2.0 * N * M * K * batch)
     L.check(L.lib().smx_gemm(layout, dt(a), pa, lda or la, sa, pb, ldb or lb, sb, pc, ldc or lc, sc, N, M, K, batch,
                              splits, ctypes.byref(epi), _stream()), "smx_gemm")
+    _pe(tok)
     return c
 
 
@@ -109,8 +159,11 @@ def wgrad(dz, x, gW, rows, M, K, batch=1, sz=0, sx=0, sw=0, lddz=None, ldx=None,
     if dbias is not None:
         assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == batch * M and K % 4 == 0
     ws = _workspace(L.lib().smx_linear_wgrad_workspace(rows, M, K, batch), dz.device, slot=1)
+    tok = _pb(f"wgrad(+reduce) {'bf16' if _es(dz) == 2 else 'f32'} dW({M}x{K}) over {rows} frames{'' if batch == 1 else ' x%d' % batch}",
+              batch * ((M + K) * rows * _es(dz) + 4 * M * K), 2.0 * rows * M * K * batch) if _PROF is not None else None
     L.check(L.lib().smx_linear_wgrad(dt(dz), pz, lddz or lz, sz, px, ldx or lx, sx, pw, lddw or lw, sw, _p(dbias), rows, M, K,
                                      batch, alpha, _p(ws), _stream()), "smx_linear_wgrad")
+    _pe(tok)
 
 
 def wgrad_partial(dz, x, rows, M, K, ws, batch=1, sz=0, sx=0, lddz=None, ldx=None, want_bias=False):
@@ -119,14 +172,19 @@ def wgrad_partial(dz, x, rows, M, K, ws, batch=1, sz=0, sx=0, lddz=None, ldx=Non
     pz, lz = _mat(dz)
     px, lx = _mat(x)
     n, st, bo = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    tok = _pb(f"wgrad slabs {'bf16' if _es(dz) == 2 else 'f32'} dW({M}x{K}) over {rows} frames{'' if batch == 1 else ' x%d' % batch}",
+              batch * ((M + K) * rows * _es(dz) + 4 * M * K), 2.0 * rows * M * K * batch) if _PROF is not None else None
     L.check(L.lib().smx_linear_wgrad_partial(dt(dz), pz, lddz or lz, sz, px, ldx or lx, sx, rows, M, K, batch,
                                              1 if want_bias else 0, _p(ws), ctypes.byref(n), ctypes.byref(st),
                                              ctypes.byref(bo), _stream()), "smx_linear_wgrad_partial")
+    _pe(tok)
     return n.value, st.value, bo.value
 
 
-def reduce_jobs(jobs_dev, starts_dev, njobs, total_blocks):
+def reduce_jobs(jobs_dev, starts_dev, njobs, total_blocks, nbytes=0):
+    tok = _pb(f"reduce_jobs ({njobs} jobs)", nbytes)
     L.check(L.lib().smx_reduce_jobs(_p(jobs_dev), _p(starts_dev), njobs, total_blocks, _stream()), "smx_reduce_jobs")
+    _pe(tok)
 
 
 def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, gdiv=0, drop=None):
@@ -137,8 +195,10 @@ def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, 
     pg, ldg = (_mat(dgroup) if dgroup is not None else (None, 0))
     ws = _workspace(L.lib().smx_act_mask_bwd_workspace(N, M), dy.device, slot=3) if dbias is not None else None
     dp, ds = (drop if drop is not None else (0.0, 0))
+    tok = _pb(f"act_mask_bwd ({N}x{M})", (1 + (z is not None) + (dz is not None)) * N * M * _es(dy))
     L.check(L.lib().smx_act_mask_bwd(dt(dy), pdy, lddy, pz, ldz, _p(mask), pdz, lddz, N, M, act, alpha, _p(dbias), pg,
                                      ldg, gdiv, dp, ds, _p(ws), _stream()), "smx_act_mask_bwd")
+    _pe(tok)
     return dz
 
 
@@ -161,8 +221,10 @@ def masked_mean(s, mask, B, T, scale=True, want_inv=False):
     out = torch.empty((B, D), dtype=torch.float32, device=s.device)
     inv = torch.empty((B,), dtype=torch.float32, device=s.device) if want_inv else None
     ws = _workspace(L.lib().smx_masked_mean_workspace(B, T, D), s.device)
+    tok = _pb(f"masked_mean pool ({B},{T},{D})", B * T * D * _es(s) + B * T + 4 * B * D)
     L.check(L.lib().smx_masked_mean_fwd(dt(s), ps, lds, _p(mask), _p(out), _p(inv), B, T, D, 1 if scale else 0, _p(ws),
                                         _stream()), "smx_masked_mean_fwd")
+    _pe(tok)
     return out, inv
 
 
@@ -170,8 +232,10 @@ def bcast_rows(g, inv, ds, B, T, drop=None):
     """ds[b*T+t, :] = D(g[b,:] * inv[b])   (D: optional fused dropout (p, seed), index row * D + col)"""
     pds, ldds = _mat(ds)
     dp, dseed = drop if drop is not None else (0.0, 0)
+    tok = _pb(f"bcast_rows ({B},{T},{ds.shape[1]})", B * T * ds.shape[1] * _es(ds))
     L.check(L.lib().smx_masked_mean_bwd(dt(ds), _p(g), _p(inv), pds, ldds, B, T, ds.shape[1], dp, dseed, _stream()),
             "smx_masked_mean_bwd")
+    _pe(tok)
     return ds
 
 
@@ -179,8 +243,10 @@ def bcast_rows_act_bwd(g, inv, ds, B, T, z, mask, act):
     """ds[b*T+t, :] = g[b,:] * inv[b] * act'(z[b*T+t, :]) * mask[b*T+t]   (z and / or mask may be None)"""
     pds, ldds = _mat(ds)
     pz, ldz = (_mat(z) if z is not None else (None, 0))
+    tok = _pb(f"bcast_rows+act_bwd ({B},{T},{ds.shape[1]})", (1 + (z is not None)) * B * T * ds.shape[1] * _es(ds))
     L.check(L.lib().smx_masked_mean_bwd_act(dt(ds), _p(g), _p(inv), pds, ldds, pz, ldz, _p(mask), act, B, T, ds.shape[1],
                                             _stream()), "smx_masked_mean_bwd_act")
+    _pe(tok)
     return ds
 
 
@@ -211,8 +277,10 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE):
     y = torch.empty((N, D), dtype=x.dtype, device=x.device)
     stats = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
     px, ldx = _mat(x)
+    tok = _pb(f"layernorm_fwd ({N}x{D})", 2 * N * D * _es(x))
     L.check(L.lib().smx_layernorm_fwd(dt(x), px, ldx, _p(gamma), _p(beta), _p(y), D, _p(stats), N, D, eps, act, _stream()),
             "smx_layernorm_fwd")
+    _pe(tok)
     return y, stats
 
 
@@ -226,8 +294,10 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     pr, ldr = (_mat(res) if res is not None else (None, 0))
     if ws is None:
         ws = _workspace(L.lib().smx_layernorm_bwd_workspace(N, D), x.device, slot=2)
+    tok = _pb(f"layernorm_bwd ({N}x{D}){'+res' if res is not None else ''}", (3 + (res is not None)) * N * D * _es(x))
     L.check(L.lib().smx_layernorm_bwd(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), _mat(dx)[1], _p(dgamma),
                                       _p(dbeta), N, D, _p(ws), _stream()), "smx_layernorm_bwd")
+    _pe(tok)
     return dx
 
 
@@ -235,8 +305,10 @@ def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=N
     y = torch.empty((B * T, D), dtype=p.dtype, device=p.device)
     pp, ldp = _mat(p)
     pg, ldg = (_mat(gate) if gate is not None else (None, 0))
+    tok = _pb(f"dwconv_fwd ({B},{T},{D}) k={k}", 3 * B * T * D * _es(p))
     L.check(L.lib().smx_dwconv1d_glu_fwd(dt(p), pp, ldp, _p(w), _p(bias), pg, ldg, _p(y), D, B, T, D, k, 1 if glu else 0,
                                          pad_mode, chunk, _stream()), "smx_dwconv1d_glu_fwd")
+    _pe(tok)
     return y
 
 
@@ -249,10 +321,12 @@ def dwconv_bwd(dy, p, w, bias, dw, dbias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, 
     pp, ldp = _mat(p)
     pg, ldg = (_mat(gate) if gate is not None else (None, 0))
     ws = _workspace(L.lib().smx_dwconv1d_glu_bwd_workspace(B, T, D, k), p.device, slot=4)
+    tok = _pb(f"dwconv_bwd ({B},{T},{D}) k={k}", 5 * B * T * D * _es(p))
     L.check(L.lib().smx_dwconv1d_glu_bwd(dt(p), pdy, lddy, pp, ldp, _p(w), _p(bias), pg, ldg, _p(dp), dp.shape[1],
                                          _p(dgate), (_mat(dgate)[1] if dgate is not None else 0), _p(dw), _p(dbias), B, T, D, k,
                                          1 if glu else 0, pad_mode, chunk,
                                          _p(ws), _stream()), "smx_dwconv1d_glu_bwd")
+    _pe(tok)
     return dp, dgate
 
 
@@ -284,7 +358,9 @@ def dropout(x, p, seed, out=None):
         out = torch.empty((N, D), dtype=x.dtype, device=x.device)
     px, ldx = _mat(x)
     po, ldo = _mat(out)
+    tok = _pb(f"dropout ({N}x{D})", 2 * N * D * _es(x))
     L.check(L.lib().smx_dropout(dt(x), px, ldx, po, ldo, N, D, p, seed, _stream()), "smx_dropout")
+    _pe(tok)
     return out
 
 
@@ -311,8 +387,10 @@ def cast(src, dtype):
 
 
 def adamw_step(param, grad, m, v, shadow, lr, b1, b2, eps, wd, step, grad_scale=1.0, gscale_dev=None):
+    tok = _pb(f"adamw ({param.numel()} params)", (28 + (2 if shadow is not None else 0)) * param.numel())
     L.check(L.lib().smx_adamw_step(_p(param), _p(grad), _p(m), _p(v), _p(shadow), param.numel(), lr, b1, b2, eps, wd,
                                    step, grad_scale, _p(gscale_dev), _stream()), "smx_adamw_step")
+    _pe(tok)
 
 
 def utt_meanstd(x2, lens, mean, std, B, T, mean_norm=True, std_norm=True, eps=1e-10):

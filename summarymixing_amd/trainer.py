@@ -54,11 +54,63 @@ class FlatAdamW:
         # SMX_FORCE_ALLREDUCE=1 exercises the collective path on a single rank (identity all-reduce) for smoke tests
         self._collective = self.world > 1 or (os.environ.get("SMX_FORCE_ALLREDUCE") == "1" and dist.is_initialized())
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._clip = torch.ones(1, dtype=torch.float32, device=dev)
+        self._clip = torch.tensor([1.0, 0.0], dtype=torch.float32, device=dev)   # [clip factor (0 = skip), skipped steps]
         self._pending = []
         self._dev_step = None
         # buckets: list of (start, end) element ranges of the flat buffers, in backward-completion order
         self.buckets = buckets or [(0, total)]
+        # in-place weight changes behind the optimizer's back (module.load_state_dict of a checkpoint) must reach the bf16
+        # shadows the GEMMs read: they are only refreshed inside smx_adamw_step otherwise
+        self._hook = module.register_load_state_dict_post_hook(lambda mod, incompatible: self.refresh_shadows())
+
+    # ---- state ------------------------------------------------------------------------------------
+    def refresh_shadows(self):
+        """Re-cast the fp32 master weights into the bf16 shadows (call after ANY in-place change of param.data that did
+        not go through step(): load_state_dict does it by itself, an EMA / averaging copy_ must call this)."""
+        if self.shadow is not None and self.flat_p.is_cuda:
+            ops.L.check(ops.L.lib().smx_cast_from_f32(ops.L.BF16, ops._p(self.flat_p), ops._p(self.shadow), self.total,
+                                                      ops._stream()), "smx_cast_from_f32")
+
+    def state_dict(self):
+        """Optimizer state for checkpoint / resume (the weights themselves are in module.state_dict())."""
+        step = int(self._dev_step.item()) if self._dev_step is not None else self.step_count
+        return {"step": step, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "skipped_steps": self.skipped_steps(), "total": self.total}
+
+    def load_state_dict(self, sd):
+        if sd["total"] != self.total:
+            raise ValueError(f"FlatAdamW.load_state_dict: flat size {sd['total']} != {self.total} (different model?)")
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+        if self._dev_step is not None:
+            self._dev_step.fill_(self.step_count)
+        self._clip[1] = float(sd.get("skipped_steps", 0))
+        self.refresh_shadows()
+
+    def skipped_steps(self):
+        """Steps whose gradient norm was NaN / Inf and whose update was therefore skipped (host read)."""
+        return int(self._clip[1].item())
+
+    def _rebind_grads(self):
+        """param.grad must be a view of flat_g.  torch's module.zero_grad() (set_to_none=True) detaches it and the kernels
+        then accumulate into freshly allocated tensors: fold those back (single rank), or fail loudly when buckets may
+        already have been all-reduced without them."""
+        base = self.flat_g.data_ptr()
+        for p, o in zip(self.params, self.offs):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * o:
+                continue
+            if self._collective:
+                raise RuntimeError("FlatAdamW: a parameter's .grad no longer points into the flat gradient buffer "
+                                   "(module.zero_grad(set_to_none=True)?) - use optimizer.zero_grad(); the gradient buckets "
+                                   "were all-reduced without it")
+            view = self.flat_g[o:o + p.numel()].view(p.shape)
+            if g is None:
+                view.zero_()
+            else:
+                view.copy_(g)
+            p.grad = view
 
     # ---- bucket plumbing ---------------------------------------------------------------------------
     def param_range(self, params):
@@ -92,6 +144,8 @@ class FlatAdamW:
 
     def step(self, reduce_all=False):
         F.flush_deferred()          # (no-op unless a backward ran outside functional.block)
+        if not (self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._rebind_grads()
         if self._collective:
             if reduce_all:
                 self.reduce_bucket_async(0, self.total)

@@ -40,3 +40,23 @@ def cell_dims_from_sd(sd, meta, enc_dim):
     else:
         kw["summary_hid_dim"], kw["summary_out_dim"] = [8], mg[-1]
     return kw
+
+
+def rms_rel(a, b):
+    """||a-b||_2 / ||b||_2 over the finite entries (the RMS-relative error reported next to rel_err)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    fin = torch.isfinite(b)
+    a, b = a[fin], b[fin]
+    if b.numel() == 0:
+        return 0.0
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def report(name, entries):
+    """Append measured errors to gpurun_out/parity_errors.jsonl (copied into DESIGN.md §2 / profiles/ by hand)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity_errors.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **entries}) + "\n")

@@ -173,3 +173,35 @@ def test_training_mode_gradients_match_finite_differences(kind):
         wpar.copy_(w0)
     fd, an = (fp - fm) / (2 * eps), (gw * u).sum()
     assert abs(float(fd - an)) <= 3e-2 * max(1.0, abs(float(an))), (kind, "dW", float(fd), float(an))
+
+
+@pytest.mark.parametrize("kind,seeds", [("conformer", 7), ("branchformer", 6)])
+def test_dropout_site_count_matches_reference(kind, seeds):
+    """Every dropout site of the reference layer draws exactly one seed per forward (the cell's dropout of
+    cat[local, summary] draws two, one per half).  Reference sites - Conformer.py:458-472,507-536: FFN inner + FFN module
+    (x2 modules), the cell's own (summary_mixing.py:237-239), the conv module's (Conformer.py:146-152) = 6 sites / 7 seeds;
+    Branchformer.py:270-334 + upstream CSGU: the cell's own, dropout(x1), the CSGU's dropout(x1 * conv(x2)), dropout(x2),
+    dropout(merge) = 5 sites / 6 seeds.  The cell's global_dropout is the cell default 0.1 in the Branchformer."""
+    from summarymixing_amd import ops
+    d = 32
+    if kind == "conformer":
+        from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoderLayer
+        layer = ConformerEncoderLayer(d_model=d, d_ffn=64, nhead=2, kernel_size=7, activation="swish", dropout=0.15,
+                                      attention_type="SummaryMixing", local_proj_hid_dim=[d], local_proj_out_dim=d,
+                                      summary_hid_dim=[d], mode="SummaryMixing-fast")
+        assert layer.mha_layer.global_dropout == 0.15           # Conformer.py:443 passes the layer dropout
+    else:
+        from summarymixing_amd.lobes.models.transformer.Branchformer import BranchformerEncoderLayer
+        layer = BranchformerEncoderLayer(d_model=d, nhead=1, kernel_size=7, activation="gelu", dropout=0.15,
+                                         csgu_linear_units=64, local_proj_hid_dim=[d], local_proj_out_dim=d,
+                                         summary_hid_dim=[d], summary_out_dim=d, mode="SummaryMixing")
+        assert layer.mha_layer.global_dropout == 0.1            # Branchformer.py:209-218: the cell default
+    layer = layer.cuda().train()
+    x = torch.randn(2, 20, d, device="cuda")
+    c0 = ops._drop_state["counter"]
+    layer(x)
+    assert ops._drop_state["counter"] - c0 == seeds
+    layer.eval()
+    c0 = ops._drop_state["counter"]
+    layer(x)
+    assert ops._drop_state["counter"] == c0

@@ -50,7 +50,7 @@ def test_branchformer_layer_golden(dtype):
                                      attention_type="SummaryMixing", csgu_linear_units=96, local_proj_hid_dim=[d],
                                      local_proj_out_dim=d, summary_hid_dim=[d], summary_out_dim=d, mode="SummaryMixing")
     layer.load_state_dict(sd, strict=True)
-    layer.cuda()
+    layer.cuda().eval()      # (the cell keeps its default global_dropout = 0.1 in train(), as the reference: Branchformer.py:209-218)
     x = a["x"].cuda().to(dtype).requires_grad_(True)
     y, _ = layer(x, src_key_padding_mask=a["pad_mask"].cuda())
     ftol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (2e-2, 5e-2)

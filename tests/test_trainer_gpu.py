@@ -1,0 +1,237 @@
+"""FlatAdamW on the GPU: the HIP backward writing into the flat gradient buffer, per-layer buckets
+all-reduced as each layer's backward ends, global-norm clip + smx_adamw_step - with world > 1 and over RCCL.
+
+  * 2 ranks sharing cuda:0 over gloo (the box has ONE GPU; on a node the same code is one rank per GPU over RCCL):
+    utterance-sharded step == single-process step on the concatenated batch (gradients and updated weights);
+  * a single-rank `nccl` (= RCCL) group with SMX_FORCE_ALLREDUCE=1: the bucketed collective path gives bit-for-bit the
+    weights of the collective-free step;
+  * optimizer housekeeping: bf16 shadows follow load_state_dict, state_dict round trip, torch's zero_grad(set_to_none)
+    does not lose gradients, a non-finite gradient norm skips the update."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+COMMON = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SMX_ROOT"])
+from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+from summarymixing_amd.trainer import FlatAdamW
+
+def model(dtype_seed=0):
+    torch.manual_seed(7)
+    d = 64
+    enc = ConformerEncoder(2, d, 128, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast")
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+            elif "bias" in n:
+                p.normal_(0, 0.05)
+    return enc.cuda()
+
+def hooks(enc, opt):
+    for layer in enc.layers:
+        rng = opt.param_range(list(layer.parameters()))
+        layer._on_bwd_done = (lambda r=rng: opt.reduce_bucket_async(*r))
+
+def tail(enc, opt):
+    first = opt.param_range(list(enc.layers[0].parameters()))[0]
+    last = opt.param_range(list(enc.layers[-1].parameters()))[1]
+    if first > 0:
+        opt.reduce_bucket_async(0, first)
+    if last < opt.total:
+        opt.reduce_bucket_async(last, opt.total)
+
+def one_step(enc, opt, x, pad, r, collective):
+    opt.zero_grad()
+    y, _ = enc(x, src_key_padding_mask=pad)
+    y.backward(r)
+    if collective:
+        tail(enc, opt)
+    opt.step()
+
+g = torch.Generator().manual_seed(3)
+B, T, d = 4, 120, 64
+X = torch.randn(B, T, d, generator=g).cuda()
+R = torch.randn(B, T, d, generator=g).cuda()
+lens = torch.tensor([T, 77, 101, 64])
+PAD = (torch.arange(T)[None] < lens[:, None]).cuda()
+'''
+
+DP_WORKER = COMMON + r'''
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dtype = torch.bfloat16 if os.environ["SMX_DTYPE"] == "bf16" else torch.float32
+torch.cuda.set_device(0)
+# reference: ONE process, the whole batch, no collective (built before the process group exists); the DP job averages the
+# shard gradients (1 / world), so the reference loss carries the same factor
+ref = model()
+ropt = FlatAdamW(ref, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
+assert ropt.world == 1 and not ropt._collective
+one_step(ref, ropt, X.to(dtype), PAD, (R / world).to(dtype), False)
+ref_g = ropt.flat_g.clone()
+
+dist.init_process_group("gloo", rank=rank, world_size=world)
+enc = model()
+opt = FlatAdamW(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
+assert opt.world == world and opt._collective
+hooks(enc, opt)
+sl = slice(rank * B // world, (rank + 1) * B // world)            # this rank's utterances
+one_step(enc, opt, X[sl].to(dtype), PAD[sl], R[sl].to(dtype), True)
+
+def close(a, b, what, tol):
+    err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    assert err < tol, f"rank {rank} {what}: rel err {err:.3e}"
+tol = 2e-5 if dtype == torch.float32 else 2e-2
+close(opt.flat_g / world, ref_g, "all-reduced gradient", tol)
+close(opt.flat_p, ropt.flat_p, "updated weights", tol if dtype == torch.float32 else 2e-3)
+# every rank ends with the same weights, bit for bit
+mine = opt.flat_p.cpu()
+other = [torch.empty_like(mine) for _ in range(world)]
+dist.all_gather(other, mine)
+assert all(torch.equal(o, mine) for o in other), "ranks diverged"
+dist.barrier()
+print(f"rank {rank} OK")
+'''
+
+NCCL_WORKER = COMMON + r'''
+torch.cuda.set_device(0)
+dtype = torch.bfloat16
+ref = model()
+ropt = FlatAdamW(ref, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
+assert not ropt._collective
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+enc = model()
+opt = FlatAdamW(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
+assert opt._collective and opt.world == 1, "SMX_FORCE_ALLREDUCE=1 must switch the RCCL bucket path on"
+hooks(enc, opt)
+for it in range(3):
+    one_step(ref, ropt, X.to(dtype), PAD, R.to(dtype), False)
+    one_step(enc, opt, X.to(dtype), PAD, R.to(dtype), True)
+torch.cuda.synchronize()
+assert torch.equal(opt.flat_g, ropt.flat_g), "gradients differ"
+assert torch.equal(opt.flat_p, ropt.flat_p), "weights differ"
+assert torch.equal(opt.shadow, ropt.shadow)
+dist.barrier()
+dist.destroy_process_group()
+print("rank 0 OK")
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(script, world, extra):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SMX_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    for rank, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+            out += "\n[timeout]"
+        assert p.returncode == 0 and f"rank {rank} OK" in out, f"rank {rank} failed:\n{out[-3000:]}"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_two_ranks_hip_backward_through_buckets_equals_single_process(dtype):
+    _launch(DP_WORKER, 2, {"SMX_DTYPE": dtype})
+
+
+def test_single_rank_rccl_bucket_path_is_bit_identical():
+    _launch(NCCL_WORKER, 1, {"SMX_FORCE_ALLREDUCE": "1"})
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` self-launches N ranks; with fewer GPUs visible it must fail loudly, never run 1 rank."""
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout), (p.returncode, p.stderr[-500:])
+    assert '"n_gpus"' not in p.stdout
+
+
+def _small(dtype=torch.bfloat16):
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    from summarymixing_amd.trainer import FlatAdamW
+    torch.manual_seed(5)
+    d = 64
+    enc = ConformerEncoder(1, d, 128, 4, kernel_size=15, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast").cuda()
+    opt = FlatAdamW(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
+    x = torch.randn(3, 50, d, device="cuda").to(dtype)
+    r = torch.randn(3, 50, d, device="cuda").to(dtype)
+    return enc, opt, x, r
+
+
+def test_shadows_follow_load_state_dict_and_optimizer_state_round_trips():
+    enc, opt, x, r = _small()
+    for _ in range(2):
+        opt.zero_grad()
+        enc(x)[0].backward(r)
+        opt.step()
+    sd_model = {k: v.clone() for k, v in enc.state_dict().items()}
+    sd_opt = opt.state_dict()
+    assert sd_opt["step"] == 2
+    with torch.no_grad():
+        y_ref = enc(x)[0].clone()
+    # a third step from the checkpointed state, twice: directly, and after clobbering + restoring everything
+    opt.zero_grad(); enc(x)[0].backward(r); opt.step()
+    p_after = opt.flat_p.clone()
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.mul_(0.5)                                   # in-place change behind the optimizer's back
+    opt.exp_avg.zero_(); opt.exp_avg_sq.fill_(7.0); opt.step_count = 99
+    enc.load_state_dict(sd_model)                         # post-hook: the bf16 shadows must follow
+    opt.load_state_dict(sd_opt)
+    with torch.no_grad():
+        assert torch.equal(enc(x)[0], y_ref), "bf16 shadows are stale after load_state_dict"
+    opt.zero_grad(); enc(x)[0].backward(r); opt.step()
+    assert torch.equal(opt.flat_p, p_after), "resume is not bit-identical"
+
+
+def test_module_zero_grad_set_to_none_keeps_gradients():
+    enc, opt, x, r = _small(torch.float32)
+    opt.zero_grad(); enc(x)[0].backward(r)
+    g_ref = opt.flat_g.clone()
+    opt.step()
+    p_ref = opt.flat_p.clone()
+    enc2, opt2, _, _ = _small(torch.float32)
+    enc2.zero_grad(set_to_none=True)                      # detaches every .grad from the flat buffer
+    enc2(x)[0].backward(r)
+    opt2.step()                                           # must fold the fresh gradient tensors back, not apply decay only
+    assert torch.equal(opt2.flat_g, g_ref) and torch.equal(opt2.flat_p, p_ref)
+    assert all(p.grad.data_ptr() == opt2.flat_g.data_ptr() + 4 * o for p, o in zip(opt2.params, opt2.offs))
+
+
+def test_non_finite_gradient_norm_skips_the_update():
+    enc, opt, x, r = _small()
+    opt.zero_grad(); enc(x)[0].backward(r); opt.step()
+    p0, m0, sh0 = opt.flat_p.clone(), opt.exp_avg.clone(), opt.shadow.clone()
+    opt.zero_grad(); enc(x)[0].backward(r)
+    opt.flat_g[123] = float("nan")                        # one poisoned gradient element (a bad batch)
+    opt.step()
+    assert opt.skipped_steps() == 1
+    assert torch.equal(opt.flat_p, p0) and torch.equal(opt.exp_avg, m0) and torch.equal(opt.shadow, sh0)
+    opt.zero_grad(); enc(x)[0].backward(r); opt.flat_g[5] = float("inf"); opt.step()
+    assert opt.skipped_steps() == 2 and torch.equal(opt.flat_p, p0)
+    opt.zero_grad(); enc(x)[0].backward(r); opt.step()    # a clean step still updates
+    assert opt.skipped_steps() == 2 and not torch.equal(opt.flat_p, p0) and torch.isfinite(opt.flat_p).all()
