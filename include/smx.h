@@ -98,6 +98,27 @@ int smx_linear_wgrad_partial(int dtype, const void* dZ, int64_t lddz, int64_t st
                              int64_t strideX, int rows, int M, int K, int batch, int want_bias, void* workspace,
                              int32_t* nslabs, int64_t* slab_stride, int64_t* bias_offset, void* stream);
 
+/* ALL the weight gradients of one encoder layer in one launch (bf16): for every item w
+ *   slabs_w[s] (M_w x K_w, fp32) = dZ_w[rows of slice s]^T X_w[rows of slice s],     s < splits
+ * and, with want_bias, bias partials [splits][M_w] (column sums of dZ_w) behind the slabs in the item's workspace
+ * (smx_wgrad_group_workspace(M, K, splits) bytes, 16-byte aligned); fold them with smx_reduce_jobs
+ * (src = workspace, src_stride = M*K, nsrc = splits; bias: src = workspace + splits*M*K floats, src_stride = M).
+ * Every item reduces over the SAME `rows` frames (rows % 64 == 0: peel a tail through smx_linear_wgrad), M and K are
+ * multiples of 256, operands 16-byte aligned with leading dimensions % 8 == 0.  One 512-thread workgroup per CU owns a
+ * (weight, 256 x 256 tile, K slice) item; smx_wgrad_group_splits picks the slice count that fills the chip once.
+ * Autograd backward (dW, db) of all the nn.Linear / Conv1d(k=1) modules of a ConformerEncoderLayer /
+ * BranchformerEncoderLayer (Conformer.py:479-537, Branchformer.py:243-334) at once. */
+#define SMX_WGRAD_GROUP_MAX 16
+typedef struct smx_wgrad_item {
+  const void* dZ; int64_t lddz;      /* (rows, M) gradient w.r.t. the layer's pre-activation                 */
+  const void* X;  int64_t ldx;       /* (rows, K) the layer's input                                          */
+  void* workspace;                   /* [splits][M*K] fp32 slabs, then [splits][M] bias partials             */
+  int32_t M, K, want_bias, pad;
+} smx_wgrad_item;
+int smx_wgrad_group_splits(int rows, const smx_wgrad_item* items, int nitems);
+size_t smx_wgrad_group_workspace(int M, int K, int splits);
+int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items, int nitems, int splits, void* stream);
+
 /* One launch for many small fixed-order reductions
  *   dst[i*ldd + j] += alpha * sum_{s < nsrc} src[s*src_stride + i*src_ld + j]      (i < rows, j < cols; src_ld 0 = cols)
  * : weight-gradient slabs, bias partials, LayerNorm dgamma/dbeta partial rows.  `vec` = 1

@@ -27,6 +27,14 @@ class ReduceJob(ctypes.Structure):
                 ("src_ld", ctypes.c_int32)]
 
 
+class WgradItem(ctypes.Structure):
+    _fields_ = [("dZ", c_vp), ("lddz", c_i64), ("X", c_vp), ("ldx", c_i64), ("workspace", c_vp),
+                ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("want_bias", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+WGRAD_GROUP_MAX = 16
+
+
 class Epilogue(ctypes.Structure):
     _fields_ = [("bias", c_vp), ("bias_batch_stride", c_i64),
                 ("c0", c_vp), ("ldc0", c_i64), ("c0_mode", ctypes.c_int32), ("c0_div", ctypes.c_int32),
@@ -51,6 +59,9 @@ SIGNATURES = {
                                c_f, c_vp, c_vp]),
     "smx_linear_wgrad_partial": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp,
                                        ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_vp]),
+    "smx_wgrad_group_splits": (c_i, [c_i, ctypes.POINTER(WgradItem), c_i]),
+    "smx_wgrad_group_workspace": (c_sz, [c_i, c_i, c_i]),
+    "smx_wgrad_group": (c_i, [c_i, c_i, ctypes.POINTER(WgradItem), c_i, c_i, c_vp]),
     "smx_reduce_job_blocks": (c_i, [ctypes.POINTER(ReduceJob)]),
     "smx_reduce_jobs": (c_i, [c_vp, c_vp, c_i, c_i, c_vp]),
     "smx_layernorm_bwd_blocks": (c_i, [c_i]),

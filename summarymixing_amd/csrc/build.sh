@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wall -Wno-unused-function)
 mkdir -p "${HERE}/obj"
 pids=()
-for f in capi gemm rowwise dwconv frontend ctc reduce; do
+for f in capi gemm rowwise dwconv frontend ctc reduce wgrad_group; do
   src="${HERE}/${f}.hip"; obj="${HERE}/obj/${f}.o"
   if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/smx_common.h" -nt "$obj" || "${HERE}/../../include/smx.h" -nt "$obj" ]]; then
     "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$obj" &
@@ -15,5 +15,5 @@ for f in capi gemm rowwise dwconv frontend ctc reduce; do
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${HERE}"/obj/{capi,gemm,rowwise,dwconv,frontend,ctc,reduce}.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${HERE}"/obj/{capi,gemm,rowwise,dwconv,frontend,ctc,reduce,wgrad_group}.o
 echo "built $OUT"

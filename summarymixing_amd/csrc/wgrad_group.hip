@@ -1,0 +1,269 @@
+// wgrad_group.hip — ALL the weight gradients of one encoder layer in ONE launch (bf16, gfx950).
+//
+//   for every weight w of the group:   dW_w (M_w x K_w) = dZ_w^T X_w     reduce over the same `rows` frames
+//
+// Why a grouped kernel (profiles/r01_step_c2b_v14.txt): one launch per weight needs ~24 split-K
+// slices of a 1024 x 256 weight to fill 256 CUs - 42 K steps per workgroup between a DMA cold start and a slab
+// epilogue, 25 MB of fp32 slabs per weight (200 MB per layer, written and read back), and with 128 x 128 tiles every
+// operand byte crosses L2 -> LDS 3.2 times.  A Conformer layer has 8 such weights = 23 tiles of 256 x 256: together
+// they fill the chip with 11 slices each, i.e. ~90 K steps per workgroup, 8x less slab volume, and the 256 x 256 tile
+// halves the L2 -> LDS traffic per flop.
+//
+// Kernel: one workgroup of 512 threads (8 waves, 4 x 2) per CU owns one (weight, 256 x 256 tile, K slice) item.  Both
+// operands are reduce-strided (a k row = 256 contiguous columns = 512 B) and go HBM/L2 -> LDS by
+// global_load_lds_dwordx4 into a ring of NST stages of BK frames (128 KB of LDS: 2 x 64 or 4 x 32 frames), one barrier
+// per K step, no operand VGPRs; fragments come out through ds_read_b64_tr_b16 (hardware 4 x 16 transpose).
+// LDS image of an operand stage: element (k, c) at k * 512 + (((c >> 3) ^ ((k & 3) << 2)) << 4) + (c & 7) * 2 - the DMA
+// lands a 1 KB piece (2 k rows) linearly, so the XOR is applied to the SOURCE column granule (cf. gemm_tn_dma_kernel).
+// Each wave accumulates 64 x 128 outputs (8 fragments of 32 x 32, 128 accumulator registers); the bias gradient
+// (column sums of dZ) is summed on the VALU from the A fragments the wave holds anyway, in the waves that own the
+// first X column tile.  Output: fp32 slabs [splits][M][K] (+ [splits][M] bias partials) per weight, folded into the
+// gradients by smx_reduce_jobs in a fixed order (bit-reproducible, no atomics).
+#include <stdlib.h>
+
+#include "smx_common.h"
+
+namespace smx {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int WG_MAX_ITEMS = SMX_WGRAD_GROUP_MAX;
+constexpr int WG_TILE = 256;
+
+struct WgItem {
+  const bf16_t* A;      // dZ (rows x M), row stride lda
+  const bf16_t* B;      // X  (rows x K), row stride ldb
+  float* ws;            // [splits][M*K] slabs, then [splits][M] bias partials
+  long lda, ldb;
+  int M, K;
+  int tile0, tiles_m;   // first global tile index of this weight, K / 256
+  int want_bias, pad;
+};
+
+struct WgGroupParams {
+  WgItem it[WG_MAX_ITEMS];
+  int nitems, total_tiles, splits, ksteps_per_split, rows;   // rows: multiple of 64 (the host peels the tail)
+};
+
+__device__ __forceinline__ void wg_glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// fragment of a reduce-strided stage (512-byte k rows): lane (l31, hi) receives k = kk*16 + hi*8 .. +7 of column cbase+l31
+__device__ __forceinline__ bf16x8 wg_frag(const char* lds, int cbase, int l31, int hi, int kk) {
+  typedef short short4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) short4_t* lds_s4;
+  const int lane = l31 | (hi << 5);
+  const int li = lane & 15, g1 = (lane >> 4) & 1;
+  const int k = kk * 16 + hi * 8 + (li >> 2);           // (k & 3) == li >> 2; row k + 4 has the same swizzle
+  const int c = cbase + g1 * 16 + (li & 3) * 4;
+  const char* p0 = lds + k * 512 + ((((c >> 3) ^ ((li >> 2) << 2)) << 4) + (c & 7) * 2);
+  const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
+  const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * 512));
+  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
+}
+
+__device__ __forceinline__ float wg_sum8(const bf16x8& f) {
+  const uint4 u = __builtin_bit_cast(uint4, f);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { s0 += __uint_as_float(w[q] << 16); s1 += __uint_as_float(w[q] & 0xffff0000u); }
+  return s0 + s1;
+}
+
+template <int BK>
+__global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams p) {
+  constexpr int NST = 128 / BK;                          // ring stages in 128 KB
+  constexpr int OP_BYTES = BK * 512, STAGE_BYTES = 2 * OP_BYTES;
+  constexpr int NPC = BK / 16;                           // 1 KB pieces (2 k rows) per wave, operand and stage
+  static_assert(BK == 64 || BK == 32, "ring of 2 x 64 or 4 x 32 frames");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi = lane >> 5;
+
+  // ---- work item: each XCD (workgroup id % 8) takes a contiguous run of the (split, tile) list, so the tiles of one
+  // weight that read the same K range sit on the same XCD's L2 at the same time
+  const int nwork = p.total_tiles * p.splits;
+  const int per = (nwork + 7) >> 3;
+  const int q = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || q >= nwork) return;
+  const int split = q / p.total_tiles, tg = q % p.total_tiles;
+  int w = 0;
+#pragma unroll 1
+  for (int i = 1; i < p.nitems; ++i)
+    if (tg >= p.it[i].tile0) w = i;
+  const WgItem& it = p.it[w];
+  const int tl = tg - it.tile0, tile_n = tl / it.tiles_m, tile_m = tl % it.tiles_m;
+  const int n0 = tile_n * WG_TILE, m0 = tile_m * WG_TILE;
+  const int kbeg = split * p.ksteps_per_split * 64;
+  const int kend = min(p.rows, kbeg + p.ksteps_per_split * 64);
+  const int niter = kend > kbeg ? (kend - kbeg) / BK : 0;
+
+  // ---- DMA source pointers: piece pc = wave + 8 j holds k rows 2 pc, 2 pc + 1 of the stage; lane -> (row, granule)
+  const int prow = lane >> 5, krow = 2 * wave + prow;    // (k row index mod 4 is the same for every j: 16 j = 0 mod 4)
+  const int gsrc = ((lane & 31) ^ ((krow & 3) << 2)) * 8;
+  const bf16_t* pa[NPC];
+  const bf16_t* pb[NPC];
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const long kr = kbeg + 2 * (wave + 8 * j) + prow;
+    pa[j] = it.A + kr * it.lda + n0 + gsrc;
+    pb[j] = it.B + kr * it.ldb + m0 + gsrc;
+  }
+  const long stepa = (long)BK * it.lda, stepb = (long)BK * it.ldb;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem + wave * 1024);
+  auto issue = [&](int s) {
+    const uint32_t dst = wave_lds + (s % NST) * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      wg_glds16(pa[j], dst + j * 8192);
+      wg_glds16(pb[j], dst + OP_BYTES + j * 8192);
+      pa[j] += stepa;
+      pb[j] += stepb;
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+  const bool do_cs = it.want_bias && tile_m == 0 && wm == 0;     // (uniform per wave)
+
+  for (int s = 0; s < NST - 1 && s < niter; ++s) issue(s);
+  for (int itn = 0; itn < niter; ++itn) {
+    // this wave's pieces of stage `itn` have landed once at most the (2 NPC each) DMA instructions of the younger stages
+    // in flight are outstanding (vmcnt retires in order; nothing else uses vector memory in this loop)
+    const int ahead = min(NST - 2, niter - 1 - itn);
+    if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
+    else if (NST >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();                                        // ... and everybody's; the stage read last step is free again
+    if (itn + NST - 1 < niter) issue(itn + NST - 1);
+    const char* As = smem + (itn % NST) * STAGE_BYTES;
+    const char* Bs = As + OP_BYTES;
+    bf16x8 fa[2][2], fb[2][4];                           // fragments double-buffered over the 16-frame sub-steps
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[0][i] = wg_frag(As, wn * 64 + i * 32, l31, hi, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[0][j] = wg_frag(Bs, wm * 128 + j * 32, l31, hi, 0);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[nxt][i] = wg_frag(As, wn * 64 + i * 32, l31, hi, kk + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[nxt][j] = wg_frag(Bs, wm * 128 + j * 32, l31, hi, kk + 1);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bsum[i] += wg_sum8(fa[cur][i]);
+      }
+    }
+  }
+
+  // ---- slab: acc[i][j][g*4 + q] is dW[n0 + wn*64 + i*32 + l31][m0 + wm*128 + j*32 + g*8 + hi*4 + q] ----------------
+  float* slab = it.ws + (long)split * it.M * it.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + wn * 64 + i * 32 + l31;
+    float* row = slab + (long)n * it.K + m0 + wm * 128 + hi * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(row + j * 32 + g * 8) =
+            make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+  }
+  if (do_cs) {
+    float* bpart = it.ws + (long)p.splits * it.M * it.K + (long)split * it.M;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);      // the two k halves (hi = 0 / 1) of the same column
+      if (hi == 0) bpart[n0 + wn * 64 + i * 32 + l31] = s;
+    }
+  }
+}
+
+static int wg_splits(int rows, int total_tiles) {
+  static const int target_env = getenv("SMX_WGROUP_BLOCKS") ? atoi(getenv("SMX_WGROUP_BLOCKS")) : 0;
+  const int target = target_env > 0 ? target_env : 256;           // one workgroup per CU
+  int s = target / (total_tiles > 0 ? total_tiles : 1);
+  const int nk = rows / 64;
+  const int smax = nk / 8 > 0 ? nk / 8 : 1;                        // at least 8 K steps (512 frames) per slice
+  if (s > smax) s = smax;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace smx
+
+using namespace smx;
+
+extern "C" int smx_wgrad_group_splits(int rows, const smx_wgrad_item* items, int nitems) {
+  if (!items || nitems <= 0 || rows < 64) return 0;
+  int tiles = 0;
+  for (int i = 0; i < nitems; ++i) tiles += (items[i].M / WG_TILE) * (items[i].K / WG_TILE);
+  return wg_splits(rows - rows % 64, tiles);
+}
+
+extern "C" size_t smx_wgrad_group_workspace(int M, int K, int splits) {
+  if (M <= 0 || K <= 0 || splits <= 0) return 0;
+  return (size_t)splits * ((size_t)M * K + M) * sizeof(float);
+}
+
+extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items, int nitems, int splits, void* stream) {
+  SMX_REQUIRE(dtype == SMX_BF16, "smx_wgrad_group: bf16 only (fp32 weights take smx_linear_wgrad)");
+  SMX_REQUIRE(items && nitems >= 1 && nitems <= WG_MAX_ITEMS, "smx_wgrad_group: 1..%d items per launch", WG_MAX_ITEMS);
+  SMX_REQUIRE(rows >= 64 && rows % 64 == 0 && splits >= 1, "smx_wgrad_group: rows must be a positive multiple of 64 (peel the tail)");
+  WgGroupParams p;
+  memset(&p, 0, sizeof(p));
+  int tiles = 0;
+  for (int i = 0; i < nitems; ++i) {
+    const smx_wgrad_item& s = items[i];
+    SMX_REQUIRE(s.dZ && s.X && s.workspace, "smx_wgrad_group: null pointer in item %d", i);
+    SMX_REQUIRE(s.M > 0 && s.K > 0 && s.M % WG_TILE == 0 && s.K % WG_TILE == 0, "smx_wgrad_group: item %d: M, K must be multiples of 256", i);
+    SMX_REQUIRE(aligned16(s.dZ) && aligned16(s.X) && aligned16(s.workspace) && s.lddz % 8 == 0 && s.ldx % 8 == 0 &&
+                s.lddz >= s.M && s.ldx >= s.K, "smx_wgrad_group: item %d: operands must be 16-byte aligned with ld %% 8 == 0", i);
+    WgItem& d = p.it[i];
+    d.A = reinterpret_cast<const bf16_t*>(s.dZ); d.B = reinterpret_cast<const bf16_t*>(s.X);
+    d.ws = reinterpret_cast<float*>(s.workspace);
+    d.lda = s.lddz; d.ldb = s.ldx; d.M = s.M; d.K = s.K;
+    d.tile0 = tiles; d.tiles_m = s.K / WG_TILE; d.want_bias = s.want_bias;
+    tiles += (s.M / WG_TILE) * (s.K / WG_TILE);
+  }
+  p.nitems = nitems; p.total_tiles = tiles; p.splits = splits; p.rows = rows;
+  const int nk = rows / 64;
+  p.ksteps_per_split = (nk + splits - 1) / splits;
+  const int nwork = tiles * splits, per = (nwork + 7) / 8;
+  static const int bk_env = getenv("SMX_WGROUP_BK") ? atoi(getenv("SMX_WGROUP_BK")) : 64;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess)
+      return fail(SMX_ELAUNCH, "smx_wgrad_group: cannot reserve 128 KB of LDS");
+    attr_done = true;
+  }
+  if (bk_env == 32) hipLaunchKernelGGL(wgrad_group_kernel<32>, dim3(8 * per), dim3(512), 131072, s, p);
+  else hipLaunchKernelGGL(wgrad_group_kernel<64>, dim3(8 * per), dim3(512), 131072, s, p);
+  return check_launch("smx_wgrad_group");
+}

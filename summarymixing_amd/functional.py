@@ -90,11 +90,16 @@ class _Deferred:
     side_enabled = os.environ.get("SMX_WGRAD_STREAM", "1") != "0"
     side = {}        # device -> side stream of the slab GEMMs
     side_used = False
+    # grouped wgrad: the bf16 weight gradients of a block (= encoder layer) whose dims are multiples of 256 are recorded
+    # and computed by ONE smx_wgrad_group launch at the end of the block's backward (SMX_WGRAD_GROUP=0: one slab GEMM each)
+    group_enabled = os.environ.get("SMX_WGRAD_GROUP", "1") != "0"
+    group = []       # (dz, x, gW, dbias, N, M, K)
+    group_min_rows = 2048
 
 
-def deferred_ws(key, nbytes, device):
+def deferred_ws(key, nbytes, device, check=True):
     """Persistent workspace of one producer call site (keyed by the gradient buffer it feeds)."""
-    if key in _Deferred.pending:
+    if check and key in _Deferred.pending:
         flush_deferred()                       # the same parameter twice inside one block: reduce the first use now
     t = _Deferred.ws.get(key)
     if t is None and len(_Deferred.ws) >= 2048:           # gradient buffers keep being re-allocated at new addresses:
@@ -115,7 +120,38 @@ def defer(src_ptr, dst, src_stride, nsrc, rows, cols, alpha=1.0):
     _Deferred.jobs.append((src_ptr, dst.data_ptr(), src_stride, ldd, nsrc, rows, cols, alpha))
 
 
+def _launch_groups():
+    """The recorded weight gradients of this block: one smx_wgrad_group launch per (frame count, <= 16 weights); rows
+    beyond the last multiple of 64 frames go through the ordinary wgrad; slabs / bias partials become reduction jobs."""
+    recs, _Deferred.group = _Deferred.group, []
+    by_n = {}
+    for r in recs:
+        by_n.setdefault(r[4], []).append(r)
+    lib = L.lib()
+    for N, rs in by_n.items():
+        n64 = N - N % 64
+        for c0 in range(0, len(rs), L.WGRAD_GROUP_MAX):
+            chunk = rs[c0:c0 + L.WGRAD_GROUP_MAX]
+            items = (L.WgradItem * len(chunk))()
+            for it, (dz, x, gW, dbias, _, M, K) in zip(items, chunk):
+                it.dZ, it.lddz, it.X, it.ldx = dz.data_ptr(), dz.stride(0), x.data_ptr(), x.stride(0)
+                it.M, it.K, it.want_bias = M, K, int(dbias is not None)
+            splits = lib.smx_wgrad_group_splits(n64, items, len(chunk))
+            for it, (dz, x, gW, dbias, _, M, K) in zip(items, chunk):
+                ws = deferred_ws(gW.data_ptr(), lib.smx_wgrad_group_workspace(M, K, splits), dz.device, check=False)
+                it.workspace = ws.data_ptr()
+            ops.wgrad_group(items, len(chunk), n64, splits)
+            for it, (dz, x, gW, dbias, _, M, K) in zip(items, chunk):
+                defer(it.workspace, gW, M * K, splits, M, K)
+                if dbias is not None:
+                    defer(it.workspace + 4 * splits * M * K, dbias, M, splits, 1, M)
+                if n64 < N:
+                    ops.wgrad(dz[n64:], x[n64:], gW, N - n64, M, K, dbias=dbias)
+
+
 def flush_deferred():
+    if _Deferred.group:
+        _launch_groups()
     if not _Deferred.jobs:
         _Deferred.pending.clear()
         return
@@ -148,6 +184,14 @@ def _wgrad(dz, x, gW, N, M, K, dbias):
         ops.wgrad(dz, x, gW, N, M, K, dbias=dbias)
         return
     key = gW.data_ptr()
+    if (_Deferred.group_enabled and dz.dtype == torch.bfloat16 and M % 256 == 0 and K % 256 == 0
+            and N >= _Deferred.group_min_rows and dz.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+            and dz.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+        if key in _Deferred.pending:
+            flush_deferred()                   # the same parameter twice inside one block: finish the first use now
+        _Deferred.pending.add(key)
+        _Deferred.group.append((dz, x, gW, dbias, N, M, K))
+        return
     ws = deferred_ws(key, L.lib().smx_linear_wgrad_workspace(N, M, K, 1), dz.device)
     if _Deferred.side_enabled and not torch.cuda.is_current_stream_capturing():
         # the slab GEMM only feeds the deferred reduction: run it on a side stream next to the dgrad chain (its reads

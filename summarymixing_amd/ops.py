@@ -181,6 +181,19 @@ def wgrad_partial(dz, x, rows, M, K, ws, batch=1, sz=0, sx=0, lddz=None, ldx=Non
     return n.value, st.value, bo.value
 
 
+def wgrad_group(items, nitems, rows, splits):
+    """One launch for all the weight gradients of a layer (smx_wgrad_group): `items` is a ctypes array of L.WgradItem with
+    workspaces attached; the slabs / bias partials stay in those workspaces for reduce_jobs."""
+    tok = None
+    if _PROF is not None:
+        nb = sum((items[i].M + items[i].K) * rows * 2 + 4 * items[i].M * items[i].K for i in range(nitems))
+        fl = sum(2.0 * rows * items[i].M * items[i].K for i in range(nitems))
+        tok = _pb(f"wgrad_group bf16 ({nitems} weights: " + " ".join(f"{items[i].M}x{items[i].K}" for i in range(nitems)) +
+                  f") over {rows} frames", nb, fl)
+    L.check(L.lib().smx_wgrad_group(L.BF16, rows, items, nitems, splits, _stream()), "smx_wgrad_group")
+    _pe(tok)
+
+
 def reduce_jobs(jobs_dev, starts_dev, njobs, total_blocks, nbytes=0):
     tok = _pb(f"reduce_jobs ({njobs} jobs)", nbytes)
     L.check(L.lib().smx_reduce_jobs(_p(jobs_dev), _p(starts_dev), njobs, total_blocks, _stream()), "smx_reduce_jobs")

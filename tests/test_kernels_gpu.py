@@ -459,3 +459,67 @@ def test_gemm_register_domain_epilogue(N, K, M):
     assert rel_err(ya.float(), yb.float()) < 1e-6
     keep = (ya != 0).float().mean().item() / mask.float().mean().item()
     assert abs(keep - 0.85) < 0.01
+
+
+# ---- grouped wgrad: all the weight gradients of a layer in one launch (smx_wgrad_group) ------------------------------
+def _wgroup_case(rows, shapes, bias, seed=0, strided=False):
+    """shapes: list of (M, K).  Returns max rel errors of dW / db against fp64 math on the bf16 inputs."""
+    import ctypes
+    from summarymixing_amd import _lib as L, functional as F, ops
+    torch.manual_seed(seed)
+    recs = []
+    for i, (M, K) in enumerate(shapes):
+        if strided:                                   # column slices of wider buffers (explicit leading dimensions)
+            dz = (torch.randn(rows, M + 64, device="cuda") * 0.5).bfloat16()[:, 32:32 + M]
+            x = torch.randn(rows, 2 * K, device="cuda").bfloat16()[:, K:]
+        else:
+            dz = (torch.randn(rows, M, device="cuda") * 0.5).bfloat16()
+            x = torch.randn(rows, K, device="cuda").bfloat16()
+        gW = torch.randn(M, K, device="cuda")          # accumulate semantics: += on top of what is there
+        gb = torch.randn(M, device="cuda") if bias[i] else None
+        recs.append((dz, x, gW, gb, gW.clone(), gb.clone() if gb is not None else None))
+    for dz, x, gW, gb, _, _ in recs:
+        F._wgrad(dz, x, gW, rows, dz.shape[1], x.shape[1], gb)
+    assert len(F._Deferred.group) == len(shapes), "the grouped path must take these shapes"
+    F.flush_deferred()
+    torch.cuda.synchronize()
+    errs = []
+    for dz, x, gW, gb, gW0, gb0 in recs:
+        ref = gW0.double() + dz.double().t() @ x.double()
+        errs.append(float((gW.double() - ref).abs().max() / ref.abs().max()))
+        if gb is not None:
+            refb = gb0.double() + dz.double().sum(0)
+            errs.append(float((gb.double() - refb).abs().max() / refb.abs().max()))
+    return max(errs)
+
+
+@pytest.mark.parametrize("rows", [2048, 4160, 64000, 33000])      # 33000 and 4160 % 64 != 0: tail rows through the ordinary wgrad
+def test_wgrad_group_conformer_layer_shapes(rows):
+    shapes = [(1024, 256), (256, 1024), (1024, 256), (256, 1024), (512, 256), (256, 512), (512, 256), (256, 256)]
+    err = _wgroup_case(rows, shapes, [True] * 8)
+    assert err < 2e-5, err
+
+
+def test_wgrad_group_strided_operands_mixed_bias_and_single_item():
+    assert _wgroup_case(8192, [(512, 512), (256, 768)], [False, True], seed=1, strided=True) < 2e-5
+    assert _wgroup_case(16384, [(256, 256)], [True], seed=2) < 2e-5
+    # more weights than one launch takes (SMX_WGRAD_GROUP_MAX = 16): split into two launches
+    assert _wgroup_case(4096, [(256, 256)] * 18, [True, False] * 9, seed=3) < 2e-5
+
+
+def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
+    from summarymixing_amd import functional as F, ops
+    torch.manual_seed(4)
+    rows, M, K = 20000, 512, 256
+    dz = (torch.randn(rows, M, device="cuda") * 0.5).bfloat16()
+    x = torch.randn(rows, K, device="cuda").bfloat16()
+    outs = []
+    for _ in range(2):
+        gW, gb = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
+        F._wgrad(dz, x, gW, rows, M, K, gb)
+        F.flush_deferred()
+        outs.append((gW.clone(), gb.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    gW2, gb2 = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
+    ops.wgrad(dz, x, gW2, rows, M, K, dbias=gb2)        # the per-weight slab GEMM + reduction
+    assert rel_err(outs[0][0], gW2) < 1e-5 and rel_err(outs[0][1], gb2) < 1e-5
