@@ -312,8 +312,11 @@ int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, const int32
  * (smx_step_counter_add is itself a captured kernel).  NULL restores the plain by-value behaviour. */
 int smx_set_step_counter(const uint64_t* dev_counter);
 int smx_step_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream);
-/* out[0] += sum(x^2) (fp32 atomics; zero it first) — global grad-norm for clipping. */
-int smx_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* out[0] += sum(x^2) — global grad-norm for clipping (zero out[0] first).  Fixed summation order (per-block partials in
+ * `workspace`, smx_sumsq_workspace() bytes, folded by one block; no atomics): data-parallel ranks holding the same
+ * all-reduced gradients get bit-identical norms, clip factors and weights. */
+size_t smx_sumsq_workspace(void);
+int smx_sumsq(const float* x, int64_t n, float* out, void* workspace, void* stream);
 /* out[0] = min(1, max_norm / (sqrt(sumsq[0]) * inv_scale + 1e-6)) : clip factor computed on device.  `out` is fp32[2]:
  * when sumsq[0] is NaN / Inf (a bad batch: bf16 overflow, a zero-length utterance) out[0] = 0 and out[1] += 1 (skipped-step
  * counter); smx_adamw_step treats a device factor of exactly 0 as "skip the update" (no decay, no moments, no shadow

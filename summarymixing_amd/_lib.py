@@ -111,7 +111,8 @@ SIGNATURES = {
                                c_vp]),
     "smx_set_step_counter": (c_i, [c_vp]),
     "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
-    "smx_sumsq": (c_i, [c_vp, c_i64, c_vp, c_vp]),
+    "smx_sumsq_workspace": (c_sz, []),
+    "smx_sumsq": (c_i, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "smx_clip_factor": (c_i, [c_vp, c_f, c_f, c_vp, c_vp]),
 }
 

@@ -962,14 +962,27 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
   }
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out) {
+// Global gradient norm in a FIXED order (no atomics): per-block partial sums, then one block folds them.  Data-parallel
+// ranks hold bit-identical all-reduced gradients; an order-dependent norm would give them clip factors that differ in the
+// last bits and let their weights drift apart.
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* partial) {
   __shared__ float red[4];
   float s = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, int np, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ void clip_factor_kernel(const float* sumsq, float max_norm, float inv_scale, float* out) {
   const float ss = sumsq[0];
@@ -1348,12 +1361,14 @@ extern "C" int smx_adamw_step(float* param, const float* grad, float* exp_avg, f
                      step > 0 ? nullptr : g_step_counter);
   return check_launch("smx_adamw_step");
 }
-extern "C" int smx_sumsq(const float* x, int64_t n, float* out, void* stream) {
-  SMX_REQUIRE(x && out, "smx_sumsq: null pointer");
+extern "C" size_t smx_sumsq_workspace(void) { return SUMSQ_BLOCKS * sizeof(float); }
+extern "C" int smx_sumsq(const float* x, int64_t n, float* out, void* workspace, void* stream) {
+  SMX_REQUIRE(x && out && workspace, "smx_sumsq: null pointer");
   if (n <= 0) return SMX_OK;
   int g = grid1d(n);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, STREAM, x, n, out);
+  if (g > SUMSQ_BLOCKS) g = SUMSQ_BLOCKS;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, STREAM, x, n, reinterpret_cast<float*>(workspace));
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, STREAM, reinterpret_cast<const float*>(workspace), g, out);
   return check_launch("smx_sumsq");
 }
 extern "C" int smx_clip_factor(const float* sumsq, float max_norm, float inv_scale, float* out, void* stream) {

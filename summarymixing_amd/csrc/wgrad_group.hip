@@ -44,6 +44,8 @@ struct WgItem {
 struct WgGroupParams {
   WgItem it[WG_MAX_ITEMS];
   int nitems, total_tiles, splits, ksteps_per_split, rows;   // rows: multiple of 64 (the host peels the tail)
+  int ablate;           // debug (env SMX_WGROUP_ABLATE): 1 = no MFMA / fragment reads, 2 = no DMA, 4 = DMA never waited for
+  long long* dbg;       // debug (smx_debug_set_timing_buffer): per workgroup [total cycles, cycles in wait+barrier, realtime ticks, niter]
 };
 
 __device__ __forceinline__ void wg_glds16(const void* gsrc, uint32_t lds_dst) {
@@ -72,13 +74,16 @@ __device__ __forceinline__ bf16x8 wg_frag(const char* lds, int cbase, int l31, i
   return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
 }
 
-__device__ __forceinline__ float wg_sum8(const bf16x8& f) {
+// acc += sum of the 8 bf16 of a fragment: four v_dot2c_f32_bf16 against (1, 1) (hipcc has no builtin for it on gfx950;
+// the shift / mask / add formulation was ~40 VALU instructions per fragment pair and 16-frame sub-step - more issue
+// slots than the 8 MFMAs next to them leave free)
+__device__ __forceinline__ void wg_sum8(float& acc0, float& acc1, const bf16x8& f) {
   const uint4 u = __builtin_bit_cast(uint4, f);
-  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { s0 += __uint_as_float(w[q] << 16); s1 += __uint_as_float(w[q] & 0xffff0000u); }
-  return s0 + s1;
+  const uint32_t one2 = 0x3F803F80u;
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc0) : "v"(u.x), "v"(one2));
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc1) : "v"(u.y), "v"(one2));
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc0) : "v"(u.z), "v"(one2));
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc1) : "v"(u.w), "v"(one2));
 }
 
 template <int BK>
@@ -122,16 +127,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
   }
   const long stepa = (long)BK * it.lda, stepb = (long)BK * it.ldb;
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem + wave * 1024);
-  auto issue = [&](int s) {
+  const bool ab_nomfma = p.ablate & 1, ab_nodma = p.ablate & 2;
+  // pieces j0 .. j0 + nj - 1 of stage s (both operands)
+  auto issue_part = [&](int s, auto j0_tag, auto nj_tag) {
+    constexpr int J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
+    if (ab_nodma) return;
     const uint32_t dst = wave_lds + (s % NST) * STAGE_BYTES;
 #pragma unroll
-    for (int j = 0; j < NPC; ++j) {
+    for (int j = J0; j < J0 + NJ; ++j) {
       wg_glds16(pa[j], dst + j * 8192);
       wg_glds16(pb[j], dst + OP_BYTES + j * 8192);
       pa[j] += stepa;
       pb[j] += stepb;
     }
   };
+  auto issue = [&](int s) { issue_part(s, ActTag<0>{}, ActTag<NPC>{}); };
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -140,21 +150,31 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  float bsum[2] = {0.f, 0.f};
+  float bsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
   const bool do_cs = it.want_bias && tile_m == 0 && wm == 0;     // (uniform per wave)
 
+  const bool ab_nowait = p.ablate & 4;
+  long long t_start = 0, t_wait = 0, r_start = 0;
+  if (p.dbg) { t_start = clock64(); r_start = wall_clock64(); }
   for (int s = 0; s < NST - 1 && s < niter; ++s) issue(s);
   for (int itn = 0; itn < niter; ++itn) {
+    long long tw0 = 0;
+    if (p.dbg) tw0 = clock64();
     // this wave's pieces of stage `itn` have landed once at most the (2 NPC each) DMA instructions of the younger stages
     // in flight are outstanding (vmcnt retires in order; nothing else uses vector memory in this loop)
     const int ahead = min(NST - 2, niter - 1 - itn);
-    if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
+    if (ab_nowait) {}
+    else if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
     else if (NST >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();                                        // ... and everybody's; the stage read last step is free again
-    if (itn + NST - 1 < niter) issue(itn + NST - 1);
+    // the refill of the stage that was read last step is issued piecewise between the MFMA groups below (a DMA piece
+    // costs 100-200 issue cycles: eight of them in front of the first MFMA left the matrix pipe idle after every barrier)
+    if (p.dbg) t_wait += clock64() - tw0;
+    const bool refill = itn + NST - 1 < niter;
     const char* As = smem + (itn % NST) * STAGE_BYTES;
     const char* Bs = As + OP_BYTES;
+    if (ab_nomfma) { if (refill) issue(itn + NST - 1); continue; }
     bf16x8 fa[2][2], fb[2][4];                           // fragments double-buffered over the 16-frame sub-steps
 #pragma unroll
     for (int i = 0; i < 2; ++i) fa[0][i] = wg_frag(As, wn * 64 + i * 32, l31, hi, 0);
@@ -176,11 +196,26 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
       if (do_cs) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) bsum[i] += wg_sum8(fa[cur][i]);
+        for (int i = 0; i < 2; ++i) wg_sum8(bsum[i][0], bsum[i][1], fa[cur][i]);
+      }
+      if (refill) {
+        if constexpr (BK == 64) {                        // NPC = 4: one piece pair per sub-step
+          if (kk == 0) issue_part(itn + NST - 1, ActTag<0>{}, ActTag<1>{});
+          else if (kk == 1) issue_part(itn + NST - 1, ActTag<1>{}, ActTag<1>{});
+          else if (kk == 2) issue_part(itn + NST - 1, ActTag<2>{}, ActTag<1>{});
+          else issue_part(itn + NST - 1, ActTag<3>{}, ActTag<1>{});
+        } else {                                         // NPC = 2, two sub-steps
+          if (kk == 0) issue_part(itn + NST - 1, ActTag<0>{}, ActTag<1>{});
+          else issue_part(itn + NST - 1, ActTag<1>{}, ActTag<1>{});
+        }
       }
     }
   }
 
+  if (p.dbg && t == 0) {
+    long long* d = p.dbg + (long)blockIdx.x * 4;
+    d[0] = clock64() - t_start; d[1] = t_wait; d[2] = wall_clock64() - r_start; d[3] = niter;
+  }
   // ---- slab: acc[i][j][g*4 + q] is dW[n0 + wn*64 + i*32 + l31][m0 + wm*128 + j*32 + g*8 + hi*4 + q] ----------------
   float* slab = it.ws + (long)split * it.M * it.K;
 #pragma unroll
@@ -198,7 +233,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
     float* bpart = it.ws + (long)p.splits * it.M * it.K + (long)split * it.M;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);      // the two k halves (hi = 0 / 1) of the same column
+      const float b = bsum[i][0] + bsum[i][1];
+      const float s = b + __shfl_xor(b, 32, 64);                   // the two k halves (hi = 0 / 1) of the same column
       if (hi == 0) bpart[n0 + wn * 64 + i * 32 + l31] = s;
     }
   }
@@ -217,6 +253,9 @@ static int wg_splits(int rows, int total_tiles) {
 }  // namespace smx
 
 using namespace smx;
+
+static long long* g_wg_dbg = nullptr;
+extern "C" void smx_debug_set_wgroup_timing_buffer(void* p) { g_wg_dbg = reinterpret_cast<long long*>(p); }
 
 extern "C" int smx_wgrad_group_splits(int rows, const smx_wgrad_item* items, int nitems) {
   if (!items || nitems <= 0 || rows < 64) return 0;
@@ -255,6 +294,9 @@ extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items,
   p.ksteps_per_split = (nk + splits - 1) / splits;
   const int nwork = tiles * splits, per = (nwork + 7) / 8;
   static const int bk_env = getenv("SMX_WGROUP_BK") ? atoi(getenv("SMX_WGROUP_BK")) : 64;
+  static const int ablate_env = getenv("SMX_WGROUP_ABLATE") ? atoi(getenv("SMX_WGROUP_ABLATE")) : 0;
+  p.ablate = ablate_env;
+  p.dbg = g_wg_dbg;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr_done = false;
   if (!attr_done) {

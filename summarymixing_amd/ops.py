@@ -477,7 +477,8 @@ def step_counter_add(counter, inc=1):
 
 
 def sumsq(x, out):
-    L.check(L.lib().smx_sumsq(_p(x), x.numel(), _p(out), _stream()), "smx_sumsq")
+    ws = _workspace(L.lib().smx_sumsq_workspace(), x.device, slot=6)
+    L.check(L.lib().smx_sumsq(_p(x), x.numel(), _p(out), _p(ws), _stream()), "smx_sumsq")
 
 
 def clip_factor(sumsq_t, max_norm, inv_scale, out):

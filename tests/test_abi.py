@@ -49,3 +49,9 @@ def test_no_cpu_fallback():
     m = SummaryMixing(8, 1, [8], 8, [8], 8, global_dropout=0.0)
     with pytest.raises((AssertionError, RuntimeError)):
         m(torch.randn(1, 3, 8))
+
+
+def test_wgrad_item_struct_layout_matches_header():
+    from summarymixing_amd import _lib
+    assert ctypes.sizeof(_lib.WgradItem) == 56  # 5 x 8 + 4 x 4 bytes, see include/smx.h smx_wgrad_item
+    assert ctypes.sizeof(_lib.ReduceJob) == 56

@@ -93,7 +93,9 @@ def close(a, b, what, tol):
     assert err < tol, f"rank {rank} {what}: rel err {err:.3e}"
 tol = 2e-5 if dtype == torch.float32 else 2e-2
 close(opt.flat_g / world, ref_g, "all-reduced gradient", tol)
-close(opt.flat_p, ropt.flat_p, "updated weights", tol if dtype == torch.float32 else 2e-3)
+# (Adam's first step moves every weight by ~lr * sign(g): with bf16 activations a near-zero gradient element may flip sign
+#  between the sharded and the full-batch run, so the bf16 weights can only agree to ~2 lr = 2e-2 of max|w| ~ 1)
+close(opt.flat_p, ropt.flat_p, "updated weights", tol if dtype == torch.float32 else 3e-2)
 # every rank ends with the same weights, bit for bit
 mine = opt.flat_p.cpu()
 other = [torch.empty_like(mine) for _ in range(world)]
