@@ -609,9 +609,11 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 else:
                     _dense_pool_bwd(dsd, B, T, Wn, ds_out)
             elif pool_kind == "mean":
-                dc0 = torch.zeros((B, s_out), dtype=torch.float32, device=dev)
                 _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
-                                    True, None, dgroup=dc0, gdiv=T, dx_out=dlocal_out, up=up_local)
+                                    True, None, dx_out=dlocal_out, up=up_local)
+                # per-utterance sums of dZ (the gradient of the C0 side input) through the fixed-order pool kernel: the
+                # fused variant (smx_act_mask_bwd dgroup) adds with fp32 atomics, i.e. not bit-reproducibly
+                dc0, _ = ops.masked_mean(dzm, None, B, T, scale=False)
                 dc0_t = ops.cast(dc0, dtype)
                 if gWm is not None:      # dW_s += dc0^T sbar
                     ops.wgrad(dc0_t, sbar_t, gWm[:, lw:], B, s_out, sdim)
