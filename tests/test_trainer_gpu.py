@@ -176,7 +176,7 @@ def _small(dtype=torch.bfloat16):
     from summarymixing_amd.trainer import FlatAdamW
     torch.manual_seed(5)
     d = 64
-    enc = ConformerEncoder(1, d, 128, 4, kernel_size=15, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+    enc = ConformerEncoder(1, d, 128, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
                            local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast").cuda()
     opt = FlatAdamW(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
     x = torch.randn(3, 50, d, device="cuda").to(dtype)
