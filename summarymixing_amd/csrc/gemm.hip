@@ -586,9 +586,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
-template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, bool DMA = false>
+template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC>
 __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
-  static_assert(!DMA || (sizeof(T) == 2 && A_KC && VEC), "LDS-DMA staging of A: bf16, reduce-contiguous, aligned");
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
@@ -600,20 +599,19 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   constexpr int PH_ROWS = 32 * PH_FRAGS;
   constexpr int NPH = TILE_N / PH_ROWS;
   constexpr int EPI_BYTES = PH_ROWS * (TILE_M * 4 + 16);         // fp32 rows, 16 B row pad
-  constexpr int RING = DMA ? 2 : 1;                              // LDS-DMA: two A stages, one landing while one is multiplied
-  constexpr int AB_BYTES = RING * A_BYTES + B_BYTES;
+  constexpr int AB_BYTES = A_BYTES + B_BYTES;
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N) * 4;              // bias[TILE_M] | row factors[TILE_N] (mask * alpha)
-  // the DMA ring fills the 64 KB static LDS limit: its small epilogue arrays live behind the epilogue staging rows
-  // inside the (by then dead) ring, fenced by one extra barrier
-  constexpr bool ALIAS_SIDE = DMA || (SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536);
+  // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
+  // inside the (by then dead) operand stage, fenced by one extra barrier
+  constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536;
   static_assert(!ALIAS_SIDE || EPI_BYTES + RED_BYTES + SIDE_BYTES + 64 <= SMEM_BYTES, "epilogue arrays do not fit");
   __shared__ __attribute__((aligned(16))) char smem[ALIAS_SIDE ? SMEM_BYTES : SMEM_BYTES + RED_BYTES + SIDE_BYTES];
   float* red = reinterpret_cast<float*>(smem + (ALIAS_SIDE ? (EPI_BYTES + 63) / 64 * 64 : SMEM_BYTES));
   float* side = red + TILE_M;
   char* As = smem;
-  char* Bs = smem + RING * A_BYTES;
+  char* Bs = smem + A_BYTES;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wn = wave >> 1, wm = wave & 1;
@@ -708,62 +706,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 #pragma unroll
   for (int q = 0; q < CSN; ++q) cs[q] = 0.f;
   const bool do_cs = !A_KC && p.acolsum != nullptr && tile_m == 0;
-  if constexpr (DMA) {
-    // ---- LDS-DMA main loop: the A tiles (the activation stream, the operand that comes from HBM) go HBM -> LDS
-    // without touching a VGPR, into a ring of two stages; the weights (L2 resident) keep the register path.  Measured
-    // (tools/glds_probe.hip, 1 GB panel): the DMA path streams 6.1 TB/s where global -> register -> ds_write tops out
-    // at 2.9 TB/s.  Same LDS image as the register path (128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7):
-    // the swizzle is applied to the SOURCE address, because lane i of a piece always lands at +16 i.
-    // Waits: hipcc does not count the DMA.  Stage it+1 of A is issued BEFORE the register loads of B's stage it+1, so
-    // the wait hipcc emits for those registers (vmcnt retires in order) also covers the older DMA pieces.
-    const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
-    const int niter = (kend - kbeg) / BK;
-    uint4 rb[TILE_M / 32];
-    auto issue_a = [&](int it) {
-      const int buf = it & 1, k0 = kbeg + it * BK;
-#pragma unroll
-      for (int j = 0; j < TILE_N / 32; ++j) {              // TILE_N / 8 pieces of 8 rows (1 KB each), 4 waves
-        const int ins = wave + 4 * j, row = ins * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        const long gr = min(n0 + row, p.N - 1);
-        glds16(A + gr * p.lda + k0 + lc * 8, __builtin_amdgcn_readfirstlane(lds_base + buf * A_BYTES + ins * 1024));
-      }
-    };
-    if (niter > 0) {
-      issue_a(0);
-      load_b(rb, kbeg);
-    }
-    SMX_STAMP(1);
-    for (int it = 0; it < niter; ++it) {
-      stage_store<T, B_KC, TILE_M>(rb, Bs, t);             // (waits for B's registers and therefore for A's stage `it`)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // explicit: nothing of this wave is in flight at the barrier
-      lds_barrier();
-      if (it + 1 < niter) {
-        issue_a(it + 1);
-        load_b(rb, kbeg + (it + 1) * BK);
-      }
-      As = smem + (it & 1) * A_BYTES;
-      if (!ab_nomfma) {
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-          bf16x8 fa[FN], fb[FM];
-#pragma unroll
-          for (int i = 0; i < FN; ++i) fa[i] = frag_kc(As, fpa[i], kk);
-#pragma unroll
-          for (int j = 0; j < FM; ++j) {
-            if constexpr (B_KC) fb[j] = frag_kc(Bs, fpb[j], kk);
-            else fb[j] = frag_bf16<B_KC, TILE_M>(Bs, wm * WM + j * 32 + l31, kk, hi);
-          }
-#pragma unroll
-          for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-      }
-      lds_barrier();                                       // Bs and A buffer (it & 1) are free again
-    }
-  } else {
+  {
   // NS register stages of BK reduce-elements each are in flight (issue-early / write-late): for the K = 256..512
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
   // about one HBM/L2 round trip for its whole main loop instead of one per K tile (measured: 2.9 K cycles per
@@ -890,7 +833,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     }
     return;
   }
-  if constexpr (sizeof(T) == 2 && TILE_N == 128 && TILE_M == 128 && VEC && !DMA) {
+  if constexpr (sizeof(T) == 2 && TILE_N == 128 && TILE_M == 128 && VEC) {
     if (p.reg_epi) {
       // ---- register-domain epilogue (bias / activation / row mask / dropout / saved Z only; bf16 output) -------------
       // The math runs on the accumulator fragments of all four waves at once; what goes through LDS is the finished bf16
@@ -1083,248 +1026,6 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 }
 
 
-// ---- row-panel kernel: output-heavy GEMMs with a short reduction (bf16, K <= 256, M >= 512) ---------------------------
-// The FFN up-projection shape (K = 256 -> M = 1024) writes 8x the bytes it reads, and in gemm_kernel the stores of one
-// workgroup's epilogue sit in front of the operand loads of its CU neighbours (the vector-memory pipeline is in order):
-// main loop and epilogue ablate to 45 + 64 us but run in 91-118 us.  Here ONE workgroup per CU owns a 128-row panel of A,
-// keeps all of it in LDS (<= 64 KB) and walks the column tiles of the output:
-//   * A is fetched once per panel instead of once per column tile;
-//   * the (L2-resident) weight tile of column tile c+1 is requested into registers DURING the main loop of tile c, one
-//     K step at a time right after that step's registers were written to LDS, and waited for BEFORE the first store of
-//     tile c's epilogue - so no load is ever queued behind this workgroup's own stores (vmcnt retires in order and
-//     counts stores), and the stores of tile c drain while tile c+1 multiplies;
-//   * the epilogue staging rows have their own LDS, so the next B stage can be written while slow waves still store.
-// LDS: A panel 64 KB + two B stages + 33 KB staging = 131-140 KB (dynamic), 1 workgroup (4 waves) per CU.
-// unconditional 16-byte operand loads for the panel kernel (rows clamped instead of predicated: K % 64 == 0, and the
-// columns / rows past the edge are never stored) - a predicated load costs a branch and a conservative vmcnt(0)
-template <bool KC, int ROWS>
-__device__ __forceinline__ void panel_load(uint4 (&reg)[ROWS / 32], const bf16_t* base, long ld, int row0, int rows_total,
-                                           int k0, int t) {
-#pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i) {
-    const int v = t + 256 * i;
-    if constexpr (KC) {
-      const int rg = min(row0 + (v >> 3), rows_total - 1);
-      reg[i] = *reinterpret_cast<const uint4*>(base + (long)rg * ld + k0 + (v & 7) * 8);
-    } else {
-      constexpr int RC = ROWS / 8;
-      const int rg = min(row0 + (v % RC) * 8, rows_total - 8);
-      reg[i] = *reinterpret_cast<const uint4*>(base + (long)(k0 + v / RC) * ld + rg);
-    }
-  }
-}
-
-template <int N>
-__device__ __forceinline__ void settle_regs(uint4 (&r)[N]) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) { settle(r[i].x); settle(r[i].y); settle(r[i].z); settle(r[i].w); }
-}
-
-// LDS plan of the panel kernel: [A panel: 4 K steps][B stage(s)][epilogue staging (aliases the B stage when it is single)]
-template <bool B_KC, int TN>
-struct PanelLds {
-  static constexpr int A_BYTES = lds_bytes<bf16_t, TN, true>();
-  static constexpr int B_BYTES = lds_bytes<bf16_t, 128, B_KC>();
-  static constexpr int NBUF = TN == 128 ? 2 : 1;
-  static constexpr int EPI_BYTES = ((TN / 2) * (128 * 4 + 16) + 63) / 64 * 64;
-  static constexpr bool ALIAS = NBUF == 1;
-  static constexpr int BS_BYTES = ALIAS ? (B_BYTES > EPI_BYTES ? B_BYTES : EPI_BYTES) : NBUF * B_BYTES;
-  static constexpr int STG_OFF = 4 * A_BYTES + (ALIAS ? 0 : BS_BYTES);
-  static constexpr int RED_OFF = 4 * A_BYTES + BS_BYTES + (ALIAS ? 0 : EPI_BYTES);
-  static constexpr int TOTAL = RED_OFF + (128 + 128 + TN) * 4;
-  static constexpr int OCC = TN == 128 ? 1 : (3 * TOTAL <= 160 * 1024 ? 3 : 2);
-};
-
-// ---- row-panel kernel: output-heavy GEMMs with a short reduction (bf16, K <= 256, M >= 512) ---------------------------
-// The FFN up-projection shape (K = 256 -> M = 1024) writes 8x the bytes it reads.  In gemm_kernel every 128 x 128 output
-// tile is a workgroup of its own: it pays a full operand round trip (nothing to multiply until the tile's A and B rows have
-// arrived) and its loads queue behind the epilogue stores of the CU's other workgroups (the vector-memory pipeline is
-// in order) - main loop and epilogue ablate to 45 + 64 us but run in 91-118 us.  Here a workgroup owns a TN-row panel
-// of A, keeps ALL of it in LDS (TN x K <= 64 KB) and walks the column tiles of the output:
-//   * A is fetched once per panel instead of once per column tile;
-//   * the (L2-resident) weight tile of column tile c+1 is requested into registers DURING the main loop of tile c - each
-//     K step's registers are re-loaded right after they were written to LDS - and waited for BEFORE the first store of
-//     tile c's epilogue: no load is ever queued behind this workgroup's own stores (vmcnt retires in order and counts
-//     stores), and the stores of tile c drain while tile c+1 multiplies;
-//   * all loads are unconditional (clamped rows) and nothing is pending at the loop head, so the compiler places no
-//     vmcnt wait inside the main loop.
-// Status: correct (tests/test_kernels_gpu.py::test_gemm_row_panel_variant_in_subprocess) but SLOWER than the tiled kernel
-// (FFN up-projection at 64000 frames: 152 us vs 98 us) and therefore opt-in (SMX_GEMM_PANEL=1).  Per-wave clock stamps
-// (tools/panel_stamps.py): with ONE workgroup (4 waves) per CU - the 131 KB of LDS allow no more - every phase is
-// latency-bound: main loop 6.3 K cycles per column tile (the 64 MFMAs need 2 K), each 64-row epilogue phase 6.3 K, and
-// even the skeleton without MFMA and epilogue (4 x [LDS write of a B stage + its reload + barrier]) takes 3.6 K: one
-// wave per SIMD hides nothing.  A TN = 64 build (51 KB, three workgroups per CU) spilled at the 168-register budget
-// and was slower still.  What the experiment settles: pure stores in this pattern run at 6.8 TB/s even from one
-// workgroup per CU that drains after every tile (tools/store_probe2.hip), so the tiled kernel's epilogue is not bound
-// by store bandwidth; the next attempt should keep >= 2 waves per SIMD (a 512-thread workgroup whose wave groups
-// work on different column tiles of the same LDS-resident panel).
-template <bool B_KC, int TN>
-__global__ __launch_bounds__(256, (PanelLds<B_KC, TN>::OCC)) void gemm_panel_kernel(GemmParams p) {
-  typedef bf16_t T;
-  typedef PanelLds<B_KC, TN> PL;
-  constexpr int BK = 64, TM = 128, KS_MAX = 4, WN = TN / 2, WM = 64, FN = WN / 32, FM = 2;
-  constexpr int A_BYTES = PL::A_BYTES, B_BYTES = PL::B_BYTES;
-  constexpr int PH_ROWS = TN / 2, NPH = 2, STG_LD = TM * 4 + 16;
-  extern __shared__ __attribute__((aligned(16))) char dsm[];
-  char* Ap = dsm;
-  char* Bs = dsm + KS_MAX * A_BYTES;
-  char* stg = dsm + PL::STG_OFF;
-  float* red = reinterpret_cast<float*>(dsm + PL::RED_OFF);
-  float* side = red + TM;                                // bias[TM] | row factors[TN]
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi = lane >> 5;
-  const int tile_n = blockIdx.x, n0 = tile_n * TN;
-  const int ksteps = p.K / BK;
-  const T* A = reinterpret_cast<const T*>(p.A);
-  const T* B = reinterpret_cast<const T*>(p.B);
-  const smx_epilogue& e = p.e;
-  long long* dbgp = p.dbg ? p.dbg + ((long)blockIdx.x * 4 + wave) * 8 : nullptr;
-#define SMX_PSTAMP(k) do { if (dbgp && lane == 0) dbgp[k] = clock64(); } while (0)
-  SMX_PSTAMP(0);
-
-  uint4 rb[KS_MAX][TM / 32];
-#pragma unroll
-  for (int ks = 0; ks < KS_MAX; ++ks)
-#pragma unroll
-    for (int i = 0; i < TM / 32; ++i) rb[ks][i] = make_uint4(0, 0, 0, 0);
-  {
-    uint4 ra[KS_MAX][TN / 32];
-#pragma unroll
-    for (int ks = 0; ks < KS_MAX; ++ks)
-      if (ks < ksteps) panel_load<true, TN>(ra[ks], A, p.lda, n0, p.N, ks * BK, t);
-#pragma unroll
-    for (int ks = 0; ks < KS_MAX; ++ks)
-      if (ks < ksteps) panel_load<B_KC, TM>(rb[ks], B, p.ldb, 0, p.M, ks * BK, t);
-#pragma unroll
-    for (int ks = 0; ks < KS_MAX; ++ks)
-      if (ks < ksteps) stage_store<T, true, TN>(ra[ks], Ap + ks * A_BYTES, t);
-  }
-  // (one-time) nothing is pending at the loop head
-#pragma unroll
-  for (int ks = 0; ks < KS_MAX; ++ks) settle_regs(rb[ks]);
-  float bias_v = (t < TM && e.bias && t < p.M) ? e.bias[t] : 0.f;
-  if (t >= TM && t < TM + TN) {
-    const int n = n0 + t - TM;
-    side[t] = ((e.row_mask && n < p.N) ? (e.row_mask[n] ? 1.f : 0.f) : 1.f) * e.alpha;
-  }
-  const int osz = (e.out_mode == SMX_OUT_T) ? 2 : 4;
-  SMX_PSTAMP(1);
-
-#pragma unroll 1
-  for (int tm = 0; tm < p.tiles_m; ++tm) {
-    const int m0 = tm * TM;
-    const bool more = tm + 1 < p.tiles_m;
-    if (tm == 1) SMX_PSTAMP(2);
-    f32x16 acc[FN][FM];
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS_MAX; ++ks) {
-      if (ks < ksteps) {
-        char* Bb = Bs + (PL::NBUF == 2 ? (ks & 1) * B_BYTES : 0);
-        stage_store<T, B_KC, TM>(rb[ks], Bb, t);
-        if (more) panel_load<B_KC, TM>(rb[ks], B, p.ldb, m0 + TM, p.M, ks * BK, t);   // the next column tile's K step
-        lds_barrier();
-        const char* As = Ap + ks * A_BYTES;
-        if (!(p.ablate & 2)) {
-#pragma unroll
-          for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 fa[FN], fb[FM];
-#pragma unroll
-            for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<true, TN>(As, wn * WN + i * 32 + l31, kk, hi);
-#pragma unroll
-            for (int j = 0; j < FM; ++j) fb[j] = frag_bf16<B_KC, TM>(Bb, wm * WM + j * 32 + l31, kk, hi);
-#pragma unroll
-            for (int i = 0; i < FN; ++i)
-#pragma unroll
-              for (int j = 0; j < FM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-          }
-        }
-        if (PL::NBUF == 1) lds_barrier();                // single B stage: every wave is done reading it
-      }
-    }
-    if (tm == 1) SMX_PSTAMP(3);
-    if (t < TM) side[t] = bias_v;                        // (visible after the first epilogue barrier)
-    float bias_n = 0.f;
-    if (more) {
-      if (t < TM && e.bias && m0 + TM + t < p.M) bias_n = e.bias[m0 + TM + t];
-      // the next tile's operands have landed before this tile's first store: nothing waits behind the stores
-#pragma unroll
-      for (int ks = 0; ks < KS_MAX; ++ks) settle_regs(rb[ks]);
-      settle(bias_n);
-    }
-    if (tm == 1) SMX_PSTAMP(4);
-    if (p.ablate & 1) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) sacc += acc[i][j][q];
-      if (sacc == 123.456f) reinterpret_cast<float*>(p.C)[0] = sacc;
-      lds_barrier();
-      bias_v = bias_n;
-      continue;
-    }
-#pragma unroll 1
-    for (int ph = 0; ph < NPH; ++ph) {
-      lds_barrier();
-      if (wn == ph) {
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-          for (int j = 0; j < FM; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<float4*>(stg + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
-                  make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-      }
-      lds_barrier();
-      if (osz == 2) epilogue_phase<T, 2, TN, TM, true>(p, stg, side, ph, n0 + ph * PH_ROWS, m0, 0, 0, t);
-      else epilogue_phase<T, 4, TN, TM, true>(p, stg, side, ph, n0 + ph * PH_ROWS, m0, 0, 0, t);
-      if (e.colsum) {
-        lds_barrier();
-        if (t < TM) {
-          const int rows = min(PH_ROWS, p.N - (n0 + ph * PH_ROWS));
-          float sum = ph == 0 ? 0.f : red[t];
-          for (int r = 0; r < rows; ++r) sum += *reinterpret_cast<const float*>(stg + r * STG_LD + t * 4);
-          if (ph < NPH - 1) red[t] = sum;
-          else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = sum;
-        }
-      }
-      if (tm == 1) SMX_PSTAMP(5 + ph);
-    }
-    if (PL::ALIAS) lds_barrier();                        // the staging rows are the next tile's B stage
-    bias_v = bias_n;
-  }
-  SMX_PSTAMP(7);
-#undef SMX_PSTAMP
-}
-
-template <bool B_KC, int TN>
-static int launch_panel(GemmParams& p, hipStream_t s) {
-  constexpr int LDS = PanelLds<B_KC, TN>::TOTAL;
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<B_KC, TN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return fail(SMX_ELAUNCH, "smx_gemm: cannot reserve %d bytes of LDS for the panel kernel", LDS);
-    once = true;
-  }
-  p.tiles_n = (p.N + TN - 1) / TN;
-  p.tiles_m = (p.M + 127) / 128;
-  hipLaunchKernelGGL((gemm_panel_kernel<B_KC, TN>), dim3(p.tiles_n), dim3(256), LDS, s, p);
-  if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
-  return check_launch("smx_gemm");
-}
-
 // ---- wgrad (TN) with both operands on the LDS-DMA path ---------------------------------------------------------------
 // dW = dZ^T X reduces over the frames: both operands are reduce-strided (a k row = 128 contiguous columns = 256 B), the
 // loop is long (rows / splits / 64 steps) and has no epilogue work inside - the shape the LDS-DMA ring fits best.  Per
@@ -1513,137 +1214,6 @@ static int launch_tn_dma(GemmParams& p, hipStream_t s) {
   return check_launch("smx_gemm");
 }
 
-// ---- NT / NN GEMM with BOTH operands on the LDS-DMA ring (128 x 128 tile, two 32 KB stages, one barrier per K step) ---
-// gemm_kernel<..., DMA = true> streams only A through the ring and keeps B on the register path (two barriers per step,
-// B's registers live across the MFMAs).  With the reduce-strided swizzle of gemm_tn_dma_kernel the weights of the dgrad
-// (NN) layout can take the DMA path as well; in the NT layout B uses A's row image.  No operand VGPRs at all.
-template <bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_dma2_kernel(GemmParams p) {
-  typedef bf16_t T;
-  constexpr int BK = 64, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
-  constexpr int OP_BYTES = BK * TILE * 2, STAGE_BYTES = 2 * OP_BYTES;
-  constexpr int PH_ROWS = 64, NPH = 2, STG_LD = TILE * 4 + 16, EPI_BYTES = (PH_ROWS * STG_LD + 63) / 64 * 64;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];      // the ring; the epilogue rows alias it
-  float* red = reinterpret_cast<float*>(smem + EPI_BYTES);                    // (both used after the main loop only)
-  float* side = red + TILE;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi = lane >> 5;
-  int tile_n, tile_m;
-  {
-    const int ntiles = p.tiles_n * p.tiles_m;
-    int bid = blockIdx.x;
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tile_n = bid / p.tiles_m; tile_m = bid % p.tiles_m;
-  }
-  const int bz = blockIdx.y;
-  const int n0 = tile_n * TILE, m0 = tile_m * TILE;
-  const int niter = p.K / BK;
-  const T* A = reinterpret_cast<const T*>(p.A) + (long)bz * p.sA;
-  const T* B = reinterpret_cast<const T*>(p.B) + (long)bz * p.sB;
-  const smx_epilogue& e = p.e;
-  // epilogue side vector, requested before the main loop (bias[TILE] | row factors[TILE])
-  float side_v = 0.f;
-  if (t < TILE) { if (e.bias && m0 + t < p.M) side_v = e.bias[(long)bz * e.bias_batch_stride + m0 + t]; }
-  else { const int n = n0 + t - TILE; side_v = ((e.row_mask && n < p.N) ? (e.row_mask[n] ? 1.f : 0.f) : 1.f) * e.alpha; }
-
-  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
-  // row-image pieces (reduce-contiguous operand): 8 rows of 128 B per piece, chunk XOR (row >> 1) & 7 on the source
-  const int rrow = lane >> 3;
-  // k-image pieces (reduce-strided operand): 4 k rows of 256 B per piece, granule XOR (k & 3) << 2 on the source
-  const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 2)) * 8;
-  auto issue = [&](int it) {
-    const int buf = it & 1;
-    const long k0 = (long)it * BK;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int pc = wave + 4 * j;
-      const int row = pc * 8 + rrow;
-      const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      const long ga = min(n0 + row, p.N - 1);
-      glds16(A + ga * p.lda + k0 + lc * 8, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + pc * 1024));
-      if constexpr (B_KC) {
-        const long gb = min(m0 + row, p.M - 1);
-        glds16(B + gb * p.ldb + k0 + lc * 8, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + OP_BYTES + pc * 1024));
-      } else {
-        const long kr = k0 + 4 * pc + prow;
-        const int mc = min(m0 + gsrc, p.M - 8);
-        glds16(B + kr * p.ldb + mc, __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + OP_BYTES + pc * 1024));
-      }
-    }
-  };
-  f32x16 acc[FN][FM];
-#pragma unroll
-  for (int i = 0; i < FN; ++i)
-#pragma unroll
-    for (int j = 0; j < FM; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  if (niter > 0) issue(0);
-  for (int it = 0; it < niter; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    if (it + 1 < niter) issue(it + 1);
-    const char* As = smem + (it & 1) * STAGE_BYTES;
-    const char* Bs = As + OP_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 fa[FN], fb[FM];
-#pragma unroll
-      for (int i = 0; i < FN; ++i) fa[i] = frag_bf16<true, TILE>(As, wn * WN + i * 32 + l31, kk, hi);
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        if constexpr (B_KC) fb[j] = frag_bf16<true, TILE>(Bs, wm * WM + j * 32 + l31, kk, hi);
-        else fb[j] = frag_tr_swz(Bs, wm * WM + j * 32 + l31, kk, hi);
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-  }
-  lds_barrier();                                         // every wave is done reading the ring
-  side[t] = side_v;
-  const int osz = (e.out_mode == SMX_OUT_T) ? 2 : 4;
-#pragma unroll 1
-  for (int ph = 0; ph < NPH; ++ph) {
-    lds_barrier();
-    if (wn == ph) {
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(smem + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
-                make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-    }
-    lds_barrier();
-    if (osz == 2) epilogue_phase<T, 2, TILE, TILE, true>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, 0, t);
-    else epilogue_phase<T, 4, TILE, TILE, true>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, 0, t);
-    if (e.colsum) {
-      lds_barrier();
-      if (t < TILE) {
-        const int rows = min(PH_ROWS, p.N - (n0 + ph * PH_ROWS));
-        float sum = ph == 0 ? 0.f : red[t];
-        for (int r = 0; r < rows; ++r) sum += *reinterpret_cast<const float*>(smem + r * STG_LD + t * 4);
-        if (ph < NPH - 1) red[t] = sum;
-        else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = sum;
-      }
-    }
-  }
-}
-
-template <bool B_KC>
-static int launch_dma2(GemmParams& p, hipStream_t s) {
-  p.tiles_n = (p.N + 127) / 128;
-  p.tiles_m = (p.M + 127) / 128;
-  hipLaunchKernelGGL((gemm_dma2_kernel<B_KC>), dim3(p.tiles_n * p.tiles_m, p.batch), dim3(256), 0, s, p);
-  if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
-  return check_launch("smx_gemm");
-}
-
 // ---- host dispatch ------------------------------------------------------------------------------------------
 template <typename T, bool A_KC, bool B_KC, int TN, int TM>
 static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
@@ -1668,11 +1238,6 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // Measured at 64000 frames: (K=1024, M=256) NT 77 -> 59 us, NN 65 -> 55 us; (K=256, M=1024) 99 -> 103 us (not used).
   static const int wide_env = getenv("SMX_GEMM_WIDE") ? atoi(getenv("SMX_GEMM_WIDE")) : -1;
   const bool wide = wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 512 && p.M <= 512));
-  static const int dma_env = getenv("SMX_GEMM_DMA") ? atoi(getenv("SMX_GEMM_DMA")) : 0;
-  // row-panel kernel (see gemm_panel_kernel; experimental, opt-in - measured slower than the tiled kernel):
-  // short reduction, wide output, enough panels to fill the chip.
-  // SMX_GEMM_PANEL: 0 off (default), 1 epilogues without a per-element side input, 2 every eligible epilogue
-  static const int panel_env = getenv("SMX_GEMM_PANEL") ? atoi(getenv("SMX_GEMM_PANEL")) : 0;
   // wgrad-shaped TN GEMMs with both operands on the LDS-DMA ring (gemm_tn_dma_kernel).  SMX_TN_DMA=0 disables it.
   static const int tn_dma_env = getenv("SMX_TN_DMA") ? atoi(getenv("SMX_TN_DMA")) : 1;
   if constexpr (sizeof(T) == 2 && !A_KC && !B_KC) {
@@ -1680,31 +1245,6 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
         p.e.out_mode != SMX_OUT_ATOMIC_F32 && !p.e.colsum && !p.e.res && !p.e.c0 && !p.e.z && !p.ablate &&
         (long)(p.N / 128) * (p.M / 128) * p.batch * p.splits >= 256)
       return launch_tn_dma(p, s);
-  }
-  // NT / NN with both operands on the LDS-DMA ring (gemm_dma2_kernel).  SMX_GEMM_DMA2: 0 off, 1 on for every eligible
-  // shape, 2 only where the wide tile is not chosen
-  static const int dma2_env = getenv("SMX_GEMM_DMA2") ? atoi(getenv("SMX_GEMM_DMA2")) : 0;
-  if constexpr (sizeof(T) == 2 && A_KC) {
-    if (dma2_env && vec && p.splits == 1 && p.K % 64 == 0 && p.K >= 64 && p.N >= 128 && p.M >= 128 && p.M % 8 == 0 &&
-        p.e.out_mode != SMX_OUT_ATOMIC_F32 && !p.ablate && (dma2_env != 2 || !wide) &&
-        (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch >= 256)
-      return launch_dma2<B_KC>(p, s);
-  }
-  if constexpr (sizeof(T) == 2 && A_KC) {
-    const bool side_in = p.e.res || p.e.c0 || (p.e.flags & SMX_EPI_ACT_GRAD);
-    if (panel_env && vec && p.splits == 1 && p.batch == 1 && p.K % 64 == 0 && p.K >= 64 && p.K <= 256 && p.M >= 512 &&
-        (p.N + 127) / 128 >= 256 && p.e.out_mode != SMX_OUT_ATOMIC_F32 && (panel_env >= 2 || !side_in))
-      return launch_panel<B_KC, 128>(p, s);
-  }
-  if constexpr (sizeof(T) == 2 && A_KC) {
-    if (dma_env && vec && !force_small && p.splits == 1 && p.K % 64 == 0 && p.K >= 64 && p.N >= 128 && p.M >= 128 &&
-        big >= 256 && (reinterpret_cast<uintptr_t>(p.A) % 16 == 0) && (dma_env != 2 || !wide)) {
-      p.tiles_n = (p.N + 127) / 128;
-      p.tiles_m = (p.M + 127) / 128;
-      hipLaunchKernelGGL((gemm_kernel<T, true, B_KC, 128, 128, true, true>), dim3(p.tiles_n * p.tiles_m, p.batch), dim3(256), 0, s, p);
-      if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
-      return check_launch("smx_gemm");
-    }
   }
   if (wide && !force_small && p.N >= 128 && p.M >= 256 && p.M % 256 == 0 && p.splits == 1 &&
       (long)((p.N + 127) / 128) * (p.M / 256) * p.batch >= 256)

@@ -436,9 +436,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         if mode == "SummaryMixing-expdecay" and sm is None and _sdim() % 8 == 0:
             # no sum_mask: (M s)/rowsum(M) with M_ij = decay^|i-j| is a two-sided exponential filter -> O(T) kernels
             # (smx_expdecay_mean_*); the frozen decay constant (summary_mixing.py:154-157) is read once
-            if "_decay" not in cfg:
-                cfg["_decay"] = float(P["decay_constant"].detach().float().cpu())
-            decay = cfg["_decay"]
+            decay = cfg["decay"]() if "decay" in cfg else float(P["decay_constant"].detach().float().cpu())
             pool_kind = "expdecay"
         elif mode == "SummaryMixing-expdecay":
             # Laplace weights (summary_mixing.py:316-365): M_ij = decay^|i-j| * binary_mask
@@ -478,6 +476,9 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         sp = SP.enabled()
         if sp and pool_kind != "mean":
             raise NotImplementedError("sequence-parallel mode supports the per-utterance mean only (no sum_mask / expdecay)")
+        if sp and p_drop > 0.0:
+            raise NotImplementedError("sequence-parallel mode is dropout-free: the fused dropout masks are indexed by the "
+                                      "LOCAL frame row, every shard would draw the same mask")
         if sp:
             # time axis sharded over the group: local partial sums + valid-frame counts, ONE all-reduce, then the mean
             ssum, _ = ops.masked_mean(s, mask, B, T, scale=False)

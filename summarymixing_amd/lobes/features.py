@@ -75,8 +75,43 @@ class InputNormalization(nn.Module):
         self.avg_factor, self.update_until_epoch = avg_factor, update_until_epoch
         self.eps = 1e-10
         self.count = 0
-        self.glob_mean = None
-        self.glob_std = None
+        # running statistics are part of the module state: in state_dict() (buffers, once they exist), moved by .to(),
+        # and saved / loaded through SpeechBrain's checkpointer hooks (_save / _load, the normalizer.ckpt format)
+        self.register_buffer("glob_mean", None)
+        self.register_buffer("glob_std", None)
+
+    # ---- persistence -----------------------------------------------------------------------------------------------
+    def get_extra_state(self):
+        return {"count": self.count}
+
+    def set_extra_state(self, state):
+        self.count = int(state.get("count", 0))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name in ("glob_mean", "glob_std"):               # buffers that do not exist yet (None) are created from the checkpoint
+            key = prefix + name
+            if key in state_dict and getattr(self, name) is None:
+                setattr(self, name, state_dict[key].detach().clone().float())
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def _statistics_dict(self):
+        """The dictionary SpeechBrain's InputNormalization writes to normalizer.ckpt."""
+        return {"count": self.count, "glob_mean": self.glob_mean, "glob_std": self.glob_std,
+                "spk_dict_mean": {}, "spk_dict_std": {}, "spk_dict_count": {}}
+
+    def _save(self, path):
+        torch.save(self._statistics_dict(), path)
+
+    def _load(self, path, end_of_epoch=False):
+        del end_of_epoch
+        stats = torch.load(path, map_location="cpu")
+        dev = self.glob_mean.device if self.glob_mean is not None else None
+        self.count = int(stats["count"])
+        for name in ("glob_mean", "glob_std"):
+            v = stats[name]
+            if v is not None and not torch.is_tensor(v):
+                v = torch.tensor(v)
+            setattr(self, name, v.float().to(dev) if (v is not None and dev is not None) else (v.float() if v is not None else None))
 
     def forward(self, x, lengths, spk_ids=None, epoch=0):
         if not x.is_cuda:
@@ -98,6 +133,8 @@ class InputNormalization(nn.Module):
         else:
             if self.glob_mean is None:
                 self.glob_mean, self.glob_std = torch.zeros(F, device=x.device), torch.ones(F, device=x.device)
+            elif self.glob_mean.device != x.device:
+                self.glob_mean, self.glob_std = self.glob_mean.to(x.device), self.glob_std.to(x.device)
             if self.training:
                 if self.count == 0:
                     ops.stats_combine(mean, std, self.glob_mean, self.glob_std, 1.0)

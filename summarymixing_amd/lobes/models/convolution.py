@@ -15,14 +15,41 @@ from ... import functional as F
 from ... import ops
 
 
-class _ConvBlock(nn.Module):
-    def __init__(self, c_in, c_out, f_in):
+class _Conv2dHolder(nn.Module):
+    """Key layout of speechbrain.nnet.CNN.Conv2d: ``.conv`` is the nn.Conv2d."""
+
+    def __init__(self, c_in, c_out):
         super().__init__()
         self.conv = nn.Conv2d(c_in, c_out, 3, stride=2)            # parameter holder (Cout, Cin, 3, 3)
+
+
+class _NormHolder(nn.Module):
+    """Key layout of speechbrain.nnet.normalization.LayerNorm: ``.norm`` is the nn.LayerNorm."""
+
+    def __init__(self, shape):
+        super().__init__()
+        self.norm = nn.LayerNorm(shape)                             # affine over (F', C) like upstream's LayerNorm
+
+
+class _ConvBlock(nn.Module):
+    """Parameter holder with the state-dict keys of upstream's ConvBlock (one layer per block):
+    ``convs.conv_0.conv.{weight,bias}``, ``convs.norm_0.norm.{weight,bias}`` - a recipe checkpoint's ``CNN`` recoverable
+    (...transducer.yaml:247-254,407-413) loads with strict=True."""
+
+    def __init__(self, c_in, c_out, f_in):
+        super().__init__()
         self.f_out = (f_in + 1) // 2
-        self.norm = nn.LayerNorm((self.f_out, c_out))               # affine over (F', C) like upstream's LayerNorm
+        self.convs = nn.ModuleDict({"conv_0": _Conv2dHolder(c_in, c_out), "norm_0": _NormHolder((self.f_out, c_out))})
         self.c_in, self.c_out = c_in, c_out
         self.kp = (9 * c_in + 7) // 8 * 8
+
+    @property
+    def conv(self):
+        return self.convs["conv_0"].conv
+
+    @property
+    def norm(self):
+        return self.convs["norm_0"].norm
 
 
 class ConvolutionFrontEnd(nn.Module):
@@ -34,12 +61,16 @@ class ConvolutionFrontEnd(nn.Module):
                 any(residuals) or any(d != 1 for d in dilations)):
             raise NotImplementedError("only the recipes' configuration is built: 3x3 kernels, stride 2, one layer per block")
         f, c = input_shape[-1], 1
-        blocks = []
-        for i in range(num_blocks):
-            blocks.append(_ConvBlock(c, out_channels[i], f))
-            f, c = blocks[-1].f_out, out_channels[i]
-        self.blocks = nn.ModuleList(blocks)
+        self.num_blocks = num_blocks
+        for i in range(num_blocks):                                 # upstream: Sequential layers named convblock_{i}
+            blk = _ConvBlock(c, out_channels[i], f)
+            self.add_module(f"convblock_{i}", blk)
+            f, c = blk.f_out, out_channels[i]
         self.p_drop = float(dropout)
+
+    @property
+    def blocks(self):
+        return [getattr(self, f"convblock_{i}") for i in range(self.num_blocks)]
 
     def state_dict_for_oracle(self):
         sd = {}

@@ -16,10 +16,11 @@ import torch.nn as nn
 from .... import _lib as L
 from .... import functional as F
 from .... import ops
+from .... import sequence_parallel as SP
 from ....nnet.activations import act_code
 from ....nnet.summary_mixing import SummaryMixing
 from ...models.VanillaNN import VanillaNN
-from .Conformer import _LayerNorm, _check_dropout
+from .Conformer import _LayerNorm
 
 
 class _CSGUConv(nn.Module):
@@ -88,6 +89,9 @@ class BranchformerEncoderLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def make_run(self, B, T, m8, src_mask):
+        if SP.enabled():
+            raise NotImplementedError("sequence-parallel mode does not cover the Branchformer: the CSGU's reflect-padded "
+                                      "depthwise convolution has no halo exchange")
         act = self.act
         pd = self.p_drop if self.training else 0.0
         cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask,
@@ -164,7 +168,6 @@ class BranchformerEncoderLayer(nn.Module):
 
     def forward(self, x, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
                 pos_embs: Optional[torch.Tensor] = None):
-        _check_dropout(self, self.p_drop, "BranchformerEncoderLayer")
         B, T, _ = x.shape
         m8 = F.mask_u8(src_key_padding_mask, B, T, x.device)
         return F.block(x, self.make_run(B, T, m8, src_mask), list(self.parameters())), None
@@ -195,7 +198,6 @@ class BranchformerEncoder(nn.Module):
         out = src
         attention_lst = []
         for layer in self.layers:
-            _check_dropout(layer, layer.p_drop, "BranchformerEncoderLayer")
             out = F.block(out, layer.make_run(B, T, m8, src_mask), list(layer.parameters()),
                           getattr(layer, "_on_bwd_done", None))
             attention_lst.append(None)

@@ -45,11 +45,6 @@ def _ffn_params(seq):
             "W2": seq[1].ffn[3].weight, "b2": seq[1].ffn[3].bias}
 
 
-def _check_dropout(module, p, what):
-    """Kept for API stability: training-mode dropout is implemented (counter-based smx_dropout)."""
-    return None
-
-
 class ConvolutionModule(nn.Module):
     def __init__(self, input_size, kernel_size=31, bias=True, activation=Swish, dropout=0.0, causal=False,
                  dilation=1, masked_false_or_true=True):
@@ -76,7 +71,6 @@ class ConvolutionModule(nn.Module):
     def forward(self, x, mask: Optional[torch.Tensor] = None, dynchunktrain_config=None):
         """Returns conv_module(x) (without the residual), mask (B,T,1) multiplies the output when
         masked_false_or_true is False (the SummaryMixing convention, Conformer.py:327-331)."""
-        _check_dropout(self, self.p_drop, "ConvolutionModule")
         B, T, d = x.shape
         if mask is not None and self.masked_false_or_true:
             mask = ~mask.bool()
@@ -149,7 +143,6 @@ class ConformerEncoderLayer(nn.Module):
 
     def forward(self, x, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
                 pos_embs: torch.Tensor = None, dynchunktrain_config=None):
-        _check_dropout(self, self.p_drop, "ConformerEncoderLayer")
         B, T, _ = x.shape
         m8 = F.mask_u8(src_key_padding_mask, B, T, x.device)
         chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
@@ -182,7 +175,6 @@ class ConformerEncoder(nn.Module):
         out = src
         attention_lst = []
         for layer in self.layers:
-            _check_dropout(layer, layer.p_drop, "ConformerEncoderLayer")
             out = F.block(out, layer.make_run(B, T, m8, src_mask, chunk), list(layer.parameters()),
                           getattr(layer, "_on_bwd_done", None))
             attention_lst.append(None)

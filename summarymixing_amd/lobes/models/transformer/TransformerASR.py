@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from .... import functional as F
+from .... import sequence_parallel as SP
 from ....nnet.activations import Swish
 from ....utils.dynamic_chunk_training import DynChunkTrainConfig  # noqa: F401
 from ...models.VanillaNN import Linear
@@ -136,13 +137,20 @@ class TransformerASR(nn.Module):
         raise NotImplementedError("the seq2seq decoder is outside the SummaryMixing hot path; call .encode()")
 
     def encode(self, src, wav_len=None, pad_idx=0, dynchunktrain_config=None, masked_false_or_true: Optional[bool] = True):
+        """TransformerASR.py:501-560.  masked_false_or_true is honoured exactly like the reference: the SummaryMixing cell
+        and conv module read the padding mask as True = VALID (masked_false_or_true=False, what EncoderWrapper and the
+        reference's own forward() pass, :344-347,:720-729); a direct call with the signature's default True hands them the
+        inverted mask - in the reference too."""
+        if SP.enabled():
+            raise NotImplementedError("sequence-parallel mode enters at the ConformerEncoder stack: the positional table, "
+                                      "the wav_len masks and the input dropout counters here are not offset per shard")
         if src.dim() == 4:
             bz, t, ch1, ch2 = src.shape
             src = src.reshape(bz, t, ch1 * ch2)
         B, T, _ = src.shape
         key_padding_mask, _, src_mask, _ = make_transformer_src_tgt_masks(
             src, None, wav_len, pad_idx=pad_idx, causal=self.causal, dynchunktrain_config=dynchunktrain_config,
-            masked_false_or_true=False)
+            masked_false_or_true=masked_false_or_true)
         lin = self.custom_src_module.layers[0].w
         if self.positional_encoding_type == "fixed_abs_sine":
             if T > self.positional_encoding.max_len:

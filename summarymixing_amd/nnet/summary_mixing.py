@@ -64,8 +64,20 @@ class SummaryMixing(nn.Module):
         """Dropout probability in effect (reference: nn.Dropout(global_dropout), active in train() only)."""
         return self.global_dropout if self.training else 0.0
 
+    def _decay(self):
+        """The frozen decay constant (summary_mixing.py:154-157) as a host float, read ONCE per parameter version: a
+        .cpu() per forward would be a blocking device sync (and would break hipGraph capture)."""
+        p = self.decay_constant
+        key = (p._version, p.data_ptr())
+        if getattr(self, "_decay_cache", (None, None))[0] != key:
+            self._decay_cache = (key, float(p.detach().float().cpu()))
+        return self._decay_cache[1]
+
     def _cfg(self):
-        return {"mode": self.mode, "act": self.act, "local_proj_out_dim": self.local_proj_out_dim}
+        cfg = {"mode": self.mode, "act": self.act, "local_proj_out_dim": self.local_proj_out_dim}
+        if hasattr(self, "decay_constant"):
+            cfg["decay"] = self._decay
+        return cfg
 
     def forward(self, x, sum_mask=None, src_padding_mask=None):
         """x (B,T,enc_dim) on the GPU, float32 or bfloat16; src_padding_mask (B,T) True = valid frame;

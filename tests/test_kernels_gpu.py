@@ -328,79 +328,37 @@ def test_expdecay_mean_matches_dense_laplace(B, T, D, dtype, tol):
     assert rel_err(out.view(B, T, D), torch.einsum("ji,bjd->bid", Wn, s3)) <= tol
 
 
-def test_gemm_lds_dma_variant_in_subprocess():
-    """The opt-in LDS-DMA main loop (SMX_GEMM_DMA=1: global_load_lds ring instead of register staging for the NT bf16
-    kernels) must pass the same GEMM tests; the knob is read once per process, hence the subprocess."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, SMX_GEMM_DMA="1")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "-m", "gpu", "-q", "-x", "-k",
-                        "test_gemm_layouts or test_gemm_epilogue_all_fields or test_gemm_act_grad_epilogue"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+def test_gemm_large_ragged_shapes_and_epilogues():
+    """The 128 x 128 tile at chip-filling sizes with ragged N / M / K: NT + bias + Swish + saved Z + row mask, NN with a
+    residual and fp32 output, the fused activation-gradient epilogue with column sums - against fp32 torch references."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(0)
+    for (N, K, M) in ((32768 + 77, 256, 1024), (32768, 192, 520), (33000, 64, 640)):
+        x = torch.randn(N, K, device="cuda").bfloat16()
+        w = (torch.randn(M, K, device="cuda") * 0.05).bfloat16()
+        b = torch.randn(M, device="cuda")
+        mask = (torch.rand(N, device="cuda") > 0.2).to(torch.uint8)
+        res = torch.randn(N, M, device="cuda").bfloat16()
+        zr = x.float() @ w.float().t() + b
 
-
-_PANEL_WORKER = r'''
-import os, sys
-import torch
-sys.path.insert(0, os.environ["SMX_ROOT"])
-from summarymixing_amd import _lib as L, ops
-torch.manual_seed(0)
-for (N, K, M) in ((32768 + 77, 256, 1024), (32768, 192, 520), (33000, 64, 640)):
-    x = torch.randn(N, K, device="cuda").bfloat16()
-    w = (torch.randn(M, K, device="cuda") * 0.05).bfloat16()
-    b = torch.randn(M, device="cuda")
-    mask = (torch.rand(N, device="cuda") > 0.2).to(torch.uint8)
-    res = torch.randn(N, M, device="cuda").bfloat16()
-    zr = x.float() @ w.float().t() + b
-    def rel(a, r):
-        return (a.float() - r).abs().max().item() / r.abs().max().item()
-    # NT: bias + swish + saved pre-activation + row mask
-    y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16); z = torch.empty_like(y)
-    ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, z=z, row_mask=mask))
-    assert rel(z, zr) < 1e-2 and rel(y, torch.nn.functional.silu(zr) * mask[:, None]) < 1e-2, (N, K, M, "NT")
-    # NN (dgrad layout) with a residual side input and fp32 output
-    wt = w.t().contiguous()
-    y32 = torch.empty(N, M, device="cuda", dtype=torch.float32)
-    ops.gemm(L.GEMM_NN, x, wt, y32, N, M, K, ops.epilogue(bias=b, res=res, out_mode=L.OUT_F32))
-    assert rel(y32, zr + res.float()) < 1e-2, (N, K, M, "NN")
-    # fused activation-gradient epilogue with the column sums (bias gradient) side output
-    zz = torch.randn(N, M, device="cuda").bfloat16()
-    cs = torch.zeros(M, device="cuda")
-    ops.gemm(L.GEMM_NN, x, wt, y, N, M, K, ops.epilogue(act=L.ACT_SWISH, act_grad_z=zz, colsum=cs))
-    zf = zz.float(); sg = torch.sigmoid(zf)
-    ref = (x.float() @ wt.float()) * (sg * (1 + zf * (1 - sg)))
-    assert rel(y, ref) < 1e-2, (N, K, M, "act-grad")
-    assert (cs - y.float().sum(0)).abs().max().item() / y.float().sum(0).abs().max().item() < 2e-2, (N, K, M, "colsum")
-print("PANEL OK")
-'''
-
-
-def test_gemm_all_dma_variant_in_subprocess():
-    """The opt-in all-DMA NT / NN GEMM (SMX_GEMM_DMA2=1: both operands through the LDS-DMA ring, gemm_dma2_kernel) on the
-    same large ragged shapes and epilogues as the row-panel test."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SMX_GEMM_DMA2="1", SMX_ROOT=root)
-    r = subprocess.run([sys.executable, "-c", _PANEL_WORKER], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "PANEL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def test_gemm_row_panel_variant_in_subprocess():
-    """The opt-in row-panel GEMM (SMX_GEMM_PANEL=2: one workgroup keeps a 128-row panel of A in LDS and walks the column
-    tiles; K <= 256, M >= 512, >= 256 panels) against fp32 torch references on panel-eligible shapes (ragged N, M, K);
-    the knob is read once per process, hence the subprocess."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SMX_GEMM_PANEL="2", SMX_ROOT=root)
-    r = subprocess.run([sys.executable, "-c", _PANEL_WORKER], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "PANEL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        def rel(a, r):
+            return (a.float() - r).abs().max().item() / r.abs().max().item()
+        y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+        z = torch.empty_like(y)
+        ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, z=z, row_mask=mask))
+        assert rel(z, zr) < 1e-2 and rel(y, torch.nn.functional.silu(zr) * mask[:, None]) < 1e-2, (N, K, M, "NT")
+        wt = w.t().contiguous()
+        y32 = torch.empty(N, M, device="cuda", dtype=torch.float32)
+        ops.gemm(L.GEMM_NN, x, wt, y32, N, M, K, ops.epilogue(bias=b, res=res, out_mode=L.OUT_F32))
+        assert rel(y32, zr + res.float()) < 1e-2, (N, K, M, "NN")
+        zz = torch.randn(N, M, device="cuda").bfloat16()
+        cs = torch.zeros(M, device="cuda")
+        ops.gemm(L.GEMM_NN, x, wt, y, N, M, K, ops.epilogue(act=L.ACT_SWISH, act_grad_z=zz, colsum=cs))
+        zf = zz.float()
+        sg = torch.sigmoid(zf)
+        ref = (x.float() @ wt.float()) * (sg * (1 + zf * (1 - sg)))
+        assert rel(y, ref) < 1e-2, (N, K, M, "act-grad")
+        assert (cs - y.float().sum(0)).abs().max().item() / y.float().sum(0).abs().max().item() < 2e-2, (N, K, M, "colsum")
 
 
 @pytest.mark.parametrize("N,M,K", [(32768, 512, 256), (32768, 256, 1024), (16384, 1536, 512)])
