@@ -9,7 +9,7 @@ mkdir -p "${HERE}/obj"
 pids=()
 for f in capi gemm rowwise dwconv frontend ctc reduce wgrad_group; do
   src="${HERE}/${f}.hip"; obj="${HERE}/obj/${f}.o"
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/smx_common.h" -nt "$obj" || "${HERE}/../../include/smx.h" -nt "$obj" ]]; then
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/smx_common.h" -nt "$obj" || "${HERE}/gemm_common.h" -nt "$obj" || "${HERE}/../../include/smx.h" -nt "$obj" ]]; then
     "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$obj" &
     pids+=($!)
   fi

@@ -21,552 +21,9 @@
 //  * blockIdx is remapped so that the M-tiles that share one A row panel land on the same XCD (same L2).
 //  * TN/wgrad reduces over the (long) frame dimension: split-K over blockIdx.y with fp32 atomics into the
 //    caller-zeroed gradient buffer.
-#include <stdlib.h>
-#include <type_traits>
-
-#include "smx_common.h"
+#include "gemm_common.h"
 
 namespace smx {
-
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-
-struct GemmParams {
-  const void* A; const void* B; void* C;
-  long lda, ldb, ldc, sA, sB, sC;
-  int N, M, K, batch, splits, kchunk;
-  int tiles_n, tiles_m;
-  smx_epilogue e;
-  int epi_vec;
-  int epi_lds;      // outputs are 16-byte addressable: stage the tile through LDS and store whole rows
-  long sSplit;      // element stride between split-K slabs of C (out_mode F32)
-  float* acolsum;                   // TN only: [splits][batch][N] partial column sums of the A operand (bias gradient)
-  const uint64_t* epoch;            // device step counter mixed into the dropout seed (or null)
-  unsigned dthresh; float dscale;   // fused dropout: drop if hash16 < dthresh>>16, survivors * dscale
-  long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
-  int nt;       // non-temporal store hints: 1 = saved pre-activation Z, 2 = the output C
-  int epi_simple;  // no element-wise side input, no column sums: the SIMPLE instantiation of epilogue_phase
-  int reg_epi;  // epilogue without element-wise side inputs: math on the accumulator fragments, bf16 staging (gemm_kernel)
-  int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
-};
-
-template <typename T> struct ElemTraits;
-template <> struct ElemTraits<bf16_t> { static constexpr int BK = 64; static constexpr int VPT = 8; };
-template <> struct ElemTraits<float>  { static constexpr int BK = 32; static constexpr int VPT = 4; };
-
-// ---- guarded 16-byte fetch of VPT consecutive elements -------------------------------------------------
-template <typename T, bool VEC>
-__device__ __forceinline__ uint4 ld_contig(const T* p, int nvalid, const T* safe) {
-  constexpr int VPT = ElemTraits<T>::VPT;
-  if constexpr (VEC) {
-    // vector mode: the host guarantees whole, aligned vectors, so a lane is either fully in or fully out.
-    // Branch-free: out-of-range lanes read a valid dummy address and are zeroed by a select, so that all the
-    // loads of a tile are issued back to back (an exec-masked branch would cost one s_waitcnt vmcnt(0) each).
-    const bool ok = nvalid >= VPT;
-    uint4 r = *reinterpret_cast<const uint4*>(ok ? p : safe);
-    return ok ? r : make_uint4(0, 0, 0, 0);
-  } else {
-    uint4 r = make_uint4(0, 0, 0, 0);
-    if (nvalid <= 0) return r;
-    uint32_t w[4] = {0, 0, 0, 0};
-    if constexpr (sizeof(T) == 2) {
-      const uint16_t* q = reinterpret_cast<const uint16_t*>(p);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < nvalid) w[i >> 1] |= (uint32_t)q[i] << ((i & 1) * 16);
-    } else {
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (i < nvalid) w[i] = q[i];
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-  }
-}
-
-// ---- stage one operand tile (ROWS x BK) : global -> registers ------------------------------------------
-// KC: element (row r, reduce k) at base[r*ld + k];  KS: at base[k*ld + r]
-template <typename T, bool KC, int ROWS, bool VEC>
-__device__ __forceinline__ void stage_load(uint4 (&reg)[ROWS / 32], const T* base, long ld, int row0, int rows_total,
-                                           int k0, int k1, int t) {
-  constexpr int BK = ElemTraits<T>::BK;
-  constexpr int VPT = ElemTraits<T>::VPT;
-  if constexpr (sizeof(T) == 2 && KC) {
-    constexpr int NV = ROWS / 32;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int v = t + 256 * i, row = v >> 3, c = v & 7;
-      int rg = row0 + row, kg = k0 + c * 8;
-      int nv = (rg < rows_total) ? (k1 - kg) : 0;
-      reg[i] = ld_contig<T, VEC>(base + (long)rg * ld + kg, nv, base);
-    }
-  } else if constexpr (sizeof(T) == 2 && !KC) {
-    constexpr int RC = ROWS / 8;           // 16-byte row chunks per k row
-    constexpr int NV = ROWS / 32;          // vectors per thread (64 k rows x RC chunks / 256 threads)
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int v = t + 256 * i, rc = v % RC, k = v / RC;
-      const int rg = row0 + rc * 8, kg = k0 + k;
-      reg[i] = ld_contig<T, VEC>(base + (long)kg * ld + rg, kg < k1 ? rows_total - rg : 0, base);
-    }
-  } else if constexpr (sizeof(T) == 4 && KC) {
-    constexpr int NV = ROWS / 32;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int v = t + 256 * i, row = v >> 3, k4 = v & 7;
-      int rg = row0 + row, kg = k0 + k4 * 4;
-      int nv = (rg < rows_total) ? (k1 - kg) : 0;
-      reg[i] = ld_contig<T, VEC>(base + (long)rg * ld + kg, nv, base);
-    }
-  } else {
-    constexpr int NV = ROWS / 32;
-    constexpr int R4 = ROWS / 4;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int v = t + 256 * i, r4 = v % R4, k = v / R4;
-      int rg = row0 + r4 * 4, kg = k0 + k;
-      reg[i] = ld_contig<T, VEC>(base + (long)kg * ld + rg, kg < k1 ? rows_total - rg : 0, base);
-    }
-  }
-  (void)BK; (void)VPT;
-}
-
-// ---- the same stage through buffer loads (bf16, aligned shapes) ---------------------------------------------------------
-// PMC (profiles/r01_pmc_sq.txt): a bias-only K=256 tile executed ~1270 VALU instructions per wave next to its 64 MFMAs,
-// about half of them in the main loop - per-load 64-bit address arithmetic and bounds predicates that the compiler
-// re-materialises every K step at the 168-register budget.  With a buffer resource the per-thread byte offsets of a
-// stage are computed ONCE (one 32-bit VGPR per vector), the K step advances through the scalar offset, and the bounds
-// check is the hardware's (out-of-range rows / k rows return zeros): the main loop's loads need no VALU at all.
-// Requirements (checked on the host, else the generic path): operand span < 2 GB; for a reduce-contiguous operand
-// K % 64 == 0 (a k tail inside a row would read the next row instead of zeros).
-#ifndef SMX_BUFLD_WIDE
-#define SMX_BUFLD_WIDE 1
-#endif
-template <typename T, bool KC, int ROWS>
-struct BufStage {
-  __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t voff[ROWS / 32];
-  uint32_t kbytes;                                       // bytes per unit k
-  __device__ __forceinline__ void init(const T* base, long ld, int row0, int rows_total, int K, int t) {
-    const long span = KC ? ((long)(rows_total - 1) * ld + K) : ((long)(K - 1) * ld + rows_total);
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), (short)0, (int)(span * (long)sizeof(T)), 0x00020000);
-    kbytes = KC ? (uint32_t)sizeof(T) : (uint32_t)(ld * (long)sizeof(T));
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int v = t + 256 * i;
-      if constexpr (KC) {
-        const int rg = row0 + (v >> 3);
-        voff[i] = rg < rows_total ? (uint32_t)(((long)rg * ld + (v & 7) * 8) * (long)sizeof(T)) : 0x80000000u;
-      } else {
-        constexpr int RC = ROWS / 8;
-        const int rg = row0 + (v % RC) * 8;
-        voff[i] = rg < rows_total ? (uint32_t)(((long)(v / RC) * ld + rg) * (long)sizeof(T)) : 0x80000000u;
-      }
-    }
-  }
-  __device__ __forceinline__ void load(uint4 (&reg)[ROWS / 32], int k0) const {
-    const uint32_t soff = (uint32_t)k0 * kbytes;         // (uniform)
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
-      const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0);
-      reg[i] = make_uint4(r.x, r.y, r.z, r.w);
-    }
-  }
-};
-
-// ---- registers -> LDS image -----------------------------------------------------------------------------
-template <typename T, bool KC, int ROWS>
-__device__ __forceinline__ void stage_store(const uint4 (&reg)[ROWS / 32], char* lds, int t) {
-  if constexpr (sizeof(T) == 2 && KC) {
-    constexpr int NV = ROWS / 32;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int v = t + 256 * i, row = v >> 3, c = v & 7;
-      *reinterpret_cast<uint4*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = reg[i];
-    }
-  } else if constexpr (sizeof(T) == 2 && !KC) {
-    // plain copy into a [k][ROWS (+32 pad)] image: the transposition is done by ds_read_b64_tr_b16 on the way out
-    constexpr int RC = ROWS / 8;
-    constexpr int NV = ROWS / 32;
-    constexpr int KSTRB = (ROWS + 32) * 2;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int v = t + 256 * i, rc = v % RC, k = v / RC;
-      *reinterpret_cast<uint4*>(lds + k * KSTRB + rc * 16) = reg[i];
-    }
-  } else if constexpr (sizeof(T) == 4 && KC) {
-    constexpr int NV = ROWS / 32;
-    constexpr int KSTR = ROWS + 4;
-    float* l = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int v = t + 256 * i, row = v >> 3, k4 = v & 7;
-      const float* f = reinterpret_cast<const float*>(&reg[i]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) l[(k4 * 4 + j) * KSTR + row] = f[j];
-    }
-  } else {
-    constexpr int NV = ROWS / 32;
-    constexpr int R4 = ROWS / 4;
-    constexpr int KSTR = ROWS + 4;
-    float* l = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int v = t + 256 * i, r4 = v % R4, k = v / R4;
-      *reinterpret_cast<uint4*>(l + k * KSTR + r4 * 4) = reg[i];
-    }
-  }
-}
-
-template <typename T, int ROWS, bool KC>
-constexpr int lds_bytes() {
-  return sizeof(T) == 2 ? (KC ? ROWS * 128 : 64 * (ROWS + 32) * 2) : 32 * (ROWS + 4) * 4;
-}
-
-// ---- fragment reads ---------------------------------------------------------------------------------------
-template <bool KC, int ROWS>
-__device__ __forceinline__ bf16x8 frag_bf16(const char* lds, int r, int kk, int hi) {
-  if constexpr (KC) {
-    int c = kk * 2 + hi;
-    uint4 v = *reinterpret_cast<const uint4*>(lds + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
-    return __builtin_bit_cast(bf16x8, v);
-  } else {
-    // reduce-strided operand: LDS holds [k][ROWS+32] (k rows of the tile, row index contiguous).  One
-    // ds_read_b64_tr_b16 hands every lane of a 16-lane group the 4 consecutive k of ITS row (hardware 4x16
-    // transpose; verified by tools/tr_probe.hip); two of them make the 8-k MFMA fragment.  Row stride +64 B keeps the
-    // four k rows of a group and the neighbouring group on distinct banks.
-    constexpr int KSTR = ROWS + 32;
-    typedef short short4_t __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) short4_t* lds_s4;
-    const int lane = (r & 31) | (hi << 5);              // r carries the lane's row; rebuild the lane id
-    const int li = lane & 15, g1 = (lane >> 4) & 1;
-    const int rbase = r - (r & 31);                     // fragment row base
-    const uint16_t* l16 = reinterpret_cast<const uint16_t*>(lds);
-    const uint16_t* p0 = l16 + (kk * 16 + hi * 8 + (li >> 2)) * KSTR + rbase + g1 * 16 + (li & 3) * 4;
-    const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
-    const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * KSTR));
-    const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
-    uint4 v = make_uint4(ua.x, ua.y, ub.x, ub.y);
-    return __builtin_bit_cast(bf16x8, v);
-  }
-}
-
-// reduce-contiguous fragments with the loop-invariant part of the swizzled address precomputed: chunk kk*2 + hi of row r
-// sits at r*128 + (((kk*2 + hi) ^ ((r >> 1) & 7)) << 4) = frag_pre(r, hi) ^ (kk << 5)  (r*128 has no bits below 128, and
-// kk*2 only touches bits 1-2 of the chunk index) - one v_xor with an immediate per fragment and sub-step
-__device__ __forceinline__ uint32_t frag_pre(int r, int hi) { return (uint32_t)(r * 128 + ((hi ^ ((r >> 1) & 7)) << 4)); }
-__device__ __forceinline__ bf16x8 frag_kc(const char* lds, uint32_t pre, int kk) {
-  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (pre ^ (uint32_t)(kk << 5))));
-}
-
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-// activation of one accumulator quad: ONE uniform switch per 4 values (never per element)
-__device__ __forceinline__ void act4(int act, float (&y)[4]) {
-  switch (act) {
-    case SMX_ACT_GELU:
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y[q] = act_fwd_c<SMX_ACT_GELU>(y[q]);
-      break;
-    case SMX_ACT_SWISH:
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y[q] = act_fwd_c<SMX_ACT_SWISH>(y[q]);
-      break;
-    case SMX_ACT_LEAKY_RELU:
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y[q] = act_fwd_c<SMX_ACT_LEAKY_RELU>(y[q]);
-      break;
-    case SMX_ACT_RELU:
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y[q] = act_fwd_c<SMX_ACT_RELU>(y[q]);
-      break;
-    default: break;
-  }
-}
-
-__device__ __forceinline__ long c0_row(const smx_epilogue& e, int n) {
-  if (e.c0_mode == SMX_C0_GROUP) return n / e.c0_div;
-  if (e.c0_mode == SMX_C0_MOD) return n % e.c0_div;
-  return n;
-}
-
-// ---- one epilogue phase: WN staged fp32 rows (LDS) -> outputs.  vmcnt retires in order and counts stores too, so
-// every side input of a batch of items (C0 / residual or saved pre-activation / mask) is requested BEFORE the
-// batch's first store; the stores then stream out without any wave waiting on them.
-// Every optional feature sits behind ONE wave-uniform branch per item (never per element), so an absent feature
-// costs no VALU work: the epilogue is VALU-issue bound when the three resident workgroups of a CU reach it together.
-// EVEC: whole, 16-byte aligned items (host-checked) -> no per-element guards at all. -------------------------------
-template <int ACT, int CW>
-__device__ __forceinline__ void act_fwd_n(float (&v)[CW]) {
-#pragma unroll
-  for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<ACT>(v[q]);
-}
-template <int ACT, int CW>
-__device__ __forceinline__ void act_grad_mul_n(float (&v)[CW], const float (&z)[CW]) {
-#pragma unroll
-  for (int q = 0; q < CW; ++q) v[q] *= act_grad_c<ACT>(z[q]);
-}
-// CW elements of type T held as raw 32-bit words -> floats
-template <typename T, int CW>
-__device__ __forceinline__ void unpack_words(const uint32_t (&w)[CW * sizeof(T) / 4], float (&f)[CW]) {
-  if constexpr (sizeof(T) == 2) {
-#pragma unroll
-    for (int q = 0; q < CW / 2; ++q) { f[2 * q] = bf16_bits_to_f32(w[q] & 0xffffu); f[2 * q + 1] = bf16_bits_to_f32(w[q] >> 16); }
-  } else {
-#pragma unroll
-    for (int q = 0; q < CW; ++q) f[q] = __uint_as_float(w[q]);
-  }
-}
-template <int NW>
-__device__ __forceinline__ void ld_words(const void* p, uint32_t (&w)[NW]) {
-  if constexpr (NW == 4) { const uint4 u = *reinterpret_cast<const uint4*>(p); w[0] = u.x; w[1] = u.y; w[2] = u.z; w[3] = u.w; }
-  else { const uint2 u = *reinterpret_cast<const uint2*>(p); w[0] = u.x; w[1] = u.y; }
-}
-template <typename T, int CW>
-__device__ __forceinline__ void st_elems(void* p, const float (&v)[CW]) {   // CW elements of type T, one store
-  if constexpr (sizeof(T) == 4) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  } else if constexpr (CW == 8) {
-    uint4 u;
-    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
-    *reinterpret_cast<uint4*>(p) = u;
-  } else {
-    uint2 u;
-    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
-    *reinterpret_cast<uint2*>(p) = u;
-  }
-}
-
-// "consume" a loaded register: the compiler places the load's s_waitcnt HERE (zero instructions otherwise)
-__device__ __forceinline__ void settle(uint32_t& w) { asm volatile("" : "+v"(w)); }
-__device__ __forceinline__ void settle(float& w) { asm volatile("" : "+v"(w)); }
-
-// side = [TILE_M] bias (0 when absent) followed by [TILE_N] row factors (row_mask * alpha), staged in LDS by the
-// kernel prologue: reading them costs LDS (lgkmcnt) traffic only, never a vmcnt wait behind in-flight stores.
-// same, with the non-temporal hint: a saved pre-activation is not read again before the backward pass
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-template <typename T, int CW>
-__device__ __forceinline__ void st_elems_nt(void* p, const float (&v)[CW]) {
-  if constexpr (sizeof(T) == 4) {
-    u32x4_t u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-    __builtin_nontemporal_store(u, reinterpret_cast<u32x4_t*>(p));
-  } else if constexpr (CW == 8) {
-    u32x4_t u = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-    __builtin_nontemporal_store(u, reinterpret_cast<u32x4_t*>(p));
-  } else {
-    u32x2_t u = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    __builtin_nontemporal_store(u, reinterpret_cast<u32x2_t*>(p));
-  }
-}
-
-// SIMPLE = 1: the epilogue has no element-wise side input and no column sums (bias / activation / saved Z / row factors /
-// dropout only); SIMPLE = 2: one element-type side input (residual, or the saved pre-activation of a fused act-grad),
-// still no C0 rows and no column sums - known at compile time, so the side-input registers, their zero fills and the feature selects vanish
-// (PMC: 113 VALU instructions per 8-element item in the general instantiation of a bias+Swish+Z epilogue).
-template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC, int SIMPLE = 0>
-__device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, const float* side, int ph, int nbase,
-                                               int m0, int bz, int split, int t) {
-  constexpr int WN = TILE_M > 128 ? 32 : TILE_N / 2;    // rows staged per phase (phase_rows() of the kernel)
-  constexpr int STG_LD = TILE_M * 4 + 16;
-  constexpr int CW = 16 / OSZ;                          // output columns per item (16 bytes)
-  constexpr int CPR = TILE_M / CW;                      // items per row
-  constexpr int RSTEP = 256 / CPR;                      // rows covered per pass of the 256 threads
-  constexpr int NIT = WN / RSTEP;                       // items per thread
-  constexpr int SW = CW * (int)sizeof(T) / 4;           // 32-bit words of one side-input item (type T)
-  typedef typename std::conditional<OSZ == 4, float, T>::type OutT;
-  const smx_epilogue& e = p.e;
-  const uint32_t dthresh = p.dthresh;
-  const float dscale = p.dscale;
-  const uint64_t dseed = dthresh ? epoch_seed(p.e.drop_seed, p.epoch) : 0;
-  const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
-  if (m >= p.M) return;
-  const float* mkrow = side + TILE_M + ph * WN;
-  char* Cb = reinterpret_cast<char*>(p.C) + ((long)bz * p.sC + (long)split * p.sSplit) * OSZ;
-  const bool ag = SIMPLE != 1 && (e.flags & SMX_EPI_ACT_GRAD) != 0;     // z is an input: multiply by act'(z)
-  const bool c0post = !SIMPLE && (e.flags & SMX_EPI_C0_POST) != 0;
-  const bool has_c0 = !SIMPLE && e.c0_mode != SMX_C0_NONE;
-  const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
-  T* Zb = (e.z && !ag) ? reinterpret_cast<T*>(e.z) + (long)bz * p.sC : nullptr;
-  // the one side input of element type: the residual, or (ACT_GRAD) the saved pre-activation
-  const T* Sb = SIMPLE == 1 ? nullptr
-                       : (ag ? reinterpret_cast<const T*>(e.z) : (e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr));
-  const long lds_ = ag ? e.ldz : e.ldr;
-
-  if constexpr (EVEC) {
-    // ---- the element-type side input (residual / saved pre-activation) of ALL the phase's items is requested and
-    // waited for before the phase's first store; the (rarer, fp32, twice as wide) C0 rows go in batches of NB items.
-    // vmcnt retires in order and counts stores: a load issued after stores can only be consumed once those stores
-    // have drained, so every such point is a full write-latency bubble - none of them sits between two stores of a
-    // kernel without side inputs, one per phase with a residual, one per batch with C0. ----
-    constexpr int NB = NIT < 2 ? NIT : 2;
-    uint32_t sw[NIT][SW];
-    if (Sb) {
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const int n = min(nbase + r0 + k * RSTEP, p.N - 1);
-        ld_words<SW>(Sb + (long)n * lds_ + m, sw[k]);
-      }
-      // settle INSIDE the branch that loads: afterwards no register is a pending load in the compiler's scoreboard on
-      // any path, so it cannot place a (conservative) vmcnt wait between the stores below
-#pragma unroll
-      for (int k = 0; k < NIT; ++k)
-#pragma unroll
-        for (int q = 0; q < SW; ++q) settle(sw[k][q]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < NIT; ++k)
-#pragma unroll
-        for (int q = 0; q < SW; ++q) sw[k][q] = 0u;
-    }
-#pragma unroll
-    for (int kb = 0; kb < NIT; kb += NB) {
-    float cv[NB][CW];
-    if (has_c0) {
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const int n = min(nbase + r0 + (kb + k) * RSTEP, p.N - 1);
-        const float* c0p = e.c0 + c0_row(e, n) * e.ldc0 + m;
-#pragma unroll
-        for (int q4 = 0; q4 < CW / 4; ++q4) {
-          const float4 c4 = *reinterpret_cast<const float4*>(c0p + 4 * q4);
-          cv[k][4 * q4] = c4.x; cv[k][4 * q4 + 1] = c4.y; cv[k][4 * q4 + 2] = c4.z; cv[k][4 * q4 + 3] = c4.w;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < NB; ++k)
-#pragma unroll
-        for (int q = 0; q < CW; ++q) settle(cv[k][q]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < NB; ++k)
-#pragma unroll
-        for (int q = 0; q < CW; ++q) cv[k][q] = 0.f;
-    }
-    // ---- math + stores: no global load inside, the stores stream out back to back ----
-#pragma unroll
-    for (int kk = 0; kk < NB; ++kk) {
-      const int k = kb + kk;
-      const int r = r0 + k * RSTEP, n = nbase + r;
-      if (n >= p.N) continue;
-      float v[CW];
-#pragma unroll
-      for (int q4 = 0; q4 < CW / 4; ++q4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
-        v[4 * q4] = a4.x; v[4 * q4 + 1] = a4.y; v[4 * q4 + 2] = a4.z; v[4 * q4 + 3] = a4.w;
-      }
-      if (e.bias) {
-#pragma unroll
-        for (int q4 = 0; q4 < CW / 4; ++q4) {
-          const float4 b4 = *reinterpret_cast<const float4*>(side + c + 4 * q4);
-          v[4 * q4] += b4.x; v[4 * q4 + 1] += b4.y; v[4 * q4 + 2] += b4.z; v[4 * q4 + 3] += b4.w;
-        }
-      }
-      if (has_c0 && !c0post) {
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] += cv[kk][q];
-      }
-      if (ag) {
-        float zf[CW];
-        unpack_words<T, CW>(sw[k], zf);
-        switch (e.act) {
-          case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, CW>(v, zf); break;
-          case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, CW>(v, zf); break;
-          case SMX_ACT_LEAKY_RELU: act_grad_mul_n<SMX_ACT_LEAKY_RELU, CW>(v, zf); break;
-          case SMX_ACT_RELU: act_grad_mul_n<SMX_ACT_RELU, CW>(v, zf); break;
-          default: break;
-        }
-      } else {
-        if (Zb) { if (p.nt & 1) st_elems_nt<T, CW>(Zb + (long)n * e.ldz + m, v); else st_elems<T, CW>(Zb + (long)n * e.ldz + m, v); }
-        switch (e.act) {
-          case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, CW>(v); break;
-          case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, CW>(v); break;
-          case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, CW>(v); break;
-          case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, CW>(v); break;
-          default: break;
-        }
-      }
-      if (dthresh) {                                     // fused inverted dropout, mask = f(seed, n * M + m)
-        dropout_apply<CW>(v, dseed, (uint64_t)n * p.M + m, dthresh, dscale);   // (m and M are multiples of CW here)
-      }
-      if (has_mk) {
-        const float mk = mkrow[r];
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] *= mk;
-      }
-      if (Sb && !ag) {
-        float rf[CW];
-        unpack_words<T, CW>(sw[k], rf);
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] += rf[q];
-      }
-      if (has_c0 && c0post) {
-#pragma unroll
-        for (int q = 0; q < CW; ++q) v[q] += cv[kk][q];
-      }
-      if (!SIMPLE && e.colsum) {                         // final values back into the item's own staged slot
-#pragma unroll
-        for (int q4 = 0; q4 < CW / 4; ++q4)
-          *reinterpret_cast<float4*>(const_cast<char*>(smem) + r * STG_LD + (c + 4 * q4) * 4) =
-              make_float4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
-      }
-      if (p.nt & 2) st_elems_nt<OutT, CW>(Cb + ((long)n * p.ldc + m) * OSZ, v); else st_elems<OutT, CW>(Cb + ((long)n * p.ldc + m) * OSZ, v);
-    }
-    }
-  } else {
-    // ragged / unaligned shapes: one element at a time (rolled loops, run-time activation)
-    const int nv = min(CW, p.M - m);
-    const float* sf = reinterpret_cast<const float*>(smem);
-#pragma unroll 1
-    for (int k = 0; k < NIT; ++k) {
-      const int r = r0 + k * RSTEP, n = nbase + r;
-      if (n >= p.N) continue;
-      const float mkv = mkrow[r];
-      const float* c0p = has_c0 ? e.c0 + c0_row(e, n) * e.ldc0 + m : nullptr;
-#pragma unroll 1
-      for (int q = 0; q < nv; ++q) {
-        float v = sf[r * (STG_LD / 4) + c + q] + side[c + q];
-        if (c0p && !c0post) v += c0p[q];
-        if (ag) {
-          v *= act_grad(e.act, to_f32(Sb[(long)n * lds_ + m + q]));
-        } else {
-          if (Zb) Zb[(long)n * e.ldz + m + q] = from_f32<T>(v);
-          v = act_fwd(e.act, v);
-        }
-        if (dthresh) v = dropout_keep(dseed, (uint64_t)n * p.M + m + q, dthresh) ? v * dscale : 0.f;
-        v *= mkv;
-        if (Sb && !ag) v += to_f32(Sb[(long)n * lds_ + m + q]);
-        if (c0p && c0post) v += c0p[q];
-        if (e.colsum) const_cast<float*>(sf)[r * (STG_LD / 4) + c + q] = v;
-        if constexpr (OSZ == 4) reinterpret_cast<float*>(Cb)[(long)n * p.ldc + m + q] = v;
-        else reinterpret_cast<uint16_t*>(Cb)[(long)n * p.ldc + m + q] = (uint16_t)f32_to_bf16_bits(v);
-      }
-    }
-  }
-}
-
-// column sums of a reduce-strided (KS) operand stage: a thread's vectors all cover the SAME columns (256 threads are
-// a multiple of the chunks per k row), so it keeps one partial sum per column it owns.  Used by the wgrad GEMM: the
-// column sums of dZ are the bias gradient, a by-product of tiles the kernel stages anyway.
-template <typename T, int ROWS>
-__device__ __forceinline__ void stage_colsum(const uint4 (&reg)[ROWS / 32], float (&cs)[16 / sizeof(T)]) {
-#pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i) {
-    const uint32_t w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { cs[2 * q] += bf16_bits_to_f32(w[q] & 0xffffu); cs[2 * q + 1] += bf16_bits_to_f32(w[q] >> 16); }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cs[q] += __uint_as_float(w[q]);
-    }
-  }
-}
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
 #ifndef SMX_OCC
@@ -575,14 +32,6 @@ __device__ __forceinline__ void stage_colsum(const uint4 (&reg)[ROWS / 32], floa
 #ifndef SMX_NS_KC
 #define SMX_NS_KC 1
 #endif
-// LDS-DMA issue of one 1 KB piece (global_load_lds_dwordx4: lane i lands at lds_dst + 16 i; M0 carries the wave-uniform
-// LDS base and is compiler-reserved, so it is saved / restored inside the statement).  hipcc does not count this
-// load: the kernel waits for it with explicit s_waitcnt vmcnt(N).
-__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
@@ -1041,19 +490,6 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 // 2 * (k & 3) rows 0/1 and 2/3 collided: SQ_LDS_BANK_CONFLICT = 2 cycles per read).
 // Bias gradient (column sums of dZ): one extra MFMA per fragment against a constant all-ones B fragment in the waves
 // that own output columns 0..63 of the first column tile - no LDS reads, no VALU.
-__device__ __forceinline__ bf16x8 frag_tr_swz(const char* lds, int r, int kk, int hi) {
-  typedef short short4_t __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) short4_t* lds_s4;
-  const int lane = (r & 31) | (hi << 5);
-  const int li = lane & 15, g1 = (lane >> 4) & 1;
-  const int k = kk * 16 + hi * 8 + (li >> 2);           // (k & 3) == li >> 2; row k + 4 has the same swizzle
-  const int c = (r - (r & 31)) + g1 * 16 + (li & 3) * 4;
-  const char* p0 = lds + k * 256 + ((((c >> 3) ^ ((li >> 2) << 2)) << 4) + (c & 7) * 2);
-  const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
-  const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * 256));
-  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
-  return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
-}
 
 #ifndef SMX_TN_BK
 #define SMX_TN_BK 64      // k rows per LDS-DMA stage of the wgrad kernel (64: ring of 2; 32: ring of 4 - measured 3-5 % slower)
@@ -1229,6 +665,7 @@ static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
 
 template <typename T, bool A_KC, bool B_KC>
 static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
+
   // big tiles once they alone fill the chip (256 CUs x 2 resident blocks); otherwise 64x64 for more blocks
   long big = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch * p.splits;
   static const int force_small = getenv("SMX_GEMM_TILE64") ? 1 : 0;   // experiment knob
