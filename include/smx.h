@@ -209,6 +209,14 @@ size_t smx_layernorm_bwd_workspace(int N, int D);
 int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                       const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
                       int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* stream);
+/* The same with a second output written from the registers that hold dX:
+ *   dX2 = alpha2 * Dropout(dX; drop_p2, drop_seed2, index n*D + c) * row_mask2[n]        (D <= 2048)
+ * - the first thing the next backward block does to this gradient (Conformer.py:507,536: the FFN module's 1/2 * dropout;
+ * :146-152,327-331: the conv module's dropout and padding mask), so that block needs no elementwise pass of its own. */
+int smx_layernorm_bwd2(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
+                       const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
+                       int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2,
+                       float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream);
 
 /* Fused GLU + depthwise Conv1d over time (Conformer.py:131-145,317-325):
  *   u[b,t,c] = P[b,t,c] * sigmoid(P[b,t,D+c]);  Y[b,t,c] = bias[c] + sum_j w[c,j] u[b,t+j-(k-1)/2,c]

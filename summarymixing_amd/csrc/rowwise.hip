@@ -542,13 +542,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_fast(const T* __restrict__ 
 // bwd: dx = R + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*act'(LN(x))*gamma.  Blocks stride over rows;
 // gamma/beta of the lane's columns live in registers for the whole kernel, U rows are in flight per wave (all
 // their loads issued before any reduction), dgamma/dbeta partial sums stay in registers until one atomic flush.
+// Optional second output of the LayerNorm backward: dX2 = alpha * Dropout(dX; seed) * row_mask - the first thing the
+// NEXT backward block does to this gradient (FFN: 1/2 * D(dy), conv module: D(dy) * mask).  Written from the registers
+// that hold dX anyway, it replaces a separate elementwise pass (one more read and one more launch per module).
+struct LnSecond {
+  void* dX2; long ld; float alpha; const uint8_t* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* epoch;
+};
+
 template <typename T, int VW, int CH, int U>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ X,
                                                             long ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int act,
                                                             const float* __restrict__ stats, const T* __restrict__ R,
                                                             long ldr, T* __restrict__ dX, long lddx,
-                                                            float* __restrict__ partial, int N_, int D) {
+                                                            float* __restrict__ partial, int N_, int D, LnSecond sec) {
+  const uint64_t sseed = sec.dX2 ? epoch_seed(sec.seed, sec.epoch) : 0;
   __shared__ float red[3][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float gam[CH][VW], bet[CH][VW], dg[CH][VW], db[CH][VW];
@@ -632,6 +640,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
             if constexpr (VW == 4) store4<T>(dX + (long)row * lddx + c, o);
             else dX[(long)row * lddx + c] = from_f32<T>(o[0]);
+            if (sec.dX2) {                               // (uniform)
+              const float mk = (sec.mask ? (sec.mask[row] ? 1.f : 0.f) : 1.f) * sec.alpha;
+              if (sec.thresh) dropout_apply_any<VW>(o, sseed, (uint64_t)row * D + c, sec.thresh, sec.scale);
+#pragma unroll
+              for (int j = 0; j < VW; ++j) o[j] *= mk;
+              T* d2 = reinterpret_cast<T*>(sec.dX2);
+              if constexpr (VW == 4) store4<T>(d2 + (long)row * sec.ld + c, o);
+              else d2[(long)row * sec.ld + c] = from_f32<T>(o[0]);
+            }
           }
         }
       }
@@ -1219,12 +1236,13 @@ template <typename T>
 static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma, const float* beta,
                        int act, const float* stats,
                        const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma, float* dbeta, int N, int D,
-                       float* partial, hipStream_t s) {
+                       float* partial, hipStream_t s, LnSecond sec) {
   auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % (4 * sizeof(T))) == 0 && ld % 4 == 0); };
-  const bool vec = D % 4 == 0 && ok(dY, lddy) && ok(X, ldx) && ok(R, ldr) && ok(dX, lddx);
+  const bool vec = D % 4 == 0 && ok(dY, lddy) && ok(X, ldx) && ok(R, ldr) && ok(dX, lddx) && ok(sec.dX2, sec.ld);
+  if (sec.dX2 && D > 2048) return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd2: the second output needs D <= 2048");
   const int blocks = ln_bwd_blocks(N);
   dim3 grid(blocks);
-#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH, (VW == 4 && CH == 1 ? SMX_LNB_U1 : (CH <= 2 ? 2 : 1))>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D)
+#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH, (VW == 4 && CH == 1 ? SMX_LNB_U1 : (CH <= 2 ? 2 : 1))>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D, sec)
   if (vec) {
     if (D <= 256) LN_BWD(4, 1);
     else if (D <= 512) LN_BWD(4, 2);
@@ -1245,14 +1263,25 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
   return check_launch("smx_layernorm_bwd");
 }
 
+extern "C" int smx_layernorm_bwd2(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
+                                  const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma,
+                                  float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2, float alpha2,
+                                  const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream) {
+  SMX_REQUIRE(dY && X && gamma && beta && stats && dX && workspace && D > 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
+              "smx_layernorm_bwd: bad arguments");
+  SMX_REQUIRE(drop_p2 >= 0.f && drop_p2 < 1.f, "smx_layernorm_bwd2: 0 <= drop_p < 1");
+  if (N == 0) return SMX_OK;
+  LnSecond sec;
+  sec.dX2 = dX2; sec.ld = lddx2; sec.alpha = alpha2; sec.mask = row_mask2;
+  sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = g_step_counter;
+  if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM, sec);
+  return ln_bwd_impl<float>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM, sec);
+}
 extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                                  const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma,
                                  float* dbeta, int N, int D, void* workspace, void* stream) {
-  SMX_REQUIRE(dY && X && gamma && beta && stats && dX && workspace && D > 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
-              "smx_layernorm_bwd: bad arguments");
-  if (N == 0) return SMX_OK;
-  if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM);
-  return ln_bwd_impl<float>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM);
+  return smx_layernorm_bwd2(dtype, dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, workspace, nullptr, 0,
+                            1.f, nullptr, 0.f, 0, stream);
 }
 
 extern "C" int smx_layernorm_bwd_blocks(int N) { return ln_bwd_blocks(N); }

@@ -658,18 +658,22 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None):
     when those are multi-dimensional (the (F', C) affine of the conv front-end)."""
     y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act)
 
-    def bwd(dy, res=None, out=None):
+    def bwd(dy, res=None, out=None, second=None):
+        """second = (alpha, mask, drop): also return alpha * D(dx) * mask, what the NEXT backward block applies first to
+        this gradient (its `pre` attribute) - written from the same registers instead of by a separate pass."""
         gw = gacc(wp).view(-1) if wp is not None else gacc(w)
         gb = gacc(bp).view(-1) if bp is not None else gacc(b)
+        if second is not None and x.shape[1] > 2048:
+            second = None
         if _Deferred.enabled and gw is not None and gb is not None:
             N, D = x.shape
             ws = deferred_ws(gw.data_ptr(), L.lib().smx_layernorm_bwd_workspace(N, D), x.device)
-            dx = ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, None, None, res, act, ws=ws, dx_out=out)
+            dx = ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, None, None, res, act, ws=ws, dx_out=out, second=second)
             nb = L.lib().smx_layernorm_bwd_blocks(N)
             defer(ws.data_ptr(), gw, 2 * D, nb, 1, D)
             defer(ws.data_ptr() + 4 * D, gb, 2 * D, nb, 1, D)
             return dx
-        return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act, dx_out=out)
+        return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act, dx_out=out, second=second)
     return y, (bwd if need_bwd else None)
 
 
@@ -685,12 +689,19 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
     if not need_bwd:
         return y, None
 
-    def bwd(dy):
+    def bwd(dy, dz_in=None, second=None):
+        """dz_in: alpha * D2(dy) already computed by the producer of dy (see `pre`); second: forwarded to the module's own
+        LayerNorm backward, the producer of the gradient this function returns (then a pair comes back)."""
         # the second Linear's dgrad epilogue applies D1 and act'(z1): it emits dZ1 directly; db1 comes out of W1's wgrad
-        dz1, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2,
-                            up=(z1, act, None, 1.0, d1, None))
+        if dz_in is not None:
+            dz1, _ = linear_bwd(dz_in, a, W2, None, L.ACT_NONE, None, 1.0, gacc(P["W2"]), gacc(P["b2"]), dz_ready=True,
+                                up=(z1, act, None, 1.0, d1, None))
+        else:
+            dz1, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2,
+                                up=(z1, act, None, 1.0, d1, None))
         dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True)
-        return ln_b(dh, res=dy)
+        return ln_b(dh, res=dy, second=second)
+    bwd.pre = (alpha, None, d2)          # what this block does first to its incoming gradient: alpha * D2(dy)
     return y, bwd
 
 def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True, p=0.0):
@@ -711,14 +722,19 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
     if not need_bwd:
         return y, None
 
-    def bwd(dy):
-        da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr)
+    def bwd(dy, dz_in=None, second=None):
+        if dz_in is not None:
+            da, _ = linear_bwd(dz_in, a, Wo, None, L.ACT_NONE, None, 1.0, gacc(P["Wo"]), gacc(P["bo"]), dz_ready=True)
+        else:
+            da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr)
         dc = ln2_b(da)
         gwd = gacc(P["wd"])
         dp, _ = ops.dwconv_bwd(dc, p_, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
                                gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
         dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
-        return ln1_b(dh, res=dy if residual else None)
+        return ln1_b(dh, res=dy if residual else None, second=second)
+    # what this block does first to its incoming gradient: D(dy) * mask (nothing to precompute without mask and dropout)
+    bwd.pre = (1.0, mask, dr) if (mask is not None or dr is not None) else None
     return y, bwd
 
 

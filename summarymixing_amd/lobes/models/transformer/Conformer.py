@@ -132,12 +132,18 @@ class ConformerEncoderLayer(nn.Module):
 
             def bwd(dy3):
                 dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
-                d4 = bn2(dy)
-                d3 = bf2(d4)
-                d2 = bconv(d3)
+                # each LayerNorm backward also writes what the NEXT block applies first to its gradient (`pre`: the FFN's
+                # 1/2 * dropout, the conv module's dropout * padding mask) - no separate elementwise pass per module
+                pre_c = getattr(bconv, "pre", None)
+                d4, d4z = bn2(dy, second=bf2.pre)
+                if pre_c is not None:
+                    d3, d3z = bf2(d4, dz_in=d4z, second=pre_c)
+                    d2 = bconv(d3, dz_in=d3z)
+                else:
+                    d2 = bconv(bf2(d4, dz_in=d4z))
                 dh = ops.rows2d(bcell(d2.view(B, T, -1)))
-                d1 = bn1(dh, res=d2)                                                   # skip gradient fused
-                return b1(d1).view(B, T, -1)
+                d1, d1z = bn1(dh, res=d2, second=b1.pre)                               # skip gradient fused
+                return b1(d1, dz_in=d1z).view(B, T, -1)
             return y5.view(B, T, -1), bwd
         return run
 

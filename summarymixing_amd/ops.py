@@ -297,9 +297,10 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE):
     return y, stats
 
 
-def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE, ws=None, dx_out=None):
+def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE, ws=None, dx_out=None, second=None):
     """ws: caller-owned workspace; with dgamma = dbeta = None the partial rows stay in it for a deferred reduce_jobs.
-    dx_out: optional (N, D) destination view (e.g. a column slice of a wider buffer)."""
+    dx_out: optional (N, D) destination view (e.g. a column slice of a wider buffer).
+    second = (alpha, row_mask_u8 | None, (p, seed) | None): also return dx2 = alpha * D(dx) * mask (smx_layernorm_bwd2)."""
     N, D = x.shape
     dx = dx_out if dx_out is not None else torch.empty((N, D), dtype=x.dtype, device=x.device)
     pdy, lddy = _mat(dy)
@@ -307,11 +308,19 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     pr, ldr = (_mat(res) if res is not None else (None, 0))
     if ws is None:
         ws = _workspace(L.lib().smx_layernorm_bwd_workspace(N, D), x.device, slot=2)
-    tok = _pb(f"layernorm_bwd ({N}x{D}){'+res' if res is not None else ''}", (3 + (res is not None)) * N * D * _es(x))
-    L.check(L.lib().smx_layernorm_bwd(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), _mat(dx)[1], _p(dgamma),
-                                      _p(dbeta), N, D, _p(ws), _stream()), "smx_layernorm_bwd")
+    dx2 = None
+    a2, m2, dp2, ds2 = 1.0, None, 0.0, 0
+    if second is not None:
+        a2, m2, drop2 = second
+        dp2, ds2 = drop2 if (drop2 is not None and drop2[0] > 0.0) else (0.0, 0)
+        dx2 = torch.empty((N, D), dtype=x.dtype, device=x.device)
+    tok = _pb(f"layernorm_bwd ({N}x{D}){'+res' if res is not None else ''}{'+2nd' if second is not None else ''}",
+              (3 + (res is not None) + (second is not None)) * N * D * _es(x))
+    L.check(L.lib().smx_layernorm_bwd2(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), _mat(dx)[1],
+                                       _p(dgamma), _p(dbeta), N, D, _p(ws), _p(dx2), D if dx2 is not None else 0, a2, _p(m2), dp2,
+                                       ds2, _stream()), "smx_layernorm_bwd")
     _pe(tok)
-    return dx
+    return dx if second is None else (dx, dx2)
 
 
 def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None):
