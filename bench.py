@@ -141,7 +141,7 @@ def pmc_traffic_bytes(tag):
     return None
 
 
-def roofline_step_kernels(step, dtype, top=6):
+def roofline_step_kernels(step, dtype, top=8):
     """One instrumented (eager) step: every libsmx launch bracketed by HIP events on its own stream (ops._PROF).
     -> (roofline of the dominant kernel family, top kernels by in-step time)."""
     from summarymixing_amd import ops
@@ -167,6 +167,9 @@ def roofline_step_kernels(step, dtype, top=6):
                 "hbm_GBps_algorithmic": nb / t / 1e9, "frac_hbm": nb / t / 1e9 / 8000.0, "mfma_TFLOPs": fl / t / 1e12,
                 "frac_mfma": fl / t / 1e12 / mfma_peak, "share_of_step_kernel_time": ms / total_ms}
     kernels = [entry(k, e) for k, e in sorted(by_name.items(), key=lambda kv: -kv[1][3])[:top]]
+    for k in kernels:                                  # HBM bytes from the committed PMC passes, where one exists for the shape
+        tag = k["kernel"].split(" +")[0].split(":")[0].strip()
+        k["traffic"] = pmc_traffic_bytes("wgrad_group bf16 (8 weights" if tag.startswith("wgrad_group bf16 (8 weights") else tag)
     fam, e = max(by_fam.items(), key=lambda kv: kv[1][3])
     d = entry(fam, e)
     intensity = e[2] / max(e[1], 1.0)

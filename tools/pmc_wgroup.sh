@@ -20,5 +20,7 @@ for k, v in sorted(acc.items()):
 f = acc.get("FETCH_SIZE"); w = acc.get("WRITE_SIZE")
 if f and w:
     f, w = sum(f)/len(f)*1024, sum(w)/len(w)*1024
-    print(f"FETCH x2 corrected {2*f/1e6:.1f} MB, WRITE {w/1e6:.1f} MB per launch")
+    print(f"wgrad_group bf16 (8 weights of a C2b layer) over 64000 frames [algorithmic 1021.8 MB: 983.0 operands + 5.8 dW + 33 slab set]: "
+          f"launches={len(acc['FETCH_SIZE'])} FETCH_SIZE={f/1e6:.1f} MB (x2 corrected {2*f/1e6:.1f} MB)  WRITE_SIZE={w/1e6:.1f} MB  "
+          f"traffic(corrected)={(2*f+w)/1e6:.1f} MB per launch")
 PY

@@ -1,19 +1,29 @@
 #!/usr/bin/env bash
-# Re-measure everything profiles/ holds (run on the GPU box through gpurun; outputs land in gpurun_out/refresh/,
-# copy them into profiles/ afterwards):  gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh v7'
+# Re-measure everything profiles/ holds for this round (run on the GPU box through gpurun; outputs land in
+# gpurun_out/refresh/, copy them into profiles/ afterwards):  gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02 v2'
 set -uo pipefail
-TAG="${1:-vX}"
+R="${1:-r02}"; TAG="${2:-vX}"
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/refresh"; mkdir -p "$OUT"
 cd "$ROOT"
-python bench.py 2>/dev/null | tail -1 > "$OUT/r01_bench_default.json"
-python bench.py --batch 64 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/r01_bench_b64.json"
-python bench.py --config c2a --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/r01_bench_c2a.json"
-python bench.py --mode forward --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/r01_bench_fwd.json"
-python bench.py --config c4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/r01_bench_c4.json"
-python bench.py --config c5 --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/r01_bench_c5.json"
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_refresh && rocprofv3 --kernel-trace --stats -d /tmp/prof_refresh -o p -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1)
-DB=$(find /tmp/prof_refresh -name '*.db' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline   (7 steps incl. warmup; C2b, B=128 x T=500, bf16, dropout 0.15)"; python tools/prof_summary.py "$DB" 7; echo; echo "## GEMM launches by grid (shape)"; python tools/prof_by_grid.py "$DB" 7; } > "$OUT/r01_step_c2b_${TAG}.txt"
-bash tools/pmc_traffic.sh > "$OUT/r01_pmc_traffic.txt" 2>&1
+python bench.py 2>/dev/null | tail -1 > "$OUT/${R}_bench_default.json"
+python bench.py --batch 64 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${R}_bench_b64.json"
+python bench.py --batch 32 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/${R}_bench_b32.json"
+python bench.py --config c2a --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${R}_bench_c2a.json"
+python bench.py --config c2a --batch 10 --frames 375 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/${R}_bench_c2a_recipe_batch.json"
+python bench.py --mode forward --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${R}_bench_fwd.json"
+python bench.py --config c4 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${R}_bench_c4.json"
+python bench.py --config c5 --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/${R}_bench_c5.json"
+prof() {  # name, header, command...
+  local name="$1" hdr="$2"; shift 2
+  (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_refresh && rocprofv3 --kernel-trace --stats -d /tmp/prof_refresh -o p -- "$@" > /dev/null 2>&1)
+  local DB; DB=$(find /tmp/prof_refresh -name '*.db' | head -1)
+  { echo "# $hdr"; python tools/prof_summary.py "$DB" "${STEPS:-1}"; echo; echo "## GEMM launches by grid (shape)"; python tools/prof_by_grid.py "$DB" "${STEPS:-1}"; } > "$OUT/$name"
+}
+STEPS=7 prof "${R}_step_c2b_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline   (7 steps incl. warmup; C2b, B=128 x T=500, bf16, dropout 0.15)" python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
+STEPS=7 prof "${R}_step_c4_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --config c4 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline   (7 steps; C4 Branchformer, B=128 x T=250)" python "$ROOT/bench.py" --config c4 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
+STEPS=8 prof "${R}_wgrad_group_isolated.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 layer   (8 launches: the 8 weight gradients of a C2b layer, 64000 frames, isolated back to back; algorithmic 983 + 1.4 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 layer
+STEPS=8 prof "${R}_wgrad_group_one_1024x256.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 one   (8 launches: dW(1024x256) alone over 64000 frames; algorithmic 164.9 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 one
+bash tools/pmc_traffic.sh > "$OUT/${R}_pmc_traffic.txt" 2>&1
+bash tools/pmc_wgroup.sh layer > "$OUT/${R}_pmc_wgrad_group.txt" 2>&1
 ls -la "$OUT"
