@@ -586,7 +586,7 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
                                     const float* bias, const void* gate, int64_t ldg, void* dP, int64_t lddp,
                                     void* dgate, int64_t lddg, float* dw, float* dbias, int B, int T, int D, int k,
                                     int glu, int pad_mode, int chunk, void* workspace, void* stream) {
-  SMX_REQUIRE(dY && P && w && dP && dw, "smx_dwconv1d_glu_bwd: null pointer");
+  SMX_REQUIRE(dY && P && w && dP && (dw || workspace), "smx_dwconv1d_glu_bwd: null pointer");
   SMX_REQUIRE(k >= 1 && k <= DW_KMAX && (k & 1), "smx_dwconv1d_glu_bwd: k=%d must be odd and <= %d", k, DW_KMAX);
   SMX_REQUIRE((gate == nullptr) == (dgate == nullptr), "smx_dwconv1d_glu_bwd: gate and dgate go together");
   if (B <= 0 || T <= 0 || D <= 0) return SMX_OK;
@@ -622,7 +622,10 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
     }
 #undef DW_BWD
     const long W = (long)D * (k + 1);
-    hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, (int)gy, D, k, dw, dbias);
+    // (dw == NULL: the partial rows [gy][D][k + 1] stay in the workspace for a deferred smx_reduce_jobs)
+    if (dw) hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, (int)gy, D, k, dw, dbias);
+  } else if (!dw) {
+    return fail(SMX_EUNSUPPORTED, "smx_dwconv1d_glu_bwd: dw == NULL (deferred reduction) needs the k = 31 vector path");
   } else if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, p, tiles_t);
   else hipLaunchKernelGGL((dwconv_bwd_kernel<float>), grid, dim3(256), 0, s, p, tiles_t);
   return check_launch("smx_dwconv1d_glu_bwd");

@@ -154,11 +154,14 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const float* inv_count, T* dS, long ldds,
                                                          int T_, int D, int RPB, uint32_t dthresh, float dscale,
                                                          uint64_t dseed_, const uint64_t* ep, const T* __restrict__ Z, long ldz,
-                                                         const uint8_t* __restrict__ mask, int act) {
+                                                         const uint8_t* __restrict__ mask, int act, int LPR) {
   const uint64_t dseed = dthresh ? epoch_seed(dseed_, ep) : 0;
   constexpr int N = VT<T>::N;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
-  const int col = (blockIdx.x * 64 + lane) * N;
+  // LPR lanes cover the columns of a row (a power of two <= 64): for narrow rows (D = 256 in bf16: 32 lanes) a wave
+  // writes 64 / LPR rows per pass instead of leaving half its lanes idle
+  const int lane = threadIdx.x & 63, b = blockIdx.z;
+  const int RPW = 64 / LPR, w = (threadIdx.x >> 6) * RPW + lane / LPR, WS = 4 * RPW;
+  const int col = (blockIdx.x * LPR + (lane & (LPR - 1))) * N;
   const int nvalid = D - col;
   if (nvalid <= 0) return;
   float v[N];
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const f
   if (Z || mask) {                                       // backward through act(.) * mask of the producing projection
     dispatch_act(Z ? act : SMX_ACT_NONE, [&](auto act_tag) {
       constexpr int ACT = decltype(act_tag)::value;
-      for (int t = t0 + w; t < t1; t += 4) {
+      for (int t = t0 + w; t < t1; t += WS) {
         const long n = (long)b * T_ + t;
         const float mk = mask ? (mask[n] ? 1.f : 0.f) : 1.f;
         float o[N];
@@ -186,9 +189,9 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const f
       }
     });
   } else if (dthresh == 0) {
-    for (int t = t0 + w; t < t1; t += 4) storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, v);
+    for (int t = t0 + w; t < t1; t += WS) storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, v);
   } else {                                               // fused inverted dropout, mask = f(seed, row * D + col)
-    for (int t = t0 + w; t < t1; t += 4) {
+    for (int t = t0 + w; t < t1; t += WS) {
       const uint64_t base = ((uint64_t)b * T_ + t) * (uint64_t)D + col;
       float o[N];
 #pragma unroll
@@ -1089,16 +1092,18 @@ static int bcast_impl(int dtype, const float* g, const float* inv_count, void* d
   const uint32_t dthresh = (uint32_t)((double)drop_p * 4294967296.0);
   const float dscale = 1.f / (1.f - drop_p);
   const int nvec = dtype == SMX_BF16 ? 8 : 4;
-  const int DC = (D + 64 * nvec - 1) / (64 * nvec), RPB = 64;
+  int LPR = 1;
+  while (LPR < 64 && LPR * nvec < D) LPR <<= 1;           // lanes per row (power of two)
+  const int DC = (D + LPR * nvec - 1) / (LPR * nvec), RPB = 64;
   dim3 grid(DC, (T + RPB - 1) / RPB, B);
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
   const bool vec = vec_ok(dS, ldds, D, nvec, es) && (Z == nullptr || vec_ok(Z, ldz, D, nvec, es));
   if (dtype == SMX_BF16) {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const bf16_t*)Z, ldz, mask, act);
-    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const bf16_t*)Z, ldz, mask, act);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const bf16_t*)Z, ldz, mask, act, LPR);
+    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const bf16_t*)Z, ldz, mask, act, LPR);
   } else {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const float*)Z, ldz, mask, act);
-    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const float*)Z, ldz, mask, act);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const float*)Z, ldz, mask, act, LPR);
+    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const float*)Z, ldz, mask, act, LPR);
   }
   return check_launch(what);
 }

@@ -164,9 +164,11 @@ def flush_deferred():
     if ent is None:
         arr = (L.ReduceJob * len(key))()
         starts = [0]
-        for i, (src, dstp, st, ldd, nsrc, rows, cols, alpha) in enumerate(key):
-            vec = int(cols % 4 == 0 and ldd % 4 == 0 and st % 4 == 0 and src % 16 == 0 and dstp % 16 == 0)
-            arr[i] = L.ReduceJob(src, dstp, st, ldd, nsrc, rows, cols, alpha, vec, 0)
+        for i, job in enumerate(key):
+            src, dstp, st, ldd, nsrc, rows, cols, alpha = job[:8]
+            src_ld = job[8] if len(job) > 8 else 0           # source row stride (0 = cols)
+            vec = int(cols % 4 == 0 and ldd % 4 == 0 and st % 4 == 0 and src_ld % 4 == 0 and src % 16 == 0 and dstp % 16 == 0)
+            arr[i] = L.ReduceJob(src, dstp, st, ldd, nsrc, rows, cols, alpha, vec, src_ld)
             starts.append(starts[-1] + L.lib().smx_reduce_job_blocks(ctypes.byref(arr[i])))
         dev = next(iter(_Deferred.ws.values())).device
         jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
@@ -677,6 +679,22 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None):
     return y, (bwd if need_bwd else None)
 
 
+def dwconv_bwd_deferred(dy, p_, wd, bd, gwd, gbd, B, T, D, k, glu, pad_mode, chunk, gate=None, dgate_out=None):
+    """ops.dwconv_bwd with the tap / bias partial rows folded by the block's one smx_reduce_jobs launch (k = 31 path)."""
+    if not (_Deferred.enabled and gwd is not None):
+        return ops.dwconv_bwd(dy, p_, wd, bd, gwd, gbd, B, T, D, k, glu, pad_mode, chunk, gate=gate, dgate_out=dgate_out)
+    nbytes = L.lib().smx_dwconv1d_glu_bwd_workspace(B, T, D, k)
+    ws = deferred_ws(gwd.data_ptr(), nbytes, dy.device)
+    dp, dg, deferred = ops.dwconv_bwd(dy, p_, wd, bd, gwd, gbd, B, T, D, k, glu, pad_mode, chunk, gate=gate, dgate_out=dgate_out,
+                                      ws=ws)
+    if deferred:
+        rows = nbytes // (D * (k + 1) * 4)
+        _Deferred.jobs.append((ws.data_ptr(), gwd.data_ptr(), D * (k + 1), k, rows, D, k, 1.0, k + 1))
+        if gbd is not None:
+            _Deferred.jobs.append((ws.data_ptr() + 4 * k, gbd.data_ptr(), D * (k + 1), 1, rows, D, 1, 1.0, k + 1))
+    return dp, dg
+
+
 def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
     """y = x + alpha * D2(W2 D1(act(W1 LN(x) + b1)) + b2)   (Conformer.py:458-472,507,536; D = dropout, p = 0 in eval).
     With p == 0 the second Linear's epilogue carries the residual and alpha (no extra pass)."""
@@ -729,8 +747,8 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
             da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr)
         dc = ln2_b(da)
         gwd = gacc(P["wd"])
-        dp, _ = ops.dwconv_bwd(dc, p_, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
-                               gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
+        dp, _ = dwconv_bwd_deferred(dc, p_, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
+                                    gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
         dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
         return ln1_b(dh, res=dy if residual else None, second=second)
     # what this block does first to its incoming gradient: D(dy) * mask (nothing to precompute without mask and dropout)

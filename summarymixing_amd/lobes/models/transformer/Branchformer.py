@@ -154,8 +154,8 @@ class BranchformerEncoderLayer(nn.Module):
                 dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
                                      drop=(pd, sd2) if pd > 0.0 else None, dx_drop=(pd, sd4) if pd > 0.0 else None)
                 du = torch.empty_like(u)                   # [d gate | d LN input]: both kernels write their half directly
-                dv, _ = ops.dwconv_bwd(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T, n, k,
-                                       False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])
+                dv, _ = F.dwconv_bwd_deferred(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T,
+                                              n, k, False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])
                 bnv(dv, out=du[:, n:])
                 dh2, _ = F.linear_bwd(du, h2, Wpre, zu, act, None, 1.0, F.gacc(Pb["Wpre"]), F.gacc(Pb["bpre"]))
                 dx = bn2(dh2, res=dy)

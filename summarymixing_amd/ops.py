@@ -334,7 +334,10 @@ def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=N
     return y
 
 
-def dwconv_bwd(dy, p, w, bias, dw, dbias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None, dgate_out=None):
+def dwconv_bwd(dy, p, w, bias, dw, dbias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None, dgate_out=None, ws=None):
+    """ws (caller-owned, smx_dwconv1d_glu_bwd_workspace bytes): the tap / bias partial rows stay in it for a deferred
+    reduce_jobs and dw / dbias are not touched; then returns (dp, dgate, deferred) - deferred False means the shape is outside
+    the partial-row path and the gradients were accumulated into dw / dbias directly."""
     dp = torch.empty((B * T, p.shape[1]), dtype=p.dtype, device=p.device)
     dgate = None
     if gate is not None:
@@ -342,14 +345,20 @@ def dwconv_bwd(dy, p, w, bias, dw, dbias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, 
     pdy, lddy = _mat(dy)
     pp, ldp = _mat(p)
     pg, ldg = (_mat(gate) if gate is not None else (None, 0))
-    ws = _workspace(L.lib().smx_dwconv1d_glu_bwd_workspace(B, T, D, k), p.device, slot=4)
     tok = _pb(f"dwconv_bwd ({B},{T},{D}) k={k}", 5 * B * T * D * _es(p))
-    L.check(L.lib().smx_dwconv1d_glu_bwd(dt(p), pdy, lddy, pp, ldp, _p(w), _p(bias), pg, ldg, _p(dp), dp.shape[1],
-                                         _p(dgate), (_mat(dgate)[1] if dgate is not None else 0), _p(dw), _p(dbias), B, T, D, k,
-                                         1 if glu else 0, pad_mode, chunk,
-                                         _p(ws), _stream()), "smx_dwconv1d_glu_bwd")
+
+    def call(pdw, pdb, wsp):
+        return L.lib().smx_dwconv1d_glu_bwd(dt(p), pdy, lddy, pp, ldp, _p(w), _p(bias), pg, ldg, _p(dp), dp.shape[1], _p(dgate),
+                                            (_mat(dgate)[1] if dgate is not None else 0), pdw, pdb, B, T, D, k, 1 if glu else 0,
+                                            pad_mode, chunk, wsp, _stream())
+    deferred = False
+    if ws is not None:
+        deferred = call(None, None, _p(ws)) == 0               # (SMX_EUNSUPPORTED: not the k = 31 vector path)
+    if not deferred:
+        own = _workspace(L.lib().smx_dwconv1d_glu_bwd_workspace(B, T, D, k), p.device, slot=4)
+        L.check(call(_p(dw), _p(dbias), _p(own)), "smx_dwconv1d_glu_bwd")
     _pe(tok)
-    return dp, dgate
+    return (dp, dgate, deferred) if ws is not None else (dp, dgate)
 
 
 def axpby(a, x, b=0.0, y0=None, out=None):
