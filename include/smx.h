@@ -61,13 +61,30 @@ typedef struct smx_epilogue {
   uint64_t drop_seed;                                     /* counter-based mask, same indexing as smx_dropout       */
   float* colsum;                                          /* [M] fp32 or NULL: colsum[m] += sum_n C[n,m] (fixed order) */
   void* workspace;                                        /* smx_gemm_colsum_workspace(N, M) bytes when colsum is set  */
+  /* SMX_EPI_LN_BWD: the GEMM output is the gradient of a LayerNorm's OUTPUT (M = the LayerNorm width) */
+  const void* ln_x;    int64_t ln_ldx;                    /* the LayerNorm input (N, M), dtype T                       */
+  const float* ln_stats; const float* ln_gamma;           /* (N, 2) mean | rstd of the forward; [M]                    */
+  float* ln_partial;                                      /* [ceil(N/128)][2][M] per-tile dgamma | dbeta partial rows  */
+  void* ln_dx2;        int64_t ln_lddx2;                  /* optional second output (see smx_layernorm_bwd2) or NULL   */
+  const uint8_t* ln_mask2; float ln_alpha2; float ln_drop_p2; uint64_t ln_drop_seed2;
+  /* SMX_EPI_LN_FWD: a LayerNorm of the (row-complete) output: lnf_y = act(LN(C)), lnf_stats = (mean, rstd) per row */
+  const float* lnf_gamma; const float* lnf_beta; void* lnf_y; int64_t lnf_ldy; float* lnf_stats; float lnf_eps; int32_t lnf_act;
 } smx_epilogue;
 /* flags.  SMX_EPI_ACT_GRAD turns the epilogue into the BACKWARD of an upstream activation layer: z is then a
  * read-only INPUT (the pre-activation the forward saved) and
  *   C[n,m] = alpha * dropout(v * act'(z[n,m])) * row_mask[n]
  * so a dgrad GEMM dX = dZ W emits the upstream layer's dZ directly (act/dropout/mask backward fused; `res` must be
  * NULL); with `colsum` the upstream bias gradient comes out of the same launch.  batch == 1, splits == 1. */
-enum { SMX_EPI_C0_POST = 1, SMX_EPI_ACT_GRAD = 2 };
+/* SMX_EPI_LN_BWD fuses the LayerNorm BACKWARD into the dgrad GEMM that produces the gradient g of the LayerNorm's output
+ * (torch.nn.LayerNorm of the Conformer modules, Conformer.py:146,152,458,475): with xhat = (ln_x - mean) * rstd,
+ *   C[n,:] = rstd * (g*gamma - mean_m(g*gamma) - xhat * mean_m(g*gamma*xhat)) + res[n,:]     (res = residual gradient)
+ * and per-tile partial rows dgamma = sum_n g * xhat, dbeta = sum_n g in ln_partial (fold with smx_reduce_jobs: two jobs,
+ * src = ln_partial (+ M), src_stride 2*M, nsrc = ceil(N/128), rows 1, cols M).  Needs the whole LayerNorm row in one
+ * tile: dtype bf16, M == 256, aligned operands, N >= 128 (smx_gemm_ln_fused_ok); no bias / act / dropout / C0 / Z.
+ * SMX_EPI_LN_FWD (same shape conditions) appends a LayerNorm FORWARD of the finished output rows: the ordinary epilogue
+ * writes C (bias, residual, dropout, mask ... as usual), then lnf_y = act(LN(C) * gamma + beta) and lnf_stats. */
+enum { SMX_EPI_C0_POST = 1, SMX_EPI_ACT_GRAD = 2, SMX_EPI_LN_BWD = 4, SMX_EPI_LN_FWD = 8 };
+int smx_gemm_ln_fused_ok(int dtype, int N, int M, int K);
 size_t smx_gemm_colsum_workspace(int N, int M);
 
 /* Batched strided MFMA GEMM  C[b] (N x M) = epilogue( op(A[b]) . op(B[b]) ), reduce length K.

@@ -16,6 +16,8 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 OUT_T, OUT_F32, OUT_ATOMIC_F32 = 0, 1, 2
 EPI_C0_POST = 1
 EPI_ACT_GRAD = 2
+EPI_LN_BWD = 4
+EPI_LN_FWD = 8
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACTS = {"none": ACT_NONE, "identity": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH,
         "leaky_relu": ACT_LEAKY_RELU, "relu": ACT_RELU}
@@ -44,7 +46,12 @@ class Epilogue(ctypes.Structure):
                 ("res", c_vp), ("ldr", c_i64),
                 ("alpha", c_f), ("flags", ctypes.c_int32),
                 ("drop_p", c_f), ("drop_pad", ctypes.c_int32), ("drop_seed", ctypes.c_uint64),
-                ("colsum", c_vp), ("workspace", c_vp)]
+                ("colsum", c_vp), ("workspace", c_vp),
+                ("ln_x", c_vp), ("ln_ldx", c_i64), ("ln_stats", c_vp), ("ln_gamma", c_vp), ("ln_partial", c_vp),
+                ("ln_dx2", c_vp), ("ln_lddx2", c_i64), ("ln_mask2", c_vp), ("ln_alpha2", c_f), ("ln_drop_p2", c_f),
+                ("ln_drop_seed2", ctypes.c_uint64),
+                ("lnf_gamma", c_vp), ("lnf_beta", c_vp), ("lnf_y", c_vp), ("lnf_ldy", c_i64), ("lnf_stats", c_vp),
+                ("lnf_eps", c_f), ("lnf_act", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/smx.h one to one (tests/test_abi.py checks the export list)
@@ -54,6 +61,7 @@ SIGNATURES = {
     "smx_gemm": (c_i, [c_i, c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i,
                        ctypes.POINTER(Epilogue), c_vp]),
     "smx_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
+    "smx_gemm_ln_fused_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "smx_linear_wgrad_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_linear_wgrad": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i, c_i,
                                c_f, c_vp, c_vp]),

@@ -35,8 +35,12 @@ namespace smx {
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
-template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC>
+// LNF: 0 = ordinary epilogue; 1 = LayerNorm backward fused (SMX_EPI_LN_BWD), 2 = LayerNorm forward appended
+// (SMX_EPI_LN_FWD) - separate instantiations of the 128 x 256 bf16 kernel, so that their extra live registers never cost
+// the ordinary one anything.
+template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0>
 __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
+  static_assert(LNF == 0 || (sizeof(T) == 2 && VEC && TILE_M == 256 && TILE_N == 128), "fused LayerNorm: bf16 128 x 256 tile");
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   constexpr int AB_BYTES = A_BYTES + B_BYTES;
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
-  constexpr int SIDE_BYTES = (TILE_M + TILE_N) * 4;              // bias[TILE_M] | row factors[TILE_N] (mask * alpha)
+  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0)) * 4;   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta]
   // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) operand stage, fenced by one extra barrier
   constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536;
@@ -377,6 +381,18 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     if (t + 256 * i < TILE_M + TILE_N) side[t + 256 * i] = side_v[i];   // (visible after the first barrier below)
   if constexpr (TILE_M > 128) {
   // (wide tile: 128 accumulator registers - duplicating the loop per variant spills there; the choice stays inside)
+  // LayerNorm fused into the epilogue (LNF; the tile holds whole rows: M == TILE_M == 256): gamma / beta are parked in
+  // LDS behind the side vector (requested before the first store of the epilogue, read back without any vmcnt wait)
+  float* lng = side + TILE_M + TILE_N;
+  float dgam[LNF == 1 ? 8 : 1], dbet[LNF == 1 ? 8 : 1];
+  if constexpr (LNF != 0) {
+    lng[t] = (LNF == 1 ? e.ln_gamma : e.lnf_gamma)[t];
+    if constexpr (LNF == 2) lng[TILE_M + t] = e.lnf_beta[t];
+    if constexpr (LNF == 1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dgam[q] = dbet[q] = 0.f;
+    }
+  }
 #pragma unroll 1
   for (int ph = 0; ph < NPH; ++ph) {
     lds_barrier();
@@ -398,6 +414,10 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     }
     lds_barrier();
     if (ph < 2) SMX_STAMP(3 + 2 * ph);
+    if constexpr (LNF == 1) {                             // the LayerNorm backward replaces the ordinary epilogue
+      epilogue_phase_lnbwd<T>(p, smem, lng, n0 + row_in_tile, t, dgam, dbet);
+      continue;
+    }
     if (sizeof(T) == 2 && osz == 2) {
       if (VEC && p.epi_simple == 1) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
       else if (VEC && p.epi_simple == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
@@ -416,7 +436,27 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
         else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = s;
       }
     }
+    if constexpr (LNF == 2) epilogue_phase_lnfwd<T>(p, smem, lng, n0 + row_in_tile, t);
     if (ph < 2) SMX_STAMP(4 + 2 * ph);
+  }
+  if constexpr (LNF == 1) {
+    {
+      // dgamma / dbeta of the tile: the 8 row groups (threads t, t + 32, ...) are folded through LDS in a fixed order into
+      // ONE partial row pair per tile
+      float* redg = reinterpret_cast<float*>(smem);
+      lds_barrier();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        redg[(t >> 5) * 256 + (t & 31) * 8 + q] = dgam[q];
+        redg[2048 + (t >> 5) * 256 + (t & 31) * 8 + q] = dbet[q];
+      }
+      lds_barrier();
+      float sg = 0.f, sb = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) { sg += redg[g * 256 + t]; sb += redg[2048 + g * 256 + t]; }
+      e.ln_partial[((long)tile_n * 2) * 256 + t] = sg;
+      e.ln_partial[((long)tile_n * 2 + 1) * 256 + t] = sb;
+    }
   }
   } else {
   // The epilogue variant is chosen ONCE, outside the phase loop: with the choice inside, the loop carried the hoisted
@@ -665,6 +705,19 @@ static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
 
 template <typename T, bool A_KC, bool B_KC>
 static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
+  if (p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_LN_FWD)) {
+    // fused LayerNorm: the tile must hold whole rows -> the 128 x 256 tile, whatever the grid size
+    if constexpr (sizeof(T) == 2 && A_KC) {
+      if (vec && p.M == 256 && p.N >= 128 && p.splits == 1 && p.batch == 1 && p.e.out_mode == SMX_OUT_T && !p.e.colsum) {
+        p.tiles_n = (p.N + 127) / 128;
+        p.tiles_m = 1;
+        if (p.e.flags & SMX_EPI_LN_BWD) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 1>), dim3(p.tiles_n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 2>), dim3(p.tiles_n), dim3(256), 0, s, p);
+        return check_launch("smx_gemm");
+      }
+    }
+    return fail(SMX_EUNSUPPORTED, "smx_gemm: fused LayerNorm needs bf16 NT / NN, M == 256, N >= 128 and 16-byte aligned operands");
+  }
 
   // big tiles once they alone fill the chip (256 CUs x 2 resident blocks); otherwise 64x64 for more blocks
   long big = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch * p.splits;
@@ -775,6 +828,14 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   if (p.e.flags & SMX_EPI_ACT_GRAD)
     SMX_REQUIRE(p.e.z && !p.e.res && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
                 "smx_gemm: SMX_EPI_ACT_GRAD needs z (input), no residual, batch == 1, splits == 1");
+  if (p.e.flags & SMX_EPI_LN_BWD)
+    SMX_REQUIRE(p.e.ln_x && p.e.ln_stats && p.e.ln_gamma && p.e.ln_partial && !p.e.bias && !p.e.c0 && !p.e.z && !p.e.row_mask &&
+                p.e.act == SMX_ACT_NONE && p.e.drop_p == 0.f && p.e.alpha == 1.f && aligned16(p.e.ln_x) && p.e.ln_ldx % 8 == 0 &&
+                (!p.e.ln_dx2 || (aligned16(p.e.ln_dx2) && p.e.ln_lddx2 % 8 == 0)) && p.e.ln_drop_p2 >= 0.f && p.e.ln_drop_p2 < 1.f,
+                "smx_gemm: SMX_EPI_LN_BWD takes ln_x / ln_stats / ln_gamma / ln_partial (+ res, ln_dx2) and no other epilogue field");
+  if (p.e.flags & SMX_EPI_LN_FWD)
+    SMX_REQUIRE(p.e.lnf_gamma && p.e.lnf_beta && p.e.lnf_y && aligned16(p.e.lnf_y) && p.e.lnf_ldy % 8 == 0 &&
+                !(p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_ACT_GRAD)), "smx_gemm: SMX_EPI_LN_FWD needs lnf_gamma / lnf_beta / lnf_y");
   if (p.e.colsum)
     SMX_REQUIRE(p.e.workspace && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
                 "smx_gemm: colsum needs a workspace (smx_gemm_colsum_workspace), batch == 1, splits == 1");
@@ -804,6 +865,10 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SMX_BF16) return launch_dtype<bf16_t>(layout, p, vec, s);
   return launch_dtype<float>(layout, p, vec, s);
+}
+
+extern "C" int smx_gemm_ln_fused_ok(int dtype, int N, int M, int K) {
+  return dtype == SMX_BF16 && M == 256 && N >= 128 && K > 0 && K % 64 == 0;
 }
 
 extern "C" size_t smx_gemm_colsum_workspace(int N, int M) {

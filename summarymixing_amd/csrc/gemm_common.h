@@ -491,7 +491,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
 #pragma unroll
         for (int q = 0; q < CW; ++q) v[q] += cv[kk][q];
       }
-      if (!SIMPLE && e.colsum) {                         // final values back into the item's own staged slot
+      if ((!SIMPLE && e.colsum) || (e.flags & SMX_EPI_LN_FWD)) {   // final values back into the item's own staged slot
 #pragma unroll
         for (int q4 = 0; q4 < CW / 4; ++q4)
           *reinterpret_cast<float4*>(const_cast<char*>(smem) + r * STG_LD + (c + 4 * q4) * 4) =
@@ -550,6 +550,152 @@ __device__ __forceinline__ void stage_colsum(const uint4 (&reg)[ROWS / 32], floa
   }
 }
 
+
+// ---- LayerNorm fused into the epilogue of a row-complete tile (TILE_M = 256 = the LayerNorm width, 256 threads, 32 staged
+// rows per phase): thread t owns the 8 columns c = (t % 32) * 8 of rows r0 + 8 k (r0 = t / 32, k < 4), so the 32 lanes of a
+// half wave hold one row and row reductions are five xor-shuffles inside the half wave. ----
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// SMX_EPI_LN_BWD: staged rows = g (gradient of the LayerNorm output).  dX = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
+// + res, optional second output alpha2 * D(dX) * mask2, dgamma / dbeta accumulated per thread (folded per tile by the caller).
+// (two items at a time: the side inputs of all four would not fit next to the 128 accumulator registers)
+template <typename T>
+__device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const char* smem, const float* lng, int nbase0, int t,
+                                                     float (&dgam)[8], float (&dbet)[8]) {
+  constexpr int STG_LD = 256 * 4 + 16, NIT = 2, RSTEP = 8, SW = 8 * (int)sizeof(T) / 4;
+  const smx_epilogue& e = p.e;
+  const int c = (t & 31) * 8, r0 = t >> 5;
+  const T* X = reinterpret_cast<const T*>(e.ln_x);
+  const T* R = reinterpret_cast<const T*>(e.res);
+  float gam[8];
+#pragma unroll
+  for (int q4 = 0; q4 < 2; ++q4) {
+    const float4 g4 = *reinterpret_cast<const float4*>(lng + c + 4 * q4);
+    gam[4 * q4] = g4.x; gam[4 * q4 + 1] = g4.y; gam[4 * q4 + 2] = g4.z; gam[4 * q4 + 3] = g4.w;
+  }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+  const int nbase = nbase0 + half * 16;
+  const char* smh = smem + half * 16 * STG_LD;
+  // every side input of the phase is requested (and waited for) before its first store
+  uint32_t xw[NIT][SW], rw[NIT][SW];
+  float2 st[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const long n = min(nbase + r0 + k * RSTEP, p.N - 1);
+    ld_words<SW>(X + n * e.ln_ldx + c, xw[k]);
+    st[k] = *reinterpret_cast<const float2*>(e.ln_stats + 2 * n);
+    if (R) ld_words<SW>(R + n * e.ldr + c, rw[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+#pragma unroll
+    for (int q = 0; q < SW; ++q) settle(xw[k][q]);
+    settle(st[k].x); settle(st[k].y);
+  }
+  if (R) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+#pragma unroll
+      for (int q = 0; q < SW; ++q) settle(rw[k][q]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+#pragma unroll
+      for (int q = 0; q < SW; ++q) rw[k][q] = 0u;
+  }
+  const uint32_t thresh2 = e.ln_dx2 ? (uint32_t)((double)e.ln_drop_p2 * 4294967296.0) : 0u;
+  const float scale2 = 1.f / (1.f - e.ln_drop_p2);
+  const uint64_t seed2 = thresh2 ? epoch_seed(e.ln_drop_seed2, p.epoch) : 0;
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int r = r0 + k * RSTEP, n = nbase + r;
+    const bool rok = n < p.N;
+    float v[8], xh[8], rf[8];
+#pragma unroll
+    for (int q4 = 0; q4 < 2; ++q4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(smh + r * STG_LD + (c + 4 * q4) * 4);
+      v[4 * q4] = a4.x; v[4 * q4 + 1] = a4.y; v[4 * q4 + 2] = a4.z; v[4 * q4 + 3] = a4.w;
+    }
+    unpack_words<T, 8>(xw[k], xh);
+    unpack_words<T, 8>(rw[k], rf);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      xh[q] = (xh[q] - st[k].x) * st[k].y;
+      const float g = rok ? v[q] : 0.f;
+      dgam[q] += g * xh[q];
+      dbet[q] += g;
+      v[q] = g * gam[q];
+      s1 += v[q];
+      s2 += v[q] * xh[q];
+    }
+    s1 = half_wave_sum(s1) * (1.f / 256.f);
+    s2 = half_wave_sum(s2) * (1.f / 256.f);
+    if (!rok) continue;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = st[k].y * (v[q] - s1 - xh[q] * s2) + rf[q];
+    st_elems<T, 8>(reinterpret_cast<T*>(p.C) + (long)n * p.ldc + c, v);
+    if (e.ln_dx2) {                                      // (uniform)
+      const float mk = (e.ln_mask2 ? (e.ln_mask2[n] ? 1.f : 0.f) : 1.f) * e.ln_alpha2;
+      if (thresh2) dropout_apply<8>(v, seed2, (uint64_t)n * 256 + c, thresh2, scale2);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] *= mk;
+      st_elems<T, 8>(reinterpret_cast<T*>(e.ln_dx2) + (long)n * e.ln_lddx2 + c, v);
+    }
+  }
+  }
+}
+
+// SMX_EPI_LN_FWD: the ordinary epilogue_phase has written the finished output values back to their staged slots (each
+// thread re-reads its own items: no barrier); lnf_y = act(LN(row) * gamma + beta), lnf_stats = (mean, rstd).
+template <typename T>
+__device__ __forceinline__ void epilogue_phase_lnfwd(const GemmParams& p, const char* smem, const float* lng, int nbase, int t) {
+  constexpr int STG_LD = 256 * 4 + 16, NIT = 4, RSTEP = 8;
+  const smx_epilogue& e = p.e;
+  const int c = (t & 31) * 8, r0 = t >> 5;
+  float gam[8], bet[8];
+#pragma unroll
+  for (int q4 = 0; q4 < 2; ++q4) {
+    const float4 g4 = *reinterpret_cast<const float4*>(lng + c + 4 * q4), b4 = *reinterpret_cast<const float4*>(lng + 256 + c + 4 * q4);
+    gam[4 * q4] = g4.x; gam[4 * q4 + 1] = g4.y; gam[4 * q4 + 2] = g4.z; gam[4 * q4 + 3] = g4.w;
+    bet[4 * q4] = b4.x; bet[4 * q4 + 1] = b4.y; bet[4 * q4 + 2] = b4.z; bet[4 * q4 + 3] = b4.w;
+  }
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int r = r0 + k * RSTEP, n = nbase + r;
+    float v[8];
+#pragma unroll
+    for (int q4 = 0; q4 < 2; ++q4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
+      v[4 * q4] = a4.x; v[4 * q4 + 1] = a4.y; v[4 * q4 + 2] = a4.z; v[4 * q4 + 3] = a4.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += v[q];
+    const float mean = half_wave_sum(s) * (1.f / 256.f);
+    float qq = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { v[q] -= mean; qq += v[q] * v[q]; }
+    const float rstd = rsqrtf(half_wave_sum(qq) * (1.f / 256.f) + e.lnf_eps);
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = v[q] * rstd * gam[q] + bet[q];
+    switch (e.lnf_act) {
+      case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 8>(v); break;
+      case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 8>(v); break;
+      case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(v); break;
+      case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 8>(v); break;
+      default: break;
+    }
+    st_elems<T, 8>(reinterpret_cast<T*>(e.lnf_y) + (long)n * e.lnf_ldy + c, v);
+    if (e.lnf_stats && (t & 31) == 0) *reinterpret_cast<float2*>(e.lnf_stats + 2 * (long)n) = make_float2(mean, rstd);
+  }
+}
 
 // LDS-DMA issue of one 1 KB piece (global_load_lds_dwordx4: lane i lands at lds_dst + 16 i; M0 carries the wave-uniform
 // LDS base and is compiler-reserved, so it is saved / restored inside the statement).  hipcc does not count this

@@ -257,8 +257,21 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
     return out, z
 
 
+_LN_FUSE = os.environ.get("SMX_LN_FUSE", "1") != "0"   # A/B knob: LayerNorm backward / forward inside the GEMM epilogues
+
+
+def ln_fusable(ln_spec, N, K_out, dtype):
+    """Can the LayerNorm (its backward closure's `.spec`) ride in the epilogue of a GEMM with N rows and K_out = the LN width
+    output columns?  (bf16, width 256, no fused activation, deferred parameter reductions on)"""
+    if not (_LN_FUSE and _Deferred.enabled and ln_spec is not None and dtype == torch.bfloat16):
+        return False
+    x = ln_spec["x"]
+    return (ln_spec["act"] == L.ACT_NONE and x.shape[1] == K_out and x.shape[0] == N and gacc(ln_spec["gw_param"]) is not None
+            and L.lib().smx_gemm_ln_fused_ok(L.BF16, N, K_out, 64) == 1 and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0)
+
+
 def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
-               drop=None, dz_ready=False, up=None, dx_drop=None):
+               drop=None, dz_ready=False, up=None, dx_drop=None, ln=None, ln_second=None):
     """Backward of y = res + alpha*D(act(x W^T + b + c0))*mask (D = the forward's fused dropout, regenerated from its
     seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate.
     dz_ready: dy already IS dZ (a downstream dgrad epilogue fused this layer's act/dropout/mask backward, see `up`).
@@ -266,7 +279,10 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
     upstream activation layer; the dgrad GEMM's epilogue then emits THAT layer's dZ (SMX_EPI_ACT_GRAD) instead of dX,
     so the (N x K) gradient never makes a separate elementwise pass (gb_up: optional colsum output; normally None,
     the upstream layer's own wgrad yields its bias gradient).
-    dx_drop = (p, seed): x is the output of a dropout of that seed; its backward rides in the dgrad epilogue."""
+    dx_drop = (p, seed): x is the output of a dropout of that seed; its backward rides in the dgrad epilogue.
+    ln = the `.spec` of a LayerNorm backward closure whose OUTPUT is x (x = LN(ln["x"])): the dgrad epilogue then runs that
+    LayerNorm backward (SMX_EPI_LN_BWD; check ln_fusable first): returns the gradient w.r.t. ln["x"] (+ res_grad), and,
+    with ln_second = (alpha, mask, drop), the pair (dx, alpha * D(dx) * mask)."""
     N, M = dy.shape
     K = x.shape[1]
     if drop is not None and drop[0] <= 0.0:
@@ -287,6 +303,17 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
     dx = None
     if need_dx:
         dx = dx_out if dx_out is not None else torch.empty((N, K), dtype=dy.dtype, device=dy.device)
+        if ln is not None:
+            assert up is None and dx_drop is None and K % 64 == 0
+            gw_ln, gb_ln = gacc(ln["gw_param"]).view(-1), gacc(ln["gb_param"]).view(-1)
+            ntile = (N + 127) // 128
+            ws = deferred_ws(gw_ln.data_ptr(), ntile * 2 * K * 4, dy.device)
+            dx2 = torch.empty((N, K), dtype=dy.dtype, device=dy.device) if ln_second is not None else None
+            e = ops.epilogue(res=res_grad, ln_bwd=(ln["x"], ln["stats"], ln["w"].detach(), ws, dx2, ln_second))
+            ops.gemm(L.GEMM_NN, dz, W, dx, N, K, M, e)
+            defer(ws.data_ptr(), gw_ln, 2 * K, ntile, 1, K)
+            defer(ws.data_ptr() + 4 * K, gb_ln, 2 * K, ntile, 1, K)
+            return ((dx, dx2) if ln_second is not None else dx), dz
         if up is not None:
             assert res_grad is None
             z_up, act_up, mask_up, alpha_up, drop_up, gb_up = up
@@ -328,7 +355,8 @@ def mlp_fwd(x, layers, act, mask, need_bwd, dtype, last_res=None, last_drop=None
     return x, saved
 
 
-def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None, dz_ready=False, last_drop=None):
+def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None, dz_ready=False, last_drop=None, ln=None,
+            ln_second=None):
     """dz_ready: dy already is the LAST layer's dZ and its bias gradient is done (fused upstream, see linear_bwd `up`).
     last_drop: the dropout mlp_fwd fused into the last layer."""
     n = len(layers)
@@ -345,7 +373,8 @@ def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=N
                 up = (saved[i - 1][1], act, saved[i - 1][2], 1.0, None, None)
             dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), gacc(ly["b"]), want_dx,
                                res_grad if first else None, dx_out=dx_out if first else None, dz_ready=dz_ready, up=up,
-                               drop=last_drop if i == n - 1 else None)
+                               drop=last_drop if i == n - 1 else None, ln=ln if first else None,
+                               ln_second=ln_second if first else None)
             dz_ready = up is not None
         else:
             Wc = wcast(ly["W"], dtype)
@@ -545,7 +574,10 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         if not need_bwd:
             return y3, None
 
-        def bwd(dy3):
+        def bwd(dy3, ln=None, ln_res=None, ln_second=None):
+            """ln / ln_res / ln_second (only when bwd.can_fuse_ln): the LayerNorm whose output is this cell's input runs its
+            backward in the epilogue of the cell's input dgrad (linear_bwd(ln=...)); then 2-D tensors come back: the
+            gradient w.r.t. that LayerNorm's input (+ ln_res), or the pair with the second output."""
             dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
             s_out = dy.shape[1]
             gWm, gbm = gacc(mg["W"]), gacc(mg["b"])
@@ -643,11 +675,15 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                     if (z_g is not None or mk_g is not None) and not sum_done:
                         ops.act_mask_bwd(ds_out, z_g[:, l:] if z_g is not None else None, mk_g,
                                          act if z_g is not None else L.ACT_NONE, 1.0, ds_out, None)
+                if ln is not None:
+                    return mlp_bwd(dg, P["global_proj"], act, sv_g, dtype, dz_ready=fuse_local, res_grad=ln_res, ln=ln,
+                                   ln_second=ln_second)
                 dx = mlp_bwd(dg, P["global_proj"], act, sv_g, dtype, dz_ready=fuse_local)
             else:
                 dx = mlp_bwd(dlocal_out, P["local_proj"], act, sv_l, dtype, dz_ready=fuse_local)
                 dx = mlp_bwd(ds_out, P["summary_proj"], act, sv_s, dtype, res_grad=dx)
             return dx.view(B, T, -1)
+        bwd.can_fuse_ln = (mode == "SummaryMixing-fast" and len(P["global_proj"]) == 1 and P["global_proj"][0]["kind"] == "linear")
         return y3, bwd
     return run
 
@@ -676,6 +712,9 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None):
             defer(ws.data_ptr() + 4 * D, gb, 2 * D, nb, 1, D)
             return dx
         return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act, dx_out=out, second=second)
+    # what a dgrad GEMM needs to run this backward in its own epilogue (linear_bwd(ln=...))
+    bwd.spec = {"x": x, "w": w, "stats": stats, "act": act, "gw_param": wp if wp is not None else w,
+                "gb_param": bp if bp is not None else b}
     return y, (bwd if need_bwd else None)
 
 
@@ -717,6 +756,10 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
         else:
             dz1, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2,
                                 up=(z1, act, None, 1.0, d1, None))
+        if ln_fusable(ln_b.spec, h.shape[0], h.shape[1], dtype):     # the LayerNorm backward rides in the dgrad epilogue
+            out, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True, res_grad=dy,
+                                ln=ln_b.spec, ln_second=second)
+            return out
         dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True)
         return ln_b(dh, res=dy, second=second)
     bwd.pre = (alpha, None, d2)          # what this block does first to its incoming gradient: alpha * D2(dy)
@@ -749,6 +792,10 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
         gwd = gacc(P["wd"])
         dp, _ = dwconv_bwd_deferred(dc, p_, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
                                     gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
+        if ln_fusable(ln1_b.spec, h.shape[0], d, dtype):
+            out, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]),
+                                res_grad=dy if residual else None, ln=ln1_b.spec, ln_second=second)
+            return out
         dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
         return ln1_b(dh, res=dy if residual else None, second=second)
     # what this block does first to its incoming gradient: D(dy) * mask (nothing to precompute without mask and dropout)

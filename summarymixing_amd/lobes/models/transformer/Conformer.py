@@ -141,8 +141,12 @@ class ConformerEncoderLayer(nn.Module):
                     d2 = bconv(d3, dz_in=d3z)
                 else:
                     d2 = bconv(bf2(d4, dz_in=d4z))
-                dh = ops.rows2d(bcell(d2.view(B, T, -1)))
-                d1, d1z = bn1(dh, res=d2, second=b1.pre)                               # skip gradient fused
+                if getattr(bcell, "can_fuse_ln", False) and F.ln_fusable(bn1.spec, d2.shape[0], d2.shape[1], dtype):
+                    # norm1's backward (+ the skip gradient, + FFN1's 1/2 * dropout) in the epilogue of the cell's input dgrad
+                    d1, d1z = bcell(d2.view(B, T, -1), ln=bn1.spec, ln_res=d2, ln_second=b1.pre)
+                else:
+                    dh = ops.rows2d(bcell(d2.view(B, T, -1)))
+                    d1, d1z = bn1(dh, res=d2, second=b1.pre)                           # skip gradient fused
                 return b1(d1, dz_in=d1z).view(B, T, -1)
             return y5.view(B, T, -1), bwd
         return run

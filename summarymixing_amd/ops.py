@@ -89,7 +89,7 @@ def rows2d(x):
 
 def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, out_mode=L.OUT_T, z=None,
              row_mask=None, res=None, alpha=1.0, bias_batch_stride=0, drop=None, c0_post=False, act_grad_z=None,
-             colsum=None):
+             colsum=None, ln_bwd=None, ln_fwd=None):
     """Build an smx_epilogue.  act_grad_z: the saved pre-activation of the UPSTREAM layer (SMX_EPI_ACT_GRAD: the GEMM
     then emits alpha * D(acc * act'(z)) * mask, i.e. the upstream dZ); colsum: fp32 [M] accumulator of the output's
     column sums (the upstream bias gradient), workspace attached by gemm()."""
@@ -120,6 +120,26 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         e.colsum = colsum.data_ptr()
     if drop is not None and drop[0] > 0.0:
         e.drop_p, e.drop_seed = drop
+    if ln_bwd is not None:
+        # (x, stats, gamma, partial, dx2 | None, second | None): SMX_EPI_LN_BWD - the GEMM output is the gradient of LN(x)
+        x, stats, gamma, partial, dx2, second = ln_bwd
+        e.ln_x, e.ln_ldx = x.data_ptr(), _mat(x)[1]
+        e.ln_stats, e.ln_gamma, e.ln_partial = stats.data_ptr(), gamma.data_ptr(), partial.data_ptr()
+        e.flags |= L.EPI_LN_BWD
+        if dx2 is not None:
+            a2, m2, drop2 = second
+            e.ln_dx2, e.ln_lddx2, e.ln_alpha2 = dx2.data_ptr(), _mat(dx2)[1], a2
+            e.ln_mask2 = m2.data_ptr() if m2 is not None else None
+            if drop2 is not None and drop2[0] > 0.0:
+                e.ln_drop_p2, e.ln_drop_seed2 = drop2
+    if ln_fwd is not None:
+        # (gamma, beta, y, stats | None, eps, act): SMX_EPI_LN_FWD - y = act(LN(output)) appended to the epilogue
+        gamma, beta, y, stats, eps, lact = ln_fwd
+        e.lnf_gamma, e.lnf_beta = gamma.data_ptr(), beta.data_ptr()
+        e.lnf_y, e.lnf_ldy = y.data_ptr(), _mat(y)[1]
+        e.lnf_stats = stats.data_ptr() if stats is not None else None
+        e.lnf_eps, e.lnf_act = eps, lact
+        e.flags |= L.EPI_LN_FWD
     return e
 
 
@@ -137,8 +157,11 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
     if _PROF is not None:
         es, osz = _es(a), (4 if epi.out_mode == L.OUT_F32 else _es(c))
         side = (1 if epi.res else 0) + (1 if epi.z else 0)            # residual / saved or re-read pre-activation
+        side += (1 if epi.flags & L.EPI_LN_BWD else 0) + (1 if epi.ln_dx2 else 0)     # the LayerNorm input; the second output
+        side += 1 if epi.flags & L.EPI_LN_FWD else 0                                   # the normalised copy of the output
         nb = batch * ((N * K + M * K + side * N * M) * es + N * M * osz)
-        tag = "".join(t for t, on in (("+bias", epi.bias), ("+act", epi.act != L.ACT_NONE and not (epi.flags & L.EPI_ACT_GRAD)),
+        tag = ("+LNbwd" if epi.flags & L.EPI_LN_BWD else "") + ("+LNfwd" if epi.flags & L.EPI_LN_FWD else "")
+        tag += "".join(t for t, on in (("+bias", epi.bias), ("+act", epi.act != L.ACT_NONE and not (epi.flags & L.EPI_ACT_GRAD)),
                                       ("+Z", epi.z and not (epi.flags & L.EPI_ACT_GRAD)), ("+actgrad(z)", epi.flags & L.EPI_ACT_GRAD),
                                       ("+res", epi.res), ("+c0", epi.c0), ("+mask", epi.row_mask), ("+drop", epi.drop_p > 0)) if on)
         tok = _pb(f"gemm {('NT', 'NN', 'TN')[layout]} {'bf16' if es == 2 else 'f32'} ({N}x{K})x({K}x{M}){'' if batch == 1 else ' x%d' % batch} {tag}",

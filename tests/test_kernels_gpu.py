@@ -481,3 +481,66 @@ def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
     gW2, gb2 = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
     ops.wgrad(dz, x, gW2, rows, M, K, dbias=gb2)        # the per-weight slab GEMM + reduction
     assert rel_err(outs[0][0], gW2) < 1e-5 and rel_err(outs[0][1], gb2) < 1e-5
+
+
+# ---- LayerNorm fused into the 128 x 256 GEMM epilogue (SMX_EPI_LN_BWD / SMX_EPI_LN_FWD) -------------------------------
+@pytest.mark.parametrize("N,K", [(4096, 1024), (33000 + 77, 512), (200, 256)])
+def test_gemm_epilogue_layernorm_backward(N, K):
+    """dgrad GEMM whose epilogue runs the LayerNorm backward (rows complete in the 128 x 256 tile): dX, the second output
+    alpha * D(dX) * mask, and the per-tile dgamma / dbeta partial rows against fp64 torch math."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(N)
+    D = 256
+    dz = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
+    W = (torch.randn(K, D, device="cuda") * 0.05).bfloat16()           # NN: dh = dz @ W
+    x = torch.randn(N, D, device="cuda").bfloat16()
+    res = torch.randn(N, D, device="cuda").bfloat16()
+    gamma = torch.randn(D, device="cuda") * 0.5 + 1.0
+    mask = (torch.rand(N, device="cuda") > 0.2).to(torch.uint8)
+    xd = x.double()
+    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    stats = torch.cat([mean, rstd], 1).float().contiguous()
+    ntile = (N + 127) // 128
+    partial = torch.zeros(ntile, 2, D, device="cuda")
+    dx, dx2 = torch.empty(N, D, device="cuda", dtype=torch.bfloat16), torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
+    e = ops.epilogue(res=res, ln_bwd=(x, stats, gamma, partial, dx2, (0.5, mask, None)))
+    ops.gemm(L.GEMM_NN, dz, W, dx, N, D, K, e)
+    g = dz.double() @ W.double()
+    xh = (xd - mean) * rstd
+    gg = g * gamma.double()
+    ref = rstd * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)) + res.double()
+    assert rel_err(dx, ref) < 1e-2
+    assert rel_err(dx2, 0.5 * ref * mask.bool()[:, None]) < 1e-2
+    assert rel_err(partial[:, 0].sum(0), (g * xh).sum(0)) < 2e-3 and rel_err(partial[:, 1].sum(0), g.sum(0)) < 2e-3
+    # the second output with dropout draws the mask of smx_dropout(seed) on the (N, 256) index space
+    seed = 0x1234567
+    e = ops.epilogue(res=res, ln_bwd=(x, stats, gamma, partial, dx2, (1.0, None, (0.25, seed))))
+    ops.gemm(L.GEMM_NN, dz, W, dx, N, D, K, e)
+    keep = ops.dropout(torch.ones(N, D, device="cuda"), 0.25, seed) != 0
+    assert torch.equal(dx2 != 0, keep & (dx2 != 0)) and ((dx2 != 0) | ~keep | (dx.float().abs() < 1e-3)).all()
+    assert rel_err(dx2, torch.where(keep, ref / 0.75, torch.zeros_like(ref))) < 1e-2
+
+
+@pytest.mark.parametrize("N,K,act", [(4096, 1024, 0), (33000 + 77, 512, 2), (200, 256, 0)])
+def test_gemm_epilogue_layernorm_forward(N, K, act):
+    """NT GEMM + bias + residual whose epilogue appends y = act(LN(C)) and the row statistics."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(N + 1)
+    D = 256
+    a = torch.randn(N, K, device="cuda").bfloat16()
+    W = (torch.randn(D, K, device="cuda") * 0.05).bfloat16()
+    b = torch.randn(D, device="cuda")
+    res = torch.randn(N, D, device="cuda").bfloat16()
+    gamma, beta = torch.randn(D, device="cuda") * 0.5 + 1.0, torch.randn(D, device="cuda") * 0.1
+    c = torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
+    y = torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
+    stats = torch.empty(N, 2, device="cuda")
+    ops.gemm(L.GEMM_NT, a, W, c, N, D, K, ops.epilogue(bias=b, res=res, alpha=0.5, ln_fwd=(gamma, beta, y, stats, 1e-5, act)))
+    cref = res.double() + 0.5 * (a.double() @ W.double().t() + b.double())
+    mean, var = cref.mean(1, keepdim=True), cref.var(1, unbiased=False, keepdim=True)
+    yref = (cref - mean) * (var + 1e-5).rsqrt() * gamma.double() + beta.double()
+    if act == 2:
+        yref = yref * torch.sigmoid(yref)
+    assert rel_err(c, cref) < 1e-2 and rel_err(y, yref) < 1e-2
+    assert rel_err(stats[:, 0], mean[:, 0]) < 1e-3 and rel_err(stats[:, 1], (var + 1e-5).rsqrt()[:, 0]) < 1e-3
