@@ -244,15 +244,30 @@ def block(x, run, params, on_bwd_done=None):
 # ----------------------------------------------------------------------------------------------------
 # Linear (+bias +act +mask +residual +side input) forward / backward on 2-D row views
 # ----------------------------------------------------------------------------------------------------
+def ln_next_ok(x, M, ln_next):
+    """Can the LayerNorm that follows a Linear (its output: N x M) ride in that GEMM's epilogue (SMX_EPI_LN_FWD)?"""
+    return (_LN_FUSE and ln_next is not None and x.dtype == torch.bfloat16 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and
+            L.lib().smx_gemm_ln_fused_ok(L.BF16, x.shape[0], M, x.shape[1]) == 1)
+
+
 def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, c0=None, c0_mode=L.C0_NONE,
-               c0_div=0, save_z=False, out=None, out_f32=False, drop=None, c0_post=False):
+               c0_div=0, save_z=False, out=None, out_f32=False, drop=None, c0_post=False, ln_next=None, ln_post=None):
+    """ln_next = (gamma, beta, eps, act, want_stats): the LayerNorm that follows this Linear runs in the GEMM epilogue
+    (check ln_next_ok first); ln_post (a list) receives (LN output, stats | None)."""
     N, K = x.shape
     M = W.shape[0]
     if out is None:
         out = torch.empty((N, M), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
+    lnf = None
+    if ln_next is not None:
+        g, b, eps, lact, want_stats = ln_next
+        hy = torch.empty((N, M), dtype=x.dtype, device=x.device)
+        st = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
+        lnf = (g.detach(), b.detach(), hy, st, eps, lact)
+        ln_post.append((hy, st))
     e = ops.epilogue(bias=bias, c0=c0, c0_mode=c0_mode, c0_div=c0_div, act=act, z=z, row_mask=mask, res=res,
-                     alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post)
+                     alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post, ln_fwd=lnf)
     ops.gemm(L.GEMM_NT, x, W, out, N, M, K, e)
     return out, z
 
@@ -452,7 +467,9 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
     output (Conformer `x + skip`, Conformer.py:530) -- its gradient is returned by bwd as a second value."""
     mode, act, l = cfg["mode"], cfg["act"], cfg["local_proj_out_dim"]
 
-    def run(x3, need_bwd, res=None):
+    def run(x3, need_bwd, res=None, ln_next=None):
+        """ln_next = (gamma, beta, eps) of the LayerNorm that follows the cell output: run in the merge GEMM's epilogue where
+        possible; a third value (LN(y), stats) | None is then returned."""
         dtype = x3.dtype
         x = ops.rows2d(x3)
         N = x.shape[0]
@@ -541,7 +558,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 ops.bcast_rows(dsbar, inv, ds, B, T)
                 dx = mlp_bwd(ds, P["summary_proj"], act, sv_s, dtype)
                 return dx.view(B, T, -1)
-            return y3, (bwd_lite if need_bwd else None)
+            return (y3, (bwd_lite if need_bwd else None), None) if ln_next is not None else (y3, (bwd_lite if need_bwd else None))
 
         # ---- merge: y = res + act(local W_l^T + sbar W_s^T + b) -------------------------------------
         mg = P["summary_local_merging"][0]
@@ -549,6 +566,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         lw = local.shape[1]
         Wl, Ws = Wm[:, :lw], Wm[:, lw:]
         cat = s1 = s2 = None
+        post = []
         if p_drop > 0.0:
             # training: dropout acts on cat[local, repeat(sbar)] per FRAME (summary_mixing.py:237-239,282-284), which
             # breaks the per-utterance factorisation -> materialise the dropped concatenation once and run K = l + s
@@ -560,19 +578,22 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             else:
                 ops.dropout(sbar, p_drop, s2, out=cat[:, lw:])
             sbar_t = None
-            y, zm = linear_fwd(cat, Wm, mg["b"], act, None, res=res, save_z=need_bwd)
+            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(cat, Wm.shape[0], ln_next)) else None
+            y, zm = linear_fwd(cat, Wm, mg["b"], act, None, res=res, save_z=need_bwd, ln_next=lnn, ln_post=post)
         elif pool_kind == "mean":
             sbar_t = ops.cast(sbar, dtype)                                         # (B, sdim) in compute dtype
             c0, _ = linear_fwd(sbar_t, Ws, None, out_f32=True)                     # (B, s_out) fp32
+            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(local, Wl.shape[0], ln_next)) else None
             y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_GROUP, c0_div=T,
-                               save_z=need_bwd)
+                               save_z=need_bwd, ln_next=lnn, ln_post=post)
         else:
             sbar_t = sbar
             c0, _ = linear_fwd(sbar, Ws, None, out_f32=True)                       # (N, s_out) fp32
             y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_ROW, save_z=need_bwd)
         y3 = y.view(B, T, -1)
+        post = post[0] if post else None
         if not need_bwd:
-            return y3, None
+            return (y3, None, post) if ln_next is not None else (y3, None)
 
         def bwd(dy3, ln=None, ln_res=None, ln_second=None):
             """ln / ln_res / ln_second (only when bwd.can_fuse_ln): the LayerNorm whose output is this cell's input runs its
@@ -684,17 +705,21 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 dx = mlp_bwd(ds_out, P["summary_proj"], act, sv_s, dtype, res_grad=dx)
             return dx.view(B, T, -1)
         bwd.can_fuse_ln = (mode == "SummaryMixing-fast" and len(P["global_proj"]) == 1 and P["global_proj"][0]["kind"] == "linear")
-        return y3, bwd
+        return (y3, bwd, post) if ln_next is not None else (y3, bwd)
     return run
 
 
 # ----------------------------------------------------------------------------------------------------
 # LayerNorm block, FFN module, Conformer conv module (2-D row views in, closures out)
 # ----------------------------------------------------------------------------------------------------
-def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None):
+def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None, pre=None):
     """y = act(LayerNorm(x)); bwd(dy, res) = res + d/dx.  w/b are flat (D) views; wp/bp name the owning parameters
-    when those are multi-dimensional (the (F', C) affine of the conv front-end)."""
-    y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act)
+    when those are multi-dimensional (the (F', C) affine of the conv front-end).
+    pre = (y, stats): the GEMM that produced x already ran this LayerNorm in its epilogue (linear_fwd(ln_next=...))."""
+    if pre is not None:
+        y, stats = pre
+    else:
+        y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act)
 
     def bwd(dy, res=None, out=None, second=None):
         """second = (alpha, mask, drop): also return alpha * D(dx) * mask, what the NEXT backward block applies first to
@@ -734,17 +759,23 @@ def dwconv_bwd_deferred(dy, p_, wd, bd, gwd, gbd, B, T, D, k, glu, pad_mode, chu
     return dp, dg
 
 
-def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
+def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln_next=None):
     """y = x + alpha * D2(W2 D1(act(W1 LN(x) + b1)) + b2)   (Conformer.py:458-472,507,536; D = dropout, p = 0 in eval).
-    With p == 0 the second Linear's epilogue carries the residual and alpha (no extra pass)."""
-    h, ln_b = ln_fwd(x, P["ln_w"], P["ln_b"], 1e-5, need_bwd)
+    With p == 0 the second Linear's epilogue carries the residual and alpha (no extra pass).
+    pre_ln = (LN(x), stats) when the producer of x already ran this module's LayerNorm in its epilogue; ln_next = (gamma,
+    beta, eps) of the LayerNorm that follows the module: it runs in the second Linear's epilogue where possible, and a
+    third value (LN(y), stats) | None is returned."""
+    h, ln_b = ln_fwd(x, P["ln_w"], P["ln_b"], 1e-5, need_bwd, pre=pre_ln)
     W1, W2 = wcast(P["W1"], dtype), wcast(P["W2"], dtype)
     d1 = (p, ops.new_dropout_seed()) if p > 0.0 else None       # both dropouts are fused into the GEMM epilogues
     d2 = (p, ops.new_dropout_seed()) if p > 0.0 else None
     a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1)
-    y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2)
+    post = []
+    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next)) else None
+    y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2, ln_next=lnn, ln_post=post)
+    post = post[0] if post else None
     if not need_bwd:
-        return y, None
+        return (y, None, post) if ln_next is not None else (y, None)
 
     def bwd(dy, dz_in=None, second=None):
         """dz_in: alpha * D2(dy) already computed by the producer of dy (see `pre`); second: forwarded to the module's own
@@ -763,14 +794,17 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0):
         dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True)
         return ln_b(dh, res=dy, second=second)
     bwd.pre = (alpha, None, d2)          # what this block does first to its incoming gradient: alpha * D2(dy)
-    return y, bwd
+    return (y, bwd, post) if ln_next is not None else (y, bwd)
 
-def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True, p=0.0):
-    """y = [x +] mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534)."""
+def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True, p=0.0, pre_ln=None, ln_next=None):
+    """y = [x +] mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534).
+    pre_ln / ln_next: as in ffn_module_fwd (the module's first LayerNorm done by the producer of x; the LayerNorm that
+    follows the module done in the out-projection's epilogue)."""
     d = x.shape[1]
     if SP.enabled():
-        return _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual, p)
-    h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd)
+        r = _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual, p)
+        return r + (None,) if ln_next is not None else r
+    h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd, pre=pre_ln)
     Wp = wcast(P["Wp"], dtype).view(2 * d, d)                    # Conv1d(d,2d,1) weight viewed as a Linear
     p_, _ = linear_fwd(h, Wp, P["bp"])
     k = P["wd"].shape[-1]
@@ -779,9 +813,12 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
     a, ln2_b = ln_fwd(c, P["ln2_w"], P["ln2_b"], 1e-5, need_bwd, act)      # LN + activation fused
     Wo = wcast(P["Wo"], dtype)
     dr = (p, ops.new_dropout_seed()) if p > 0.0 else None   # Linear -> Dropout -> * mask (+ x): one epilogue
-    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None, drop=dr)
+    post = []
+    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, Wo.shape[0], ln_next)) else None
+    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None, drop=dr, ln_next=lnn, ln_post=post)
+    post = post[0] if post else None
     if not need_bwd:
-        return y, None
+        return (y, None, post) if ln_next is not None else (y, None)
 
     def bwd(dy, dz_in=None, second=None):
         if dz_in is not None:
@@ -800,7 +837,7 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
         return ln1_b(dh, res=dy if residual else None, second=second)
     # what this block does first to its incoming gradient: D(dy) * mask (nothing to precompute without mask and dropout)
     bwd.pre = (1.0, mask, dr) if (mask is not None or dr is not None) else None
-    return y, bwd
+    return (y, bwd, post) if ln_next is not None else (y, bwd)
 
 
 def _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual, p):

@@ -120,13 +120,16 @@ class ConformerEncoderLayer(nn.Module):
         def run(x3, need):
             dtype = x3.dtype
             x = ops.rows2d(x3)
-            y1, b1 = F.ffn_module_fwd(x, P1, d_act, need, dtype, p=pd)                 # :507
-            h, bn1 = F.ln_fwd(y1, n1.weight, n1.bias, n1.eps, need)                    # :510
-            y2_3, bcell = cell(h.view(B, T, -1), need, res=y1)                        # :512-530 (skip fused)
+            # every LayerNorm that follows a Linear of width d_model = 256 runs in that GEMM's epilogue (`post` = its output and
+            # statistics, None when the shape does not qualify and the consumer runs the LayerNorm kernel itself)
+            y1, b1, post1 = F.ffn_module_fwd(x, P1, d_act, need, dtype, p=pd, ln_next=(n1.weight, n1.bias, n1.eps))   # :507
+            h, bn1 = F.ln_fwd(y1, n1.weight, n1.bias, n1.eps, need, pre=post1)         # :510
+            y2_3, bcell, post2 = cell(h.view(B, T, -1), need, res=y1, ln_next=(Pc["ln1_w"], Pc["ln1_b"], 1e-5))   # :512-530
             y2 = ops.rows2d(y2_3)
-            y3, bconv = F.conv_module_fwd(y2, Pc, d_act, m8, B, T, need, dtype, chunk, p=pd)  # :532-534
-            y4, bf2 = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd)
-            y5, bn2 = F.ln_fwd(y4, n2.weight, n2.bias, n2.eps, need)                   # :536
+            y3, bconv, post3 = F.conv_module_fwd(y2, Pc, d_act, m8, B, T, need, dtype, chunk, p=pd, pre_ln=post2,
+                                                 ln_next=(P2["ln_w"], P2["ln_b"], 1e-5))                          # :532-534
+            y4, bf2, post4 = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd, pre_ln=post3, ln_next=(n2.weight, n2.bias, n2.eps))
+            y5, bn2 = F.ln_fwd(y4, n2.weight, n2.bias, n2.eps, need, pre=post4)        # :536
             if not need:
                 return y5.view(B, T, -1), None
 
