@@ -57,7 +57,9 @@ typedef struct smx_epilogue {
   const uint8_t* row_mask;                               /* [N] 1 = valid frame, or NULL               */
   const void* res;     int64_t ldr;
   float alpha;         int32_t flags;                     /* SMX_EPI_C0_POST: add C0 after dropout/mask/alpha      */
-  float drop_p;        int32_t drop_pad;                  /* fused inverted dropout (0 = off), applied after act()  */
+  float drop_p;        int32_t drop_cols;                 /* fused inverted dropout (0 = off), applied after act();
+                                                           * drop_cols > 0: only the first drop_cols output columns,
+                                                           * masks indexed n*drop_cols + m (0: all M, n*M + m)        */
   uint64_t drop_seed;                                     /* counter-based mask, same indexing as smx_dropout       */
   float* colsum;                                          /* [M] fp32 or NULL: colsum[m] += sum_n C[n,m] (fixed order) */
   void* workspace;                                        /* smx_gemm_colsum_workspace(N, M) bytes when colsum is set  */

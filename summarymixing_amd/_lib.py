@@ -45,7 +45,7 @@ class Epilogue(ctypes.Structure):
                 ("row_mask", c_vp),
                 ("res", c_vp), ("ldr", c_i64),
                 ("alpha", c_f), ("flags", ctypes.c_int32),
-                ("drop_p", c_f), ("drop_pad", ctypes.c_int32), ("drop_seed", ctypes.c_uint64),
+                ("drop_p", c_f), ("drop_cols", ctypes.c_int32), ("drop_seed", ctypes.c_uint64),
                 ("colsum", c_vp), ("workspace", c_vp),
                 ("ln_x", c_vp), ("ln_ldx", c_i64), ("ln_stats", c_vp), ("ln_gamma", c_vp), ("ln_partial", c_vp),
                 ("ln_dx2", c_vp), ("ln_lddx2", c_i64), ("ln_mask2", c_vp), ("ln_alpha2", c_f), ("ln_drop_p2", c_f),

@@ -359,8 +359,8 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
               default: break;
             }
             const int m = m0 + wm * WM + j * 32 + g * 8 + hi * 4;
-            if (dthresh) {
-              dropout_apply<4>(v, dseed, (uint64_t)n * p.M + m, dthresh, dscale);
+            if (dthresh && m < p.drop_cols) {
+              dropout_apply<4>(v, dseed, (uint64_t)n * p.drop_cols + m, dthresh, dscale);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] *= mk[i];
@@ -861,6 +861,8 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   p.epoch = g_step_counter;
   p.acolsum = acolsum;
   p.dthresh = (unsigned)((double)p.e.drop_p * 4294967296.0);
+  SMX_REQUIRE(p.e.drop_cols >= 0 && p.e.drop_cols <= M && p.e.drop_cols % 8 == 0, "smx_gemm: drop_cols must be a multiple of 8 in [0, M]");
+  p.drop_cols = p.e.drop_cols > 0 ? p.e.drop_cols : M;
   p.dscale = 1.f / (1.f - p.e.drop_p);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SMX_BF16) return launch_dtype<bf16_t>(layout, p, vec, s);

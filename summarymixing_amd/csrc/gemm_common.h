@@ -24,6 +24,7 @@ struct GemmParams {
   float* acolsum;                   // TN only: [splits][batch][N] partial column sums of the A operand (bias gradient)
   const uint64_t* epoch;            // device step counter mixed into the dropout seed (or null)
   unsigned dthresh; float dscale;   // fused dropout: drop if hash16 < dthresh>>16, survivors * dscale
+  int drop_cols;                    // ... on output columns m < drop_cols, mask index n * drop_cols + m (= M: all columns)
   long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
   int nt;       // non-temporal store hints: 1 = saved pre-activation Z, 2 = the output C
   int epi_simple;  // no element-wise side input, no column sums: the SIMPLE instantiation of epilogue_phase
@@ -473,8 +474,8 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
           default: break;
         }
       }
-      if (dthresh) {                                     // fused inverted dropout, mask = f(seed, n * M + m)
-        dropout_apply<CW>(v, dseed, (uint64_t)n * p.M + m, dthresh, dscale);   // (m and M are multiples of CW here)
+      if (dthresh && m < p.drop_cols) {                  // fused inverted dropout, mask = f(seed, n * drop_cols + m)
+        dropout_apply<CW>(v, dseed, (uint64_t)n * p.drop_cols + m, dthresh, dscale);   // (m and drop_cols are multiples of CW here)
       }
       if (has_mk) {
         const float mk = mkrow[r];
@@ -520,7 +521,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
           if (Zb) Zb[(long)n * e.ldz + m + q] = from_f32<T>(v);
           v = act_fwd(e.act, v);
         }
-        if (dthresh) v = dropout_keep(dseed, (uint64_t)n * p.M + m + q, dthresh) ? v * dscale : 0.f;
+        if (dthresh && m + q < p.drop_cols) v = dropout_keep(dseed, (uint64_t)n * p.drop_cols + m + q, dthresh) ? v * dscale : 0.f;
         v *= mkv;
         if (Sb && !ag) v += to_f32(Sb[(long)n * lds_ + m + q]);
         if (c0p && c0post) v += c0p[q];

@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const smx_reduce_job* 
   }
   const smx_reduce_job j = jobs[lo];
   const long g = (long)((int)blockIdx.x - starts[lo]) * 256 + threadIdx.x;
-  const int pshift = j.nsrc >= 16 ? 3 : 0, P = 1 << pshift;
+  // P lanes per element group: 8 for many sources, 4 for a handful (the grouped wgrad writes ~11 slabs per weight: one
+  // lane walking them is three dependent rounds of four loads, four lanes have all their loads in flight at once)
+  const int pshift = j.nsrc >= 16 ? 3 : (j.nsrc >= 6 ? 2 : 0), P = 1 << pshift;
   const long sld = j.src_ld > 0 ? j.src_ld : j.cols;       // source row stride (elements)
   const long i = g >> pshift;
   const int part = (int)(g & (P - 1));
@@ -50,11 +52,13 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const smx_reduce_job* 
     }
     float sx = (a0.x + a1.x) + (a2.x + a3.x), sy = (a0.y + a1.y) + (a2.y + a3.y);
     float sz = (a0.z + a1.z) + (a2.z + a3.z), sw = (a0.w + a1.w) + (a2.w + a3.w);
-    if (P == 8) {
+    if (P > 1) {
 #pragma unroll
       for (int off = 1; off < 8; off <<= 1) {
-        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64);
-        sz += __shfl_xor(sz, off, 64); sw += __shfl_xor(sw, off, 64);
+        if (off < P) {
+          sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64);
+          sz += __shfl_xor(sz, off, 64); sw += __shfl_xor(sw, off, 64);
+        }
       }
     }
     if (ok && part == 0) {
@@ -77,9 +81,10 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const smx_reduce_job* 
       for (; s < j.nsrc; s += P) a0 += sp[(long)s * j.src_stride];
     }
     float a = (a0 + a1) + (a2 + a3);
-    if (P == 8) {
+    if (P > 1) {
 #pragma unroll
-      for (int off = 1; off < 8; off <<= 1) a += __shfl_xor(a, off, 64);
+      for (int off = 1; off < 8; off <<= 1)
+        if (off < P) a += __shfl_xor(a, off, 64);
     }
     if (ok && part == 0) j.dst[(long)r * j.ldd + c] += j.alpha * a;
   }
@@ -92,7 +97,7 @@ using namespace smx;
 extern "C" int smx_reduce_job_blocks(const smx_reduce_job* job_host) {
   if (!job_host || job_host->rows <= 0 || job_host->cols <= 0 || job_host->nsrc <= 0) return 0;
   const long groups = job_host->vec ? (long)job_host->rows * (job_host->cols / 4) : (long)job_host->rows * job_host->cols;
-  const long threads = groups * (job_host->nsrc >= 16 ? 8 : 1);
+  const long threads = groups * (job_host->nsrc >= 16 ? 8 : (job_host->nsrc >= 6 ? 4 : 1));
   return (int)((threads + 255) / 256);
 }
 

@@ -251,7 +251,8 @@ def ln_next_ok(x, M, ln_next):
 
 
 def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, c0=None, c0_mode=L.C0_NONE,
-               c0_div=0, save_z=False, out=None, out_f32=False, drop=None, c0_post=False, ln_next=None, ln_post=None):
+               c0_div=0, save_z=False, out=None, out_f32=False, drop=None, c0_post=False, ln_next=None, ln_post=None,
+               drop_cols=0):
     """ln_next = (gamma, beta, eps, act, want_stats): the LayerNorm that follows this Linear runs in the GEMM epilogue
     (check ln_next_ok first); ln_post (a list) receives (LN output, stats | None)."""
     N, K = x.shape
@@ -267,7 +268,8 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
         lnf = (g.detach(), b.detach(), hy, st, eps, lact)
         ln_post.append((hy, st))
     e = ops.epilogue(bias=bias, c0=c0, c0_mode=c0_mode, c0_div=c0_div, act=act, z=z, row_mask=mask, res=res,
-                     alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post, ln_fwd=lnf)
+                     alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post, ln_fwd=lnf,
+                     drop_cols=drop_cols)
     ops.gemm(L.GEMM_NT, x, W, out, N, M, K, e)
     return out, z
 
@@ -343,7 +345,7 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
 # ----------------------------------------------------------------------------------------------------
 # VanillaNN: [Linear | ParallelLinear -> act] x blocks ; mask applied in the last block's epilogue
 # ----------------------------------------------------------------------------------------------------
-def mlp_fwd(x, layers, act, mask, need_bwd, dtype, last_res=None, last_drop=None):
+def mlp_fwd(x, layers, act, mask, need_bwd, dtype, last_res=None, last_drop=None, last_out=None, last_drop_cols=0):
     """layers: list of dicts {kind: 'linear'|'parallel', W, b, H}.  x (N, F).  Returns (y, saved).
     last_res / last_drop: the last (Linear) layer's epilogue also applies dropout and adds a residual,
     y = last_res + D(act(z)) (hand the same last_drop to mlp_bwd)."""
@@ -355,7 +357,8 @@ def mlp_fwd(x, layers, act, mask, need_bwd, dtype, last_res=None, last_drop=None
         if ly["kind"] == "linear":
             Wc = wcast(ly["W"], dtype)
             y, z = linear_fwd(x, Wc, ly["b"], act, mk, save_z=need_bwd, res=last_res if last else None,
-                              drop=last_drop if last else None)
+                              drop=last_drop if last else None, out=last_out if last else None,
+                              drop_cols=last_drop_cols if last else 0)
         else:
             Wc = wcast(ly["W"], dtype)                     # (H, f, h)
             H, f, h = Wc.shape
@@ -505,8 +508,20 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             Wn = ops.cast((w / w.sum(dim=1, keepdim=True)).contiguous(), dtype)   # mask prep (T,T): plumbing
 
         # ---- projections -------------------------------------------------------------------------
+        cat = s1 = s2 = None
+        cat_has_local = False
         if mode == "SummaryMixing-fast":
-            g, sv_g = mlp_fwd(x, P["global_proj"], act, mask, need_bwd, dtype)     # (N, 2l)
+            gp = P["global_proj"]
+            if p_drop > 0.0 and len(gp) == 1 and gp[0]["kind"] == "linear" and l % 8 == 0:
+                # training: the projection writes straight into the merge input cat = [D(local) | s]: the dropout of the
+                # local half (summary_mixing.py:282-284) rides in its epilogue (columns < l only, mask indexed (n, l)); the
+                # summary half is pooled from there and then overwritten by the dropped broadcast of its mean
+                s1 = ops.new_dropout_seed()
+                cat = torch.empty((N, 2 * l), dtype=dtype, device=dev)
+                g, sv_g = mlp_fwd(x, gp, act, mask, need_bwd, dtype, last_drop=(p_drop, s1), last_out=cat, last_drop_cols=l)
+                cat_has_local = True
+            else:
+                g, sv_g = mlp_fwd(x, gp, act, mask, need_bwd, dtype)               # (N, 2l)
             local, s = g[:, :l], g[:, l:]
             sv_l = sv_s = None
         elif mode == "SummaryMixing-lite":
@@ -565,14 +580,16 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         Wm = wcast(mg["W"], dtype)                                              # (s_out, l + sdim)
         lw = local.shape[1]
         Wl, Ws = Wm[:, :lw], Wm[:, lw:]
-        cat = s1 = s2 = None
         post = []
         if p_drop > 0.0:
             # training: dropout acts on cat[local, repeat(sbar)] per FRAME (summary_mixing.py:237-239,282-284), which
             # breaks the per-utterance factorisation -> materialise the dropped concatenation once and run K = l + s
-            s1, s2 = ops.new_dropout_seed(), ops.new_dropout_seed()
-            cat = torch.empty((N, lw + sdim), dtype=dtype, device=dev)
-            ops.dropout(local, p_drop, s1, out=cat[:, :lw])
+            if cat_has_local:
+                s2 = ops.new_dropout_seed()
+            else:
+                s1, s2 = ops.new_dropout_seed(), ops.new_dropout_seed()
+                cat = torch.empty((N, lw + sdim), dtype=dtype, device=dev)
+                ops.dropout(local, p_drop, s1, out=cat[:, :lw])
             if pool_kind == "mean":
                 ops.bcast_rows(sbar, None, cat[:, lw:], B, T, drop=(p_drop, s2))   # repeat + dropout in one pass
             else:

@@ -89,7 +89,7 @@ def rows2d(x):
 
 def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, out_mode=L.OUT_T, z=None,
              row_mask=None, res=None, alpha=1.0, bias_batch_stride=0, drop=None, c0_post=False, act_grad_z=None,
-             colsum=None, ln_bwd=None, ln_fwd=None):
+             colsum=None, ln_bwd=None, ln_fwd=None, drop_cols=0):
     """Build an smx_epilogue.  act_grad_z: the saved pre-activation of the UPSTREAM layer (SMX_EPI_ACT_GRAD: the GEMM
     then emits alpha * D(acc * act'(z)) * mask, i.e. the upstream dZ); colsum: fp32 [M] accumulator of the output's
     column sums (the upstream bias gradient), workspace attached by gemm()."""
@@ -120,6 +120,7 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         e.colsum = colsum.data_ptr()
     if drop is not None and drop[0] > 0.0:
         e.drop_p, e.drop_seed = drop
+        e.drop_cols = drop_cols          # > 0: dropout on the first drop_cols output columns only (mask index n*drop_cols + m)
     if ln_bwd is not None:
         # (x, stats, gamma, partial, dx2 | None, second | None): SMX_EPI_LN_BWD - the GEMM output is the gradient of LN(x)
         x, stats, gamma, partial, dx2, second = ln_bwd
