@@ -82,7 +82,10 @@ typedef struct smx_epilogue {
  *   C[n,:] = rstd * (g*gamma - mean_m(g*gamma) - xhat * mean_m(g*gamma*xhat)) + res[n,:]     (res = residual gradient)
  * and per-tile partial rows dgamma = sum_n g * xhat, dbeta = sum_n g in ln_partial (fold with smx_reduce_jobs: two jobs,
  * src = ln_partial (+ M), src_stride 2*M, nsrc = ceil(N/128), rows 1, cols M).  Needs the whole LayerNorm row in one
- * tile: dtype bf16, M == 256, aligned operands, N >= 128 (smx_gemm_ln_fused_ok); no bias / act / dropout / C0 / Z.
+ * tile: dtype bf16, M == 256, aligned operands, N >= 128 (smx_gemm_ln_fused_ok); no bias / dropout / C0.  With
+ * lnf_act != 0 the LayerNorm had a fused activation (Y = act(LN(x)), lnf_beta required): g is first multiplied by
+ * act'(LN(x)).  With z / act set (and ln_dx2) the second output is alpha2 * D(dX * act'(z)) * mask2 (the consumer's own
+ * activation backward).
  * SMX_EPI_LN_FWD (same shape conditions) appends a LayerNorm FORWARD of the finished output rows: the ordinary epilogue
  * writes C (bias, residual, dropout, mask ... as usual), then lnf_y = act(LN(C) * gamma + beta) and lnf_stats. */
 enum { SMX_EPI_C0_POST = 1, SMX_EPI_ACT_GRAD = 2, SMX_EPI_LN_BWD = 4, SMX_EPI_LN_FWD = 8 };

@@ -35,8 +35,8 @@ namespace smx {
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
-// LNF: 0 = ordinary epilogue; 1 = LayerNorm backward fused (SMX_EPI_LN_BWD), 2 = LayerNorm forward appended
-// (SMX_EPI_LN_FWD) - separate instantiations of the 128 x 256 bf16 kernel, so that their extra live registers never cost
+// LNF: 0 = ordinary epilogue; 1 = LayerNorm backward fused (SMX_EPI_LN_BWD; 3 = with its activation extensions),
+// 2 = LayerNorm forward appended (SMX_EPI_LN_FWD) - separate instantiations of the 128 x 256 bf16 kernel, so that their extra live registers never cost
 // the ordinary one anything.
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0>
 __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
@@ -384,11 +384,12 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   // LayerNorm fused into the epilogue (LNF; the tile holds whole rows: M == TILE_M == 256): gamma / beta are parked in
   // LDS behind the side vector (requested before the first store of the epilogue, read back without any vmcnt wait)
   float* lng = side + TILE_M + TILE_N;
-  float dgam[LNF == 1 ? 8 : 1], dbet[LNF == 1 ? 8 : 1];
+  constexpr bool LNB = LNF == 1 || LNF == 3;
+  float dgam[LNB ? 8 : 1], dbet[LNB ? 8 : 1];
   if constexpr (LNF != 0) {
-    lng[t] = (LNF == 1 ? e.ln_gamma : e.lnf_gamma)[t];
-    if constexpr (LNF == 2) lng[TILE_M + t] = e.lnf_beta[t];
-    if constexpr (LNF == 1) {
+    lng[t] = (LNB ? e.ln_gamma : e.lnf_gamma)[t];
+    if (LNF == 2 || (LNF == 3 && e.lnf_act != SMX_ACT_NONE)) lng[TILE_M + t] = e.lnf_beta[t];
+    if constexpr (LNB) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) dgam[q] = dbet[q] = 0.f;
     }
@@ -414,8 +415,8 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     }
     lds_barrier();
     if (ph < 2) SMX_STAMP(3 + 2 * ph);
-    if constexpr (LNF == 1) {                             // the LayerNorm backward replaces the ordinary epilogue
-      epilogue_phase_lnbwd<T>(p, smem, lng, n0 + row_in_tile, t, dgam, dbet);
+    if constexpr (LNB) {                                  // the LayerNorm backward replaces the ordinary epilogue
+      epilogue_phase_lnbwd<T, LNF == 3>(p, smem, lng, n0 + row_in_tile, t, dgam, dbet);
       continue;
     }
     if (sizeof(T) == 2 && osz == 2) {
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     if constexpr (LNF == 2) epilogue_phase_lnfwd<T>(p, smem, lng, n0 + row_in_tile, t);
     if (ph < 2) SMX_STAMP(4 + 2 * ph);
   }
-  if constexpr (LNF == 1) {
+  if constexpr (LNB) {
     {
       // dgamma / dbeta of the tile: the 8 row groups (threads t, t + 32, ...) are folded through LDS in a fixed order into
       // ONE partial row pair per tile
@@ -711,7 +712,9 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
       if (vec && p.M == 256 && p.N >= 128 && p.splits == 1 && p.batch == 1 && p.e.out_mode == SMX_OUT_T && !p.e.colsum) {
         p.tiles_n = (p.N + 127) / 128;
         p.tiles_m = 1;
-        if (p.e.flags & SMX_EPI_LN_BWD) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 1>), dim3(p.tiles_n), dim3(256), 0, s, p);
+        if ((p.e.flags & SMX_EPI_LN_BWD) && (p.e.lnf_act != SMX_ACT_NONE || p.e.z))
+          hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 3>), dim3(p.tiles_n), dim3(256), 0, s, p);
+        else if (p.e.flags & SMX_EPI_LN_BWD) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 1>), dim3(p.tiles_n), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 2>), dim3(p.tiles_n), dim3(256), 0, s, p);
         return check_launch("smx_gemm");
       }
@@ -829,8 +832,9 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
     SMX_REQUIRE(p.e.z && !p.e.res && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
                 "smx_gemm: SMX_EPI_ACT_GRAD needs z (input), no residual, batch == 1, splits == 1");
   if (p.e.flags & SMX_EPI_LN_BWD)
-    SMX_REQUIRE(p.e.ln_x && p.e.ln_stats && p.e.ln_gamma && p.e.ln_partial && !p.e.bias && !p.e.c0 && !p.e.z && !p.e.row_mask &&
-                p.e.act == SMX_ACT_NONE && p.e.drop_p == 0.f && p.e.alpha == 1.f && aligned16(p.e.ln_x) && p.e.ln_ldx % 8 == 0 &&
+    SMX_REQUIRE(p.e.ln_x && p.e.ln_stats && p.e.ln_gamma && p.e.ln_partial && !p.e.bias && !p.e.c0 && !p.e.row_mask &&
+                (p.e.z ? (p.e.ln_dx2 && aligned16(p.e.z) && p.e.ldz % 8 == 0) : p.e.act == SMX_ACT_NONE) &&
+                (p.e.lnf_act == SMX_ACT_NONE || p.e.lnf_beta) && p.e.drop_p == 0.f && p.e.alpha == 1.f && aligned16(p.e.ln_x) && p.e.ln_ldx % 8 == 0 &&
                 (!p.e.ln_dx2 || (aligned16(p.e.ln_dx2) && p.e.ln_lddx2 % 8 == 0)) && p.e.ln_drop_p2 >= 0.f && p.e.ln_drop_p2 < 1.f,
                 "smx_gemm: SMX_EPI_LN_BWD takes ln_x / ln_stats / ln_gamma / ln_partial (+ res, ln_dx2) and no other epilogue field");
   if (p.e.flags & SMX_EPI_LN_FWD)

@@ -563,8 +563,10 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 
 // SMX_EPI_LN_BWD: staged rows = g (gradient of the LayerNorm output).  dX = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
 // + res, optional second output alpha2 * D(dX) * mask2, dgamma / dbeta accumulated per thread (folded per tile by the caller).
-// (two items at a time: the side inputs of all four would not fit next to the 128 accumulator registers)
-template <typename T>
+// (two items at a time: the side inputs of all four would not fit next to the 128 accumulator registers; EXT = the
+// variants with a fused activation of the LayerNorm and / or an activation gradient in the second output - a separate
+// instantiation, they cost ~20 registers the plain one does not have)
+template <typename T, bool EXT>
 __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const char* smem, const float* lng, int nbase0, int t,
                                                      float (&dgam)[8], float (&dbet)[8]) {
   constexpr int STG_LD = 256 * 4 + 16, NIT = 2, RSTEP = 8, SW = 8 * (int)sizeof(T) / 4;
@@ -578,6 +580,8 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
     const float4 g4 = *reinterpret_cast<const float4*>(lng + c + 4 * q4);
     gam[4 * q4] = g4.x; gam[4 * q4 + 1] = g4.y; gam[4 * q4 + 2] = g4.z; gam[4 * q4 + 3] = g4.w;
   }
+  const int lact = EXT ? e.lnf_act : SMX_ACT_NONE;       // the LayerNorm was followed by a fused activation: g *= act'(LN(x))
+  const T* Z2 = EXT ? reinterpret_cast<const T*>(e.z) : nullptr;   // second output: dX2 = alpha2 * D(dX * act'(z)) * mask2
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
   const int nbase = nbase0 + half * 16;
@@ -625,6 +629,18 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
     unpack_words<T, 8>(xw[k], xh);
     unpack_words<T, 8>(rw[k], rf);
     float s1 = 0.f, s2 = 0.f;
+    if (EXT && lact != SMX_ACT_NONE) {                   // (uniform; beta sits behind gamma in LDS)
+      float ag[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ag[q] = (xh[q] - st[k].x) * st[k].y * gam[q] + lng[256 + c + q];
+      switch (lact) {
+        case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, 8>(v, ag); break;
+        case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, 8>(v, ag); break;
+        case SMX_ACT_LEAKY_RELU: act_grad_mul_n<SMX_ACT_LEAKY_RELU, 8>(v, ag); break;
+        case SMX_ACT_RELU: act_grad_mul_n<SMX_ACT_RELU, 8>(v, ag); break;
+        default: break;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       xh[q] = (xh[q] - st[k].x) * st[k].y;
@@ -643,6 +659,19 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
     st_elems<T, 8>(reinterpret_cast<T*>(p.C) + (long)n * p.ldc + c, v);
     if (e.ln_dx2) {                                      // (uniform)
       const float mk = (e.ln_mask2 ? (e.ln_mask2[n] ? 1.f : 0.f) : 1.f) * e.ln_alpha2;
+      if (EXT && Z2) {                                   // (a load behind the dX store: one drain per item, second output only)
+        uint32_t zw[SW];
+        float zf[8];
+        ld_words<SW>(Z2 + (long)n * e.ldz + c, zw);
+        unpack_words<T, 8>(zw, zf);
+        switch (e.act) {
+          case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, 8>(v, zf); break;
+          case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, 8>(v, zf); break;
+          case SMX_ACT_LEAKY_RELU: act_grad_mul_n<SMX_ACT_LEAKY_RELU, 8>(v, zf); break;
+          case SMX_ACT_RELU: act_grad_mul_n<SMX_ACT_RELU, 8>(v, zf); break;
+          default: break;
+        }
+      }
       if (thresh2) dropout_apply<8>(v, seed2, (uint64_t)n * 256 + c, thresh2, scale2);
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] *= mk;

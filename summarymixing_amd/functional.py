@@ -283,7 +283,7 @@ def ln_fusable(ln_spec, N, K_out, dtype):
     if not (_LN_FUSE and _Deferred.enabled and ln_spec is not None and dtype == torch.bfloat16):
         return False
     x = ln_spec["x"]
-    return (ln_spec["act"] == L.ACT_NONE and x.shape[1] == K_out and x.shape[0] == N and gacc(ln_spec["gw_param"]) is not None
+    return (x.shape[1] == K_out and x.shape[0] == N and gacc(ln_spec["gw_param"]) is not None
             and L.lib().smx_gemm_ln_fused_ok(L.BF16, N, K_out, 64) == 1 and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0)
 
 
@@ -326,7 +326,8 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
             ntile = (N + 127) // 128
             ws = deferred_ws(gw_ln.data_ptr(), ntile * 2 * K * 4, dy.device)
             dx2 = torch.empty((N, K), dtype=dy.dtype, device=dy.device) if ln_second is not None else None
-            e = ops.epilogue(res=res_grad, ln_bwd=(ln["x"], ln["stats"], ln["w"].detach(), ws, dx2, ln_second))
+            lact = (ln["b"].detach(), ln["act"]) if ln["act"] != L.ACT_NONE else None
+            e = ops.epilogue(res=res_grad, ln_bwd=(ln["x"], ln["stats"], ln["w"].detach(), ws, dx2, ln_second, lact))
             ops.gemm(L.GEMM_NN, dz, W, dx, N, K, M, e)
             defer(ws.data_ptr(), gw_ln, 2 * K, ntile, 1, K)
             defer(ws.data_ptr() + 4 * K, gb_ln, 2 * K, ntile, 1, K)
@@ -612,10 +613,11 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         if not need_bwd:
             return (y3, None, post) if ln_next is not None else (y3, None)
 
-        def bwd(dy3, ln=None, ln_res=None, ln_second=None):
+        def bwd(dy3, ln=None, ln_res=None, ln_second=None, dz_in=None):
             """ln / ln_res / ln_second (only when bwd.can_fuse_ln): the LayerNorm whose output is this cell's input runs its
             backward in the epilogue of the cell's input dgrad (linear_bwd(ln=...)); then 2-D tensors come back: the
-            gradient w.r.t. that LayerNorm's input (+ ln_res), or the pair with the second output."""
+            gradient w.r.t. that LayerNorm's input (+ ln_res), or the pair with the second output.
+            dz_in: dy * act'(zm) already computed by the producer of dy (see `pre`)."""
             dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
             s_out = dy.shape[1]
             gWm, gbm = gacc(mg["W"]), gacc(mg["b"])
@@ -658,9 +660,14 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             if p_drop > 0.0:
                 # dgrad of the K = l + s merge as two GEMMs over the column halves of W: the dropout backward of each half
                 # (and the local half's act/mask backward) rides in the epilogue instead of separate passes
-                dzm = torch.empty((N, s_out), dtype=dtype, device=dev)
                 wb = gbm is not None and gWm is not None and (lw + sdim) % 4 == 0 and _WGRAD_BIAS
-                ops.act_mask_bwd(dy, zm, None, act, 1.0, dzm, None if wb else gbm)
+                if dz_in is not None:
+                    dzm = dz_in
+                    if not wb and gbm is not None:
+                        ops.act_mask_bwd(dzm, None, None, L.ACT_NONE, 1.0, None, gbm)
+                else:
+                    dzm = torch.empty((N, s_out), dtype=dtype, device=dev)
+                    ops.act_mask_bwd(dy, zm, None, act, 1.0, dzm, None if wb else gbm)
                 if gWm is not None:
                     _wgrad(dzm, cat, gWm, N, s_out, lw + sdim, gbm if wb else None)
                 if fuse_local:
@@ -682,8 +689,9 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 else:
                     _dense_pool_bwd(dsd, B, T, Wn, ds_out)
             elif pool_kind == "mean":
-                _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
-                                    True, None, dx_out=dlocal_out, up=up_local)
+                _, dzm = linear_bwd(dy if dz_in is None else dz_in, local, Wl, zm, act, None, 1.0,
+                                    gWm[:, :lw] if gWm is not None else None, gbm, True, None, dx_out=dlocal_out, up=up_local,
+                                    dz_ready=dz_in is not None)
                 # per-utterance sums of dZ (the gradient of the C0 side input) through the fixed-order pool kernel: the
                 # fused variant (smx_act_mask_bwd dgroup) adds with fp32 atomics, i.e. not bit-reproducibly
                 dc0, _ = ops.masked_mean(dzm, None, B, T, scale=False)
@@ -694,8 +702,9 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 ops.gemm(L.GEMM_NN, dc0_t, Ws, dsbar, B, sdim, s_out, ops.epilogue(out_mode=L.OUT_F32))
                 bcast_ds(dsbar)
             else:
-                _, dzm = linear_bwd(dy, local, Wl, zm, act, None, 1.0, gWm[:, :lw] if gWm is not None else None, gbm,
-                                    True, None, dx_out=dlocal_out, up=up_local)
+                _, dzm = linear_bwd(dy if dz_in is None else dz_in, local, Wl, zm, act, None, 1.0,
+                                    gWm[:, :lw] if gWm is not None else None, gbm, True, None, dx_out=dlocal_out, up=up_local,
+                                    dz_ready=dz_in is not None)
                 if gWm is not None:      # dW_s += dzm^T sbar
                     ops.wgrad(dzm, sbar_t, gWm[:, lw:], N, s_out, sdim)
                 dsb = torch.empty((N, sdim), dtype=dtype, device=dev)
@@ -722,6 +731,8 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 dx = mlp_bwd(ds_out, P["summary_proj"], act, sv_s, dtype, res_grad=dx)
             return dx.view(B, T, -1)
         bwd.can_fuse_ln = (mode == "SummaryMixing-fast" and len(P["global_proj"]) == 1 and P["global_proj"][0]["kind"] == "linear")
+        # what the cell does first to its incoming gradient: dy * act'(zm) (a producer that can, writes it as a second output)
+        bwd.pre = (1.0, None, None, zm, act) if (zm is not None and act != L.ACT_NONE) else None
         return (y3, bwd, post) if ln_next is not None else (y3, bwd)
     return run
 
@@ -755,7 +766,7 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None, pre=None):
             return dx
         return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act, dx_out=out, second=second)
     # what a dgrad GEMM needs to run this backward in its own epilogue (linear_bwd(ln=...))
-    bwd.spec = {"x": x, "w": w, "stats": stats, "act": act, "gw_param": wp if wp is not None else w,
+    bwd.spec = {"x": x, "w": w, "b": b, "stats": stats, "act": act, "gw_param": wp if wp is not None else w,
                 "gb_param": bp if bp is not None else b}
     return y, (bwd if need_bwd else None)
 
@@ -838,11 +849,13 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
         return (y, None, post) if ln_next is not None else (y, None)
 
     def bwd(dy, dz_in=None, second=None):
+        fuse2 = ln_fusable(ln2_b.spec, a.shape[0], d, dtype)     # LN2 (+ activation) backward in the out-projection's dgrad
+        kw = dict(ln=ln2_b.spec) if fuse2 else {}
         if dz_in is not None:
-            da, _ = linear_bwd(dz_in, a, Wo, None, L.ACT_NONE, None, 1.0, gacc(P["Wo"]), gacc(P["bo"]), dz_ready=True)
+            da, _ = linear_bwd(dz_in, a, Wo, None, L.ACT_NONE, None, 1.0, gacc(P["Wo"]), gacc(P["bo"]), dz_ready=True, **kw)
         else:
-            da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr)
-        dc = ln2_b(da)
+            da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr, **kw)
+        dc = da if fuse2 else ln2_b(da)
         gwd = gacc(P["wd"])
         dp, _ = dwconv_bwd_deferred(dc, p_, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
                                     gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
@@ -854,6 +867,7 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
         return ln1_b(dh, res=dy if residual else None, second=second)
     # what this block does first to its incoming gradient: D(dy) * mask (nothing to precompute without mask and dropout)
     bwd.pre = (1.0, mask, dr) if (mask is not None or dr is not None) else None
+    bwd.ln1_fused = ln_fusable(ln1_b.spec, h.shape[0], d, dtype)   # then `second` may carry (.., z, act) of the consumer
     return (y, bwd, post) if ln_next is not None else (y, bwd)
 
 

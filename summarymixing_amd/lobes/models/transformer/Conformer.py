@@ -139,16 +139,23 @@ class ConformerEncoderLayer(nn.Module):
                 # 1/2 * dropout, the conv module's dropout * padding mask) - no separate elementwise pass per module
                 pre_c = getattr(bconv, "pre", None)
                 d4, d4z = bn2(dy, second=bf2.pre)
+                # the cell's own first step, dy * act'(zm), as the second output of the conv module's fused LayerNorm backward
+                pre_cell = getattr(bcell, "pre", None) if getattr(bconv, "ln1_fused", False) else None
+                d3z = None
                 if pre_c is not None:
                     d3, d3z = bf2(d4, dz_in=d4z, second=pre_c)
-                    d2 = bconv(d3, dz_in=d3z)
                 else:
-                    d2 = bconv(bf2(d4, dz_in=d4z))
+                    d3 = bf2(d4, dz_in=d4z)
+                d2z = None
+                if pre_cell is not None:
+                    d2, d2z = bconv(d3, dz_in=d3z, second=pre_cell)
+                else:
+                    d2 = bconv(d3, dz_in=d3z)
                 if getattr(bcell, "can_fuse_ln", False) and F.ln_fusable(bn1.spec, d2.shape[0], d2.shape[1], dtype):
                     # norm1's backward (+ the skip gradient, + FFN1's 1/2 * dropout) in the epilogue of the cell's input dgrad
-                    d1, d1z = bcell(d2.view(B, T, -1), ln=bn1.spec, ln_res=d2, ln_second=b1.pre)
+                    d1, d1z = bcell(d2.view(B, T, -1), ln=bn1.spec, ln_res=d2, ln_second=b1.pre, dz_in=d2z)
                 else:
-                    dh = ops.rows2d(bcell(d2.view(B, T, -1)))
+                    dh = ops.rows2d(bcell(d2.view(B, T, -1), dz_in=d2z))
                     d1, d1z = bn1(dh, res=d2, second=b1.pre)                           # skip gradient fused
                 return b1(d1, dz_in=d1z).view(B, T, -1)
             return y5.view(B, T, -1), bwd

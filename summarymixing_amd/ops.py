@@ -123,12 +123,17 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         e.drop_cols = drop_cols          # > 0: dropout on the first drop_cols output columns only (mask index n*drop_cols + m)
     if ln_bwd is not None:
         # (x, stats, gamma, partial, dx2 | None, second | None): SMX_EPI_LN_BWD - the GEMM output is the gradient of LN(x)
-        x, stats, gamma, partial, dx2, second = ln_bwd
+        x, stats, gamma, partial, dx2, second = ln_bwd[:6]
+        if len(ln_bwd) > 6 and ln_bwd[6] is not None:      # (beta, act): the LayerNorm had a fused activation
+            e.lnf_beta, e.lnf_act = ln_bwd[6][0].data_ptr(), ln_bwd[6][1]
         e.ln_x, e.ln_ldx = x.data_ptr(), _mat(x)[1]
         e.ln_stats, e.ln_gamma, e.ln_partial = stats.data_ptr(), gamma.data_ptr(), partial.data_ptr()
         e.flags |= L.EPI_LN_BWD
         if dx2 is not None:
-            a2, m2, drop2 = second
+            a2, m2, drop2 = second[:3]
+            if len(second) > 3 and second[3] is not None:  # (z, act): dx2 = alpha * D(dx * act'(z)) * mask
+                assert z is None and act_grad_z is None
+                e.z, e.ldz, e.act = second[3].data_ptr(), _mat(second[3])[1], second[4]
             e.ln_dx2, e.ln_lddx2, e.ln_alpha2 = dx2.data_ptr(), _mat(dx2)[1], a2
             e.ln_mask2 = m2.data_ptr() if m2 is not None else None
             if drop2 is not None and drop2[0] > 0.0:

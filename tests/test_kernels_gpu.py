@@ -544,3 +544,35 @@ def test_gemm_epilogue_layernorm_forward(N, K, act):
         yref = yref * torch.sigmoid(yref)
     assert rel_err(c, cref) < 1e-2 and rel_err(y, yref) < 1e-2
     assert rel_err(stats[:, 0], mean[:, 0]) < 1e-3 and rel_err(stats[:, 1], (var + 1e-5).rsqrt()[:, 0]) < 1e-3
+
+
+def test_gemm_epilogue_layernorm_backward_with_activations():
+    """The extended instantiation: the LayerNorm had a fused activation (y = swish(LN(x)), conv module LN2) and the second
+    output carries the consumer's activation backward (dX2 = dX * swish'(z), the cell's merge)."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(11)
+    N, K, D = 3000, 256, 256
+    dz = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
+    W = (torch.randn(K, D, device="cuda") * 0.05).bfloat16()
+    x = torch.randn(N, D, device="cuda").bfloat16()
+    z2 = torch.randn(N, D, device="cuda").bfloat16()
+    gamma, beta = torch.randn(D, device="cuda") * 0.5 + 1.0, torch.randn(D, device="cuda") * 0.3
+    xd = x.double()
+    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    stats = torch.cat([mean, rstd], 1).float().contiguous()
+    partial = torch.zeros((N + 127) // 128, 2, D, device="cuda")
+    dx, dx2 = torch.empty(N, D, device="cuda", dtype=torch.bfloat16), torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
+    e = ops.epilogue(ln_bwd=(x, stats, gamma, partial, dx2, (1.0, None, None, z2, L.ACT_SWISH), (beta, L.ACT_SWISH)))
+    ops.gemm(L.GEMM_NN, dz, W, dx, N, D, K, e)
+
+    def dswish(v):
+        s = torch.sigmoid(v)
+        return s * (1 + v * (1 - s))
+    xh = (xd - mean) * rstd
+    g = (dz.double() @ W.double()) * dswish(xh * gamma.double() + beta.double())
+    gg = g * gamma.double()
+    ref = rstd * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True))
+    assert rel_err(dx, ref) < 1e-2
+    assert rel_err(dx2, ref * dswish(z2.double())) < 1.5e-2
+    assert rel_err(partial[:, 0].sum(0), (g * xh).sum(0)) < 2e-3 and rel_err(partial[:, 1].sum(0), g.sum(0)) < 2e-3
