@@ -451,7 +451,47 @@ def main():
     # workspaces), then every timed step is one graph launch.  The step count (AdamW bias correction) and the dropout
     # epoch live in a device counter, so replays still advance them (include/smx.h: smx_set_step_counter).
     run, graph_note = step, "eager"
-    if args.graph == "on" or (args.graph == "auto" and world == 1 and not force_dist and cfg["B"] * cfg["T"] < 40000):
+    dist_run = world > 1 or force_dist
+    want_graph = args.graph == "on" or (args.graph == "auto" and cfg["B"] * cfg["T"] < 40000)
+    if want_graph and train and dist_run:
+        # data parallel: two graphs with the collective between them - [zero_grad + forward + backward] | ONE all-reduce of
+        # the flat gradient buffer (eager, RCCL) | [clip + AdamW + shadow refresh].  The per-layer bucket hooks (overlap of
+        # the all-reduce with the backward) are given up in this mode: it is for per-GPU batches so small that the host
+        # launch path, not the GPU, bounds the step.
+        try:
+            opt.use_device_step_counter(True)
+            for layer in enc.transformer.encoder.layers:
+                layer._on_bwd_done = None
+
+            def fwd_bwd():
+                opt.zero_grad()
+                enc(src, wav_len).backward(r)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fwd_bwd()
+                opt.all_reduce_all()
+                opt.update_only()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_a):
+                fwd_bwd()
+            with torch.cuda.graph(g_b):
+                opt.update_only()
+
+            def run():
+                g_a.replay()
+                opt.all_reduce_all()
+                g_b.replay()
+            graph_note = "hipGraph replay x2 (forward+backward | one RCCL all-reduce of the flat gradients | update)"
+        except Exception as ex:                          # noqa: BLE001
+            if args.graph == "on":
+                raise
+            opt.use_device_step_counter(False)
+            torch.cuda.synchronize()
+            run, graph_note = step, f"eager (hipGraph capture failed: {type(ex).__name__})"
+    elif want_graph and not dist_run:
         try:
             if train:
                 opt.use_device_step_counter(True)

@@ -157,6 +157,19 @@ class FlatAdamW:
             ops.step_counter_add(self._dev_step, 1)
         self._apply_update(1.0 / self.world)
 
+    # ---- hipGraph under data parallelism: the collective stays OUTSIDE the graphs -------------------------------------
+    def all_reduce_all(self):
+        """ONE all-reduce of the whole flat gradient buffer, waited for on the current stream (used between the two
+        captured halves of a step: forward + backward | update)."""
+        if self._collective:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def update_only(self):
+        """The part of step() behind the collective (capturable: device step counter, clip, AdamW, shadows)."""
+        assert self._dev_step is not None, "call use_device_step_counter(True) before capturing"
+        ops.step_counter_add(self._dev_step, 1)
+        self._apply_update(1.0 / self.world)
+
     def _apply_update(self, gscale):
         """Global-norm clip + AdamW + bf16 shadow refresh: three HIP kernel launches, nothing visits the host."""
         clip = None

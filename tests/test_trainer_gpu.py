@@ -129,6 +129,49 @@ print("rank 0 OK")
 '''
 
 
+GRAPH_WORKER = COMMON + r'''
+# data parallel + hipGraph: [forward + backward] and [update] captured separately, ONE eager all-reduce between them
+torch.cuda.set_device(0)
+dtype = torch.bfloat16
+ref = model()
+ropt = FlatAdamW(ref, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+enc = model()
+opt = FlatAdamW(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
+assert opt._collective
+x, r = X.to(dtype), R.to(dtype)
+def fwd_bwd():
+    opt.zero_grad()
+    y, _ = enc(x, src_key_padding_mask=PAD)
+    y.backward(r)
+opt.use_device_step_counter(True)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    fwd_bwd(); opt.all_reduce_all(); opt.update_only()              # warm-up step 1 (allocates this stream's workspaces)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+with torch.cuda.graph(ga):
+    fwd_bwd()
+with torch.cuda.graph(gb):
+    opt.update_only()
+for _ in range(2):                                                   # steps 2 and 3 as graph replays
+    ga.replay(); opt.all_reduce_all(); gb.replay()
+for _ in range(3):
+    one_step(ref, ropt, x, PAD, r, False)
+torch.cuda.synchronize()
+assert torch.equal(opt.flat_g, ropt.flat_g), "gradients differ"
+# (the captured update takes AdamW's bias correction from the device step counter - powf on the device - the eager one
+#  from the host: the weights agree to fp32 rounding, not bit for bit)
+err = (opt.flat_p - ropt.flat_p).abs().max().item() / ropt.flat_p.abs().max().item()
+assert err < 1e-6, f"weights differ: {err:.3e}"
+dist.barrier()
+dist.destroy_process_group()
+print("rank 0 OK")
+'''
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -160,6 +203,12 @@ def test_two_ranks_hip_backward_through_buckets_equals_single_process(dtype):
 
 def test_single_rank_rccl_bucket_path_is_bit_identical():
     _launch(NCCL_WORKER, 1, {"SMX_FORCE_ALLREDUCE": "1"})
+
+
+def test_dp_hipgraph_split_equals_eager_steps():
+    """hipGraph under data parallelism (bench.py --graph with world > 1): two captured halves with one RCCL all-reduce of
+    the flat gradient buffer between them reproduce three eager single-process steps (gradients bit for bit)."""
+    _launch(GRAPH_WORKER, 1, {"SMX_FORCE_ALLREDUCE": "1"})
 
 
 def test_bench_refuses_more_ranks_than_gpus():
