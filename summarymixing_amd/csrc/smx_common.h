@@ -181,10 +181,21 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
   return x;
 }
+// the per-pair mixer: ONE multiply round (xorshift, multiply, xorshift).  The seed / high index bits have been through the
+// full two-round mix32 already (hm below); the 32-bit integer multiply is a quarter-rate instruction, and with two of them
+// per pair the hash was a third of the VALU time of every dropout-bearing GEMM epilogue.
+__device__ __forceinline__ uint32_t mix32_1(uint32_t x) {
+#ifdef SMX_HASH_TWO_ROUNDS
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;      // (the round-1 mixer, for A/B builds)
+#else
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+#endif
+  return x;
+}
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
   // one 32-bit hash serves the two elements of an (even, odd) index pair, 16 bits each: P(drop) = (thresh>>16)/65536
   const uint64_t pair = idx >> 1;
-  const uint32_t h = mix32((uint32_t)pair ^ mix32((uint32_t)(pair >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  const uint32_t h = mix32_1((uint32_t)pair ^ mix32((uint32_t)(pair >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
   const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
   return r >= (thresh >> 16);
 }
@@ -199,7 +210,7 @@ __device__ __forceinline__ void dropout_apply(float (&v)[NV], uint64_t seed, uin
   const uint32_t t16 = thresh >> 16, p0 = (uint32_t)pair0;
 #pragma unroll
   for (int q2 = 0; q2 < NV / 2; ++q2) {
-    const uint32_t h = mix32((p0 + (uint32_t)q2) ^ hm);
+    const uint32_t h = mix32_1((p0 + (uint32_t)q2) ^ hm);
     v[2 * q2] = (h & 0xffffu) >= t16 ? v[2 * q2] * scale : 0.f;
     v[2 * q2 + 1] = (h >> 16) >= t16 ? v[2 * q2 + 1] * scale : 0.f;
   }
