@@ -9,8 +9,11 @@ mkdir -p "${HERE}/obj"
 pids=()
 for f in capi gemm rowwise dwconv frontend ctc reduce wgrad_group; do
   src="${HERE}/${f}.hip"; obj="${HERE}/obj/${f}.o"
-  if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/smx_common.h" -nt "$obj" || "${HERE}/gemm_common.h" -nt "$obj" || "${HERE}/../../include/smx.h" -nt "$obj" ]]; then
-    "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$obj" &
+  if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/smx_common.h" -nt "$obj" || "${HERE}/gemm_common.h" -nt "$obj" || "${HERE}/dwconv_roll.h" -nt "$obj" || "${HERE}/build.sh" -nt "$obj" || "${HERE}/../../include/smx.h" -nt "$obj" ]]; then
+    extra=()
+    # dwconv: the SLP vectoriser turns the register-window FMA chains into v_pk_fma_f32 + v_pk_mov + s_nop (measured slower)
+    [[ "$f" == dwconv ]] && extra=(-fno-slp-vectorize)
+    "$HIPCC" "${FLAGS[@]}" "${extra[@]}" -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done

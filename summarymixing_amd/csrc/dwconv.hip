@@ -543,7 +543,14 @@ __global__ __launch_bounds__(256) void dw_partials_reduce_kernel(const float* __
 
 }  // namespace smx
 
+#include "dwconv_roll.h"
+
 using namespace smx;
+
+// does the rolling register-window path (dwconv_roll.h) take this call?
+static bool roll_ok(int D, int k, int glu, int pad_mode, int chunk, bool has_gate) {
+  return roll_enabled() && k == 31 && chunk <= 0 && glu && !has_gate && pad_mode == SMX_PAD_ZERO && D % 64 == 0;
+}
 
 extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
                                     const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k,
@@ -561,7 +568,14 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
   const int vw = dtype == SMX_BF16 ? 8 : 4;
   const bool fast = k == 31 && chunk <= 0 && D % vw == 0 && ldp % vw == 0 && ldy % vw == 0 && aligned16(P) && aligned16(Y) &&
                     (gate == nullptr || (ldg % vw == 0 && aligned16(gate))) && (pad_mode == SMX_PAD_ZERO || T > 15);
-  if (fast) {
+  if (roll_ok(D, k, glu, pad_mode, chunk, gate != nullptr)) {
+    SMX_REQUIRE((long)T * (ldp > ldy ? ldp : ldy) * 4 < (1L << 31), "smx_dwconv1d_glu_fwd: utterance span >= 2 GB (SMX_DWROLL=0 selects the tiled kernel)");
+    int seg, nseg, gy;
+    roll_geometry(B, T, D, &seg, &nseg, &gy);
+    dim3 g1((unsigned)(8 * (D / 64) * ((gy + 7) / 8)));
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_roll_fwd<bf16_t>), g1, dim3(256), 0, s, p, seg, nseg, gy);
+    else hipLaunchKernelGGL((dwconv_roll_fwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gy);
+  } else if (fast) {
     if (gate) {
       if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_fast<bf16_t, 31, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((dwconv_fwd_fast<float, 31, true>), grid, dim3(256), 0, s, p);
@@ -574,11 +588,32 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
   return check_launch("smx_dwconv1d_glu_fwd");
 }
 
-extern "C" size_t smx_dwconv1d_glu_bwd_workspace(int B, int T, int D, int k) {
+static long tiled_rows(int B, int T, int D) {
   const int tiles_t = (T + DW_TT - 1) / DW_TT, ctiles = (D + DW_CT - 1) / DW_CT;
   long total = (long)B * tiles_t, gy = (1024 + ctiles - 1) / ctiles;
   if (gy > total) gy = total;
   if (gy < 1) gy = 1;
+  return gy;
+}
+
+extern "C" int smx_dwconv1d_glu_bwd_partial_rows(int B, int T, int D, int k, int glu, int pad_mode, int chunk, int has_gate) {
+  if (B <= 0 || T <= 0 || D <= 0) return 0;
+  if (roll_ok(D, k, glu, pad_mode, chunk, has_gate != 0)) {
+    int seg, nseg, gy;
+    roll_geometry(B, T, D, &seg, &nseg, &gy);
+    return gy;
+  }
+  return (int)tiled_rows(B, T, D);
+}
+
+extern "C" size_t smx_dwconv1d_glu_bwd_workspace(int B, int T, int D, int k) {
+  if (B <= 0 || T <= 0 || D <= 0) return 0;
+  long gy = tiled_rows(B, T, D);
+  if (D % 64 == 0 && k == 31) {
+    int seg, nseg, gr;
+    roll_geometry(B, T, D, &seg, &nseg, &gr);
+    if (gr > gy) gy = gr;
+  }
   return (size_t)gy * D * (k + 1) * sizeof(float);
 }
 
@@ -608,7 +643,24 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
                     aligned16(P) && aligned16(dY) && aligned16(dP) && workspace != nullptr &&
                     (gate == nullptr || (ldg % vw == 0 && lddg % vw == 0 && aligned16(gate) && aligned16(dgate))) &&
                     (pad_mode == SMX_PAD_ZERO || T > 15);
-  if (fast) {
+  if (workspace != nullptr && roll_ok(D, k, glu, pad_mode, chunk, gate != nullptr)) {
+    SMX_REQUIRE((long)T * (ldp > lddp ? (ldp > lddy ? ldp : lddy) : (lddp > lddy ? lddp : lddy)) * 4 < (1L << 31),
+                "smx_dwconv1d_glu_bwd: utterance span >= 2 GB (SMX_DWROLL=0 selects the tiled kernel)");
+    int seg, nseg, gr;
+    roll_geometry(B, T, D, &seg, &nseg, &gr);
+    float* partial = reinterpret_cast<float*>(workspace);
+    const int mapc = roll_mapc() ? 1 : 0;
+    dim3 g1((unsigned)(8 * (mapc ? (D / 64 + 3) / 4 : D / 64) * ((gr + 7) / 8)));
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("SMX_DWROLL_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (dtype != SMX_BF16) hipLaunchKernelGGL((dwconv_roll_bwd<float, 0>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
+    else if (abl == 1) hipLaunchKernelGGL((dwconv_roll_bwd<bf16_t, 1>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
+    else if (abl == 2) hipLaunchKernelGGL((dwconv_roll_bwd<bf16_t, 2>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
+    else if (abl == 3) hipLaunchKernelGGL((dwconv_roll_bwd<bf16_t, 3>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
+    else hipLaunchKernelGGL((dwconv_roll_bwd<bf16_t, 0>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
+    const long W = (long)D * (k + 1);
+    if (dw) hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, gr, D, k, dw, dbias);
+  } else if (fast) {
     float* partial = reinterpret_cast<float*>(workspace);
     dim3 g1((unsigned)(8 * ctiles * ((gy + 7) / 8)));
     const bool refl = pad_mode == SMX_PAD_REFLECT, gt = gate != nullptr;

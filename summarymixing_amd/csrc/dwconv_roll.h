@@ -1,0 +1,279 @@
+// dwconv_roll.h — rolling register-window GLU + depthwise Conv1d (k = 31, zero padding): the Conformer conv module's
+// production shape (Conformer.py:131-145,190-313).  Included by dwconv.hip.
+//
+// The tiled kernels of dwconv.hip build a 64-frame tile (+30 halo rows: 1.47x the bytes) in LDS and run in barrier-separated
+// phases (load | window | FMA | store): 0.20-0.25 of the HBM roof.  Here ONE WAVE owns 64 channels (lane = channel) and walks a
+// time segment of one utterance 16 frames at a time with its 46-47 row window in registers: a feature row of 64 channels is
+// one 128-byte line per wave access, nothing goes through LDS, there are no barriers, the halo is 30 rows per SEGMENT (128
+// frames: 1.23x, L2 hits next to the neighbour segment) and the next step's rows are in flight during the current step's FMAs.
+// The kernel is issue-bound (2 x 496 FMAs per 16 outputs per lane), so every row access is ONE scalar add + ONE buffer
+// instruction: buffer descriptor per utterance, row offset in the scalar offset operand, the lane's channel in a constant VGPR.
+#pragma once
+
+namespace smx {
+
+constexpr int RW_STEP = 16;
+
+template <typename T> struct RwRaw;
+template <> struct RwRaw<bf16_t> { typedef unsigned short type; };
+template <> struct RwRaw<float> { typedef unsigned int type; };
+
+__device__ __forceinline__ float rw_f32(unsigned short x) { return bf16_bits_to_f32(x); }
+__device__ __forceinline__ float rw_f32(unsigned int x) { return __uint_as_float(x); }
+
+template <typename T>
+__device__ __forceinline__ typename RwRaw<T>::type rw_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+  else return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+template <typename T>
+__device__ __forceinline__ void rw_st(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(T) == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f32_to_bf16_bits(v), r, voff, soff, 0);
+  else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+// 16 rows r0 .. r0+15 of one utterance's (T, ld) matrix at lane offset voff: zeros outside [0, T).  The common case (all rows
+// inside) is 16 x (s_add, buffer_load); rows are wave-uniform, so the edge case is scalar branches.
+template <typename T>
+__device__ __forceinline__ void rw_fetch(typename RwRaw<T>::type (&dst)[RW_STEP], __amdgpu_buffer_rsrc_t rs, unsigned voff,
+                                         int r0, int Tn, unsigned ldb) {
+  if (r0 >= 0 && r0 + RW_STEP <= Tn) {
+    unsigned soff = (unsigned)r0 * ldb;
+#pragma unroll
+    for (int i = 0; i < RW_STEP; ++i) { dst[i] = rw_ld<T>(rs, voff, soff); soff += ldb; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RW_STEP; ++i) {
+      const int r = r0 + i;
+      typename RwRaw<T>::type v = 0;
+      if (r >= 0 && r < Tn) v = rw_ld<T>(rs, voff, (unsigned)r * ldb);
+      dst[i] = v;
+    }
+  }
+}
+
+// (iy, bx) of this workgroup: workgroup id % 8 is its XCD; the channel tiles of one run of 4 segments sit on ONE XCD
+// next to each other in dispatch order, so the 128-byte pieces of a feature row are fetched by neighbours at the same time
+__device__ __forceinline__ void rw_map(int ctiles, int& iy, int& bx) {
+  const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+  iy = (widx / ctiles) * 8 + xcd;
+  bx = widx % ctiles;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_roll_fwd(DwParams p, int seg, int nseg, int gy) {
+  constexpr int K = 31, WIN = 46, ES = (int)sizeof(T);
+  typedef typename RwRaw<T>::type raw_t;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int iy, bx;
+  rw_map(p.D / 64, iy, bx);
+  const int item = iy * 4 + wv;
+  if (iy >= gy || item >= p.B * nseg) return;
+  const int b = item / nseg, t_lo = (item % nseg) * seg, t_hi = min(p.T, t_lo + seg);
+  const int nsteps = (t_hi - t_lo + RW_STEP - 1) / RW_STEP;
+  const int ch = bx * 64 + lane;
+  float w[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = p.w[(long)ch * K + j];
+  const float bs = p.bias ? p.bias[ch] : 0.f;
+  T* Pb = const_cast<T*>(reinterpret_cast<const T*>(p.P)) + (long)b * p.T * p.ldp;
+  T* Yb = reinterpret_cast<T*>(p.Y) + (long)b * p.T * p.ldy;
+  const unsigned ldpb = (unsigned)p.ldp * ES, ldyb = (unsigned)p.ldy * ES;
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pb, (short)0, (int)(p.T * ldpb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb, (short)0, (int)(p.T * ldyb), 0x00020000);
+  const unsigned va = (unsigned)ch * ES, vg = (unsigned)(p.D + ch) * ES;
+  float win[WIN];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) win[i] = 0.f;
+  raw_t pa0[RW_STEP], pg0[RW_STEP], pa1[RW_STEP], pg1[RW_STEP];       // two steps of rows in flight
+  // window row i at step s is frame t_lo + 16 s - 15 + i; the step's 16 fetched frames land in rows 30..45
+  // (a zero 'a' gives u = 0 whatever the gate: zero padding needs no flag)
+  auto step = [&](raw_t (&pa)[RW_STEP], raw_t (&pg)[RW_STEP], int s) {
+#pragma unroll
+    for (int i = 0; i < RW_STEP; ++i) win[30 + i] = rw_f32(pa[i]) * sigmoidf_(rw_f32(pg[i]));
+    if (s + 2 < nsteps) {
+      rw_fetch<T>(pa, rP, va, t_lo + 15 + (s + 2) * RW_STEP, p.T, ldpb);
+      rw_fetch<T>(pg, rP, vg, t_lo + 15 + (s + 2) * RW_STEP, p.T, ldpb);
+    }
+    if (s >= 0) {
+      const int r0 = t_lo + s * RW_STEP;
+      unsigned soff = (unsigned)r0 * ldyb;
+#pragma unroll
+      for (int o = 0; o < RW_STEP; ++o) {
+        float acc = bs;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
+        if (r0 + o < t_hi) rw_st<T>(acc, rY, va, soff);
+        soff += ldyb;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WIN - RW_STEP; ++i) win[i] = win[i + RW_STEP];
+  };
+  rw_fetch<T>(pa0, rP, va, t_lo + 15 - 2 * RW_STEP, p.T, ldpb);
+  rw_fetch<T>(pg0, rP, vg, t_lo + 15 - 2 * RW_STEP, p.T, ldpb);
+  rw_fetch<T>(pa1, rP, va, t_lo + 15 - RW_STEP, p.T, ldpb);
+  rw_fetch<T>(pg1, rP, vg, t_lo + 15 - RW_STEP, p.T, ldpb);
+  for (int s = -2; s < nsteps; s += 2) {
+    step(pa0, pg0, s);
+    if (s + 1 < nsteps) step(pa1, pg1, s + 1);
+  }
+}
+
+// backward: dP = GLU'(conv^T dY), tap / bias gradient partial rows [gy][D][K + 1] (one per workgroup, the four waves folded in
+// a fixed order), reduced by dw_partials_reduce_kernel or a deferred smx_reduce_jobs.
+// ABL (diagnostic, SMX_DWROLL_ABLATE): 1 = no FMAs, 2 = no loads, 3 = no stores
+template <typename T, int ABL>
+__global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int nseg, int gy, float* __restrict__ partial, int mapc) {
+  constexpr int K = 31, WIN = 47, ES = (int)sizeof(T);
+  typedef typename RwRaw<T>::type raw_t;
+  __shared__ float wls[4][K][64];
+  __shared__ float red[4][64 * 33];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ctiles = p.D / 64;
+  int item, tile;
+  if (mapc) {                                   // the 4 waves of a workgroup: 4 adjacent channel tiles of ONE segment
+    const int cgroups = (ctiles + 3) / 4;
+    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+    item = (widx / cgroups) * 8 + xcd;
+    tile = (widx % cgroups) * 4 + wv;
+    if (item >= gy) return;
+    if (tile >= ctiles) { item = p.B * nseg; tile = ctiles - 1; }
+  } else {
+    int iy, bx;
+    rw_map(ctiles, iy, bx);
+    if (iy >= gy) return;
+    item = iy * 4 + wv; tile = bx;
+  }
+  const int ch = tile * 64 + lane;
+  float (*wl)[64] = wls[mapc ? wv : 0];
+  if (mapc) { for (int j = 0; j < K; ++j) wl[j][lane] = p.w[(long)ch * K + j]; }
+  else { for (int j = wv; j < K; j += 4) wl[j][lane] = p.w[(long)ch * K + j]; }
+  __syncthreads();
+  float dw[K], dbs = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) dw[j] = 0.f;
+  if (item < p.B * nseg) {
+    const int b = item / nseg, t_lo = (item % nseg) * seg, t_hi = min(p.T, t_lo + seg);
+    const int nsteps = (t_hi - t_lo + RW_STEP - 1) / RW_STEP;
+    T* Pb = const_cast<T*>(reinterpret_cast<const T*>(p.P)) + (long)b * p.T * p.ldp;
+    T* Gb = reinterpret_cast<T*>(p.Y) + (long)b * p.T * p.ldy;                   // dY
+    T* Ob = reinterpret_cast<T*>(p.dP) + (long)b * p.T * p.lddp;
+    const unsigned ldpb = (unsigned)p.ldp * ES, ldyb = (unsigned)p.ldy * ES, ldob = (unsigned)p.lddp * ES;
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pb, (short)0, (int)(p.T * ldpb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(Gb, (short)0, (int)(p.T * ldyb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(Ob, (short)0, (int)(p.T * ldob), 0x00020000);
+    const unsigned va = (unsigned)ch * ES, vg = (unsigned)(p.D + ch) * ES;
+    float uw[WIN], gw[WIN], sgp[RW_STEP];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) { uw[i] = 0.f; gw[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < RW_STEP; ++i) sgp[i] = 0.f;
+    raw_t pa[RW_STEP], pg[RW_STEP], pd[RW_STEP];
+    if (ABL == 2) {
+#pragma unroll
+      for (int i = 0; i < RW_STEP; ++i) { pa[i] = (raw_t)(0x3f80 + lane); pg[i] = (raw_t)(0x3f00 + i); pd[i] = (raw_t)(0x3e80 + i); }
+    }
+    // window row i at step s is frame t_lo + 16 s - 15 + i: the step's outputs (rows 15..30) are the frames fetched one step
+    // earlier, the 16 frames fetched now land in rows 31..46.  The fetches of the next step are issued as soon as their
+    // registers are free (dY rows right after the window took them, a / gate rows after the GLU).
+    if (ABL != 2) rw_fetch<T>(pd, rG, va, t_lo - RW_STEP, p.T, ldyb);
+    if (ABL != 2) rw_fetch<T>(pa, rP, va, t_lo - RW_STEP, p.T, ldpb);
+    if (ABL != 2) rw_fetch<T>(pg, rP, vg, t_lo - RW_STEP, p.T, ldpb);
+    for (int s = -2; s < nsteps; ++s) {
+#pragma unroll
+      for (int i = 0; i < RW_STEP; ++i) gw[31 + i] = rw_f32(pd[i]);
+      if (s + 1 < nsteps) if (ABL != 2) rw_fetch<T>(pd, rG, va, t_lo + (s + 2) * RW_STEP, p.T, ldyb);
+      if (s >= 0) {
+        // du(tau) = sum_j w_j dY(tau - j + 15); GLU backward with the gate sigmoid kept from the step that fetched the frame
+        float du[RW_STEP];
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) du[o] = 0.f;
+#pragma unroll
+        for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
+          const float wj = wl[j][lane];
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
+        }
+        const int r0 = t_lo + s * RW_STEP;
+        unsigned soff = (unsigned)r0 * ldob;
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) {
+          if (r0 + o < t_hi && (ABL != 3 || du[o] == 123.456f)) {
+            const float sg = sgp[o];
+            rw_st<T>(du[o] * sg, rO, va, soff);
+            rw_st<T>(du[o] * uw[15 + o] * (1.f - sg), rO, vg, soff);            // du * a * sg * (1 - sg), u = a * sg
+          }
+          soff += ldob;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RW_STEP; ++i) {
+        const float sg = sigmoidf_(rw_f32(pg[i]));
+        sgp[i] = sg;
+        uw[31 + i] = rw_f32(pa[i]) * sg;
+      }
+      if (s + 1 < nsteps) {
+        if (ABL != 2) rw_fetch<T>(pa, rP, va, t_lo + (s + 2) * RW_STEP, p.T, ldpb);
+        if (ABL != 2) rw_fetch<T>(pg, rP, vg, t_lo + (s + 2) * RW_STEP, p.T, ldpb);
+      }
+      if (s >= 0) {
+        // dw_j += sum_t dY(t) u(t + j - 15), dbias += sum_t dY(t)   (frames beyond T are zero rows)
+#pragma unroll
+        for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
+          dw[j] += sacc;
+        }
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) dbs += gw[15 + o];
+      }
+#pragma unroll
+      for (int i = 0; i < WIN - RW_STEP; ++i) { uw[i] = uw[i + RW_STEP]; gw[i] = gw[i + RW_STEP]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) red[wv][lane * 33 + j] = dw[j];
+  red[wv][lane * 33 + K] = dbs;
+  __syncthreads();
+  if (mapc) {
+    if (item < p.B * nseg) {
+      float* out = partial + ((long)item * p.D + tile * 64) * (K + 1);
+      for (int idx = lane; idx < 64 * (K + 1); idx += 64) out[idx] = red[wv][(idx >> 5) * 33 + (idx & 31)];
+    }
+    return;
+  }
+  float* out = partial + ((long)(item >> 2) * p.D + tile * 64) * (K + 1);
+  for (int idx = threadIdx.x; idx < 64 * (K + 1); idx += 256) {
+    const int c = idx >> 5, j = idx & 31, a = c * 33 + j;
+    out[idx] = ((red[0][a] + red[1][a]) + red[2][a]) + red[3][a];
+  }
+}
+
+inline bool roll_mapc() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMX_DWROLL_MAPC"); on = (e && e[0] == '1') ? 1 : 0; }
+  return on == 1;
+}
+
+// time segment per wave: 128 frames (8 steps; 30 halo rows = 1.23x) unless that leaves the chip short of waves
+inline void roll_geometry(int B, int T, int D, int* seg, int* nseg, int* gy) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("SMX_DWROLL_SEG"); forced = e ? atoi(e) : 0; }
+  int s = forced > 0 ? (forced + 15) / 16 * 16 : 128;
+  if (forced <= 0) {
+    while (s > 32 && (long)B * ((T + s - 1) / s) * (D / 64) < 2048) s >>= 1;    // < 2 waves per SIMD: shorter segments
+  }
+  *seg = s;
+  *nseg = (T + s - 1) / s;
+  *gy = roll_mapc() ? B * *nseg : (int)(((long)B * *nseg + 3) / 4);
+}
+
+inline bool roll_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SMX_DWROLL"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+
+}  // namespace smx

@@ -150,7 +150,10 @@ def test_chunk_mean_fwd_bwd(left, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
-@pytest.mark.parametrize("B,T,D,k,chunk", [(2, 150, 96, 31, 0), (3, 70, 40, 7, 0), (2, 100, 64, 31, 16), (1, 9, 8, 5, 4)])
+@pytest.mark.parametrize("B,T,D,k,chunk", [(2, 150, 96, 31, 0), (3, 70, 40, 7, 0), (2, 100, 64, 31, 16), (1, 9, 8, 5, 4),
+                                           # D % 64 == 0, k = 31, no chunking: the rolling register-window kernels (dwconv_roll.h)
+                                           (2, 150, 128, 31, 0), (3, 500, 64, 31, 0), (1, 9, 64, 31, 0), (5, 131, 192, 31, 0),
+                                           (128, 500, 256, 31, 0)])
 def test_glu_dwconv_fwd_bwd(B, T, D, k, chunk, dtype, tol):
     from oracle import smx_oracle as O
     L, ops = _ops()
