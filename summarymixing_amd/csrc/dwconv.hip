@@ -573,7 +573,7 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
     int seg, nseg, gy;
     roll_geometry(B, T, D, &seg, &nseg, &gy);
     dim3 g1((unsigned)(8 * (D / 64) * ((gy + 7) / 8)));
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_roll_fwd<bf16_t>), g1, dim3(256), 0, s, p, seg, nseg, gy);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL(dwconv_rolls_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
     else hipLaunchKernelGGL((dwconv_roll_fwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gy);
   } else if (fast) {
     if (gate) {
@@ -649,15 +649,13 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
     int seg, nseg, gr;
     roll_geometry(B, T, D, &seg, &nseg, &gr);
     float* partial = reinterpret_cast<float*>(workspace);
-    const int mapc = roll_mapc() ? 1 : 0;
-    dim3 g1((unsigned)(8 * (mapc ? (D / 64 + 3) / 4 : D / 64) * ((gr + 7) / 8)));
+    dim3 g1((unsigned)(8 * (D / 64) * ((gr + 7) / 8)));
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("SMX_DWROLL_ABLATE"); abl = e ? atoi(e) : 0; }
-    if (dtype != SMX_BF16) hipLaunchKernelGGL((dwconv_roll_bwd<float, 0>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
-    else if (abl == 1) hipLaunchKernelGGL((dwconv_roll_bwd<bf16_t, 1>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
-    else if (abl == 2) hipLaunchKernelGGL((dwconv_roll_bwd<bf16_t, 2>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
-    else if (abl == 3) hipLaunchKernelGGL((dwconv_roll_bwd<bf16_t, 3>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
-    else hipLaunchKernelGGL((dwconv_roll_bwd<bf16_t, 0>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial, mapc);
+    if (dtype != SMX_BF16) hipLaunchKernelGGL((dwconv_roll_bwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+    else if (abl == 1) hipLaunchKernelGGL((dwconv_rolls_bwd<1>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+    else if (abl == 2) hipLaunchKernelGGL((dwconv_rolls_bwd<2>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+    else hipLaunchKernelGGL((dwconv_rolls_bwd<0>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
     const long W = (long)D * (k + 1);
     if (dw) hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, gr, D, k, dw, dbias);
   } else if (fast) {

@@ -3,11 +3,15 @@
 //
 // The tiled kernels of dwconv.hip build a 64-frame tile (+30 halo rows: 1.47x the bytes) in LDS and run in barrier-separated
 // phases (load | window | FMA | store): 0.20-0.25 of the HBM roof.  Here ONE WAVE owns 64 channels (lane = channel) and walks a
-// time segment of one utterance 16 frames at a time with its 46-47 row window in registers: a feature row of 64 channels is
-// one 128-byte line per wave access, nothing goes through LDS, there are no barriers, the halo is 30 rows per SEGMENT (128
-// frames: 1.23x, L2 hits next to the neighbour segment) and the next step's rows are in flight during the current step's FMAs.
-// The kernel is issue-bound (2 x 496 FMAs per 16 outputs per lane), so every row access is ONE scalar add + ONE buffer
-// instruction: buffer descriptor per utterance, row offset in the scalar offset operand, the lane's channel in a constant VGPR.
+// time segment of one utterance 16 frames at a time with its 46-47 row window in registers: no workgroup barriers, the halo
+// is 30 rows per SEGMENT (128 frames: 1.23x, L2 hits next to the neighbour segment) and the rows of the next two steps are in
+// flight during the current step's 2 x 496 FMAs.
+//   dwconv_roll_*  (fp32): every row access is one scalar add + one buffer instruction of 4 bytes per lane.
+//   dwconv_rolls_* (bf16): the vector-memory pipe retires one 64-lane instruction per 16 cycles whatever its width, so 2-byte
+//     accesses cap a CU at 8 B / clk (measured: loads + stores alone 48 us for 164 MB).  Rows arrive by LDS-DMA instead
+//     (buffer_load_dwordx4 ... lds: 8 rows x 128 B per instruction, no VGPRs, zero fill outside the utterance by the
+//     descriptor's range check) into a per-wave ring of two steps, the window is filled by ds_read_u16, results leave through
+//     a per-wave LDS tile as 16-byte stores: 10 vector-memory instructions per step instead of 80.
 #pragma once
 
 namespace smx {
@@ -122,34 +126,20 @@ __global__ __launch_bounds__(256) void dwconv_roll_fwd(DwParams p, int seg, int 
 
 // backward: dP = GLU'(conv^T dY), tap / bias gradient partial rows [gy][D][K + 1] (one per workgroup, the four waves folded in
 // a fixed order), reduced by dw_partials_reduce_kernel or a deferred smx_reduce_jobs.
-// ABL (diagnostic, SMX_DWROLL_ABLATE): 1 = no FMAs, 2 = no loads, 3 = no stores
-template <typename T, int ABL>
-__global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int nseg, int gy, float* __restrict__ partial, int mapc) {
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int nseg, int gy, float* __restrict__ partial) {
   constexpr int K = 31, WIN = 47, ES = (int)sizeof(T);
   typedef typename RwRaw<T>::type raw_t;
-  __shared__ float wls[4][K][64];
+  __shared__ float wl[K][64];
   __shared__ float red[4][64 * 33];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ctiles = p.D / 64;
-  int item, tile;
-  if (mapc) {                                   // the 4 waves of a workgroup: 4 adjacent channel tiles of ONE segment
-    const int cgroups = (ctiles + 3) / 4;
-    const int xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
-    item = (widx / cgroups) * 8 + xcd;
-    tile = (widx % cgroups) * 4 + wv;
-    if (item >= gy) return;
-    if (tile >= ctiles) { item = p.B * nseg; tile = ctiles - 1; }
-  } else {
-    int iy, bx;
-    rw_map(ctiles, iy, bx);
-    if (iy >= gy) return;
-    item = iy * 4 + wv; tile = bx;
-  }
-  const int ch = tile * 64 + lane;
-  float (*wl)[64] = wls[mapc ? wv : 0];
-  if (mapc) { for (int j = 0; j < K; ++j) wl[j][lane] = p.w[(long)ch * K + j]; }
-  else { for (int j = wv; j < K; j += 4) wl[j][lane] = p.w[(long)ch * K + j]; }
+  int iy, bx;
+  rw_map(p.D / 64, iy, bx);
+  if (iy >= gy) return;
+  const int ch = bx * 64 + lane;
+  for (int j = wv; j < K; j += 4) wl[j][lane] = p.w[(long)ch * K + j];
   __syncthreads();
+  const int item = iy * 4 + wv;
   float dw[K], dbs = 0.f;
 #pragma unroll
   for (int j = 0; j < K; ++j) dw[j] = 0.f;
@@ -170,27 +160,23 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
 #pragma unroll
     for (int i = 0; i < RW_STEP; ++i) sgp[i] = 0.f;
     raw_t pa[RW_STEP], pg[RW_STEP], pd[RW_STEP];
-    if (ABL == 2) {
-#pragma unroll
-      for (int i = 0; i < RW_STEP; ++i) { pa[i] = (raw_t)(0x3f80 + lane); pg[i] = (raw_t)(0x3f00 + i); pd[i] = (raw_t)(0x3e80 + i); }
-    }
     // window row i at step s is frame t_lo + 16 s - 15 + i: the step's outputs (rows 15..30) are the frames fetched one step
     // earlier, the 16 frames fetched now land in rows 31..46.  The fetches of the next step are issued as soon as their
     // registers are free (dY rows right after the window took them, a / gate rows after the GLU).
-    if (ABL != 2) rw_fetch<T>(pd, rG, va, t_lo - RW_STEP, p.T, ldyb);
-    if (ABL != 2) rw_fetch<T>(pa, rP, va, t_lo - RW_STEP, p.T, ldpb);
-    if (ABL != 2) rw_fetch<T>(pg, rP, vg, t_lo - RW_STEP, p.T, ldpb);
+    rw_fetch<T>(pd, rG, va, t_lo - RW_STEP, p.T, ldyb);
+    rw_fetch<T>(pa, rP, va, t_lo - RW_STEP, p.T, ldpb);
+    rw_fetch<T>(pg, rP, vg, t_lo - RW_STEP, p.T, ldpb);
     for (int s = -2; s < nsteps; ++s) {
 #pragma unroll
       for (int i = 0; i < RW_STEP; ++i) gw[31 + i] = rw_f32(pd[i]);
-      if (s + 1 < nsteps) if (ABL != 2) rw_fetch<T>(pd, rG, va, t_lo + (s + 2) * RW_STEP, p.T, ldyb);
+      if (s + 1 < nsteps) rw_fetch<T>(pd, rG, va, t_lo + (s + 2) * RW_STEP, p.T, ldyb);
       if (s >= 0) {
         // du(tau) = sum_j w_j dY(tau - j + 15); GLU backward with the gate sigmoid kept from the step that fetched the frame
         float du[RW_STEP];
 #pragma unroll
         for (int o = 0; o < RW_STEP; ++o) du[o] = 0.f;
 #pragma unroll
-        for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
+        for (int j = 0; j < K; ++j) {
           const float wj = wl[j][lane];
 #pragma unroll
           for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
@@ -199,7 +185,7 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
         unsigned soff = (unsigned)r0 * ldob;
 #pragma unroll
         for (int o = 0; o < RW_STEP; ++o) {
-          if (r0 + o < t_hi && (ABL != 3 || du[o] == 123.456f)) {
+          if (r0 + o < t_hi) {
             const float sg = sgp[o];
             rw_st<T>(du[o] * sg, rO, va, soff);
             rw_st<T>(du[o] * uw[15 + o] * (1.f - sg), rO, vg, soff);            // du * a * sg * (1 - sg), u = a * sg
@@ -214,13 +200,13 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
         uw[31 + i] = rw_f32(pa[i]) * sg;
       }
       if (s + 1 < nsteps) {
-        if (ABL != 2) rw_fetch<T>(pa, rP, va, t_lo + (s + 2) * RW_STEP, p.T, ldpb);
-        if (ABL != 2) rw_fetch<T>(pg, rP, vg, t_lo + (s + 2) * RW_STEP, p.T, ldpb);
+        rw_fetch<T>(pa, rP, va, t_lo + (s + 2) * RW_STEP, p.T, ldpb);
+        rw_fetch<T>(pg, rP, vg, t_lo + (s + 2) * RW_STEP, p.T, ldpb);
       }
       if (s >= 0) {
         // dw_j += sum_t dY(t) u(t + j - 15), dbias += sum_t dY(t)   (frames beyond T are zero rows)
 #pragma unroll
-        for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
+        for (int j = 0; j < K; ++j) {
           float sacc = 0.f;
 #pragma unroll
           for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
@@ -237,24 +223,229 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
   for (int j = 0; j < K; ++j) red[wv][lane * 33 + j] = dw[j];
   red[wv][lane * 33 + K] = dbs;
   __syncthreads();
-  if (mapc) {
-    if (item < p.B * nseg) {
-      float* out = partial + ((long)item * p.D + tile * 64) * (K + 1);
-      for (int idx = lane; idx < 64 * (K + 1); idx += 64) out[idx] = red[wv][(idx >> 5) * 33 + (idx & 31)];
-    }
-    return;
-  }
-  float* out = partial + ((long)(item >> 2) * p.D + tile * 64) * (K + 1);
+  float* out = partial + ((long)iy * p.D + bx * 64) * (K + 1);
   for (int idx = threadIdx.x; idx < 64 * (K + 1); idx += 256) {
     const int c = idx >> 5, j = idx & 31, a = c * 33 + j;
     out[idx] = ((red[0][a] + red[1][a]) + red[2][a]) + red[3][a];
   }
 }
 
-inline bool roll_mapc() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("SMX_DWROLL_MAPC"); on = (e && e[0] == '1') ? 1 : 0; }
-  return on == 1;
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16: rows through a per-wave LDS ring (LDS-DMA in, 16-byte stores out)
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* rw_lds_vp;
+
+template <int N> __device__ __forceinline__ void rw_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most n vector-memory operations are outstanding (n wave-uniform; rounded down to an encodable case)
+__device__ __forceinline__ void rw_wait_vm(int n) {
+  if (n >= 14) rw_vm<14>(); else if (n >= 10) rw_vm<10>(); else if (n >= 8) rw_vm<8>(); else if (n >= 6) rw_vm<6>();
+  else if (n >= 4) rw_vm<4>(); else if (n >= 2) rw_vm<2>(); else rw_vm<0>();
+}
+__device__ __forceinline__ void rw_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// 16 rows r0 .. r0+15 (128 B of each: this wave's 64 bf16 channels) -> 2 KB at LDS byte address dst, rows outside the buffer
+// (before the utterance: the offset wraps far beyond num_records; behind it: offset >= T * ld) arrive as zeros.
+// vpre = (lane / 8) * ld + (lane % 8) * 16 + this wave's column byte offset.  Two instructions, not counted by hipcc.
+__device__ __forceinline__ void rw_dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* dst, unsigned vpre, int r0, unsigned ldb) {
+  const unsigned s0 = (unsigned)r0 * ldb;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rw_lds_vp)dst, 16, vpre + s0, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rw_lds_vp)(dst + 1024), 16, vpre + s0 + 8 * ldb, 0, 0, 0);
+}
+
+__device__ __forceinline__ float rw_lds_bf16(const unsigned char* base, int off) {
+  return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(base + off));
+}
+
+__global__ __launch_bounds__(256) void dwconv_rolls_fwd(DwParams p, int seg, int nseg, int gy) {
+  constexpr int K = 31, WIN = 46, SLOT = 4096, OUT = 2 * SLOT, WAVE = OUT + 2048;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][WAVE];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int iy, bx;
+  rw_map(p.D / 64, iy, bx);
+  const int item = iy * 4 + wv;
+  if (iy >= gy || item >= p.B * nseg) return;
+  const int b = item / nseg, t_lo = (item % nseg) * seg, t_hi = min(p.T, t_lo + seg);
+  const int nsteps = (t_hi - t_lo + RW_STEP - 1) / RW_STEP;
+  const int ch = bx * 64 + lane;
+  float w[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = p.w[(long)ch * K + j];
+  const float bs = p.bias ? p.bias[ch] : 0.f;
+  bf16_t* Pb = const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.P)) + (long)b * p.T * p.ldp;
+  bf16_t* Yb = reinterpret_cast<bf16_t*>(p.Y) + (long)b * p.T * p.ldy;
+  const unsigned ldpb = (unsigned)p.ldp * 2, ldyb = (unsigned)p.ldy * 2;
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pb, (short)0, (int)(p.T * ldpb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb, (short)0, (int)(p.T * ldyb), 0x00020000);
+  const unsigned vcol = (unsigned)(lane & 7) * 16 + (unsigned)bx * 128;
+  const unsigned vpa = (unsigned)(lane >> 3) * ldpb + vcol, vpg = vpa + (unsigned)p.D * 2;
+  const unsigned vpy = (unsigned)(lane >> 3) * ldyb + vcol;
+  unsigned char* st = stage[wv];
+  float win[WIN];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) win[i] = 0.f;
+  // window row i at step s is frame t_lo + 16 s - 15 + i; the step's 16 frames (ring slot s & 1) land in rows 30..45
+  // (a zero 'a' gives u = 0 whatever the gate: zero padding needs no flag)
+  auto dma = [&](int s) {
+    unsigned char* d = st + (s & 1) * SLOT;
+    const int r0 = t_lo + 15 + s * RW_STEP;
+    rw_dma16(rP, d, vpa, r0, ldpb);
+    rw_dma16(rP, d + 2048, vpg, r0, ldpb);
+  };
+  dma(-2);
+  dma(-1);
+  for (int s = -2; s < nsteps; ++s) {
+    // vector-memory operations younger than this step's 4 DMA pieces: stores of step s-2 (2), DMA of step s+1 (4), stores of s-1 (2)
+    rw_wait_vm(s < 0 ? 4 : (s >= 2 ? 2 : 0) + (s + 1 < nsteps ? 4 : 0) + (s >= 1 ? 2 : 0));
+    const unsigned char* sl = st + (s & 1) * SLOT + lane * 2;
+#pragma unroll
+    for (int i = 0; i < RW_STEP; ++i) win[30 + i] = rw_lds_bf16(sl, i * 128) * sigmoidf_(rw_lds_bf16(sl, 2048 + i * 128));
+    rw_lgkm0();                                        // the slot is read: it can take the rows of step s + 2
+    if (s + 2 < nsteps) dma(s + 2);
+    if (s >= 0) {
+      unsigned short* ob = reinterpret_cast<unsigned short*>(st + OUT) + lane;
+#pragma unroll
+      for (int o = 0; o < RW_STEP; ++o) {
+        float acc = bs;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
+        ob[o * 64] = (unsigned short)f32_to_bf16_bits(acc);
+      }
+      asm volatile("" ::: "memory");                   // (LDS is in order within a wave: a compiler fence is enough)
+      const unsigned s0 = (unsigned)(t_lo + s * RW_STEP) * ldyb;
+      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const u32v4 v = *reinterpret_cast<const u32v4*>(st + OUT + k * 1024 + lane * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rY, vpy + s0 + k * 8 * ldyb, 0, 0);   // rows >= T are dropped by the range check
+      }
+      asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < WIN - RW_STEP; ++i) win[i] = win[i + RW_STEP];
+  }
+}
+
+// ABL (diagnostic, SMX_DWROLL_ABLATE): 1 = no FMAs, 2 = no DMA
+template <int ABL>
+__global__ __launch_bounds__(256) void dwconv_rolls_bwd(DwParams p, int seg, int nseg, int gy, float* __restrict__ partial) {
+  constexpr int K = 31, WIN = 47, SLOT = 6144, OUT = 2 * SLOT, WAVE = OUT + 4096;
+  __shared__ float wl[K][64];
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][WAVE];            // (the 4 x 8448-byte reduction rows alias it)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int iy, bx;
+  rw_map(p.D / 64, iy, bx);
+  if (iy >= gy) return;
+  const int ch = bx * 64 + lane;
+  for (int j = wv; j < K; j += 4) wl[j][lane] = p.w[(long)ch * K + j];
+  __syncthreads();
+  const int item = iy * 4 + wv;
+  float dw[K], dbs = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) dw[j] = 0.f;
+  if (item < p.B * nseg) {
+    const int b = item / nseg, t_lo = (item % nseg) * seg, t_hi = min(p.T, t_lo + seg);
+    const int nsteps = (t_hi - t_lo + RW_STEP - 1) / RW_STEP;
+    bf16_t* Pb = const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.P)) + (long)b * p.T * p.ldp;
+    bf16_t* Gb = reinterpret_cast<bf16_t*>(p.Y) + (long)b * p.T * p.ldy;            // dY
+    bf16_t* Ob = reinterpret_cast<bf16_t*>(p.dP) + (long)b * p.T * p.lddp;
+    const unsigned ldpb = (unsigned)p.ldp * 2, ldyb = (unsigned)p.ldy * 2, ldob = (unsigned)p.lddp * 2;
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pb, (short)0, (int)(p.T * ldpb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(Gb, (short)0, (int)(p.T * ldyb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(Ob, (short)0, (int)(p.T * ldob), 0x00020000);
+    const unsigned vcol = (unsigned)(lane & 7) * 16 + (unsigned)bx * 128, vrow = (unsigned)(lane >> 3);
+    const unsigned vpa = vrow * ldpb + vcol, vpg = vpa + (unsigned)p.D * 2, vpd = vrow * ldyb + vcol;
+    const unsigned vo1 = vrow * ldob + vcol, vo2 = vo1 + (unsigned)p.D * 2;
+    unsigned char* st = stage[wv];
+    float uw[WIN], gw[WIN], sgp[RW_STEP];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) { uw[i] = 0.f; gw[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < RW_STEP; ++i) sgp[i] = 0.f;
+    // window row i at step s is frame t_lo + 16 s - 15 + i: the step's outputs (rows 15..30) are the frames that arrived one
+    // step earlier, the 16 frames of ring slot s & 1 land in rows 31..46
+    auto dma = [&](int s) {
+      if (ABL == 2) return;
+      unsigned char* d = st + (s & 1) * SLOT;
+      const int r0 = t_lo + (s + 1) * RW_STEP;
+      rw_dma16(rG, d, vpd, r0, ldyb);
+      rw_dma16(rP, d + 2048, vpa, r0, ldpb);
+      rw_dma16(rP, d + 4096, vpg, r0, ldpb);
+    };
+    dma(-2);
+    dma(-1);
+    for (int s = -2; s < nsteps; ++s) {
+      // younger than this step's 6 DMA pieces: stores of step s-2 (4), DMA of step s+1 (6), stores of step s-1 (4)
+      rw_wait_vm(s < 0 ? 6 : (s >= 2 ? 4 : 0) + (s + 1 < nsteps ? 6 : 0) + (s >= 1 ? 4 : 0));
+      const unsigned char* sl = st + (s & 1) * SLOT + lane * 2;
+#pragma unroll
+      for (int i = 0; i < RW_STEP; ++i) gw[31 + i] = rw_lds_bf16(sl, i * 128);
+      float sgn[RW_STEP];
+#pragma unroll
+      for (int i = 0; i < RW_STEP; ++i) {
+        sgn[i] = sigmoidf_(rw_lds_bf16(sl, 4096 + i * 128));
+        uw[31 + i] = rw_lds_bf16(sl, 2048 + i * 128) * sgn[i];
+      }
+      rw_lgkm0();                                      // the slot is read: it can take the rows of step s + 2
+      if (s + 2 < nsteps) dma(s + 2);
+      if (s >= 0) {
+        // du(tau) = sum_j w_j dY(tau - j + 15); GLU backward with the gate sigmoid kept from the step that brought the frame
+        float du[RW_STEP];
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) du[o] = 0.f;
+#pragma unroll
+        for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
+          const float wj = wl[j][lane];
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
+        }
+        unsigned short* ob = reinterpret_cast<unsigned short*>(st + OUT) + lane;
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) {
+          const float sg = sgp[o];
+          ob[o * 64] = (unsigned short)f32_to_bf16_bits(du[o] * sg);
+          ob[1024 + o * 64] = (unsigned short)f32_to_bf16_bits(du[o] * uw[15 + o] * (1.f - sg));   // du a sg (1 - sg), u = a sg
+        }
+        asm volatile("" ::: "memory");                 // (LDS is in order within a wave: a compiler fence is enough)
+        const unsigned s0 = (unsigned)(t_lo + s * RW_STEP) * ldob;
+        typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                  // rows >= T are dropped by the descriptor's range check
+          const u32v4 v1 = *reinterpret_cast<const u32v4*>(st + OUT + k * 1024 + lane * 16);
+          const u32v4 v2 = *reinterpret_cast<const u32v4*>(st + OUT + 2048 + k * 1024 + lane * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v1, rO, vo1 + s0 + k * 8 * ldob, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v2, rO, vo2 + s0 + k * 8 * ldob, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < RW_STEP; ++i) sgp[i] = sgn[i];
+      if (s >= 0) {
+        // dw_j += sum_t dY(t) u(t + j - 15), dbias += sum_t dY(t)   (frames beyond T are zero rows)
+#pragma unroll
+        for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
+          dw[j] += sacc;
+        }
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) dbs += gw[15 + o];
+      }
+#pragma unroll
+      for (int i = 0; i < WIN - RW_STEP; ++i) { uw[i] = uw[i + RW_STEP]; gw[i] = gw[i + RW_STEP]; }
+    }
+  }
+  __syncthreads();                                     // every wave is done with its ring: the reduction rows take its place
+  float* red = reinterpret_cast<float*>(&stage[0][0]);
+#pragma unroll
+  for (int j = 0; j < K; ++j) red[wv * 2112 + lane * 33 + j] = dw[j];
+  red[wv * 2112 + lane * 33 + K] = dbs;
+  __syncthreads();
+  float* out = partial + ((long)iy * p.D + bx * 64) * (K + 1);
+  for (int idx = threadIdx.x; idx < 64 * (K + 1); idx += 256) {
+    const int a = (idx >> 5) * 33 + (idx & 31);
+    out[idx] = ((red[a] + red[2112 + a]) + red[2 * 2112 + a]) + red[3 * 2112 + a];
+  }
 }
 
 // time segment per wave: 128 frames (8 steps; 30 halo rows = 1.23x) unless that leaves the chip short of waves
@@ -267,7 +458,7 @@ inline void roll_geometry(int B, int T, int D, int* seg, int* nseg, int* gy) {
   }
   *seg = s;
   *nseg = (T + s - 1) / s;
-  *gy = roll_mapc() ? B * *nseg : (int)(((long)B * *nseg + 3) / 4);
+  *gy = (int)(((long)B * *nseg + 3) / 4);
 }
 
 inline bool roll_enabled() {
