@@ -44,6 +44,7 @@ struct WgItem {
 struct WgGroupParams {
   WgItem it[WG_MAX_ITEMS];
   int nitems, total_tiles, splits, ksteps_per_split, rows;   // rows: multiple of 64 (the host peels the tail)
+  int pingpong;         // SMX_WGROUP_PP: 1 = upper four waves refill before their MFMAs, lower four after; 2 = + a mid-step barrier
   int ablate;           // debug (env SMX_WGROUP_ABLATE): 1 = no MFMA / fragment reads, 2 = no DMA, 4 = DMA never waited for
   long long* dbg;       // debug (smx_debug_set_timing_buffer): per workgroup [total cycles, cycles in wait+barrier, realtime ticks, niter]
 };
@@ -175,6 +176,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
     const char* As = smem + (itn % NST) * STAGE_BYTES;
     const char* Bs = As + OP_BYTES;
     if (ab_nomfma) { if (refill) issue(itn + NST - 1); continue; }
+    // ping-pong (p.pingpong): waves w and w + 4 share a SIMD; the upper four issue the whole refill BEFORE their MFMAs, the
+    // lower four AFTER theirs, so that on every SIMD one wave's DMA issue runs beside the other wave's matrix work
+    const bool pp = p.pingpong != 0, pp2 = p.pingpong == 2;
+    if (pp && wave >= 4) {
+      if (refill) issue(itn + NST - 1);
+      if (pp2) __builtin_amdgcn_s_barrier();             // (mid-step barrier: the lower four have finished their MFMAs)
+    }
     bf16x8 fa[2][2], fb[2][4];                           // fragments double-buffered over the 16-frame sub-steps
 #pragma unroll
     for (int i = 0; i < 2; ++i) fa[0][i] = wg_frag(As, wn * 64 + i * 32, l31, hi, 0);
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
 #pragma unroll
         for (int i = 0; i < 2; ++i) wg_sum8(bsum[i][0], bsum[i][1], fa[cur][i]);
       }
-      if (refill) {
+      if (refill && !pp) {
         if constexpr (BK == 64) {                        // NPC = 4: one piece pair per sub-step
           if (kk == 0) issue_part(itn + NST - 1, ActTag<0>{}, ActTag<1>{});
           else if (kk == 1) issue_part(itn + NST - 1, ActTag<1>{}, ActTag<1>{});
@@ -209,6 +217,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
           else issue_part(itn + NST - 1, ActTag<1>{}, ActTag<1>{});
         }
       }
+    }
+    if (pp && wave < 4) {
+      if (pp2) __builtin_amdgcn_s_barrier();
+      if (refill) issue(itn + NST - 1);
     }
   }
 
@@ -293,9 +305,11 @@ extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items,
   const int nk = rows / 64;
   p.ksteps_per_split = (nk + splits - 1) / splits;
   const int nwork = tiles * splits, per = (nwork + 7) / 8;
-  static const int bk_env = getenv("SMX_WGROUP_BK") ? atoi(getenv("SMX_WGROUP_BK")) : 64;
+  static const int bk_env = getenv("SMX_WGROUP_BK") ? atoi(getenv("SMX_WGROUP_BK")) : 32;   // (measured in the step: 32 + ping-pong 1)
   static const int ablate_env = getenv("SMX_WGROUP_ABLATE") ? atoi(getenv("SMX_WGROUP_ABLATE")) : 0;
   p.ablate = ablate_env;
+  static const int pp_env = getenv("SMX_WGROUP_PP") ? atoi(getenv("SMX_WGROUP_PP")) : 1;
+  p.pingpong = pp_env;
   p.dbg = g_wg_dbg;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr_done = false;
