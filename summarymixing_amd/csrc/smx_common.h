@@ -181,14 +181,17 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
   return x;
 }
-// the per-pair mixer: ONE multiply round (xorshift, multiply, xorshift).  The seed / high index bits have been through the
-// full two-round mix32 already (hm below); the 32-bit integer multiply is a quarter-rate instruction, and with two of them
-// per pair the hash was a third of the VALU time of every dropout-bearing GEMM epilogue.
+// the per-pair mixer: two rounds of (xorshift, 24-bit multiply).  v_mul_u32_u24 is a full-rate instruction, the 32-bit
+// v_mul_lo_u32 of mix32 a quarter-rate one, and with two of those per pair the hash was a third of the VALU time of every
+// dropout-bearing GEMM epilogue.  ONE multiply round is not enough whatever its width: idx -> C * idx is an arithmetic
+// progression mod 2^32, and the keep decisions of elements 4 / 8 / 16 apart came out 0.4 correlated (tests/test_dropout_gpu.py
+// ::test_dropout_mask_is_uncorrelated; this mixer: |corr| < 0.005 at every lag, like the two-round mix32).  The seed / high
+// index bits go through the full mix32 (hm below).
 __device__ __forceinline__ uint32_t mix32_1(uint32_t x) {
 #ifdef SMX_HASH_TWO_ROUNDS
   x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;      // (the round-1 mixer, for A/B builds)
 #else
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+  x ^= x >> 16; x = __umul24(x, 0xeb352du); x ^= x >> 12; x = __umul24(x, 0xd2b74du); x ^= x >> 16;
 #endif
   return x;
 }

@@ -30,6 +30,27 @@ def test_dropout_kernel_statistics_and_determinism():
     assert (m.mean(0) - 0.5).abs().max() < 0.06 and (m.mean(1) - 0.5).abs().max() < 0.15
 
 
+@pytest.mark.parametrize("p", [0.15, 0.5])
+@pytest.mark.parametrize("seed", [1234, 0xDEADBEEFCAFEF00D, 77])
+def test_dropout_mask_is_uncorrelated(p, seed):
+    """The counter-based mask must look like independent Bernoulli draws: no correlation between elements a few columns or
+    rows apart (a one-multiply mixer - an arithmetic progression mod 2^32 - gave 0.4 at column lags 4 / 8 / 16), row means
+    within the binomial spread.  Both mask generators (standalone kernel, GEMM epilogue) share the device function."""
+    from summarymixing_amd import ops
+    n, D = 4096, 256
+    k = (ops.dropout(torch.ones(n, D, device="cuda", dtype=torch.bfloat16), p, seed) != 0).double()
+    m = k.mean().item()
+    assert abs(m - (1 - p)) < 3e-3
+    c, v = k - m, m * (1 - m)
+    for lag in (1, 2, 3, 4, 5, 6, 8, 16, 32, 64, 128):
+        assert abs((c[:, :-lag] * c[:, lag:]).mean().item()) / v < 0.01, ("column lag", lag)
+    for lag in (1, 2, 3, 4, 7):
+        assert abs((c[:-lag] * c[lag:]).mean().item()) / v < 0.01, ("row lag", lag)
+    assert abs((c[:-1, :-1] * c[1:, 1:]).mean().item()) / v < 0.01
+    sd_row, sd_col = (v / D) ** 0.5, (v / n) ** 0.5
+    assert (k.mean(1) - m).abs().max().item() < 5.5 * sd_row and (k.mean(0) - m).abs().max().item() < 5.5 * sd_col
+
+
 @pytest.mark.parametrize("mode", ["SummaryMixing-fast", "SummaryMixing"])
 def test_cell_dropout_backward_uses_forward_mask(mode):
     """y is piecewise linear in x for relu; with a fixed seed stream the directional derivative must equal <dx, v>."""
@@ -166,7 +187,8 @@ def test_training_mode_gradients_match_finite_differences(kind):
         an = (gx * v).sum()
         assert abs(float(fd - an)) <= 3e-2 * max(1.0, abs(float(an))), (kind, "dx", float(fd), float(an))
     u = torch.randn_like(wpar)
-    with torch.no_grad():
+    eps = 3e-3                                            # (a unit-variance direction is a 5 % change of xavier weights at 1e-2:
+    with torch.no_grad():                                 #  the curvature term alone reached 5 % of the derivative)
         w0 = wpar.detach().clone()
         wpar.copy_(w0 + eps * u); fp = f(x)
         wpar.copy_(w0 - eps * u); fm = f(x)
