@@ -254,7 +254,7 @@ int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, 
  * stay in the workspace for smx_reduce_jobs (two jobs with src_ld = k+1); SMX_EUNSUPPORTED outside the k = 31 path. */
 size_t smx_dwconv1d_glu_bwd_workspace(int B, int T, int D, int k);
 /* how many partial rows the call below leaves in the workspace for these arguments (the nsrc of the two reduction jobs) */
-int smx_dwconv1d_glu_bwd_partial_rows(int B, int T, int D, int k, int glu, int pad_mode, int chunk, int has_gate);
+int smx_dwconv1d_glu_bwd_partial_rows(int dtype, int B, int T, int D, int k, int glu, int pad_mode, int chunk, int has_gate);
 int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, const void* P, int64_t ldp, const float* w,
                          const float* bias, const void* gate, int64_t ldg, void* dP, int64_t lddp, void* dgate,
                          int64_t lddg, float* dw, float* dbias, int B, int T, int D, int k, int glu, int pad_mode,

@@ -460,15 +460,19 @@ __global__ __launch_bounds__(256) void dwconv_bwd_fast(DwParams p, int tiles_t, 
           const bool top = idx < PAD;
           const int tau = top ? 1 + idx : p.T - 1 - PAD + (idx - PAD);
           const int o = tau - t0;
-          if (o < 0 || o >= DW_TT || tau < 1 || tau > p.T - 2) continue;
+          // frames 1..PAD are mirrored at the top, frames T-1-PAD..T-2 at the bottom; for T < 32 a frame can sit in both
+          // ranges: its top pass then does both folds and the bottom pass skips it
+          const bool in_top = tau >= 1 && tau <= PAD && tau <= p.T - 1;
+          const bool in_bot = tau >= 0 && tau <= p.T - 2 && tau >= p.T - 1 - PAD;
+          if (o < 0 || o >= DW_TT || (top ? !in_top : (!in_bot || in_top))) continue;
           float add = 0.f;
-          if (top) {                                   // virtual frame -tau mirrors frame tau: taps j <= PAD - tau
+          if (in_top) {                                // virtual frame -tau mirrors frame tau: taps j <= PAD - tau
             const int r0 = 2 * PAD - tau - t0;         // g row of tap 0; tap j reads row r0 - j (frame PAD - tau - j)
             const int jlo = max(max(0, r0 - (ROWS - 1)), PAD - tau - p.T + 1), jhi = min(PAD - tau, r0);
 #pragma unroll 4
             for (int j = jlo; j <= jhi; ++j) add += wl[j][cl] * g[r0 - j][cl];
           }
-          if (tau >= p.T - 1 - PAD) {                   // virtual frame 2(T-1)-tau mirrors frame tau: taps j >= T-1-tau+PAD
+          if (in_bot) {                                // virtual frame 2(T-1)-tau mirrors frame tau: taps j >= T-1-tau+PAD
             const int r0 = 2 * (p.T - 1) - tau + 2 * PAD - t0;   // tap j reads row r0 - j (frame 2(T-1) - tau - j + PAD)
             const int jlo = max(max(0, p.T - 1 - tau + PAD), r0 - (ROWS - 1));
             const int jhi = min(min(K - 1, r0), 2 * (p.T - 1) - tau + PAD);
@@ -547,9 +551,15 @@ __global__ __launch_bounds__(256) void dw_partials_reduce_kernel(const float* __
 
 using namespace smx;
 
-// does the rolling register-window path (dwconv_roll.h) take this call?
-static bool roll_ok(int D, int k, int glu, int pad_mode, int chunk, bool has_gate) {
-  return roll_enabled() && k == 31 && chunk <= 0 && glu && !has_gate && pad_mode == SMX_PAD_ZERO && D % 64 == 0;
+// does a rolling register-window path (dwconv_roll.h) take this call?  1 = GLU + zero padding (bf16 and fp32),
+// 2 = CSGU gate + reflect padding (bf16)
+static int roll_kind(int dtype, int T, int D, int k, int glu, int pad_mode, int chunk, bool has_gate) {
+  if (!roll_enabled() || k != 31 || chunk > 0 || D % 64 != 0) return 0;
+  if (glu && !has_gate && pad_mode == SMX_PAD_ZERO) return 1;
+  static int csgu = -1;
+  if (csgu < 0) { const char* e = getenv("SMX_DWROLL_CSGU"); csgu = (e && e[0] == '0') ? 0 : 1; }
+  if (csgu && !glu && has_gate && pad_mode == SMX_PAD_REFLECT && dtype == SMX_BF16 && T > 15) return 2;
+  return 0;
 }
 
 extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
@@ -568,12 +578,18 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
   const int vw = dtype == SMX_BF16 ? 8 : 4;
   const bool fast = k == 31 && chunk <= 0 && D % vw == 0 && ldp % vw == 0 && ldy % vw == 0 && aligned16(P) && aligned16(Y) &&
                     (gate == nullptr || (ldg % vw == 0 && aligned16(gate))) && (pad_mode == SMX_PAD_ZERO || T > 15);
-  if (roll_ok(D, k, glu, pad_mode, chunk, gate != nullptr)) {
-    SMX_REQUIRE((long)T * (ldp > ldy ? ldp : ldy) * 4 < (1L << 31), "smx_dwconv1d_glu_fwd: utterance span >= 2 GB (SMX_DWROLL=0 selects the tiled kernel)");
+  int rk = roll_kind(dtype, T, D, k, glu, pad_mode, chunk, gate != nullptr);
+  // the bf16 kernels move 16-byte pieces (LDS-DMA in, dwordx4 out): rows and bases must be 16-byte aligned, else tiled
+  if (rk && dtype == SMX_BF16 && !(ldp % 8 == 0 && ldy % 8 == 0 && aligned16(P) && aligned16(Y) &&
+                                   (gate == nullptr || (ldg % 8 == 0 && aligned16(gate))))) rk = 0;
+  if (rk) {
+    const long ldmax = ldp > ldy ? (ldp > ldg ? ldp : ldg) : (ldy > ldg ? ldy : ldg);
+    SMX_REQUIRE((long)T * ldmax * 4 < (1L << 31), "smx_dwconv1d_glu_fwd: utterance span >= 2 GB (SMX_DWROLL=0 selects the tiled kernel)");
     int seg, nseg, gy;
     roll_geometry(B, T, D, &seg, &nseg, &gy);
     dim3 g1((unsigned)(8 * (D / 64) * ((gy + 7) / 8)));
-    if (dtype == SMX_BF16) hipLaunchKernelGGL(dwconv_rolls_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
+    if (rk == 2) hipLaunchKernelGGL(dwconv_rollc_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
+    else if (dtype == SMX_BF16) hipLaunchKernelGGL(dwconv_rolls_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
     else hipLaunchKernelGGL((dwconv_roll_fwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gy);
   } else if (fast) {
     if (gate) {
@@ -596,9 +612,10 @@ static long tiled_rows(int B, int T, int D) {
   return gy;
 }
 
-extern "C" int smx_dwconv1d_glu_bwd_partial_rows(int B, int T, int D, int k, int glu, int pad_mode, int chunk, int has_gate) {
+extern "C" int smx_dwconv1d_glu_bwd_partial_rows(int dtype, int B, int T, int D, int k, int glu, int pad_mode, int chunk,
+                                                 int has_gate) {
   if (B <= 0 || T <= 0 || D <= 0) return 0;
-  if (roll_ok(D, k, glu, pad_mode, chunk, has_gate != 0)) {
+  if (roll_kind(dtype, T, D, k, glu, pad_mode, chunk, has_gate != 0)) {
     int seg, nseg, gy;
     roll_geometry(B, T, D, &seg, &nseg, &gy);
     return gy;
@@ -643,16 +660,25 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
                     aligned16(P) && aligned16(dY) && aligned16(dP) && workspace != nullptr &&
                     (gate == nullptr || (ldg % vw == 0 && lddg % vw == 0 && aligned16(gate) && aligned16(dgate))) &&
                     (pad_mode == SMX_PAD_ZERO || T > 15);
-  if (workspace != nullptr && roll_ok(D, k, glu, pad_mode, chunk, gate != nullptr)) {
-    SMX_REQUIRE((long)T * (ldp > lddp ? (ldp > lddy ? ldp : lddy) : (lddp > lddy ? lddp : lddy)) * 4 < (1L << 31),
-                "smx_dwconv1d_glu_bwd: utterance span >= 2 GB (SMX_DWROLL=0 selects the tiled kernel)");
+  int rk = workspace ? roll_kind(dtype, T, D, k, glu, pad_mode, chunk, gate != nullptr) : 0;
+  if (rk && dtype == SMX_BF16 && !(ldp % 8 == 0 && lddy % 8 == 0 && lddp % 8 == 0 && aligned16(P) && aligned16(dY) && aligned16(dP) &&
+                                   (gate == nullptr || (ldg % 8 == 0 && lddg % 8 == 0 && aligned16(gate) && aligned16(dgate))))) rk = 0;
+  if (rk) {
+    long ldmax = ldp > lddp ? (ldp > lddy ? ldp : lddy) : (lddp > lddy ? lddp : lddy);
+    if (ldg > ldmax) ldmax = ldg;
+    if (lddg > ldmax) ldmax = lddg;
+    SMX_REQUIRE((long)T * ldmax * 4 < (1L << 31), "smx_dwconv1d_glu_bwd: utterance span >= 2 GB (SMX_DWROLL=0 selects the tiled kernel)");
     int seg, nseg, gr;
     roll_geometry(B, T, D, &seg, &nseg, &gr);
     float* partial = reinterpret_cast<float*>(workspace);
     dim3 g1((unsigned)(8 * (D / 64) * ((gr + 7) / 8)));
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("SMX_DWROLL_ABLATE"); abl = e ? atoi(e) : 0; }
-    if (dtype != SMX_BF16) hipLaunchKernelGGL((dwconv_roll_bwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+    if (rk == 2) {
+      hipLaunchKernelGGL(dwconv_rollc_bwd, g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+      // the gradient of the mirrored virtual frames goes back to frames 1..15 / T-16..T-2 (30 rows per utterance)
+      hipLaunchKernelGGL(dwconv_csgu_fold_kernel, dim3((unsigned)((D / 2 + 63) / 64), (unsigned)B), dim3(64), 0, s, p);
+    } else if (dtype != SMX_BF16) hipLaunchKernelGGL((dwconv_roll_bwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
     else if (abl == 1) hipLaunchKernelGGL((dwconv_rolls_bwd<1>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
     else if (abl == 2) hipLaunchKernelGGL((dwconv_rolls_bwd<2>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
     else hipLaunchKernelGGL((dwconv_rolls_bwd<0>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);

@@ -448,6 +448,262 @@ __global__ __launch_bounds__(256) void dwconv_rolls_bwd(DwParams p, int seg, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// CSGU (Branchformer cgMLP): y = (conv_reflect(v) + bias) * gate, bf16, same per-wave rolling structure.  The reflect padding
+// is a row MAP applied to the DMA source (frame -r reads frame r, frame T-1+r reads frame T-1-r), so the window simply holds
+// the padded signal.  Backward: dgate = dY * (conv(v) + bias) (forward recomputed from the window), c = dY * gate,
+// dv = conv^T(c) for the real frames; the gradient that the mirrored virtual frames send back to frames 1..15 and
+// T-16..T-2 is added by dwconv_csgu_fold_kernel afterwards (30 rows per utterance).
+// ---------------------------------------------------------------------------------------------------------------------
+// 16 rows r0 .. r0+15 mirrored into [0, T) (rows still outside: zeros)
+__device__ __forceinline__ void rw_dma16_reflect(__amdgpu_buffer_rsrc_t rs, unsigned char* dst, unsigned vcol, int vrow, int r0,
+                                                 int Tn, unsigned ldb) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int r = r0 + 8 * k + vrow;
+    r = r < 0 ? -r : (r >= Tn ? 2 * (Tn - 1) - r : r);
+    const unsigned off = (r >= 0 && r < Tn) ? (unsigned)r * ldb + vcol : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (rw_lds_vp)(dst + 1024 * k), 16, off, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_rollc_fwd(DwParams p, int seg, int nseg, int gy) {
+  constexpr int K = 31, WIN = 46, SLOT = 4096, OUT = 2 * SLOT, WAVE = OUT + 2048;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][WAVE];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int iy, bx;
+  rw_map(p.D / 64, iy, bx);
+  const int item = iy * 4 + wv;
+  if (iy >= gy || item >= p.B * nseg) return;
+  const int b = item / nseg, t_lo = (item % nseg) * seg, t_hi = min(p.T, t_lo + seg);
+  const int nsteps = (t_hi - t_lo + RW_STEP - 1) / RW_STEP;
+  const int ch = bx * 64 + lane;
+  float w[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) w[j] = p.w[(long)ch * K + j];
+  const float bs = p.bias ? p.bias[ch] : 0.f;
+  bf16_t* Pb = const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.P)) + (long)b * p.T * p.ldp;
+  bf16_t* Gb = const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.gate)) + (long)b * p.T * p.ldg;
+  bf16_t* Yb = reinterpret_cast<bf16_t*>(p.Y) + (long)b * p.T * p.ldy;
+  const unsigned ldpb = (unsigned)p.ldp * 2, ldgb = (unsigned)p.ldg * 2, ldyb = (unsigned)p.ldy * 2;
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pb, (short)0, (int)(p.T * ldpb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(Gb, (short)0, (int)(p.T * ldgb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb, (short)0, (int)(p.T * ldyb), 0x00020000);
+  const unsigned vcol = (unsigned)(lane & 7) * 16 + (unsigned)bx * 128;
+  const int vrow = lane >> 3;
+  const unsigned vpg = (unsigned)vrow * ldgb + vcol, vpy = (unsigned)vrow * ldyb + vcol;
+  unsigned char* st = stage[wv];
+  float win[WIN];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) win[i] = 0.f;
+  // ring slot s & 1: [v rows t_lo + 15 + 16 s ..][gate rows t_lo + 16 s .. (the step's OUTPUT frames)]
+  auto dma = [&](int s) {
+    unsigned char* d = st + (s & 1) * SLOT;
+    rw_dma16_reflect(rP, d, vcol, vrow, t_lo + 15 + s * RW_STEP, p.T, ldpb);
+    rw_dma16(rG, d + 2048, vpg, t_lo + s * RW_STEP, ldgb);
+  };
+  dma(-2);
+  dma(-1);
+  for (int s = -2; s < nsteps; ++s) {
+    rw_wait_vm(s < 0 ? 4 : (s >= 2 ? 2 : 0) + (s + 1 < nsteps ? 4 : 0) + (s >= 1 ? 2 : 0));
+    const unsigned char* sl = st + (s & 1) * SLOT + lane * 2;
+    float gt[RW_STEP];
+#pragma unroll
+    for (int i = 0; i < RW_STEP; ++i) { win[30 + i] = rw_lds_bf16(sl, i * 128); gt[i] = rw_lds_bf16(sl, 2048 + i * 128); }
+    rw_lgkm0();
+    if (s + 2 < nsteps) dma(s + 2);
+    if (s >= 0) {
+      unsigned short* ob = reinterpret_cast<unsigned short*>(st + OUT) + lane;
+#pragma unroll
+      for (int o = 0; o < RW_STEP; ++o) {
+        float acc = bs;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
+        ob[o * 64] = (unsigned short)f32_to_bf16_bits(acc * gt[o]);
+      }
+      asm volatile("" ::: "memory");
+      const unsigned s0 = (unsigned)(t_lo + s * RW_STEP) * ldyb;
+      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const u32v4 v = *reinterpret_cast<const u32v4*>(st + OUT + k * 1024 + lane * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rY, vpy + s0 + k * 8 * ldyb, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < WIN - RW_STEP; ++i) win[i] = win[i + RW_STEP];
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_rollc_bwd(DwParams p, int seg, int nseg, int gy, float* __restrict__ partial) {
+  constexpr int K = 31, WIN = 47, SLOT = 6144, OUT = 2 * SLOT, WAVE = OUT + 4096;
+  __shared__ float wl[K][64];
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][WAVE];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int iy, bx;
+  rw_map(p.D / 64, iy, bx);
+  if (iy >= gy) return;
+  const int ch = bx * 64 + lane;
+  for (int j = wv; j < K; j += 4) wl[j][lane] = p.w[(long)ch * K + j];
+  __syncthreads();
+  const int item = iy * 4 + wv;
+  float dw[K], dbs = 0.f;
+#pragma unroll
+  for (int j = 0; j < K; ++j) dw[j] = 0.f;
+  if (item < p.B * nseg) {
+    const int b = item / nseg, t_lo = (item % nseg) * seg, t_hi = min(p.T, t_lo + seg);
+    const int nsteps = (t_hi - t_lo + RW_STEP - 1) / RW_STEP;
+    const float bs = p.bias ? p.bias[ch] : 0.f;
+    bf16_t* Pb = const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.P)) + (long)b * p.T * p.ldp;       // v
+    bf16_t* Gb = const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(p.gate)) + (long)b * p.T * p.ldg;
+    bf16_t* Yb = reinterpret_cast<bf16_t*>(p.Y) + (long)b * p.T * p.ldy;                                    // dY
+    bf16_t* Ob = reinterpret_cast<bf16_t*>(p.dP) + (long)b * p.T * p.lddp;                                  // dv
+    bf16_t* Qb = reinterpret_cast<bf16_t*>(p.dgate) + (long)b * p.T * p.lddg;
+    const unsigned ldpb = (unsigned)p.ldp * 2, ldgb = (unsigned)p.ldg * 2, ldyb = (unsigned)p.ldy * 2;
+    const unsigned ldob = (unsigned)p.lddp * 2, ldqb = (unsigned)p.lddg * 2;
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pb, (short)0, (int)(p.T * ldpb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(Gb, (short)0, (int)(p.T * ldgb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(Yb, (short)0, (int)(p.T * ldyb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(Ob, (short)0, (int)(p.T * ldob), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(Qb, (short)0, (int)(p.T * ldqb), 0x00020000);
+    const unsigned vcol = (unsigned)(lane & 7) * 16 + (unsigned)bx * 128;
+    const int vrow = lane >> 3;
+    const unsigned vpd = (unsigned)vrow * ldyb + vcol, vpgt = (unsigned)vrow * ldgb + vcol;
+    const unsigned vo = (unsigned)vrow * ldob + vcol, vq = (unsigned)vrow * ldqb + vcol;
+    unsigned char* st = stage[wv];
+    float vw[WIN], cw[WIN], dyp[RW_STEP];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) { vw[i] = 0.f; cw[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < RW_STEP; ++i) dyp[i] = 0.f;
+    // window row i at step s is frame t_lo + 16 s - 15 + i (vw: the reflect-padded v, cw: c = dY * gate, zero outside the
+    // utterance); outputs = rows 15..30 = the frames that arrived one step earlier
+    auto dma = [&](int s) {
+      unsigned char* d = st + (s & 1) * SLOT;
+      const int r0 = t_lo + (s + 1) * RW_STEP;
+      rw_dma16(rY, d, vpd, r0, ldyb);
+      rw_dma16(rG, d + 2048, vpgt, r0, ldgb);
+      rw_dma16_reflect(rP, d + 4096, vcol, vrow, r0, p.T, ldpb);
+    };
+    dma(-2);
+    dma(-1);
+    for (int s = -2; s < nsteps; ++s) {
+      rw_wait_vm(s < 0 ? 6 : (s >= 2 ? 4 : 0) + (s + 1 < nsteps ? 6 : 0) + (s >= 1 ? 4 : 0));
+      const unsigned char* sl = st + (s & 1) * SLOT + lane * 2;
+      float dyn[RW_STEP];
+#pragma unroll
+      for (int i = 0; i < RW_STEP; ++i) {
+        dyn[i] = rw_lds_bf16(sl, i * 128);
+        cw[31 + i] = dyn[i] * rw_lds_bf16(sl, 2048 + i * 128);
+        vw[31 + i] = rw_lds_bf16(sl, 4096 + i * 128);
+      }
+      rw_lgkm0();
+      if (s + 2 < nsteps) dma(s + 2);
+      if (s >= 0) {
+        float du[RW_STEP], cv[RW_STEP];
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) { du[o] = 0.f; cv[o] = bs; }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const float wj = wl[j][lane];
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o) { du[o] += wj * cw[30 + o - j]; cv[o] += wj * vw[o + j]; }
+        }
+        unsigned short* ob = reinterpret_cast<unsigned short*>(st + OUT) + lane;
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) {
+          ob[o * 64] = (unsigned short)f32_to_bf16_bits(du[o]);
+          ob[1024 + o * 64] = (unsigned short)f32_to_bf16_bits(dyp[o] * cv[o]);
+        }
+        asm volatile("" ::: "memory");
+        const int r0 = t_lo + s * RW_STEP;
+        typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const u32v4 v1 = *reinterpret_cast<const u32v4*>(st + OUT + k * 1024 + lane * 16);
+          const u32v4 v2 = *reinterpret_cast<const u32v4*>(st + OUT + 2048 + k * 1024 + lane * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v1, rO, vo + (unsigned)(r0 + 8 * k) * ldob, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v2, rQ, vq + (unsigned)(r0 + 8 * k) * ldqb, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int i = 0; i < RW_STEP; ++i) dyp[i] = dyn[i];
+      if (s >= 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o) sacc += cw[15 + o] * vw[o + j];
+          dw[j] += sacc;
+        }
+#pragma unroll
+        for (int o = 0; o < RW_STEP; ++o) dbs += cw[15 + o];
+      }
+#pragma unroll
+      for (int i = 0; i < WIN - RW_STEP; ++i) { vw[i] = vw[i + RW_STEP]; cw[i] = cw[i + RW_STEP]; }
+    }
+  }
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(&stage[0][0]);
+#pragma unroll
+  for (int j = 0; j < K; ++j) red[wv * 2112 + lane * 33 + j] = dw[j];
+  red[wv * 2112 + lane * 33 + K] = dbs;
+  __syncthreads();
+  float* out = partial + ((long)iy * p.D + bx * 64) * (K + 1);
+  for (int idx = threadIdx.x; idx < 64 * (K + 1); idx += 256) {
+    const int a = (idx >> 5) * 33 + (idx & 31);
+    out[idx] = ((red[a] + red[2112 + a]) + red[2 * 2112 + a]) + red[3 * 2112 + a];
+  }
+}
+
+// The gradient the mirrored virtual frames send back (T >= 16), c = dY * gate:
+//   top:    dv[tau]         += sum_{j=0}^{15-tau} w_j      c[15 - tau - j]        tau = 1..15   (virtual frame -tau)
+//   bottom: dv[T-1-kk]      += sum_{m=0}^{15-kk}  w_{15+kk+m} c[T-1-m]            kk  = 1..15   (virtual frame T-1+kk)
+// One thread owns two adjacent channels of one utterance and does both edges one after the other (for T < 31 a frame can
+// receive both terms): 30 rows of c, 30 taps, 2 x 120 FMAs, 30 read-modify-writes of 4 bytes.
+__global__ __launch_bounds__(64) void dwconv_csgu_fold_kernel(DwParams p) {
+  constexpr int K = 31;
+  const int c2 = (blockIdx.x * 64 + threadIdx.x) * 2, b = blockIdx.y;
+  if (c2 >= p.D) return;
+  const bf16_t* dY = reinterpret_cast<const bf16_t*>(p.Y) + (long)b * p.T * p.ldy + c2;
+  const bf16_t* G = reinterpret_cast<const bf16_t*>(p.gate) + (long)b * p.T * p.ldg + c2;
+  bf16_t* dV = reinterpret_cast<bf16_t*>(p.dP) + (long)b * p.T * p.lddp + c2;
+  auto ld2 = [](const bf16_t* q, float& lo, float& hi) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(q);
+    lo = bf16_bits_to_f32(u & 0xffffu); hi = bf16_bits_to_f32(u >> 16);
+  };
+#pragma unroll 1
+  for (int edge = 0; edge < 2; ++edge) {
+    float c0[15], c1[15], w0[15], w1[15];
+#pragma unroll
+    for (int m = 0; m < 15; ++m) {
+      const long t = edge == 0 ? m : p.T - 1 - m;          // c row m of this edge
+      float y0, y1, g0, g1;
+      ld2(dY + t * p.ldy, y0, y1);
+      ld2(G + t * p.ldg, g0, g1);
+      c0[m] = y0 * g0; c1[m] = y1 * g1;
+      const int j = edge == 0 ? m : 16 + m;                 // taps 0..14 (top) / 16..30 (bottom)
+      w0[m] = p.w[(long)c2 * K + j]; w1[m] = p.w[(long)(c2 + 1) * K + j];
+    }
+#pragma unroll
+    for (int q = 1; q <= 15; ++q) {                        // q = tau (top) or kk (bottom)
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int m = 0; m <= 15 - q; ++m) {
+        // top: tap j = m, row 15 - q - m;  bottom: tap 15 + q + m = w[..][q - 1 + m], row m
+        const int wi = edge == 0 ? m : q - 1 + m, ci = edge == 0 ? 15 - q - m : m;
+        a0 += w0[wi] * c0[ci]; a1 += w1[wi] * c1[ci];
+      }
+      bf16_t* o = dV + (long)(edge == 0 ? q : p.T - 1 - q) * p.lddp;
+      float o0, o1;
+      ld2(o, o0, o1);
+      *reinterpret_cast<uint32_t*>(o) = pack_bf16x2(o0 + a0, o1 + a1);
+    }
+  }
+}
+
 // time segment per wave: 128 frames (8 steps; 30 halo rows = 1.23x) unless that leaves the chip short of waves
 inline void roll_geometry(int B, int T, int D, int* seg, int* nseg, int* gy) {
   static int forced = -1;

@@ -780,7 +780,7 @@ def dwconv_bwd_deferred(dy, p_, wd, bd, gwd, gbd, B, T, D, k, glu, pad_mode, chu
     dp, dg, deferred = ops.dwconv_bwd(dy, p_, wd, bd, gwd, gbd, B, T, D, k, glu, pad_mode, chunk, gate=gate, dgate_out=dgate_out,
                                       ws=ws)
     if deferred:
-        rows = L.lib().smx_dwconv1d_glu_bwd_partial_rows(B, T, D, k, 1 if glu else 0, pad_mode, chunk, int(gate is not None))
+        rows = L.lib().smx_dwconv1d_glu_bwd_partial_rows(L.BF16 if dy.dtype == torch.bfloat16 else L.F32, B, T, D, k, 1 if glu else 0, pad_mode, chunk, int(gate is not None))
         _Deferred.jobs.append((ws.data_ptr(), gwd.data_ptr(), D * (k + 1), k, rows, D, k, 1.0, k + 1))
         if gbd is not None:
             _Deferred.jobs.append((ws.data_ptr() + 4 * k, gbd.data_ptr(), D * (k + 1), 1, rows, D, 1, 1.0, k + 1))

@@ -179,7 +179,9 @@ def test_glu_dwconv_fwd_bwd(B, T, D, k, chunk, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
-@pytest.mark.parametrize("B,T,D,k", [(2, 90, 48, 7), (2, 150, 64, 31), (1, 40, 16, 31), (3, 129, 72, 31)])
+@pytest.mark.parametrize("B,T,D,k", [(2, 90, 48, 7), (2, 150, 64, 31), (1, 40, 16, 31), (3, 129, 72, 31),
+                                     # D % 64 == 0, k = 31, bf16: the rolling CSGU kernels + edge-fold kernel (dwconv_roll.h)
+                                     (4, 250, 128, 31), (2, 31, 64, 31), (3, 16, 64, 31), (2, 47, 192, 31), (16, 250, 1536, 31)])
 def test_gated_reflect_dwconv_fwd_bwd(B, T, D, k, dtype, tol):
     """Branchformer CSGU form: y = gate * conv_reflect(x)  (k=31 takes the register-window fast path)."""
     L, ops = _ops()
