@@ -564,9 +564,15 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             sbar = _dense_pool_fwd(s, B, T, Wn)
 
         if mode == "SummaryMixing-lite":
-            y3 = ops.cast(sbar, dtype).unsqueeze(1).expand(B, T, sdim)            # stride-0 view like :308
+            if res is None:
+                y3 = ops.cast(sbar, dtype).unsqueeze(1).expand(B, T, sdim)        # stride-0 view like :308
+            else:                                                                 # inside an encoder layer: res + summary
+                yb = torch.empty((N, sdim), dtype=dtype, device=dev)
+                ops.bcast_rows(sbar, None, yb, B, T)
+                y3 = ops.axpby(1.0, res, 1.0, yb).view(B, T, sdim)
 
-            def bwd_lite(dy3):
+            def bwd_lite(dy3, dz_in=None):
+                assert dz_in is None
                 dy = ops.rows2d(dy3.contiguous())
                 dsbar, _ = ops.masked_mean(dy, None, B, T, scale=False)            # sum over time
                 SP.all_reduce_sum(dsbar)                                           # (sequence-parallel: over all shards)
@@ -909,7 +915,8 @@ def _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual,
     if not need_bwd:
         return y, None
 
-    def bwd(dy):
+    def bwd(dy, dz_in=None, second=None):
+        assert dz_in is None and second is None       # (no `pre` attribute: the caller keeps its elementwise passes)
         da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr)
         dc = ln2_b(da)
         dce = torch.zeros((B, Te, d), dtype=dtype, device=x.device)       # the halo outputs were dropped: zero gradient

@@ -41,6 +41,36 @@ def test_conformer_layer_golden(name, dtype):
         assert rel_err(params[k].grad, g) <= gtol, (k, rel_err(params[k].grad, g))
 
 
+@pytest.mark.parametrize("mode", ["SummaryMixing", "SummaryMixing-fast", "SummaryMixing-lite", "SummaryMixing-expdecay"])
+def test_conformer_layer_every_cell_mode_matches_oracle(mode):
+    """The layer adds the cell's output to its residual stream inside the cell's last kernel (`res`): every mode, the
+    summary-only lite mode included, must agree with the oracle on the output and on dL/dx (fp32, ragged lengths)."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoderLayer
+    torch.manual_seed(5)
+    d, B, T = 64, 3, 37
+    layer = ConformerEncoderLayer(d_model=d, d_ffn=128, nhead=2, kernel_size=31, activation="swish", dropout=0.0,
+                                  attention_type="SummaryMixing", local_proj_hid_dim=[d], local_proj_out_dim=d,
+                                  summary_hid_dim=[d], mode=mode)
+    with torch.no_grad():
+        for p_ in layer.parameters():
+            if p_.dim() > 1:
+                torch.nn.init.xavier_normal_(p_)
+    layer = layer.cuda().eval()
+    sd = {k: v.detach().double().cpu() for k, v in layer.state_dict().items()}
+    x = torch.randn(B, T, d)
+    pad = torch.arange(T)[None] < torch.tensor([T, 20, 29])[:, None]
+    r = torch.randn(B, T, d)
+    xr = x.double().requires_grad_(True)
+    yr = O.conformer_layer(xr, sd, "", "swish", mode, d, None, pad)
+    (yr * r.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y, _ = layer(xg, src_key_padding_mask=pad.cuda())
+    (y * r.cuda()).sum().backward()
+    assert rel_err(y, yr) <= 1e-4, rel_err(y, yr)
+    assert rel_err(xg.grad, xr.grad) <= 1e-3, rel_err(xg.grad, xr.grad)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_branchformer_layer_golden(dtype):
     from summarymixing_amd.lobes.models.transformer.Branchformer import BranchformerEncoderLayer
