@@ -471,9 +471,12 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
     output (Conformer `x + skip`, Conformer.py:530) -- its gradient is returned by bwd as a second value."""
     mode, act, l = cfg["mode"], cfg["act"], cfg["local_proj_out_dim"]
 
-    def run(x3, need_bwd, res=None, ln_next=None):
+    def run(x3, need_bwd, res=None, ln_next=None, out=None, out_drop=None):
         """ln_next = (gamma, beta, eps) of the LayerNorm that follows the cell output: run in the merge GEMM's epilogue where
-        possible; a third value (LN(y), stats) | None is then returned."""
+        possible; a third value (LN(y), stats) | None is then returned.
+        out / out_drop = (p, seed): the caller applies dropout to the cell output and wants it in a (N, s_out) view of its own
+        buffer (the Branchformer's merge input): both ride in the merge GEMM's epilogue, and the backward takes the dropout
+        backward into its first pass (not for the lite mode)."""
         dtype = x3.dtype
         x = ops.rows2d(x3)
         N = x.shape[0]
@@ -530,7 +533,17 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             local = None
             sv_l = sv_g = None
         else:
-            local, sv_l = mlp_fwd(x, P["local_proj"], act, mask, need_bwd, dtype)
+            lp = P["local_proj"]
+            lw_ = lp[-1]["W"].shape[0] if lp[-1]["kind"] == "linear" else 0
+            if p_drop > 0.0 and lw_ and lw_ % 8 == 0 and _sdim() % 8 == 0:
+                # training: the local projection's last Linear writes D(local) straight into the merge input
+                # cat = [D(local) | D(repeat(sbar))] (summary_mixing.py:237-239): its dropout rides in the GEMM epilogue
+                s1 = ops.new_dropout_seed()
+                cat = torch.empty((N, lw_ + _sdim()), dtype=dtype, device=dev)
+                local, sv_l = mlp_fwd(x, lp, act, mask, need_bwd, dtype, last_drop=(p_drop, s1), last_out=cat[:, :lw_])
+                cat_has_local = True
+            else:
+                local, sv_l = mlp_fwd(x, lp, act, mask, need_bwd, dtype)
             s, sv_s = mlp_fwd(x, P["summary_proj"], act, mask, need_bwd, dtype)
             sv_g = None
         sdim = s.shape[1]
@@ -603,17 +616,19 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 ops.dropout(sbar, p_drop, s2, out=cat[:, lw:])
             sbar_t = None
             lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(cat, Wm.shape[0], ln_next)) else None
-            y, zm = linear_fwd(cat, Wm, mg["b"], act, None, res=res, save_z=need_bwd, ln_next=lnn, ln_post=post)
+            y, zm = linear_fwd(cat, Wm, mg["b"], act, None, res=res, save_z=need_bwd, ln_next=lnn, ln_post=post, out=out,
+                               drop=out_drop)
         elif pool_kind == "mean":
             sbar_t = ops.cast(sbar, dtype)                                         # (B, sdim) in compute dtype
             c0, _ = linear_fwd(sbar_t, Ws, None, out_f32=True)                     # (B, s_out) fp32
             lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(local, Wl.shape[0], ln_next)) else None
             y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_GROUP, c0_div=T,
-                               save_z=need_bwd, ln_next=lnn, ln_post=post)
+                               save_z=need_bwd, ln_next=lnn, ln_post=post, out=out, drop=out_drop)
         else:
             sbar_t = sbar
             c0, _ = linear_fwd(sbar, Ws, None, out_f32=True)                       # (N, s_out) fp32
-            y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_ROW, save_z=need_bwd)
+            y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_ROW, save_z=need_bwd, out=out,
+                               drop=out_drop)
         y3 = y.view(B, T, -1)
         post = post[0] if post else None
         if not need_bwd:
@@ -624,7 +639,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             backward in the epilogue of the cell's input dgrad (linear_bwd(ln=...)); then 2-D tensors come back: the
             gradient w.r.t. that LayerNorm's input (+ ln_res), or the pair with the second output.
             dz_in: dy * act'(zm) already computed by the producer of dy (see `pre`)."""
-            dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+            dy = ops.rows2d(dy3) if out_drop is not None else ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
             s_out = dy.shape[1]
             gWm, gbm = gacc(mg["W"]), gacc(mg["b"])
             # buffer that receives [dlocal | ds] for the fast mode (one dg for the fused projection)
@@ -673,7 +688,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                         ops.act_mask_bwd(dzm, None, None, L.ACT_NONE, 1.0, None, gbm)
                 else:
                     dzm = torch.empty((N, s_out), dtype=dtype, device=dev)
-                    ops.act_mask_bwd(dy, zm, None, act, 1.0, dzm, None if wb else gbm)
+                    ops.act_mask_bwd(dy, zm, None, act, 1.0, dzm, None if wb else gbm, drop=out_drop)
                 if gWm is not None:
                     _wgrad(dzm, cat, gWm, N, s_out, lw + sdim, gbm if wb else None)
                 if fuse_local:
@@ -697,7 +712,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             elif pool_kind == "mean":
                 _, dzm = linear_bwd(dy if dz_in is None else dz_in, local, Wl, zm, act, None, 1.0,
                                     gWm[:, :lw] if gWm is not None else None, gbm, True, None, dx_out=dlocal_out, up=up_local,
-                                    dz_ready=dz_in is not None)
+                                    dz_ready=dz_in is not None, drop=out_drop)
                 # per-utterance sums of dZ (the gradient of the C0 side input) through the fixed-order pool kernel: the
                 # fused variant (smx_act_mask_bwd dgroup) adds with fp32 atomics, i.e. not bit-reproducibly
                 dc0, _ = ops.masked_mean(dzm, None, B, T, scale=False)
@@ -710,7 +725,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             else:
                 _, dzm = linear_bwd(dy if dz_in is None else dz_in, local, Wl, zm, act, None, 1.0,
                                     gWm[:, :lw] if gWm is not None else None, gbm, True, None, dx_out=dlocal_out, up=up_local,
-                                    dz_ready=dz_in is not None)
+                                    dz_ready=dz_in is not None, drop=out_drop)
                 if gWm is not None:      # dW_s += dzm^T sbar
                     ops.wgrad(dzm, sbar_t, gWm[:, lw:], N, s_out, sdim)
                 dsb = torch.empty((N, sdim), dtype=dtype, device=dev)

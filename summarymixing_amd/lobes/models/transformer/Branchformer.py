@@ -108,7 +108,17 @@ class BranchformerEncoderLayer(nn.Module):
             dev = x.device
             # branch 1: SummaryMixing(LN(x))
             h1, bn1 = F.ln_fwd(x, nm.weight, nm.bias, nm.eps, need)
-            y1_3, bcell = cell(h1.view(B, T, d), need)
+            # training: the dropout of the cell's output (:279) and its placement in the merge input ride in the cell's last
+            # GEMM epilogue (and the dropout backward in the cell's first backward pass)
+            fuse_y1 = pd > 0.0 and self.mode != "SummaryMixing-lite"
+            cat = sd1 = None
+            if fuse_y1:
+                c1 = self.mha_layer._params()["summary_local_merging"][0]["W"].shape[0]
+                cat = torch.empty((N, c1 + d), dtype=dtype, device=dev)
+                sd1 = ops.new_dropout_seed()
+                y1_3, bcell = cell(h1.view(B, T, d), need, out=cat[:, :c1], out_drop=(pd, sd1))
+            else:
+                y1_3, bcell = cell(h1.view(B, T, d), need)
             y1 = ops.rows2d(y1_3.contiguous() if y1_3.stride(1) == 0 else y1_3)
             c1 = y1.shape[1]
             # branch 2: cgMLP(LN(x))
@@ -122,12 +132,15 @@ class BranchformerEncoderLayer(nn.Module):
             wd = Pb["wd"].detach().reshape(n, k)
             g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1)
             # both branches land in one (N, c1 + d) buffer = the merge input (no torch.cat)
-            cat = torch.empty((N, c1 + d), dtype=dtype, device=dev)
-            sd1 = sd2 = sd3 = sd4 = None
+            if cat is None:
+                cat = torch.empty((N, c1 + d), dtype=dtype, device=dev)
+            sd2 = sd3 = sd4 = None
             if pd > 0.0:                                    # dropout on both branches and on the merge (:279,295,334)
-                sd1, sd2, sd3, sd4 = (ops.new_dropout_seed() for _ in range(4))
+                if not fuse_y1:
+                    sd1 = ops.new_dropout_seed()
+                    ops.dropout(y1, pd, sd1, out=cat[:, :c1])
+                sd2, sd3, sd4 = (ops.new_dropout_seed() for _ in range(3))
                 ops.dropout(g, pd, sd4, out=g)              # the CSGU's own dropout on x1 * conv(x2) (upstream CSGU.forward)
-                ops.dropout(y1, pd, sd1, out=cat[:, :c1])
             else:
                 ops.axpby(1.0, y1, out=cat[:, :c1])
             F.linear_fwd(g, Wpost, Pb["bpost"], out=cat[:, c1:], drop=(pd, sd2) if pd > 0.0 else None)   # Linear + dropout
@@ -149,7 +162,7 @@ class BranchformerEncoderLayer(nn.Module):
                 else:
                     dcat = F.mlp_bwd(ops.dropout(dy, pd, sd3) if pd > 0.0 else dy, merge, act, sv_m, dtype)
                 # the cell's gradient: a contiguous (N, c1) copy either way, the dropout backward rides in it
-                d1 = ops.dropout(dcat[:, :c1], pd, sd1) if pd > 0.0 else dcat[:, :c1].contiguous()
+                d1 = dcat[:, :c1] if fuse_y1 else (ops.dropout(dcat[:, :c1], pd, sd1) if pd > 0.0 else dcat[:, :c1].contiguous())
                 # branch 2 backward (the dropout backward of its half rides in linear_bwd's activation/mask pass)
                 dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
                                      drop=(pd, sd2) if pd > 0.0 else None, dx_drop=(pd, sd4) if pd > 0.0 else None)
