@@ -677,6 +677,13 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                         ops.bcast_rows_act_bwd(dsbar_, inv, ds_out, B, T, z_g[:, l:] if z_g is not None else None, mk_g, act)
                         sum_done = True
                         return
+                elif mode != "SummaryMixing-fast" and P["summary_proj"][-1]["kind"] == "linear":
+                    # full / expdecay modes: the same for the last layer of summary_proj (its mlp_bwd then starts from dZ)
+                    z_s, mk_s = sv_s[-1][1], sv_s[-1][2]
+                    if z_s is not None or mk_s is not None:
+                        ops.bcast_rows_act_bwd(dsbar_, inv, ds_out, B, T, z_s, mk_s, act if z_s is not None else L.ACT_NONE)
+                        sum_done = True
+                        return
                 ops.bcast_rows(dsbar_, inv, ds_out, B, T)
             if p_drop > 0.0:
                 # dgrad of the K = l + s merge as two GEMMs over the column halves of W: the dropout backward of each half
@@ -749,7 +756,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 dx = mlp_bwd(dg, P["global_proj"], act, sv_g, dtype, dz_ready=fuse_local)
             else:
                 dx = mlp_bwd(dlocal_out, P["local_proj"], act, sv_l, dtype, dz_ready=fuse_local)
-                dx = mlp_bwd(ds_out, P["summary_proj"], act, sv_s, dtype, res_grad=dx)
+                dx = mlp_bwd(ds_out, P["summary_proj"], act, sv_s, dtype, res_grad=dx, dz_ready=sum_done)
             return dx.view(B, T, -1)
         bwd.can_fuse_ln = (mode == "SummaryMixing-fast" and len(P["global_proj"]) == 1 and P["global_proj"][0]["kind"] == "linear")
         # what the cell does first to its incoming gradient: dy * act'(zm) (a producer that can, writes it as a second output)
