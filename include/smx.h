@@ -248,6 +248,12 @@ int smx_layernorm_bwd2(int dtype, const void* dY, int64_t lddy, const void* X, i
 int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
                          const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k, int glu,
                          int pad_mode, int chunk, void* stream);
+/* Same with an inverted dropout of the output fused in (mask index = global row * D + channel, as smx_dropout on Y):
+ * the CSGU's own dropout (upstream ConvolutionalSpatialGatingUnit.forward).  Only the rolling CSGU kernel carries it
+ * (bf16, k = 31, gate, reflect padding, D % 64 == 0, aligned rows); SMX_EUNSUPPORTED otherwise - run smx_dropout. */
+int smx_dwconv1d_glu_fwd_drop(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
+                              const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k, int glu,
+                              int pad_mode, int chunk, float drop_p, uint64_t drop_seed, void* stream);
 /* dP (same shape as P), dw/dbias += ; dgate optional (= dY * conv).  workspace: smx_dwconv1d_glu_bwd_workspace bytes
  * (per-block partial tap gradients of the fast path, reduced in a fixed order; NULL selects the generic kernel).
  * dw == NULL (and dbias == NULL): the partial rows [smx_dwconv1d_glu_bwd_partial_rows][D][k+1] (taps, then the bias term)

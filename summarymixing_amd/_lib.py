@@ -96,6 +96,8 @@ SIGNATURES = {
                                  c_vp, c_i, c_i, c_vp, c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp]),
     "smx_dwconv1d_glu_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_vp]),
+    "smx_dwconv1d_glu_fwd_drop": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i,
+                                        c_i, c_i, c_f, ctypes.c_uint64, c_vp]),
     "smx_dwconv1d_glu_bwd_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_dwconv1d_glu_bwd_partial_rows": (c_i, [c_i] * 9),
     "smx_dwconv1d_glu_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,

@@ -23,6 +23,7 @@ struct DwParams {
   void* dgate; long lddg;
   float* dw; float* dbias;
   int B, T, D, k, glu, pad_mode, chunk;
+  unsigned dthresh; float dscale; uint64_t dseed; const uint64_t* epoch;   // fused dropout of the output (rolling CSGU forward only)
 };
 
 __device__ __forceinline__ int map_frame(int tau, int T, int pad_mode) {
@@ -562,9 +563,26 @@ static int roll_kind(int dtype, int T, int D, int k, int glu, int pad_mode, int 
   return 0;
 }
 
+static int dwconv_fwd_impl(int dtype, const void* P, int64_t ldp, const float* w, const float* bias, const void* gate, int64_t ldg,
+                           void* Y, int64_t ldy, int B, int T, int D, int k, int glu, int pad_mode, int chunk, float drop_p,
+                           uint64_t drop_seed, void* stream);
+
 extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
                                     const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k,
                                     int glu, int pad_mode, int chunk, void* stream) {
+  return dwconv_fwd_impl(dtype, P, ldp, w, bias, gate, ldg, Y, ldy, B, T, D, k, glu, pad_mode, chunk, 0.f, 0, stream);
+}
+
+extern "C" int smx_dwconv1d_glu_fwd_drop(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
+                                         const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k,
+                                         int glu, int pad_mode, int chunk, float drop_p, uint64_t drop_seed, void* stream) {
+  SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_dwconv1d_glu_fwd_drop: 0 <= drop_p < 1");
+  return dwconv_fwd_impl(dtype, P, ldp, w, bias, gate, ldg, Y, ldy, B, T, D, k, glu, pad_mode, chunk, drop_p, drop_seed, stream);
+}
+
+static int dwconv_fwd_impl(int dtype, const void* P, int64_t ldp, const float* w, const float* bias, const void* gate, int64_t ldg,
+                           void* Y, int64_t ldy, int B, int T, int D, int k, int glu, int pad_mode, int chunk, float drop_p,
+                           uint64_t drop_seed, void* stream) {
   SMX_REQUIRE(P && w && Y, "smx_dwconv1d_glu_fwd: null pointer");
   SMX_REQUIRE(k >= 1 && k <= DW_KMAX && (k & 1), "smx_dwconv1d_glu_fwd: k=%d must be odd and <= %d", k, DW_KMAX);
   SMX_REQUIRE(pad_mode != SMX_PAD_REFLECT || (k - 1) / 2 < T, "smx_dwconv1d_glu_fwd: reflect pad needs (k-1)/2 < T");
@@ -588,9 +606,15 @@ extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const
     int seg, nseg, gy;
     roll_geometry(B, T, D, &seg, &nseg, &gy);
     dim3 g1((unsigned)(8 * (D / 64) * ((gy + 7) / 8)));
-    if (rk == 2) hipLaunchKernelGGL(dwconv_rollc_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
+    if (drop_p > 0.f && rk != 2) return fail(SMX_EUNSUPPORTED, "smx_dwconv1d_glu_fwd_drop: fused output dropout needs the rolling CSGU kernel");
+    if (rk == 2) {
+      p.dthresh = (unsigned)((double)drop_p * 4294967296.0); p.dscale = 1.f / (1.f - drop_p); p.dseed = drop_seed; p.epoch = g_step_counter;
+      hipLaunchKernelGGL(dwconv_rollc_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
+    }
     else if (dtype == SMX_BF16) hipLaunchKernelGGL(dwconv_rolls_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
     else hipLaunchKernelGGL((dwconv_roll_fwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gy);
+  } else if (drop_p > 0.f) {
+    return fail(SMX_EUNSUPPORTED, "smx_dwconv1d_glu_fwd_drop: fused output dropout needs the rolling CSGU kernel");
   } else if (fast) {
     if (gate) {
       if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_fwd_fast<bf16_t, 31, true>), grid, dim3(256), 0, s, p);

@@ -492,6 +492,8 @@ __global__ __launch_bounds__(256) void dwconv_rollc_fwd(DwParams p, int seg, int
   const unsigned vcol = (unsigned)(lane & 7) * 16 + (unsigned)bx * 128;
   const int vrow = lane >> 3;
   const unsigned vpg = (unsigned)vrow * ldgb + vcol, vpy = (unsigned)vrow * ldyb + vcol;
+  const uint32_t dthresh = p.dthresh;
+  const uint64_t dseed = dthresh ? epoch_seed(p.dseed, p.epoch) : 0;
   unsigned char* st = stage[wv];
   float win[WIN];
 #pragma unroll
@@ -519,7 +521,12 @@ __global__ __launch_bounds__(256) void dwconv_rollc_fwd(DwParams p, int seg, int
         float acc = bs;
 #pragma unroll
         for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
-        ob[o * 64] = (unsigned short)f32_to_bf16_bits(acc * gt[o]);
+        float yv = acc * gt[o];
+        if (dthresh) {                                   // the CSGU's own dropout: mask index = global row * D + channel
+          const uint64_t idx = ((uint64_t)b * p.T + (uint64_t)(t_lo + s * RW_STEP + o)) * (uint64_t)p.D + ch;
+          yv = dropout_keep(dseed, idx, dthresh) ? yv * p.dscale : 0.f;
+        }
+        ob[o * 64] = (unsigned short)f32_to_bf16_bits(yv);
       }
       asm volatile("" ::: "memory");
       const unsigned s0 = (unsigned)(t_lo + s * RW_STEP) * ldyb;

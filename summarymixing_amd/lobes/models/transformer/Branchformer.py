@@ -130,17 +130,19 @@ class BranchformerEncoderLayer(nn.Module):
             v, bnv = F.ln_fwd(u2, Pb["ln_w"], Pb["ln_b"], 1e-5, need)
             k = Pb["wd"].shape[-1]
             wd = Pb["wd"].detach().reshape(n, k)
-            g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1)
+            # (the CSGU's own dropout on x1 * conv(x2), upstream CSGU.forward, rides in the kernel where it can)
+            sd4 = ops.new_dropout_seed() if pd > 0.0 else None
+            g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1,
+                               drop=(pd, sd4) if pd > 0.0 else None)
             # both branches land in one (N, c1 + d) buffer = the merge input (no torch.cat)
             if cat is None:
                 cat = torch.empty((N, c1 + d), dtype=dtype, device=dev)
-            sd2 = sd3 = sd4 = None
+            sd2 = sd3 = None
             if pd > 0.0:                                    # dropout on both branches and on the merge (:279,295,334)
                 if not fuse_y1:
                     sd1 = ops.new_dropout_seed()
                     ops.dropout(y1, pd, sd1, out=cat[:, :c1])
-                sd2, sd3, sd4 = (ops.new_dropout_seed() for _ in range(3))
-                ops.dropout(g, pd, sd4, out=g)              # the CSGU's own dropout on x1 * conv(x2) (upstream CSGU.forward)
+                sd2, sd3 = (ops.new_dropout_seed() for _ in range(2))
             else:
                 ops.axpby(1.0, y1, out=cat[:, :c1])
             F.linear_fwd(g, Wpost, Pb["bpost"], out=cat[:, c1:], drop=(pd, sd2) if pd > 0.0 else None)   # Linear + dropout

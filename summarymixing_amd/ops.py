@@ -6,6 +6,8 @@ views ``(rows, cols)`` with unit stride along cols; the row stride is the leadin
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -352,14 +354,23 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     return dx if second is None else (dx, dx2)
 
 
-def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None):
+def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None, drop=None):
+    """drop = (p, seed): inverted dropout of the output (the CSGU's own), fused where the kernel can (rolling CSGU path),
+    else a separate in-place smx_dropout with the same mask."""
     y = torch.empty((B * T, D), dtype=p.dtype, device=p.device)
     pp, ldp = _mat(p)
     pg, ldg = (_mat(gate) if gate is not None else (None, 0))
     tok = _pb(f"dwconv_fwd ({B},{T},{D}) k={k}", 3 * B * T * D * _es(p))
-    L.check(L.lib().smx_dwconv1d_glu_fwd(dt(p), pp, ldp, _p(w), _p(bias), pg, ldg, _p(y), D, B, T, D, k, 1 if glu else 0,
-                                         pad_mode, chunk, _stream()), "smx_dwconv1d_glu_fwd")
+    fused = False
+    if drop is not None and drop[0] > 0.0 and os.environ.get("SMX_CSGU_DROP_FUSE", "1") != "0":
+        fused = L.lib().smx_dwconv1d_glu_fwd_drop(dt(p), pp, ldp, _p(w), _p(bias), pg, ldg, _p(y), D, B, T, D, k, 1 if glu else 0,
+                                                  pad_mode, chunk, drop[0], drop[1], _stream()) == 0
+    if not fused:
+        L.check(L.lib().smx_dwconv1d_glu_fwd(dt(p), pp, ldp, _p(w), _p(bias), pg, ldg, _p(y), D, B, T, D, k, 1 if glu else 0,
+                                             pad_mode, chunk, _stream()), "smx_dwconv1d_glu_fwd")
     _pe(tok)
+    if drop is not None and drop[0] > 0.0 and not fused:
+        dropout(y, drop[0], drop[1], out=y)
     return y
 
 

@@ -135,6 +135,30 @@ def test_fused_epilogue_dropout_equals_standalone_kernel():
     assert rel_err(dz, dz2) < 1e-6
 
 
+def test_csgu_fused_output_dropout_equals_standalone_kernel():
+    """The rolling CSGU forward applies the CSGU's own dropout to its output: same mask as smx_dropout on the result
+    (index = global row * D + channel), values equal up to the one bf16 rounding the separate pass adds."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(2)
+    B, T, D, k = 4, 250, 128, 31
+    x = torch.randn(B * T, D, device="cuda").bfloat16()
+    gate = torch.randn(B * T, D, device="cuda").bfloat16()
+    w = torch.randn(D, k, device="cuda") * 0.3
+    bias = torch.randn(D, device="cuda")
+    y1 = ops.dwconv_fwd(x, w, bias, B, T, D, k, False, L.PAD_REFLECT, 0, gate, drop=(0.15, 99))
+    y0 = ops.dwconv_fwd(x, w, bias, B, T, D, k, False, L.PAD_REFLECT, 0, gate)
+    ops.dropout(y0, 0.15, 99, out=y0)
+    assert torch.equal(y1 == 0, y0 == 0) and 0.13 < (y1 == 0).float().mean().item() < 0.17
+    assert rel_err(y1, y0) < 1e-2
+    # a shape the rolling kernel does not take: the wrapper falls back to the separate pass with the same mask
+    D2 = 48
+    x2, g2 = x[:, :D2].contiguous(), gate[:, :D2].contiguous()
+    a = ops.dwconv_fwd(x2, w[:D2].contiguous(), bias[:D2].contiguous(), B, T, D2, k, False, L.PAD_REFLECT, 0, g2, drop=(0.15, 5))
+    b = ops.dwconv_fwd(x2, w[:D2].contiguous(), bias[:D2].contiguous(), B, T, D2, k, False, L.PAD_REFLECT, 0, g2)
+    ops.dropout(b, 0.15, 5, out=b)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("kind", ["conformer", "branchformer"])
 def test_training_mode_gradients_match_finite_differences(kind):
     """With the dropout seeds pinned (counter reset before every call) a training-mode layer is a deterministic, piecewise
