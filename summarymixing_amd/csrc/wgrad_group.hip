@@ -253,13 +253,29 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
 }
 
 static int wg_splits(int rows, int total_tiles) {
+  // K slices per tile: tiles * s workgroups run in rounds of one per CU, so the choice is a quantisation problem: 23 tiles
+  // (C2b layer) x 11 = 253 fills one round; 92 tiles (d_model 512) x 2 = 184 leaves 28 % of the chip idle, x 3 = 276 needs a
+  // second round for 20 workgroups, x 8 = 736 fills 2.9 rounds (C2a step 49.4 -> 48.7 ms).  Every extra slice costs one more
+  // fp32 slab per tile (written, read back by smx_reduce_jobs): score = fill of the last round - 1 % per slice.
   static const int target_env = getenv("SMX_WGROUP_BLOCKS") ? atoi(getenv("SMX_WGROUP_BLOCKS")) : 0;
-  const int target = target_env > 0 ? target_env : 256;           // one workgroup per CU
-  int s = target / (total_tiles > 0 ? total_tiles : 1);
+  if (total_tiles < 1) total_tiles = 1;
   const int nk = rows / 64;
   const int smax = nk / 8 > 0 ? nk / 8 : 1;                        // at least 8 K steps (512 frames) per slice
-  if (s > smax) s = smax;
-  return s < 1 ? 1 : s;
+  if (target_env > 0) {
+    int s = target_env / total_tiles;
+    if (s > smax) s = smax;
+    return s < 1 ? 1 : s;
+  }
+  const int cus = 256;
+  int best = 1;
+  double best_score = -1.0;
+  for (int s = 1; s <= smax && (long)s * total_tiles <= 4L * cus; ++s) {
+    const long w = (long)s * total_tiles;
+    const double fill = (double)w / (double)(((w + cus - 1) / cus) * cus);
+    const double score = fill - 0.01 * s;
+    if (score > best_score + 1e-9) { best_score = score; best = s; }
+  }
+  return best;
 }
 
 }  // namespace smx
