@@ -45,7 +45,7 @@ struct WgGroupParams {
   WgItem it[WG_MAX_ITEMS];
   int nitems, total_tiles, splits, ksteps_per_split, rows;   // rows: multiple of 64 (the host peels the tail)
   int pingpong;         // SMX_WGROUP_PP: 1 = upper four waves refill before their MFMAs, lower four after; 2 = + a mid-step barrier
-  int ablate;           // debug (env SMX_WGROUP_ABLATE): 1 = no MFMA / fragment reads, 2 = no DMA, 4 = DMA never waited for
+  int ablate;           // debug (env SMX_WGROUP_ABLATE): 1 = no MFMA / fragment reads, 2 = no DMA, 4 = DMA never waited for, 8 = no X pieces
   long long* dbg;       // debug (smx_debug_set_timing_buffer): per workgroup [total cycles, cycles in wait+barrier, realtime ticks, niter]
 };
 
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
 #pragma unroll
     for (int j = J0; j < J0 + NJ; ++j) {
       wg_glds16(pa[j], dst + j * 8192);
-      wg_glds16(pb[j], dst + OP_BYTES + j * 8192);
+      if (!(p.ablate & 8)) wg_glds16(pb[j], dst + OP_BYTES + j * 8192);      // (8: no B pieces - is the DMA rate the bound?)
       pa[j] += stepa;
       pb[j] += stepb;
     }

@@ -10,7 +10,8 @@ from summarymixing_amd import functional as F  # noqa: E402
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 64000
 which = sys.argv[2] if len(sys.argv) > 2 else "layer"
 shapes = {"layer": [(1024, 256), (256, 1024), (1024, 256), (256, 1024), (512, 256), (256, 512), (512, 256), (256, 256)],
-          "one": [(1024, 256)]}[which]
+          "one": [(1024, 256)],
+          "c2a": [(2048, 512), (512, 2048), (2048, 512), (512, 2048), (1024, 512), (512, 1024), (1024, 512), (512, 512)]}[which]
 ops_ = [((torch.randn(rows, M, device="cuda") * 0.5).bfloat16(), torch.randn(rows, K, device="cuda").bfloat16(),
          torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")) for M, K in shapes]
 for _ in range(8):
