@@ -13,6 +13,16 @@ if layout == "NT":
     y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16); z = torch.empty_like(y); b = torch.randn(M, device="cuda")
     e = ops.epilogue(bias=b, act=L.ACT_SWISH, z=z)
     fn = lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e)
+elif layout == "NNag":     # dgrad with the fused activation backward + dropout (the FFN's dz1 = (dy W2) * act'(z1))
+    w = (torch.randn(K, M, device="cuda") * 0.05).bfloat16(); y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+    zin = torch.randn(N, M, device="cuda").bfloat16()
+    e = ops.epilogue(act=L.ACT_SWISH, act_grad_z=zin, drop=(0.15, 1234))
+    fn = lambda: ops.gemm(L.GEMM_NN, x, w, y, N, M, K, e)
+elif layout == "NTd":      # up-projection with dropout
+    w = (torch.randn(M, K, device="cuda") * 0.05).bfloat16()
+    y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16); z = torch.empty_like(y); b = torch.randn(M, device="cuda")
+    e = ops.epilogue(bias=b, act=L.ACT_SWISH, z=z, drop=(0.15, 77))
+    fn = lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e)
 elif layout == "NN":
     w = (torch.randn(K, M, device="cuda") * 0.05).bfloat16(); y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
     fn = lambda: ops.gemm(L.GEMM_NN, x, w, y, N, M, K)
