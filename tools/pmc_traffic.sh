@@ -31,3 +31,8 @@ run "pool f32  (8,30000,512) masked_sum_stage1 [algorithmic 491.8 MB]" masked_su
 run "gemm NT bf16 (64000x256)x(256x1024)+bias+swish+Z = bench.py roofline kernel [algorithmic 295.4 MB: 33.3 read, 262.1 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NT 64000 256 1024
 run "gemm NT bf16 (32000x256)x(256x1024)+bias+swish+Z [algorithmic 147.9 MB: 16.9 read, 131.1 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NT 32000 256 1024
 run "gemm NT bf16 (32000x512)x(512x2048)+bias+swish+Z [algorithmic 297.0 MB: 34.9 read, 262.1 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NT 32000 512 2048
+run "gemm NN bf16 (64000x256)x(256x1024) +actgrad(z)+drop [algorithmic 295.4 MB: 164.3 read, 131.1 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NNag 64000 256 1024
+run "gemm NN bf16 64000x1024 . 1024x256 plain dgrad, no LayerNorm epilogue [algorithmic 164.4 MB: 131.6 read, 32.8 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NN 64000 1024 256
+run "gemm NT bf16 64000x1024 . 1024x256 +bias+res+drop, no LayerNorm epilogue [algorithmic 197.1 MB: 164.4 read, 32.8 write]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTres 64000 1024 256
+run "dwconv_bwd (128,500,256) k=31 [algorithmic 163.8 MB: 98.3 read, 65.5 write]" dwconv_rolls_bwd python3 "$ROOT/tools/one_dwconv.py"
+run "dwconv_fwd (128,500,256) k=31 [algorithmic 98.3 MB: 65.5 read, 32.8 write]" dwconv_rolls_fwd python3 "$ROOT/tools/one_dwconv.py"
