@@ -760,7 +760,7 @@ static int launch_dtype(int layout, GemmParams& p, bool vec, hipStream_t s) {
 
 using namespace smx;
 
-static long long* g_dbg_stamps = nullptr;
+long long* g_dbg_stamps = nullptr;   // (also read by ffn.hip)
 extern "C" void smx_debug_set_timing_buffer(void* p) { g_dbg_stamps = reinterpret_cast<long long*>(p); }
 
 static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,
