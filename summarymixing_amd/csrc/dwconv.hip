@@ -686,7 +686,13 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
                     (pad_mode == SMX_PAD_ZERO || T > 15);
   int rk = workspace ? roll_kind(dtype, T, D, k, glu, pad_mode, chunk, gate != nullptr) : 0;
   if (rk && dtype == SMX_BF16 && !(ldp % 8 == 0 && lddy % 8 == 0 && lddp % 8 == 0 && aligned16(P) && aligned16(dY) && aligned16(dP) &&
-                                   (gate == nullptr || (ldg % 8 == 0 && lddg % 8 == 0 && aligned16(gate) && aligned16(dgate))))) rk = 0;
+                                   (gate == nullptr || (ldg % 8 == 0 && lddg % 8 == 0 && aligned16(gate) && aligned16(dgate))))) {
+    // misaligned bf16 operands drop to the tiled kernel, which writes tiled_rows() partial rows - not the rolling count that
+    // smx_dwconv1d_glu_bwd_partial_rows (it sees no pointers) reports for these sizes: a deferred reduction would fold the
+    // wrong number of rows.  Deferred mode therefore refuses; the caller reduces immediately.
+    if (!dw) return fail(SMX_EUNSUPPORTED, "smx_dwconv1d_glu_bwd: deferred reduction needs 16-byte aligned bf16 rows on the rolling path");
+    rk = 0;
+  }
   if (rk) {
     long ldmax = ldp > lddp ? (ldp > lddy ? ldp : lddy) : (lddp > lddy ? lddp : lddy);
     if (ldg > ldmax) ldmax = ldg;

@@ -195,10 +195,15 @@ __device__ __forceinline__ uint32_t mix32_1(uint32_t x) {
 #endif
   return x;
 }
+// mix32_1's first multiply reads only the low 24 bits of x ^ (x >> 16): bits 24-31 of the pair index reach it only through
+// bits 8-15, so pairs i and i ^ 0x02000200 (elements 2^25 + 2^10 apart - inside one 64000 x 1024 hidden tensor) hashed
+// identically.  The top byte of the pair index is therefore folded into the per-group word through its own
+// multiply (one v_lshrrev + v_mul_u32_u24 + v_xor per GROUP of NV elements; a group never straddles a 2^24 pair boundary).
+__device__ __forceinline__ uint32_t pair_hi_mix(uint32_t pair_lo) { return __umul24(pair_lo >> 24, 0x9e3779u); }
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
   // one 32-bit hash serves the two elements of an (even, odd) index pair, 16 bits each: P(drop) = (thresh>>16)/65536
   const uint64_t pair = idx >> 1;
-  const uint32_t h = mix32_1((uint32_t)pair ^ mix32((uint32_t)(pair >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+  const uint32_t h = mix32_1((uint32_t)pair ^ mix32((uint32_t)(pair >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) ^ pair_hi_mix((uint32_t)pair));
   const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
   return r >= (thresh >> 16);
 }
@@ -209,7 +214,7 @@ template <int NV>
 __device__ __forceinline__ void dropout_apply(float (&v)[NV], uint64_t seed, uint64_t idx0, uint32_t thresh, float scale) {
   static_assert(NV % 2 == 0, "whole (even, odd) pairs");
   const uint64_t pair0 = idx0 >> 1;
-  const uint32_t hm = mix32((uint32_t)(pair0 >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32);
+  const uint32_t hm = mix32((uint32_t)(pair0 >> 32) + (uint32_t)seed) ^ (uint32_t)(seed >> 32) ^ pair_hi_mix((uint32_t)pair0);
   const uint32_t t16 = thresh >> 16, p0 = (uint32_t)pair0;
 #pragma unroll
   for (int q2 = 0; q2 < NV / 2; ++q2) {

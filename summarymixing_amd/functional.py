@@ -97,15 +97,23 @@ class _Deferred:
     group_min_rows = 2048
 
 
+def _evict_workspaces():
+    """Gradient buffers keep being re-allocated at new addresses: drop the stale workspaces (and the tables that name them).
+    Only called between producers - never while a group launch is being assembled (an eviction from inside
+    _launch_groups dropped the only references to workspaces already attached to the launch's items)."""
+    flush_deferred()
+    _Deferred.ws.clear()
+    _Deferred.cache.clear()
+
+
 def deferred_ws(key, nbytes, device, check=True):
-    """Persistent workspace of one producer call site (keyed by the gradient buffer it feeds)."""
+    """Persistent workspace of one producer call site (keyed by the gradient buffer it feeds).  check=False (the grouped
+    wgrad assembling its items): no flush, no eviction - the caller did both before it started."""
     if check and key in _Deferred.pending:
         flush_deferred()                       # the same parameter twice inside one block: reduce the first use now
     t = _Deferred.ws.get(key)
-    if t is None and len(_Deferred.ws) >= 2048:           # gradient buffers keep being re-allocated at new addresses:
-        flush_deferred()                                   # drop the stale workspaces (and the tables that name them)
-        _Deferred.ws.clear()
-        _Deferred.cache.clear()
+    if check and t is None and len(_Deferred.ws) >= 2048:
+        _evict_workspaces()
         _Deferred.pending.add(key)
     if t is None or t.numel() < nbytes or t.device != device:
         t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
@@ -124,6 +132,8 @@ def _launch_groups():
     """The recorded weight gradients of this block: one smx_wgrad_group launch per (frame count, <= 16 weights); rows
     beyond the last multiple of 64 frames go through the ordinary wgrad; slabs / bias partials become reduction jobs."""
     recs, _Deferred.group = _Deferred.group, []
+    if len(_Deferred.ws) + len(recs) >= 2048:             # eviction check ONCE, before any workspace is attached to an item
+        _evict_workspaces()                               # (the group list is already detached: this folds the earlier producers' jobs only)
     by_n = {}
     for r in recs:
         by_n.setdefault(r[4], []).append(r)
@@ -244,9 +254,16 @@ def block(x, run, params, on_bwd_done=None):
 # ----------------------------------------------------------------------------------------------------
 # Linear (+bias +act +mask +residual +side input) forward / backward on 2-D row views
 # ----------------------------------------------------------------------------------------------------
-def ln_next_ok(x, M, ln_next):
-    """Can the LayerNorm that follows a Linear (its output: N x M) ride in that GEMM's epilogue (SMX_EPI_LN_FWD)?"""
-    return (_LN_FUSE and ln_next is not None and x.dtype == torch.bfloat16 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and
+def _vec_ok(*ts):
+    """16-byte aligned base and a leading dimension that keeps every row 16-byte aligned (what the vector kernels need)."""
+    return all(t is None or (t.data_ptr() % 16 == 0 and (t.stride(0) * t.element_size()) % 16 == 0) for t in ts)
+
+
+def ln_next_ok(x, M, ln_next, W=None, res=None):
+    """Can the LayerNorm that follows a Linear (its output: N x M) ride in that GEMM's epilogue (SMX_EPI_LN_FWD)?
+    W / res: the weight (view) and residual the GEMM will be given - a column slice with an odd offset is not 16-byte aligned
+    and the fused instantiation has no scalar path."""
+    return (_LN_FUSE and ln_next is not None and x.dtype == torch.bfloat16 and _vec_ok(x, W, res) and
             L.lib().smx_gemm_ln_fused_ok(L.BF16, x.shape[0], M, x.shape[1]) == 1)
 
 
@@ -277,14 +294,16 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
 _LN_FUSE = os.environ.get("SMX_LN_FUSE", "1") != "0"   # A/B knob: LayerNorm backward / forward inside the GEMM epilogues
 
 
-def ln_fusable(ln_spec, N, K_out, dtype):
-    """Can the LayerNorm (its backward closure's `.spec`) ride in the epilogue of a GEMM with N rows and K_out = the LN width
-    output columns?  (bf16, width 256, no fused activation, deferred parameter reductions on)"""
+def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
+    """Can the LayerNorm (its backward closure's `.spec`) ride in the epilogue of the dgrad GEMM dX (N x K_out) = dZ (N x reduce) W
+    with K_out = the LN width?  (bf16, width 256, deferred parameter reductions on.)  `reduce` is the REAL reduce length of
+    that GEMM - the producing Linear's output width (d_ffn, 2 l, 2 d): the fused instantiation has no ragged-K path, so a width
+    that is not a multiple of 64 must take the standalone LayerNorm kernel (the check used a constant 64)."""
     if not (_LN_FUSE and _Deferred.enabled and ln_spec is not None and dtype == torch.bfloat16):
         return False
     x = ln_spec["x"]
     return (x.shape[1] == K_out and x.shape[0] == N and gacc(ln_spec["gw_param"]) is not None
-            and L.lib().smx_gemm_ln_fused_ok(L.BF16, N, K_out, 64) == 1 and x.data_ptr() % 16 == 0 and x.stride(0) % 8 == 0)
+            and L.lib().smx_gemm_ln_fused_ok(L.BF16, N, K_out, reduce) == 1 and _vec_ok(x, W))
 
 
 def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
@@ -615,13 +634,13 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             else:
                 ops.dropout(sbar, p_drop, s2, out=cat[:, lw:])
             sbar_t = None
-            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(cat, Wm.shape[0], ln_next)) else None
+            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(cat, Wm.shape[0], ln_next, Wm, res)) else None
             y, zm = linear_fwd(cat, Wm, mg["b"], act, None, res=res, save_z=need_bwd, ln_next=lnn, ln_post=post, out=out,
                                drop=out_drop)
         elif pool_kind == "mean":
             sbar_t = ops.cast(sbar, dtype)                                         # (B, sdim) in compute dtype
             c0, _ = linear_fwd(sbar_t, Ws, None, out_f32=True)                     # (B, s_out) fp32
-            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(local, Wl.shape[0], ln_next)) else None
+            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(local, Wl.shape[0], ln_next, Wl, res)) else None
             y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_GROUP, c0_div=T,
                                save_z=need_bwd, ln_next=lnn, ln_post=post, out=out, drop=out_drop)
         else:
@@ -759,6 +778,8 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 dx = mlp_bwd(ds_out, P["summary_proj"], act, sv_s, dtype, res_grad=dx, dz_ready=sum_done)
             return dx.view(B, T, -1)
         bwd.can_fuse_ln = (mode == "SummaryMixing-fast" and len(P["global_proj"]) == 1 and P["global_proj"][0]["kind"] == "linear")
+        if bwd.can_fuse_ln:      # the dgrad that would carry the LayerNorm backward: dX = dG (N x 2l) W_g - what ln_fusable must check
+            bwd.ln_reduce, bwd.ln_W = P["global_proj"][0]["W"].shape[0], wcast(P["global_proj"][0]["W"], dtype)
         # what the cell does first to its incoming gradient: dy * act'(zm) (a producer that can, writes it as a second output)
         bwd.pre = (1.0, None, None, zm, act) if (zm is not None and act != L.ACT_NONE) else None
         return (y3, bwd, post) if ln_next is not None else (y3, bwd)
@@ -782,8 +803,9 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None, pre=None):
         this gradient (its `pre` attribute) - written from the same registers instead of by a separate pass."""
         gw = gacc(wp).view(-1) if wp is not None else gacc(w)
         gb = gacc(bp).view(-1) if bp is not None else gacc(b)
-        if second is not None and x.shape[1] > 2048:
-            second = None
+        wide2 = None
+        if second is not None and x.shape[1] > 2048:       # the fused second output exists for D <= 2048: do it in separate
+            wide2, second = second, None                   # passes, but ALWAYS return the pair the caller unpacks (ADVICE r02)
         if _Deferred.enabled and gw is not None and gb is not None:
             N, D = x.shape
             ws = deferred_ws(gw.data_ptr(), L.lib().smx_layernorm_bwd_workspace(N, D), x.device)
@@ -791,8 +813,14 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None, pre=None):
             nb = L.lib().smx_layernorm_bwd_blocks(N)
             defer(ws.data_ptr(), gw, 2 * D, nb, 1, D)
             defer(ws.data_ptr() + 4 * D, gb, 2 * D, nb, 1, D)
-            return dx
-        return ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act, dx_out=out, second=second)
+        else:
+            dx = ops.layernorm_bwd(dy, x, w.detach(), b.detach(), stats, gw, gb, res, act, dx_out=out, second=second)
+        if wide2 is not None:
+            a2, m2, d2 = wide2[:3]
+            dx2 = ops.dropout(dx, d2[0], d2[1]) if (d2 is not None and d2[0] > 0.0) else dx
+            dx2 = ops.act_mask_bwd(dx2, None, m2, L.ACT_NONE, a2, torch.empty_like(dx)) if (m2 is not None or a2 != 1.0 or dx2 is dx) else dx2
+            return dx, dx2
+        return dx
     # what a dgrad GEMM needs to run this backward in its own epilogue (linear_bwd(ln=...))
     bwd.spec = {"x": x, "w": w, "b": b, "stats": stats, "act": act, "gw_param": wp if wp is not None else w,
                 "gb_param": bp if bp is not None else b}
@@ -827,7 +855,7 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
     d2 = (p, ops.new_dropout_seed()) if p > 0.0 else None
     a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1)
     post = []
-    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next)) else None
+    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x)) else None
     y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2, ln_next=lnn, ln_post=post)
     post = post[0] if post else None
     if not need_bwd:
@@ -843,7 +871,7 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
         else:
             dz1, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2,
                                 up=(z1, act, None, 1.0, d1, None))
-        if ln_fusable(ln_b.spec, h.shape[0], h.shape[1], dtype):     # the LayerNorm backward rides in the dgrad epilogue
+        if ln_fusable(ln_b.spec, h.shape[0], h.shape[1], dtype, W1.shape[0], W1):     # the LayerNorm backward rides in the dgrad epilogue
             out, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True, res_grad=dy,
                                 ln=ln_b.spec, ln_second=second)
             return out
@@ -870,14 +898,14 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
     Wo = wcast(P["Wo"], dtype)
     dr = (p, ops.new_dropout_seed()) if p > 0.0 else None   # Linear -> Dropout -> * mask (+ x): one epilogue
     post = []
-    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, Wo.shape[0], ln_next)) else None
+    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, Wo.shape[0], ln_next, Wo, x if residual else None)) else None
     y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None, drop=dr, ln_next=lnn, ln_post=post)
     post = post[0] if post else None
     if not need_bwd:
         return (y, None, post) if ln_next is not None else (y, None)
 
     def bwd(dy, dz_in=None, second=None):
-        fuse2 = ln_fusable(ln2_b.spec, a.shape[0], d, dtype)     # LN2 (+ activation) backward in the out-projection's dgrad
+        fuse2 = ln_fusable(ln2_b.spec, a.shape[0], d, dtype, Wo.shape[0], Wo)     # LN2 (+ activation) backward in the out-projection's dgrad
         kw = dict(ln=ln2_b.spec) if fuse2 else {}
         if dz_in is not None:
             da, _ = linear_bwd(dz_in, a, Wo, None, L.ACT_NONE, None, 1.0, gacc(P["Wo"]), gacc(P["bo"]), dz_ready=True, **kw)
@@ -887,7 +915,7 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
         gwd = gacc(P["wd"])
         dp, _ = dwconv_bwd_deferred(dc, p_, wd, P["bd"].detach() if P["bd"] is not None else None, gwd.view(d, k),
                                     gacc(P["bd"]), B, T, d, k, True, L.PAD_ZERO, chunk)
-        if ln_fusable(ln1_b.spec, h.shape[0], d, dtype):
+        if ln_fusable(ln1_b.spec, h.shape[0], d, dtype, 2 * d, Wp):
             out, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]),
                                 res_grad=dy if residual else None, ln=ln1_b.spec, ln_second=second)
             return out
@@ -895,7 +923,7 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
         return ln1_b(dh, res=dy if residual else None, second=second)
     # what this block does first to its incoming gradient: D(dy) * mask (nothing to precompute without mask and dropout)
     bwd.pre = (1.0, mask, dr) if (mask is not None or dr is not None) else None
-    bwd.ln1_fused = ln_fusable(ln1_b.spec, h.shape[0], d, dtype)   # then `second` may carry (.., z, act) of the consumer
+    bwd.ln1_fused = ln_fusable(ln1_b.spec, h.shape[0], d, dtype, 2 * d, Wp)   # then `second` may carry (.., z, act) of the consumer
     return (y, bwd, post) if ln_next is not None else (y, bwd)
 
 

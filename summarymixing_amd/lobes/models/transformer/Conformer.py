@@ -151,7 +151,7 @@ class ConformerEncoderLayer(nn.Module):
                     d2, d2z = bconv(d3, dz_in=d3z, second=pre_cell)
                 else:
                     d2 = bconv(d3, dz_in=d3z)
-                if getattr(bcell, "can_fuse_ln", False) and F.ln_fusable(bn1.spec, d2.shape[0], d2.shape[1], dtype):
+                if getattr(bcell, "can_fuse_ln", False) and F.ln_fusable(bn1.spec, d2.shape[0], d2.shape[1], dtype, bcell.ln_reduce, bcell.ln_W):
                     # norm1's backward (+ the skip gradient, + FFN1's 1/2 * dropout) in the epilogue of the cell's input dgrad
                     d1, d1z = bcell(d2.view(B, T, -1), ln=bn1.spec, ln_res=d2, ln_second=b1.pre, dz_in=d2z)
                 else:

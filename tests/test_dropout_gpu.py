@@ -30,6 +30,20 @@ def test_dropout_kernel_statistics_and_determinism():
     assert (m.mean(0) - 0.5).abs().max() < 0.06 and (m.mean(1) - 0.5).abs().max() < 0.15
 
 
+def test_dropout_mask_has_no_duplicate_at_pair_distance_0x02000200():
+    """the pair hash read only 24 bits of idx ^ (idx >> 16), so elements 2 * 0x02000200 apart (inside one 64000 x 1024
+    hidden tensor) always shared their keep / drop decision.  With the top index byte folded in they are independent."""
+    from summarymixing_amd import ops
+    N, D = 66000, 1024                                   # 67.6 M elements > 2 * 0x02000200 + margin
+    x = torch.ones(N, D, device="cuda", dtype=torch.bfloat16)
+    m = (ops.dropout(x, 0.5, 4242) != 0).view(-1)
+    dist = 2 * 0x02000200
+    a, b = m[: m.numel() - dist], m[dist:]
+    agree = (a == b).float().mean().item()
+    assert abs(agree - 0.5) < 5e-3, f"masks {dist} elements apart agree {agree:.4f} of the time (0.5 = independent, 1.0 = the old duplicate)"
+    assert abs(m.float().mean().item() - 0.5) < 2e-3
+
+
 @pytest.mark.parametrize("p", [0.15, 0.5])
 @pytest.mark.parametrize("seed", [1234, 0xDEADBEEFCAFEF00D, 77])
 def test_dropout_mask_is_uncorrelated(p, seed):
