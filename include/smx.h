@@ -71,7 +71,13 @@ typedef struct smx_epilogue {
   const uint8_t* ln_mask2; float ln_alpha2; float ln_drop_p2; uint64_t ln_drop_seed2;
   /* SMX_EPI_LN_FWD: a LayerNorm of the (row-complete) output: lnf_y = act(LN(C)), lnf_stats = (mean, rstd) per row */
   const float* lnf_gamma; const float* lnf_beta; void* lnf_y; int64_t lnf_ldy; float* lnf_stats; float lnf_eps; int32_t lnf_act;
+  /* fp32 residual stream (torch autocast semantics: Linear I/O in bf16, the residual adds and LayerNorm inputs in fp32 -
+   * Conformer.py:507,530,532-536): SMX_IO_RES_F32 = `res` is float32 (needs out_mode SMX_OUT_F32: C is the new stream
+   * tensor); SMX_IO_LNX_F32 = `ln_x` (SMX_EPI_LN_BWD) is float32.  lnf_y is dtype T (the next GEMM's input) unless
+   * SMX_IO_LNFY_F32 (the LayerNorm output is itself the stream: the layer-final norm2, Conformer.py:536). */
+  int32_t io_flags;    int32_t pad_;
 } smx_epilogue;
+enum { SMX_IO_RES_F32 = 1, SMX_IO_LNX_F32 = 2, SMX_IO_LNFY_F32 = 4 };
 /* flags.  SMX_EPI_ACT_GRAD turns the epilogue into the BACKWARD of an upstream activation layer: z is then a
  * read-only INPUT (the pre-activation the forward saved) and
  *   C[n,m] = alpha * dropout(v * act'(z[n,m])) * row_mask[n]
@@ -227,6 +233,10 @@ int smx_layernorm_bwd_blocks(int N);
  * fixed order: bit-reproducible, no atomics. */
 int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const float* gamma, const float* beta, void* Y,
                       int64_t ldy, float* stats, int N, int D, float eps, int act, void* stream);
+/* The same with a float32 input X and an output of dtype `dtype` (fp32 residual stream -> bf16 GEMM input), and the
+ * backward with a float32 X (dY, R, dX, dX2 dtype `dtype`): torch.nn.LayerNorm under autocast. */
+int smx_layernorm_fwd_x32(int dtype, const float* X, int64_t ldx, const float* gamma, const float* beta, void* Y,
+                          int64_t ldy, float* stats, int N, int D, float eps, int act, void* stream);
 size_t smx_layernorm_bwd_workspace(int N, int D);
 int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                       const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
@@ -239,6 +249,10 @@ int smx_layernorm_bwd2(int dtype, const void* dY, int64_t lddy, const void* X, i
                        const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
                        int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2,
                        float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream);
+int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, const float* X, int64_t ldx, const float* gamma,
+                           const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
+                           int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2,
+                           float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream);
 
 /* Fused GLU + depthwise Conv1d over time (Conformer.py:131-145,317-325):
  *   u[b,t,c] = P[b,t,c] * sigmoid(P[b,t,D+c]);  Y[b,t,c] = bias[c] + sum_j w[c,j] u[b,t+j-(k-1)/2,c]

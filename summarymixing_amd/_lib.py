@@ -18,6 +18,7 @@ EPI_C0_POST = 1
 EPI_ACT_GRAD = 2
 EPI_LN_BWD = 4
 EPI_LN_FWD = 8
+IO_RES_F32, IO_LNX_F32, IO_LNFY_F32 = 1, 2, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACTS = {"none": ACT_NONE, "identity": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH,
         "leaky_relu": ACT_LEAKY_RELU, "relu": ACT_RELU}
@@ -51,7 +52,8 @@ class Epilogue(ctypes.Structure):
                 ("ln_dx2", c_vp), ("ln_lddx2", c_i64), ("ln_mask2", c_vp), ("ln_alpha2", c_f), ("ln_drop_p2", c_f),
                 ("ln_drop_seed2", ctypes.c_uint64),
                 ("lnf_gamma", c_vp), ("lnf_beta", c_vp), ("lnf_y", c_vp), ("lnf_ldy", c_i64), ("lnf_stats", c_vp),
-                ("lnf_eps", c_f), ("lnf_act", ctypes.c_int32)]
+                ("lnf_eps", c_f), ("lnf_act", ctypes.c_int32),
+                ("io_flags", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/smx.h one to one (tests/test_abi.py checks the export list)
@@ -89,6 +91,9 @@ SIGNATURES = {
     "smx_expdecay_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp]),
     "smx_expdecay_mean_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp]),
     "smx_layernorm_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
+    "smx_layernorm_fwd_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
+    "smx_layernorm_bwd2_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                     c_vp, c_i, c_i, c_vp, c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp]),
     "smx_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
     "smx_layernorm_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                 c_vp, c_i, c_i, c_vp, c_vp]),

@@ -41,6 +41,7 @@ namespace smx {
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0>
 __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
   static_assert(LNF == 0 || (sizeof(T) == 2 && VEC && TILE_M == 256 && TILE_N == 128), "fused LayerNorm: bf16 128 x 256 tile");
+  static_assert(LNF <= 3 || LNF == 5 || LNF == 7, "LNF: 1 / 3 LayerNorm backward (3: extended), 2 forward, +4 = float32 ln_x");
   constexpr int BK = ElemTraits<T>::BK;
   constexpr int WN = TILE_N / 2, WM = TILE_M / 2;
   constexpr int FN = WN / 32, FM = WM / 32;
@@ -384,11 +385,11 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   // LayerNorm fused into the epilogue (LNF; the tile holds whole rows: M == TILE_M == 256): gamma / beta are parked in
   // LDS behind the side vector (requested before the first store of the epilogue, read back without any vmcnt wait)
   float* lng = side + TILE_M + TILE_N;
-  constexpr bool LNB = LNF == 1 || LNF == 3;
+  constexpr bool LNB = (LNF & 3) == 1 || (LNF & 3) == 3;  // (LNF & 4: the LayerNorm input is float32, SMX_IO_LNX_F32)
   float dgam[LNB ? 8 : 1], dbet[LNB ? 8 : 1];
   if constexpr (LNF != 0) {
     lng[t] = (LNB ? e.ln_gamma : e.lnf_gamma)[t];
-    if (LNF == 2 || (LNF == 3 && e.lnf_act != SMX_ACT_NONE)) lng[TILE_M + t] = e.lnf_beta[t];
+    if (LNF == 2 || ((LNF & 3) == 3 && e.lnf_act != SMX_ACT_NONE)) lng[TILE_M + t] = e.lnf_beta[t];
     if constexpr (LNB) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) dgam[q] = dbet[q] = 0.f;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     lds_barrier();
     if (ph < 2) SMX_STAMP(3 + 2 * ph);
     if constexpr (LNB) {                                  // the LayerNorm backward replaces the ordinary epilogue
-      epilogue_phase_lnbwd<T, LNF == 3>(p, smem, lng, n0 + row_in_tile, t, dgam, dbet);
+      epilogue_phase_lnbwd<T, (LNF & 3) == 3, (LNF & 4) != 0>(p, smem, lng, n0 + row_in_tile, t, dgam, dbet);
       continue;
     }
     if (sizeof(T) == 2 && osz == 2) {
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
       else if (VEC && p.epi_simple == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
       else epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     } else if (VEC && p.epi_simple == 1) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+    else if (VEC && p.epi_simple == 2 && sizeof(T) == 2) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     if (e.colsum) {
       // column sums of this phase's outputs (the bias gradient of a fused backward): every item was written back to
@@ -437,7 +439,11 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
         else if (m0 + t < p.M) reinterpret_cast<float*>(e.workspace)[(long)tile_n * p.M + m0 + t] = s;
       }
     }
-    if constexpr (LNF == 2) epilogue_phase_lnfwd<T>(p, smem, lng, n0 + row_in_tile, t);
+    if constexpr (LNF == 2) {
+      // (fp32 output: the items of epilogue_phase are 4 columns wide, a thread re-reads slots other threads wrote back)
+      if (osz == 4) lds_barrier();
+      epilogue_phase_lnfwd<T>(p, smem, lng, n0 + row_in_tile, t);
+    }
     if (ph < 2) SMX_STAMP(4 + 2 * ph);
   }
   if constexpr (LNB) {
@@ -509,6 +515,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     else if (lvl == 2) run_phases(ActTag<2>{}, ActTag<2>{});
     else run_phases(ActTag<2>{}, ActTag<0>{});
   } else if (lvl == 1) run_phases(ActTag<4>{}, ActTag<1>{});
+  else if (lvl == 2 && sizeof(T) == 2) run_phases(ActTag<4>{}, ActTag<2>{});
   else run_phases(ActTag<4>{}, ActTag<0>{});
   }
   SMX_STAMP(7);
@@ -709,12 +716,17 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   if (p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_LN_FWD)) {
     // fused LayerNorm: the tile must hold whole rows -> the 128 x 256 tile, whatever the grid size
     if constexpr (sizeof(T) == 2 && A_KC) {
-      if (vec && p.M == 256 && p.N >= 128 && p.splits == 1 && p.batch == 1 && p.e.out_mode == SMX_OUT_T && !p.e.colsum) {
+      const bool lnb = (p.e.flags & SMX_EPI_LN_BWD) != 0, xf32 = (p.e.io_flags & SMX_IO_LNX_F32) != 0;
+      // (the forward variant may write the new fp32 stream tensor: SMX_OUT_F32; the backward variants emit dtype T)
+      if (vec && p.M == 256 && p.N >= 128 && p.splits == 1 && p.batch == 1 && !p.e.colsum &&
+          (p.e.out_mode == SMX_OUT_T || (!lnb && p.e.out_mode == SMX_OUT_F32))) {
         p.tiles_n = (p.N + 127) / 128;
         p.tiles_m = 1;
-        if ((p.e.flags & SMX_EPI_LN_BWD) && (p.e.lnf_act != SMX_ACT_NONE || p.e.z))
-          hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 3>), dim3(p.tiles_n), dim3(256), 0, s, p);
-        else if (p.e.flags & SMX_EPI_LN_BWD) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 1>), dim3(p.tiles_n), dim3(256), 0, s, p);
+        const bool ext = lnb && (p.e.lnf_act != SMX_ACT_NONE || p.e.z);
+        if (ext && xf32) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 7>), dim3(p.tiles_n), dim3(256), 0, s, p);
+        else if (ext) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 3>), dim3(p.tiles_n), dim3(256), 0, s, p);
+        else if (lnb && xf32) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 5>), dim3(p.tiles_n), dim3(256), 0, s, p);
+        else if (lnb) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 1>), dim3(p.tiles_n), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 128, 256, true, 2>), dim3(p.tiles_n), dim3(256), 0, s, p);
         return check_launch("smx_gemm");
       }
@@ -831,12 +843,18 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   if (p.e.flags & SMX_EPI_ACT_GRAD)
     SMX_REQUIRE(p.e.z && !p.e.res && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
                 "smx_gemm: SMX_EPI_ACT_GRAD needs z (input), no residual, batch == 1, splits == 1");
+  if (p.e.io_flags & SMX_IO_RES_F32)
+    SMX_REQUIRE(p.e.res && p.e.out_mode == SMX_OUT_F32 && !(p.e.flags & (SMX_EPI_ACT_GRAD | SMX_EPI_LN_BWD)) && aligned16(p.e.res) && p.e.ldr % 4 == 0,
+                "smx_gemm: SMX_IO_RES_F32 needs a 16-byte aligned float32 `res`, out_mode SMX_OUT_F32 and no ACT_GRAD / LN_BWD");
+  if (p.e.io_flags & SMX_IO_LNX_F32)
+    SMX_REQUIRE((p.e.flags & SMX_EPI_LN_BWD) && p.e.ln_ldx % 4 == 0, "smx_gemm: SMX_IO_LNX_F32 goes with SMX_EPI_LN_BWD");
   if (p.e.flags & SMX_EPI_LN_BWD)
     SMX_REQUIRE(p.e.ln_x && p.e.ln_stats && p.e.ln_gamma && p.e.ln_partial && !p.e.bias && !p.e.c0 && !p.e.row_mask &&
                 (p.e.z ? (p.e.ln_dx2 && aligned16(p.e.z) && p.e.ldz % 8 == 0) : p.e.act == SMX_ACT_NONE) &&
                 (p.e.lnf_act == SMX_ACT_NONE || p.e.lnf_beta) && p.e.drop_p == 0.f && p.e.alpha == 1.f && aligned16(p.e.ln_x) && p.e.ln_ldx % 8 == 0 &&
                 (!p.e.ln_dx2 || (aligned16(p.e.ln_dx2) && p.e.ln_lddx2 % 8 == 0)) && p.e.ln_drop_p2 >= 0.f && p.e.ln_drop_p2 < 1.f,
                 "smx_gemm: SMX_EPI_LN_BWD takes ln_x / ln_stats / ln_gamma / ln_partial (+ res, ln_dx2) and no other epilogue field");
+  if (p.e.io_flags & SMX_IO_LNFY_F32) SMX_REQUIRE(p.e.flags & SMX_EPI_LN_FWD, "smx_gemm: SMX_IO_LNFY_F32 goes with SMX_EPI_LN_FWD");
   if (p.e.flags & SMX_EPI_LN_FWD)
     SMX_REQUIRE(p.e.lnf_gamma && p.e.lnf_beta && p.e.lnf_y && aligned16(p.e.lnf_y) && p.e.lnf_ldy % 8 == 0 &&
                 !(p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_ACT_GRAD)), "smx_gemm: SMX_EPI_LN_FWD needs lnf_gamma / lnf_beta / lnf_y");

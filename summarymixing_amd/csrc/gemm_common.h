@@ -362,6 +362,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   constexpr int RSTEP = NTHR / CPR;                     // rows covered per pass of the workgroup's threads
   constexpr int NIT = WN / RSTEP;                       // items per thread
   constexpr int SW = CW * (int)sizeof(T) / 4;           // 32-bit words of one side-input item (type T)
+  constexpr int SWR = OSZ == 4 ? CW : SW;               // ... or of a float32 residual item (SMX_IO_RES_F32: fp32 output only)
   typedef typename std::conditional<OSZ == 4, float, T>::type OutT;
   const smx_epilogue& e = p.e;
   const uint32_t dthresh = p.dthresh;
@@ -380,6 +381,9 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   const T* Sb = SIMPLE == 1 ? nullptr
                        : (ag ? reinterpret_cast<const T*>(e.z) : (e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr));
   const long lds_ = ag ? e.ldz : e.ldr;
+  // fp32 residual stream: `res` holds float32 (the new stream tensor C is float32 too, OSZ == 4: same 4-column items)
+  const bool rf32 = OSZ == 4 && SIMPLE != 1 && !ag && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr;
+  const float* Sbf = rf32 ? reinterpret_cast<const float*>(e.res) + (long)bz * p.sC : nullptr;
 
   if constexpr (EVEC) {
     // ---- the element-type side input (residual / saved pre-activation) of ALL the phase's items is requested and
@@ -388,12 +392,29 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
     // have drained, so every such point is a full write-latency bubble - none of them sits between two stores of a
     // kernel without side inputs, one per phase with a residual, one per batch with C0. ----
     constexpr int NB = NIT < 2 ? NIT : 2;
-    uint32_t sw[NIT][SW];
-    if (Sb) {
+    uint32_t sw[NIT][SWR];
+    if (rf32) {
+      if constexpr (OSZ == 4) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+          const int n = min(nbase + r0 + k * RSTEP, p.N - 1);
+          ld_words<SWR>(Sbf + (long)n * lds_ + m, sw[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+#pragma unroll
+          for (int q = 0; q < SWR; ++q) settle(sw[k][q]);
+      }
+    } else if (Sb) {
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         const int n = min(nbase + r0 + k * RSTEP, p.N - 1);
-        ld_words<SW>(Sb + (long)n * lds_ + m, sw[k]);
+        uint32_t w_[SW];
+        ld_words<SW>(Sb + (long)n * lds_ + m, w_);
+#pragma unroll
+        for (int q = 0; q < SW; ++q) sw[k][q] = w_[q];
+#pragma unroll
+        for (int q = SW; q < SWR; ++q) sw[k][q] = 0u;
       }
       // settle INSIDE the branch that loads: afterwards no register is a pending load in the compiler's scoreboard on
       // any path, so it cannot place a (conservative) vmcnt wait between the stores below
@@ -405,7 +426,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
 #pragma unroll
       for (int k = 0; k < NIT; ++k)
 #pragma unroll
-        for (int q = 0; q < SW; ++q) sw[k][q] = 0u;
+        for (int q = 0; q < SWR; ++q) sw[k][q] = 0u;
     }
 #pragma unroll
     for (int kb = 0; kb < NIT; kb += NB) {
@@ -456,7 +477,10 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
       }
       if (ag) {
         float zf[CW];
-        unpack_words<T, CW>(sw[k], zf);
+        { uint32_t w_[SW];
+#pragma unroll
+          for (int q = 0; q < SW; ++q) w_[q] = sw[k][q];
+          unpack_words<T, CW>(w_, zf); }
         switch (e.act) {
           case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, CW>(v, zf); break;
           case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, CW>(v, zf); break;
@@ -482,9 +506,17 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
 #pragma unroll
         for (int q = 0; q < CW; ++q) v[q] *= mk;
       }
-      if (Sb && !ag) {
+      if (rf32) {
+        if constexpr (OSZ == 4) {
+#pragma unroll
+          for (int q = 0; q < CW; ++q) v[q] += __uint_as_float(sw[k][q]);
+        }
+      } else if (Sb && !ag) {
         float rf[CW];
-        unpack_words<T, CW>(sw[k], rf);
+        { uint32_t w_[SW];
+#pragma unroll
+          for (int q = 0; q < SW; ++q) w_[q] = sw[k][q];
+          unpack_words<T, CW>(w_, rf); }
 #pragma unroll
         for (int q = 0; q < CW; ++q) v[q] += rf[q];
       }
@@ -523,7 +555,8 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
         }
         if (dthresh && m + q < p.drop_cols) v = dropout_keep(dseed, (uint64_t)n * p.drop_cols + m + q, dthresh) ? v * dscale : 0.f;
         v *= mkv;
-        if (Sb && !ag) v += to_f32(Sb[(long)n * lds_ + m + q]);
+        if (rf32) v += Sbf[(long)n * lds_ + m + q];
+        else if (Sb && !ag) v += to_f32(Sb[(long)n * lds_ + m + q]);
         if (c0p && c0post) v += c0p[q];
         if (e.colsum) const_cast<float*>(sf)[r * (STG_LD / 4) + c + q] = v;
         if constexpr (OSZ == 4) reinterpret_cast<float*>(Cb)[(long)n * p.ldc + m + q] = v;
@@ -566,13 +599,15 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // (two items at a time: the side inputs of all four would not fit next to the 128 accumulator registers; EXT = the
 // variants with a fused activation of the LayerNorm and / or an activation gradient in the second output - a separate
 // instantiation, they cost ~20 registers the plain one does not have)
-template <typename T, bool EXT>
+// XF32: the LayerNorm input ln_x is float32 (SMX_IO_LNX_F32, fp32 residual stream); everything else stays dtype T
+template <typename T, bool EXT, bool XF32 = false>
 __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const char* smem, const float* lng, int nbase0, int t,
                                                      float (&dgam)[8], float (&dbet)[8]) {
-  constexpr int STG_LD = 256 * 4 + 16, NIT = 2, RSTEP = 8, SW = 8 * (int)sizeof(T) / 4;
+  constexpr int STG_LD = 256 * 4 + 16, NIT = 2, RSTEP = 8, SW = 8 * (int)sizeof(T) / 4, SWX = XF32 ? 8 : SW;
+  typedef typename std::conditional<XF32, float, T>::type XT;
   const smx_epilogue& e = p.e;
   const int c = (t & 31) * 8, r0 = t >> 5;
-  const T* X = reinterpret_cast<const T*>(e.ln_x);
+  const XT* X = reinterpret_cast<const XT*>(e.ln_x);
   const T* R = reinterpret_cast<const T*>(e.res);
   float gam[8];
 #pragma unroll
@@ -587,19 +622,24 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
   const int nbase = nbase0 + half * 16;
   const char* smh = smem + half * 16 * STG_LD;
   // every side input of the phase is requested (and waited for) before its first store
-  uint32_t xw[NIT][SW], rw[NIT][SW];
+  uint32_t xw[NIT][SWX], rw[NIT][SW];
   float2 st[NIT];
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
     const long n = min(nbase + r0 + k * RSTEP, p.N - 1);
-    ld_words<SW>(X + n * e.ln_ldx + c, xw[k]);
+    if constexpr (XF32) {
+      const uint4 a_ = *reinterpret_cast<const uint4*>(X + n * e.ln_ldx + c), b_ = *reinterpret_cast<const uint4*>(X + n * e.ln_ldx + c + 4);
+      xw[k][0] = a_.x; xw[k][1] = a_.y; xw[k][2] = a_.z; xw[k][3] = a_.w; xw[k][4] = b_.x; xw[k][5] = b_.y; xw[k][6] = b_.z; xw[k][7] = b_.w;
+    } else {
+      ld_words<SW>(X + n * e.ln_ldx + c, xw[k]);
+    }
     st[k] = *reinterpret_cast<const float2*>(e.ln_stats + 2 * n);
     if (R) ld_words<SW>(R + n * e.ldr + c, rw[k]);
   }
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
 #pragma unroll
-    for (int q = 0; q < SW; ++q) settle(xw[k][q]);
+    for (int q = 0; q < SWX; ++q) settle(xw[k][q]);
     settle(st[k].x); settle(st[k].y);
   }
   if (R) {
@@ -626,7 +666,12 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
       const float4 a4 = *reinterpret_cast<const float4*>(smh + r * STG_LD + (c + 4 * q4) * 4);
       v[4 * q4] = a4.x; v[4 * q4 + 1] = a4.y; v[4 * q4 + 2] = a4.z; v[4 * q4 + 3] = a4.w;
     }
-    unpack_words<T, 8>(xw[k], xh);
+    if constexpr (XF32) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xh[q] = __uint_as_float(xw[k][q]);
+    } else {
+      unpack_words<T, 8>(xw[k], xh);
+    }
     unpack_words<T, 8>(rw[k], rf);
     float s1 = 0.f, s2 = 0.f;
     if (EXT && lact != SMX_ACT_NONE) {                   // (uniform; beta sits behind gamma in LDS)
@@ -722,7 +767,13 @@ __device__ __forceinline__ void epilogue_phase_lnfwd(const GemmParams& p, const 
       case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 8>(v); break;
       default: break;
     }
-    st_elems<T, 8>(reinterpret_cast<T*>(e.lnf_y) + (long)n * e.lnf_ldy + c, v);
+    if (e.io_flags & SMX_IO_LNFY_F32) {                  // (uniform) the LayerNorm output IS the fp32 residual stream (norm2)
+      float* yp = reinterpret_cast<float*>(e.lnf_y) + (long)n * e.lnf_ldy + c;
+      *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      st_elems<T, 8>(reinterpret_cast<T*>(e.lnf_y) + (long)n * e.lnf_ldy + c, v);
+    }
     if (e.lnf_stats && (t & 31) == 0) *reinterpret_cast<float2*>(e.lnf_stats + 2 * (long)n) = make_float2(mean, rstd);
   }
 }

@@ -462,8 +462,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* X, long ldx
 // Single-read forward for D <= 256 * CH (D % 4 == 0, aligned rows): the row lives in registers (one 4-element vector
 // per lane and chunk), U rows are in flight per wave (all their loads issued before the first reduction), workgroups
 // stride over the rows.  The generic kernel above re-reads the row three times behind three dependent latencies.
-template <typename T, int CH, int U>
-__global__ __launch_bounds__(256) void layernorm_fwd_fast(const T* __restrict__ X, long ldx, const float* __restrict__ gamma,
+// TX: element type of the input (float for the fp32 residual stream: LayerNorm(fp32 x) -> dtype T, smx_layernorm_fwd_x32)
+template <typename T, int CH, int U, typename TX = T>
+__global__ __launch_bounds__(256) void layernorm_fwd_fast(const TX* __restrict__ X, long ldx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ Y, long ldy,
                                                           float* __restrict__ stats, int N_, int D, float eps, int act) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_fast(const T* __restrict__ 
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
           const int c = (lane + 64 * i) * 4;
-          if (c < D) load4<T>(X + (long)row * ldx + c, f[u][i]);
+          if (c < D) load4<TX>(X + (long)row * ldx + c, f[u][i]);
           else f[u][i][0] = f[u][i][1] = f[u][i][2] = f[u][i][3] = 0.f;
         }
       }
@@ -552,8 +553,8 @@ struct LnSecond {
   void* dX2; long ld; float alpha; const uint8_t* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* epoch;
 };
 
-template <typename T, int VW, int CH, int U>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ X,
+template <typename T, int VW, int CH, int U, typename TX = T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dY, long lddy, const TX* __restrict__ X,
                                                             long ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int act,
                                                             const float* __restrict__ stats, const T* __restrict__ R,
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int i = 0; i < CH; ++i) {
           const int c = (lane + 64 * i) * VW;
           const int cc = c < D ? c : 0;                  // idle lanes re-read column 0
-          if constexpr (VW == 4) { load4<T>(dY + (long)row * lddy + cc, fdy[u][i]); load4<T>(X + (long)row * ldx + cc, fx[u][i]); }
+          if constexpr (VW == 4) { load4<T>(dY + (long)row * lddy + cc, fdy[u][i]); load4<TX>(X + (long)row * ldx + cc, fx[u][i]); }
           else { fdy[u][i][0] = to_f32(dY[(long)row * lddy + cc]); fx[u][i][0] = to_f32(X[(long)row * ldx + cc]); }
           // the residual gradient is requested with the operands: loaded after the reductions it was a second dependent
           // round trip per row group
@@ -1229,6 +1230,24 @@ extern "C" int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const fl
   return check_launch("smx_layernorm_fwd");
 }
 
+extern "C" int smx_layernorm_fwd_x32(int dtype, const float* X, int64_t ldx, const float* gamma, const float* beta, void* Y,
+                                     int64_t ldy, float* stats, int N, int D, float eps, int act, void* stream) {
+  SMX_REQUIRE(X && Y && gamma && beta && N >= 0 && D > 0, "smx_layernorm_fwd_x32: bad arguments");
+  if (dtype == SMX_F32) return smx_layernorm_fwd(dtype, X, ldx, gamma, beta, Y, ldy, stats, N, D, eps, act, stream);
+  SMX_REQUIRE(dtype == SMX_BF16, "smx_layernorm_fwd_x32: bad dtype");
+  if (N == 0) return SMX_OK;
+  const bool vec = D % 4 == 0 && D <= 2048 && aligned16(X) && ldx % 4 == 0 && aligned8(Y) && ldy % 4 == 0 && aligned16(gamma) && aligned16(beta);
+  if (!vec) return fail(SMX_EUNSUPPORTED, "smx_layernorm_fwd_x32: needs D %% 4 == 0, D <= 2048 and aligned rows");
+  const int ch = (D + 255) / 256;
+  const int U = ch <= 1 ? 4 : (ch <= 2 ? 2 : 1);
+  int blocks = (N + 4 * U - 1) / (4 * U);
+  if (blocks > 2048) blocks = 2048;
+#define LN_FWDX(CH_, U_) hipLaunchKernelGGL((layernorm_fwd_fast<bf16_t, CH_, U_, float>), dim3(blocks), dim3(256), 0, STREAM, X, ldx, gamma, beta, (bf16_t*)Y, ldy, stats, N, D, eps, act)
+  if (ch <= 1) LN_FWDX(1, 4); else if (ch <= 2) LN_FWDX(2, 2); else if (ch <= 4) LN_FWDX(4, 1); else LN_FWDX(8, 1);
+#undef LN_FWDX
+  return check_launch("smx_layernorm_fwd_x32");
+}
+
 static int ln_bwd_blocks(int N) {
   int blocks = (N + 7) / 8;
   return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
@@ -1281,6 +1300,34 @@ extern "C" int smx_layernorm_bwd2(int dtype, const void* dY, int64_t lddy, const
   sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = g_step_counter;
   if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM, sec);
   return ln_bwd_impl<float>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM, sec);
+}
+extern "C" int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, const float* X, int64_t ldx, const float* gamma,
+                                      const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx,
+                                      float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2, float alpha2,
+                                      const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream) {
+  if (dtype == SMX_F32)
+    return smx_layernorm_bwd2(dtype, dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, workspace, dX2, lddx2,
+                              alpha2, row_mask2, drop_p2, drop_seed2, stream);
+  SMX_REQUIRE(dtype == SMX_BF16 && dY && X && gamma && beta && stats && dX && workspace && D > 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
+              "smx_layernorm_bwd2_x32: bad arguments");
+  SMX_REQUIRE(drop_p2 >= 0.f && drop_p2 < 1.f, "smx_layernorm_bwd2_x32: 0 <= drop_p < 1");
+  if (N == 0) return SMX_OK;
+  typedef bf16_t T;
+  auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % 8) == 0 && ld % 4 == 0); };
+  const bool vec = D % 4 == 0 && D <= 2048 && ok(dY, lddy) && aligned16(X) && ldx % 4 == 0 && ok(R, ldr) && ok(dX, lddx) && ok(dX2, lddx2);
+  if (!vec) return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd2_x32: needs D %% 4 == 0, D <= 2048 and aligned rows");
+  LnSecond sec;
+  sec.dX2 = dX2; sec.ld = lddx2; sec.alpha = alpha2; sec.mask = row_mask2;
+  sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = g_step_counter;
+  const int blocks = ln_bwd_blocks(N);
+  dim3 grid(blocks);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipStream_t s = STREAM;
+#define LN_BWDX(CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4, CH, (CH == 1 ? SMX_LNB_U1 : (CH <= 2 ? 2 : 1)), float>), grid, dim3(256), 0, s, (const T*)dY, lddy, X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D, sec)
+  if (D <= 256) LN_BWDX(1); else if (D <= 512) LN_BWDX(2); else if (D <= 1024) LN_BWDX(4); else LN_BWDX(8);
+#undef LN_BWDX
+  if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
+  return check_launch("smx_layernorm_bwd2_x32");
 }
 extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                                  const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma,

@@ -55,6 +55,18 @@ def wcast(param, dtype):
 
 _WGRAD_BIAS = os.environ.get("SMX_NO_WGRAD_BIAS") != "1"     # A/B knob: bias gradients as a by-product of the wgrad GEMM
 
+# Residual-stream dtype of a bf16 model.  "fp32" (default) = torch autocast semantics, what the reference's `precision: bf16`
+# means (…transducer.yaml:61): Linear inputs / outputs in bf16, the residual adds (Conformer.py:507,530,532-536) and the
+# LayerNorm inputs in float32 - the stream tensors x, x + 1/2 FFN, + cell, + conv, and the layer-final LayerNorm output are
+# stored in float32, everything a GEMM reads or writes stays bf16.  "bf16" (SMX_RESIDUAL=bf16, the round-1/2 behaviour) stores
+# the stream in bf16 too: ~7 % faster, 2e-2 instead of < 1e-2 max-rel on the 12-layer forward.  Gradients are bf16 in both.
+RESIDUAL_F32 = os.environ.get("SMX_RESIDUAL", "fp32").lower() not in ("bf16", "bfloat16")
+
+
+def stream_dtype(compute_dtype):
+    """dtype of the residual stream for a model computing in `compute_dtype`."""
+    return torch.float32 if (compute_dtype == torch.bfloat16 and RESIDUAL_F32 and not SP.enabled()) else compute_dtype
+
 
 def gacc(param):
     """fp32 gradient accumulator of a parameter (kernels add into it)."""
@@ -274,13 +286,16 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
     (check ln_next_ok first); ln_post (a list) receives (LN output, stats | None)."""
     N, K = x.shape
     M = W.shape[0]
+    if res is not None and res.dtype == torch.float32 and x.dtype != torch.float32:
+        out_f32 = True                                   # fp32 residual stream: res + alpha * (bf16 GEMM) is the next stream tensor
     if out is None:
         out = torch.empty((N, M), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
     lnf = None
     if ln_next is not None:
-        g, b, eps, lact, want_stats = ln_next
-        hy = torch.empty((N, M), dtype=x.dtype, device=x.device)
+        g, b, eps, lact, want_stats = ln_next[:5]
+        # ln_next[5] = True: the LayerNorm output is itself the stream (the layer-final norm2): stream dtype, else GEMM input dtype
+        hy = torch.empty((N, M), dtype=out.dtype if (len(ln_next) > 5 and ln_next[5]) else x.dtype, device=x.device)
         st = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
         lnf = (g.detach(), b.detach(), hy, st, eps, lact)
         ln_post.append((hy, st))
@@ -346,7 +361,8 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
             ws = deferred_ws(gw_ln.data_ptr(), ntile * 2 * K * 4, dy.device)
             dx2 = torch.empty((N, K), dtype=dy.dtype, device=dy.device) if ln_second is not None else None
             lact = (ln["b"].detach(), ln["act"]) if ln["act"] != L.ACT_NONE else None
-            e = ops.epilogue(res=res_grad, ln_bwd=(ln["x"], ln["stats"], ln["w"].detach(), ws, dx2, ln_second, lact))
+            e = ops.epilogue(res=res_grad, ln_bwd=(ln["x"], ln["stats"], ln["w"].detach(), ws, dx2, ln_second, lact,
+                                                   ln["x"].dtype != dy.dtype))
             ops.gemm(L.GEMM_NN, dz, W, dx, N, K, M, e)
             defer(ws.data_ptr(), gw_ln, 2 * K, ntile, 1, K)
             defer(ws.data_ptr() + 4 * K, gb_ln, 2 * K, ntile, 1, K)
@@ -599,7 +615,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             if res is None:
                 y3 = ops.cast(sbar, dtype).unsqueeze(1).expand(B, T, sdim)        # stride-0 view like :308
             else:                                                                 # inside an encoder layer: res + summary
-                yb = torch.empty((N, sdim), dtype=dtype, device=dev)
+                yb = torch.empty((N, sdim), dtype=res.dtype, device=dev)           # (res.dtype: the stream may be float32)
                 ops.bcast_rows(sbar, None, yb, B, T)
                 y3 = ops.axpby(1.0, res, 1.0, yb).view(B, T, sdim)
 
@@ -789,14 +805,15 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
 # ----------------------------------------------------------------------------------------------------
 # LayerNorm block, FFN module, Conformer conv module (2-D row views in, closures out)
 # ----------------------------------------------------------------------------------------------------
-def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None, pre=None):
+def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None, pre=None, out_dtype=None):
     """y = act(LayerNorm(x)); bwd(dy, res) = res + d/dx.  w/b are flat (D) views; wp/bp name the owning parameters
     when those are multi-dimensional (the (F', C) affine of the conv front-end).
-    pre = (y, stats): the GEMM that produced x already ran this LayerNorm in its epilogue (linear_fwd(ln_next=...))."""
+    pre = (y, stats): the GEMM that produced x already ran this LayerNorm in its epilogue (linear_fwd(ln_next=...)).
+    out_dtype: dtype of y when x is the float32 residual stream of a bf16 model (gradients then have the dtype of dy)."""
     if pre is not None:
         y, stats = pre
     else:
-        y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act)
+        y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act, out_dtype=out_dtype)
 
     def bwd(dy, res=None, out=None, second=None):
         """second = (alpha, mask, drop): also return alpha * D(dx) * mask, what the NEXT backward block applies first to
@@ -849,13 +866,13 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
     pre_ln = (LN(x), stats) when the producer of x already ran this module's LayerNorm in its epilogue; ln_next = (gamma,
     beta, eps) of the LayerNorm that follows the module: it runs in the second Linear's epilogue where possible, and a
     third value (LN(y), stats) | None is returned."""
-    h, ln_b = ln_fwd(x, P["ln_w"], P["ln_b"], 1e-5, need_bwd, pre=pre_ln)
+    h, ln_b = ln_fwd(x, P["ln_w"], P["ln_b"], 1e-5, need_bwd, pre=pre_ln, out_dtype=dtype)
     W1, W2 = wcast(P["W1"], dtype), wcast(P["W2"], dtype)
     d1 = (p, ops.new_dropout_seed()) if p > 0.0 else None       # both dropouts are fused into the GEMM epilogues
     d2 = (p, ops.new_dropout_seed()) if p > 0.0 else None
     a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1)
     post = []
-    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x)) else None
+    lnn = ((ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) + tuple(ln_next[3:4])) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x)) else None
     y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2, ln_next=lnn, ln_post=post)
     post = post[0] if post else None
     if not need_bwd:
@@ -888,7 +905,7 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
     if SP.enabled():
         r = _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual, p)
         return r + (None,) if ln_next is not None else r
-    h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd, pre=pre_ln)
+    h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd, pre=pre_ln, out_dtype=dtype)
     Wp = wcast(P["Wp"], dtype).view(2 * d, d)                    # Conv1d(d,2d,1) weight viewed as a Linear
     p_, _ = linear_fwd(h, Wp, P["bp"])
     k = P["wd"].shape[-1]
@@ -1002,7 +1019,8 @@ def final_norm(x3, ln):
 
 def input_proj_pe(src3, W, b, pe, T, p=0.0):
     """x = D(src W^T + b) + PE[t]  (TransformerASR.py:349-354,542,547-549).  Without dropout the abs-sine table enters
-    the GEMM epilogue as a per-frame side input indexed n % T, so the add costs no extra pass."""
+    the GEMM epilogue as a per-frame side input indexed n % T, so the add costs no extra pass.  The output opens the residual
+    stream: float32 for a bf16 model unless SMX_RESIDUAL=bf16 (stream_dtype)."""
     B = src3.shape[0]
 
     def run(xin, need):
@@ -1010,12 +1028,15 @@ def input_proj_pe(src3, W, b, pe, T, p=0.0):
         x = ops.rows2d(xin)
         Wc = wcast(W, dtype)
         dr = (p, ops.new_dropout_seed()) if p > 0.0 else None
-        y, _ = linear_fwd(x, Wc, b, c0=pe, c0_mode=L.C0_MOD, c0_div=T, drop=dr, c0_post=True)
+        y, _ = linear_fwd(x, Wc, b, c0=pe, c0_mode=L.C0_MOD, c0_div=T, drop=dr, c0_post=True,
+                          out_f32=stream_dtype(dtype) == torch.float32 and dtype != torch.float32)
         if not need:
             return y.view(B, T, -1), None
 
         def bwd(dy3):
             dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+            if dy.dtype != dtype:                            # (autograd hands a float32 gradient for the float32 stream tensor)
+                dy = ops.cast(dy, dtype)
             dx, _ = linear_bwd(dy, x, Wc, None, L.ACT_NONE, None, 1.0, gacc(W), gacc(b), need_dx=xin.requires_grad, drop=dr)
             return dx.view(xin.shape) if dx is not None else None
         return y.view(B, T, -1), bwd

@@ -108,7 +108,9 @@ class ConformerEncoderLayer(nn.Module):
         self.norm2 = _LayerNorm(d_model)
         self.drop = nn.Dropout(dropout)
 
-    def make_run(self, B, T, m8, src_mask, chunk):
+    def make_run(self, B, T, m8, src_mask, chunk, compute_dtype=None):
+        """compute_dtype: dtype of the GEMM operands when the incoming stream x3 is the float32 residual stream of a bf16
+        model (functional.RESIDUAL_F32); None = everything in x3.dtype."""
         d_act = self.act
         P1, P2 = _ffn_params(self.ffn_module1), _ffn_params(self.ffn_module2)
         Pc = self.convolution_module.params()
@@ -118,23 +120,26 @@ class ConformerEncoderLayer(nn.Module):
                           self.mha_layer.global_dropout if self.training else 0.0)
 
         def run(x3, need):
-            dtype = x3.dtype
+            dtype = compute_dtype or x3.dtype
             x = ops.rows2d(x3)
             # every LayerNorm that follows a Linear of width d_model = 256 runs in that GEMM's epilogue (`post` = its output and
             # statistics, None when the shape does not qualify and the consumer runs the LayerNorm kernel itself)
             y1, b1, post1 = F.ffn_module_fwd(x, P1, d_act, need, dtype, p=pd, ln_next=(n1.weight, n1.bias, n1.eps))   # :507
-            h, bn1 = F.ln_fwd(y1, n1.weight, n1.bias, n1.eps, need, pre=post1)         # :510
+            h, bn1 = F.ln_fwd(y1, n1.weight, n1.bias, n1.eps, need, pre=post1, out_dtype=dtype)         # :510
             y2_3, bcell, post2 = cell(h.view(B, T, -1), need, res=y1, ln_next=(Pc["ln1_w"], Pc["ln1_b"], 1e-5))   # :512-530
             y2 = ops.rows2d(y2_3)
             y3, bconv, post3 = F.conv_module_fwd(y2, Pc, d_act, m8, B, T, need, dtype, chunk, p=pd, pre_ln=post2,
                                                  ln_next=(P2["ln_w"], P2["ln_b"], 1e-5))                          # :532-534
-            y4, bf2, post4 = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd, pre_ln=post3, ln_next=(n2.weight, n2.bias, n2.eps))
+            # (norm2's output is the layer output = the next layer's residual stream: stream dtype, 4th element of ln_next)
+            y4, bf2, post4 = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd, pre_ln=post3, ln_next=(n2.weight, n2.bias, n2.eps, True))
             y5, bn2 = F.ln_fwd(y4, n2.weight, n2.bias, n2.eps, need, pre=post4)        # :536
             if not need:
                 return y5.view(B, T, -1), None
 
             def bwd(dy3):
                 dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+                if dy.dtype != dtype:                      # (a float32 gradient from autograd for the float32 stream: gradients run in the compute dtype)
+                    dy = ops.cast(dy, dtype)
                 # each LayerNorm backward also writes what the NEXT block applies first to its gradient (`pre`: the FFN's
                 # 1/2 * dropout, the conv module's dropout * padding mask) - no separate elementwise pass per module
                 pre_c = getattr(bconv, "pre", None)
@@ -188,15 +193,44 @@ class ConformerEncoder(nn.Module):
         self.attention_type = attention_type
 
     def forward(self, src, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
-                pos_embs: Optional[torch.Tensor] = None, dynchunktrain_config=None):
-        B, T, _ = src.shape
+                pos_embs: Optional[torch.Tensor] = None, dynchunktrain_config=None, _compute_dtype=None):
+        B, T, d = src.shape
         m8 = F.mask_u8(src_key_padding_mask, B, T, src.device)
         chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
-        out = src
-        attention_lst = []
-        for layer in self.layers:
-            out = F.block(out, layer.make_run(B, T, m8, src_mask, chunk), list(layer.parameters()),
-                          getattr(layer, "_on_bwd_done", None))
-            attention_lst.append(None)
-        out = F.final_norm(out, self.norm.norm)
-        return out, attention_lst
+        norm = self.norm.norm
+        layers = list(self.layers)
+        # compute dtype: what the caller says (TransformerASR.encode hands over the float32 stream of a bf16 model), else the
+        # input's; the stream between the layers is functional.stream_dtype(compute) - float32 for a bf16 model by default
+        compute = _compute_dtype or src.dtype
+        stream = F.stream_dtype(compute)
+
+        def run(xin, need):
+            """The whole stack as ONE autograd block: the gradient between two layers never visits autograd (which would cast
+            the bf16 gradient of a float32 stream tensor with an aten kernel per layer); every layer's parameter-gradient
+            reductions and its bucket hook still run right behind that layer's backward."""
+            x = xin
+            if x.dtype != stream:
+                x = ops.cast(ops.rows2d(x), stream).view(B, T, d)
+            bwds = []
+            for layer in layers:
+                x, b = layer.make_run(B, T, m8, src_mask, chunk, compute_dtype=compute)(x, need)
+                bwds.append((b, getattr(layer, "_on_bwd_done", None)))
+            y, bn = F.ln_fwd(ops.rows2d(x), norm.weight, norm.bias, norm.eps, need, out_dtype=compute)
+            if not need:
+                return y.view(B, T, d), None
+
+            def bwd(dy3):
+                dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+                if dy.dtype != compute:
+                    dy = ops.cast(dy, compute)
+                g = bn(dy).view(B, T, d)
+                F.flush_deferred()
+                for b, done in reversed(bwds):
+                    g = b(g)
+                    F.flush_deferred()                     # this layer's parameter gradients are final ...
+                    if done is not None:
+                        done()                             # ... before its bucket is all-reduced (trainer.FlatAdamW)
+                return g if g.dtype == xin.dtype else ops.cast(ops.rows2d(g), xin.dtype).view(B, T, d)
+            return y.view(B, T, d), bwd
+        out = F.block(src, run, list(self.parameters()))
+        return out, [None] * len(layers)

@@ -111,6 +111,8 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         e.row_mask = row_mask.data_ptr()
     if res is not None:
         e.res, e.ldr = res.data_ptr(), _mat(res)[1]
+        if res.dtype == torch.float32 and out_mode == L.OUT_F32:
+            e.io_flags |= L.IO_RES_F32                   # fp32 residual stream next to bf16 operands
     e.alpha = alpha
     e.flags = L.EPI_C0_POST if c0_post else 0
     if act_grad_z is not None:
@@ -129,6 +131,8 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         if len(ln_bwd) > 6 and ln_bwd[6] is not None:      # (beta, act): the LayerNorm had a fused activation
             e.lnf_beta, e.lnf_act = ln_bwd[6][0].data_ptr(), ln_bwd[6][1]
         e.ln_x, e.ln_ldx = x.data_ptr(), _mat(x)[1]
+        if x.dtype == torch.float32 and len(ln_bwd) > 7 and ln_bwd[7]:     # (x float32 next to bf16 gradients)
+            e.io_flags |= L.IO_LNX_F32
         e.ln_stats, e.ln_gamma, e.ln_partial = stats.data_ptr(), gamma.data_ptr(), partial.data_ptr()
         e.flags |= L.EPI_LN_BWD
         if dx2 is not None:
@@ -145,6 +149,8 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         gamma, beta, y, stats, eps, lact = ln_fwd
         e.lnf_gamma, e.lnf_beta = gamma.data_ptr(), beta.data_ptr()
         e.lnf_y, e.lnf_ldy = y.data_ptr(), _mat(y)[1]
+        if y.dtype == torch.float32 and out_mode == L.OUT_F32 and res is not None and res.dtype == torch.float32:
+            e.io_flags |= L.IO_LNFY_F32                  # the LayerNorm output is the fp32 residual stream itself
         e.lnf_stats = stats.data_ptr() if stats is not None else None
         e.lnf_eps, e.lnf_act = eps, lact
         e.flags |= L.EPI_LN_FWD
@@ -316,14 +322,22 @@ def expdecay_mean(s, out, B, T, decay, reverse=False):
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE):
+def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE, out_dtype=None):
+    """out_dtype (default x.dtype): bf16 output of a float32 input = LayerNorm of the fp32 residual stream feeding a bf16 GEMM
+    (smx_layernorm_fwd_x32)."""
     N, D = x.shape
-    y = torch.empty((N, D), dtype=x.dtype, device=x.device)
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((N, D), dtype=out_dtype, device=x.device)
     stats = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
     px, ldx = _mat(x)
-    tok = _pb(f"layernorm_fwd ({N}x{D})", 2 * N * D * _es(x))
-    L.check(L.lib().smx_layernorm_fwd(dt(x), px, ldx, _p(gamma), _p(beta), _p(y), D, _p(stats), N, D, eps, act, _stream()),
-            "smx_layernorm_fwd")
+    tok = _pb(f"layernorm_fwd ({N}x{D})", N * D * (_es(x) + _es(y)))
+    if out_dtype != x.dtype:
+        assert x.dtype == torch.float32, "mixed LayerNorm: float32 in, compute dtype out"
+        L.check(L.lib().smx_layernorm_fwd_x32(dt(y), px, ldx, _p(gamma), _p(beta), _p(y), D, _p(stats), N, D, eps, act, _stream()),
+                "smx_layernorm_fwd_x32")
+    else:
+        L.check(L.lib().smx_layernorm_fwd(dt(x), px, ldx, _p(gamma), _p(beta), _p(y), D, _p(stats), N, D, eps, act, _stream()),
+                "smx_layernorm_fwd")
     _pe(tok)
     return y, stats
 
@@ -333,7 +347,8 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     dx_out: optional (N, D) destination view (e.g. a column slice of a wider buffer).
     second = (alpha, row_mask_u8 | None, (p, seed) | None): also return dx2 = alpha * D(dx) * mask (smx_layernorm_bwd2)."""
     N, D = x.shape
-    dx = dx_out if dx_out is not None else torch.empty((N, D), dtype=x.dtype, device=x.device)
+    gdt = dy.dtype                                       # gradient dtype; x may be float32 next to bf16 gradients (fp32 residual stream)
+    dx = dx_out if dx_out is not None else torch.empty((N, D), dtype=gdt, device=x.device)
     pdy, lddy = _mat(dy)
     px, ldx = _mat(x)
     pr, ldr = (_mat(res) if res is not None else (None, 0))
@@ -344,12 +359,14 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     if second is not None:
         a2, m2, drop2 = second
         dp2, ds2 = drop2 if (drop2 is not None and drop2[0] > 0.0) else (0.0, 0)
-        dx2 = torch.empty((N, D), dtype=x.dtype, device=x.device)
+        dx2 = torch.empty((N, D), dtype=gdt, device=x.device)
     tok = _pb(f"layernorm_bwd ({N}x{D}){'+res' if res is not None else ''}{'+2nd' if second is not None else ''}",
-              (3 + (res is not None) + (second is not None)) * N * D * _es(x))
-    L.check(L.lib().smx_layernorm_bwd2(dt(x), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), _mat(dx)[1],
-                                       _p(dgamma), _p(dbeta), N, D, _p(ws), _p(dx2), D if dx2 is not None else 0, a2, _p(m2), dp2,
-                                       ds2, _stream()), "smx_layernorm_bwd")
+              ((2 + (res is not None) + (second is not None)) * _es(dy) + _es(x)) * N * D)
+    fn = L.lib().smx_layernorm_bwd2 if x.dtype == gdt else L.lib().smx_layernorm_bwd2_x32
+    assert x.dtype == gdt or x.dtype == torch.float32
+    L.check(fn(dt(dy), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), _mat(dx)[1],
+               _p(dgamma), _p(dbeta), N, D, _p(ws), _p(dx2), D if dx2 is not None else 0, a2, _p(m2), dp2,
+               ds2, _stream()), "smx_layernorm_bwd")
     _pe(tok)
     return dx if second is None else (dx, dx2)
 

@@ -40,7 +40,8 @@ def test_version_and_error_string_need_no_gpu():
 
 def test_epilogue_struct_layout_matches_header():
     from summarymixing_amd import _lib
-    assert ctypes.sizeof(_lib.Epilogue) == 256  # 32 x 8 bytes, see include/smx.h smx_epilogue
+    assert ctypes.sizeof(_lib.Epilogue) == 264  # 33 x 8 bytes (round 3: + io_flags, pad_), see include/smx.h smx_epilogue
+    assert _lib.Epilogue.io_flags.offset == 256
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
