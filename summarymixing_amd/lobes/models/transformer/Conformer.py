@@ -171,7 +171,16 @@ class ConformerEncoderLayer(nn.Module):
         B, T, _ = x.shape
         m8 = F.mask_u8(src_key_padding_mask, B, T, x.device)
         chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
-        run = self.make_run(B, T, m8, src_mask, chunk)
+        stream = F.stream_dtype(x.dtype)
+        if stream == x.dtype:
+            return F.block(x, self.make_run(B, T, m8, src_mask, chunk), list(self.parameters())), None
+        # a bf16 layer called on its own: the same float32 residual stream as inside the encoder stack (cast in, cast out)
+        inner = self.make_run(B, T, m8, src_mask, chunk, compute_dtype=x.dtype)
+        d = x.shape[2]
+
+        def run(xin, need):
+            y, b = inner(ops.cast(ops.rows2d(xin), stream).view(B, T, d), need)
+            return ops.cast(ops.rows2d(y), xin.dtype).view(B, T, d), b
         return F.block(x, run, list(self.parameters())), None
 
     def forward_streaming(self, *a, **k):

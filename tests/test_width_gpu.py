@@ -89,7 +89,10 @@ def _compare(name, dtype, y, gx, gp, yref, gref, ftol, gtol, rms_ftol, rms_gtol)
 
 
 # tolerances: (forward max-rel, gradient max-rel, forward RMS-rel, gradient RMS-rel)
-TOLS = {torch.float32: (1e-3, 1e-3, 1e-3, 1e-3), torch.bfloat16: (2e-2, 5e-2, 1e-2, 2e-2)}
+# bf16, Conformer (float32 residual stream = the reference's autocast semantics): the north_star bars, 1e-2 forward / 3e-2 gradients
+TOLS = {torch.float32: (1e-3, 1e-3, 1e-3, 1e-3), torch.bfloat16: (1e-2, 3e-2, 1e-2, 2e-2)}
+# the Branchformer still stores its residual stream in bf16 (round-2 tolerances)
+TOLS_BF16_STREAM = {torch.float32: (1e-3, 1e-3, 1e-3, 1e-3), torch.bfloat16: (2e-2, 5e-2, 1e-2, 2e-2)}
 
 
 def _conformer(layers, d, f):
@@ -141,7 +144,7 @@ def test_c4_branchformer_layer_cv_dims_fwd_bwd_all_grads(dtype):
     sd32 = {k: v.clone() for k, v in enc.state_dict().items()}
     yref, gref = _oracle("c4", lambda xd, sd: O.branchformer_encoder(xd, sd, "", "gelu", "SummaryMixing", d, None, pad), sd32, x, r)
     y, gx, gp = _run_gpu(enc, lambda m, xg: m(xg, src_key_padding_mask=pad.cuda())[0], x, r, dtype)
-    _compare("c4_branchformer_1layer_d512_csgu3072_16500frames", dtype, y, gx, gp, yref, gref, *TOLS[dtype])
+    _compare("c4_branchformer_1layer_d512_csgu3072_16500frames", dtype, y, gx, gp, yref, gref, *TOLS_BF16_STREAM[dtype])
 
 
 def test_c2b_twelve_layers_bf16_forward_error_report():
@@ -160,4 +163,4 @@ def test_c2b_twelve_layers_bf16_forward_error_report():
          "bf16_rmsrel": rms_rel(y16, ref)}
     report("c2b_12layers_forward_33000frames", e)
     assert e["fp32_maxrel"] <= 1e-3 and e["fp32_rmsrel"] <= 1e-3, e
-    assert e["bf16_maxrel"] <= 5e-2 and e["bf16_rmsrel"] <= 1.5e-2, e
+    assert e["bf16_maxrel"] <= 1e-2 and e["bf16_rmsrel"] <= 1e-2, e          # north_star bar at the benchmarked depth (2.1e-2 with a bf16 stream)
