@@ -1005,6 +1005,44 @@ def _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual,
     return y, bwd
 
 
+def encoder_stack(src, layers, make_layer_run, norm, params, compute_dtype=None):
+    """A whole encoder stack (layers + final LayerNorm) as ONE autograd block.  make_layer_run(layer, compute) -> run(x3, need).
+    compute: dtype of the GEMM operands (default: the input's); the residual stream between the layers is
+    stream_dtype(compute) - float32 for a bf16 model by default.  The gradient between two layers never visits autograd (it
+    would cast the bf16 gradient of a float32 stream tensor with one aten kernel per layer); every layer's parameter-gradient
+    reductions and its bucket hook (`_on_bwd_done`, trainer.FlatAdamW) still run right behind that layer's backward."""
+    B, T, d = src.shape
+    compute = compute_dtype or src.dtype
+    stream = stream_dtype(compute)
+
+    def run(xin, need):
+        x = xin
+        if x.dtype != stream:
+            x = ops.cast(ops.rows2d(x), stream).view(B, T, d)
+        bwds = []
+        for layer in layers:
+            x, b = make_layer_run(layer, compute)(x, need)
+            bwds.append((b, getattr(layer, "_on_bwd_done", None)))
+        y, bn = ln_fwd(ops.rows2d(x), norm.weight, norm.bias, norm.eps, need, out_dtype=compute)
+        if not need:
+            return y.view(B, T, d), None
+
+        def bwd(dy3):
+            dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+            if dy.dtype != compute:
+                dy = ops.cast(dy, compute)
+            g = bn(dy).view(B, T, d)
+            flush_deferred()
+            for b, done in reversed(bwds):
+                g = b(g)
+                flush_deferred()                       # this layer's parameter gradients are final ...
+                if done is not None:
+                    done()                             # ... before its bucket is all-reduced
+            return g if g.dtype == xin.dtype else ops.cast(ops.rows2d(g), xin.dtype).view(B, T, d)
+        return y.view(B, T, d), bwd
+    return block(src, run, params)
+
+
 def final_norm(x3, ln):
     """Encoder-final LayerNorm (eps 1e-6; Conformer.py:738,784 / Branchformer.py:444,489) as one block."""
     B, T, d = x3.shape

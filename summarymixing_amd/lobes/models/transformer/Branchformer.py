@@ -88,7 +88,7 @@ class BranchformerEncoderLayer(nn.Module):
         self.norm_conv = _LayerNorm(d_model)
         self.dropout = nn.Dropout(dropout)
 
-    def make_run(self, B, T, m8, src_mask):
+    def make_run(self, B, T, m8, src_mask, compute_dtype=None):
         if SP.enabled():
             raise NotImplementedError("sequence-parallel mode does not cover the Branchformer: the CSGU's reflect-padded "
                                       "depthwise convolution has no halo exchange")
@@ -102,12 +102,12 @@ class BranchformerEncoderLayer(nn.Module):
         s_out = self.mha_layer.summary_out_dim if self.mode != "SummaryMixing-lite" else self.mha_layer.summary_out_dim
 
         def run(x3, need):
-            dtype = x3.dtype
+            dtype = compute_dtype or x3.dtype              # (x3 may be the float32 residual stream of a bf16 model)
             x = ops.rows2d(x3)
             N, d = x.shape
             dev = x.device
             # branch 1: SummaryMixing(LN(x))
-            h1, bn1 = F.ln_fwd(x, nm.weight, nm.bias, nm.eps, need)
+            h1, bn1 = F.ln_fwd(x, nm.weight, nm.bias, nm.eps, need, out_dtype=dtype)
             # training: the dropout of the cell's output (:279) and its placement in the merge input ride in the cell's last
             # GEMM epilogue (and the dropout backward in the cell's first backward pass)
             fuse_y1 = pd > 0.0 and self.mode != "SummaryMixing-lite"
@@ -122,7 +122,7 @@ class BranchformerEncoderLayer(nn.Module):
             y1 = ops.rows2d(y1_3.contiguous() if y1_3.stride(1) == 0 else y1_3)
             c1 = y1.shape[1]
             # branch 2: cgMLP(LN(x))
-            h2, bn2 = F.ln_fwd(x, nc.weight, nc.bias, nc.eps, need)
+            h2, bn2 = F.ln_fwd(x, nc.weight, nc.bias, nc.eps, need, out_dtype=dtype)
             Wpre, Wpost = F.wcast(Pb["Wpre"], dtype), F.wcast(Pb["Wpost"], dtype)
             u, zu = F.linear_fwd(h2, Wpre, Pb["bpre"], act, None, save_z=need)           # (N, csgu)
             n = u.shape[1] // 2
@@ -153,12 +153,14 @@ class BranchformerEncoderLayer(nn.Module):
                 m_out, sv_m = F.mlp_fwd(cat, merge, act, None, need, dtype)
                 if pd > 0.0:
                     ops.dropout(m_out, pd, sd3, out=m_out)
-                y = ops.axpby(1.0, x, 1.0, m_out)
+                y = ops.axpby(1.0, x, 1.0, ops.cast(m_out, x.dtype))
             if not need:
                 return y.view(B, T, d), None
 
             def bwd(dy3):
                 dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+                if dy.dtype != dtype:
+                    dy = ops.cast(dy, dtype)
                 if merge[-1]["kind"] == "linear":
                     dcat = F.mlp_bwd(dy, merge, act, sv_m, dtype, last_drop=mdrop)
                 else:
@@ -183,9 +185,17 @@ class BranchformerEncoderLayer(nn.Module):
 
     def forward(self, x, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
                 pos_embs: Optional[torch.Tensor] = None):
-        B, T, _ = x.shape
+        B, T, d = x.shape
         m8 = F.mask_u8(src_key_padding_mask, B, T, x.device)
-        return F.block(x, self.make_run(B, T, m8, src_mask), list(self.parameters())), None
+        stream = F.stream_dtype(x.dtype)
+        if stream == x.dtype:
+            return F.block(x, self.make_run(B, T, m8, src_mask), list(self.parameters())), None
+        inner = self.make_run(B, T, m8, src_mask, compute_dtype=x.dtype)     # a bf16 layer on its own: float32 stream inside
+
+        def run(xin, need):
+            y, b = inner(ops.cast(ops.rows2d(xin), stream).view(B, T, d), need)
+            return ops.cast(ops.rows2d(y), xin.dtype).view(B, T, d), b
+        return F.block(x, run, list(self.parameters())), None
 
 
 class BranchformerEncoder(nn.Module):
@@ -205,15 +215,11 @@ class BranchformerEncoder(nn.Module):
         self.attention_type = attention_type
 
     def forward(self, src, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
-                pos_embs: Optional[torch.Tensor] = None, dynchunktrain_config=None):
+                pos_embs: Optional[torch.Tensor] = None, dynchunktrain_config=None, _compute_dtype=None):
         if dynchunktrain_config is not None:
             raise NotImplementedError("Dynamic chunk training is not supported for the Branchformer (as the reference)")
         B, T, _ = src.shape
         m8 = F.mask_u8(src_key_padding_mask, B, T, src.device)
-        out = src
-        attention_lst = []
-        for layer in self.layers:
-            out = F.block(out, layer.make_run(B, T, m8, src_mask), list(layer.parameters()),
-                          getattr(layer, "_on_bwd_done", None))
-            attention_lst.append(None)
-        return F.final_norm(out, self.norm.norm), attention_lst
+        out = F.encoder_stack(src, list(self.layers), lambda layer, compute: layer.make_run(B, T, m8, src_mask, compute_dtype=compute),
+                              self.norm.norm, list(self.parameters()), _compute_dtype)
+        return out, [None] * len(self.layers)

@@ -206,40 +206,8 @@ class ConformerEncoder(nn.Module):
         B, T, d = src.shape
         m8 = F.mask_u8(src_key_padding_mask, B, T, src.device)
         chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
-        norm = self.norm.norm
-        layers = list(self.layers)
-        # compute dtype: what the caller says (TransformerASR.encode hands over the float32 stream of a bf16 model), else the
-        # input's; the stream between the layers is functional.stream_dtype(compute) - float32 for a bf16 model by default
-        compute = _compute_dtype or src.dtype
-        stream = F.stream_dtype(compute)
-
-        def run(xin, need):
-            """The whole stack as ONE autograd block: the gradient between two layers never visits autograd (which would cast
-            the bf16 gradient of a float32 stream tensor with an aten kernel per layer); every layer's parameter-gradient
-            reductions and its bucket hook still run right behind that layer's backward."""
-            x = xin
-            if x.dtype != stream:
-                x = ops.cast(ops.rows2d(x), stream).view(B, T, d)
-            bwds = []
-            for layer in layers:
-                x, b = layer.make_run(B, T, m8, src_mask, chunk, compute_dtype=compute)(x, need)
-                bwds.append((b, getattr(layer, "_on_bwd_done", None)))
-            y, bn = F.ln_fwd(ops.rows2d(x), norm.weight, norm.bias, norm.eps, need, out_dtype=compute)
-            if not need:
-                return y.view(B, T, d), None
-
-            def bwd(dy3):
-                dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
-                if dy.dtype != compute:
-                    dy = ops.cast(dy, compute)
-                g = bn(dy).view(B, T, d)
-                F.flush_deferred()
-                for b, done in reversed(bwds):
-                    g = b(g)
-                    F.flush_deferred()                     # this layer's parameter gradients are final ...
-                    if done is not None:
-                        done()                             # ... before its bucket is all-reduced (trainer.FlatAdamW)
-                return g if g.dtype == xin.dtype else ops.cast(ops.rows2d(g), xin.dtype).view(B, T, d)
-            return y.view(B, T, d), bwd
-        out = F.block(src, run, list(self.parameters()))
-        return out, [None] * len(layers)
+        # compute dtype: what the caller says (TransformerASR.encode hands over the float32 stream of a bf16 model), else the input's
+        out = F.encoder_stack(src, list(self.layers),
+                              lambda layer, compute: layer.make_run(B, T, m8, src_mask, chunk, compute_dtype=compute),
+                              self.norm.norm, list(self.parameters()), _compute_dtype)
+        return out, [None] * len(self.layers)

@@ -160,7 +160,7 @@ class TransformerASR(nn.Module):
             pe = torch.zeros((T, lin.weight.shape[0]), device=src.device)
         x = F.input_proj_pe(src, lin.weight, lin.bias, pe, T, self.p_drop if self.training else 0.0)
         # (x is the residual stream: float32 for a bf16 model by default - the encoder is told the GEMM dtype)
-        kw = {"_compute_dtype": src.dtype} if isinstance(self.encoder, ConformerEncoder) else {}
+        kw = {"_compute_dtype": src.dtype}
         out, _ = self.encoder(src=x, src_mask=src_mask, src_key_padding_mask=key_padding_mask, pos_embs=None,
                               dynchunktrain_config=dynchunktrain_config, **kw)
         return out

@@ -84,7 +84,7 @@ def test_branchformer_layer_golden(dtype):
     layer.cuda().eval()      # (the cell keeps its default global_dropout = 0.1 in train(), as the reference: Branchformer.py:209-218)
     x = a["x"].cuda().to(dtype).requires_grad_(True)
     y, _ = layer(x, src_key_padding_mask=a["pad_mask"].cuda())
-    ftol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (2e-2, 5e-2)
+    ftol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (1e-2, 5e-2)      # (float32 stream; parameter gradients over 2 x 23 frames)
     assert rel_err(y, a["y"]) <= ftol, rel_err(y, a["y"])
     (y.float() * a["r"].cuda()).sum().backward()
     assert rel_err(x.grad, a["gx"]) <= gtol, rel_err(x.grad, a["gx"])
@@ -132,7 +132,8 @@ def test_encoder_wrapper_golden(name, dtype):
         kw["dynchunktrain_config"] = DynChunkTrainConfig(*meta["dynchunk"])
     with torch.no_grad():
         y = enc(src.cuda().to(dtype), a["wav_len"].cuda(), **kw)
-    # bf16: 1e-2 (north_star) for the Conformer stacks - float32 residual stream; the Branchformer keeps a bf16 stream (3e-2)
+    # bf16: 1e-2 (north_star) with the float32 residual stream.  The Branchformer golden (d = 32, csgu 96: a bf16 GEMM over K = 32
+    # has no averaging) measures 2.0e-2; at the CommonVoice widths the same layer holds 1e-2 (tests/test_width_gpu.py)
     tol = 1e-3 if dtype == torch.float32 else (3e-2 if meta["encoder_module"] == "branchformer" else 1e-2)
     assert rel_err(y, a["y"]) <= tol, rel_err(y, a["y"])
 

@@ -91,8 +91,7 @@ def _compare(name, dtype, y, gx, gp, yref, gref, ftol, gtol, rms_ftol, rms_gtol)
 # tolerances: (forward max-rel, gradient max-rel, forward RMS-rel, gradient RMS-rel)
 # bf16, Conformer (float32 residual stream = the reference's autocast semantics): the north_star bars, 1e-2 forward / 3e-2 gradients
 TOLS = {torch.float32: (1e-3, 1e-3, 1e-3, 1e-3), torch.bfloat16: (1e-2, 3e-2, 1e-2, 2e-2)}
-# the Branchformer still stores its residual stream in bf16 (round-2 tolerances)
-TOLS_BF16_STREAM = {torch.float32: (1e-3, 1e-3, 1e-3, 1e-3), torch.bfloat16: (2e-2, 5e-2, 1e-2, 2e-2)}
+TOLS_BF16_STREAM = TOLS
 
 
 def _conformer(layers, d, f):
