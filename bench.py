@@ -115,7 +115,7 @@ def time_kernel(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-PMC_FILES = ("r02_pmc_traffic.txt", "r02_pmc_wgrad_group.txt", "r01_pmc_traffic.txt")
+PMC_FILES = ("r03_pmc_traffic.txt", "r03_pmc_wgrad_group.txt", "r02_pmc_traffic.txt", "r02_pmc_wgrad_group.txt", "r01_pmc_traffic.txt")
 PMC_NOTE = ("HBM bytes per launch read from the COMMITTED PMC passes under profiles/ (TCC FETCH_SIZE x2-corrected + "
             "WRITE_SIZE, separate --pmc passes of tools/pmc_traffic.sh / pmc_wgroup.sh on this exact shape) - a constant of the build, "
             "not measured in this run; null when no pass exists for the shape")
@@ -167,23 +167,30 @@ def roofline_step_kernels(step, dtype, top=8):
                 "hbm_GBps_algorithmic": nb / t / 1e9, "frac_hbm": nb / t / 1e9 / 8000.0, "mfma_TFLOPs": fl / t / 1e12,
                 "frac_mfma": fl / t / 1e12 / mfma_peak, "share_of_step_kernel_time": ms / total_ms}
     kernels = [entry(k, e) for k, e in sorted(by_name.items(), key=lambda kv: -kv[1][3])[:top]]
-    for k in kernels:                                  # HBM bytes from the committed PMC passes, where one exists for the shape
-        tag = k["kernel"].split(" +")[0].split(":")[0].strip()
-        k["traffic"] = pmc_traffic_bytes("wgrad_group bf16 (8 weights" if tag.startswith("wgrad_group bf16 (8 weights") else tag)
+    for k in kernels:                                  # HBM bytes from the committed PMC passes: the launch's full name first
+        full = k["kernel"].strip()                     # (shape + epilogue, the round-3 passes), then the bare shape (rounds 1-2)
+        tag = full.split(" +")[0].split(":")[0].strip()
+        k["traffic"] = (pmc_traffic_bytes(full + " [") or
+                        pmc_traffic_bytes("wgrad_group bf16 (8 weights" if tag.startswith("wgrad_group bf16 (8 weights") else tag))
+
+    def roof_of(label, e, d):
+        intensity = e[2] / max(e[1], 1.0)
+        bound = "hbm" if intensity < mfma_peak * 1e12 / 8000e9 else "mfma"
+        return {"kernel": label, "bound": bound, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                "achieved": d["hbm_GBps_algorithmic"] if bound == "hbm" else d["mfma_TFLOPs"],
+                "peak": 8000.0 if bound == "hbm" else mfma_peak,
+                "frac": d["frac_hbm"] if bound == "hbm" else d["frac_mfma"],
+                "launch_us": d["in_step_avg_us"], "calls_per_step": e[0], "share_of_step_kernel_time": d["share_of_step_kernel_time"],
+                "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "arithmetic_intensity_flop_per_byte": intensity,
+                "mfma_TFLOPs": d["mfma_TFLOPs"], "mfma_frac": d["frac_mfma"], "step_kernel_time_ms": total_ms}
+    # headline: the ONE kernel (symbol family + shape + epilogue) with the largest share of the step's kernel time
+    top_name, top_e = max(by_name.items(), key=lambda kv: kv[1][3])
+    roof = roof_of(top_name + " (in-step average over its launches, HIP events on the launch stream)", top_e, kernels[0])
+    roof["traffic"], roof["traffic_note"] = kernels[0].get("traffic"), PMC_NOTE
+    # and, for continuity with rounds 1-2, the dominant kernel FAMILY aggregated over all its shapes
     fam, e = max(by_fam.items(), key=lambda kv: kv[1][3])
-    d = entry(fam, e)
-    intensity = e[2] / max(e[1], 1.0)
-    bound = "hbm" if intensity < mfma_peak * 1e12 / 8000e9 else "mfma"
-    roof = {"kernel": f"{fam} (all {e[0]} in-step launches of the family, HIP events on their launch streams)",
-            "bound": bound, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-            "achieved": d["hbm_GBps_algorithmic"] if bound == "hbm" else d["mfma_TFLOPs"],
-            "peak": 8000.0 if bound == "hbm" else mfma_peak,
-            "frac": d["frac_hbm"] if bound == "hbm" else d["frac_mfma"],
-            "launch_us": d["in_step_avg_us"], "calls_per_step": e[0], "share_of_step_kernel_time": d["share_of_step_kernel_time"],
-            "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "arithmetic_intensity_flop_per_byte": intensity,
-            "mfma_TFLOPs": d["mfma_TFLOPs"], "mfma_frac": d["frac_mfma"],
-            "step_kernel_time_ms": total_ms, "traffic": None, "traffic_note": PMC_NOTE}
-    return roof, kernels
+    fam_roof = roof_of(f"{fam} (all {e[0]} in-step launches of the family)", e, entry(fam, e))
+    return roof, kernels, fam_roof
 
 
 def roofline_wgrad(cfg, dtype):
@@ -264,10 +271,18 @@ def cpu_baseline(cfg, train):
     workload: same model shapes, fp32, B=4 utterances of the same T (about 10-30 s of CPU work).  Timed at
     min(all cores, 32) threads (the reported value) and at 8 threads."""
     from oracle import smx_oracle as O
-    cores = min(os.cpu_count() or 1, 32)   # torch CPU scales poorly past ~32 threads on these small GEMMs
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
+    except Exception:                                     # noqa: BLE001
+        phys = max(1, (os.cpu_count() or 2) // 2)
+    # SURVEY 8(d): "all physical cores and n = 8"; torch CPU scales poorly past ~32 threads on these small GEMMs, so 32 is
+    # timed as well and the BEST of the three is the reported value (VERDICT r02: the 32-thread value flattered the GPU)
+    thread_counts = sorted({min(8, phys), min(32, phys), phys})
+    cores = thread_counts[0]
     torch.set_num_threads(cores)
     if cfg.get("stack_only"):
-        return cpu_baseline_stack(cfg, cores)
+        return cpu_baseline_stack(cfg, min(32, phys))
     enc = build_encoder(cfg, "cpu")
     sd = {k: v.detach().clone().requires_grad_(train and v.is_floating_point())
           for k, v in enc.transformer.state_dict().items() if k != "positional_encoding.pe"}
@@ -293,19 +308,19 @@ def cpu_baseline(cfg, train):
             step()
             n += 1
         return (time.perf_counter() - t0) / n, n
-    dt, n = timed(12.0)
     frames = small["B"] * small["T"]
-    out = {"value": frames / dt, "unit": "encoder frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-           "host_cpus": os.cpu_count(),
-           "sample": f"oracle/smx_oracle.py asr_encode {'fwd+bwd' if train else 'fwd'}, fp32, B={small['B']} x T={small['T']} "
-                     f"of the same model, {n} steps, torch {torch.__version__}, {cores} threads"}
-    if cores > 8:
-        torch.set_num_threads(8)
-        dt8, n8 = timed(6.0)
-        out["value_8_threads"] = frames / dt8
-        out["sample_8_threads"] = f"same sample, {n8} steps, 8 threads"
-        torch.set_num_threads(cores)
-    return out
+    by_threads = {}
+    for nt in thread_counts:
+        torch.set_num_threads(nt)
+        dt, n = timed(8.0 if nt == thread_counts[0] else 6.0)
+        by_threads[nt] = (frames / dt, n)
+    best = max(by_threads, key=lambda k: by_threads[k][0])
+    return {"value": by_threads[best][0], "unit": "encoder frames/s", "cores": best, "kind": "port", "cpu_model": cpu_model(),
+            "host_cpus": os.cpu_count(), "physical_cores": phys,
+            "frames_per_s_by_threads": {str(k): v[0] for k, v in by_threads.items()},
+            "sample": f"oracle/smx_oracle.py asr_encode {'fwd+bwd' if train else 'fwd'}, fp32, B={small['B']} x T={small['T']} "
+                      f"of the same model, {by_threads[best][1]} steps, torch {torch.__version__}; best of "
+                      f"{thread_counts} threads = {best}"}
 
 
 def cpu_baseline_stack(cfg, cores):
@@ -353,6 +368,9 @@ def main():
                     help="weak: every rank runs the config's batch (default); strong: the GLOBAL batch is the config's batch, "
                          "each of the N ranks gets B / N utterances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-points", action="store_true",
+                    help="skip the extra_points of the default line (SURVEY 8d batches: C2b B=64 x 500, C2a B=10 x 375, and the bf16 "
+                         "residual stream), each a short child run of this script")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -536,6 +554,8 @@ def main():
                    "padded_frames_per_step": frames_per_step, "valid_frames_rank0": valid_frames,
                    "input": f"(B,T,{cfg['input']}) N(0,1), wav_len U(0.5,1), zero padded",
                    "dropout": (args.dropout if train else 0.0), "parallelism": f"dp{world}", "init": "xavier_normal seed 3407",
+                   "residual_stream": ("float32 (torch autocast semantics, the reference's `precision: bf16`)" if F_stream_f32(dtype)
+                                       else ("bf16 (SMX_RESIDUAL=bf16)" if dtype == torch.bfloat16 else "float32 model")),
                    "launch": graph_note},
     }
     if args.config in FLOPS_PER_FRAME_FWD:
@@ -544,17 +564,47 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             if train and world == 1 and not force_dist:
-                out["roofline"], out["roofline_kernels"] = roofline_step_kernels(step, dtype)
+                out["roofline"], out["roofline_kernels"], out["roofline_family"] = roofline_step_kernels(step, dtype)
                 out["roofline_isolated"] = [roofline_wgrad(cfg, dtype), roofline_gemm(cfg, dtype)]
             else:
                 out["roofline"] = roofline_gemm(cfg, dtype)
             out["roofline_pool"] = roofline_pool(dtype)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, train)
+        default_line = (args.config == "c2b" and train and world == 1 and not force_dist and args.batch is None
+                        and args.frames is None and args.dtype == "bf16")
+        if default_line and not args.no_extra_points:
+            out["extra_points"] = extra_points()
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def F_stream_f32(dtype):
+    from summarymixing_amd import functional as F
+    return dtype == torch.bfloat16 and F.stream_dtype(dtype) == torch.float32
+
+
+def extra_points():
+    """Short child runs of this script (free of this process's allocations): the batches SURVEY 8(d) defines next to the
+    headline's B = 128 x 500, and the headline config on the bf16 residual stream."""
+    import subprocess
+    pts = []
+    runs = (("C2b B=64 x T=500 (SURVEY 8d saturating batch)", ["--config", "c2b", "--batch", "64"], {}),
+            ("C2a recipe batch B=10 x T=375 (150 s of audio, ...transducer.yaml:116)", ["--config", "c2a", "--batch", "10", "--frames", "375"], {}),
+            ("C2b B=128 x T=500 on the bf16 residual stream (SMX_RESIDUAL=bf16, rounds 1-2)", ["--config", "c2b"], {"SMX_RESIDUAL": "bf16"}))
+    for label, extra, env in runs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "4", "--no-cpu-baseline", "--no-roofline",
+               "--no-extra-points"] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, **env))
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            pts.append({"point": label, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                        "launch": d["config"]["launch"], "residual_stream": d["config"]["residual_stream"]})
+        except Exception as ex:                          # noqa: BLE001
+            pts.append({"point": label, "error": f"{type(ex).__name__}: {ex}"[:200]})
+    return pts
 
 
 def main_stack(args, cfg, dtype, dev, rank, world):
@@ -606,7 +656,9 @@ def main_stack(args, cfg, dtype, dev, rank, world):
            "config": {"workload": cfg["name"] + " forward", "per_gpu_batch": B, "enc_frames_per_utt": T if not sp else T // world,
                       "padded_frames_per_step": frames_per_step, "valid_frames": int(lens.sum()),
                       "input": f"(B,T,{cfg['d']}) N(0,1) into the encoder stack, lengths U(0.5,1), zero padded",
-                      "parallelism": (f"sp{world} (time axis sharded)" if sp else f"dp{world}"), "launch": "eager"},
+                      "parallelism": (f"sp{world} (time axis sharded)" if sp else f"dp{world}"), "launch": "eager",
+                      "residual_stream": ("float32 (torch autocast semantics)" if (F_stream_f32(dtype) and not sp) else
+                                          ("bf16" if dtype == torch.bfloat16 else "float32 model"))},
            "model_tflops": value * FLOPS_PER_FRAME_FWD["c5"] / 1e12}
     if rank == 0:
         if not args.no_roofline:

@@ -43,6 +43,32 @@ enum { SMX_PAD_ZERO = 0, SMX_PAD_REFLECT = 1 };
 int smx_version(void);
 const char* smx_last_error(void);
 
+/* The library's tuning / diagnostic knobs.  They are read from the environment ONCE, when the library is first used, into
+ * this struct (never again: no getenv on any call path); smx_get_config returns the values in force.  Every field defaults
+ * to the measured-best setting; the SMX_* variable that overrides it is named in the comment.  Ablation switches
+ * (SMX_GEMM_ABLATE, SMX_WGROUP_ABLATE, SMX_DWROLL_ABLATE) only exist in builds with -DSMX_DIAG and read 0 otherwise. */
+typedef struct smx_config {
+  int32_t gemm_tile64;      /* SMX_GEMM_TILE64: force the 64 x 64 tile (0)                                   */
+  int32_t gemm_wide;        /* SMX_GEMM_WIDE: -1 auto, 0 / 1 force the 128 x 256 tile off / on               */
+  int32_t tn_dma;           /* SMX_TN_DMA: wgrad (TN) GEMM on the LDS-DMA ring (1)                           */
+  int32_t nt_z;             /* SMX_NT_Z: non-temporal stores for saved pre-activations (1)                   */
+  int64_t nt_bytes;         /* SMX_NT_BYTES: outputs at least this large are streamed past the caches (96 MB) */
+  int32_t reg_epi;          /* SMX_REG_EPI: register-domain epilogue 0 off, 1 always, 2 without a saved Z (2) */
+  int32_t epi_simple;       /* SMX_EPI_SIMPLE: specialised epilogue instantiations 0 / 1 / 2 (2)             */
+  int32_t wgrad_blocks;     /* SMX_WGRAD_BLOCKS: workgroup target of the per-weight wgrad (0 = 384)          */
+  int32_t wgrad_min_rows;   /* SMX_WGRAD_MIN_ROWS: frames per split-K slice at least (0 = 512)               */
+  int32_t pool_blocks;      /* SMX_POOL_BLOCKS: workgroup target of the masked-sum pool kernel (512)         */
+  int32_t wgroup_blocks;    /* SMX_WGROUP_BLOCKS: workgroup target of the grouped wgrad (0 = one per CU)     */
+  int32_t wgroup_bk;        /* SMX_WGROUP_BK: frames per ring stage of the grouped wgrad, 32 or 64 (32)      */
+  int32_t wgroup_pp;        /* SMX_WGROUP_PP: ping-pong issue order 0 / 1 / 2 (1)                            */
+  int32_t dwroll;           /* SMX_DWROLL: rolling register-window depthwise conv (1)                        */
+  int32_t dwroll_csgu;      /* SMX_DWROLL_CSGU: ... for the CSGU form (1)                                    */
+  int32_t dwroll_seg;       /* SMX_DWROLL_SEG: frames per wave segment (0 = auto)                            */
+  int32_t gemm_ablate, wgroup_ablate, dwroll_ablate;   /* SMX_DIAG builds only                                  */
+  int32_t diag_build;       /* 1 when the library was compiled with -DSMX_DIAG                               */
+} smx_config;
+int smx_get_config(smx_config* out);
+
 /* Epilogue of the fused projection GEMM:
  *   v      = acc + bias[m] + C0[map(n), m]
  *   Z[n,m] = v                                   (optional pre-activation store, dtype T)
@@ -76,6 +102,8 @@ typedef struct smx_epilogue {
    * tensor); SMX_IO_LNX_F32 = `ln_x` (SMX_EPI_LN_BWD) is float32.  lnf_y is dtype T (the next GEMM's input) unless
    * SMX_IO_LNFY_F32 (the LayerNorm output is itself the stream: the layer-final norm2, Conformer.py:536). */
   int32_t io_flags;    int32_t pad_;
+  /* device step counter of THIS call's fused dropout (see smx_set_step_counter); NULL = the calling thread's binding */
+  const uint64_t* epoch;
 } smx_epilogue;
 enum { SMX_IO_RES_F32 = 1, SMX_IO_LNX_F32 = 2, SMX_IO_LNFY_F32 = 4 };
 /* flags.  SMX_EPI_ACT_GRAD turns the epilogue into the BACKWARD of an upstream activation layer: z is then a
@@ -359,7 +387,9 @@ int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, const int32
                      void* grad, int64_t ldg, void* workspace, void* stream);
 
 /* step <= 0: the bias-correction step is read from the device step counter (smx_set_step_counter) instead. */
-/* Optional device step counter (one uint64 in device memory), the only process-global of the library.  While set
+/* Optional device step counter (one uint64 in device memory).  The binding is PER HOST THREAD (thread-local, not
+ * process-global: two optimizers driven from two threads do not share it); a GEMM call can also name its counter
+ * explicitly in smx_epilogue.epoch.  While set
  * (non-NULL), every fused / standalone dropout mixes the counter's current value into its seed and smx_adamw_step with
  * step <= 0 takes its step from it: a whole training step can then be captured ONCE in a hipGraph (all kernel
  * arguments constant) and replayed - masks and bias correction still advance, because the counter does

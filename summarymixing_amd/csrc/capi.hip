@@ -25,8 +25,42 @@ int check_launch(const char* what) {
 
 }  // namespace smx
 
+#include <stdlib.h>
 namespace smx {
-const uint64_t* g_step_counter = nullptr;
+thread_local const uint64_t* g_step_counter = nullptr;
+static int env_i(const char* n, int dflt) { const char* e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; }
+static long env_l(const char* n, long dflt) { const char* e = getenv(n); return (e && e[0]) ? atol(e) : dflt; }
+const smx_config& cfg() {
+  // function-local static: initialised exactly once (thread-safe), on the first call of any entry point that needs a knob
+  static const smx_config c = [] {
+    smx_config k;
+    memset(&k, 0, sizeof(k));
+    k.gemm_tile64 = getenv("SMX_GEMM_TILE64") ? 1 : 0;
+    k.gemm_wide = env_i("SMX_GEMM_WIDE", -1);
+    k.tn_dma = env_i("SMX_TN_DMA", 1);
+    k.nt_z = env_i("SMX_NT_Z", 1);
+    k.nt_bytes = env_l("SMX_NT_BYTES", 96L << 20);
+    k.reg_epi = env_i("SMX_REG_EPI", 2);
+    k.epi_simple = env_i("SMX_EPI_SIMPLE", 2);
+    k.wgrad_blocks = env_i("SMX_WGRAD_BLOCKS", 0);
+    k.wgrad_min_rows = env_i("SMX_WGRAD_MIN_ROWS", 0);
+    k.pool_blocks = (int)env_l("SMX_POOL_BLOCKS", 512);
+    k.wgroup_blocks = env_i("SMX_WGROUP_BLOCKS", 0);
+    k.wgroup_bk = env_i("SMX_WGROUP_BK", 32);
+    k.wgroup_pp = env_i("SMX_WGROUP_PP", 1);
+    { const char* e = getenv("SMX_DWROLL"); k.dwroll = (e && e[0] == '0') ? 0 : 1; }
+    { const char* e = getenv("SMX_DWROLL_CSGU"); k.dwroll_csgu = (e && e[0] == '0') ? 0 : 1; }
+    k.dwroll_seg = env_i("SMX_DWROLL_SEG", 0);
+#ifdef SMX_DIAG
+    k.gemm_ablate = env_i("SMX_GEMM_ABLATE", 0);
+    k.wgroup_ablate = env_i("SMX_WGROUP_ABLATE", 0);
+    k.dwroll_ablate = env_i("SMX_DWROLL_ABLATE", 0);
+    k.diag_build = 1;
+#endif
+    return k;
+  }();
+  return c;
+}
 __global__ void step_counter_add_kernel(uint64_t* c, uint64_t inc) { c[0] += inc; }
 }  // namespace smx
 
@@ -40,5 +74,10 @@ extern "C" int smx_step_counter_add(uint64_t* dev_counter, uint64_t inc, void* s
   return smx::check_launch("smx_step_counter_add");
 }
 
+extern "C" int smx_get_config(smx_config* out) {
+  SMX_REQUIRE(out, "smx_get_config: null pointer");
+  *out = smx::cfg();
+  return SMX_OK;
+}
 extern "C" int smx_version(void) { return SMX_VERSION; }
 extern "C" const char* smx_last_error(void) { return smx::last_error_buf(); }

@@ -557,8 +557,7 @@ using namespace smx;
 static int roll_kind(int dtype, int T, int D, int k, int glu, int pad_mode, int chunk, bool has_gate) {
   if (!roll_enabled() || k != 31 || chunk > 0 || D % 64 != 0) return 0;
   if (glu && !has_gate && pad_mode == SMX_PAD_ZERO) return 1;
-  static int csgu = -1;
-  if (csgu < 0) { const char* e = getenv("SMX_DWROLL_CSGU"); csgu = (e && e[0] == '0') ? 0 : 1; }
+  const int csgu = cfg().dwroll_csgu;
   if (csgu && !glu && has_gate && pad_mode == SMX_PAD_REFLECT && dtype == SMX_BF16 && T > 15) return 2;
   return 0;
 }
@@ -702,8 +701,7 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
     roll_geometry(B, T, D, &seg, &nseg, &gr);
     float* partial = reinterpret_cast<float*>(workspace);
     dim3 g1((unsigned)(8 * (D / 64) * ((gr + 7) / 8)));
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("SMX_DWROLL_ABLATE"); abl = e ? atoi(e) : 0; }
+    const int abl = cfg().dwroll_ablate;                  // (0 unless built with -DSMX_DIAG)
     if (rk == 2) {
       hipLaunchKernelGGL(dwconv_rollc_bwd, g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
       // the gradient of the mirrored virtual frames goes back to frames 1..15 / T-16..T-2 (30 rows per utterance)

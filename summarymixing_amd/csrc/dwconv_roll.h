@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64) void dwconv_csgu_fold_kernel(DwParams p) {
 // time segment per wave: 128 frames (8 steps; 30 halo rows = 1.23x) unless that leaves the chip short of waves
 inline void roll_geometry(int B, int T, int D, int* seg, int* nseg, int* gy) {
   static int forced = -1;
-  if (forced < 0) { const char* e = getenv("SMX_DWROLL_SEG"); forced = e ? atoi(e) : 0; }
+  if (forced < 0) forced = cfg().dwroll_seg;
   int s = forced > 0 ? (forced + 15) / 16 * 16 : 128;
   if (forced <= 0) {
     while (s > 32 && (long)B * ((T + s - 1) / s) * (D / 64) < 2048) s >>= 1;    // < 2 waves per SIMD: shorter segments
@@ -726,7 +726,7 @@ inline void roll_geometry(int B, int T, int D, int* seg, int* nseg, int* gy) {
 
 inline bool roll_enabled() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("SMX_DWROLL"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (on < 0) on = cfg().dwroll;
   return on == 1;
 }
 

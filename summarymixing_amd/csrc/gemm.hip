@@ -154,7 +154,11 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   for (int i = 0; i < FN; ++i) fpa[i] = frag_pre(wn * WN + i * 32 + l31, hi);
 #pragma unroll
   for (int j = 0; j < FM; ++j) fpb[j] = frag_pre(wm * WM + j * 32 + l31, hi);
-  const bool ab_nold = p.ablate & 4, ab_nomfma = p.ablate & 2, ab_nost = p.ablate & 1;
+#ifdef SMX_DIAG
+  const bool ab_nold = p.ablate & 4, ab_nomfma = p.ablate & 2, ab_nost = p.ablate & 1;   // tools/one_gemm.py phase ablations
+#else
+  constexpr bool ab_nold = false, ab_nomfma = false, ab_nost = false;                     // (compiled out of the product)
+#endif
   constexpr int CSN = 16 / (int)sizeof(T);
   float cs[CSN];
 #pragma unroll
@@ -736,15 +740,15 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
 
   // big tiles once they alone fill the chip (256 CUs x 2 resident blocks); otherwise 64x64 for more blocks
   long big = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch * p.splits;
-  static const int force_small = getenv("SMX_GEMM_TILE64") ? 1 : 0;   // experiment knob
+  const int force_small = cfg().gemm_tile64;             // experiment knob
   // wide 128 x 256 tile (2 workgroups per CU, 128 accumulator registers per lane): when it covers the whole output
   // width (M == 256: the activation panel is fetched exactly once and 500 tiles fill the 512 slots in one round at
   // 64000 frames) or when the reduction is long enough for the doubled MFMA-per-LDS-read ratio to matter.
   // Measured at 64000 frames: (K=1024, M=256) NT 77 -> 59 us, NN 65 -> 55 us; (K=256, M=1024) 99 -> 103 us (not used).
-  static const int wide_env = getenv("SMX_GEMM_WIDE") ? atoi(getenv("SMX_GEMM_WIDE")) : -1;
+  const int wide_env = cfg().gemm_wide;
   const bool wide = wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 512 && p.M <= 512));
   // wgrad-shaped TN GEMMs with both operands on the LDS-DMA ring (gemm_tn_dma_kernel).  SMX_TN_DMA=0 disables it.
-  static const int tn_dma_env = getenv("SMX_TN_DMA") ? atoi(getenv("SMX_TN_DMA")) : 1;
+  const int tn_dma_env = cfg().tn_dma;
   if constexpr (sizeof(T) == 2 && !A_KC && !B_KC) {
     if (tn_dma_env && vec && p.N % 128 == 0 && p.M % 128 == 0 && p.K % 64 == 0 && p.kchunk % 64 == 0 && p.K >= 64 &&
         p.e.out_mode != SMX_OUT_ATOMIC_F32 && !p.e.colsum && !p.e.res && !p.e.c0 && !p.e.z && !p.ablate &&
@@ -864,23 +868,22 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   // Store policy.  Z (the pre-activation saved for the backward pass) is not read again for a long time: always
   // streamed past the caches.  The output C is consumed by the next kernel: streamed only when it is too large to
   // survive in the 256 MB MALL anyway (measured: FFN up-projection at 64000 frames 118 -> 96 us, no change at 32000).
-  static const long nt_bytes = getenv("SMX_NT_BYTES") ? atol(getenv("SMX_NT_BYTES")) : (96L << 20);
-  static const int nt_z = getenv("SMX_NT_Z") ? atoi(getenv("SMX_NT_Z")) : 1;
+  const long nt_bytes = cfg().nt_bytes;
+  const int nt_z = cfg().nt_z;
   p.nt = (nt_z ? 1 : 0) | (((long)N * M * (long)cs * batch >= nt_bytes) ? 2 : 0);
   // register-domain epilogue (gemm_kernel): 0 off, 1 every eligible epilogue, 2 (default) only without a saved Z - measured
   // at 64000 frames: bias-only K=256 -> M=1024 102 -> 77 us, NN+bias 91 -> 71 us, but bias+Swish+Z 99 -> 99 us; training
   // steps unchanged with either setting, forward-only steps -2 % (C2b) / -4 % (C5)
-  static const int reg_epi_env = getenv("SMX_REG_EPI") ? atoi(getenv("SMX_REG_EPI")) : 2;
+  const int reg_epi_env = cfg().reg_epi;
   p.reg_epi = reg_epi_env && (reg_epi_env != 2 || p.e.z == nullptr) && dtype == SMX_BF16 && p.e.out_mode == SMX_OUT_T && !p.e.res && !p.e.c0 && !p.e.colsum &&
               !(p.e.flags & SMX_EPI_ACT_GRAD) && splits == 1 && p.epi_lds && M % 8 == 0 &&
               (p.e.z == nullptr || (aligned16(p.e.z) && p.e.ldz % 8 == 0)) && aligned16(C) && ldc % 8 == 0 && strideC % 8 == 0;
-  static const int simple_env = getenv("SMX_EPI_SIMPLE") ? atoi(getenv("SMX_EPI_SIMPLE")) : 2;
+  const int simple_env = cfg().epi_simple;
   p.epi_simple = 0;
   if (simple_env && !p.e.c0 && !p.e.colsum) p.epi_simple = (p.e.res || (p.e.flags & SMX_EPI_ACT_GRAD)) ? (simple_env >= 2 ? 2 : 0) : 1;
-  static const int ablate = getenv("SMX_GEMM_ABLATE") ? atoi(getenv("SMX_GEMM_ABLATE")) : 0;
-  p.ablate = ablate;
+  p.ablate = cfg().gemm_ablate;                          // (0 unless built with -DSMX_DIAG)
   p.dbg = g_dbg_stamps;
-  p.epoch = g_step_counter;
+  p.epoch = p.e.epoch ? p.e.epoch : g_step_counter;
   p.acolsum = acolsum;
   p.dthresh = (unsigned)((double)p.e.drop_p * 4294967296.0);
   SMX_REQUIRE(p.e.drop_cols >= 0 && p.e.drop_cols <= M && p.e.drop_cols % 8 == 0, "smx_gemm: drop_cols must be a multiple of 8 in [0, M]");
@@ -991,7 +994,7 @@ static int wgrad_splits(int rows, int M, int K, int batch) {
   // workgroups to aim for: exactly two per CU.  640 (2.5 per CU) leaves half the CUs with a third workgroup and the
   // launch takes as long as those; measured at 64000 frames: 71 -> 66 us (1024x256), 42 -> 35 us (256x256).
   // (The wide 128x256 tile does not help here: 2.5x slower with two register stages (spills), 71 vs 66 us with one.)
-  static const int target_env = getenv("SMX_WGRAD_BLOCKS") ? atoi(getenv("SMX_WGRAD_BLOCKS")) : 0;
+  const int target_env = cfg().wgrad_blocks;
   // (with the LDS-DMA kernel and the wgrads on a side stream next to the dgrad chain, 384 = 1.5 per CU is the better
   // target for the step: C2b 27.04 -> 26.56 ms; fewer, longer splits also mean less slab traffic for the reduction)
   const long target = target_env > 0 ? target_env : 384;
@@ -999,7 +1002,7 @@ static int wgrad_splits(int rows, int M, int K, int batch) {
   // a whole split lives on one XCD (XCD x owns splits x, x + 8, ..): a split count that is not a multiple of 8 leaves
   // XCDs idle (6 splits of a 3072 x 512 weight: 236 us; 8 splits: 199 us)
   if (s >= 4) s = (s + 7) / 8 * 8;
-  static const int min_rows_env = getenv("SMX_WGRAD_MIN_ROWS") ? atoi(getenv("SMX_WGRAD_MIN_ROWS")) : 0;
+  const int min_rows_env = cfg().wgrad_min_rows;
   const int min_rows = min_rows_env > 0 ? min_rows_env : 512;   // frames per split: fewer, longer splits when the batch is small (slab traffic)
   long smax = (rows + min_rows - 1) / min_rows;
   if (s > smax) s = smax;

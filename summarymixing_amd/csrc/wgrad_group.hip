@@ -128,7 +128,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
   }
   const long stepa = (long)BK * it.lda, stepb = (long)BK * it.ldb;
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem + wave * 1024);
+#ifdef SMX_DIAG
   const bool ab_nomfma = p.ablate & 1, ab_nodma = p.ablate & 2;
+#else
+  constexpr bool ab_nomfma = false, ab_nodma = false;     // (ablations compiled out of the product)
+#endif
   // pieces j0 .. j0 + nj - 1 of stage s (both operands)
   auto issue_part = [&](int s, auto j0_tag, auto nj_tag) {
     constexpr int J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
@@ -137,7 +141,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
 #pragma unroll
     for (int j = J0; j < J0 + NJ; ++j) {
       wg_glds16(pa[j], dst + j * 8192);
+#ifdef SMX_DIAG
       if (!(p.ablate & 8)) wg_glds16(pb[j], dst + OP_BYTES + j * 8192);      // (8: no B pieces - is the DMA rate the bound?)
+#else
+      wg_glds16(pb[j], dst + OP_BYTES + j * 8192);
+#endif
       pa[j] += stepa;
       pb[j] += stepb;
     }
@@ -154,7 +162,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
   float bsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
   const bool do_cs = it.want_bias && tile_m == 0 && wm == 0;     // (uniform per wave)
 
+#ifdef SMX_DIAG
   const bool ab_nowait = p.ablate & 4;
+#else
+  constexpr bool ab_nowait = false;
+#endif
   long long t_start = 0, t_wait = 0, r_start = 0;
   if (p.dbg) { t_start = clock64(); r_start = wall_clock64(); }
   for (int s = 0; s < NST - 1 && s < niter; ++s) issue(s);
@@ -257,7 +269,7 @@ static int wg_splits(int rows, int total_tiles) {
   // (C2b layer) x 11 = 253 fills one round; 92 tiles (d_model 512) x 2 = 184 leaves 28 % of the chip idle, x 3 = 276 needs a
   // second round for 20 workgroups, x 8 = 736 fills 2.9 rounds (C2a step 49.4 -> 48.7 ms).  Every extra slice costs one more
   // fp32 slab per tile (written, read back by smx_reduce_jobs): score = fill of the last round - 1 % per slice.
-  static const int target_env = getenv("SMX_WGROUP_BLOCKS") ? atoi(getenv("SMX_WGROUP_BLOCKS")) : 0;
+  const int target_env = cfg().wgroup_blocks;
   if (total_tiles < 1) total_tiles = 1;
   const int nk = rows / 64;
   const int smax = nk / 8 > 0 ? nk / 8 : 1;                        // at least 8 K steps (512 frames) per slice
@@ -321,10 +333,10 @@ extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items,
   const int nk = rows / 64;
   p.ksteps_per_split = (nk + splits - 1) / splits;
   const int nwork = tiles * splits, per = (nwork + 7) / 8;
-  static const int bk_env = getenv("SMX_WGROUP_BK") ? atoi(getenv("SMX_WGROUP_BK")) : 32;   // (measured in the step: 32 + ping-pong 1)
-  static const int ablate_env = getenv("SMX_WGROUP_ABLATE") ? atoi(getenv("SMX_WGROUP_ABLATE")) : 0;
+  const int bk_env = cfg().wgroup_bk;                     // (measured in the step: 32 + ping-pong 1)
+  const int ablate_env = cfg().wgroup_ablate;             // (0 unless built with -DSMX_DIAG)
   p.ablate = ablate_env;
-  static const int pp_env = getenv("SMX_WGROUP_PP") ? atoi(getenv("SMX_WGROUP_PP")) : 1;
+  const int pp_env = cfg().wgroup_pp;
   p.pingpong = pp_env;
   p.dbg = g_wg_dbg;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -170,10 +170,13 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
     tok = None
     if _PROF is not None:
         es, osz = _es(a), (4 if epi.out_mode == L.OUT_F32 else _es(c))
-        side = (1 if epi.res else 0) + (1 if epi.z else 0)            # residual / saved or re-read pre-activation
-        side += (1 if epi.flags & L.EPI_LN_BWD else 0) + (1 if epi.ln_dx2 else 0)     # the LayerNorm input; the second output
-        side += 1 if epi.flags & L.EPI_LN_FWD else 0                                   # the normalised copy of the output
-        nb = batch * ((N * K + M * K + side * N * M) * es + N * M * osz)
+        # algorithmic bytes of the side tensors: residual (float32 on the fp32 residual stream), saved / re-read pre-activation,
+        # the LayerNorm input of a fused backward (float32 on the fp32 stream), its second output, the normalised copy of a
+        # fused forward (float32 when it is the stream itself)
+        side = (4 if epi.io_flags & L.IO_RES_F32 else es) * (1 if epi.res else 0) + es * (1 if epi.z else 0)
+        side += (4 if epi.io_flags & L.IO_LNX_F32 else es) * (1 if epi.flags & L.EPI_LN_BWD else 0) + es * (1 if epi.ln_dx2 else 0)
+        side += (4 if epi.io_flags & L.IO_LNFY_F32 else es) * (1 if epi.flags & L.EPI_LN_FWD else 0)
+        nb = batch * ((N * K + M * K) * es + side * N * M + N * M * osz)
         tag = ("+LNbwd" if epi.flags & L.EPI_LN_BWD else "") + ("+LNfwd" if epi.flags & L.EPI_LN_FWD else "")
         tag += "".join(t for t, on in (("+bias", epi.bias), ("+act", epi.act != L.ACT_NONE and not (epi.flags & L.EPI_ACT_GRAD)),
                                       ("+Z", epi.z and not (epi.flags & L.EPI_ACT_GRAD)), ("+actgrad(z)", epi.flags & L.EPI_ACT_GRAD),

@@ -93,3 +93,57 @@ def test_gemm_full_size_linearity_and_fp32_agreement():
     assert rel_err(y16, y32) <= 2e-6                      # same products, fp32 accumulation in both
     s = (x1.float() + x2.float())
     assert rel_err(mm(s, torch.float32), y32 + mm(x2, torch.float32)) <= 1e-5
+
+
+def test_c5_twelve_layer_stack_at_full_size_properties():
+    """BASELINE config 5 at the STACK level: the 12-layer d = 512 Conformer-SummaryMixing encoder on (8, 30000, 512), bf16 (what
+    `bench.py --config c5` times; the oracle would need hours).  Properties: finite; per-utterance independence and
+    padding-blindness of the SUMMARY (an utterance run ALONE, truncated to its own length, gives the same frames - except
+    the last 12 x 15: the reference's conv module reads the content of padded frames through its k = 31 window, one halo
+    per layer, SURVEY 7 "padding is not neutral"; the summary mean counts valid frames only); deterministic; linear in T."""
+    import time
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(3407)
+    B, T, d = 8, 30000, 512
+    enc = ConformerEncoder(12, d, 2048, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast")
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+    enc = enc.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    lens = torch.round((0.5 + 0.5 * torch.rand(B, generator=g)) * T).long()
+    lens[0] = T
+    pad = torch.arange(T)[None, :] < lens[:, None]
+    x = (torch.randn(B, T, d, generator=g) * pad[..., None]).cuda().bfloat16()
+    pad = pad.cuda()
+
+    def run(xx, pp):
+        with torch.no_grad():
+            return enc(xx, src_key_padding_mask=pp)[0]
+    y = run(x, pad)
+    assert y.shape == (B, T, d) and torch.isfinite(y).all()
+    assert torch.equal(y, run(x, pad))                                   # bit-reproducible
+    for b in (1, 6):
+        Lb = int(lens[b])
+        alone = run(x[b:b + 1, :Lb].contiguous(), torch.ones(1, Lb, dtype=torch.bool, device="cuda"))
+        keep = Lb - 12 * 15 - 8                                          # beyond the reach of the padded frames' content
+        e = rel_err(y[b, :keep], alone[0, :keep])
+        assert e <= 1e-2, (b, e)                                         # (different split-T pool partials / tile rows: bf16 noise only)
+    # an utterance does not see its neighbours: replace every OTHER utterance by noise of another length pattern
+    x2 = x.clone()
+    x2[2:] = (torch.randn(B - 2, T, d, generator=g).cuda().bfloat16() * pad[2:, :, None])
+    y2 = run(x2, pad)
+    assert rel_err(y2[:2], y[:2]) <= 1e-5
+    # linear in T
+    def timed(xx, pp):
+        run(xx, pp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(xx, pp)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    t_full = timed(x, pad)
+    t_half = timed(x[:, :T // 2].contiguous(), pad[:, :T // 2].contiguous())
+    assert 1.6 <= t_full / t_half <= 2.4, (t_full, t_half)
