@@ -367,6 +367,13 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank runs the config's batch (default); strong: the GLOBAL batch is the config's batch, "
                          "each of the N ranks gets B / N utterances")
+    ap.add_argument("--dynchunk", default=None, metavar="CHUNK[,LEFT]",
+                    help="Dynamic Chunk Training batch (…transducer.yaml:84-91): chunk size in encoder frames and, optionally, the "
+                         "left context in chunks (default: unlimited) - chunked summary means and Dynamic Chunk Convolution")
+    ap.add_argument("--reduce", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="gradient exchange of the data-parallel step (trainer.FlatAdamW): one all-reduce per layer bucket, or "
+                         "reduce-scatter + sharded AdamW + all-gather of the weights")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradients on the wire (xGMI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-points", action="store_true",
                     help="skip the extra_points of the default line (SURVEY 8d batches: C2b B=64 x 500, C2a B=10 x 375, and the bf16 "
@@ -430,7 +437,8 @@ def main():
     opt = None
     if train:
         opt = FlatAdamW(enc, lr=8e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
-                        compute_dtype=dtype)
+                        compute_dtype=dtype, reduce=args.reduce,
+                        grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32)
         if world > 1 or force_dist:   # one gradient bucket per encoder layer, reduced as soon as its backward is done
             for layer in enc.transformer.encoder.layers:
                 rng = opt.param_range(list(layer.parameters()))
@@ -438,11 +446,16 @@ def main():
     else:
         enc.eval()
     src, wav_len, r, valid_frames = synthetic_batch(cfg, rank, dev, dtype)
+    enc_kw = {}
+    if args.dynchunk:
+        from summarymixing_amd.utils.dynamic_chunk_training import DynChunkTrainConfig
+        parts = [int(x) for x in args.dynchunk.split(",")]
+        enc_kw["dynchunktrain_config"] = DynChunkTrainConfig(parts[0], parts[1] if len(parts) > 1 else None)
 
     def step():
         if train:
             opt.zero_grad()
-            y = enc(src, wav_len)
+            y = enc(src, wav_len, **enc_kw)
             y.backward(r)
             if world > 1 or force_dist:   # parameters outside the layer buckets (input Linear, final LN)
                 first = opt.param_range(list(enc.transformer.encoder.layers[0].parameters()))[0]
@@ -454,7 +467,7 @@ def main():
             opt.step()
         else:
             with torch.no_grad():
-                enc(src, wav_len)
+                enc(src, wav_len, **enc_kw)
 
     def barrier():
         if world > 1 or force_dist:
@@ -467,10 +480,12 @@ def main():
     # hipGraph: the ~1100 kernel launches of a step cost ~14 ms of host time - hidden behind the GPU at 64000 frames per
     # step, the bottleneck below ~30000.  One capture (after the eager warm-up has created gradients, shadows and
     # workspaces), then every timed step is one graph launch.  The step count (AdamW bias correction) and the dropout
-    # epoch live in a device counter, so replays still advance them (include/smx.h: smx_set_step_counter).
+    # epoch live in a device counter, so replays still advance them (include/smx.h: smx_step_counter_add).
     run, graph_note = step, "eager"
     dist_run = world > 1 or force_dist
     want_graph = args.graph == "on" or (args.graph == "auto" and cfg["B"] * cfg["T"] < 40000)
+    if want_graph and train and dist_run and args.reduce == "rs_ag":
+        want_graph = False                                # (the sharded update holds collectives: kept out of graphs)
     if want_graph and train and dist_run:
         # data parallel: two graphs with the collective between them - [zero_grad + forward + backward] | ONE all-reduce of
         # the flat gradient buffer (eager, RCCL) | [clip + AdamW + shadow refresh].  The per-layer bucket hooks (overlap of
@@ -483,7 +498,7 @@ def main():
 
             def fwd_bwd():
                 opt.zero_grad()
-                enc(src, wav_len).backward(r)
+                enc(src, wav_len, **enc_kw).backward(r)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -530,6 +545,8 @@ def main():
                 opt.use_device_step_counter(False)
             torch.cuda.synchronize()
             run, graph_note = step, f"eager (hipGraph capture failed: {type(ex).__name__})"
+    if opt is not None and dist_run:
+        opt.measure_comm(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -556,11 +573,28 @@ def main():
                    "dropout": (args.dropout if train else 0.0), "parallelism": f"dp{world}", "init": "xavier_normal seed 3407",
                    "residual_stream": ("float32 (torch autocast semantics, the reference's `precision: bf16`)" if F_stream_f32(dtype)
                                        else ("bf16 (SMX_RESIDUAL=bf16)" if dtype == torch.bfloat16 else "float32 model")),
+                   "dynchunk": ({"chunk_size": enc_kw["dynchunktrain_config"].chunk_size,
+                                 "left_context_chunks": enc_kw["dynchunktrain_config"].left_context_size} if enc_kw else None),
                    "launch": graph_note},
     }
     if args.config in FLOPS_PER_FRAME_FWD:
         fl = FLOPS_PER_FRAME_FWD[args.config] * (3.0 if train else 1.0)
         out["model_tflops"] = value * fl / 1e12
+    if opt is not None:
+        # data-parallel exchange: what crosses xGMI per step and how much of it the backward pass did NOT hide (time the
+        # compute stream stood waiting for the collectives, mean over the timed steps, max over ranks)
+        ce = opt.comm_exposed_ms() if dist_run else 0.0
+        if world > 1 or force_dist:
+            ct = torch.tensor([ce], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(ct, op=torch.distributed.ReduceOp.MAX)
+            ce = float(ct.item())
+        gb = opt.total * (2 if args.grad_dtype == "bf16" else 4)
+        out["comm"] = {"reduce": args.reduce, "grad_dtype": args.grad_dtype, "buckets": len(enc.transformer.encoder.layers) + 2,
+                       "gradient_bytes_per_rank": gb,
+                       "wire_bytes_per_rank": (2.0 * (world - 1) / world * gb if args.reduce == "allreduce"
+                                               else (world - 1) / world * (gb + opt.total * 4)),
+                       "comm_exposed_ms": ce}
+        out["comm_exposed_ms"] = ce
     if rank == 0:
         if not args.no_roofline:
             if train and world == 1 and not force_dist:
@@ -572,7 +606,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, train)
         default_line = (args.config == "c2b" and train and world == 1 and not force_dist and args.batch is None
-                        and args.frames is None and args.dtype == "bf16")
+                        and args.frames is None and args.dtype == "bf16" and not args.dynchunk)
         if default_line and not args.no_extra_points:
             out["extra_points"] = extra_points()
         print(json.dumps(out), flush=True)

@@ -102,7 +102,7 @@ typedef struct smx_epilogue {
    * tensor); SMX_IO_LNX_F32 = `ln_x` (SMX_EPI_LN_BWD) is float32.  lnf_y is dtype T (the next GEMM's input) unless
    * SMX_IO_LNFY_F32 (the LayerNorm output is itself the stream: the layer-final norm2, Conformer.py:536). */
   int32_t io_flags;    int32_t pad_;
-  /* device step counter of THIS call's fused dropout (see smx_set_step_counter); NULL = the calling thread's binding */
+  /* device step counter mixed into this call's fused dropout seed (see smx_step_counter_add), or NULL */
   const uint64_t* epoch;
 } smx_epilogue;
 enum { SMX_IO_RES_F32 = 1, SMX_IO_LNX_F32 = 2, SMX_IO_LNFY_F32 = 4 };
@@ -204,7 +204,7 @@ int smx_linear_act_mask_fwd(int dtype, const void* X, int64_t ldx, const void* W
 size_t smx_act_mask_bwd_workspace(int N, int M);
 int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
                      const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
-                     float* dbias, float* dgroup, int64_t lddgroup, int group_div, float drop_p, uint64_t drop_seed,
+                     float* dbias, float* dgroup, int64_t lddgroup, int group_div, float drop_p, uint64_t drop_seed, const uint64_t* epoch,
                      void* workspace, void* stream);
 
 /* Masked mean over time: out[b,:] = sum_t S[b,t,:] * mask[b,t] / sum_t mask[b,t]   (fp32 out (B,D)).
@@ -221,7 +221,7 @@ int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const uint8_t* ma
  * training dropout of the concatenated merge input fused in (drop_p > 0: mask = f(seed, row * D + col), the
  * smx_dropout indexing; summary_mixing.py:237-239). */
 int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B, int T,
-                        int D, float drop_p, uint64_t drop_seed, void* stream);
+                        int D, float drop_p, uint64_t drop_seed, const uint64_t* epoch, void* stream);
 
 /* Same broadcast with the activation / mask backward of the projection that produced the summary columns fused in:
  *   dS[b,t,:] = g[b,:] * inv_count[b] * act'(Z[b,t,:]) * row_mask[b,t]      (Z and/or row_mask given)
@@ -276,11 +276,11 @@ int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, in
 int smx_layernorm_bwd2(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                        const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
                        int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2,
-                       float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream);
+                       float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, const uint64_t* epoch, void* stream);
 int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, const float* X, int64_t ldx, const float* gamma,
                            const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
                            int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2,
-                           float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream);
+                           float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, const uint64_t* epoch, void* stream);
 
 /* Fused GLU + depthwise Conv1d over time (Conformer.py:131-145,317-325):
  *   u[b,t,c] = P[b,t,c] * sigmoid(P[b,t,D+c]);  Y[b,t,c] = bias[c] + sum_j w[c,j] u[b,t+j-(k-1)/2,c]
@@ -295,7 +295,7 @@ int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, 
  * (bf16, k = 31, gate, reflect padding, D % 64 == 0, aligned rows); SMX_EUNSUPPORTED otherwise - run smx_dropout. */
 int smx_dwconv1d_glu_fwd_drop(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
                               const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k, int glu,
-                              int pad_mode, int chunk, float drop_p, uint64_t drop_seed, void* stream);
+                              int pad_mode, int chunk, float drop_p, uint64_t drop_seed, const uint64_t* epoch, void* stream);
 /* dP (same shape as P), dw/dbias += ; dgate optional (= dY * conv).  workspace: smx_dwconv1d_glu_bwd_workspace bytes
  * (per-block partial tap gradients of the fast path, reduced in a fixed order; NULL selects the generic kernel).
  * dw == NULL (and dbias == NULL): the partial rows [smx_dwconv1d_glu_bwd_partial_rows][D][k+1] (taps, then the bias term)
@@ -332,7 +332,7 @@ int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b, const voi
 /* Inverted dropout with a counter-based generator: Y[n,c] = keep(seed, n*D+c) ? X[n,c]/(1-p) : 0 (in place allowed).
  * The mask is a pure function of (seed, element index): calling it again on the gradient with the same seed is the
  * backward.  Replaces nn.Dropout at summary_mixing.py:238,283, Conformer.py:157,461-472, TransformerASR.py:353. */
-int smx_dropout(int dtype, const void* X, int64_t ldx, void* Y, int64_t ldy, int N, int D, float p, uint64_t seed,
+int smx_dropout(int dtype, const void* X, int64_t ldx, void* Y, int64_t ldy, int N, int D, float p, uint64_t seed, const uint64_t* epoch,
                 void* stream);
 /* Y[n,:] += table[n % R,:] (fp32 table): abs-sine positional encoding added after the input dropout
  * (TransformerASR.py:547-549). */
@@ -348,7 +348,7 @@ int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n, void* str
  * updated parameters cast to bf16. */
 int smx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                    int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                   float grad_scale, const float* gscale_dev, void* stream);
+                   float grad_scale, const float* gscale_dev, const uint64_t* step_dev, void* stream);
 /* ---- InputNormalization between the filterbank and the CNN front-end (recipe key `normalize`:
  * speechbrain.processing.features.InputNormalization, …transducer.yaml:167-169; upstream-only arithmetic). ----
  * smx_utt_meanstd: mean[b,f] and unbiased std[b,f] over the frames t < len[b] (std clamped below by eps; 0 / 1 when the
@@ -386,15 +386,14 @@ int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, const int32
                      const int32_t* tgt_len, int B, int T, int V, int Smax, int blank, const float* nll, const float* gscale,
                      void* grad, int64_t ldg, void* workspace, void* stream);
 
-/* step <= 0: the bias-correction step is read from the device step counter (smx_set_step_counter) instead. */
-/* Optional device step counter (one uint64 in device memory).  The binding is PER HOST THREAD (thread-local, not
- * process-global: two optimizers driven from two threads do not share it); a GEMM call can also name its counter
- * explicitly in smx_epilogue.epoch.  While set
- * (non-NULL), every fused / standalone dropout mixes the counter's current value into its seed and smx_adamw_step with
- * step <= 0 takes its step from it: a whole training step can then be captured ONCE in a hipGraph (all kernel
- * arguments constant) and replayed - masks and bias correction still advance, because the counter does
- * (smx_step_counter_add is itself a captured kernel).  NULL restores the plain by-value behaviour. */
-int smx_set_step_counter(const uint64_t* dev_counter);
+/* Device step counter (one uint64 in device memory) - an explicit ARGUMENT of every call that uses it, never library
+ * state: `epoch` of smx_dropout / smx_masked_mean_bwd(_act) / smx_act_mask_bwd / smx_layernorm_bwd2 /
+ * smx_dwconv1d_glu_fwd_drop, smx_epilogue.epoch of the GEMMs, `step_dev` of smx_adamw_step.  With a non-NULL counter a
+ * fused / standalone dropout mixes the counter's current value into its seed and smx_adamw_step with step <= 0 takes its
+ * bias-correction step from it: a whole training step can then be captured ONCE in a hipGraph (all kernel arguments
+ * constant) and replayed - masks and bias correction still advance, because the counter does (smx_step_counter_add is
+ * itself a captured kernel).  NULL = the plain by-value behaviour.  The library holds no process-global state besides
+ * the read-once smx_config and the per-thread error string. */
 int smx_step_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream);
 /* out[0] += sum(x^2) — global grad-norm for clipping (zero out[0] first).  Fixed summation order (per-block partials in
  * `workspace`, smx_sumsq_workspace() bytes, folded by one block; no atomics): data-parallel ranks holding the same

@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmx.so")
+# SMX_LIB: another build of the same library (e.g. libsmx_diag.so = csrc/build.sh with SMX_DIAG=1, for the ablation tools)
+LIB_PATH = os.environ.get("SMX_LIB") or os.path.join(_HERE, "libsmx.so")
 
 c_i, c_i64, c_f, c_vp, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
@@ -53,7 +54,8 @@ class Epilogue(ctypes.Structure):
                 ("ln_drop_seed2", ctypes.c_uint64),
                 ("lnf_gamma", c_vp), ("lnf_beta", c_vp), ("lnf_y", c_vp), ("lnf_ldy", c_i64), ("lnf_stats", c_vp),
                 ("lnf_eps", c_f), ("lnf_act", ctypes.c_int32),
-                ("io_flags", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("io_flags", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("epoch", c_vp)]
 
 
 # name -> (restype, argtypes); mirrors include/smx.h one to one (tests/test_abi.py checks the export list)
@@ -79,10 +81,10 @@ SIGNATURES = {
                                       ctypes.POINTER(Epilogue), c_vp]),
     "smx_act_mask_bwd_workspace": (c_sz, [c_i, c_i]),
     "smx_act_mask_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp,
-                               c_i64, c_i, c_f, ctypes.c_uint64, c_vp, c_vp]),
+                               c_i64, c_i, c_f, ctypes.c_uint64, c_vp, c_vp, c_vp]),
     "smx_masked_mean_workspace": (c_sz, [c_i, c_i, c_i]),
     "smx_masked_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
-    "smx_masked_mean_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, ctypes.c_uint64, c_vp]),
+    "smx_masked_mean_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_masked_mean_bwd_act": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "smx_chunk_mean_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_chunk_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
@@ -93,16 +95,16 @@ SIGNATURES = {
     "smx_layernorm_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "smx_layernorm_fwd_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "smx_layernorm_bwd2_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
-                                     c_vp, c_i, c_i, c_vp, c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp]),
+                                     c_vp, c_i, c_i, c_vp, c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
     "smx_layernorm_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                 c_vp, c_i, c_i, c_vp, c_vp]),
     "smx_layernorm_bwd2": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
-                                 c_vp, c_i, c_i, c_vp, c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp]),
+                                 c_vp, c_i, c_i, c_vp, c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_dwconv1d_glu_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i,
                                    c_i, c_i, c_vp]),
     "smx_dwconv1d_glu_fwd_drop": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i,
-                                        c_i, c_i, c_f, ctypes.c_uint64, c_vp]),
+                                        c_i, c_i, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_dwconv1d_glu_bwd_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_dwconv1d_glu_bwd_partial_rows": (c_i, [c_i] * 9),
     "smx_dwconv1d_glu_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
@@ -113,11 +115,11 @@ SIGNATURES = {
     "smx_im2col_s2": (c_i, [c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_col2im_s2": (c_i, [c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_axpby": (c_i, [c_i, c_f, c_vp, c_i64, c_f, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
-    "smx_dropout": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_f, ctypes.c_uint64, c_vp]),
+    "smx_dropout": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_add_rowtable": (c_i, [c_i, c_vp, c_i64, c_vp, c_i, c_i, c_i, c_vp]),
     "smx_cast_from_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
     "smx_cast_to_f32": (c_i, [c_i, c_vp, c_vp, c_i64, c_vp]),
-    "smx_adamw_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_vp, c_vp]),
+    "smx_adamw_step": (c_i, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_vp, c_vp, c_vp]),
     "smx_utt_meanstd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_vp]),
     "smx_stats_combine": (c_i, [c_vp, c_vp, c_i, c_i, c_vp, c_vp, c_f, c_vp]),
     "smx_colnorm": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_vp]),
@@ -127,7 +129,7 @@ SIGNATURES = {
     "smx_ctc_loss_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "smx_ctc_loss_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_i64, c_vp,
                                c_vp]),
-    "smx_set_step_counter": (c_i, [c_vp]),
+    "smx_get_config": (c_i, [c_vp]),
     "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
     "smx_sumsq_workspace": (c_sz, []),
     "smx_sumsq": (c_i, [c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -151,6 +153,24 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+class Config(ctypes.Structure):
+    """smx_config of include/smx.h: the knobs the library read from the environment once."""
+    _fields_ = [("gemm_tile64", ctypes.c_int32), ("gemm_wide", ctypes.c_int32), ("tn_dma", ctypes.c_int32), ("nt_z", ctypes.c_int32),
+                ("nt_bytes", ctypes.c_int64), ("reg_epi", ctypes.c_int32), ("epi_simple", ctypes.c_int32),
+                ("wgrad_blocks", ctypes.c_int32), ("wgrad_min_rows", ctypes.c_int32), ("pool_blocks", ctypes.c_int32),
+                ("wgroup_blocks", ctypes.c_int32), ("wgroup_bk", ctypes.c_int32), ("wgroup_pp", ctypes.c_int32),
+                ("dwroll", ctypes.c_int32), ("dwroll_csgu", ctypes.c_int32), ("dwroll_seg", ctypes.c_int32),
+                ("gemm_ablate", ctypes.c_int32), ("wgroup_ablate", ctypes.c_int32), ("dwroll_ablate", ctypes.c_int32),
+                ("diag_build", ctypes.c_int32)]
+
+
+def get_config():
+    """The knobs in force as a dict (smx_get_config)."""
+    c = Config()
+    check(lib().smx_get_config(ctypes.byref(c)), "smx_get_config")
+    return {name: getattr(c, name) for name, _ in Config._fields_}
 
 
 def check(code, what):

@@ -26,8 +26,8 @@ int check_launch(const char* what) {
 }  // namespace smx
 
 #include <stdlib.h>
+
 namespace smx {
-thread_local const uint64_t* g_step_counter = nullptr;
 static int env_i(const char* n, int dflt) { const char* e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; }
 static long env_l(const char* n, long dflt) { const char* e = getenv(n); return (e && e[0]) ? atol(e) : dflt; }
 const smx_config& cfg() {
@@ -64,10 +64,6 @@ const smx_config& cfg() {
 __global__ void step_counter_add_kernel(uint64_t* c, uint64_t inc) { c[0] += inc; }
 }  // namespace smx
 
-extern "C" int smx_set_step_counter(const uint64_t* dev_counter) {
-  smx::g_step_counter = dev_counter;
-  return SMX_OK;
-}
 extern "C" int smx_step_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream) {
   SMX_REQUIRE(dev_counter, "smx_step_counter_add: null pointer");
   hipLaunchKernelGGL(smx::step_counter_add_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), dev_counter, inc);

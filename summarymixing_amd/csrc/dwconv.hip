@@ -555,33 +555,34 @@ using namespace smx;
 // does a rolling register-window path (dwconv_roll.h) take this call?  1 = GLU + zero padding (bf16 and fp32),
 // 2 = CSGU gate + reflect padding (bf16)
 static int roll_kind(int dtype, int T, int D, int k, int glu, int pad_mode, int chunk, bool has_gate) {
-  if (!roll_enabled() || k != 31 || chunk > 0 || D % 64 != 0) return 0;
-  if (glu && !has_gate && pad_mode == SMX_PAD_ZERO) return 1;
+  if (!roll_enabled() || k != 31 || D % 64 != 0) return 0;
+  // Dynamic Chunk Convolution (chunk > 0): the GLU kernels take chunks of at least 8 frames (the recipes sample 8..32)
+  if (glu && !has_gate && pad_mode == SMX_PAD_ZERO && (chunk <= 0 || chunk >= 8)) return 1;
   const int csgu = cfg().dwroll_csgu;
-  if (csgu && !glu && has_gate && pad_mode == SMX_PAD_REFLECT && dtype == SMX_BF16 && T > 15) return 2;
+  if (chunk <= 0 && csgu && !glu && has_gate && pad_mode == SMX_PAD_REFLECT && dtype == SMX_BF16 && T > 15) return 2;
   return 0;
 }
 
 static int dwconv_fwd_impl(int dtype, const void* P, int64_t ldp, const float* w, const float* bias, const void* gate, int64_t ldg,
                            void* Y, int64_t ldy, int B, int T, int D, int k, int glu, int pad_mode, int chunk, float drop_p,
-                           uint64_t drop_seed, void* stream);
+                           uint64_t drop_seed, const uint64_t* epoch, void* stream);
 
 extern "C" int smx_dwconv1d_glu_fwd(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
                                     const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k,
                                     int glu, int pad_mode, int chunk, void* stream) {
-  return dwconv_fwd_impl(dtype, P, ldp, w, bias, gate, ldg, Y, ldy, B, T, D, k, glu, pad_mode, chunk, 0.f, 0, stream);
+  return dwconv_fwd_impl(dtype, P, ldp, w, bias, gate, ldg, Y, ldy, B, T, D, k, glu, pad_mode, chunk, 0.f, 0, nullptr, stream);
 }
 
 extern "C" int smx_dwconv1d_glu_fwd_drop(int dtype, const void* P, int64_t ldp, const float* w, const float* bias,
                                          const void* gate, int64_t ldg, void* Y, int64_t ldy, int B, int T, int D, int k,
-                                         int glu, int pad_mode, int chunk, float drop_p, uint64_t drop_seed, void* stream) {
+                                         int glu, int pad_mode, int chunk, float drop_p, uint64_t drop_seed, const uint64_t* epoch, void* stream) {
   SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_dwconv1d_glu_fwd_drop: 0 <= drop_p < 1");
-  return dwconv_fwd_impl(dtype, P, ldp, w, bias, gate, ldg, Y, ldy, B, T, D, k, glu, pad_mode, chunk, drop_p, drop_seed, stream);
+  return dwconv_fwd_impl(dtype, P, ldp, w, bias, gate, ldg, Y, ldy, B, T, D, k, glu, pad_mode, chunk, drop_p, drop_seed, epoch, stream);
 }
 
 static int dwconv_fwd_impl(int dtype, const void* P, int64_t ldp, const float* w, const float* bias, const void* gate, int64_t ldg,
                            void* Y, int64_t ldy, int B, int T, int D, int k, int glu, int pad_mode, int chunk, float drop_p,
-                           uint64_t drop_seed, void* stream) {
+                           uint64_t drop_seed, const uint64_t* epoch, void* stream) {
   SMX_REQUIRE(P && w && Y, "smx_dwconv1d_glu_fwd: null pointer");
   SMX_REQUIRE(k >= 1 && k <= DW_KMAX && (k & 1), "smx_dwconv1d_glu_fwd: k=%d must be odd and <= %d", k, DW_KMAX);
   SMX_REQUIRE(pad_mode != SMX_PAD_REFLECT || (k - 1) / 2 < T, "smx_dwconv1d_glu_fwd: reflect pad needs (k-1)/2 < T");
@@ -607,11 +608,14 @@ static int dwconv_fwd_impl(int dtype, const void* P, int64_t ldp, const float* w
     dim3 g1((unsigned)(8 * (D / 64) * ((gy + 7) / 8)));
     if (drop_p > 0.f && rk != 2) return fail(SMX_EUNSUPPORTED, "smx_dwconv1d_glu_fwd_drop: fused output dropout needs the rolling CSGU kernel");
     if (rk == 2) {
-      p.dthresh = (unsigned)((double)drop_p * 4294967296.0); p.dscale = 1.f / (1.f - drop_p); p.dseed = drop_seed; p.epoch = g_step_counter;
+      p.dthresh = (unsigned)((double)drop_p * 4294967296.0); p.dscale = 1.f / (1.f - drop_p); p.dseed = drop_seed; p.epoch = epoch;
       hipLaunchKernelGGL(dwconv_rollc_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
     }
-    else if (dtype == SMX_BF16) hipLaunchKernelGGL(dwconv_rolls_fwd, g1, dim3(256), 0, s, p, seg, nseg, gy);
-    else hipLaunchKernelGGL((dwconv_roll_fwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gy);
+    else if (dtype == SMX_BF16) {
+      if (chunk > 0) hipLaunchKernelGGL((dwconv_rolls_fwd<true>), g1, dim3(256), 0, s, p, seg, nseg, gy);
+      else hipLaunchKernelGGL((dwconv_rolls_fwd<false>), g1, dim3(256), 0, s, p, seg, nseg, gy);
+    } else if (chunk > 0) hipLaunchKernelGGL((dwconv_roll_fwd<float, true>), g1, dim3(256), 0, s, p, seg, nseg, gy);
+    else hipLaunchKernelGGL((dwconv_roll_fwd<float, false>), g1, dim3(256), 0, s, p, seg, nseg, gy);
   } else if (drop_p > 0.f) {
     return fail(SMX_EUNSUPPORTED, "smx_dwconv1d_glu_fwd_drop: fused output dropout needs the rolling CSGU kernel");
   } else if (fast) {
@@ -701,14 +705,21 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
     roll_geometry(B, T, D, &seg, &nseg, &gr);
     float* partial = reinterpret_cast<float*>(workspace);
     dim3 g1((unsigned)(8 * (D / 64) * ((gr + 7) / 8)));
-    const int abl = cfg().dwroll_ablate;                  // (0 unless built with -DSMX_DIAG)
+#ifdef SMX_DIAG
+    const int abl = cfg().dwroll_ablate;
+#endif
     if (rk == 2) {
       hipLaunchKernelGGL(dwconv_rollc_bwd, g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
       // the gradient of the mirrored virtual frames goes back to frames 1..15 / T-16..T-2 (30 rows per utterance)
       hipLaunchKernelGGL(dwconv_csgu_fold_kernel, dim3((unsigned)((D / 2 + 63) / 64), (unsigned)B), dim3(64), 0, s, p);
-    } else if (dtype != SMX_BF16) hipLaunchKernelGGL((dwconv_roll_bwd<float>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+    } else if (dtype != SMX_BF16) {
+      if (chunk > 0) hipLaunchKernelGGL((dwconv_roll_bwd<float, true>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+      else hipLaunchKernelGGL((dwconv_roll_bwd<float, false>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+    } else if (chunk > 0) hipLaunchKernelGGL((dwconv_rolls_bwd<0, true>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+#ifdef SMX_DIAG
     else if (abl == 1) hipLaunchKernelGGL((dwconv_rolls_bwd<1>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
     else if (abl == 2) hipLaunchKernelGGL((dwconv_rolls_bwd<2>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
+#endif
     else hipLaunchKernelGGL((dwconv_rolls_bwd<0>), g1, dim3(256), 0, s, p, seg, nseg, gr, partial);
     const long W = (long)D * (k + 1);
     if (dw) hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, gr, D, k, dw, dbias);

@@ -56,6 +56,46 @@ __device__ __forceinline__ void rw_fetch(typename RwRaw<T>::type (&dst)[RW_STEP]
   }
 }
 
+// ---- Dynamic Chunk Convolution (Conformer.py:190-313; `chunk` > 0) ----------------------------------------------------
+// Frame t sees no input beyond the end of its own chunk of c frames.  With m = t mod c:
+//   forward and tap gradient: the right-context taps j = 16..30 (input frame t + j - 15) exist for j - 15 <= c - 1 - m,
+//   input gradient at frame tau: the taps j = 16..30 (output frame tau - (j - 15)) exist for j - 15 <= tau mod c;
+// the taps j = 0..15 always exist.  t mod c is wave-uniform, so the conditional taps are ONE computed scalar branch into a
+// chain (no per-tap select, and the taps that do not exist are not executed): f(d) for d = 1 .. min(depth, 15).
+template <int D> struct RwTap { static constexpr int value = D; };
+template <int BASE, int N, typename F>
+__device__ __forceinline__ void rw_taps_run(F&& f) {                    // f(BASE + 1) .. f(BASE + N)
+  if constexpr (N > 0) {
+    f(RwTap<BASE + 1>{});
+    rw_taps_run<BASE + 1, N - 1>(f);
+  }
+}
+// f(BASE + 1) .. f(BASE + r) for 0 <= r < 2 N (N a power of two): a binary tree of structured if / else, log2(2 N) scalar
+// branches per call (a switch with fall-through costs a branch and flag moves PER TAP once hipcc has structurised it)
+template <int BASE, int N, typename F>
+__device__ __forceinline__ void rw_taps_tree(int r, F&& f) {
+  if constexpr (N >= 1) {
+    if (r >= N) {
+      rw_taps_run<BASE, N>(f);
+      rw_taps_tree<BASE + N, N / 2>(r - N, f);
+    } else {
+      rw_taps_tree<BASE, N / 2>(r, f);
+    }
+  }
+}
+template <typename F>
+__device__ __forceinline__ void rw_taps_down(int depth, F&& f) {        // f(1) .. f(min(depth, 15))
+  if (depth >= 15) rw_taps_run<0, 15>(f);
+  else rw_taps_tree<0, 8>(depth, f);
+}
+// (t0 + o) mod c for t0 mod c = m0 < c, 0 <= o < 16 <= 2 c
+__device__ __forceinline__ int rw_mod(int m0, int o, int c) {
+  int m = m0 + o;
+  if (m >= c) m -= c;
+  if (m >= c) m -= c;
+  return m;
+}
+
 // (iy, bx) of this workgroup: workgroup id % 8 is its XCD; the channel tiles of one run of 4 segments sit on ONE XCD
 // next to each other in dispatch order, so the 128-byte pieces of a feature row are fetched by neighbours at the same time
 __device__ __forceinline__ void rw_map(int ctiles, int& iy, int& bx) {
@@ -64,7 +104,7 @@ __device__ __forceinline__ void rw_map(int ctiles, int& iy, int& bx) {
   bx = widx % ctiles;
 }
 
-template <typename T>
+template <typename T, bool CH = false>
 __global__ __launch_bounds__(256) void dwconv_roll_fwd(DwParams p, int seg, int nseg, int gy) {
   constexpr int K = 31, WIN = 46, ES = (int)sizeof(T);
   typedef typename RwRaw<T>::type raw_t;
@@ -90,6 +130,8 @@ __global__ __launch_bounds__(256) void dwconv_roll_fwd(DwParams p, int seg, int 
 #pragma unroll
   for (int i = 0; i < WIN; ++i) win[i] = 0.f;
   raw_t pa0[RW_STEP], pg0[RW_STEP], pa1[RW_STEP], pg1[RW_STEP];       // two steps of rows in flight
+  const int cz = CH ? p.chunk : 1;
+  int m0 = CH ? t_lo % cz : 0;                                          // (frame of the step's first output) mod chunk
   // window row i at step s is frame t_lo + 16 s - 15 + i; the step's 16 fetched frames land in rows 30..45
   // (a zero 'a' gives u = 0 whatever the gate: zero padding needs no flag)
   auto step = [&](raw_t (&pa)[RW_STEP], raw_t (&pg)[RW_STEP], int s) {
@@ -105,11 +147,18 @@ __global__ __launch_bounds__(256) void dwconv_roll_fwd(DwParams p, int seg, int 
 #pragma unroll
       for (int o = 0; o < RW_STEP; ++o) {
         float acc = bs;
+        if constexpr (!CH) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
+          for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc += w[j] * win[o + j];
+          rw_taps_down(cz - 1 - rw_mod(m0, o, cz), [&](auto d) { acc += w[15 + decltype(d)::value] * win[o + 15 + decltype(d)::value]; });
+        }
         if (r0 + o < t_hi) rw_st<T>(acc, rY, va, soff);
         soff += ldyb;
       }
+      if constexpr (CH) m0 = rw_mod(m0, RW_STEP, cz);
     }
 #pragma unroll
     for (int i = 0; i < WIN - RW_STEP; ++i) win[i] = win[i + RW_STEP];
@@ -126,7 +175,7 @@ __global__ __launch_bounds__(256) void dwconv_roll_fwd(DwParams p, int seg, int 
 
 // backward: dP = GLU'(conv^T dY), tap / bias gradient partial rows [gy][D][K + 1] (one per workgroup, the four waves folded in
 // a fixed order), reduced by dw_partials_reduce_kernel or a deferred smx_reduce_jobs.
-template <typename T>
+template <typename T, bool CH = false>
 __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int nseg, int gy, float* __restrict__ partial) {
   constexpr int K = 31, WIN = 47, ES = (int)sizeof(T);
   typedef typename RwRaw<T>::type raw_t;
@@ -160,6 +209,8 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
 #pragma unroll
     for (int i = 0; i < RW_STEP; ++i) sgp[i] = 0.f;
     raw_t pa[RW_STEP], pg[RW_STEP], pd[RW_STEP];
+    const int cz = CH ? p.chunk : 1;
+    int m0 = CH ? t_lo % cz : 0;                         // (frame of the step's first output) mod chunk
     // window row i at step s is frame t_lo + 16 s - 15 + i: the step's outputs (rows 15..30) are the frames fetched one step
     // earlier, the 16 frames fetched now land in rows 31..46.  The fetches of the next step are issued as soon as their
     // registers are free (dY rows right after the window took them, a / gate rows after the GLU).
@@ -175,11 +226,24 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
         float du[RW_STEP];
 #pragma unroll
         for (int o = 0; o < RW_STEP; ++o) du[o] = 0.f;
+        if constexpr (!CH) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          const float wj = wl[j][lane];
+          for (int j = 0; j < K; ++j) {
+            const float wj = wl[j][lane];
 #pragma unroll
-          for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
+            for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
+          }
+        } else {
+          // output frames before the chunk of tau do not see it: taps j = 15 + d (output frame tau - d) for d <= tau mod c only
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float wj = wl[j][lane];
+#pragma unroll
+            for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
+          }
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o)
+            rw_taps_down(rw_mod(m0, o, cz), [&](auto d) { du[o] += wl[15 + decltype(d)::value][lane] * gw[15 + o - decltype(d)::value]; });
         }
         const int r0 = t_lo + s * RW_STEP;
         unsigned soff = (unsigned)r0 * ldob;
@@ -205,12 +269,27 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
       }
       if (s >= 0) {
         // dw_j += sum_t dY(t) u(t + j - 15), dbias += sum_t dY(t)   (frames beyond T are zero rows)
+        if constexpr (!CH) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-          float sacc = 0.f;
+          for (int j = 0; j < K; ++j) {
+            float sacc = 0.f;
 #pragma unroll
-          for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
-          dw[j] += sacc;
+            for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
+            dw[j] += sacc;
+          }
+        } else {
+          // the forward's taps: j = 15 + d (input frame t + d) exists for d <= c - 1 - t mod c
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
+            dw[j] += sacc;
+          }
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o)
+            rw_taps_down(cz - 1 - rw_mod(m0, o, cz), [&](auto d) { dw[15 + decltype(d)::value] += gw[15 + o] * uw[o + 15 + decltype(d)::value]; });
+          m0 = rw_mod(m0, RW_STEP, cz);
         }
 #pragma unroll
         for (int o = 0; o < RW_STEP; ++o) dbs += gw[15 + o];
@@ -256,6 +335,7 @@ __device__ __forceinline__ float rw_lds_bf16(const unsigned char* base, int off)
   return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(base + off));
 }
 
+template <bool CH = false>
 __global__ __launch_bounds__(256) void dwconv_rolls_fwd(DwParams p, int seg, int nseg, int gy) {
   constexpr int K = 31, WIN = 46, SLOT = 4096, OUT = 2 * SLOT, WAVE = OUT + 2048;
   __shared__ __attribute__((aligned(16))) unsigned char stage[4][WAVE];
@@ -291,6 +371,8 @@ __global__ __launch_bounds__(256) void dwconv_rolls_fwd(DwParams p, int seg, int
     rw_dma16(rP, d, vpa, r0, ldpb);
     rw_dma16(rP, d + 2048, vpg, r0, ldpb);
   };
+  const int cz = CH ? p.chunk : 1;
+  int m0 = CH ? t_lo % cz : 0;                          // (frame of the step's first output) mod chunk
   dma(-2);
   dma(-1);
   for (int s = -2; s < nsteps; ++s) {
@@ -306,10 +388,17 @@ __global__ __launch_bounds__(256) void dwconv_rolls_fwd(DwParams p, int seg, int
 #pragma unroll
       for (int o = 0; o < RW_STEP; ++o) {
         float acc = bs;
+        if constexpr (!CH) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
+          for (int j = 0; j < K; ++j) acc += w[j] * win[o + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc += w[j] * win[o + j];
+          rw_taps_down(cz - 1 - rw_mod(m0, o, cz), [&](auto d) { acc += w[15 + decltype(d)::value] * win[o + 15 + decltype(d)::value]; });
+        }
         ob[o * 64] = (unsigned short)f32_to_bf16_bits(acc);
       }
+      if constexpr (CH) m0 = rw_mod(m0, RW_STEP, cz);
       asm volatile("" ::: "memory");                   // (LDS is in order within a wave: a compiler fence is enough)
       const unsigned s0 = (unsigned)(t_lo + s * RW_STEP) * ldyb;
       typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
@@ -326,7 +415,7 @@ __global__ __launch_bounds__(256) void dwconv_rolls_fwd(DwParams p, int seg, int
 }
 
 // ABL (diagnostic, SMX_DWROLL_ABLATE): 1 = no FMAs, 2 = no DMA
-template <int ABL>
+template <int ABL, bool CH = false>
 __global__ __launch_bounds__(256) void dwconv_rolls_bwd(DwParams p, int seg, int nseg, int gy, float* __restrict__ partial) {
   constexpr int K = 31, WIN = 47, SLOT = 6144, OUT = 2 * SLOT, WAVE = OUT + 4096;
   __shared__ float wl[K][64];
@@ -371,6 +460,8 @@ __global__ __launch_bounds__(256) void dwconv_rolls_bwd(DwParams p, int seg, int
       rw_dma16(rP, d + 2048, vpa, r0, ldpb);
       rw_dma16(rP, d + 4096, vpg, r0, ldpb);
     };
+    const int cz = CH ? p.chunk : 1;
+    int m0 = CH ? t_lo % cz : 0;                         // (frame of the step's first output) mod chunk
     dma(-2);
     dma(-1);
     for (int s = -2; s < nsteps; ++s) {
@@ -392,11 +483,24 @@ __global__ __launch_bounds__(256) void dwconv_rolls_bwd(DwParams p, int seg, int
         float du[RW_STEP];
 #pragma unroll
         for (int o = 0; o < RW_STEP; ++o) du[o] = 0.f;
+        if constexpr (!CH) {
 #pragma unroll
-        for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
-          const float wj = wl[j][lane];
+          for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
+            const float wj = wl[j][lane];
 #pragma unroll
-          for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
+            for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
+          }
+        } else {
+          // output frames before the chunk of tau do not see it: taps j = 15 + d (output frame tau - d) for d <= tau mod c only
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float wj = wl[j][lane];
+#pragma unroll
+            for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
+          }
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o)
+            rw_taps_down(rw_mod(m0, o, cz), [&](auto d) { du[o] += wl[15 + decltype(d)::value][lane] * gw[15 + o - decltype(d)::value]; });
         }
         unsigned short* ob = reinterpret_cast<unsigned short*>(st + OUT) + lane;
 #pragma unroll
@@ -421,12 +525,27 @@ __global__ __launch_bounds__(256) void dwconv_rolls_bwd(DwParams p, int seg, int
       for (int i = 0; i < RW_STEP; ++i) sgp[i] = sgn[i];
       if (s >= 0) {
         // dw_j += sum_t dY(t) u(t + j - 15), dbias += sum_t dY(t)   (frames beyond T are zero rows)
+        if constexpr (!CH) {
 #pragma unroll
-        for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
-          float sacc = 0.f;
+          for (int j = 0; j < (ABL == 1 ? 1 : K); ++j) {
+            float sacc = 0.f;
 #pragma unroll
-          for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
-          dw[j] += sacc;
+            for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
+            dw[j] += sacc;
+          }
+        } else {
+          // the forward's taps: j = 15 + d (input frame t + d) exists for d <= c - 1 - t mod c
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int o = 0; o < RW_STEP; ++o) sacc += gw[15 + o] * uw[o + j];
+            dw[j] += sacc;
+          }
+#pragma unroll
+          for (int o = 0; o < RW_STEP; ++o)
+            rw_taps_down(cz - 1 - rw_mod(m0, o, cz), [&](auto d) { dw[15 + decltype(d)::value] += gw[15 + o] * uw[o + 15 + decltype(d)::value]; });
+          m0 = rw_mod(m0, RW_STEP, cz);
         }
 #pragma unroll
         for (int o = 0; o < RW_STEP; ++o) dbs += gw[15 + o];

@@ -883,7 +883,7 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   if (simple_env && !p.e.c0 && !p.e.colsum) p.epi_simple = (p.e.res || (p.e.flags & SMX_EPI_ACT_GRAD)) ? (simple_env >= 2 ? 2 : 0) : 1;
   p.ablate = cfg().gemm_ablate;                          // (0 unless built with -DSMX_DIAG)
   p.dbg = g_dbg_stamps;
-  p.epoch = p.e.epoch ? p.e.epoch : g_step_counter;
+  p.epoch = p.e.epoch;
   p.acolsum = acolsum;
   p.dthresh = (unsigned)((double)p.e.drop_p * 4294967296.0);
   SMX_REQUIRE(p.e.drop_cols >= 0 && p.e.drop_cols <= M && p.e.drop_cols % 8 == 0, "smx_gemm: drop_cols must be a multiple of 8 in [0, M]");

@@ -1088,7 +1088,7 @@ extern "C" int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const 
 }
 
 static int bcast_impl(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B, int T, int D,
-                      float drop_p, uint64_t drop_seed, const void* Z, int64_t ldz, const uint8_t* mask, int act, void* stream,
+                      float drop_p, uint64_t drop_seed, const uint64_t* epoch, const void* Z, int64_t ldz, const uint8_t* mask, int act, void* stream,
                       const char* what) {
   const uint32_t dthresh = (uint32_t)((double)drop_p * 4294967296.0);
   const float dscale = 1.f / (1.f - drop_p);
@@ -1100,20 +1100,20 @@ static int bcast_impl(int dtype, const float* g, const float* inv_count, void* d
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
   const bool vec = vec_ok(dS, ldds, D, nvec, es) && (Z == nullptr || vec_ok(Z, ldz, D, nvec, es));
   if (dtype == SMX_BF16) {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const bf16_t*)Z, ldz, mask, act, LPR);
-    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const bf16_t*)Z, ldz, mask, act, LPR);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, true>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, epoch, (const bf16_t*)Z, ldz, mask, act, LPR);
+    else hipLaunchKernelGGL((bcast_rows_kernel<bf16_t, false>), grid, dim3(256), 0, STREAM, g, inv_count, (bf16_t*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, epoch, (const bf16_t*)Z, ldz, mask, act, LPR);
   } else {
-    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const float*)Z, ldz, mask, act, LPR);
-    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, g_step_counter, (const float*)Z, ldz, mask, act, LPR);
+    if (vec) hipLaunchKernelGGL((bcast_rows_kernel<float, true>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, epoch, (const float*)Z, ldz, mask, act, LPR);
+    else hipLaunchKernelGGL((bcast_rows_kernel<float, false>), grid, dim3(256), 0, STREAM, g, inv_count, (float*)dS, ldds, T, D, RPB, dthresh, dscale, drop_seed, epoch, (const float*)Z, ldz, mask, act, LPR);
   }
   return check_launch(what);
 }
 
 extern "C" int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B,
-                                   int T, int D, float drop_p, uint64_t drop_seed, void* stream) {
+                                   int T, int D, float drop_p, uint64_t drop_seed, const uint64_t* epoch, void* stream) {
   SMX_REQUIRE(g && dS, "smx_masked_mean_bwd: null pointer");
   SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_masked_mean_bwd: 0 <= drop_p < 1");
-  return bcast_impl(dtype, g, inv_count, dS, ldds, B, T, D, drop_p, drop_seed, nullptr, 0, nullptr, SMX_ACT_NONE, stream,
+  return bcast_impl(dtype, g, inv_count, dS, ldds, B, T, D, drop_p, drop_seed, epoch, nullptr, 0, nullptr, SMX_ACT_NONE, stream,
                     "smx_masked_mean_bwd");
 }
 
@@ -1121,7 +1121,7 @@ extern "C" int smx_masked_mean_bwd_act(int dtype, const float* g, const float* i
                                        const void* Z, int64_t ldz, const uint8_t* row_mask, int act, int B, int T, int D,
                                        void* stream) {
   SMX_REQUIRE(g && dS && (Z || row_mask), "smx_masked_mean_bwd_act: null pointer");
-  return bcast_impl(dtype, g, inv_count, dS, ldds, B, T, D, 0.f, 0, Z, ldz, row_mask, Z ? act : SMX_ACT_NONE, stream,
+  return bcast_impl(dtype, g, inv_count, dS, ldds, B, T, D, 0.f, 0, nullptr, Z, ldz, row_mask, Z ? act : SMX_ACT_NONE, stream,
                     "smx_masked_mean_bwd_act");
 }
 
@@ -1290,24 +1290,24 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
 extern "C" int smx_layernorm_bwd2(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                                   const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma,
                                   float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2, float alpha2,
-                                  const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream) {
+                                  const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, const uint64_t* epoch, void* stream) {
   SMX_REQUIRE(dY && X && gamma && beta && stats && dX && workspace && D > 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
               "smx_layernorm_bwd: bad arguments");
   SMX_REQUIRE(drop_p2 >= 0.f && drop_p2 < 1.f, "smx_layernorm_bwd2: 0 <= drop_p < 1");
   if (N == 0) return SMX_OK;
   LnSecond sec;
   sec.dX2 = dX2; sec.ld = lddx2; sec.alpha = alpha2; sec.mask = row_mask2;
-  sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = g_step_counter;
+  sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = epoch;
   if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM, sec);
   return ln_bwd_impl<float>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM, sec);
 }
 extern "C" int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, const float* X, int64_t ldx, const float* gamma,
                                       const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx,
                                       float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2, float alpha2,
-                                      const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, void* stream) {
+                                      const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, const uint64_t* epoch, void* stream) {
   if (dtype == SMX_F32)
     return smx_layernorm_bwd2(dtype, dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, workspace, dX2, lddx2,
-                              alpha2, row_mask2, drop_p2, drop_seed2, stream);
+                              alpha2, row_mask2, drop_p2, drop_seed2, epoch, stream);
   SMX_REQUIRE(dtype == SMX_BF16 && dY && X && gamma && beta && stats && dX && workspace && D > 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
               "smx_layernorm_bwd2_x32: bad arguments");
   SMX_REQUIRE(drop_p2 >= 0.f && drop_p2 < 1.f, "smx_layernorm_bwd2_x32: 0 <= drop_p < 1");
@@ -1318,7 +1318,7 @@ extern "C" int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, c
   if (!vec) return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd2_x32: needs D %% 4 == 0, D <= 2048 and aligned rows");
   LnSecond sec;
   sec.dX2 = dX2; sec.ld = lddx2; sec.alpha = alpha2; sec.mask = row_mask2;
-  sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = g_step_counter;
+  sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = epoch;
   const int blocks = ln_bwd_blocks(N);
   dim3 grid(blocks);
   float* partial = reinterpret_cast<float*>(workspace);
@@ -1333,7 +1333,7 @@ extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const 
                                  const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX, int64_t lddx, float* dgamma,
                                  float* dbeta, int N, int D, void* workspace, void* stream) {
   return smx_layernorm_bwd2(dtype, dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, workspace, nullptr, 0,
-                            1.f, nullptr, 0.f, 0, stream);
+                            1.f, nullptr, 0.f, 0, nullptr, stream);
 }
 
 extern "C" int smx_layernorm_bwd_blocks(int N) { return ln_bwd_blocks(N); }
@@ -1346,7 +1346,7 @@ extern "C" size_t smx_act_mask_bwd_workspace(int N, int M) { return (size_t)((N 
 extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const void* Z, int64_t ldz,
                                 const uint8_t* row_mask, void* dZ, int64_t lddz, int N, int M, int act, float alpha,
                                 float* dbias, float* dgroup, int64_t lddgroup, int group_div, float drop_p,
-                                uint64_t drop_seed, void* workspace, void* stream) {
+                                uint64_t drop_seed, const uint64_t* epoch, void* workspace, void* stream) {
   SMX_REQUIRE(dY && N >= 0 && M > 0, "smx_act_mask_bwd: bad arguments");
   SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_act_mask_bwd: 0 <= drop_p < 1");
   const uint32_t dthresh = (uint32_t)((double)drop_p * 4294967296.0);
@@ -1364,14 +1364,14 @@ extern "C" int smx_act_mask_bwd(int dtype, const void* dY, int64_t lddy, const v
     float* partial = reinterpret_cast<float*>(workspace);
     const int ny = min((N + RS - 1) / RS, ACT_BWD_YMAX);
     dim3 grid((chunks + LPR - 1) / LPR, ny);
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed, g_step_counter);
-    else hipLaunchKernelGGL((act_mask_bwd_vec_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed, g_step_counter);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_vec_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed, epoch);
+    else hipLaunchKernelGGL((act_mask_bwd_vec_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, LPR, partial, dthresh, dscale, drop_seed, epoch);
     if (dbias) hipLaunchKernelGGL(colsum_partials_kernel, dim3((M + 15) / 16), dim3(256), 0, STREAM, partial, ny, M, dbias);
   } else {
     const int RS = 128;
     dim3 grid((M + 255) / 256, (N + RS - 1) / RS);
-    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed, g_step_counter);
-    else hipLaunchKernelGGL((act_mask_bwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed, g_step_counter);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((act_mask_bwd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)dY, lddy, (const bf16_t*)Z, ldz, row_mask, (bf16_t*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed, epoch);
+    else hipLaunchKernelGGL((act_mask_bwd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)dY, lddy, (const float*)Z, ldz, row_mask, (float*)dZ, lddz, N, M, act, alpha, dbias, dgroup, lddgroup, group_div, RS, dthresh, dscale, drop_seed, epoch);
   }
   return check_launch("smx_act_mask_bwd");
 }
@@ -1395,14 +1395,14 @@ extern "C" int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b
 }
 
 extern "C" int smx_dropout(int dtype, const void* X, int64_t ldx, void* Y, int64_t ldy, int N, int D, float p,
-                           uint64_t seed, void* stream) {
+                           uint64_t seed, const uint64_t* epoch, void* stream) {
   SMX_REQUIRE(X && Y && p >= 0.f && p < 1.f, "smx_dropout: bad arguments (0 <= p < 1)");
   if (N <= 0 || D <= 0) return SMX_OK;
   const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
   const float scale = 1.f / (1.f - p);
   int grid = grid1d((long)N * ((D + 3) / 4));
-  if (dtype == SMX_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)X, ldx, (bf16_t*)Y, ldy, N, D, thresh, scale, seed, g_step_counter);
-  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, STREAM, (const float*)X, ldx, (float*)Y, ldy, N, D, thresh, scale, seed, g_step_counter);
+  if (dtype == SMX_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid), dim3(256), 0, STREAM, (const bf16_t*)X, ldx, (bf16_t*)Y, ldy, N, D, thresh, scale, seed, epoch);
+  else hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, STREAM, (const float*)X, ldx, (float*)Y, ldy, N, D, thresh, scale, seed, epoch);
   return check_launch("smx_dropout");
 }
 
@@ -1432,14 +1432,14 @@ extern "C" int smx_cast_to_f32(int dtype, const void* src, float* dst, int64_t n
 
 extern "C" int smx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
                               int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                              float grad_scale, const float* gscale_dev, void* stream) {
+                              float grad_scale, const float* gscale_dev, const uint64_t* step_dev, void* stream) {
   SMX_REQUIRE(param && grad && exp_avg && exp_avg_sq, "smx_adamw_step: bad arguments");
   if (n <= 0) return SMX_OK;
-  SMX_REQUIRE(step > 0 || g_step_counter, "smx_adamw_step: step <= 0 needs smx_set_step_counter()");
+  SMX_REQUIRE(step > 0 || step_dev, "smx_adamw_step: step <= 0 needs the device step counter (step_dev)");
   float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq,
                      (uint16_t*)shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, gscale_dev,
-                     step > 0 ? nullptr : g_step_counter);
+                     step > 0 ? nullptr : step_dev);
   return check_launch("smx_adamw_step");
 }
 extern "C" size_t smx_sumsq_workspace(void) { return SUMSQ_BLOCKS * sizeof(float); }

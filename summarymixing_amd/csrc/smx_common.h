@@ -233,10 +233,9 @@ __device__ __forceinline__ void dropout_apply_any(float (&v)[NV], uint64_t seed,
     for (int q = 0; q < NV; ++q) v[q] = dropout_keep(seed, idx0 + q, thresh) ? v[q] * scale : 0.f;
   }
 }
-// Optional device step counter (smx_set_step_counter): when set, every dropout seed is mixed with its current value,
-// so a training step captured once in a hipGraph (constant kernel arguments) still draws fresh masks at every replay.
-extern thread_local const uint64_t* g_step_counter;     // (per host thread: smx_set_step_counter)
 const smx_config& cfg();                                 // the knobs of include/smx.h, read from the environment once (capi.hip)
+// Optional device step counter (an explicit `epoch` argument of every call with a dropout): the seed is mixed with its
+// current value, so a training step captured once in a hipGraph (constant kernel arguments) still draws fresh masks at every replay.
 __device__ __forceinline__ uint64_t epoch_seed(uint64_t seed, const uint64_t* ep) {
   return ep ? seed ^ (ep[0] * 0x9E3779B97F4A7C15ull) : seed;
 }

@@ -96,6 +96,7 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
     then emits alpha * D(acc * act'(z)) * mask, i.e. the upstream dZ); colsum: fp32 [M] accumulator of the output's
     column sums (the upstream bias gradient), workspace attached by gemm()."""
     e = L.Epilogue()
+    e.epoch = _epoch()                # (the device step counter of the training loop, or NULL: set_step_counter below)
     e.bias = bias.data_ptr() if bias is not None else None
     e.bias_batch_stride = bias_batch_stride
     if c0 is not None:
@@ -250,7 +251,7 @@ def act_mask_bwd(dy, z, mask, act, alpha=1.0, dz=None, dbias=None, dgroup=None, 
     dp, ds = (drop if drop is not None else (0.0, 0))
     tok = _pb(f"act_mask_bwd ({N}x{M})", (1 + (z is not None) + (dz is not None)) * N * M * _es(dy))
     L.check(L.lib().smx_act_mask_bwd(dt(dy), pdy, lddy, pz, ldz, _p(mask), pdz, lddz, N, M, act, alpha, _p(dbias), pg,
-                                     ldg, gdiv, dp, ds, _p(ws), _stream()), "smx_act_mask_bwd")
+                                     ldg, gdiv, dp, ds, _epoch(), _p(ws), _stream()), "smx_act_mask_bwd")
     _pe(tok)
     return dz
 
@@ -286,7 +287,7 @@ def bcast_rows(g, inv, ds, B, T, drop=None):
     pds, ldds = _mat(ds)
     dp, dseed = drop if drop is not None else (0.0, 0)
     tok = _pb(f"bcast_rows ({B},{T},{ds.shape[1]})", B * T * ds.shape[1] * _es(ds))
-    L.check(L.lib().smx_masked_mean_bwd(dt(ds), _p(g), _p(inv), pds, ldds, B, T, ds.shape[1], dp, dseed, _stream()),
+    L.check(L.lib().smx_masked_mean_bwd(dt(ds), _p(g), _p(inv), pds, ldds, B, T, ds.shape[1], dp, dseed, _epoch(), _stream()),
             "smx_masked_mean_bwd")
     _pe(tok)
     return ds
@@ -369,7 +370,7 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     assert x.dtype == gdt or x.dtype == torch.float32
     L.check(fn(dt(dy), pdy, lddy, px, ldx, _p(gamma), _p(beta), act, _p(stats), pr, ldr, _p(dx), _mat(dx)[1],
                _p(dgamma), _p(dbeta), N, D, _p(ws), _p(dx2), D if dx2 is not None else 0, a2, _p(m2), dp2,
-               ds2, _stream()), "smx_layernorm_bwd")
+               ds2, _epoch(), _stream()), "smx_layernorm_bwd")
     _pe(tok)
     return dx if second is None else (dx, dx2)
 
@@ -384,7 +385,7 @@ def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=N
     fused = False
     if drop is not None and drop[0] > 0.0 and os.environ.get("SMX_CSGU_DROP_FUSE", "1") != "0":
         fused = L.lib().smx_dwconv1d_glu_fwd_drop(dt(p), pp, ldp, _p(w), _p(bias), pg, ldg, _p(y), D, B, T, D, k, 1 if glu else 0,
-                                                  pad_mode, chunk, drop[0], drop[1], _stream()) == 0
+                                                  pad_mode, chunk, drop[0], drop[1], _epoch(), _stream()) == 0
     if not fused:
         L.check(L.lib().smx_dwconv1d_glu_fwd(dt(p), pp, ldp, _p(w), _p(bias), pg, ldg, _p(y), D, B, T, D, k, 1 if glu else 0,
                                              pad_mode, chunk, _stream()), "smx_dwconv1d_glu_fwd")
@@ -450,7 +451,7 @@ def dropout(x, p, seed, out=None):
     px, ldx = _mat(x)
     po, ldo = _mat(out)
     tok = _pb(f"dropout ({N}x{D})", 2 * N * D * _es(x))
-    L.check(L.lib().smx_dropout(dt(x), px, ldx, po, ldo, N, D, p, seed, _stream()), "smx_dropout")
+    L.check(L.lib().smx_dropout(dt(x), px, ldx, po, ldo, N, D, p, seed, _epoch(), _stream()), "smx_dropout")
     _pe(tok)
     return out
 
@@ -480,7 +481,7 @@ def cast(src, dtype):
 def adamw_step(param, grad, m, v, shadow, lr, b1, b2, eps, wd, step, grad_scale=1.0, gscale_dev=None):
     tok = _pb(f"adamw ({param.numel()} params)", (28 + (2 if shadow is not None else 0)) * param.numel())
     L.check(L.lib().smx_adamw_step(_p(param), _p(grad), _p(m), _p(v), _p(shadow), param.numel(), lr, b1, b2, eps, wd,
-                                   step, grad_scale, _p(gscale_dev), _stream()), "smx_adamw_step")
+                                   step, grad_scale, _p(gscale_dev), _epoch() if step <= 0 else None, _stream()), "smx_adamw_step")
     _pe(tok)
 
 
@@ -543,11 +544,22 @@ def ctc_bwd(lp2, targets, in_len, tgt_len, B, T, blank, nll, gscale, ws):
     return g
 
 
+_STEP_COUNTER = None          # the training loop's device step counter (held HERE, in the Python host; libsmx has no such state)
+
+
+def _epoch():
+    return None if _STEP_COUNTER is None else ctypes.c_void_p(_STEP_COUNTER.data_ptr())
+
+
 def set_step_counter(counter):
-    """Register (or clear, with None) the device step counter: an int64 tensor of one element (see include/smx.h)."""
+    """Use (or stop using, with None) a device step counter - an int64 tensor of one element - in every dropout seed and
+    AdamW bias correction issued through this module.  The library takes the counter as an explicit argument of each
+    call (include/smx.h: `epoch`, smx_epilogue.epoch, `step_dev`); this module-level variable is the host's training
+    loop state, the place torch keeps its own default generator."""
+    global _STEP_COUNTER
     if counter is not None:
         assert counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1
-    L.check(L.lib().smx_set_step_counter(_p(counter)), "smx_set_step_counter")
+    _STEP_COUNTER = counter
 
 
 def step_counter_add(counter, inc=1):

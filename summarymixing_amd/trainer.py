@@ -10,6 +10,17 @@ for the gradients, the two AdamW moments and the bf16 shadow weights the GEMMs r
   * global-norm clipping + AdamW + the bf16 shadow refresh are three kernel launches per step
     (smx_sumsq, smx_clip_factor, smx_adamw_step), the clip factor never visits the host.
 Forward/backward need no communication: utterances never interact.
+
+Gradient exchange options (xGMI is point-to-point, 7 links x ~153 GB/s per GPU, so a ring collective is per-link bound and
+its cost is the bytes on the wire):
+  reduce="allreduce"  one all-reduce per bucket (default);
+  reduce="rs_ag"      reduce-scatter per bucket, clip + AdamW on this rank's 1/world shard of every bucket only, then an
+                      all-gather of the updated weights - the same bytes on the wire as the ring all-reduce, but the
+                      weights (not the gradients) travel in the second half, so with grad_dtype=bfloat16 only the
+                      gradient half is rounded and the optimizer work per rank drops by 1/world;
+  grad_dtype=torch.bfloat16   gradients cross the wire in bf16 (half the bytes; the accumulation inside the kernels, the
+                      clip and AdamW stay fp32).
+comm_exposed_ms() reports how long the compute stream stood waiting for the collectives (bench.py prints it).
 """
 import os
 
@@ -24,7 +35,12 @@ ALIGN = 64   # elements; keeps every parameter view 256-byte aligned in fp32 and
 
 class FlatAdamW:
     def __init__(self, module, lr=8e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
-                 compute_dtype=torch.bfloat16, process_group=None, buckets=None):
+                 compute_dtype=torch.bfloat16, process_group=None, buckets=None, reduce="allreduce", grad_dtype=torch.float32):
+        if reduce not in ("allreduce", "rs_ag"):
+            raise ValueError("FlatAdamW: reduce must be 'allreduce' or 'rs_ag'")
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("FlatAdamW: grad_dtype must be torch.float32 or torch.bfloat16")
+        self.reduce, self.grad_dtype = reduce, grad_dtype
         self.params = [p for p in module.parameters() if p.requires_grad]
         dev = self.params[0].device
         offs, total = [], 0
@@ -57,6 +73,18 @@ class FlatAdamW:
         self._clip = torch.tensor([1.0, 0.0], dtype=torch.float32, device=dev)   # [clip factor (0 = skip), skipped steps]
         self._pending = []
         self._dev_step = None
+        # communication staging: a bf16 image of the gradients (grad_dtype=bfloat16) and, for rs_ag, this rank's shard of the
+        # reduced gradients / of the updated weights (bucket [a, b) -> shard elements [a/world, b/world) of these buffers)
+        rank = dist.get_rank(process_group) if (dist.is_available() and dist.is_initialized()) else 0
+        self.rank = rank
+        self._comm = torch.zeros(total, dtype=torch.bfloat16, device=dev) if (self._collective and grad_dtype == torch.bfloat16) else None
+        if self._collective and reduce == "rs_ag":
+            assert total % self.world == 0, "flat size must divide by the world size (ALIGN = 64 elements)"
+            self._shard_g = torch.zeros(total // self.world, dtype=torch.float32, device=dev)
+            self._shard_p = torch.zeros(total // self.world, dtype=torch.float32, device=dev)
+            self._shard_c = torch.zeros(total // self.world, dtype=torch.bfloat16, device=dev) if self._comm is not None else None
+        self._reduced = []            # bucket ranges whose collective was launched in this step (rs_ag: the shards to update)
+        self._measure, self._exposed = False, []
         # buckets: list of (start, end) element ranges of the flat buffers, in backward-completion order
         self.buckets = buckets or [(0, total)]
         # in-place weight changes behind the optimizer's back (module.load_state_dict of a checkpoint) must reach the bf16
@@ -122,10 +150,61 @@ class FlatAdamW:
         end = self.offs[hi + 1] if hi + 1 < len(self.offs) else self.total
         return self.offs[lo], end
 
+    def _shard(self, start, end):
+        """This rank's 1/world piece of bucket [start, end): (first element, end element) in the flat buffers."""
+        n = (end - start) // self.world
+        return start + self.rank * n, start + (self.rank + 1) * n
+
     def reduce_bucket_async(self, start, end):
-        """Launch the all-reduce of one gradient bucket (called right after its producer's backward)."""
-        if self._collective:
-            self._pending.append(dist.all_reduce(self.flat_g[start:end], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        """Launch the collective of one gradient bucket (called right after its producer's backward): an all-reduce, or -
+        reduce="rs_ag" - a reduce-scatter that leaves this rank's 1/world shard of the summed bucket in the shard buffer."""
+        if not self._collective:
+            return
+        W = self.world
+        assert (end - start) % W == 0, "bucket length must divide by the world size"
+        src = self.flat_g[start:end]
+        if self._comm is not None:                        # bf16 on the wire
+            src = self._comm[start:end]
+            self._k_cast(self.flat_g[start:end], src)
+        if self.reduce == "allreduce":
+            work = dist.all_reduce(src, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            dst = (self._shard_c if self._comm is not None else self._shard_g)[start // W:end // W]
+            work = dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._pending.append(work)
+        self._reduced.append((start, end))
+
+    def _finish_reduce(self):
+        """Wait for the launched collectives (the compute stream waits, not the host) and bring bf16 results back to fp32."""
+        ev = None
+        if self._measure and self.flat_p.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if self._comm is not None:
+            W = self.world
+            for a, b in self._reduced:
+                if self.reduce == "allreduce":
+                    self._k_cast(self._comm[a:b], self.flat_g[a:b])
+                else:
+                    self._k_cast(self._shard_c[a // W:b // W], self._shard_g[a // W:b // W])
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
+
+    def measure_comm(self, enable=True):
+        """Record, from now on, how long the compute stream waits for the gradient collectives in every step."""
+        self._measure, self._exposed = enable, []
+
+    def comm_exposed_ms(self):
+        """Mean time per step the compute stream stood waiting for the collectives (+ the bf16 casts back) since
+        measure_comm(True): communication NOT hidden behind the backward pass.  Host read (synchronises)."""
+        if not self._exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -133,7 +212,7 @@ class FlatAdamW:
     def use_device_step_counter(self, enable=True):
         """Keep the step count (AdamW bias correction, dropout epoch) in device memory so that a whole training step
         can be captured once in a hipGraph (``torch.cuda.graph``) and replayed: no kernel argument changes between
-        steps, the counter does (include/smx.h: smx_set_step_counter)."""
+        steps, the counter does (include/smx.h: smx_step_counter_add)."""
         if enable:
             if self._dev_step is None:
                 self._dev_step = torch.full((1,), self.step_count, dtype=torch.int64, device=self.flat_p.device)
@@ -149,37 +228,80 @@ class FlatAdamW:
         if self._collective:
             if reduce_all:
                 self.reduce_bucket_async(0, self.total)
-            for w in self._pending:
-                w.wait()
-            self._pending = []
+            self._finish_reduce()
         self.step_count += 1
         if self._dev_step is not None:
             ops.step_counter_add(self._dev_step, 1)
         self._apply_update(1.0 / self.world)
+        self._reduced = []
 
     # ---- hipGraph under data parallelism: the collective stays OUTSIDE the graphs -------------------------------------
     def all_reduce_all(self):
         """ONE all-reduce of the whole flat gradient buffer, waited for on the current stream (used between the two
         captured halves of a step: forward + backward | update)."""
         if self._collective:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+            self._reduced = []                            # (everything is reduced here: earlier entries are stale)
+            self.reduce_bucket_async(0, self.total)
+            self._finish_reduce()
 
     def update_only(self):
         """The part of step() behind the collective (capturable: device step counter, clip, AdamW, shadows)."""
         assert self._dev_step is not None, "call use_device_step_counter(True) before capturing"
+        assert not (self._collective and self.reduce == "rs_ag"), "update_only (graph capture) needs reduce='allreduce'"
         ops.step_counter_add(self._dev_step, 1)
         self._apply_update(1.0 / self.world)
 
+    # ---- the update: device kernels behind three primitives (the gloo tests substitute CPU restatements) -------------
+    def _k_cast(self, src, dst):
+        """dst <- src between float32 and bfloat16 (smx_cast_from_f32 / smx_cast_to_f32)."""
+        lib, n = ops.L.lib(), src.numel()
+        if src.dtype == torch.float32:
+            ops.L.check(lib.smx_cast_from_f32(ops.L.BF16, ops._p(src), ops._p(dst), n, ops._stream()), "smx_cast_from_f32")
+        else:
+            ops.L.check(lib.smx_cast_to_f32(ops.L.BF16, ops._p(src), ops._p(dst), n, ops._stream()), "smx_cast_to_f32")
+
+    def _k_sumsq(self, g):
+        ops.sumsq(g, self._sumsq)                         # _sumsq[0] += sum(g^2), fixed summation order
+
+    def _k_clip(self, gscale):
+        ops.clip_factor(self._sumsq, self.max_grad_norm, gscale, self._clip)
+
+    def _k_adamw(self, a, b, g, gscale, clip):
+        """AdamW on flat elements [a, b) with the gradient tensor g (b - a elements)."""
+        ops.adamw_step(self.flat_p[a:b], g, self.exp_avg[a:b], self.exp_avg_sq[a:b],
+                       self.shadow[a:b] if self.shadow is not None else None, self.lr, self.betas[0], self.betas[1], self.eps,
+                       self.wd, 0 if self._dev_step is not None else self.step_count, gscale, clip)
+
     def _apply_update(self, gscale):
-        """Global-norm clip + AdamW + bf16 shadow refresh: three HIP kernel launches, nothing visits the host."""
+        """Global-norm clip + AdamW + bf16 shadow refresh: three HIP kernel launches per owned range, nothing visits the
+        host.  reduce="rs_ag": the ranges are this rank's shards of the reduce-scattered buckets, the squared norm is
+        completed by one scalar all-reduce and the updated weights are all-gathered bucket by bucket."""
+        sharded = self._collective and self.reduce == "rs_ag"
+        W = self.world
+        if sharded:
+            covered = sum(b - a for a, b in self._reduced)
+            assert covered == self.total, f"rs_ag: the reduced buckets cover {covered} of {self.total} elements"
+            work = [(self._shard(a, b), self._shard_g[a // W:b // W]) for a, b in self._reduced]
+        else:
+            work = [((0, self.total), self.flat_g)]
         clip = None
         if self.max_grad_norm is not None and self.max_grad_norm > 0:
             self._sumsq.zero_()
-            ops.sumsq(self.flat_g, self._sumsq)
-            ops.clip_factor(self._sumsq, self.max_grad_norm, gscale, self._clip)
+            for _, g in work:
+                self._k_sumsq(g)
+            if sharded:
+                dist.all_reduce(self._sumsq, op=dist.ReduceOp.SUM, group=self.pg)
+            self._k_clip(gscale)
             clip = self._clip
-        ops.adamw_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.shadow, self.lr, self.betas[0],
-                       self.betas[1], self.eps, self.wd, 0 if self._dev_step is not None else self.step_count, gscale, clip)
+        for (a, b), g in work:
+            self._k_adamw(a, b, g, gscale, clip)
+        if sharded:
+            for a, b in self._reduced:
+                sa, sb = self._shard(a, b)
+                mine = self._shard_p[a // W:b // W]
+                mine.copy_(self.flat_p[sa:sb])
+                dist.all_gather_into_tensor(self.flat_p[a:b], mine, group=self.pg)
+            self.refresh_shadows()
 
     def grad_norm(self):
         """Host read of the last global gradient norm (diagnostics only)."""

@@ -40,8 +40,8 @@ def test_version_and_error_string_need_no_gpu():
 
 def test_epilogue_struct_layout_matches_header():
     from summarymixing_amd import _lib
-    assert ctypes.sizeof(_lib.Epilogue) == 264  # 33 x 8 bytes (round 3: + io_flags, pad_), see include/smx.h smx_epilogue
-    assert _lib.Epilogue.io_flags.offset == 256
+    assert ctypes.sizeof(_lib.Epilogue) == 272  # 34 x 8 bytes (round 3: + io_flags, pad_, epoch), see include/smx.h smx_epilogue
+    assert _lib.Epilogue.io_flags.offset == 256 and _lib.Epilogue.epoch.offset == 264
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
@@ -56,3 +56,21 @@ def test_wgrad_item_struct_layout_matches_header():
     from summarymixing_amd import _lib
     assert ctypes.sizeof(_lib.WgradItem) == 56  # 5 x 8 + 4 x 4 bytes, see include/smx.h smx_wgrad_item
     assert ctypes.sizeof(_lib.ReduceJob) == 56
+
+
+def test_config_is_read_once_and_queryable():
+    """smx_get_config returns the knobs the library read from the environment (include/smx.h: smx_config); a later change
+    of the environment does not reach the library (no getenv on any call path)."""
+    from summarymixing_amd import _lib
+    before = _lib.get_config()
+    assert before["epi_simple"] == int(os.environ.get("SMX_EPI_SIMPLE", 2)) and before["wgroup_bk"] in (32, 64)
+    assert before["diag_build"] == 0 and before["gemm_ablate"] == 0 and before["wgroup_ablate"] == 0 and before["dwroll_ablate"] == 0
+    old = os.environ.get("SMX_WGROUP_PP")
+    os.environ["SMX_WGROUP_PP"] = "2" if before["wgroup_pp"] != 2 else "0"
+    try:
+        assert _lib.get_config() == before
+    finally:
+        if old is None:
+            del os.environ["SMX_WGROUP_PP"]
+        else:
+            os.environ["SMX_WGROUP_PP"] = old

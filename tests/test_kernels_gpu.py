@@ -153,7 +153,11 @@ def test_chunk_mean_fwd_bwd(left, dtype, tol):
 @pytest.mark.parametrize("B,T,D,k,chunk", [(2, 150, 96, 31, 0), (3, 70, 40, 7, 0), (2, 100, 64, 31, 16), (1, 9, 8, 5, 4),
                                            # D % 64 == 0, k = 31, no chunking: the rolling register-window kernels (dwconv_roll.h)
                                            (2, 150, 128, 31, 0), (3, 500, 64, 31, 0), (1, 9, 64, 31, 0), (5, 131, 192, 31, 0),
-                                           (128, 500, 256, 31, 0)])
+                                           (128, 500, 256, 31, 0),
+                                           # Dynamic Chunk Convolution in the rolling kernels (chunk >= 8; 7 stays on the tiled ones):
+                                           # chunks that divide / straddle the 16-frame steps and the 128-frame wave segments
+                                           (2, 150, 128, 31, 8), (1, 300, 64, 31, 13), (2, 200, 64, 31, 32), (1, 130, 64, 31, 50),
+                                           (3, 257, 64, 31, 24), (2, 100, 64, 31, 7), (1, 40, 64, 31, 100), (16, 500, 256, 31, 8)])
 def test_glu_dwconv_fwd_bwd(B, T, D, k, chunk, dtype, tol):
     from oracle import smx_oracle as O
     L, ops = _ops()

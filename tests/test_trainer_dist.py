@@ -133,3 +133,125 @@ def test_flat_views_alias_parameters():
     p.grad.fill_(1.0)
     assert opt.flat_g[: p.numel()].eq(1).all() and p.data_ptr() == opt.flat_p.data_ptr()
     assert opt.total % 64 == 0 and all(o % 64 == 0 for o in opt.offs)
+
+
+# ---- reduce="rs_ag" and grad_dtype=bfloat16 (world 2, gloo) ------------------------------------------------------------
+class _CpuKernels:
+    """CPU restatements of the three device primitives of FlatAdamW._apply_update (smx_cast_*, smx_sumsq, smx_clip_factor,
+    smx_adamw_step), so that the sharded update runs through the product's own control flow here."""
+
+    def _k_cast(self, src, dst):
+        dst.copy_(src)
+
+    def _k_sumsq(self, g):
+        self._sumsq += (g.double() ** 2).sum().float()
+
+    def _k_clip(self, gscale):
+        nrm = float(self._sumsq.sqrt()) * gscale
+        self._clip[0] = min(1.0, self.max_grad_norm / (nrm + 1e-6))
+
+    def _k_adamw(self, a, b, g, gscale, clip):
+        g = g * gscale * (float(clip[0]) if clip is not None else 1.0)
+        b1, b2 = self.betas
+        p, m, v = self.flat_p[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b]
+        p.mul_(1 - self.lr * self.wd)
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+        p.addcdiv_(m, v.sqrt() / bc2 ** 0.5 + self.eps, value=-self.lr / bc1)
+
+
+def _worker_modes(rank, world, port, out, reduce, grad_dtype):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from summarymixing_amd.trainer import FlatAdamW
+
+        class Opt(_CpuKernels, FlatAdamW):
+            pass
+        enc = _model()
+        opt = Opt(enc, lr=1e-2, max_grad_norm=0.5, compute_dtype=torch.float32, reduce=reduce, grad_dtype=grad_dtype)
+        ranges = [opt.param_range(list(l.parameters())) for l in enc.layers]
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(4, 9, 16, generator=g)
+        R = torch.randn(4, 9, 16, generator=g)
+        lens = torch.tensor([9, 5, 7, 9])
+        pad = torch.arange(9)[None] < lens[:, None]
+        sl = slice(rank * 2, rank * 2 + 2)
+        for _ in range(2):                                       # two steps: the moments and the gathered weights carry over
+            opt.zero_grad()
+            _oracle_grads_into(enc, X[sl], pad[sl], R[sl])
+            for a, b in reversed(ranges):
+                opt.reduce_bucket_async(a, b)
+            opt.reduce_bucket_async(ranges[-1][1], opt.total)
+            opt.step()
+        torch.save({"params": opt.flat_p.clone(), "clip": opt._clip.clone(), "flat_g": opt.flat_g.clone(),
+                    "shard_g": opt._shard_g.clone() if reduce == "rs_ag" else None,
+                    "ranges": list(reversed(ranges)) + [(ranges[-1][1], opt.total)]}, out + f".{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_process_reference(steps=2):
+    from summarymixing_amd.trainer import FlatAdamW
+
+    class Opt(_CpuKernels, FlatAdamW):
+        pass
+    enc = _model()
+    opt = Opt(enc, lr=1e-2, max_grad_norm=0.5, compute_dtype=torch.float32)
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(4, 9, 16, generator=g)
+    R = torch.randn(4, 9, 16, generator=g)
+    lens = torch.tensor([9, 5, 7, 9])
+    pad = torch.arange(9)[None] < lens[:, None]
+    for _ in range(steps):
+        opt.zero_grad()
+        _oracle_grads_into(enc, X, pad, R)
+        opt.flat_g.mul_(0.5)                                     # the DP step averages over the 2 ranks
+        opt.step()
+    return opt
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("reduce,grad_dtype,tol", [("rs_ag", torch.float32, 1e-3), ("allreduce", torch.bfloat16, 5e-2),
+                                                   ("rs_ag", torch.bfloat16, 5e-2)])
+def test_dp2_reduce_modes_match_single_process(tmp_path, reduce, grad_dtype, tol):
+    """reduce-scatter + sharded AdamW + all-gather (and gradients in bf16 on the wire) give the weights of the
+    single-process step on the concatenated batch; both ranks end with IDENTICAL weights."""
+    out = str(tmp_path / "r")
+    mp.spawn(_worker_modes, args=(2, _free_port(), out, reduce, grad_dtype), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["params"], r1["params"])               # ranks never drift apart
+    assert float(r0["clip"][0]) < 1.0                            # the clip was active (norm completed across the shards)
+    ref = _single_process_reference()
+    # (1) the gradients the update saw: sum over the ranks (= 2 x the single-process mean gradient), exact in fp32,
+    #     within three bf16 roundings (each rank's cast, the sum) when they cross the wire in bf16
+    if reduce == "rs_ag":
+        got_g = torch.zeros_like(ref.flat_g)
+        for a, b in r0["ranges"]:
+            n = (b - a) // 2
+            got_g[a:a + n] = r0["shard_g"][a // 2:b // 2]
+            got_g[a + n:b] = r1["shard_g"][a // 2:b // 2]
+    else:
+        got_g = r0["flat_g"]
+    want_g = ref.flat_g * 2
+    gerr = (got_g - want_g).abs().max().item() / want_g.abs().max().item()
+    assert gerr <= (1e-5 if grad_dtype == torch.float32 else 2 ** -7), gerr
+    # (2) the UPDATE (two AdamW steps of size ~lr).  Adam normalises every element by its own sqrt(v), so elements whose
+    #     gradient is ~0 turn bf16 rounding into sign flips: RMS over the whole vector for bf16, max-abs for fp32
+    base = FlatAdamWBase()
+    du, dr = r0["params"] - base, ref.flat_p - base
+    if grad_dtype == torch.float32:
+        err = (du - dr).abs().max().item() / dr.abs().max().item()
+    else:
+        err = ((du - dr).pow(2).mean().sqrt() / dr.pow(2).mean().sqrt()).item()
+    assert err <= tol, err
+
+
+def FlatAdamWBase():
+    """The initial flat weights (same seed as every worker)."""
+    from summarymixing_amd.trainer import FlatAdamW
+
+    class Opt(_CpuKernels, FlatAdamW):
+        pass
+    return Opt(_model(), compute_dtype=torch.float32).flat_p.clone()

@@ -113,16 +113,28 @@ ropt = FlatAdamW(ref, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
 assert not ropt._collective
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 enc = model()
-opt = FlatAdamW(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype)
+reduce = os.environ.get("SMX_REDUCE", "allreduce")
+gdt = torch.bfloat16 if os.environ.get("SMX_GRAD_DTYPE") == "bf16" else torch.float32
+opt = FlatAdamW(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype, reduce=reduce, grad_dtype=gdt)
 assert opt._collective and opt.world == 1, "SMX_FORCE_ALLREDUCE=1 must switch the RCCL bucket path on"
 hooks(enc, opt)
+opt.measure_comm(True)
 for it in range(3):
     one_step(ref, ropt, X.to(dtype), PAD, R.to(dtype), False)
     one_step(enc, opt, X.to(dtype), PAD, R.to(dtype), True)
 torch.cuda.synchronize()
-assert torch.equal(opt.flat_g, ropt.flat_g), "gradients differ"
-assert torch.equal(opt.flat_p, ropt.flat_p), "weights differ"
-assert torch.equal(opt.shadow, ropt.shadow)
+assert opt.comm_exposed_ms() >= 0.0 and len(opt._exposed) == 3
+if gdt == torch.float32:
+    # reduce-scatter / all-gather over one rank move every bucket through the shard buffers: still bit for bit
+    assert torch.equal(opt.flat_g, ropt.flat_g), "gradients differ"
+    assert torch.equal(opt.flat_p, ropt.flat_p), "weights differ"
+    assert torch.equal(opt.shadow, ropt.shadow)
+else:
+    # gradients crossed the wire in bf16: one rounding (2^-9 relative per element) of what the update saw
+    got = opt._shard_g if reduce == "rs_ag" else opt.flat_g
+    ok = (got - ropt.flat_g).abs() <= ropt.flat_g.abs() * 2.0 ** -8 + 1e-30
+    assert bool(ok.all()), "bf16 gradient image off by more than one rounding"
+    assert torch.equal(opt.shadow, opt.flat_p.bfloat16()), "bf16 shadows do not follow the gathered weights"
 dist.barrier()
 dist.destroy_process_group()
 print("rank 0 OK")
@@ -203,6 +215,14 @@ def test_two_ranks_hip_backward_through_buckets_equals_single_process(dtype):
 
 def test_single_rank_rccl_bucket_path_is_bit_identical():
     _launch(NCCL_WORKER, 1, {"SMX_FORCE_ALLREDUCE": "1"})
+
+
+@pytest.mark.parametrize("reduce,grad_dtype", [("rs_ag", "fp32"), ("allreduce", "bf16"), ("rs_ag", "bf16")])
+def test_single_rank_rccl_reduce_modes(reduce, grad_dtype):
+    """FlatAdamW(reduce="rs_ag") / grad_dtype=bfloat16 over RCCL (one rank: the collectives are identities, the staging
+    buffers, casts, shard arithmetic and the all-gather of the weights are the real ones; world 2 runs on gloo in
+    tests/test_trainer_dist.py)."""
+    _launch(NCCL_WORKER, 1, {"SMX_FORCE_ALLREDUCE": "1", "SMX_REDUCE": reduce, "SMX_GRAD_DTYPE": grad_dtype})
 
 
 def test_dp_hipgraph_split_equals_eager_steps():
