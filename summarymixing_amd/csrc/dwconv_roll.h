@@ -88,13 +88,8 @@ __device__ __forceinline__ void rw_taps_down(int depth, F&& f) {        // f(1) 
   if (depth >= 15) rw_taps_run<0, 15>(f);
   else rw_taps_tree<0, 8>(depth, f);
 }
-// (t0 + o) mod c for t0 mod c = m0 < c, 0 <= o < 16 <= 2 c
-__device__ __forceinline__ int rw_mod(int m0, int o, int c) {
-  int m = m0 + o;
-  if (m >= c) m -= c;
-  if (m >= c) m -= c;
-  return m;
-}
+// t mod c of consecutive frames, carried as a running scalar (any c >= 1): m' = m + 1, wrapped
+__device__ __forceinline__ int rw_next(int m, int c) { return m + 1 == c ? 0 : m + 1; }
 
 // (iy, bx) of this workgroup: workgroup id % 8 is its XCD; the channel tiles of one run of 4 segments sit on ONE XCD
 // next to each other in dispatch order, so the 128-byte pieces of a feature row are fetched by neighbours at the same time
@@ -131,7 +126,7 @@ __global__ __launch_bounds__(256) void dwconv_roll_fwd(DwParams p, int seg, int 
   for (int i = 0; i < WIN; ++i) win[i] = 0.f;
   raw_t pa0[RW_STEP], pg0[RW_STEP], pa1[RW_STEP], pg1[RW_STEP];       // two steps of rows in flight
   const int cz = CH ? p.chunk : 1;
-  int m0 = CH ? t_lo % cz : 0;                                          // (frame of the step's first output) mod chunk
+  int m0 = CH ? t_lo % cz : 0;                                          // (frame of the next output) mod chunk
   // window row i at step s is frame t_lo + 16 s - 15 + i; the step's 16 fetched frames land in rows 30..45
   // (a zero 'a' gives u = 0 whatever the gate: zero padding needs no flag)
   auto step = [&](raw_t (&pa)[RW_STEP], raw_t (&pg)[RW_STEP], int s) {
@@ -153,12 +148,12 @@ __global__ __launch_bounds__(256) void dwconv_roll_fwd(DwParams p, int seg, int 
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) acc += w[j] * win[o + j];
-          rw_taps_down(cz - 1 - rw_mod(m0, o, cz), [&](auto d) { acc += w[15 + decltype(d)::value] * win[o + 15 + decltype(d)::value]; });
+          rw_taps_down(cz - 1 - m0, [&](auto d) { acc += w[15 + decltype(d)::value] * win[o + 15 + decltype(d)::value]; });
+          m0 = rw_next(m0, cz);
         }
         if (r0 + o < t_hi) rw_st<T>(acc, rY, va, soff);
         soff += ldyb;
       }
-      if constexpr (CH) m0 = rw_mod(m0, RW_STEP, cz);
     }
 #pragma unroll
     for (int i = 0; i < WIN - RW_STEP; ++i) win[i] = win[i + RW_STEP];
@@ -241,9 +236,12 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
 #pragma unroll
             for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
           }
+          int m = m0;
 #pragma unroll
-          for (int o = 0; o < RW_STEP; ++o)
-            rw_taps_down(rw_mod(m0, o, cz), [&](auto d) { du[o] += wl[15 + decltype(d)::value][lane] * gw[15 + o - decltype(d)::value]; });
+          for (int o = 0; o < RW_STEP; ++o) {
+            rw_taps_down(m, [&](auto d) { du[o] += wl[15 + decltype(d)::value][lane] * gw[15 + o - decltype(d)::value]; });
+            m = rw_next(m, cz);
+          }
         }
         const int r0 = t_lo + s * RW_STEP;
         unsigned soff = (unsigned)r0 * ldob;
@@ -287,9 +285,10 @@ __global__ __launch_bounds__(256) void dwconv_roll_bwd(DwParams p, int seg, int 
             dw[j] += sacc;
           }
 #pragma unroll
-          for (int o = 0; o < RW_STEP; ++o)
-            rw_taps_down(cz - 1 - rw_mod(m0, o, cz), [&](auto d) { dw[15 + decltype(d)::value] += gw[15 + o] * uw[o + 15 + decltype(d)::value]; });
-          m0 = rw_mod(m0, RW_STEP, cz);
+          for (int o = 0; o < RW_STEP; ++o) {
+            rw_taps_down(cz - 1 - m0, [&](auto d) { dw[15 + decltype(d)::value] += gw[15 + o] * uw[o + 15 + decltype(d)::value]; });
+            m0 = rw_next(m0, cz);
+          }
         }
 #pragma unroll
         for (int o = 0; o < RW_STEP; ++o) dbs += gw[15 + o];
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(256) void dwconv_rolls_fwd(DwParams p, int seg, int
     rw_dma16(rP, d + 2048, vpg, r0, ldpb);
   };
   const int cz = CH ? p.chunk : 1;
-  int m0 = CH ? t_lo % cz : 0;                          // (frame of the step's first output) mod chunk
+  int m0 = CH ? t_lo % cz : 0;                          // (frame of the next output) mod chunk
   dma(-2);
   dma(-1);
   for (int s = -2; s < nsteps; ++s) {
@@ -394,11 +393,11 @@ __global__ __launch_bounds__(256) void dwconv_rolls_fwd(DwParams p, int seg, int
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) acc += w[j] * win[o + j];
-          rw_taps_down(cz - 1 - rw_mod(m0, o, cz), [&](auto d) { acc += w[15 + decltype(d)::value] * win[o + 15 + decltype(d)::value]; });
+          rw_taps_down(cz - 1 - m0, [&](auto d) { acc += w[15 + decltype(d)::value] * win[o + 15 + decltype(d)::value]; });
+          m0 = rw_next(m0, cz);
         }
         ob[o * 64] = (unsigned short)f32_to_bf16_bits(acc);
       }
-      if constexpr (CH) m0 = rw_mod(m0, RW_STEP, cz);
       asm volatile("" ::: "memory");                   // (LDS is in order within a wave: a compiler fence is enough)
       const unsigned s0 = (unsigned)(t_lo + s * RW_STEP) * ldyb;
       typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
@@ -498,9 +497,12 @@ __global__ __launch_bounds__(256) void dwconv_rolls_bwd(DwParams p, int seg, int
 #pragma unroll
             for (int o = 0; o < RW_STEP; ++o) du[o] += wj * gw[30 + o - j];
           }
+          int m = m0;
 #pragma unroll
-          for (int o = 0; o < RW_STEP; ++o)
-            rw_taps_down(rw_mod(m0, o, cz), [&](auto d) { du[o] += wl[15 + decltype(d)::value][lane] * gw[15 + o - decltype(d)::value]; });
+          for (int o = 0; o < RW_STEP; ++o) {
+            rw_taps_down(m, [&](auto d) { du[o] += wl[15 + decltype(d)::value][lane] * gw[15 + o - decltype(d)::value]; });
+            m = rw_next(m, cz);
+          }
         }
         unsigned short* ob = reinterpret_cast<unsigned short*>(st + OUT) + lane;
 #pragma unroll
@@ -543,9 +545,10 @@ __global__ __launch_bounds__(256) void dwconv_rolls_bwd(DwParams p, int seg, int
             dw[j] += sacc;
           }
 #pragma unroll
-          for (int o = 0; o < RW_STEP; ++o)
-            rw_taps_down(cz - 1 - rw_mod(m0, o, cz), [&](auto d) { dw[15 + decltype(d)::value] += gw[15 + o] * uw[o + 15 + decltype(d)::value]; });
-          m0 = rw_mod(m0, RW_STEP, cz);
+          for (int o = 0; o < RW_STEP; ++o) {
+            rw_taps_down(cz - 1 - m0, [&](auto d) { dw[15 + decltype(d)::value] += gw[15 + o] * uw[o + 15 + decltype(d)::value]; });
+            m0 = rw_next(m0, cz);
+          }
         }
 #pragma unroll
         for (int o = 0; o < RW_STEP; ++o) dbs += gw[15 + o];

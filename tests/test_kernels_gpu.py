@@ -154,10 +154,11 @@ def test_chunk_mean_fwd_bwd(left, dtype, tol):
                                            # D % 64 == 0, k = 31, no chunking: the rolling register-window kernels (dwconv_roll.h)
                                            (2, 150, 128, 31, 0), (3, 500, 64, 31, 0), (1, 9, 64, 31, 0), (5, 131, 192, 31, 0),
                                            (128, 500, 256, 31, 0),
-                                           # Dynamic Chunk Convolution in the rolling kernels (chunk >= 8; 7 stays on the tiled ones):
-                                           # chunks that divide / straddle the 16-frame steps and the 128-frame wave segments
+                                           # Dynamic Chunk Convolution in the rolling kernels: chunks that divide / straddle the
+                                           # 16-frame steps and the 128-frame wave segments, chunk > T, chunk = 1
                                            (2, 150, 128, 31, 8), (1, 300, 64, 31, 13), (2, 200, 64, 31, 32), (1, 130, 64, 31, 50),
-                                           (3, 257, 64, 31, 24), (2, 100, 64, 31, 7), (1, 40, 64, 31, 100), (16, 500, 256, 31, 8)])
+                                           (3, 257, 64, 31, 24), (2, 100, 64, 31, 7), (1, 40, 64, 31, 100), (2, 70, 64, 31, 1),
+                                           (4, 500, 256, 31, 4), (4, 500, 256, 31, 16), (16, 500, 256, 31, 8)])
 def test_glu_dwconv_fwd_bwd(B, T, D, k, chunk, dtype, tol):
     from oracle import smx_oracle as O
     L, ops = _ops()
