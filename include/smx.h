@@ -328,6 +328,14 @@ int smx_mel_db(int out_dtype, const float* spec, int64_t lds, int im_off, const 
                float amin, float top_db, void* out, int B, int T, void* workspace, void* stream);
 int smx_im2col_s2(int dtype, const void* x, void* col, int B, int T, int F, int C, int Kp, void* stream);
 int smx_col2im_s2(int dtype, const void* dcol, void* dx, int B, int T, int F, int C, int Kp, void* stream);
+/* Y (N, M) = X (N, 16) W (M, 16)^T + bias: the first block's convolution (9 taps of one input channel in 16 columns) on
+ * the VALU, bf16 in / out, fp32 accumulation; dense rows.  SMX_EUNSUPPORTED for other shapes (use smx_gemm). */
+int smx_linear_k16_fwd(int dtype, const void* X, const void* W, const float* bias, void* Y, int64_t N, int M, void* stream);
+/* Direct input gradient of that convolution, without the (rows, 9 C) column matrix: dX (B,T,F,C) from dY
+ * (B,ceil(T/2),ceil(F/2),O) and the GEMM-layout weight Wg (O, Kp) (column (dt*3+df)*C + c).  Built for the recipe's second
+ * block (bf16, C = 64, O = 32; SMX_EUNSUPPORTED otherwise: use the dgrad GEMM + smx_col2im_s2).  MFMA, no atomics. */
+int smx_conv2d_s2_dgrad(int dtype, const void* dY, const void* Wg, void* dX, int B, int T, int F, int C, int O, int Kp,
+                        void* stream);
 
 /* y = a*x (+ b*y0): generic strided elementwise helper (dtype T). */
 int smx_axpby(int dtype, float a, const void* X, int64_t ldx, float b, const void* Y0, int64_t ldy0, void* Y,

@@ -114,6 +114,8 @@ SIGNATURES = {
     "smx_mel_db": (c_i, [c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_f, c_f, c_vp, c_i, c_i, c_vp, c_vp]),
     "smx_im2col_s2": (c_i, [c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_col2im_s2": (c_i, [c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "smx_linear_k16_fwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_vp]),
+    "smx_conv2d_s2_dgrad": (c_i, [c_i, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_axpby": (c_i, [c_i, c_f, c_vp, c_i64, c_f, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
     "smx_dropout": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_add_rowtable": (c_i, [c_i, c_vp, c_i64, c_vp, c_i, c_i, c_i, c_vp]),

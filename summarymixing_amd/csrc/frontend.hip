@@ -151,6 +151,151 @@ __global__ __launch_bounds__(256) void col2im_s2_kernel(const T* __restrict__ dc
   }
 }
 
+// im2col for C % 8 == 0 in 16-byte pieces: one thread = (output row, tap, 8 channels): one 16-byte load, one 16-byte store
+// (the element-wise kernel above spends 2.4 ms on the 1.47 GB col of the second block: two integer divisions per element)
+__global__ __launch_bounds__(256) void im2col_s2_vec_kernel(const uint4* __restrict__ x, uint4* __restrict__ col, int B, int T_,
+                                                            int F, int C8, int T2, int F2, int Kp8) {
+  const long rows = (long)B * T2 * F2;
+  const int per_row = 9 * C8;                                 // (Kp == 9 C for C % 8 == 0: no padding columns)
+  for (long row = blockIdx.x * 4L + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const int f2 = (int)(row % F2);
+    const long r2 = row / F2;
+    const int t2 = (int)(r2 % T2), b = (int)(r2 / T2);
+    for (int e = threadIdx.x & 63; e < per_row; e += 64) {
+      const int tap = e / C8, c8 = e - tap * C8, dt = tap / 3, df = tap - dt * 3;
+      const int t = reflect1(2 * t2 + dt - 1, T_), f = reflect1(2 * f2 + df - 1, F);
+      col[row * Kp8 + e] = x[(((long)b * T_ + t) * F + f) * C8 + c8];
+    }
+  }
+}
+
+// ---- thin Linear: Y[n, m] = sum_k X[n, k] W[m, k] + bias[m] for K = 16 (the first conv block: 9 taps of ONE input channel,
+// padded to 16 columns) - 16 MACs per output are VALU work next to the 128 bytes a row writes; the MFMA GEMM's tile machinery
+// spends 790 us on the 655 MB output at B = 128 x 20 s.  Thread = 8 output channels of one row, weights in registers.
+__global__ __launch_bounds__(256) void linear_k16_kernel(const uint4* __restrict__ X, const bf16_t* __restrict__ W,
+                                                         const float* __restrict__ bias, uint4* __restrict__ Y, long N_, int M) {
+  const int cgs = M >> 3;                                        // channel groups per row (divides 256)
+  const long gid = blockIdx.x * 256L + threadIdx.x;
+  const int cg = (int)(gid % cgs);
+  const long stride = (long)gridDim.x * 256 / cgs;
+  float w[8][16], bs[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    bs[m] = bias ? bias[cg * 8 + m] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[m][k] = to_f32(W[(long)(cg * 8 + m) * 16 + k]);
+  }
+  for (long row = gid / cgs; row < N_; row += stride) {
+    const uint4 a = X[row * 2], b = X[row * 2 + 1];
+    const uint32_t xw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float x[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { x[2 * k] = bf16_bits_to_f32(xw[k] & 0xffffu); x[2 * k + 1] = bf16_bits_to_f32(xw[k] >> 16); }
+    float acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      acc[m] = bs[m];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[m] += w[m][k] * x[k];
+    }
+    Y[row * cgs + cg] = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                                   pack_bf16x2(acc[6], acc[7]));
+  }
+}
+
+// ---- direct input gradient of the 3x3 / stride 2 / reflect-pad-1 convolution (C = 64 input, O = 32 output channels) -------
+// dx[b,t,f,c] = sum over the output pixels (t2,f2) and taps (dt,df) whose (reflected) source is (t,f) of
+//               sum_o dy[b,t2,f2,o] W[o,dt,df,c]
+// Replaces the dgrad GEMM (dcol = dy W: 1.47 GB written at B = 128 x 20 s) + col2im (1.47 GB read, element-wise gather):
+// 2.1 + 3.2 ms -> one pass that reads dy (82 MB, cache resident) and writes dx (655 MB) once.
+// One wave owns 32 consecutive input pixels (one MFMA column each): for every tap whose source exists for at least one of
+// them (wave-uniform ballot; stride 2 makes a tap valid for one parity of t / f only, the two reflected edge taps are
+// extra virtual taps) the 32 output channels of the source pixel are the B operand, read straight from global memory
+// (16 bytes per lane, rows without a source read zeros through the buffer range check); W^T fragments sit in LDS in
+// fragment order.  D[channel][pixel]: a lane ends with 4 consecutive channels of its pixel per 8-channel group.
+typedef __attribute__((ext_vector_type(8))) __bf16 fe_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float fe_f32x16;
+typedef uint32_t fe_u32x4 __attribute__((ext_vector_type(4)));
+
+// source coordinate of virtual tap v (0..2: dt = v direct; 3: the mirrored row -1, dt = 0; 4: the mirrored row L, dt = 2)
+__device__ __forceinline__ bool conv_s2_src(int v, int t, int L, int L2, int& t2, int& dt) {
+  if (v < 3) { dt = v; const int s = t + 1 - v; t2 = s >> 1; return s >= 0 && !(s & 1) && t2 < L2; }
+  if (v == 3) { dt = 0; t2 = 0; return t == 1; }
+  dt = 2; t2 = (L - 1) >> 1;                                    // 2 t2 + 1 == L: only for odd L
+  return (L & 1) && t == L - 2 && t2 < L2;
+}
+
+__global__ __launch_bounds__(256) void conv2d_s2_dgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wg,
+                                                              bf16_t* __restrict__ dx, int B, int T_, int F, int T2, int F2,
+                                                              int Kp, long ntiles) {
+  constexpr int C = 64, O = 32;
+  __shared__ fe_u32x4 Wl[9 * 2 * 2 * 64];                       // [tap][channel block][o chunk][lane]: 36 KB
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  for (int e = threadIdx.x; e < 9 * 2 * 2 * 64; e += 256) {
+    const int ln = e & 63, oc = (e >> 6) & 1, cb = (e >> 7) & 1, tap = e >> 8;
+    const int c = cb * 32 + (ln & 31), o0 = oc * 16 + (ln >> 5) * 8;
+    uint32_t w4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t lo = reinterpret_cast<const uint16_t*>(wg)[(long)(o0 + 2 * q) * Kp + tap * C + c];
+      const uint32_t hi16 = reinterpret_cast<const uint16_t*>(wg)[(long)(o0 + 2 * q + 1) * Kp + tap * C + c];
+      w4[q] = lo | (hi16 << 16);
+    }
+    Wl[e] = fe_u32x4{w4[0], w4[1], w4[2], w4[3]};
+  }
+  __syncthreads();
+  const long npix = (long)B * T_ * F;
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dy), (short)0,
+                                                                       (int)((long)B * T2 * F2 * O * 2), 0x00020000);
+  for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long pix = tile * 32 + l31;
+    const bool pv = pix < npix;
+    const long pc = pv ? pix : npix - 1;
+    const int f = (int)(pc % F);
+    const long r = pc / F;
+    const int t = (int)(r % T_), b = (int)(r / T_);
+    fe_f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+#pragma unroll 1
+    for (int vt = 0; vt < 5; ++vt) {
+      int t2, dt;
+      const bool srct = conv_s2_src(vt, t, T_, T2, t2, dt);     // (no short-circuit: dt / df are functions of the virtual tap
+      const bool okt = pv && srct;                              //  alone and must be set in every lane)
+      if (!__builtin_amdgcn_ballot_w64(okt)) continue;
+      dt = vt < 3 ? vt : (vt == 3 ? 0 : 2);
+#pragma unroll 1
+      for (int vf = 0; vf < 5; ++vf) {
+        int f2, df;
+        const bool srcf = conv_s2_src(vf, f, F, F2, f2, df);
+        const bool ok = okt && srcf;
+        if (!__builtin_amdgcn_ballot_w64(ok)) continue;
+        df = vf < 3 ? vf : (vf == 3 ? 0 : 2);
+        const unsigned off = ok ? (unsigned)((((long)b * T2 + t2) * F2 + f2) * (O * 2) + hi * 16) : 0x80000000u;
+        const fe_u32x4 b0 = __builtin_bit_cast(fe_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+        const fe_u32x4 b1 = __builtin_bit_cast(fe_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + 32, 0, 0));
+        const fe_u32x4* wp = Wl + (dt * 3 + df) * 256 + lane;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fe_bf16x8, wp[cb * 128]), __builtin_bit_cast(fe_bf16x8, b0), acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fe_bf16x8, wp[cb * 128 + 64]), __builtin_bit_cast(fe_bf16x8, b1), acc[cb], 0, 0, 0);
+        }
+      }
+    }
+    if (pv) {
+      bf16_t* o = dx + pix * C + hi * 4;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint2*>(o + cb * 32 + g * 8) =
+              make_uint2(pack_bf16x2(acc[cb][g * 4], acc[cb][g * 4 + 1]), pack_bf16x2(acc[cb][g * 4 + 2], acc[cb][g * 4 + 3]));
+    }
+  }
+}
+
 // ---- InputNormalization (speechbrain.processing.features.InputNormalization, recipe key `normalize`) ---------------
 // per-utterance mean and unbiased std over the valid frames t < len[b] of every feature; grid (ceil(F/64), B), 256
 // threads = 64 features x 4 time groups; two passes over the (small) feature block for a stable variance
@@ -253,9 +398,42 @@ extern "C" int smx_im2col_s2(int dtype, const void* x, void* col, int B, int T, 
   const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
   const long total = (long)B * T2 * F2 * Kp;
   if (total <= 0) return SMX_OK;
+  if (dtype == SMX_BF16 && C % 8 == 0 && Kp == 9 * C && aligned16(x) && aligned16(col)) {
+    const long rows = (long)B * T2 * F2;
+    long g = (rows + 3) / 4;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(im2col_s2_vec_kernel, dim3((unsigned)g), dim3(256), 0, STREAM, (const uint4*)x, (uint4*)col, B, T, F, C / 8, T2, F2, Kp / 8);
+    return check_launch("smx_im2col_s2");
+  }
   if (dtype == SMX_BF16) hipLaunchKernelGGL((im2col_s2_kernel<bf16_t>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const bf16_t*)x, (bf16_t*)col, B, T, F, C, T2, F2, Kp);
   else hipLaunchKernelGGL((im2col_s2_kernel<float>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const float*)x, (float*)col, B, T, F, C, T2, F2, Kp);
   return check_launch("smx_im2col_s2");
+}
+
+extern "C" int smx_linear_k16_fwd(int dtype, const void* X, const void* W, const float* bias, void* Y, int64_t N, int M, void* stream) {
+  SMX_REQUIRE(X && W && Y, "smx_linear_k16_fwd: null pointer");
+  if (dtype != SMX_BF16 || M % 8 != 0 || 256 % (M / 8) != 0 || !aligned16(X) || !aligned16(Y))
+    return fail(SMX_EUNSUPPORTED, "smx_linear_k16_fwd: bf16, M a multiple of 8 with M / 8 dividing 256, 16-byte aligned rows");
+  if (N <= 0) return SMX_OK;
+  long g = (N * (M / 8) + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  hipLaunchKernelGGL(linear_k16_kernel, dim3((unsigned)g), dim3(256), 0, STREAM, (const uint4*)X, (const bf16_t*)W, bias, (uint4*)Y, (long)N, M);
+  return check_launch("smx_linear_k16_fwd");
+}
+
+extern "C" int smx_conv2d_s2_dgrad(int dtype, const void* dY, const void* Wg, void* dX, int B, int T, int F, int C, int O, int Kp,
+                                   void* stream) {
+  SMX_REQUIRE(dY && Wg && dX && T >= 4 && F >= 4 && Kp >= 9 * C, "smx_conv2d_s2_dgrad: bad arguments");
+  if (dtype != SMX_BF16 || C != 64 || O != 32) return fail(SMX_EUNSUPPORTED, "smx_conv2d_s2_dgrad: built for bf16, C = 64, O = 32");
+  const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
+  SMX_REQUIRE((long)B * T2 * F2 * O * 2 < (1L << 31), "smx_conv2d_s2_dgrad: dY >= 2 GB");
+  SMX_REQUIRE(aligned16(dY) && aligned16(dX), "smx_conv2d_s2_dgrad: 16-byte aligned tensors");
+  const long ntiles = ((long)B * T * F + 31) / 32;
+  long g = (ntiles + 3) / 4;
+  if (g > 256 * 4) g = 256 * 4;                            // persistent workgroups: the 36 KB weight image is built once each
+  hipLaunchKernelGGL(conv2d_s2_dgrad_kernel, dim3((unsigned)g), dim3(256), 0, STREAM, (const bf16_t*)dY, (const bf16_t*)Wg,
+                     (bf16_t*)dX, B, T, F, T2, F2, Kp, ntiles);
+  return check_launch("smx_conv2d_s2_dgrad");
 }
 
 extern "C" int smx_col2im_s2(int dtype, const void* dcol, void* dx, int B, int T, int F, int C, int Kp, void* stream) {

@@ -29,6 +29,9 @@ namespace smx {
 #ifndef SMX_OCC
 #define SMX_OCC 3
 #endif
+#ifndef SMX_NS_SMALL
+#define SMX_NS_SMALL 4      // register stages in flight of the 64 x 64 tile (latency-bound small grids: see the main loop)
+#endif
 #ifndef SMX_NS_KC
 #define SMX_NS_KC 1
 #endif
@@ -169,7 +172,11 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
   // about one HBM/L2 round trip for its whole main loop instead of one per K tile (measured: 2.9 K cycles per
   // K tile with a single stage, the MFMAs themselves need ~0.5 K).
-  constexpr int NS = A_KC ? SMX_NS_KC : (TILE_M > 128 ? 1 : 2);   // (two stages of a 128x256 tile pair would spill)
+  // The 64 x 64 tile runs when the grid is too small to fill the chip with big tiles (the recipe batch of 3750 frames:
+  // 472 workgroups, ~2 per CU): nothing hides a workgroup's own round trips there, one stage in flight cost 0.6 us per
+  // K tile (17 - 20 us for K = 2048).  Its 16 accumulator registers leave room for 4 stages (64 registers).
+  constexpr int NS = A_KC ? ((TILE_N == 64 && TILE_M == 64) ? SMX_NS_SMALL : SMX_NS_KC)
+                          : (TILE_M > 128 ? 1 : 2);              // (two stages of a 128x256 tile pair would spill)
   uint4 ra[NS][TILE_N / 32], rb[NS][TILE_M / 32];
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_)

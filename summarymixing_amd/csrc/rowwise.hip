@@ -241,6 +241,23 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const T* X, long ldx, fl
       if (i < nvalid) o[i] = sc * (((acc[i] + red[0][lane * N + i]) + red[1][lane * N + i]) + red[2][lane * N + i]);
   }
 }
+// Unlimited left context: the window of chunk c is the whole prefix 0..c (reverse: the suffix c..NC-1), which the window
+// kernel used to add up chunk by chunk - a dependent chain of up to NC loads per workgroup (237 us at NC = 32 against ~10 us of
+// bytes).  One pass turns csum into its running sums in place instead (thread = one column of one utterance, the NC loads
+// are independent and unrolled), and the window kernel reads ONE row.  Fixed order: bit-reproducible.
+__global__ __launch_bounds__(256) void chunk_prefix_kernel(float* csum, int D, int NC, int reverse) {
+  const int col = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (col >= D) return;
+  float* p = csum + (long)b * NC * D + col;
+  float acc = 0.f;
+  if (!reverse) {
+#pragma unroll 8
+    for (int c = 0; c < NC; ++c) { acc += p[(long)c * D]; p[(long)c * D] = acc; }
+  } else {
+#pragma unroll 8
+    for (int c = NC - 1; c >= 0; --c) { acc += p[(long)c * D]; p[(long)c * D] = acc; }
+  }
+}
 // fwd: out rows of chunk c = (sum_{c'=lo..c} csum[c']) / wlen(c);  bwd (reverse=1): rows of chunk c =
 // sum_{c'=c..hi} csum[c'] (csum already scaled by 1/wlen).  grid (DC, NC, B)
 template <typename T, bool VEC>
@@ -252,8 +269,9 @@ __global__ __launch_bounds__(256) void chunk_window_kernel(const float* csum, T*
   const int nvalid = D - col;
   if (nvalid <= 0) return;
   int clo, chi;
-  if (!reverse) { clo = left < 0 ? 0 : max(0, c - left); chi = c; }
-  else { clo = c; chi = left < 0 ? NC - 1 : min(NC - 1, c + left); }
+  if (left < 0) { clo = c; chi = c; }                    // (csum holds running sums already: chunk_prefix_kernel)
+  else if (!reverse) { clo = max(0, c - left); chi = c; }
+  else { clo = c; chi = min(NC - 1, c + left); }
   float acc[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) acc[i] = 0.f;
@@ -737,6 +755,88 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(const T* __rest
   }
 }
 
+// the same with 4 consecutive columns per thread (8-byte accesses in bf16): thread t owns columns (t + 256 i) * 4 .. + 3.
+// The 2-byte accesses of the kernel above cap it at the vector-memory issue rate (1.58 ms for the 2 GB of the front-end's
+// (128128, 2560) LayerNorm backward = 1.3 TB/s).
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_wide4_kernel(const T* __restrict__ dY, long lddy, const T* __restrict__ X,
+                                                                  long ldx, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, int act,
+                                                                  const float* __restrict__ stats, const T* __restrict__ R,
+                                                                  long ldr, T* __restrict__ dX, long lddx,
+                                                                  float* __restrict__ partial, int N_, int D) {
+  __shared__ float red[2][4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  float gam[CH][4], bet[CH][4], dg[CH][4], db[CH][4];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = (t + 256 * i) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      gam[i][q] = c < D ? gamma[c + q] : 0.f;
+      bet[i][q] = (c < D && act != SMX_ACT_NONE) ? beta[c + q] : 0.f;
+      dg[i][q] = db[i][q] = 0.f;
+    }
+  }
+  for (int row = blockIdx.x; row < N_; row += gridDim.x) {
+    const float mean = stats[2 * (long)row], rstd = stats[2 * (long)row + 1];
+    float g[CH][4], xh[CH][4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (t + 256 * i) * 4;
+      if (c < D) {
+        load4<T>(X + (long)row * ldx + c, xh[i]);
+        load4<T>(dY + (long)row * lddy + c, g[i]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[i][q] = xh[i][q] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xhat = (xh[i][q] - mean) * rstd;
+        float dyn = g[i][q];
+        if (act != SMX_ACT_NONE) dyn *= act_grad(act, xhat * gam[i][q] + bet[i][q]);
+        const bool in = (t + 256 * i) * 4 < D;
+        xh[i][q] = in ? xhat : 0.f;
+        dyn = in ? dyn : 0.f;
+        g[i][q] = dyn * gam[i][q];
+        s1 += g[i][q]; s2 += g[i][q] * xh[i][q];
+        dg[i][q] += dyn * xh[i][q]; db[i][q] += dyn;
+      }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    __syncthreads();
+    if (lane == 0) { red[0][w] = s1; red[1][w] = s2; }
+    __syncthreads();
+    const float m1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D;
+    const float m2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)D;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (t + 256 * i) * 4;
+      if (c < D) {
+        float o[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (R) load4<T>(R + (long)row * ldr + c, rr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = rstd * (g[i][q] - m1 - xh[i][q] * m2) + rr[q];
+        store4<T>(dX + (long)row * lddx + c, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = (t + 256 * i) * 4;
+    if (c < D) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        partial[((long)blockIdx.x * 2) * D + c + q] = dg[i][q];
+        partial[((long)blockIdx.x * 2 + 1) * D + c + q] = db[i][q];
+      }
+    }
+  }
+}
+
 // dgamma[c] += sum_b partial[b][0][c]; dbeta[c] += sum_b partial[b][1][c]   (fixed order => bit-reproducible)
 // block = 32 columns x 8 row groups; every thread sums nblocks/8 partial rows with 4 independent accumulators.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int D,
@@ -1140,6 +1240,7 @@ static int chunk_mean_impl(const void* X, int64_t ldx, void* out, int64_t ldo, i
   const bool v1 = vec_ok(X, ldx, D, nvec, sizeof(T)), v2 = vec_ok(out, ldo, D, nvec, sizeof(T));
   if (v1) hipLaunchKernelGGL((chunk_sum_kernel<T, true>), grid, dim3(256), 0, s, (const T*)X, ldx, csum, T_, D, chunk, NC, left, reverse);
   else hipLaunchKernelGGL((chunk_sum_kernel<T, false>), grid, dim3(256), 0, s, (const T*)X, ldx, csum, T_, D, chunk, NC, left, reverse);
+  if (left < 0) hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)B), dim3(256), 0, s, csum, D, NC, reverse);
   if (v2) hipLaunchKernelGGL((chunk_window_kernel<T, true>), grid, dim3(256), 0, s, csum, (T*)out, ldo, T_, D, chunk, NC, left, reverse);
   else hipLaunchKernelGGL((chunk_window_kernel<T, false>), grid, dim3(256), 0, s, csum, (T*)out, ldo, T_, D, chunk, NC, left, reverse);
   return check_launch("smx_chunk_mean");
@@ -1272,6 +1373,8 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
     else if (D <= 512) LN_BWD(4, 2);
     else if (D <= 1024) LN_BWD(4, 4);
     else if (D <= 2048) LN_BWD(4, 8);
+    else if (D <= 3072) hipLaunchKernelGGL((layernorm_bwd_wide4_kernel<T, 3>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D);
+    else if (D <= 4096) hipLaunchKernelGGL((layernorm_bwd_wide4_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D);
     else if (D <= 4096) hipLaunchKernelGGL((layernorm_bwd_wide_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D);
     else return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd: D=%d > 4096", D);
   } else {

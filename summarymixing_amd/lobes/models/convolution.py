@@ -15,6 +15,10 @@ from ... import functional as F
 from ... import ops
 
 
+import os
+_DIRECT_DGRAD = os.environ.get("SMX_CONV_DIRECT_DGRAD", "1") != "0"      # A/B knob: smx_conv2d_s2_dgrad instead of GEMM + col2im
+
+
 class _Conv2dHolder(nn.Module):
     """Key layout of speechbrain.nnet.CNN.Conv2d: ``.conv`` is the nn.Conv2d."""
 
@@ -97,7 +101,9 @@ class ConvolutionFrontEnd(nn.Module):
                 wg = torch.zeros((blk.c_out, blk.kp), dtype=torch.float32, device=h.device)
                 wg[:, :9 * C] = blk.conv.weight.detach().permute(0, 2, 3, 1).reshape(blk.c_out, 9 * C)
                 wgc = ops.cast(wg, dtype)
-                y, _ = F.linear_fwd(col, wgc, blk.conv.bias.detach())                         # (B*T2*F2, Cout)
+                y = ops.linear_k16(col, wgc, blk.conv.bias.detach()) if blk.kp == 16 else None   # first block: 9 taps, VALU
+                if y is None:
+                    y, _ = F.linear_fwd(col, wgc, blk.conv.bias.detach())                     # (B*T2*F2, Cout)
                 yr = y.view(B * T2, F2 * blk.c_out)
                 a, ln_b = F.ln_fwd(yr, blk.norm.weight.view(-1), blk.norm.bias.view(-1), blk.norm.eps, need,
                                    L.ACT_LEAKY_RELU, wp=blk.norm.weight, bp=blk.norm.bias)
@@ -121,15 +127,17 @@ class ConvolutionFrontEnd(nn.Module):
                     dy = ln_b(da).view(B * T2 * F2, blk.c_out)
                     gw = torch.zeros((blk.c_out, blk.kp), dtype=torch.float32, device=dy.device)
                     first = bi == 0
+                    # the second block's input gradient comes from the direct kernel (no (rows, 9 C) gradient matrix, no col2im)
+                    direct = (not first) and _DIRECT_DGRAD and ops.conv2d_s2_dgrad_ok(dy, C, blk.c_out, T_, F_)
                     dcol, _ = F.linear_bwd(dy, col, wgc, None, L.ACT_NONE, None, 1.0, gw, F.gacc(blk.conv.bias),
-                                           need_dx=not first)
+                                           need_dx=not first and not direct)
                     g = F.gacc(blk.conv.weight)                       # fold the GEMM-layout gradient back (9*Cin*Cout values)
                     F.flush_deferred()                                # gw is a temporary: its slab reduction must have run
                     if g is not None:
                         g.add_(gw[:, :9 * C].view(blk.c_out, 3, 3, C).permute(0, 3, 1, 2))
                     if first:
                         return None
-                    d = ops.col2im_s2(dcol, B, T_, F_, C)
+                    d = ops.conv2d_s2_dgrad(dy, wgc, B, T_, F_, C) if direct else ops.col2im_s2(dcol, B, T_, F_, C)
                 return None
             return h, bwd
         return F.block(x, run, list(self.parameters()))

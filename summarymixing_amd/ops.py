@@ -604,6 +604,35 @@ def im2col_s2(x, Kp):
     return col
 
 
+def linear_k16(x, W, bias):
+    """y = x W^T + bias for K = 16 on the VALU (smx_linear_k16_fwd), or None when the shape is not the kernel's."""
+    N, K = x.shape
+    M = W.shape[0]
+    if not (x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and K == 16 and x.is_contiguous() and W.is_contiguous()
+            and M % 8 == 0 and 256 % (M // 8) == 0):
+        return None
+    y = torch.empty((N, M), dtype=x.dtype, device=x.device)
+    tok = _pb(f"linear_k16 ({N}x16)x(16x{M})", N * (K + M) * 2)
+    L.check(L.lib().smx_linear_k16_fwd(dt(x), _p(x), _p(W), _p(bias), _p(y), N, M, _stream()), "smx_linear_k16_fwd")
+    _pe(tok)
+    return y
+
+
+def conv2d_s2_dgrad_ok(dy, C, O, T, F_):
+    """Does the direct dgrad kernel (smx_conv2d_s2_dgrad) take this block?  (bf16, 64 -> 32 channels: the recipe's second)"""
+    return dy.dtype == torch.bfloat16 and C == 64 and O == 32 and T >= 4 and F_ >= 4 and dy.numel() * 2 < (1 << 31)
+
+
+def conv2d_s2_dgrad(dy, wg, B, T, F_, C):
+    """dx (B,T,F,C) of the 3x3 / stride 2 / reflect-pad-1 convolution from dy (B*T2*F2, O) and the GEMM-layout weight."""
+    dx = torch.empty((B, T, F_, C), dtype=dy.dtype, device=dy.device)
+    tok = _pb(f"conv2d_s2_dgrad ({B},{T},{F_},{C})", dx.numel() * 2 + dy.numel() * 2)
+    L.check(L.lib().smx_conv2d_s2_dgrad(dt(dy), _p(dy), _p(wg), _p(dx), B, T, F_, C, dy.shape[1], wg.shape[1], _stream()),
+            "smx_conv2d_s2_dgrad")
+    _pe(tok)
+    return dx
+
+
 def col2im_s2(dcol, B, T, F_, C):
     dx = torch.empty((B, T, F_, C), dtype=dcol.dtype, device=dcol.device)
     L.check(L.lib().smx_col2im_s2(dt(dcol), _p(dcol), _p(dx), B, T, F_, C, dcol.shape[1], _stream()), "smx_col2im_s2")

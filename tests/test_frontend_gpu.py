@@ -117,3 +117,32 @@ def test_input_normalization_matches_spec(norm_type, dtype, tol):
         x = (torch.randn(B, T, F) * 3.0).to(dtype)
         ref = O.input_normalization(x.double(), lens, st, norm_type="global", training=False)
         assert rel_err(mod(x.cuda(), lens.cuda()), ref) <= tol and mod.count == 4
+
+
+@pytest.mark.parametrize("B,T,Fq", [(2, 19, 40), (2, 20, 40), (1, 5, 4), (3, 4, 7), (1, 1001, 40)])
+def test_direct_conv_dgrad_matches_float64_conv_transpose(B, T, Fq):
+    """smx_conv2d_s2_dgrad (the recipe's second block: 64 -> 32 channels, 3x3, stride 2, reflect pad 1) against autograd
+    of the float64 convolution, and against the dgrad GEMM + col2im pair it replaces."""
+    import torch.nn.functional as tF
+    from summarymixing_amd import ops
+    torch.manual_seed(T + Fq)
+    C, O = 64, 32
+    T2, F2 = (T + 1) // 2, (Fq + 1) // 2
+    W = torch.randn(O, C, 3, 3) * 0.1
+    dy = torch.randn(B, T2, F2, O)
+    x = torch.zeros(B, C, T, Fq, dtype=torch.float64, requires_grad=True)
+    Wb = W.bfloat16().double()
+    dyb = dy.bfloat16().double()
+    y = tF.conv2d(tF.pad(x, (1, 1, 1, 1), mode="reflect"), Wb, None, stride=2)            # (B, O, T2, F2)
+    (y * dyb.permute(0, 3, 1, 2)).sum().backward()
+    ref = x.grad.permute(0, 2, 3, 1)                                                       # (B, T, F, C)
+    wg = W.permute(0, 2, 3, 1).reshape(O, 9 * C).cuda().bfloat16().contiguous()            # GEMM layout: column (dt*3+df)*C + c
+    dy2 = dy.cuda().bfloat16().reshape(B * T2 * F2, O).contiguous()
+    assert ops.conv2d_s2_dgrad_ok(dy2, C, O, T, Fq)
+    got = ops.conv2d_s2_dgrad(dy2, wg, B, T, Fq, C)
+    torch.cuda.synchronize()
+    assert rel_err(got, ref) <= 1e-2                             # fp32 accumulation of bf16 products, one bf16 rounding at the end
+    dcol = torch.empty(B * T2 * F2, 9 * C, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(ops.L.GEMM_NN, dy2, wg, dcol, B * T2 * F2, 9 * C, O, ops.epilogue())
+    old = ops.col2im_s2(dcol, B, T, Fq, C)
+    assert rel_err(got, old.float()) <= 2e-2                     # (the old path rounds the 9 C gradient columns to bf16 first)
