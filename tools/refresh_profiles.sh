@@ -1,8 +1,8 @@
 #!/usr/bin/env bash
 # Re-measure everything profiles/ holds for this round (run on the GPU box through gpurun; outputs land in
-# gpurun_out/refresh/, copy them into profiles/ afterwards):  gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02 v2'
+# gpurun_out/refresh/, copy them into profiles/ afterwards):  gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03 v2'
 set -uo pipefail
-R="${1:-r02}"; TAG="${2:-vX}"
+R="${1:-r03}"; TAG="${2:-vX}"
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/refresh"; mkdir -p "$OUT"
 cd "$ROOT"
@@ -14,6 +14,10 @@ python bench.py --config c2a --batch 10 --frames 375 --steps 20 --warmup 5 2>/de
 python bench.py --mode forward --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${R}_bench_fwd.json"
 python bench.py --config c4 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${R}_bench_c4.json"
 python bench.py --config c5 --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/${R}_bench_c5.json"
+python bench.py --dynchunk 8,2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/${R}_bench_dynchunk_8_2.json"
+python bench.py --dynchunk 16 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/${R}_bench_dynchunk_16.json"
+SMX_RESIDUAL=bf16 python bench.py --no-cpu-baseline --no-roofline --no-extra-points 2>/dev/null | tail -1 > "$OUT/${R}_bench_bf16_stream.json"
+python tools/frontend_bench.py "$(python -c "import json;print(json.load(open('$OUT/${R}_bench_default.json'))['ms_per_step'])")" > "$OUT/${R}_frontend.txt" 2>/dev/null
 prof() {  # name, header, command...
   local name="$1" hdr="$2"; shift 2
   (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_refresh && rocprofv3 --kernel-trace --stats -d /tmp/prof_refresh -o p -- "$@" > /dev/null 2>&1)
@@ -22,6 +26,11 @@ prof() {  # name, header, command...
 }
 STEPS=7 prof "${R}_step_c2b_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline   (7 steps incl. warmup; C2b, B=128 x T=500, bf16, dropout 0.15)" python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
 STEPS=7 prof "${R}_step_c4_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --config c4 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline   (7 steps; C4 Branchformer, B=128 x T=250)" python "$ROOT/bench.py" --config c4 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
+STEPS=7 prof "${R}_step_c2a_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --config c2a --steps 5 --warmup 2 --no-cpu-baseline --no-roofline   (7 steps; C2a Conformer d=512 f=2048, B=128 x T=500)" python "$ROOT/bench.py" --config c2a --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
+STEPS=7 prof "${R}_fwd_c5_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline   (7 forward passes; C5 12-layer stack, 8 x 30000 x 512)" python "$ROOT/bench.py" --config c5 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
+STEPS=25 prof "${R}_step_c2a_recipe_batch_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --config c2a --batch 10 --frames 375 --steps 20 --warmup 5   (25 steps; the recipe's batch of 150 s: 3750 frames, hipGraph replay)" python "$ROOT/bench.py" --config c2a --batch 10 --frames 375 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline
+STEPS=7 prof "${R}_step_c2b_dynchunk_8_2_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --dynchunk 8,2 --steps 5 --warmup 2   (7 steps; C2b with DynChunk chunk 8, left context 2 chunks)" python "$ROOT/bench.py" --dynchunk 8,2 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
+STEPS=1 prof "${R}_frontend_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python tools/frontend_bench.py   (waveform -> fbank -> InputNormalization -> CNN fwd / fwd+bwd at B = 128 x 20 s; per-call averages are the figures, the 'step' total covers all timed repetitions)" python "$ROOT/tools/frontend_bench.py"
 STEPS=8 prof "${R}_wgrad_group_isolated.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 layer   (8 launches: the 8 weight gradients of a C2b layer, 64000 frames, isolated back to back; algorithmic 983 + 1.4 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 layer
 STEPS=8 prof "${R}_wgrad_group_one_1024x256.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 one   (8 launches: dW(1024x256) alone over 64000 frames; algorithmic 164.9 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 one
 bash tools/pmc_traffic.sh > "$OUT/${R}_pmc_traffic.txt" 2>&1
