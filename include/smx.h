@@ -100,15 +100,12 @@ typedef struct smx_epilogue {
   /* fp32 residual stream (torch autocast semantics: Linear I/O in bf16, the residual adds and LayerNorm inputs in fp32 -
    * Conformer.py:507,530,532-536): SMX_IO_RES_F32 = `res` is float32 (needs out_mode SMX_OUT_F32: C is the new stream
    * tensor); SMX_IO_LNX_F32 = `ln_x` (SMX_EPI_LN_BWD) is float32.  lnf_y is dtype T (the next GEMM's input) unless
-   * SMX_IO_LNFY_F32 (the LayerNorm output is itself the stream: the layer-final norm2, Conformer.py:536).
-   * SMX_IO_Z_DACT: the z buffer carries act'(pre-activation) instead of the pre-activation - written so by the forward
-   * (the transcendental is shared with act()), multiplied as is by SMX_EPI_ACT_GRAD: no exp / rcp per element in the
-   * backward epilogue, same bytes.  For layers whose saved z has no other reader (the FFN up-projection). */
+   * SMX_IO_LNFY_F32 (the LayerNorm output is itself the stream: the layer-final norm2, Conformer.py:536). */
   int32_t io_flags;    int32_t pad_;
   /* device step counter mixed into this call's fused dropout seed (see smx_step_counter_add), or NULL */
   const uint64_t* epoch;
 } smx_epilogue;
-enum { SMX_IO_RES_F32 = 1, SMX_IO_LNX_F32 = 2, SMX_IO_LNFY_F32 = 4, SMX_IO_Z_DACT = 8 };
+enum { SMX_IO_RES_F32 = 1, SMX_IO_LNX_F32 = 2, SMX_IO_LNFY_F32 = 4 };
 /* flags.  SMX_EPI_ACT_GRAD turns the epilogue into the BACKWARD of an upstream activation layer: z is then a
  * read-only INPUT (the pre-activation the forward saved) and
  *   C[n,m] = alpha * dropout(v * act'(z[n,m])) * row_mask[n]

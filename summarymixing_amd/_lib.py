@@ -19,7 +19,7 @@ EPI_C0_POST = 1
 EPI_ACT_GRAD = 2
 EPI_LN_BWD = 4
 EPI_LN_FWD = 8
-IO_RES_F32, IO_LNX_F32, IO_LNFY_F32, IO_Z_DACT = 1, 2, 4, 8
+IO_RES_F32, IO_LNX_F32, IO_LNFY_F32 = 1, 2, 4
 PAD_ZERO, PAD_REFLECT = 0, 1
 ACTS = {"none": ACT_NONE, "identity": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH,
         "leaky_relu": ACT_LEAKY_RELU, "relu": ACT_RELU}

@@ -851,8 +851,6 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   }
   // the vector kernels take whole 16-byte items in the epilogue as well (no per-element guards anywhere)
   vec = vec && p.epi_lds && M % (int)(16 / cs) == 0;
-  if (p.e.io_flags & SMX_IO_Z_DACT)
-    SMX_REQUIRE(p.e.z && !(p.e.flags & SMX_EPI_LN_BWD), "smx_gemm: SMX_IO_Z_DACT needs z and no SMX_EPI_LN_BWD");
   if (p.e.flags & SMX_EPI_ACT_GRAD)
     SMX_REQUIRE(p.e.z && !p.e.res && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
                 "smx_gemm: SMX_EPI_ACT_GRAD needs z (input), no residual, batch == 1, splits == 1");
@@ -884,7 +882,7 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   // at 64000 frames: bias-only K=256 -> M=1024 102 -> 77 us, NN+bias 91 -> 71 us, but bias+Swish+Z 99 -> 99 us; training
   // steps unchanged with either setting, forward-only steps -2 % (C2b) / -4 % (C5)
   const int reg_epi_env = cfg().reg_epi;
-  p.reg_epi = reg_epi_env && (reg_epi_env != 2 || p.e.z == nullptr) && !(p.e.io_flags & SMX_IO_Z_DACT) && dtype == SMX_BF16 && p.e.out_mode == SMX_OUT_T && !p.e.res && !p.e.c0 && !p.e.colsum &&
+  p.reg_epi = reg_epi_env && (reg_epi_env != 2 || p.e.z == nullptr) && dtype == SMX_BF16 && p.e.out_mode == SMX_OUT_T && !p.e.res && !p.e.c0 && !p.e.colsum &&
               !(p.e.flags & SMX_EPI_ACT_GRAD) && splits == 1 && p.epi_lds && M % 8 == 0 &&
               (p.e.z == nullptr || (aligned16(p.e.z) && p.e.ldz % 8 == 0)) && aligned16(C) && ldc % 8 == 0 && strideC % 8 == 0;
   const int simple_env = cfg().epi_simple;

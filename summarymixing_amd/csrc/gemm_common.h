@@ -288,29 +288,6 @@ __device__ __forceinline__ void act_fwd_n(float (&v)[CW]) {
 #pragma unroll
   for (int q = 0; q < CW; ++q) v[q] = act_fwd_c<ACT>(v[q]);
 }
-// v <- act(v), d <- act'(v) with the transcendental shared (SMX_IO_Z_DACT: the forward saves act'(z) in place of z, the
-// act-grad dgrad then only multiplies - no exp / rcp per element in the backward epilogue)
-template <int ACT>
-__device__ __forceinline__ void act_fwd_dact_c(float& v, float& d) {
-  if constexpr (ACT == SMX_ACT_GELU) {
-    float e;
-    const float erfv = gelu_parts(v, e);
-    const float h = 0.5f * (1.0f + erfv);
-    d = h + v * (0.39894228040143267794f * e);
-    v = v * h;
-  } else if constexpr (ACT == SMX_ACT_SWISH) {
-    const float s = sigmoidf_(v);
-    d = s * (1.0f + v * (1.0f - s));
-    v = v * s;
-  } else if constexpr (ACT == SMX_ACT_LEAKY_RELU) { d = v >= 0.f ? 1.f : 0.01f; v = v * d; }
-  else if constexpr (ACT == SMX_ACT_RELU) { d = v > 0.f ? 1.f : 0.f; v = v * d; }
-  else d = 1.f;
-}
-template <int ACT, int CW>
-__device__ __forceinline__ void act_fwd_dact_n(float (&v)[CW], float (&d)[CW]) {
-#pragma unroll
-  for (int q = 0; q < CW; ++q) act_fwd_dact_c<ACT>(v[q], d[q]);
-}
 template <int ACT, int CW>
 __device__ __forceinline__ void act_grad_mul_n(float (&v)[CW], const float (&z)[CW]) {
 #pragma unroll
@@ -396,7 +373,6 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
   const float* mkrow = side + TILE_M + ph * WN;
   char* Cb = reinterpret_cast<char*>(p.C) + ((long)bz * p.sC + (long)split * p.sSplit) * OSZ;
   const bool ag = SIMPLE != 1 && (e.flags & SMX_EPI_ACT_GRAD) != 0;     // z is an input: multiply by act'(z)
-  const bool zd = (e.io_flags & SMX_IO_Z_DACT) != 0;                    // z holds / receives act'(pre-activation), not the pre-activation
   const bool c0post = !SIMPLE && (e.flags & SMX_EPI_C0_POST) != 0;
   const bool has_c0 = !SIMPLE && e.c0_mode != SMX_C0_NONE;
   const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
@@ -505,10 +481,6 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
 #pragma unroll
           for (int q = 0; q < SW; ++q) w_[q] = sw[k][q];
           unpack_words<T, CW>(w_, zf); }
-        if (zd) {                                          // z holds act'(pre-activation) already
-#pragma unroll
-          for (int q = 0; q < CW; ++q) v[q] *= zf[q];
-        } else
         switch (e.act) {
           case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, CW>(v, zf); break;
           case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, CW>(v, zf); break;
@@ -516,16 +488,6 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
           case SMX_ACT_RELU: act_grad_mul_n<SMX_ACT_RELU, CW>(v, zf); break;
           default: break;
         }
-      } else if (Zb && zd) {                               // forward, saving act'(z) in place of z
-        float dz_[CW];
-        switch (e.act) {
-          case SMX_ACT_GELU: act_fwd_dact_n<SMX_ACT_GELU, CW>(v, dz_); break;
-          case SMX_ACT_SWISH: act_fwd_dact_n<SMX_ACT_SWISH, CW>(v, dz_); break;
-          case SMX_ACT_LEAKY_RELU: act_fwd_dact_n<SMX_ACT_LEAKY_RELU, CW>(v, dz_); break;
-          case SMX_ACT_RELU: act_fwd_dact_n<SMX_ACT_RELU, CW>(v, dz_); break;
-          default: act_fwd_dact_n<SMX_ACT_NONE, CW>(v, dz_); break;
-        }
-        if (p.nt & 1) st_elems_nt<T, CW>(Zb + (long)n * e.ldz + m, dz_); else st_elems<T, CW>(Zb + (long)n * e.ldz + m, dz_);
       } else {
         if (Zb) { if (p.nt & 1) st_elems_nt<T, CW>(Zb + (long)n * e.ldz + m, v); else st_elems<T, CW>(Zb + (long)n * e.ldz + m, v); }
         switch (e.act) {
@@ -586,10 +548,9 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
         float v = sf[r * (STG_LD / 4) + c + q] + side[c + q];
         if (c0p && !c0post) v += c0p[q];
         if (ag) {
-          const float zq = to_f32(Sb[(long)n * lds_ + m + q]);
-          v *= zd ? zq : act_grad(e.act, zq);
+          v *= act_grad(e.act, to_f32(Sb[(long)n * lds_ + m + q]));
         } else {
-          if (Zb) Zb[(long)n * e.ldz + m + q] = from_f32<T>(zd ? act_grad(e.act, v) : v);
+          if (Zb) Zb[(long)n * e.ldz + m + q] = from_f32<T>(v);
           v = act_fwd(e.act, v);
         }
         if (dthresh && m + q < p.drop_cols) v = dropout_keep(dseed, (uint64_t)n * p.drop_cols + m + q, dthresh) ? v * dscale : 0.f;

@@ -301,12 +301,11 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
         ln_post.append((hy, st))
     e = ops.epilogue(bias=bias, c0=c0, c0_mode=c0_mode, c0_div=c0_div, act=act, z=z, row_mask=mask, res=res,
                      alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post, ln_fwd=lnf,
-                     drop_cols=drop_cols, z_dact=(save_z == "dact"))
+                     drop_cols=drop_cols)
     ops.gemm(L.GEMM_NT, x, W, out, N, M, K, e)
     return out, z
 
 
-_Z_DACT = os.environ.get("SMX_Z_DACT", "1") != "0"     # A/B knob: the FFN saves act'(z) instead of z (SMX_IO_Z_DACT)
 _LN_FUSE = os.environ.get("SMX_LN_FUSE", "1") != "0"   # A/B knob: LayerNorm backward / forward inside the GEMM epilogues
 
 
@@ -370,9 +369,8 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
             return ((dx, dx2) if ln_second is not None else dx), dz
         if up is not None:
             assert res_grad is None
-            z_up, act_up, mask_up, alpha_up, drop_up, gb_up = up[:6]
-            e = ops.epilogue(act=act_up, act_grad_z=z_up, row_mask=mask_up, alpha=alpha_up, drop=drop_up, colsum=gb_up,
-                             z_dact=len(up) > 6 and up[6])
+            z_up, act_up, mask_up, alpha_up, drop_up, gb_up = up
+            e = ops.epilogue(act=act_up, act_grad_z=z_up, row_mask=mask_up, alpha=alpha_up, drop=drop_up, colsum=gb_up)
         else:
             assert dx_drop is None or res_grad is None
             e = ops.epilogue(res=res_grad, drop=dx_drop)
@@ -872,9 +870,7 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
     W1, W2 = wcast(P["W1"], dtype), wcast(P["W2"], dtype)
     d1 = (p, ops.new_dropout_seed()) if p > 0.0 else None       # both dropouts are fused into the GEMM epilogues
     d2 = (p, ops.new_dropout_seed()) if p > 0.0 else None
-    # z1 has ONE reader, the second Linear's act-grad dgrad: save act'(z1) in its place (SMX_IO_Z_DACT: the sigmoid / erf is
-    # computed once, in the forward epilogue; the backward epilogue only multiplies)
-    a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=("dact" if _Z_DACT else True) if need_bwd else False, drop=d1)
+    a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1)
     post = []
     lnn = ((ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) + tuple(ln_next[3:4])) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x)) else None
     y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2, ln_next=lnn, ln_post=post)
@@ -888,10 +884,10 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
         # the second Linear's dgrad epilogue applies D1 and act'(z1): it emits dZ1 directly; db1 comes out of W1's wgrad
         if dz_in is not None:
             dz1, _ = linear_bwd(dz_in, a, W2, None, L.ACT_NONE, None, 1.0, gacc(P["W2"]), gacc(P["b2"]), dz_ready=True,
-                                up=(z1, act, None, 1.0, d1, None, _Z_DACT))
+                                up=(z1, act, None, 1.0, d1, None))
         else:
             dz1, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2,
-                                up=(z1, act, None, 1.0, d1, None, _Z_DACT))
+                                up=(z1, act, None, 1.0, d1, None))
         if ln_fusable(ln_b.spec, h.shape[0], h.shape[1], dtype, W1.shape[0], W1):     # the LayerNorm backward rides in the dgrad epilogue
             out, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True, res_grad=dy,
                                 ln=ln_b.spec, ln_second=second)

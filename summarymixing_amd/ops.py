@@ -91,9 +91,8 @@ def rows2d(x):
 
 def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, out_mode=L.OUT_T, z=None,
              row_mask=None, res=None, alpha=1.0, bias_batch_stride=0, drop=None, c0_post=False, act_grad_z=None,
-             colsum=None, ln_bwd=None, ln_fwd=None, drop_cols=0, z_dact=False):
-    """Build an smx_epilogue.  z_dact: the z buffer carries act'(pre-activation) instead of the pre-activation
-    (SMX_IO_Z_DACT; pass it to the forward that writes z AND to the act_grad_z call that reads it).  act_grad_z: the saved pre-activation of the UPSTREAM layer (SMX_EPI_ACT_GRAD: the GEMM
+             colsum=None, ln_bwd=None, ln_fwd=None, drop_cols=0):
+    """Build an smx_epilogue.  act_grad_z: the saved pre-activation of the UPSTREAM layer (SMX_EPI_ACT_GRAD: the GEMM
     then emits alpha * D(acc * act'(z)) * mask, i.e. the upstream dZ); colsum: fp32 [M] accumulator of the output's
     column sums (the upstream bias gradient), workspace attached by gemm()."""
     e = L.Epilogue()
@@ -106,8 +105,6 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         e.c0 = c0.data_ptr()
         e.c0_mode, e.c0_div = c0_mode, c0_div
     e.act, e.out_mode = act, out_mode
-    if z_dact and (z is not None or act_grad_z is not None):
-        e.io_flags |= L.IO_Z_DACT
     if z is not None:
         e.z, e.ldz = z.data_ptr(), _mat(z)[1]
     if row_mask is not None:
