@@ -33,6 +33,9 @@ STEPS=7 prof "${R}_step_c2b_dynchunk_8_2_${TAG}.txt" "rocprofv3 --kernel-trace -
 STEPS=1 prof "${R}_frontend_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python tools/frontend_bench.py   (waveform -> fbank -> InputNormalization -> CNN fwd / fwd+bwd at B = 128 x 20 s; per-call averages are the figures, the 'step' total covers all timed repetitions)" python "$ROOT/tools/frontend_bench.py"
 STEPS=8 prof "${R}_wgrad_group_isolated.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 layer   (8 launches: the 8 weight gradients of a C2b layer, 64000 frames, isolated back to back; algorithmic 983 + 1.4 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 layer
 STEPS=8 prof "${R}_wgrad_group_one_1024x256.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 one   (8 launches: dW(1024x256) alone over 64000 frames; algorithmic 164.9 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 one
-bash tools/pmc_traffic.sh > "$OUT/${R}_pmc_traffic.txt" 2>&1
-bash tools/pmc_wgroup.sh layer > "$OUT/${R}_pmc_wgrad_group.txt" 2>&1
+# counter passes last and only on request (PMC=1): after them the box has been seen to lose its device for the next process
+if [[ "${PMC:-0}" == "1" ]]; then
+  bash tools/pmc_traffic.sh > "$OUT/${R}_pmc_traffic.txt" 2>&1
+  bash tools/pmc_wgroup.sh layer > "$OUT/${R}_pmc_wgrad_group.txt" 2>&1
+fi
 ls -la "$OUT"
