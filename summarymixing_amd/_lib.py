@@ -149,6 +149,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or bash summarymixing_amd/csrc/build.sh). summarymixing_amd has no fallback path.")
+        # torch first: libsmx.so needs libamdhip64.so, and the process must end up with ONE HIP runtime - the one torch
+        # ships and initialises.  Loaded the other way round (libsmx pulling /opt/rocm's copy in before `import torch`), the
+        # library's launches fail with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   // The 64 x 64 tile runs when the grid is too small to fill the chip with big tiles (the recipe batch of 3750 frames:
   // 472 workgroups, ~2 per CU): nothing hides a workgroup's own round trips there, one stage in flight cost 0.6 us per
   // K tile (17 - 20 us for K = 2048).  Its 16 accumulator registers leave room for 4 stages (64 registers).
-  constexpr int NS = A_KC ? ((TILE_N == 64 && TILE_M == 64) ? SMX_NS_SMALL : SMX_NS_KC)
+  constexpr int NS = A_KC ? ((TILE_N == 64 && TILE_M == 64) ? SMX_NS_SMALL : (TILE_M > 128 ? 1 : SMX_NS_KC))
                           : (TILE_M > 128 ? 1 : 2);              // (two stages of a 128x256 tile pair would spill)
   uint4 ra[NS][TILE_N / 32], rb[NS][TILE_M / 32];
 #pragma unroll
