@@ -586,3 +586,27 @@ def test_gemm_epilogue_layernorm_backward_with_activations():
     assert rel_err(dx, ref) < 1e-2
     assert rel_err(dx2, ref * dswish(z2.double())) < 1.5e-2
     assert rel_err(partial[:, 0].sum(0), (g * xh).sum(0)) < 2e-3 and rel_err(partial[:, 1].sum(0), g.sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("chunk", [4, 8, 16])
+def test_chunked_dwconv_backward_is_bit_reproducible(chunk):
+    """Dynamic Chunk Convolution in the rolling kernels: per-wave partial tap gradients reduced in a fixed order - two runs
+    on the same inputs give bit-identical dP, dW and dbias (no atomics), at D = 256, k = 31 (the Conformer shape)."""
+    L, ops = _ops()
+    torch.manual_seed(chunk)
+    B, T, D, k = 8, 500, 256, 31
+    p = torch.randn(B * T, 2 * D, device="cuda").bfloat16()
+    dy = torch.randn(B * T, D, device="cuda").bfloat16()
+    w = torch.randn(D, k, device="cuda") * 0.3
+    bias = torch.randn(D, device="cuda")
+    outs = []
+    for _ in range(2):
+        dw, db = torch.zeros(D, k, device="cuda"), torch.zeros(D, device="cuda")
+        dp, _ = ops.dwconv_bwd(dy, p, w, bias, dw, db, B, T, D, k, True, L.PAD_ZERO, chunk)
+        torch.cuda.synchronize()
+        outs.append((dp.clone(), dw.clone(), db.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    y1 = ops.dwconv_fwd(p, w, bias, B, T, D, k, True, L.PAD_ZERO, chunk).clone()
+    y2 = ops.dwconv_fwd(p, w, bias, B, T, D, k, True, L.PAD_ZERO, chunk)
+    assert torch.equal(y1, y2)
