@@ -64,10 +64,13 @@ typedef struct smx_config {
   int32_t dwroll;           /* SMX_DWROLL: rolling register-window depthwise conv (1)                        */
   int32_t dwroll_csgu;      /* SMX_DWROLL_CSGU: ... for the CSGU form (1)                                    */
   int32_t dwroll_seg;       /* SMX_DWROLL_SEG: frames per wave segment (0 = auto)                            */
+  int32_t ln_tile_rows;     /* rows of the LayerNorm-fused GEMM tile (128; see smx_gemm_ln_tile_rows)        */
   int32_t gemm_ablate, wgroup_ablate, dwroll_ablate;   /* SMX_DIAG builds only                                  */
   int32_t diag_build;       /* 1 when the library was compiled with -DSMX_DIAG                               */
 } smx_config;
 int smx_get_config(smx_config* out);
+/* rows per tile of the LayerNorm-fused GEMMs (SMX_EPI_LN_BWD writes ceil(N / rows) partial row pairs into ln_partial) */
+int smx_gemm_ln_tile_rows(void);
 
 /* Epilogue of the fused projection GEMM:
  *   v      = acc + bias[m] + C0[map(n), m]
@@ -92,7 +95,7 @@ typedef struct smx_epilogue {
   /* SMX_EPI_LN_BWD: the GEMM output is the gradient of a LayerNorm's OUTPUT (M = the LayerNorm width) */
   const void* ln_x;    int64_t ln_ldx;                    /* the LayerNorm input (N, M), dtype T                       */
   const float* ln_stats; const float* ln_gamma;           /* (N, 2) mean | rstd of the forward; [M]                    */
-  float* ln_partial;                                      /* [ceil(N/128)][2][M] per-tile dgamma | dbeta partial rows  */
+  float* ln_partial;                                      /* [ceil(N/smx_gemm_ln_tile_rows())][2][M] per-tile dgamma | dbeta partial rows */
   void* ln_dx2;        int64_t ln_lddx2;                  /* optional second output (see smx_layernorm_bwd2) or NULL   */
   const uint8_t* ln_mask2; float ln_alpha2; float ln_drop_p2; uint64_t ln_drop_seed2;
   /* SMX_EPI_LN_FWD: a LayerNorm of the (row-complete) output: lnf_y = act(LN(C)), lnf_stats = (mean, rstd) per row */

@@ -132,6 +132,7 @@ SIGNATURES = {
     "smx_ctc_loss_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_i64, c_vp,
                                c_vp]),
     "smx_get_config": (c_i, [c_vp]),
+    "smx_gemm_ln_tile_rows": (c_i, []),
     "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
     "smx_sumsq_workspace": (c_sz, []),
     "smx_sumsq": (c_i, [c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -167,7 +168,7 @@ class Config(ctypes.Structure):
                 ("nt_bytes", ctypes.c_int64), ("reg_epi", ctypes.c_int32), ("epi_simple", ctypes.c_int32),
                 ("wgrad_blocks", ctypes.c_int32), ("wgrad_min_rows", ctypes.c_int32), ("pool_blocks", ctypes.c_int32),
                 ("wgroup_blocks", ctypes.c_int32), ("wgroup_bk", ctypes.c_int32), ("wgroup_pp", ctypes.c_int32),
-                ("dwroll", ctypes.c_int32), ("dwroll_csgu", ctypes.c_int32), ("dwroll_seg", ctypes.c_int32),
+                ("dwroll", ctypes.c_int32), ("dwroll_csgu", ctypes.c_int32), ("dwroll_seg", ctypes.c_int32), ("ln_tile_rows", ctypes.c_int32),
                 ("gemm_ablate", ctypes.c_int32), ("wgroup_ablate", ctypes.c_int32), ("dwroll_ablate", ctypes.c_int32),
                 ("diag_build", ctypes.c_int32)]
 

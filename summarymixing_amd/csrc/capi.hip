@@ -51,6 +51,7 @@ const smx_config& cfg() {
     { const char* e = getenv("SMX_DWROLL"); k.dwroll = (e && e[0] == '0') ? 0 : 1; }
     { const char* e = getenv("SMX_DWROLL_CSGU"); k.dwroll_csgu = (e && e[0] == '0') ? 0 : 1; }
     k.dwroll_seg = env_i("SMX_DWROLL_SEG", 0);
+    k.ln_tile_rows = 128;
 #ifdef SMX_DIAG
     k.gemm_ablate = env_i("SMX_GEMM_ABLATE", 0);
     k.wgroup_ablate = env_i("SMX_WGROUP_ABLATE", 0);
@@ -75,5 +76,6 @@ extern "C" int smx_get_config(smx_config* out) {
   *out = smx::cfg();
   return SMX_OK;
 }
+extern "C" int smx_gemm_ln_tile_rows(void) { return smx::cfg().ln_tile_rows; }
 extern "C" int smx_version(void) { return SMX_VERSION; }
 extern "C" const char* smx_last_error(void) { return smx::last_error_buf(); }

@@ -179,9 +179,12 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
                           : (TILE_M > 128 ? 1 : 2);              // (two stages of a 128x256 tile pair would spill)
   uint4 ra[NS][TILE_N / 32], rb[NS][TILE_M / 32];
 #pragma unroll
-  for (int s_ = 0; s_ < NS; ++s_)
+  for (int s_ = 0; s_ < NS; ++s_) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[s_][i] = rb[s_][i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < TILE_N / 32; ++i) ra[s_][i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TILE_M / 32; ++i) rb[s_][i] = make_uint4(0, 0, 0, 0);
+  }
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_) {
     const int kk = kbeg + s_ * BK;
@@ -731,6 +734,9 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
       // (the forward variant may write the new fp32 stream tensor: SMX_OUT_F32; the backward variants emit dtype T)
       if (vec && p.M == 256 && p.N >= 128 && p.splits == 1 && p.batch == 1 && !p.e.colsum &&
           (p.e.out_mode == SMX_OUT_T || (!lnb && p.e.out_mode == SMX_OUT_F32))) {
+        // (a 64 x 256 variant - twice the workgroups, two K tiles in flight each - was built and measured in round 3: correct,
+        //  but 21.1-21.3 ms against 19.9 ms for the C2b step: the weight panel is re-read per 64 rows and the MFMA-per-LDS-read
+        //  ratio halves; the instantiations were removed again)
         p.tiles_n = (p.N + 127) / 128;
         p.tiles_m = 1;
         const bool ext = lnb && (p.e.lnf_act != SMX_ACT_NONE || p.e.z);
@@ -783,7 +789,7 @@ static int launch_dtype(int layout, GemmParams& p, bool vec, hipStream_t s) {
 
 using namespace smx;
 
-long long* g_dbg_stamps = nullptr;   // (also read by ffn.hip)
+long long* g_dbg_stamps = nullptr;   // (tools/gemm_stamps.py; the parked tools/experiments/ffn_fused kernel reads it too)
 extern "C" void smx_debug_set_timing_buffer(void* p) { g_dbg_stamps = reinterpret_cast<long long*>(p); }
 
 static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,

@@ -383,7 +383,7 @@ def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=N
     pg, ldg = (_mat(gate) if gate is not None else (None, 0))
     tok = _pb(f"dwconv_fwd ({B},{T},{D}) k={k}", 3 * B * T * D * _es(p))
     fused = False
-    if drop is not None and drop[0] > 0.0 and os.environ.get("SMX_CSGU_DROP_FUSE", "1") != "0":
+    if drop is not None and drop[0] > 0.0 and _CSGU_DROP_FUSE:
         fused = L.lib().smx_dwconv1d_glu_fwd_drop(dt(p), pp, ldp, _p(w), _p(bias), pg, ldg, _p(y), D, B, T, D, k, 1 if glu else 0,
                                                   pad_mode, chunk, drop[0], drop[1], _epoch(), _stream()) == 0
     if not fused:
@@ -544,6 +544,7 @@ def ctc_bwd(lp2, targets, in_len, tgt_len, B, T, blank, nll, gscale, ws):
     return g
 
 
+_CSGU_DROP_FUSE = os.environ.get("SMX_CSGU_DROP_FUSE", "1") != "0"     # (read once, like the library's own knobs)
 _STEP_COUNTER = None          # the training loop's device step counter (held HERE, in the Python host; libsmx has no such state)
 
 

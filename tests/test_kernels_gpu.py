@@ -511,7 +511,8 @@ def test_gemm_epilogue_layernorm_backward(N, K):
     mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
     rstd = (var + 1e-5).rsqrt()
     stats = torch.cat([mean, rstd], 1).float().contiguous()
-    ntile = (N + 127) // 128
+    tr = L.lib().smx_gemm_ln_tile_rows()
+    ntile = (N + tr - 1) // tr
     partial = torch.zeros(ntile, 2, D, device="cuda")
     dx, dx2 = torch.empty(N, D, device="cuda", dtype=torch.bfloat16), torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
     e = ops.epilogue(res=res, ln_bwd=(x, stats, gamma, partial, dx2, (0.5, mask, None)))
@@ -571,7 +572,8 @@ def test_gemm_epilogue_layernorm_backward_with_activations():
     mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
     rstd = (var + 1e-5).rsqrt()
     stats = torch.cat([mean, rstd], 1).float().contiguous()
-    partial = torch.zeros((N + 127) // 128, 2, D, device="cuda")
+    tr = L.lib().smx_gemm_ln_tile_rows()
+    partial = torch.zeros((N + tr - 1) // tr, 2, D, device="cuda")
     dx, dx2 = torch.empty(N, D, device="cuda", dtype=torch.bfloat16), torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
     e = ops.epilogue(ln_bwd=(x, stats, gamma, partial, dx2, (1.0, None, None, z2, L.ACT_SWISH), (beta, L.ACT_SWISH)))
     ops.gemm(L.GEMM_NN, dz, W, dx, N, D, K, e)
