@@ -37,9 +37,11 @@ __global__ __launch_bounds__(256) void frame_window_kernel(const float* __restri
 __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S, long lds, int im_off, const float* __restrict__ fb,
                                                      int n_bins, int n_mels, float amin, float* __restrict__ db,
                                                      float* __restrict__ bmax, int N_) {
-  extern __shared__ float pw[];                        // 4 x n_bins
+  extern __shared__ float pw[];                        // 4 x n_bins power rows | n_mels x MELW filter bands
+  constexpr int MELW = 48;                             // widest band kept in LDS (n_fft = 512, 80 mels: <= 27 bins); longer tails read global
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* P = pw + w * n_bins;
+  float* band = pw + 4 * n_bins;
   constexpr int MPL = 4;                               // filters per lane (n_mels <= 256)
   int lo[MPL], hi[MPL];
 #pragma unroll
@@ -50,8 +52,13 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S
       const float* fr = fb + (long)m * n_bins;
       for (int f = 0; f < n_bins; ++f)
         if (fr[f] != 0.f) { lo[k] = min(lo[k], f); hi[k] = f + 1; }
+      // the band's weights are the same for every frame: once into LDS (a global load per tap and frame made this kernel
+      // latency-bound: 845 us for 256 000 frames)
+      if (w == 0)
+        for (int j = 0; j < MELW; ++j) band[m * MELW + j] = (lo[k] + j < hi[k]) ? fr[lo[k] + j] : 0.f;
     }
   }
+  __syncthreads();
   for (int n = blockIdx.x * 4 + w; n < N_; n += gridDim.x * 4) {
     const float* s = S + (long)n * lds;
     for (int f = lane; f < n_bins; f += 64) { const float re = s[f], im = s[im_off + f]; P[f] = re * re + im * im; }
@@ -62,9 +69,14 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S
       const int m = lane + 64 * k;
       if (m < n_mels) {
         const float* fr = fb + (long)m * n_bins;
-        float a = 0.f;
-        for (int f = lo[k]; f < hi[k]; ++f) a += P[f] * fr[f];
-        db[(long)n * n_mels + m] = 10.f * log10f(fmaxf(a, amin));
+        const float* bw = band + m * MELW;
+        const int wdt = hi[k] - lo[k], wl = min(wdt, MELW);
+        float a0 = 0.f, a1 = 0.f;
+        int j = 0;
+        for (; j + 1 < wl; j += 2) { a0 += P[lo[k] + j] * bw[j]; a1 += P[lo[k] + j + 1] * bw[j + 1]; }
+        if (j < wl) a0 += P[lo[k] + j] * bw[j];
+        for (int f = lo[k] + MELW; f < hi[k]; ++f) a1 += P[f] * fr[f];
+        db[(long)n * n_mels + m] = 10.f * log10f(fmaxf(a0 + a1, amin));
       }
     }
     __builtin_amdgcn_wave_barrier();                     // (P is rewritten by the next frame)
@@ -384,7 +396,7 @@ extern "C" int smx_mel_db(int out_dtype, const float* spec, int64_t lds, int im_
   SMX_REQUIRE(n_mels <= 256, "smx_mel_db: n_mels=%d > 256", n_mels);
   int mblocks = (N + 3) / 4;
   if (mblocks > 2048) mblocks = 2048;
-  hipLaunchKernelGGL(mel_db_kernel, dim3(mblocks), dim3(256), 4 * n_bins * sizeof(float), STREAM, spec, lds, im_off, fb, n_bins,
+  hipLaunchKernelGGL(mel_db_kernel, dim3(mblocks), dim3(256), (4 * n_bins + n_mels * 48) * sizeof(float), STREAM, spec, lds, im_off, fb, n_bins,
                      n_mels, amin, db, bmax, N);
   hipLaunchKernelGGL(utt_max_kernel, dim3(B), dim3(256), 0, STREAM, db, T, n_mels, umax);
   const long total = (long)N * n_mels;
