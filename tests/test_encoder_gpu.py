@@ -171,3 +171,42 @@ def test_conformer_encoder_vs_oracle_mid_size(dtype):
         y, _ = enc.cuda()(x.cuda().to(dtype), src_key_padding_mask=pad.cuda())
     tol = 1e-3 if dtype == torch.float32 else 1e-2
     assert rel_err(y, ref) <= tol, rel_err(y, ref)
+
+
+@pytest.mark.parametrize("chunk,left", [(8, 2), (13, None), (16, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conformer_encoder_dynchunk_at_width_vs_oracle(dtype, chunk, left):
+    """DynChunk training batch at the benchmarked width (d = 256, k = 31: Dynamic Chunk Convolution in the rolling kernels,
+    chunked summary means with limited / unlimited left context): forward and dL/dx against the fp64 oracle."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd import functional as F
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    from summarymixing_amd.utils.dynamic_chunk_training import DynChunkTrainConfig
+    torch.manual_seed(chunk)
+    B, T, d = 3, 150, 256
+    enc = ConformerEncoder(2, d, 512, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast")
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+            elif "bias" in n:
+                p.normal_(0, 0.05)
+    sd = {k: v.double() for k, v in enc.state_dict().items()}
+    x = torch.randn(B, T, d)
+    lens = torch.tensor([T, 61, 133])
+    pad = torch.arange(T)[None] < lens[:, None]
+    cfg = DynChunkTrainConfig(chunk, left)
+    sm = F.DynChunkMask(T, chunk, left)
+    xr = x.double().requires_grad_(True)
+    dense = O.dynchunk_sum_mask(T, chunk, left)                 # the reference's (T, T) mask (TransformerASR.py:85-110)
+    assert torch.equal(dense, sm.dense("cpu"))
+    ref = O.conformer_encoder(xr, sd, "", "swish", "SummaryMixing-fast", d, dense, pad, chunk)
+    r = torch.randn(B, T, d)
+    (ref * r.double()).sum().backward()
+    xg = x.cuda().to(dtype).requires_grad_(True)
+    y, _ = enc.cuda()(xg, src_mask=sm, src_key_padding_mask=pad.cuda(), dynchunktrain_config=cfg)
+    (y.float() * r.cuda()).sum().backward()
+    ftol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (1e-2, 3e-2)
+    assert rel_err(y, ref) <= ftol, rel_err(y, ref)
+    assert rel_err(xg.grad, xr.grad) <= gtol, rel_err(xg.grad, xr.grad)
