@@ -278,13 +278,35 @@ __global__ __launch_bounds__(256) void conv2d_s2_dgrad_kernel(const bf16_t* __re
       const bool okt = pv && srct;                              //  alone and must be set in every lane)
       if (!__builtin_amdgcn_ballot_w64(okt)) continue;
       dt = vt < 3 ? vt : (vt == 3 ? 0 : 2);
+      // the three direct f taps together: 6 loads in flight, then 12 MFMAs (a tap that is invalid for a lane reads zeros; the
+      // matrix pipe is idle anyway) - one round trip per vt instead of one per tap
+      {
+        fe_u32x4 bb[3][2];
+#pragma unroll
+        for (int vf = 0; vf < 3; ++vf) {
+          int f2, df;
+          const bool ok = okt && conv_s2_src(vf, f, F, F2, f2, df);
+          const unsigned off = ok ? (unsigned)((((long)b * T2 + t2) * F2 + f2) * (O * 2) + hi * 16) : 0x80000000u;
+          bb[vf][0] = __builtin_bit_cast(fe_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
+          bb[vf][1] = __builtin_bit_cast(fe_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + 32, 0, 0));
+        }
+#pragma unroll
+        for (int vf = 0; vf < 3; ++vf) {
+          const fe_u32x4* wp = Wl + (dt * 3 + vf) * 256 + lane;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fe_bf16x8, wp[cb * 128]), __builtin_bit_cast(fe_bf16x8, bb[vf][0]), acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fe_bf16x8, wp[cb * 128 + 64]), __builtin_bit_cast(fe_bf16x8, bb[vf][1]), acc[cb], 0, 0, 0);
+          }
+        }
+      }
 #pragma unroll 1
-      for (int vf = 0; vf < 5; ++vf) {
+      for (int vf = 3; vf < 5; ++vf) {                         // the two mirrored edge columns: rare, skipped by ballot
         int f2, df;
         const bool srcf = conv_s2_src(vf, f, F, F2, f2, df);
         const bool ok = okt && srcf;
         if (!__builtin_amdgcn_ballot_w64(ok)) continue;
-        df = vf < 3 ? vf : (vf == 3 ? 0 : 2);
+        df = vf == 3 ? 0 : 2;
         const unsigned off = ok ? (unsigned)((((long)b * T2 + t2) * F2 + f2) * (O * 2) + hi * 16) : 0x80000000u;
         const fe_u32x4 b0 = __builtin_bit_cast(fe_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off, 0, 0));
         const fe_u32x4 b1 = __builtin_bit_cast(fe_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, off + 32, 0, 0));
