@@ -82,7 +82,7 @@ def test_gemm_strided_views_and_batch(dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
-@pytest.mark.parametrize("D", [256, 144, 30, 512])
+@pytest.mark.parametrize("D", [256, 144, 30, 512, 2560, 3332, 4096, 2050])   # > 2048: the wide-row kernels (front-end: 40 x 64)
 def test_layernorm_fwd_bwd(D, dtype, tol):
     L, ops = _ops()
     torch.manual_seed(D)
@@ -90,7 +90,8 @@ def test_layernorm_fwd_bwd(D, dtype, tol):
     x = (torch.randn(N, D, device="cuda") * 2 + 0.5).to(dtype)
     g = torch.randn(D, device="cuda") * 0.3 + 1
     b = torch.randn(D, device="cuda") * 0.3
-    for act, fn in [(L.ACT_NONE, lambda v: v), (L.ACT_SWISH, torch.nn.functional.silu)]:
+    for act, fn in [(L.ACT_NONE, lambda v: v), (L.ACT_SWISH, torch.nn.functional.silu),
+                    (L.ACT_LEAKY_RELU, lambda v: torch.nn.functional.leaky_relu(v, 0.01))]:
         y, stats = ops.layernorm_fwd(x, g, b, 1e-5, True, act)
         xr = x.double().requires_grad_(True)
         gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
