@@ -99,19 +99,23 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(DwParams p) {
 }
 
 // backward: persistent blocks over (b, t-tile) pairs of one channel tile; dw accumulates in LDS.
+// Tap / bias gradients: every wave keeps its own sums in registers over all its tiles, the four waves are folded in a fixed
+// order at the end and the workgroup writes ONE partial row [D][k + 1] (partial != NULL: reduced by dw_partials_reduce_kernel,
+// bit-reproducible - round 3; LDS and global fp32 atomics before) or, without a workspace, adds it to dw / dbias atomically.
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwParams p, int tiles_t) {
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwParams p, int tiles_t, float* __restrict__ partial) {
   __shared__ float u[DW_ROWS][DW_CT];
   __shared__ float g[DW_ROWS][DW_CT];     // dYg with halo
   __shared__ float wl[DW_KMAX][DW_CT];
-  __shared__ float dwl[DW_KMAX][DW_CT];
-  __shared__ float dbl[DW_CT];
+  __shared__ float red[3][DW_CT];
   const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ch = blockIdx.x * DW_CT + cl;
   const int pad = (p.k - 1) / 2;
   const int rows = DW_TT + 2 * pad;
-  for (int j = wv; j < p.k; j += 4) { wl[j][cl] = ch < p.D ? p.w[(long)ch * p.k + j] : 0.f; dwl[j][cl] = 0.f; }
-  if (wv == 0) dbl[cl] = 0.f;
+  for (int j = wv; j < p.k; j += 4) wl[j][cl] = ch < p.D ? p.w[(long)ch * p.k + j] : 0.f;
+  float dwr[DW_KMAX], dbr = 0.f;
+#pragma unroll
+  for (int j = 0; j < DW_KMAX; ++j) dwr[j] = 0.f;
   const T* dY = reinterpret_cast<const T*>(p.Y);
   const T* G = reinterpret_cast<const T*>(p.gate);
   const T* P = reinterpret_cast<const T*>(p.P);
@@ -156,19 +160,22 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwParams p, int tiles_t
           if (t < p.T) dG[((long)b * p.T + t) * p.lddg + ch] = from_f32<T>(to_f32(dY[((long)b * p.T + t) * p.ldy + ch]) * acc[o]);
         }
       }
-      for (int j = 0; j < p.k; ++j) {
-        float s = 0.f;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) {
-          int t = t0 + f0 + o, tau = t + j - pad;
-          bool ok = p.chunk > 0 ? (tau < (t / p.chunk + 1) * p.chunk) : true;
-          s += ok ? g[pad + f0 + o][cl] * u[f0 + o + j][cl] : 0.f;
+      for (int j = 0; j < DW_KMAX; ++j) {
+        if (j < p.k) {                                    // (uniform)
+          float s = 0.f;
+#pragma unroll
+          for (int o = 0; o < 16; ++o) {
+            int t = t0 + f0 + o, tau = t + j - pad;
+            bool ok = p.chunk > 0 ? (tau < (t / p.chunk + 1) * p.chunk) : true;
+            s += ok ? g[pad + f0 + o][cl] * u[f0 + o + j][cl] : 0.f;
+          }
+          dwr[j] += s;
         }
-        atomicAdd(&dwl[j][cl], s);
       }
 #pragma unroll
       for (int o = 0; o < 16; ++o) dbp += g[pad + f0 + o][cl];
-      atomicAdd(&dbl[cl], dbp);
+      dbr += dbp;
       // (2) du(tau) = sum_j w_j dYg(tau - j + pad)  [+ reflect folds], then GLU backward
       float du[16];
 #pragma unroll
@@ -223,10 +230,21 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwParams p, int tiles_t
       }
     }
   }
-  __syncthreads();
-  if (ch < p.D) {
-    for (int j = wv; j < p.k; j += 4) atomicAdd(p.dw + (long)ch * p.k + j, dwl[j][cl]);
-    if (wv == 0 && p.dbias) atomicAdd(p.dbias + ch, dbl[cl]);
+#pragma unroll
+  for (int j = 0; j <= DW_KMAX; ++j) {
+    if (j < p.k || j == DW_KMAX) {                        // (uniform; j == DW_KMAX: the bias gradient)
+      const float v = j < DW_KMAX ? dwr[j < DW_KMAX ? j : 0] : dbr;
+      __syncthreads();
+      if (wv > 0) red[wv - 1][cl] = v;
+      __syncthreads();
+      if (wv == 0 && ch < p.D) {
+        const float tot = ((v + red[0][cl]) + red[1][cl]) + red[2][cl];
+        const int jj = j < DW_KMAX ? j : p.k;
+        if (partial) partial[((long)blockIdx.y * p.D + ch) * (p.k + 1) + jj] = tot;
+        else if (j < DW_KMAX) atomicAdd(p.dw + (long)ch * p.k + j, tot);
+        else if (p.dbias) atomicAdd(p.dbias + ch, tot);
+      }
+    }
   }
 }
 
@@ -741,7 +759,13 @@ extern "C" int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, con
     if (dw) hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, (int)gy, D, k, dw, dbias);
   } else if (!dw) {
     return fail(SMX_EUNSUPPORTED, "smx_dwconv1d_glu_bwd: dw == NULL (deferred reduction) needs the k = 31 vector path");
-  } else if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, p, tiles_t);
-  else hipLaunchKernelGGL((dwconv_bwd_kernel<float>), grid, dim3(256), 0, s, p, tiles_t);
+  } else {
+    // generic shapes (k != 31, D % 8 != 0, ...): with a workspace one partial row per workgroup + the fixed-order reduction
+    float* partial = reinterpret_cast<float*>(workspace);
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((dwconv_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, p, tiles_t, partial);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<float>), grid, dim3(256), 0, s, p, tiles_t, partial);
+    const long W = (long)D * (k + 1);
+    if (partial) hipLaunchKernelGGL(dw_partials_reduce_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, s, partial, (int)gy, D, k, dw, dbias);
+  }
   return check_launch("smx_dwconv1d_glu_bwd");
 }

@@ -591,13 +591,14 @@ def test_gemm_epilogue_layernorm_backward_with_activations():
     assert rel_err(partial[:, 0].sum(0), (g * xh).sum(0)) < 2e-3 and rel_err(partial[:, 1].sum(0), g.sum(0)) < 2e-3
 
 
-@pytest.mark.parametrize("chunk", [4, 8, 16])
-def test_chunked_dwconv_backward_is_bit_reproducible(chunk):
+@pytest.mark.parametrize("chunk,D,k", [(4, 256, 31), (8, 256, 31), (16, 256, 31), (0, 40, 7), (6, 72, 15), (0, 64, 31)])
+def test_chunked_dwconv_backward_is_bit_reproducible(chunk, D, k):
     """Dynamic Chunk Convolution in the rolling kernels: per-wave partial tap gradients reduced in a fixed order - two runs
-    on the same inputs give bit-identical dP, dW and dbias (no atomics), at D = 256, k = 31 (the Conformer shape)."""
+    on the same inputs give bit-identical dP, dW and dbias (no atomics), at D = 256, k = 31 (the Conformer shape); the
+    generic tiled kernel (other k / D) goes through per-workgroup partial rows as well since round 3."""
     L, ops = _ops()
-    torch.manual_seed(chunk)
-    B, T, D, k = 8, 500, 256, 31
+    torch.manual_seed(chunk + k)
+    B, T = 8, 500
     p = torch.randn(B * T, 2 * D, device="cuda").bfloat16()
     dy = torch.randn(B * T, D, device="cuda").bfloat16()
     w = torch.randn(D, k, device="cuda") * 0.3
