@@ -328,6 +328,19 @@ int smx_mel_db(int out_dtype, const float* spec, int64_t lds, int im_off, const 
                float amin, float top_db, void* out, int B, int T, void* workspace, void* stream);
 int smx_im2col_s2(int dtype, const void* x, void* col, int B, int T, int F, int C, int Kp, void* stream);
 int smx_col2im_s2(int dtype, const void* dcol, void* dx, int B, int T, int F, int C, int Kp, void* stream);
+/* The first conv block in one pass per direction (1 input channel, O = 64, F a multiple of 16 up to 160; SMX_EUNSUPPORTED
+ * otherwise: im2col + smx_linear_k16_fwd / smx_gemm + smx_layernorm_*).  X (B,T,F) and Y / dA (B*ceil(T/2), (F/2)*O) dtype T;
+ * W9 (O, 9) fp32 taps (dt*3 + df), gamma / beta ((F/2)*O) fp32.
+ *   fwd: Y = act(LayerNorm_row(conv3x3_s2_reflect(X) + bias) * gamma + beta), stats (rows, 2) = mean | rstd
+ *   bwd: grads[(F/2)*O | (F/2)*O | O*9 | O] += dgamma | dbeta | dW9 | dbias, from dA and X alone (the convolution is recomputed;
+ *        nothing of activation size is written); `workspace` = smx_conv1_ln_workspace bytes of per-workgroup partial rows,
+ *        folded in a fixed order. */
+size_t smx_conv1_ln_workspace(int B, int T, int F, int O);
+int smx_conv1_ln_fwd(int dtype, const void* X, const float* W9, const float* bias, const float* gamma, const float* beta, float eps,
+                     int act, void* Y, float* stats, int B, int T, int F, int O, void* stream);
+int smx_conv1_ln_bwd(int dtype, const void* dA, const void* X, const float* W9, const float* bias, const float* gamma,
+                     const float* beta, const float* stats, int act, float* grads, void* workspace, int B, int T, int F, int O,
+                     void* stream);
 /* Y (N, M) = X (N, 16) W (M, 16)^T + bias: the first block's convolution (9 taps of one input channel in 16 columns) on
  * the VALU, bf16 in / out, fp32 accumulation; dense rows.  SMX_EUNSUPPORTED for other shapes (use smx_gemm). */
 int smx_linear_k16_fwd(int dtype, const void* X, const void* W, const float* bias, void* Y, int64_t N, int M, void* stream);

@@ -114,6 +114,9 @@ SIGNATURES = {
     "smx_mel_db": (c_i, [c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_f, c_f, c_vp, c_i, c_i, c_vp, c_vp]),
     "smx_im2col_s2": (c_i, [c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_col2im_s2": (c_i, [c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "smx_conv1_ln_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
+    "smx_conv1_ln_fwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
+    "smx_conv1_ln_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "smx_linear_k16_fwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_vp]),
     "smx_conv2d_s2_dgrad": (c_i, [c_i, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_axpby": (c_i, [c_i, c_f, c_vp, c_i64, c_f, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),

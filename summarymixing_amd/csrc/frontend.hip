@@ -181,6 +181,209 @@ __global__ __launch_bounds__(256) void im2col_s2_vec_kernel(const uint4* __restr
   }
 }
 
+// ---- first conv block in ONE pass per direction (the recipe's shape: 1 input channel, O = 64 output channels, F2 = F / 2 a
+// multiple of 8; 3 x 3, stride 2, reflect pad 1; LayerNorm over the (F2, O) row; activation) ---------------------------------
+//   forward : a[b,t2,f2,c] = act(LN_row(conv(x)[b,t2,:,:] + bias) * gamma + beta),  stats[b,t2] = (mean, rstd)
+//   backward: from dA and x alone - the convolution is recomputed (9 MACs per output), so neither the pre-LayerNorm
+//             tensor nor the patch matrix is ever stored, and since the block's input is the feature map (no gradient
+//             wanted) NOTHING of activation size is written: only per-workgroup partial rows
+//             [dgamma (F2 O) | dbeta (F2 O) | dW (O x 9) | dbias (O)], reduced in a fixed order by rows_sum_add_kernel.
+// One workgroup walks rows (b, t2); thread t owns the channel pair c0 = 2 (t % 32) at f2 = t / 32 + 8 i: its 9-tap weights
+// sit in registers, the row's 3 x (F + 2) input window in LDS, a row's 2 NI values per thread in registers between the
+// statistics pass and the normalisation.  Replaces im2col (0.26 ms) + the K = 16 Linear (0.30) + LayerNorm (0.42) by one
+// 655 MB write, and the wide LayerNorm backward (0.50) + conv-1 wgrad GEMM (0.17) by one 655 MB read (B = 128 x 20 s).
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void conv1_ln_fwd_kernel(const T* __restrict__ X, const float* __restrict__ W9,
+                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int act,
+                                                           T* __restrict__ Y, float* __restrict__ stats, int B, int T_, int F,
+                                                           int T2) {
+  constexpr int O = 64;
+  __shared__ float xs[3][164];                            // (F + 2) <= 162 columns: column fi + 1 = reflected feature fi
+  __shared__ float red[2][4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int c0 = 2 * (t & 31), fb = t >> 5, F2 = F / 2, D = F2 * O;
+  float w0[9], w1[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { w0[j] = W9[c0 * 9 + j]; w1[j] = W9[(c0 + 1) * 9 + j]; }
+  const float b0 = bias ? bias[c0] : 0.f, b1 = bias ? bias[c0 + 1] : 0.f;
+  float gm[NI][2], bt[NI][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int o = (fb + 8 * i) * O + c0;
+    gm[i][0] = gamma[o]; gm[i][1] = gamma[o + 1]; bt[i][0] = beta[o]; bt[i][1] = beta[o + 1];
+  }
+  const long rows = (long)B * T2;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int b = (int)(row / T2), t2 = (int)(row % T2);
+    __syncthreads();
+    for (int e = t; e < 3 * (F + 2); e += 256) {
+      const int dt = e / (F + 2), fi = e % (F + 2) - 1;
+      const int ti = reflect1(2 * t2 + dt - 1, T_), ff = reflect1(fi, F);
+      xs[dt][fi + 1] = to_f32(X[((long)b * T_ + ti) * F + ff]);
+    }
+    __syncthreads();
+    float y[NI][2], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int f2 = fb + 8 * i;
+      float a0 = b0, a1 = b1;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int df = 0; df < 3; ++df) {
+          const float xv = xs[dt][2 * f2 + df];
+          a0 += w0[dt * 3 + df] * xv; a1 += w1[dt * 3 + df] * xv;
+        }
+      y[i][0] = a0; y[i][1] = a1;
+      s1 += a0 + a1;
+    }
+    s1 = wave_sum(s1);
+    if (lane == 0) red[0][wv] = s1;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const float e0 = y[i][0] - mean, e1 = y[i][1] - mean; s2 += e0 * e0 + e1 * e1; }
+    s2 = wave_sum(s2);                                     // (two passes over the registers: no E[y^2] - mean^2 cancellation)
+    if (lane == 0) red[1][wv] = s2;
+    __syncthreads();
+    const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)D;
+    const float rstd = rsqrtf(var + eps);
+    if (t == 0 && stats) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    T* yr = Y + row * D;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int o = (fb + 8 * i) * O + c0;
+      const float v0 = act_fwd(act, (y[i][0] - mean) * rstd * gm[i][0] + bt[i][0]);
+      const float v1 = act_fwd(act, (y[i][1] - mean) * rstd * gm[i][1] + bt[i][1]);
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(yr + o) = pack_bf16x2(v0, v1);
+      else *reinterpret_cast<float2*>(yr + o) = make_float2(v0, v1);
+    }
+  }
+}
+
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void conv1_ln_bwd_kernel(const T* __restrict__ dA, const T* __restrict__ X,
+                                                           const float* __restrict__ W9, const float* __restrict__ bias,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ stats, int act, float* __restrict__ partial,
+                                                           int B, int T_, int F, int T2) {
+  constexpr int O = 64;
+  __shared__ float xs[3][164];
+  __shared__ float red[2][4];
+  __shared__ float fold[8][32][20];                       // [f group][channel pair][dW 2 x 9 | db 2]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int c0 = 2 * (t & 31), fb = t >> 5, F2 = F / 2, D = F2 * O;
+  float w0[9], w1[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { w0[j] = W9[c0 * 9 + j]; w1[j] = W9[(c0 + 1) * 9 + j]; }
+  const float b0 = bias ? bias[c0] : 0.f, b1 = bias ? bias[c0 + 1] : 0.f;
+  float gm[NI][2], bt[NI][2], dgm[NI][2], dbt[NI][2], dw0[9], dw1[9], db0 = 0.f, db1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int o = (fb + 8 * i) * O + c0;
+    gm[i][0] = gamma[o]; gm[i][1] = gamma[o + 1]; bt[i][0] = beta[o]; bt[i][1] = beta[o + 1];
+    dgm[i][0] = dgm[i][1] = dbt[i][0] = dbt[i][1] = 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) dw0[j] = dw1[j] = 0.f;
+  const long rows = (long)B * T2;
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int b = (int)(row / T2), t2 = (int)(row % T2);
+    __syncthreads();
+    for (int e = t; e < 3 * (F + 2); e += 256) {
+      const int dt = e / (F + 2), fi = e % (F + 2) - 1;
+      const int ti = reflect1(2 * t2 + dt - 1, T_), ff = reflect1(fi, F);
+      xs[dt][fi + 1] = to_f32(X[((long)b * T_ + ti) * F + ff]);
+    }
+    __syncthreads();
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const T* dr = dA + row * D;
+    float xh[NI][2], g[NI][2], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int f2 = fb + 8 * i, o = f2 * O + c0;
+      float a0 = b0, a1 = b1;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int df = 0; df < 3; ++df) {
+          const float xv = xs[dt][2 * f2 + df];
+          a0 += w0[dt * 3 + df] * xv; a1 += w1[dt * 3 + df] * xv;
+        }
+      float d0, d1;
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(dr + o);
+        d0 = bf16_bits_to_f32(u & 0xffffu); d1 = bf16_bits_to_f32(u >> 16);
+      } else {
+        const float2 u = *reinterpret_cast<const float2*>(dr + o);
+        d0 = u.x; d1 = u.y;
+      }
+      xh[i][0] = (a0 - mean) * rstd; xh[i][1] = (a1 - mean) * rstd;
+      if (act != SMX_ACT_NONE) {                           // (uniform)
+        d0 *= act_grad(act, xh[i][0] * gm[i][0] + bt[i][0]);
+        d1 *= act_grad(act, xh[i][1] * gm[i][1] + bt[i][1]);
+      }
+      dgm[i][0] += d0 * xh[i][0]; dgm[i][1] += d1 * xh[i][1];
+      dbt[i][0] += d0; dbt[i][1] += d1;
+      g[i][0] = d0 * gm[i][0]; g[i][1] = d1 * gm[i][1];
+      s1 += g[i][0] + g[i][1]; s2 += g[i][0] * xh[i][0] + g[i][1] * xh[i][1];
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { red[0][wv] = s1; red[1][wv] = s2; }
+    __syncthreads();
+    const float m1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D;
+    const float m2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int f2 = fb + 8 * i;
+      const float dy0 = rstd * (g[i][0] - m1 - xh[i][0] * m2), dy1 = rstd * (g[i][1] - m1 - xh[i][1] * m2);
+      db0 += dy0; db1 += dy1;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int df = 0; df < 3; ++df) {
+          const float xv = xs[dt][2 * f2 + df];
+          dw0[dt * 3 + df] += dy0 * xv; dw1[dt * 3 + df] += dy1 * xv;
+        }
+    }
+  }
+  // partial row of this workgroup: [dgamma D | dbeta D | dW O x 9 | dbias O]
+  float* pr = partial + (long)blockIdx.x * (2 * D + O * 10);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int o = (fb + 8 * i) * O + c0;
+    pr[o] = dgm[i][0]; pr[o + 1] = dgm[i][1]; pr[D + o] = dbt[i][0]; pr[D + o + 1] = dbt[i][1];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { fold[fb][t & 31][j] = dw0[j]; fold[fb][t & 31][9 + j] = dw1[j]; }
+  fold[fb][t & 31][18] = db0; fold[fb][t & 31][19] = db1;
+  __syncthreads();
+  for (int e = t; e < 32 * 20; e += 256) {                 // the 8 f groups in a fixed order
+    const int cp = e / 20, j = e % 20;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += fold[q][cp][j];
+    const int c = 2 * cp + (j >= 18 ? j - 18 : j / 9);
+    if (j < 18) pr[2 * D + c * 9 + j % 9] = sum; else pr[2 * D + O * 9 + c] = sum;
+  }
+}
+
+// out[i] += sum_r partial[r][i]  (fixed order: bit-reproducible)
+__global__ __launch_bounds__(256) void rows_sum_add_kernel(const float* __restrict__ partial, int nrows, long W, float* __restrict__ out) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= W) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < nrows; r += 4) {
+    s0 += partial[(long)r * W + i]; s1 += partial[(long)(r + 1) * W + i];
+    s2 += partial[(long)(r + 2) * W + i]; s3 += partial[(long)(r + 3) * W + i];
+  }
+  for (; r < nrows; ++r) s0 += partial[(long)r * W + i];
+  out[i] += (s0 + s1) + (s2 + s3);
+}
+
 // ---- thin Linear: Y[n, m] = sum_k X[n, k] W[m, k] + bias[m] for K = 16 (the first conv block: 9 taps of ONE input channel,
 // padded to 16 columns) - 16 MACs per output are VALU work next to the 128 bytes a row writes; the MFMA GEMM's tile machinery
 // spends 790 us on the 655 MB output at B = 128 x 20 s.  Thread = 8 output channels of one row, weights in registers.
@@ -442,6 +645,57 @@ extern "C" int smx_im2col_s2(int dtype, const void* x, void* col, int B, int T, 
   if (dtype == SMX_BF16) hipLaunchKernelGGL((im2col_s2_kernel<bf16_t>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const bf16_t*)x, (bf16_t*)col, B, T, F, C, T2, F2, Kp);
   else hipLaunchKernelGGL((im2col_s2_kernel<float>), dim3(fgrid(total)), dim3(256), 0, STREAM, (const float*)x, (float*)col, B, T, F, C, T2, F2, Kp);
   return check_launch("smx_im2col_s2");
+}
+
+static int conv1_blocks(long rows) { return (int)(rows < 768 ? rows : 768); }   // persistent: 3 workgroups per CU, 768 partial rows
+static bool conv1_shape_ok(int T, int F, int O) { return O == 64 && F % 16 == 0 && F >= 16 && F <= 160 && (F / 2) / 8 <= 10 && T >= 2; }
+extern "C" size_t smx_conv1_ln_workspace(int B, int T, int F, int O) {
+  if (B <= 0 || T <= 0 || !conv1_shape_ok(T, F, O)) return 0;
+  const long rows = (long)B * ((T + 1) / 2);
+  return (size_t)conv1_blocks(rows) * (2 * (F / 2) * O + O * 10) * sizeof(float);
+}
+#define SMX_CONV1_NI(NI_, CALL)                                           \
+  switch (NI_) {                                                          \
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break; \
+    case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 9: CALL(9); break; default: CALL(10); break; \
+  }
+extern "C" int smx_conv1_ln_fwd(int dtype, const void* X, const float* W9, const float* bias, const float* gamma, const float* beta,
+                                float eps, int act, void* Y, float* stats, int B, int T, int F, int O, void* stream) {
+  SMX_REQUIRE(X && W9 && gamma && beta && Y, "smx_conv1_ln_fwd: null pointer");
+  if (!conv1_shape_ok(T, F, O)) return fail(SMX_EUNSUPPORTED, "smx_conv1_ln_fwd: built for O = 64, F a multiple of 16 up to 160");
+  if (B <= 0) return SMX_OK;
+  const int T2 = (T + 1) / 2, NI = (F / 2) / 8;
+  const long rows = (long)B * T2;
+  long g = rows < 256L * 16 ? rows : 256L * 16;
+#define CALL(N_)                                                                                                              \
+  do {                                                                                                                         \
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((conv1_ln_fwd_kernel<bf16_t, N_>), dim3((unsigned)g), dim3(256), 0, STREAM, (const bf16_t*)X, W9, bias, gamma, beta, eps, act, (bf16_t*)Y, stats, B, T, F, T2); \
+    else hipLaunchKernelGGL((conv1_ln_fwd_kernel<float, N_>), dim3((unsigned)g), dim3(256), 0, STREAM, (const float*)X, W9, bias, gamma, beta, eps, act, (float*)Y, stats, B, T, F, T2); \
+  } while (0)
+  SMX_CONV1_NI(NI, CALL)
+#undef CALL
+  return check_launch("smx_conv1_ln_fwd");
+}
+extern "C" int smx_conv1_ln_bwd(int dtype, const void* dA, const void* X, const float* W9, const float* bias, const float* gamma,
+                                const float* beta, const float* stats, int act, float* grads, void* workspace, int B, int T, int F,
+                                int O, void* stream) {
+  SMX_REQUIRE(dA && X && W9 && gamma && beta && stats && grads && workspace, "smx_conv1_ln_bwd: null pointer");
+  if (!conv1_shape_ok(T, F, O)) return fail(SMX_EUNSUPPORTED, "smx_conv1_ln_bwd: built for O = 64, F a multiple of 16 up to 160");
+  if (B <= 0) return SMX_OK;
+  const int T2 = (T + 1) / 2, NI = (F / 2) / 8;
+  const long rows = (long)B * T2;
+  const int g = conv1_blocks(rows);
+  float* partial = reinterpret_cast<float*>(workspace);
+#define CALL(N_)                                                                                                              \
+  do {                                                                                                                         \
+    if (dtype == SMX_BF16) hipLaunchKernelGGL((conv1_ln_bwd_kernel<bf16_t, N_>), dim3(g), dim3(256), 0, STREAM, (const bf16_t*)dA, (const bf16_t*)X, W9, bias, gamma, beta, stats, act, partial, B, T, F, T2); \
+    else hipLaunchKernelGGL((conv1_ln_bwd_kernel<float, N_>), dim3(g), dim3(256), 0, STREAM, (const float*)dA, (const float*)X, W9, bias, gamma, beta, stats, act, partial, B, T, F, T2); \
+  } while (0)
+  SMX_CONV1_NI(NI, CALL)
+#undef CALL
+  const long W = 2L * (F / 2) * O + O * 10;
+  hipLaunchKernelGGL(rows_sum_add_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, STREAM, partial, g, W, grads);
+  return check_launch("smx_conv1_ln_bwd");
 }
 
 extern "C" int smx_linear_k16_fwd(int dtype, const void* X, const void* W, const float* bias, void* Y, int64_t N, int M, void* stream) {

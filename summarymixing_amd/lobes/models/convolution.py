@@ -16,6 +16,7 @@ from ... import ops
 
 
 import os
+_FUSED_BLOCK1 = os.environ.get("SMX_CONV_FUSED_BLOCK1", "1") != "0"      # A/B knob: smx_conv1_ln_fwd / _bwd instead of im2col + Linear + LayerNorm
 _DIRECT_DGRAD = os.environ.get("SMX_CONV_DIRECT_DGRAD", "1") != "0"      # A/B knob: smx_conv2d_s2_dgrad instead of GEMM + col2im
 
 
@@ -96,6 +97,19 @@ class ConvolutionFrontEnd(nn.Module):
             for bi, blk in enumerate(blocks):
                 _, T_, F_, C = h.shape
                 T2, F2 = (T_ + 1) // 2, (F_ + 1) // 2
+                if bi == 0 and C == 1 and _FUSED_BLOCK1 and ops.conv1_ln_ok(h.view(B, T_, F_), blk.c_out):
+                    # first block in ONE pass (conv + LayerNorm + LeakyReLU; the backward recomputes the conv from x)
+                    x3 = h.view(B, T_, F_)
+                    w9 = blk.conv.weight.detach().reshape(blk.c_out, 9).float().contiguous()
+                    a, st = ops.conv1_ln_fwd(x3, w9, blk.conv.bias.detach(), blk.norm.weight.detach().view(-1),
+                                             blk.norm.bias.detach().view(-1), blk.norm.eps, L.ACT_LEAKY_RELU, need)
+                    seed = None
+                    if pd > 0.0:
+                        seed = ops.new_dropout_seed()
+                        ops.dropout(a, pd, seed, out=a)
+                    saved.append(("fused1", x3, w9, st, seed, blk, bi))
+                    h = a.view(B, T2, F2, blk.c_out)
+                    continue
                 col = ops.im2col_s2(h, blk.kp)
                 # GEMM-layout weight (Cout, Kp): column (dt*3+df)*Cin + c  <- conv.weight (Cout, Cin, 3, 3)
                 wg = torch.zeros((blk.c_out, blk.kp), dtype=torch.float32, device=h.device)
@@ -119,6 +133,22 @@ class ConvolutionFrontEnd(nn.Module):
             def bwd(dout):
                 d = dout.contiguous()
                 for shape, col, wgc, ln_b, seed, blk, bi in reversed(saved):
+                    if isinstance(shape, str):                       # the fused first block: gradients from dA and x alone
+                        x3, w9, st = col, wgc, ln_b
+                        T2, F2 = (x3.shape[1] + 1) // 2, x3.shape[2] // 2
+                        da = d.reshape(B * T2, F2 * blk.c_out)
+                        if seed is not None:
+                            da = ops.dropout(da, pd, seed)
+                        gr = ops.conv1_ln_bwd(da, x3, w9, blk.conv.bias.detach(), blk.norm.weight.detach().view(-1),
+                                              blk.norm.bias.detach().view(-1), st, L.ACT_LEAKY_RELU)
+                        Dn = F2 * blk.c_out
+                        for prm, piece in ((blk.norm.weight, gr[:Dn]), (blk.norm.bias, gr[Dn:2 * Dn]),
+                                           (blk.conv.weight, gr[2 * Dn:2 * Dn + 9 * blk.c_out]),
+                                           (blk.conv.bias, gr[2 * Dn + 9 * blk.c_out:])):
+                            g = F.gacc(prm)
+                            if g is not None:
+                                g.add_(piece.view(g.shape))
+                        return None
                     _, T_, F_, C = shape
                     T2, F2 = (T_ + 1) // 2, (F_ + 1) // 2
                     da = d.reshape(B * T2, F2 * blk.c_out)

@@ -602,6 +602,41 @@ def im2col_s2(x, Kp):
     return col
 
 
+def conv1_ln_ok(x, O):
+    """Does the fused first conv block (smx_conv1_ln_fwd / _bwd) take this input?  x (B, T, F) contiguous, one input channel."""
+    B, T, F_ = x.shape
+    return (x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous() and O == 64 and F_ % 16 == 0 and 16 <= F_ <= 160
+            and T >= 2 and L.lib().smx_conv1_ln_workspace(B, T, F_, O) > 0)
+
+
+def conv1_ln_fwd(x, w9, bias, gamma, beta, eps, act, need_stats=True):
+    """a = act(LayerNorm(conv3x3_s2_reflect(x) + bias) * gamma + beta) in one pass: x (B,T,F) -> (B*T2, (F/2)*O), stats."""
+    B, T, F_ = x.shape
+    O = w9.shape[0]
+    T2 = (T + 1) // 2
+    y = torch.empty((B * T2, (F_ // 2) * O), dtype=x.dtype, device=x.device)
+    stats = torch.empty((B * T2, 2), dtype=torch.float32, device=x.device) if need_stats else None
+    tok = _pb(f"conv1_ln_fwd ({B},{T},{F_})->{O}", x.numel() * _es(x) + y.numel() * _es(y))
+    L.check(L.lib().smx_conv1_ln_fwd(dt(x), _p(x), _p(w9), _p(bias), _p(gamma), _p(beta), eps, act, _p(y), _p(stats), B, T, F_, O,
+                                     _stream()), "smx_conv1_ln_fwd")
+    _pe(tok)
+    return y, stats
+
+
+def conv1_ln_bwd(da, x, w9, bias, gamma, beta, stats, act):
+    """Gradients of the fused first conv block from dA and x: a flat fp32 tensor [dgamma | dbeta | dW9 (O,9) | dbias]."""
+    B, T, F_ = x.shape
+    O = w9.shape[0]
+    D = (F_ // 2) * O
+    grads = torch.zeros(2 * D + O * 10, dtype=torch.float32, device=x.device)
+    ws = _workspace(L.lib().smx_conv1_ln_workspace(B, T, F_, O), x.device, slot=5)
+    tok = _pb(f"conv1_ln_bwd ({B},{T},{F_})->{O}", da.numel() * _es(da) + x.numel() * _es(x))
+    L.check(L.lib().smx_conv1_ln_bwd(dt(x), _p(da), _p(x), _p(w9), _p(bias), _p(gamma), _p(beta), _p(stats), act, _p(grads), _p(ws),
+                                     B, T, F_, O, _stream()), "smx_conv1_ln_bwd")
+    _pe(tok)
+    return grads
+
+
 def linear_k16(x, W, bias):
     """y = x W^T + bias for K = 16 on the VALU (smx_linear_k16_fwd), or None when the shape is not the kernel's."""
     N, K = x.shape
