@@ -146,3 +146,42 @@ def test_direct_conv_dgrad_matches_float64_conv_transpose(B, T, Fq):
     ops.gemm(ops.L.GEMM_NN, dy2, wg, dcol, B * T2 * F2, 9 * C, O, ops.epilogue())
     old = ops.col2im_s2(dcol, B, T, Fq, C)
     assert rel_err(got, old.float()) <= 2e-2                     # (the old path rounds the 9 C gradient columns to bf16 first)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("B,T,Fq", [(2, 37, 80), (3, 8, 16), (1, 2, 160), (2, 101, 48)])
+def test_fused_first_conv_block_matches_float64(B, T, Fq, dtype, tol):
+    """smx_conv1_ln_fwd / _bwd (conv 3x3 s2 reflect + LayerNorm over (F/2, 64) + LeakyReLU in one pass; the backward recomputes
+    the convolution) against float64 torch autograd: output, statistics and all four parameter gradients."""
+    import torch.nn.functional as tF
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(T * Fq)
+    O, F2, T2 = 64, Fq // 2, (T + 1) // 2
+    x = torch.randn(B, T, Fq)
+    W = (torch.randn(O, 1, 3, 3) * 0.4).double().requires_grad_(True)
+    b = (torch.randn(O) * 0.2).double().requires_grad_(True)
+    g = (torch.randn(F2, O) * 0.3 + 1).double().requires_grad_(True)
+    be = (torch.randn(F2, O) * 0.3).double().requires_grad_(True)
+    xq = x.cuda().to(dtype)
+    xr = xq.double().cpu()
+    y = tF.conv2d(tF.pad(xr[:, None], (1, 1, 1, 1), mode="reflect"), W, b, stride=2).permute(0, 2, 3, 1)   # (B, T2, F2, O)
+    ref = tF.leaky_relu(tF.layer_norm(y, (F2, O), g, be, 1e-5), 0.01)
+    assert ops.conv1_ln_ok(xq, O)
+    w9 = W.detach().reshape(O, 9).float().cuda().contiguous()
+    a, st = ops.conv1_ln_fwd(xq, w9, b.detach().float().cuda(), g.detach().float().cuda().view(-1),
+                             be.detach().float().cuda().view(-1), 1e-5, L.ACT_LEAKY_RELU)
+    assert rel_err(a.view(B, T2, F2, O), ref) <= tol
+    mean = y.detach().reshape(B * T2, -1).mean(1)
+    assert rel_err(st[:, 0], mean) <= 1e-4 if mean.abs().max() > 1e-3 else True
+    da = torch.randn(B * T2, F2 * O)
+    daq = da.cuda().to(dtype)
+    (ref * daq.double().cpu().view(B, T2, F2, O)).sum().backward()
+    gr = ops.conv1_ln_bwd(daq, xq, w9, b.detach().float().cuda(), g.detach().float().cuda().view(-1),
+                          be.detach().float().cuda().view(-1), st, L.ACT_LEAKY_RELU)
+    D = F2 * O
+    gt = 3 * tol
+    assert rel_err(gr[:D], g.grad.reshape(-1)) <= gt and rel_err(gr[D:2 * D], be.grad.reshape(-1)) <= gt
+    assert rel_err(gr[2 * D:2 * D + 9 * O], W.grad.reshape(-1)) <= gt and rel_err(gr[2 * D + 9 * O:], b.grad) <= gt
+    gr2 = ops.conv1_ln_bwd(daq, xq, w9, b.detach().float().cuda(), g.detach().float().cuda().view(-1),
+                           be.detach().float().cuda().view(-1), st, L.ACT_LEAKY_RELU)
+    assert torch.equal(gr, gr2)                                  # fixed-order reductions: bit-reproducible
