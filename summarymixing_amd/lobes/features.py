@@ -13,6 +13,10 @@ from .. import _lib as L
 from .. import ops
 
 
+import os
+_IMPLICIT_FRAMES = os.environ.get("SMX_FBANK_IMPLICIT_FRAMES", "1") != "0"   # A/B knob: the DFT GEMM reads the waveform in place
+
+
 class Fbank(nn.Module):
     def __init__(self, deltas=False, context=False, requires_grad=False, sample_rate=16000, f_min=0, f_max=None, n_fft=400,
                  n_mels=40, filter_shape="triangular", param_change_factor=1.0, param_rand_factor=0.0, left_frames=5,
@@ -35,6 +39,10 @@ class Fbank(nn.Module):
         basis[self.im_off:self.im_off + n_bins] = -torch.sin(ang)
         self.register_buffer("basis", basis.float(), persistent=False)
         self.register_buffer("window", torch.hamming_window(self.win, dtype=torch.float32), persistent=False)
+        # the analysis window folded into the DFT basis: frames are then plain overlapping rows of the (zero-padded) waveform
+        # and the GEMM reads them in place (leading dimension = hop), no (B*T, n_fft) frame matrix is written
+        win64 = torch.hamming_window(self.win, dtype=torch.float64)
+        self.register_buffer("basis_w", (basis * win64[None, :]).float(), persistent=False)
         # HTK-mel triangular filters (n_mels, n_bins)
         f_max = sample_rate / 2 if f_max is None else f_max
         to_mel = lambda hz: 2595.0 * math.log10(1.0 + hz / 700.0)
@@ -51,9 +59,19 @@ class Fbank(nn.Module):
         assert wav.dim() == 2 and wav.dtype == torch.float32 and wav.is_cuda
         B, Lw = wav.shape
         T = 1 + Lw // self.hop
-        frames = ops.frame_window(wav.contiguous(), self.window, T, self.n_fft, self.hop)
         spec = torch.empty((B * T, self.basis.shape[0]), dtype=torch.float32, device=wav.device)
-        ops.gemm(L.GEMM_NT, frames, self.basis, spec, B * T, self.basis.shape[0], self.n_fft)
+        if _IMPLICIT_FRAMES and self.hop % 4 == 0:
+            # center=True: n_fft/2 zeros on both sides; frame t of utterance b = samples [t*hop, t*hop + n_fft) of the padded row
+            half = self.n_fft // 2
+            Lp = (Lw + self.n_fft + 3) // 4 * 4
+            wp = torch.zeros((B, Lp), dtype=torch.float32, device=wav.device)
+            wp[:, half:half + Lw] = wav
+            M = self.basis.shape[0]
+            ops.gemm(L.GEMM_NT, wp[0, :self.n_fft].view(1, -1), self.basis_w, spec[:T], T, M, self.n_fft, batch=B, sa=Lp, sb=0,
+                     sc=T * M, lda=self.hop)
+        else:
+            frames = ops.frame_window(wav.contiguous(), self.window, T, self.n_fft, self.hop)
+            ops.gemm(L.GEMM_NT, frames, self.basis, spec, B * T, self.basis.shape[0], self.n_fft)
         return ops.mel_db(spec, self.im_off, self.fb, B, T, self.amin, self.top_db, out_dtype)
 
 
