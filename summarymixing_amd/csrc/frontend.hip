@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void conv1_ln_bwd_kernel(const T* __restrict__
                                                            const float* __restrict__ stats, int act, float* __restrict__ partial,
                                                            int B, int T_, int F, int T2) {
   constexpr int O = 64;
-  __shared__ float xs[3][164];
-  __shared__ float red[2][4];
+  __shared__ float xs[2][3][164];                         // double-buffered: the next row's window lands while this one is used
+  __shared__ float red[2][2][4];
   __shared__ float fold[8][32][20];                       // [f group][channel pair][dW 2 x 9 | db 2]
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int c0 = 2 * (t & 31), fb = t >> 5, F2 = F / 2, D = F2 * O;
@@ -288,37 +288,55 @@ __global__ __launch_bounds__(256) void conv1_ln_bwd_kernel(const T* __restrict__
 #pragma unroll
   for (int j = 0; j < 9; ++j) dw0[j] = dw1[j] = 0.f;
   const long rows = (long)B * T2;
-  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+  // the loads of row r + stride (its dA values, its window, its statistics) are issued before the arithmetic of row r
+  auto window = [&](long row, int buf) {
     const int b = (int)(row / T2), t2 = (int)(row % T2);
-    __syncthreads();
     for (int e = t; e < 3 * (F + 2); e += 256) {
       const int dt = e / (F + 2), fi = e % (F + 2) - 1;
       const int ti = reflect1(2 * t2 + dt - 1, T_), ff = reflect1(fi, F);
-      xs[dt][fi + 1] = to_f32(X[((long)b * T_ + ti) * F + ff]);
+      xs[buf][dt][fi + 1] = to_f32(X[((long)b * T_ + ti) * F + ff]);
     }
-    __syncthreads();
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  };
+  auto load_da = [&](long row, float (&d)[NI][2]) {
     const T* dr = dA + row * D;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int o = (fb + 8 * i) * O + c0;
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t u = *reinterpret_cast<const uint32_t*>(dr + o);
+        d[i][0] = bf16_bits_to_f32(u & 0xffffu); d[i][1] = bf16_bits_to_f32(u >> 16);
+      } else {
+        const float2 u = *reinterpret_cast<const float2*>(dr + o);
+        d[i][0] = u.x; d[i][1] = u.y;
+      }
+    }
+  };
+  float dn[NI][2];
+  float mean_n = 0.f, rstd_n = 0.f;
+  long row = blockIdx.x;
+  int buf = 0;
+  if (row < rows) { window(row, 0); load_da(row, dn); mean_n = stats[2 * row]; rstd_n = stats[2 * row + 1]; }
+  for (; row < rows; row += gridDim.x, buf ^= 1) {
+    __syncthreads();                                       // this row's window is complete; the other buffer is free
+    float d[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { d[i][0] = dn[i][0]; d[i][1] = dn[i][1]; }
+    const float mean = mean_n, rstd = rstd_n;
+    const long nxt = row + gridDim.x;
+    if (nxt < rows) { window(nxt, buf ^ 1); load_da(nxt, dn); mean_n = stats[2 * nxt]; rstd_n = stats[2 * nxt + 1]; }
     float xh[NI][2], g[NI][2], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int f2 = fb + 8 * i, o = f2 * O + c0;
+      const int f2 = fb + 8 * i;
       float a0 = b0, a1 = b1;
 #pragma unroll
       for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
         for (int df = 0; df < 3; ++df) {
-          const float xv = xs[dt][2 * f2 + df];
+          const float xv = xs[buf][dt][2 * f2 + df];
           a0 += w0[dt * 3 + df] * xv; a1 += w1[dt * 3 + df] * xv;
         }
-      float d0, d1;
-      if constexpr (sizeof(T) == 2) {
-        const uint32_t u = *reinterpret_cast<const uint32_t*>(dr + o);
-        d0 = bf16_bits_to_f32(u & 0xffffu); d1 = bf16_bits_to_f32(u >> 16);
-      } else {
-        const float2 u = *reinterpret_cast<const float2*>(dr + o);
-        d0 = u.x; d1 = u.y;
-      }
+      float d0 = d[i][0], d1 = d[i][1];
       xh[i][0] = (a0 - mean) * rstd; xh[i][1] = (a1 - mean) * rstd;
       if (act != SMX_ACT_NONE) {                           // (uniform)
         d0 *= act_grad(act, xh[i][0] * gm[i][0] + bt[i][0]);
@@ -330,10 +348,10 @@ __global__ __launch_bounds__(256) void conv1_ln_bwd_kernel(const T* __restrict__
       s1 += g[i][0] + g[i][1]; s2 += g[i][0] * xh[i][0] + g[i][1] * xh[i][1];
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { red[0][wv] = s1; red[1][wv] = s2; }
+    if (lane == 0) { red[buf][0][wv] = s1; red[buf][1][wv] = s2; }   // (double-buffered like the window: one barrier per row)
     __syncthreads();
-    const float m1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D;
-    const float m2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)D;
+    const float m1 = ((red[buf][0][0] + red[buf][0][1]) + (red[buf][0][2] + red[buf][0][3])) / (float)D;
+    const float m2 = ((red[buf][1][0] + red[buf][1][1]) + (red[buf][1][2] + red[buf][1][3])) / (float)D;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int f2 = fb + 8 * i;
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(256) void conv1_ln_bwd_kernel(const T* __restrict__
       for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
         for (int df = 0; df < 3; ++df) {
-          const float xv = xs[dt][2 * f2 + df];
+          const float xv = xs[buf][dt][2 * f2 + df];
           dw0[dt * 3 + df] += dy0 * xv; dw1[dt * 3 + df] += dy1 * xv;
         }
     }
