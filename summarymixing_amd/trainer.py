@@ -193,6 +193,8 @@ class FlatAdamW:
         if ev is not None:
             ev[1].record()
             self._exposed.append(ev)
+            if len(self._exposed) > 256:                   # (a long run keeps the most recent steps only)
+                del self._exposed[:128]
 
     def measure_comm(self, enable=True):
         """Record, from now on, how long the compute stream waits for the gradient collectives in every step."""
