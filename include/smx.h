@@ -402,7 +402,8 @@ int smx_log_softmax_bwd(int dtype, const void* dY, int64_t lddy, const void* Y, 
  *   bwd: grad[b,t,v] = gscale[b] * (exp(lp) - exp(log sum_{s: l'_s = v} alpha*beta/y + nll[b])), zero for t >= in_len[b]
  *        and for utterances with infinite nll (the convention of torch's ctc_loss backward: the gradient w.r.t. the
  *        unnormalised logits; pushing it through smx_log_softmax_bwd leaves it unchanged).  gscale[b] carries the
- *        reduction (1/B, 1/tgt_len, ...) times the upstream gradient.  Must follow smx_ctc_loss_fwd on the same workspace. */
+ *        reduction (1/B, 1/tgt_len, ...) times the upstream gradient.  Must follow smx_ctc_loss_fwd on the same workspace.
+ *        The per-label sums follow each label's occurrence chain in a fixed order: no atomics, bit-reproducible. */
 size_t smx_ctc_workspace(int B, int T, int Smax);
 int smx_ctc_loss_fwd(int dtype, const void* log_probs, int64_t ldlp, const int32_t* targets, const int32_t* in_len,
                      const int32_t* tgt_len, int B, int T, int V, int Smax, int blank, float* nll, void* workspace, void* stream);

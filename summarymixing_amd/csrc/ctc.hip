@@ -191,15 +191,38 @@ __global__ __launch_bounds__(256) void ctc_beta_kernel(const T* __restrict__ LP,
 // gradient w.r.t. the (log-softmax-normalised) inputs, torch.nn.functional.ctc_loss convention (Graves eq. 16):
 //   G[b,t,v] = gscale[b] * ( exp(lp[b,t,v]) - exp( log sum_{s: l'_s = v} occ[b,t,s] + nll[b] ) )
 // and 0 for t >= in_len[b] or when nll[b] is infinite (zero_infinity).  grid = B*Tmax rows, block = 256.
+// Occurrence chains of the target labels of one utterance (independent of t): first[k] = 1 when no k' < k carries the same
+// label, next[k] = the next k' > k with the same label or -1.  The gradient kernel sums the occupancies of a label along its
+// chain, ONE thread per label in increasing k: no atomics, bit-reproducible (round 3; LDS float atomics before).
+__global__ __launch_bounds__(256) void ctc_chain_kernel(const int* __restrict__ targets, int Smax, const int* __restrict__ tgt_len,
+                                                        int* __restrict__ chain) {
+  const int b = blockIdx.x, S = min(tgt_len[b], Smax);
+  const int* tg = targets + (long)b * Smax;
+  int* nxt = chain + (long)b * 2 * Smax;
+  int* first = nxt + Smax;
+  for (int k = threadIdx.x; k < S; k += 256) {
+    const int c = tg[k];
+    int n = -1, f = 1;
+    for (int j = k + 1; j < S; ++j)
+      if (tg[j] == c) { n = j; break; }
+    for (int j = 0; j < k; ++j)
+      if (tg[j] == c) { f = 0; break; }
+    nxt[k] = n;
+    first[k] = f;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ LP, long ldlp, int Tmax, int V,
                                                        const int* __restrict__ targets, int Smax,
                                                        const int* __restrict__ in_len, const int* __restrict__ tgt_len,
                                                        int blank, const float* __restrict__ occ, int Lmax,
                                                        const float* __restrict__ nll, const float* __restrict__ gscale,
-                                                       T* __restrict__ G, long ldg) {
-  extern __shared__ float acc[];                         // V floats + 4 (block max)
+                                                       const int* __restrict__ chain, T* __restrict__ G, long ldg) {
+  extern __shared__ float acc[];                         // V floats | Lmax floats (exp(occ - max) per state)
   __shared__ float redm[4];
+  __shared__ float redb[4];
+  float* es = acc + V;
   const int row = blockIdx.x, b = row / Tmax, t = row % Tmax;
   T* g = G + (long)row * ldg;
   const float nl = nll[b];
@@ -210,6 +233,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ LP,
   }
   const int S = min(tgt_len[b], Smax), L = 2 * S + 1;
   const int* tg = targets + (long)b * Smax;
+  const int* nxt = chain + (long)b * 2 * Smax;
+  const int* first = nxt + Smax;
   const float* oc = occ + ((long)b * Tmax + t) * Lmax;
   for (int v = threadIdx.x; v < V; v += 256) acc[v] = 0.f;
   float m = NEG_INF;
@@ -219,12 +244,30 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ LP,
   if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
   __syncthreads();
   m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  float bsum = 0.f;
   if (m > NEG_INF) {
     for (int s = threadIdx.x; s < L; s += 256) {
       const float o = oc[s];
-      if (o > NEG_INF) atomicAdd(&acc[state_label(tg, s, blank)], expf(o - m));
+      es[s] = o > NEG_INF ? expf(o - m) : 0.f;
     }
   }
+  __syncthreads();
+  if (m > NEG_INF) {
+    // blank states (even s): per-thread sums in increasing s, then a fixed-order fold
+    for (int s = 2 * threadIdx.x; s < L; s += 512) bsum += es[s];
+    bsum = wave_sum(bsum);
+    if ((threadIdx.x & 63) == 0) redb[threadIdx.x >> 6] = bsum;
+    // label states (odd s = 2 k + 1): the first occurrence of a label walks its chain
+    for (int k = threadIdx.x; k < S; k += 256) {
+      if (first[k]) {
+        float sum = es[2 * k + 1];
+        for (int j = nxt[k]; j >= 0; j = nxt[j]) sum += es[2 * j + 1];
+        acc[tg[k]] = sum;                                  // (a label equal to `blank` cannot occur in the targets)
+      }
+    }
+  }
+  __syncthreads();
+  if (m > NEG_INF && threadIdx.x == 0) acc[blank] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
   __syncthreads();
   const float sc = gscale[b];
   const T* lp = LP + (long)row * ldlp;
@@ -262,7 +305,11 @@ extern "C" int smx_log_softmax_bwd(int dtype, const void* dY, int64_t lddy, cons
 
 static int ctc_lmax(int Smax) { return 2 * Smax + 1; }
 
-extern "C" size_t smx_ctc_workspace(int B, int T, int Smax) { return (size_t)B * T * ctc_lmax(Smax) * sizeof(float); }
+// [forward / occupancy variables (B, T, Lmax) fp32][label occurrence chains (B, 2, Smax) int32]
+static size_t ctc_alpha_bytes(int B, int T, int Smax) { return ((size_t)B * T * ctc_lmax(Smax) * sizeof(float) + 15) / 16 * 16; }
+extern "C" size_t smx_ctc_workspace(int B, int T, int Smax) {
+  return ctc_alpha_bytes(B, T, Smax) + (size_t)B * 2 * (Smax > 0 ? Smax : 1) * sizeof(int);
+}
 
 extern "C" int smx_ctc_loss_fwd(int dtype, const void* log_probs, int64_t ldlp, const int32_t* targets, const int32_t* in_len,
                                 const int32_t* tgt_len, int B, int T, int V, int Smax, int blank, float* nll, void* workspace,
@@ -292,14 +339,17 @@ extern "C" int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, 
   if (B == 0) return SMX_OK;
   const size_t shm = 2 * (size_t)Lmax * sizeof(float);
   float* alpha = reinterpret_cast<float*>(workspace);
+  int* chain = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + ctc_alpha_bytes(B, T, Smax));
+  SMX_REQUIRE(((size_t)V + Lmax) * sizeof(float) <= 64 * 1024, "smx_ctc_loss_bwd: V + 2 Smax + 1 = %d floats do not fit the 64 KB of LDS", V + Lmax);
+  hipLaunchKernelGGL(ctc_chain_kernel, dim3(B), dim3(256), 0, STREAM, targets, Smax, tgt_len, chain);
 #define CTC_BETA(TT, KS_) hipLaunchKernelGGL((ctc_beta_kernel<TT, KS_>), dim3(B), dim3(256), shm, STREAM, (const TT*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax)
 #define CTC_BETA_T(TT) do { if (Lmax <= 256) CTC_BETA(TT, 1); else if (Lmax <= 512) CTC_BETA(TT, 2); else if (Lmax <= 1024) CTC_BETA(TT, 4); else if (Lmax <= 2048) CTC_BETA(TT, 8); else if (Lmax <= 4096) CTC_BETA(TT, 16); else CTC_BETA(TT, 32); } while (0)
   if (dtype == SMX_BF16) {
     CTC_BETA_T(bf16_t);
-    hipLaunchKernelGGL((ctc_grad_kernel<bf16_t>), dim3(B * T), dim3(256), (size_t)V * sizeof(float), STREAM, (const bf16_t*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll, gscale, (bf16_t*)grad, ldg);
+    hipLaunchKernelGGL((ctc_grad_kernel<bf16_t>), dim3(B * T), dim3(256), ((size_t)V + Lmax) * sizeof(float), STREAM, (const bf16_t*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll, gscale, chain, (bf16_t*)grad, ldg);
   } else {
     CTC_BETA_T(float);
-    hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(B * T), dim3(256), (size_t)V * sizeof(float), STREAM, (const float*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll, gscale, (float*)grad, ldg);
+    hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(B * T), dim3(256), ((size_t)V + Lmax) * sizeof(float), STREAM, (const float*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax, nll, gscale, chain, (float*)grad, ldg);
   }
 #undef CTC_BETA_T
 #undef CTC_BETA
