@@ -344,6 +344,18 @@ int smx_conv1_ln_bwd(int dtype, const void* dA, const void* X, const float* W9, 
 /* Y (N, M) = X (N, 16) W (M, 16)^T + bias: the first block's convolution (9 taps of one input channel in 16 columns) on
  * the VALU, bf16 in / out, fp32 accumulation; dense rows.  SMX_EUNSUPPORTED for other shapes (use smx_gemm). */
 int smx_linear_k16_fwd(int dtype, const void* X, const void* W, const float* bias, void* Y, int64_t N, int M, void* stream);
+/* The second block's convolution and its weight gradient WITHOUT the (rows, 9 C) patch matrix: the MFMA GEMM kernels gather
+ * their operand from the channels-last input X (B,T,F,C) themselves (one tap per K tile / column tile).  Built for bf16, C = 64
+ * (SMX_EUNSUPPORTED otherwise: smx_im2col_s2 + smx_gemm / smx_linear_wgrad).  Wg / dWg (O, Kp) GEMM layout (column
+ * (dt*3+df)*C + c); Y / dY (B*ceil(T/2)*ceil(F/2), O) dense.
+ *   fwd  : Y = conv(X) + bias
+ *   wgrad: dWg (fp32) += dY^T patches(X), dbias += column sums of dY; slab split-K + fixed-order reduction (`workspace` =
+ *          smx_conv2d_s2_wgrad_workspace bytes, 16-byte aligned). */
+int smx_conv2d_s2_fwd(int dtype, const void* X, const void* Wg, const float* bias, void* Y, int B, int T, int F, int C, int O,
+                      int Kp, void* stream);
+size_t smx_conv2d_s2_wgrad_workspace(int B, int T, int F, int C, int O);
+int smx_conv2d_s2_wgrad(int dtype, const void* dY, const void* X, float* dWg, float* dbias, int B, int T, int F, int C, int O,
+                        int Kp, void* workspace, void* stream);
 /* Direct input gradient of that convolution, without the (rows, 9 C) column matrix: dX (B,T,F,C) from dY
  * (B,ceil(T/2),ceil(F/2),O) and the GEMM-layout weight Wg (O, Kp) (column (dt*3+df)*C + c).  Built for the recipe's second
  * block (bf16, C = 64, O = 32; SMX_EUNSUPPORTED otherwise: use the dgrad GEMM + smx_col2im_s2).  MFMA, no atomics. */

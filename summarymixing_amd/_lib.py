@@ -118,6 +118,9 @@ SIGNATURES = {
     "smx_conv1_ln_fwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "smx_conv1_ln_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "smx_linear_k16_fwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_vp]),
+    "smx_conv2d_s2_fwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "smx_conv2d_s2_wgrad_workspace": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "smx_conv2d_s2_wgrad": (c_i, [c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_conv2d_s2_dgrad": (c_i, [c_i, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_axpby": (c_i, [c_i, c_f, c_vp, c_i64, c_f, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp]),
     "smx_dropout": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_f, ctypes.c_uint64, c_vp, c_vp]),

@@ -41,8 +41,13 @@ namespace smx {
 // LNF: 0 = ordinary epilogue; 1 = LayerNorm backward fused (SMX_EPI_LN_BWD; 3 = with its activation extensions),
 // 2 = LayerNorm forward appended (SMX_EPI_LN_FWD) - separate instantiations of the 128 x 256 bf16 kernel, so that their extra live registers never cost
 // the ordinary one anything.
-template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0>
+// GATHER (bf16, 64 x 64 tile): 1 = the A operand of an NT GEMM, 2 = the B operand of a TN GEMM is the implicit patch matrix of a
+// 3 x 3 / stride 2 convolution over 64 channels (GemmParams::g_*): the front-end's second block without im2col.
+template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0, int GATHER = 0>
 __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
+  static_assert(GATHER == 0 || (sizeof(T) == 2 && VEC && TILE_N == 64 && TILE_M == 64 && LNF == 0), "GATHER: bf16 64 x 64 tile");
+  static_assert(GATHER != 1 || (A_KC && B_KC), "GATHER 1: NT");
+  static_assert(GATHER != 2 || (!A_KC && !B_KC), "GATHER 2: TN");
   static_assert(LNF == 0 || (sizeof(T) == 2 && VEC && TILE_M == 256 && TILE_N == 128), "fused LayerNorm: bf16 128 x 256 tile");
   static_assert(LNF <= 3 || LNF == 5 || LNF == 7, "LNF: 1 / 3 LayerNorm backward (3: extended), 2 forward, +4 = float32 ln_x");
   constexpr int BK = ElemTraits<T>::BK;
@@ -113,16 +118,22 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   constexpr bool BUFLD = sizeof(T) == 2 && VEC && (SMX_BUFLD_WIDE || TILE_M <= 128);
   BufStage<T, A_KC, TILE_N> bufa;
   BufStage<T, B_KC, TILE_M> bufb;
+  GatherStageKC<GATHER == 1 ? TILE_N : 32> gka;
+  GatherStageKS<GATHER == 2 ? TILE_M : 32> gkb;
   if constexpr (BUFLD) {
-    bufa.init(A, p.lda, n0, p.N, p.K, t);
-    bufb.init(B, p.ldb, m0, p.M, p.K, t);
+    if constexpr (GATHER == 1) gka.init(p.A, p.g_npix, p, n0, t);
+    else bufa.init(A, p.lda, n0, p.N, p.K, t);
+    if constexpr (GATHER == 2) gkb.init(p.B, p.g_npix, m0, t);
+    else bufb.init(B, p.ldb, m0, p.M, p.K, t);
   }
   auto load_a = [&](uint4 (&reg)[TILE_N / 32], int k0) {
-    if constexpr (BUFLD) bufa.load(reg, k0);
+    if constexpr (GATHER == 1) gka.load(reg, k0, p);
+    else if constexpr (BUFLD) bufa.load(reg, k0);
     else stage_load<T, A_KC, TILE_N, VEC>(reg, A, p.lda, n0, p.N, k0, kend, t);
   };
   auto load_b = [&](uint4 (&reg)[TILE_M / 32], int k0) {
-    if constexpr (BUFLD) bufb.load(reg, k0);
+    if constexpr (GATHER == 2) gkb.load(reg, k0, kend, p);
+    else if constexpr (BUFLD) bufb.load(reg, k0);
     else stage_load<T, B_KC, TILE_M, VEC>(reg, B, p.ldb, m0, p.M, k0, kend, t);
   };
 
@@ -795,7 +806,9 @@ extern "C" void smx_debug_set_timing_buffer(void* p) { g_dbg_stamps = reinterpre
 static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,
                      int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K,
                      int batch, int splits, int64_t split_stride, const smx_epilogue* epi, void* stream,
-                     float* acolsum = nullptr) {
+                     float* acolsum = nullptr, const int* conv = nullptr) {
+  // conv = {T, F}: the K-contiguous operand A (NT) / the reduce-strided operand B (TN) is the implicit 3x3-stride-2 patch matrix
+  // of the channels-last tensor (batches, T, F, 64) behind that pointer (bf16, 64 channels: gemm_kernel<..., GATHER>)
   SMX_REQUIRE(A && B && C, "smx_gemm: null operand");
   SMX_REQUIRE(N >= 0 && M >= 0 && K >= 0 && batch >= 1 && splits >= 1, "smx_gemm: bad sizes N=%d M=%d K=%d", N, M, K);
   SMX_REQUIRE(dtype == SMX_F32 || dtype == SMX_BF16, "smx_gemm: bad dtype %d", dtype);
@@ -903,6 +916,23 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   p.drop_cols = p.e.drop_cols > 0 ? p.e.drop_cols : M;
   p.dscale = 1.f / (1.f - p.e.drop_p);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (conv) {
+    const long rows = layout == SMX_GEMM_NT ? N : K;      // patch rows = output pixels
+    p.g_T = conv[0]; p.g_F = conv[1]; p.g_T2 = (conv[0] + 1) / 2; p.g_F2 = (conv[1] + 1) / 2;
+    const long nb = rows / ((long)p.g_T2 * p.g_F2);
+    p.g_npix = nb * p.g_T * p.g_F;
+    SMX_REQUIRE(dtype == SMX_BF16 && vec && batch == 1 && rows == nb * p.g_T2 * p.g_F2 && p.g_npix * 128 < (1L << 31) &&
+                    (layout == SMX_GEMM_NT ? (K == 576 && splits == 1) : (layout == SMX_GEMM_TN && M == 576)),
+                "smx_gemm (implicit conv operand): bf16, 64 channels, whole batches of patch rows, input < 2 GB");
+    p.gather = layout == SMX_GEMM_NT ? 1 : 2;
+    p.tiles_n = (p.N + 63) / 64;
+    p.tiles_m = (p.M + 63) / 64;
+    dim3 grid(p.tiles_n * p.tiles_m, 1);
+    if (p.splits > 1) grid = dim3(8 * p.tiles_n * p.tiles_m * ((p.splits + 7) / 8), 1);
+    if (layout == SMX_GEMM_NT) hipLaunchKernelGGL((gemm_kernel<bf16_t, true, true, 64, 64, true, 0, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, 64, 64, true, 0, 2>), grid, dim3(256), 0, s, p);
+    return check_launch("smx_gemm (implicit conv operand)");
+  }
   if (dtype == SMX_BF16) return launch_dtype<bf16_t>(layout, p, vec, s);
   return launch_dtype<float>(layout, p, vec, s);
 }
@@ -1037,7 +1067,8 @@ extern "C" size_t smx_linear_wgrad_workspace(int rows, int M, int K, int batch) 
 
 // slabs (+ bias partials) only; shared by the immediate and the deferred entry point
 static int wgrad_slabs(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx, int64_t strideX,
-                       int rows, int M, int K, int batch, bool want_bias, float* ws, int* splits_out, void* stream) {
+                       int rows, int M, int K, int batch, bool want_bias, float* ws, int* splits_out, void* stream,
+                       const int* conv = nullptr) {
   smx_epilogue e;
   memset(&e, 0, sizeof(e));
   const int BK = dtype == SMX_BF16 ? 64 : 32;
@@ -1048,7 +1079,7 @@ static int wgrad_slabs(int dtype, const void* dZ, int64_t lddz, int64_t strideZ,
   float* bpart = want_bias ? ws + (long)splits * slab : nullptr;   // [splits][batch][M] behind the slabs
   *splits_out = splits;
   return gemm_impl(SMX_GEMM_TN, dtype, dZ, lddz, strideZ, X, ldx, strideX, ws, K, (int64_t)M * K, M, K, rows, batch, splits,
-                   slab, &e, stream, bpart);
+                   slab, &e, stream, bpart, conv);
 }
 
 extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,
@@ -1081,6 +1112,47 @@ extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws,
                      splits, slab, dW, lddw, strideW, M, K, batch, alpha, bpart, dbias);
   return check_launch("smx_linear_wgrad");
+}
+
+// ---- the front-end's second conv block (64 -> O channels, 3 x 3, stride 2, reflect pad 1) WITHOUT the patch matrix: the
+// GEMM kernels gather their operand from the channels-last input (gemm_kernel<..., GATHER>, one tap per K tile / column tile)
+extern "C" int smx_conv2d_s2_fwd(int dtype, const void* X, const void* Wg, const float* bias, void* Y, int B, int T, int F, int C,
+                                 int O, int Kp, void* stream) {
+  SMX_REQUIRE(X && Wg && Y && T >= 2 && F >= 2 && Kp >= 9 * C, "smx_conv2d_s2_fwd: bad arguments");
+  if (dtype != SMX_BF16 || C != 64 || O % 8 != 0) return fail(SMX_EUNSUPPORTED, "smx_conv2d_s2_fwd: built for bf16, C = 64, O %% 8 == 0");
+  if (B <= 0) return SMX_OK;
+  smx_epilogue e;
+  memset(&e, 0, sizeof(e));
+  e.alpha = 1.f;
+  e.bias = bias;
+  const int conv[2] = {T, F};
+  const long rows = (long)B * ((T + 1) / 2) * ((F + 1) / 2);
+  SMX_REQUIRE(rows < (1L << 31), "smx_conv2d_s2_fwd: too many output pixels");
+  return gemm_impl(SMX_GEMM_NT, dtype, X, 9 * C, 0, Wg, Kp, 0, Y, O, 0, (int)rows, O, 9 * C, 1, 1, 0, &e, stream, nullptr, conv);
+}
+extern "C" size_t smx_conv2d_s2_wgrad_workspace(int B, int T, int F, int C, int O) {
+  const long rows = (long)B * ((T + 1) / 2) * ((F + 1) / 2);
+  return smx_linear_wgrad_workspace((int)rows, O, 9 * C, 1);
+}
+extern "C" int smx_conv2d_s2_wgrad(int dtype, const void* dY, const void* X, float* dWg, float* dbias, int B, int T, int F, int C,
+                                   int O, int Kp, void* workspace, void* stream) {
+  SMX_REQUIRE(dY && X && dWg && workspace && aligned16(workspace) && T >= 2 && F >= 2 && Kp >= 9 * C, "smx_conv2d_s2_wgrad: bad arguments");
+  if (dtype != SMX_BF16 || C != 64 || O % 8 != 0) return fail(SMX_EUNSUPPORTED, "smx_conv2d_s2_wgrad: built for bf16, C = 64, O %% 8 == 0");
+  if (B <= 0) return SMX_OK;
+  const long rows = (long)B * ((T + 1) / 2) * ((F + 1) / 2);
+  const int conv[2] = {T, F}, K = 9 * C;
+  float* ws = reinterpret_cast<float*>(workspace);
+  int splits = 1;
+  int rc = wgrad_slabs(dtype, dY, O, 0, X, K, 0, (int)rows, O, K, 1, dbias != nullptr, ws, &splits, stream, conv);
+  if (rc != SMX_OK) return rc;
+  const long slab = (long)O * K;
+  float* bpart = dbias ? ws + (long)splits * slab : nullptr;
+  long total = (long)O * (K / 4) * (splits >= 16 ? 8 : 1);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ws, splits,
+                     slab, dWg, (long)Kp, (long)O * Kp, O, K, 1, 1.f, bpart, dbias);
+  return check_launch("smx_conv2d_s2_wgrad");
 }
 
 extern "C" int smx_linear_wgrad_partial(int dtype, const void* dZ, int64_t lddz, int64_t strideZ, const void* X, int64_t ldx,

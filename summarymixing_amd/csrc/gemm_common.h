@@ -30,6 +30,11 @@ struct GemmParams {
   int epi_simple;  // no element-wise side input, no column sums: the SIMPLE instantiation of epilogue_phase
   int reg_epi;  // epilogue without element-wise side inputs: math on the accumulator fragments, bf16 staging (gemm_kernel)
   int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
+  // implicit 3x3 / stride 2 / reflect-pad-1 patch matrix (gemm_kernel<..., GATHER>): the operand "rows x 9 C" is never
+  // materialised - row n = (b, t2, f2), columns [tap * 64, tap * 64 + 64) = the 64 channels of input pixel
+  // (reflect(2 t2 + dt - 1), reflect(2 f2 + df - 1)) of the channels-last tensor (B, g_T, g_F, 64)
+  int g_T, g_F, g_T2, g_F2, gather;   // gather: 0 none, 1 A operand (NT), 2 B operand (TN)
+  long g_npix;                        // B * g_T * g_F
 };
 
 template <typename T> struct ElemTraits;
@@ -152,6 +157,69 @@ struct BufStage {
     for (int i = 0; i < ROWS / 32; ++i) {
       typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
       const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i], soff, 0);
+      reg[i] = make_uint4(r.x, r.y, r.z, r.w);
+    }
+  }
+};
+
+// ---- implicit conv-patch operand (C = 64 channels = one tap per BK = 64 reduce elements / per 64-column tile) --------------
+__device__ __forceinline__ int gather_reflect(int i, int L) { return i < 0 ? -i : (i >= L ? 2 * (L - 1) - i : i); }
+// KC form (NT forward): the tile's ROWS patch rows, one 64-wide tap per K step.  Thread piece i: row v >> 3, 16-byte chunk v & 7.
+template <int ROWS>
+struct GatherStageKC {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int tt[ROWS / 32], ff[ROWS / 32], bb[ROWS / 32];      // 2 t2 - 1, 2 f2 - 1, b * T * F (pixels); bb < 0: row beyond N
+  uint32_t coff;
+  __device__ __forceinline__ void init(const void* base, long npix, const GemmParams& p, int row0, int t) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)(npix * 128), 0x00020000);
+    coff = (uint32_t)(t & 7) * 16;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int rg = row0 + ((t + 256 * i) >> 3);
+      const int f2 = rg % p.g_F2, r2 = rg / p.g_F2, t2 = r2 % p.g_T2, b = r2 / p.g_T2;
+      tt[i] = 2 * t2 - 1; ff[i] = 2 * f2 - 1;
+      bb[i] = rg < p.N ? b * p.g_T * p.g_F : -1;
+    }
+  }
+  __device__ __forceinline__ void load(uint4 (&reg)[ROWS / 32], int k0, const GemmParams& p) const {
+    const int tap = k0 >> 6, dt = tap / 3, df = tap - dt * 3;  // (uniform)
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int pix = bb[i] + gather_reflect(tt[i] + dt, p.g_T) * p.g_F + gather_reflect(ff[i] + df, p.g_F);
+      const uint32_t off = bb[i] >= 0 ? (uint32_t)pix * 128u + coff : 0x80000000u;
+      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+      const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+      reg[i] = make_uint4(r.x, r.y, r.z, r.w);
+    }
+  }
+};
+// reduce-strided form (TN weight gradient): the K rows of a stage are patch rows n = k0 + krow, the tile's 64 columns are ONE tap
+template <int ROWS>
+struct GatherStageKS {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int dt, df, krow[ROWS / 32];
+  uint32_t coff[ROWS / 32];
+  __device__ __forceinline__ void init(const void* base, long npix, int m0, int t) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)(npix * 128), 0x00020000);
+    const int tap = m0 >> 6;
+    dt = tap / 3; df = tap - dt * 3;
+    constexpr int RC = ROWS / 8;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int v = t + 256 * i;
+      krow[i] = v / RC;
+      coff[i] = (uint32_t)(v % RC) * 16;
+    }
+  }
+  __device__ __forceinline__ void load(uint4 (&reg)[ROWS / 32], int k0, int kend, const GemmParams& p) const {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int n = k0 + krow[i];
+      const int f2 = n % p.g_F2, r2 = n / p.g_F2, t2 = r2 % p.g_T2, b = r2 / p.g_T2;
+      const int pix = b * p.g_T * p.g_F + gather_reflect(2 * t2 - 1 + dt, p.g_T) * p.g_F + gather_reflect(2 * f2 - 1 + df, p.g_F);
+      const uint32_t off = n < kend ? (uint32_t)pix * 128u + coff[i] : 0x80000000u;
+      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+      const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
       reg[i] = make_uint4(r.x, r.y, r.z, r.w);
     }
   }

@@ -17,6 +17,7 @@ from ... import ops
 
 import os
 _FUSED_BLOCK1 = os.environ.get("SMX_CONV_FUSED_BLOCK1", "1") != "0"      # A/B knob: smx_conv1_ln_fwd / _bwd instead of im2col + Linear + LayerNorm
+_DIRECT_CONV2 = os.environ.get("SMX_CONV_DIRECT", "1") != "0"            # A/B knob: forward / wgrad GEMMs gather from the input, no im2col
 _DIRECT_DGRAD = os.environ.get("SMX_CONV_DIRECT_DGRAD", "1") != "0"      # A/B knob: smx_conv2d_s2_dgrad instead of GEMM + col2im
 
 
@@ -110,14 +111,20 @@ class ConvolutionFrontEnd(nn.Module):
                     saved.append(("fused1", x3, w9, st, seed, blk, bi))
                     h = a.view(B, T2, F2, blk.c_out)
                     continue
-                col = ops.im2col_s2(h, blk.kp)
                 # GEMM-layout weight (Cout, Kp): column (dt*3+df)*Cin + c  <- conv.weight (Cout, Cin, 3, 3)
                 wg = torch.zeros((blk.c_out, blk.kp), dtype=torch.float32, device=h.device)
                 wg[:, :9 * C] = blk.conv.weight.detach().permute(0, 2, 3, 1).reshape(blk.c_out, 9 * C)
                 wgc = ops.cast(wg, dtype)
-                y = ops.linear_k16(col, wgc, blk.conv.bias.detach()) if blk.kp == 16 else None   # first block: 9 taps, VALU
-                if y is None:
-                    y, _ = F.linear_fwd(col, wgc, blk.conv.bias.detach())                     # (B*T2*F2, Cout)
+                nocol = _DIRECT_CONV2 and ops.conv2d_s2_direct_ok(h, blk.c_out) and ops.conv2d_s2_dgrad_ok(h, C, blk.c_out, T_, F_)
+                if nocol:
+                    # second block without the (rows, 9 C) patch matrix: the GEMMs gather from h (forward, wgrad; dgrad direct)
+                    col = h
+                    y = ops.conv2d_s2_fwd(h, wgc, blk.conv.bias.detach(), blk.c_out)
+                else:
+                    col = ops.im2col_s2(h, blk.kp)
+                    y = ops.linear_k16(col, wgc, blk.conv.bias.detach()) if blk.kp == 16 else None   # first block: 9 taps, VALU
+                    if y is None:
+                        y, _ = F.linear_fwd(col, wgc, blk.conv.bias.detach())                     # (B*T2*F2, Cout)
                 yr = y.view(B * T2, F2 * blk.c_out)
                 a, ln_b = F.ln_fwd(yr, blk.norm.weight.view(-1), blk.norm.bias.view(-1), blk.norm.eps, need,
                                    L.ACT_LEAKY_RELU, wp=blk.norm.weight, bp=blk.norm.bias)
@@ -125,7 +132,7 @@ class ConvolutionFrontEnd(nn.Module):
                 if pd > 0.0:
                     seed = ops.new_dropout_seed()
                     ops.dropout(a, pd, seed, out=a)
-                saved.append((h.shape, col, wgc, ln_b, seed, blk, bi))
+                saved.append((h.shape, col, wgc, ln_b, seed, blk, bi if not nocol else -bi))
                 h = a.view(B, T2, F2, blk.c_out)
             if not need:
                 return h, None
@@ -156,6 +163,14 @@ class ConvolutionFrontEnd(nn.Module):
                         da = ops.dropout(da, pd, seed)
                     dy = ln_b(da).view(B * T2 * F2, blk.c_out)
                     gw = torch.zeros((blk.c_out, blk.kp), dtype=torch.float32, device=dy.device)
+                    if bi < 0:                                       # (saved without a patch matrix: col IS the block input)
+                        gb = F.gacc(blk.conv.bias)
+                        ops.conv2d_s2_wgrad(dy, col, gw, gb if gb is not None else torch.zeros(blk.c_out, device=dy.device))
+                        g = F.gacc(blk.conv.weight)
+                        if g is not None:
+                            g.add_(gw[:, :9 * C].view(blk.c_out, 3, 3, C).permute(0, 3, 1, 2))
+                        d = ops.conv2d_s2_dgrad(dy, wgc, B, T_, F_, C)
+                        continue
                     first = bi == 0
                     # the second block's input gradient comes from the direct kernel (no (rows, 9 C) gradient matrix, no col2im)
                     direct = (not first) and _DIRECT_DGRAD and ops.conv2d_s2_dgrad_ok(dy, C, blk.c_out, T_, F_)

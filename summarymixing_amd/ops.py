@@ -651,6 +651,35 @@ def linear_k16(x, W, bias):
     return y
 
 
+def conv2d_s2_direct_ok(x, O):
+    """Do the patch-matrix-free kernels (smx_conv2d_s2_fwd / _wgrad) take this block input x (B, T, F, C)?"""
+    B, T, F_, C = x.shape
+    return (x.dtype == torch.bfloat16 and x.is_contiguous() and C == 64 and O % 8 == 0 and T >= 2 and F_ >= 2
+            and x.numel() * 2 < (1 << 31) and x.data_ptr() % 16 == 0)
+
+
+def conv2d_s2_fwd(x, wg, bias, O):
+    """y (B*T2*F2, O) = conv3x3_s2_reflect(x) + bias with the GEMM gathering its operand from x (B,T,F,64) in place."""
+    B, T, F_, C = x.shape
+    rows = B * ((T + 1) // 2) * ((F_ + 1) // 2)
+    y = torch.empty((rows, O), dtype=x.dtype, device=x.device)
+    tok = _pb(f"conv2d_s2_fwd ({B},{T},{F_},{C})->{O}", x.numel() * 2 + y.numel() * 2, 2.0 * rows * O * 9 * C)
+    L.check(L.lib().smx_conv2d_s2_fwd(dt(x), _p(x), _p(wg), _p(bias), _p(y), B, T, F_, C, O, wg.shape[1], _stream()), "smx_conv2d_s2_fwd")
+    _pe(tok)
+    return y
+
+
+def conv2d_s2_wgrad(dy, x, gw, gbias):
+    """gw (O, Kp) fp32 += dy^T patches(x), gbias (O) += column sums of dy (slab split-K, fixed-order reduction)."""
+    B, T, F_, C = x.shape
+    O = dy.shape[1]
+    ws = _workspace(L.lib().smx_conv2d_s2_wgrad_workspace(B, T, F_, C, O), x.device, slot=6)
+    tok = _pb(f"conv2d_s2_wgrad ({B},{T},{F_},{C})->{O}", x.numel() * 2 + dy.numel() * 2, 2.0 * dy.shape[0] * O * 9 * C)
+    L.check(L.lib().smx_conv2d_s2_wgrad(dt(x), _p(dy), _p(x), _p(gw), _p(gbias), B, T, F_, C, O, gw.shape[1], _p(ws), _stream()),
+            "smx_conv2d_s2_wgrad")
+    _pe(tok)
+
+
 def conv2d_s2_dgrad_ok(dy, C, O, T, F_):
     """Does the direct dgrad kernel (smx_conv2d_s2_dgrad) take this block?  (bf16, 64 -> 32 channels: the recipe's second)"""
     return dy.dtype == torch.bfloat16 and C == 64 and O == 32 and T >= 4 and F_ >= 4 and dy.numel() * 2 < (1 << 31)

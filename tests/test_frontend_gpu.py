@@ -185,3 +185,35 @@ def test_fused_first_conv_block_matches_float64(B, T, Fq, dtype, tol):
     gr2 = ops.conv1_ln_bwd(daq, xq, w9, b.detach().float().cuda(), g.detach().float().cuda().view(-1),
                            be.detach().float().cuda().view(-1), st, L.ACT_LEAKY_RELU)
     assert torch.equal(gr, gr2)                                  # fixed-order reductions: bit-reproducible
+
+
+@pytest.mark.parametrize("B,T,Fq", [(2, 19, 40), (2, 20, 40), (1, 5, 4), (3, 4, 7), (1, 1001, 40), (4, 64, 38)])
+def test_patch_free_conv_forward_and_wgrad_match_float64(B, T, Fq):
+    """smx_conv2d_s2_fwd / _wgrad (the GEMM kernels gather the 3x3-stride-2 patches from the channels-last input: no im2col)
+    against the float64 convolution and its autograd weight / bias gradient; two wgrad runs are bit-identical."""
+    import torch.nn.functional as tF
+    from summarymixing_amd import ops
+    torch.manual_seed(3 * T + Fq)
+    C, O = 64, 32
+    T2, F2 = (T + 1) // 2, (Fq + 1) // 2
+    x = torch.randn(B, T, Fq, C).cuda().bfloat16()
+    W = (torch.randn(O, C, 3, 3) * 0.1).bfloat16()
+    bias = torch.randn(O) * 0.3
+    Wd = W.double().requires_grad_(True)
+    bd = bias.double().requires_grad_(True)
+    ref = tF.conv2d(tF.pad(x.double().cpu().permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect"), Wd, bd, stride=2).permute(0, 2, 3, 1)
+    wg = W.permute(0, 2, 3, 1).reshape(O, 9 * C).cuda().contiguous()
+    assert ops.conv2d_s2_direct_ok(x, O)
+    y = ops.conv2d_s2_fwd(x, wg, bias.cuda(), O)
+    assert rel_err(y.view(B, T2, F2, O), ref) <= 1e-2
+    dy = torch.randn(B * T2 * F2, O).cuda().bfloat16()
+    (ref * dy.double().cpu().view(B, T2, F2, O)).sum().backward()
+    outs = []
+    for _ in range(2):
+        gw, gb = torch.zeros(O, 9 * C, device="cuda"), torch.zeros(O, device="cuda")
+        ops.conv2d_s2_wgrad(dy, x, gw, gb)
+        torch.cuda.synchronize()
+        outs.append((gw.clone(), gb.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    gw_ref = Wd.grad.permute(0, 2, 3, 1).reshape(O, 9 * C)
+    assert rel_err(outs[0][0], gw_ref) <= 1e-3 and rel_err(outs[0][1], bd.grad) <= 1e-3
