@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S
     for (int f = lane; f < n_bins; f += 64) { const float re = s[f], im = s[im_off + f]; P[f] = re * re + im * im; }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes are visible to all its lanes
+    float fmx = -3.0e38f;
 #pragma unroll
     for (int k = 0; k < MPL; ++k) {
       const int m = lane + 64 * k;
@@ -76,12 +77,18 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S
         for (; j + 1 < wl; j += 2) { a0 += P[lo[k] + j] * bw[j]; a1 += P[lo[k] + j + 1] * bw[j + 1]; }
         if (j < wl) a0 += P[lo[k] + j] * bw[j];
         for (int f = lo[k] + MELW; f < hi[k]; ++f) a1 += P[f] * fr[f];
-        db[(long)n * n_mels + m] = 10.f * log10f(fmaxf(a0 + a1, amin));
+        const float dbv = 10.f * log10f(fmaxf(a0 + a1, amin));
+        db[(long)n * n_mels + m] = dbv;
+        fmx = fmaxf(fmx, dbv);
       }
     }
+    // the frame's maximum (the per-utterance top_db clamp needs max over the utterance: utt_max_kernel then reads one value per
+    // frame instead of n_mels)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fmx = fmaxf(fmx, __shfl_xor(fmx, off, 64));
+    if (lane == 0) bmax[n] = fmx;
     __builtin_amdgcn_wave_barrier();                     // (P is rewritten by the next frame)
   }
-  (void)bmax;
 }
 
 // umax[b] = max over the blocks of utterance b (blocks never straddle utterances when T % 4 == 0; otherwise the
@@ -625,7 +632,7 @@ extern "C" int smx_frame_window(const float* wav, int64_t ldw, const float* wind
 }
 
 extern "C" size_t smx_fbank_workspace(int B, int T, int n_mels) {
-  return ((size_t)B * T * n_mels + (size_t)(B * (long)T + 3) / 4 + B + 16) * sizeof(float);
+  return ((size_t)B * T * n_mels + (size_t)B * T + B + 16) * sizeof(float);   // dB values | one maximum per frame | one per utterance
 }
 
 extern "C" int smx_mel_db(int out_dtype, const float* spec, int64_t lds, int im_off, const float* fb, int n_bins, int n_mels,
@@ -635,13 +642,13 @@ extern "C" int smx_mel_db(int out_dtype, const float* spec, int64_t lds, int im_
   const int N = B * T;
   float* db = reinterpret_cast<float*>(workspace);
   float* bmax = db + (size_t)N * n_mels;
-  float* umax = bmax + (N + 3) / 4;
+  float* umax = bmax + N;
   SMX_REQUIRE(n_mels <= 256, "smx_mel_db: n_mels=%d > 256", n_mels);
   int mblocks = (N + 3) / 4;
   if (mblocks > 2048) mblocks = 2048;
   hipLaunchKernelGGL(mel_db_kernel, dim3(mblocks), dim3(256), (4 * n_bins + n_mels * 48) * sizeof(float), STREAM, spec, lds, im_off, fb, n_bins,
                      n_mels, amin, db, bmax, N);
-  hipLaunchKernelGGL(utt_max_kernel, dim3(B), dim3(256), 0, STREAM, db, T, n_mels, umax);
+  hipLaunchKernelGGL(utt_max_kernel, dim3(B), dim3(256), 0, STREAM, bmax, T, 1, umax);
   const long total = (long)N * n_mels;
   if (out_dtype == SMX_BF16) hipLaunchKernelGGL((topdb_clamp_kernel<bf16_t>), dim3(fgrid(total)), dim3(256), 0, STREAM, db, umax, top_db, (bf16_t*)out, (long)T * n_mels, total);
   else hipLaunchKernelGGL((topdb_clamp_kernel<float>), dim3(fgrid(total)), dim3(256), 0, STREAM, db, umax, top_db, (float*)out, (long)T * n_mels, total);
