@@ -321,6 +321,13 @@ int smx_dwconv1d_glu_bwd(int dtype, const void* dY, int64_t lddy, const void* P,
  *   smx_im2col_s2 : x (B,T,F,C) -> col (B*ceil(T/2)*ceil(F/2), Kp), column (dt*3+df)*C + c, zero beyond 9*C
  *   conv          : smx_gemm(NT) col x W^T + bias, then smx_layernorm_fwd over (F2*Cout) with fused LeakyReLU
  *   smx_col2im_s2 : backward of im2col (gather form, no atomics). */
+/* The same DFT without the frame matrix and at half the reduction length: frames are rows of the zero-padded waveform
+ * (wav_padded (B, ldw): n_fft / 2 zeros in front, frame t of utterance b = samples [t hop, t hop + n_fft)), the (symmetric) window is
+ * folded into the bases, and the real DFT is split into its cosine part on s[j] = x[j] + x[n - j] (basis_cos (rows_basis, n/2 + 4):
+ * window[j] cos(2 pi k j / n) for j <= n/2, zero behind) and its sine part on d[j] = x[j] - x[n - j] (basis_sin (rows_basis, n/2):
+ * -window[j] sin(2 pi k j / n)); s and d are formed inside the GEMM's operand loader.  spec (B*T, lds): re at column k, im at im_off + k. */
+int smx_dft_frames(const float* wav_padded, int64_t ldw, const float* basis_cos, const float* basis_sin, float* spec, int64_t lds,
+                   int im_off, int B, int T, int n_fft, int hop, int rows_basis, void* stream);
 int smx_frame_window(const float* wav, int64_t ldw, const float* window, float* frames, int B, int L, int T, int n_fft,
                      int hop, void* stream);
 size_t smx_fbank_workspace(int B, int T, int n_mels);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "smx_dwconv1d_glu_bwd_partial_rows": (c_i, [c_i] * 9),
     "smx_dwconv1d_glu_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                    c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
+    "smx_dft_frames": (c_i, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_frame_window": (c_i, [c_vp, c_i64, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "smx_fbank_workspace": (c_sz, [c_i, c_i, c_i]),
     "smx_mel_db": (c_i, [c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_f, c_f, c_vp, c_i, c_i, c_vp, c_vp]),

@@ -45,7 +45,8 @@ namespace smx {
 // 3 x 3 / stride 2 convolution over 64 channels (GemmParams::g_*): the front-end's second block without im2col.
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0, int GATHER = 0>
 __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
-  static_assert(GATHER == 0 || (sizeof(T) == 2 && VEC && TILE_N == 64 && TILE_M == 64 && LNF == 0), "GATHER: bf16 64 x 64 tile");
+  static_assert(GATHER == 0 || GATHER >= 3 || (sizeof(T) == 2 && VEC && TILE_N == 64 && TILE_M == 64 && LNF == 0), "GATHER 1 / 2: bf16 64 x 64 tile");
+  static_assert(GATHER < 3 || (sizeof(T) == 4 && A_KC && B_KC && LNF == 0), "GATHER 3 / 4 (folded DFT frames): float32 NT");
   static_assert(GATHER != 1 || (A_KC && B_KC), "GATHER 1: NT");
   static_assert(GATHER != 2 || (!A_KC && !B_KC), "GATHER 2: TN");
   static_assert(LNF == 0 || (sizeof(T) == 2 && VEC && TILE_M == 256 && TILE_N == 128), "fused LayerNorm: bf16 128 x 256 tile");
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   }
   auto load_a = [&](uint4 (&reg)[TILE_N / 32], int k0) {
     if constexpr (GATHER == 1) gka.load(reg, k0, p);
+    else if constexpr (GATHER >= 3) fold_stage_load<GATHER, TILE_N>(reg, reinterpret_cast<const float*>(A), p.lda, n0, p.N, k0, p.g_T, t);
     else if constexpr (BUFLD) bufa.load(reg, k0);
     else stage_load<T, A_KC, TILE_N, VEC>(reg, A, p.lda, n0, p.N, k0, kend, t);
   };
@@ -916,6 +918,20 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   p.drop_cols = p.e.drop_cols > 0 ? p.e.drop_cols : M;
   p.dscale = 1.f / (1.f - p.e.drop_p);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (conv && conv[0] < 0) {
+    // folded DFT frames: conv = {-3 | -4, n_fft}; A = zero-padded waveform rows (lda = hop), float32 NT, batch = utterances
+    SMX_REQUIRE(dtype == SMX_F32 && layout == SMX_GEMM_NT && splits == 1 && conv[1] % 8 == 0 &&
+                    K == (conv[0] == -3 ? conv[1] / 2 + 4 : conv[1] / 2) && lda % 4 == 0 && aligned16(A),
+                "smx_gemm (folded DFT operand): float32 NT, K = n_fft / 2 (+ 4 for the cosine part)");
+    p.g_T = conv[1];
+    p.gather = -conv[0];
+    p.tiles_n = (p.N + 127) / 128;
+    p.tiles_m = (p.M + 127) / 128;
+    dim3 grid(p.tiles_n * p.tiles_m, p.batch);
+    if (conv[0] == -3) hipLaunchKernelGGL((gemm_kernel<float, true, true, 128, 128, true, 0, 3>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<float, true, true, 128, 128, true, 0, 4>), grid, dim3(256), 0, s, p);
+    return check_launch("smx_gemm (folded DFT operand)");
+  }
   if (conv) {
     const long rows = layout == SMX_GEMM_NT ? N : K;      // patch rows = output pixels
     p.g_T = conv[0]; p.g_F = conv[1]; p.g_T2 = (conv[0] + 1) / 2; p.g_F2 = (conv[1] + 1) / 2;
@@ -1116,6 +1132,25 @@ extern "C" int smx_linear_wgrad(int dtype, const void* dZ, int64_t lddz, int64_t
 
 // ---- the front-end's second conv block (64 -> O channels, 3 x 3, stride 2, reflect pad 1) WITHOUT the patch matrix: the
 // GEMM kernels gather their operand from the channels-last input (gemm_kernel<..., GATHER>, one tap per K tile / column tile)
+// DFT of overlapping frames of a zero-padded waveform, window folded into the bases (symmetric window): see fold_stage_load
+extern "C" int smx_dft_frames(const float* wav_padded, int64_t ldw, const float* basis_cos, const float* basis_sin, float* spec,
+                              int64_t lds, int im_off, int B, int T, int n_fft, int hop, int rows_basis, void* stream) {
+  SMX_REQUIRE(wav_padded && basis_cos && basis_sin && spec && n_fft % 8 == 0 && hop % 4 == 0 && rows_basis % 4 == 0 &&
+                  rows_basis <= im_off && lds >= im_off + rows_basis && lds % 4 == 0 && ldw % 4 == 0 && ldw >= (int64_t)(T - 1) * hop + n_fft + 4,
+              "smx_dft_frames: bad arguments");
+  if (B <= 0 || T <= 0) return SMX_OK;
+  smx_epilogue e;
+  memset(&e, 0, sizeof(e));
+  e.alpha = 1.f;
+  const int kc = n_fft / 2 + 4, ks = n_fft / 2;
+  const int cv[2] = {-3, n_fft}, sv[2] = {-4, n_fft};
+  int rc = gemm_impl(SMX_GEMM_NT, SMX_F32, wav_padded, hop, ldw, basis_cos, kc, 0, spec, lds, (int64_t)T * lds, T, rows_basis, kc, B, 1, 0,
+                     &e, stream, nullptr, cv);
+  if (rc != SMX_OK) return rc;
+  return gemm_impl(SMX_GEMM_NT, SMX_F32, wav_padded, hop, ldw, basis_sin, ks, 0, spec + im_off, lds, (int64_t)T * lds, T, rows_basis, ks, B, 1,
+                   0, &e, stream, nullptr, sv);
+}
+
 extern "C" int smx_conv2d_s2_fwd(int dtype, const void* X, const void* Wg, const float* bias, void* Y, int B, int T, int F, int C,
                                  int O, int Kp, void* stream) {
   SMX_REQUIRE(X && Wg && Y && T >= 2 && F >= 2 && Kp >= 9 * C, "smx_conv2d_s2_fwd: bad arguments");

@@ -225,6 +225,37 @@ struct GatherStageKS {
   }
 };
 
+// ---- folded DFT operand (float32 NT): the real DFT of a windowed frame x[0..n) with a symmetric window needs only
+//   s[j] = x[j] + x[n - j] (cosine part, j = 0..n/2, the two end points alone) and d[j] = x[j] - x[n - j] (sine part, j = 1..n/2-1):
+// two GEMMs of half the reduction length instead of one over n.  The A tile is built from TWO 16-byte loads of the frame (one
+// of them walking backwards from x[n - j]) while it passes through the registers; frames are rows of the zero-padded waveform
+// (leading dimension = hop).  MODE 3 = s (columns >= n/2 + 1 are zero), MODE 4 = d (column 0 is zero).
+template <int MODE, int ROWS>
+__device__ __forceinline__ void fold_stage_load(uint4 (&reg)[ROWS / 32], const float* base, long ld, int row0, int rows_total,
+                                                int k0, int nfft, int t) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int half = nfft >> 1;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int v = t + 256 * i, row = v >> 3, k4 = v & 7;
+    const int rg = row0 + row, kg = k0 + k4 * 4;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rg < rows_total && kg <= (MODE == 3 ? half : half - 1)) {
+      const float* xr = base + (long)rg * ld;
+      const f4u a = *reinterpret_cast<const f4u*>(xr + kg);
+      const f4u b = *reinterpret_cast<const f4u*>(xr + nfft - kg - 3);       // x[n - j] for j = kg + 3 .. kg
+      const float pa[4] = {a.x, a.y, a.z, a.w}, pb[4] = {b.w, b.z, b.y, b.x};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = kg + e;
+        if (MODE == 3) o[e] = j > half ? 0.f : ((j == 0 || j == half) ? pa[e] : pa[e] + pb[e]);
+        else o[e] = (j == 0 || j >= half) ? 0.f : pa[e] - pb[e];
+      }
+    }
+    reg[i] = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+  }
+}
+
 // ---- registers -> LDS image -----------------------------------------------------------------------------
 template <typename T, bool KC, int ROWS>
 __device__ __forceinline__ void stage_store(const uint4 (&reg)[ROWS / 32], char* lds, int t) {

@@ -14,6 +14,7 @@ from .. import ops
 
 
 import os
+_FOLDED_DFT = os.environ.get("SMX_FBANK_FOLDED_DFT", "1") != "0"              # A/B knob: cosine / sine halves of half the length
 _IMPLICIT_FRAMES = os.environ.get("SMX_FBANK_IMPLICIT_FRAMES", "1") != "0"   # A/B knob: the DFT GEMM reads the waveform in place
 
 
@@ -43,6 +44,16 @@ class Fbank(nn.Module):
         # and the GEMM reads them in place (leading dimension = hop), no (B*T, n_fft) frame matrix is written
         win64 = torch.hamming_window(self.win, dtype=torch.float64)
         self.register_buffer("basis_w", (basis * win64[None, :]).float(), persistent=False)
+        # ... and, the window being symmetric (w[j] = w[n - j]), the real DFT in two halves of half the length: the cosine part on
+        # x[j] + x[n - j] (j = 0 .. n/2), the sine part on x[j] - x[n - j]; both sums are formed inside the GEMM's operand loader
+        half = n_fft // 2
+        self.fold = bool(torch.allclose(win64[1:], win64[1:].flip(0))) and n_fft % 8 == 0
+        bc = torch.zeros(self.im_off, half + 4, dtype=torch.float64)
+        bc[:n_bins, :half + 1] = torch.cos(ang[:, :half + 1]) * win64[None, :half + 1]
+        bs = torch.zeros(self.im_off, half, dtype=torch.float64)
+        bs[:n_bins] = -torch.sin(ang[:, :half]) * win64[None, :half]
+        self.register_buffer("basis_cos", bc.float().contiguous(), persistent=False)
+        self.register_buffer("basis_sin", bs.float().contiguous(), persistent=False)
         # HTK-mel triangular filters (n_mels, n_bins)
         f_max = sample_rate / 2 if f_max is None else f_max
         to_mel = lambda hz: 2595.0 * math.log10(1.0 + hz / 700.0)
@@ -63,12 +74,15 @@ class Fbank(nn.Module):
         if _IMPLICIT_FRAMES and self.hop % 4 == 0:
             # center=True: n_fft/2 zeros on both sides; frame t of utterance b = samples [t*hop, t*hop + n_fft) of the padded row
             half = self.n_fft // 2
-            Lp = (Lw + self.n_fft + 3) // 4 * 4
+            Lp = (Lw + self.n_fft + 4 + 3) // 4 * 4
             wp = torch.zeros((B, Lp), dtype=torch.float32, device=wav.device)
             wp[:, half:half + Lw] = wav
             M = self.basis.shape[0]
-            ops.gemm(L.GEMM_NT, wp[0, :self.n_fft].view(1, -1), self.basis_w, spec[:T], T, M, self.n_fft, batch=B, sa=Lp, sb=0,
-                     sc=T * M, lda=self.hop)
+            if self.fold and _FOLDED_DFT:
+                ops.dft_frames(wp, self.basis_cos, self.basis_sin, spec, self.im_off, B, T, self.n_fft, self.hop)
+            else:
+                ops.gemm(L.GEMM_NT, wp[0, :self.n_fft].view(1, -1), self.basis_w, spec[:T], T, M, self.n_fft, batch=B, sa=Lp, sb=0,
+                         sc=T * M, lda=self.hop)
         else:
             frames = ops.frame_window(wav.contiguous(), self.window, T, self.n_fft, self.hop)
             ops.gemm(L.GEMM_NT, frames, self.basis, spec, B * T, self.basis.shape[0], self.n_fft)

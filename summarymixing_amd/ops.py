@@ -602,6 +602,15 @@ def im2col_s2(x, Kp):
     return col
 
 
+def dft_frames(wav_padded, basis_cos, basis_sin, spec, im_off, B, T, n_fft, hop):
+    """spec (B*T, lds) <- DFT of the overlapping frames of the zero-padded waveform rows (smx_dft_frames: no frame matrix, folded
+    cosine / sine halves)."""
+    tok = _pb(f"dft_frames ({B},{T}) n_fft={n_fft}", wav_padded.numel() * 4 + spec.numel() * 4, 2.0 * B * T * n_fft * (n_fft / 2 + 1))
+    L.check(L.lib().smx_dft_frames(_p(wav_padded), wav_padded.stride(0), _p(basis_cos), _p(basis_sin), _p(spec), spec.stride(0), im_off,
+                                   B, T, n_fft, hop, basis_cos.shape[0], _stream()), "smx_dft_frames")
+    _pe(tok)
+
+
 def conv1_ln_ok(x, O):
     """Does the fused first conv block (smx_conv1_ln_fwd / _bwd) take this input?  x (B, T, F) contiguous, one input channel."""
     B, T, F_ = x.shape
