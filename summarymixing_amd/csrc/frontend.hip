@@ -43,15 +43,23 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S
   float* P = pw + w * n_bins;
   float* band = pw + 4 * n_bins;
   constexpr int MPL = 4;                               // filters per lane (n_mels <= 256)
+  // band limits of every filter, found by the whole workgroup with coalesced row reads (a lane walking its own filter row was
+  // 2 x 257 uncoalesced loads per lane and workgroup: most of this kernel's 0.5 ms)
+  __shared__ int slo[256], shi[256];
+  for (int m = threadIdx.x; m < 256; m += 256) { slo[m] = n_bins; shi[m] = 0; }
+  __syncthreads();
+  for (int m = 0; m < n_mels; ++m)
+    for (int f = threadIdx.x; f < n_bins; f += 256)
+      if (fb[(long)m * n_bins + f] != 0.f) { atomicMin(&slo[m], f); atomicMax(&shi[m], f + 1); }
+  __syncthreads();
   int lo[MPL], hi[MPL];
 #pragma unroll
   for (int k = 0; k < MPL; ++k) {
     const int m = lane + 64 * k;
     lo[k] = n_bins; hi[k] = 0;
     if (m < n_mels) {
+      lo[k] = slo[m]; hi[k] = shi[m];
       const float* fr = fb + (long)m * n_bins;
-      for (int f = 0; f < n_bins; ++f)
-        if (fr[f] != 0.f) { lo[k] = min(lo[k], f); hi[k] = f + 1; }
       // the band's weights are the same for every frame: once into LDS (a global load per tap and frame made this kernel
       // latency-bound: 845 us for 256 000 frames)
       if (w == 0)
