@@ -48,12 +48,6 @@ class Fbank(nn.Module):
         # x[j] + x[n - j] (j = 0 .. n/2), the sine part on x[j] - x[n - j]; both sums are formed inside the GEMM's operand loader
         half = n_fft // 2
         self.fold = bool(torch.allclose(win64[1:], win64[1:].flip(0))) and n_fft % 8 == 0
-        bc = torch.zeros(self.im_off, half + 4, dtype=torch.float64)
-        bc[:n_bins, :half + 1] = torch.cos(ang[:, :half + 1]) * win64[None, :half + 1]
-        bs = torch.zeros(self.im_off, half, dtype=torch.float64)
-        bs[:n_bins] = -torch.sin(ang[:, :half]) * win64[None, :half]
-        self.register_buffer("basis_cos", bc.float().contiguous(), persistent=False)
-        self.register_buffer("basis_sin", bs.float().contiguous(), persistent=False)
         # HTK-mel triangular filters (n_mels, n_bins)
         f_max = sample_rate / 2 if f_max is None else f_max
         to_mel = lambda hz: 2595.0 * math.log10(1.0 + hz / 700.0)
@@ -64,6 +58,18 @@ class Fbank(nn.Module):
         slope = (freqs[None, :] - hz[1:-1][:, None]) / band[:, None]
         self.register_buffer("fb", torch.clamp(torch.minimum(slope + 1.0, -slope + 1.0), min=0.0).float().contiguous(),
                              persistent=False)
+        # the Nyquist bin carries no weight in any mel filter (the last triangle ends exactly at f_max = sample_rate / 2): without
+        # it the bases have n_fft / 2 = 256 rows = exactly two 128-row GEMM tiles instead of three
+        fbm = torch.clamp(torch.minimum(slope + 1.0, -slope + 1.0), min=0.0)
+        self.drop_nyquist = bool(self.fold and n_bins == half + 1 and half % 128 == 0 and float(fbm[:, -1].abs().max()) == 0.0)
+        rows = half if self.drop_nyquist else self.im_off
+        bc = torch.zeros(rows, half + 4, dtype=torch.float64)
+        bc[:min(n_bins, rows), :half + 1] = (torch.cos(ang[:, :half + 1]) * win64[None, :half + 1])[:rows]
+        bs = torch.zeros(rows, half, dtype=torch.float64)
+        bs[:min(n_bins, rows)] = (-torch.sin(ang[:, :half]) * win64[None, :half])[:rows]
+        self.register_buffer("basis_cos", bc.float().contiguous(), persistent=False)
+        self.register_buffer("basis_sin", bs.float().contiguous(), persistent=False)
+        self.register_buffer("fb_nn", fbm[:, :half].float().contiguous(), persistent=False)     # filters without the Nyquist column
 
     def forward(self, wav, out_dtype=torch.float32):
         """wav (B, L) float32 on the GPU -> (B, 1 + L // hop, n_mels)."""
@@ -80,6 +86,8 @@ class Fbank(nn.Module):
             M = self.basis.shape[0]
             if self.fold and _FOLDED_DFT:
                 ops.dft_frames(wp, self.basis_cos, self.basis_sin, spec, self.im_off, B, T, self.n_fft, self.hop)
+                if self.drop_nyquist:                           # (column n_fft / 2 of spec was not computed and is not read)
+                    return ops.mel_db(spec, self.im_off, self.fb_nn, B, T, self.amin, self.top_db, out_dtype)
             else:
                 ops.gemm(L.GEMM_NT, wp[0, :self.n_fft].view(1, -1), self.basis_w, spec[:T], T, M, self.n_fft, batch=B, sa=Lp, sb=0,
                          sc=T * M, lda=self.hop)

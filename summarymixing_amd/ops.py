@@ -638,7 +638,7 @@ def conv1_ln_bwd(da, x, w9, bias, gamma, beta, stats, act):
     O = w9.shape[0]
     D = (F_ // 2) * O
     grads = torch.zeros(2 * D + O * 10, dtype=torch.float32, device=x.device)
-    ws = _workspace(L.lib().smx_conv1_ln_workspace(B, T, F_, O), x.device, slot=5)
+    ws = _workspace(L.lib().smx_conv1_ln_workspace(B, T, F_, O), x.device, slot=7)
     tok = _pb(f"conv1_ln_bwd ({B},{T},{F_})->{O}", da.numel() * _es(da) + x.numel() * _es(x))
     L.check(L.lib().smx_conv1_ln_bwd(dt(x), _p(da), _p(x), _p(w9), _p(bias), _p(gamma), _p(beta), _p(stats), act, _p(grads), _p(ws),
                                      B, T, F_, O, _stream()), "smx_conv1_ln_bwd")
