@@ -81,7 +81,9 @@ class Fbank(nn.Module):
             # center=True: n_fft/2 zeros on both sides; frame t of utterance b = samples [t*hop, t*hop + n_fft) of the padded row
             half = self.n_fft // 2
             Lp = (Lw + self.n_fft + 4 + 3) // 4 * 4
-            wp = torch.zeros((B, Lp), dtype=torch.float32, device=wav.device)
+            wp = torch.empty((B, Lp), dtype=torch.float32, device=wav.device)   # (only the two margins are zero-filled)
+            wp[:, :half] = 0.0
+            wp[:, half + Lw:] = 0.0
             wp[:, half:half + Lw] = wav
             M = self.basis.shape[0]
             if self.fold and _FOLDED_DFT:
