@@ -697,6 +697,193 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
+#ifndef SMX_LN_WG8_UF
+#define SMX_LN_WG8_UF 2        // rows in flight per workgroup, forward
+#endif
+#ifndef SMX_LN_WG8_UB
+#define SMX_LN_WG8_UB 1        // ... backward (one row: 100 registers, the whole grid resident; 32000 x 1536: 115 -> 92 us with two rows, 62 us with one)
+#endif
+#ifndef SMX_LN_WG8_FBLOCKS
+#define SMX_LN_WG8_FBLOCKS 2048
+#endif
+#ifndef SMX_LN_WG8_FROM
+#define SMX_LN_WG8_FROM 1024   // rows wider than this (and <= 2048, bf16) take the workgroup-per-row kernels
+#endif
+// ---- mid-width rows (1024 < D <= 2048, bf16; the CSGU LayerNorm over 1536 channels of the Branchformer's cgMLP) ----------------
+// One WORKGROUP per row, thread t owns the 8 consecutive columns 8 t (one 16-byte access per tensor and row), U rows in flight
+// per iteration, workgroups stride over the rows; gamma / beta (and the dgamma / dbeta partial sums) of the thread's columns live
+// in registers for the whole kernel.  The wave-per-row kernels above need 8 chunks of 4 columns per lane at this width: 128
+// parameter registers per lane (backward: 256 VGPRs = ONE wave per SIMD with one 9 KB row in flight: 2.45 TB/s; forward: every
+// one of the 8192 waves fetched its own 12 KB of gamma / beta for ~4 rows of 3 KB: 2.2 TB/s; tools/step_records.py c4).
+__device__ __forceinline__ void ld8_bf16(const bf16_t* p, float (&f)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void st8_bf16(bf16_t* p, const float (&f)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+__device__ __forceinline__ void ld8_f32(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+// sums of U values per thread over the workgroup (4 waves): wave shuffles, then 4 partials per value through LDS
+template <int U>
+__device__ __forceinline__ void wg_sum(float (&v)[U], float (*red)[4], int lane, int w) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] += __shfl_xor(v[u], off, 64);
+  if (lane == 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) red[u][w] = v[u];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < U; ++u) v[u] = (red[u][0] + red[u][1]) + (red[u][2] + red[u][3]);
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void layernorm_fwd_wg8_kernel(const bf16_t* __restrict__ X, long ldx, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, bf16_t* __restrict__ Y, long ldy,
+                                                                float* __restrict__ stats, int N_, int D, float eps, int act) {
+  __shared__ float red[2][U][4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = t * 8;
+  const bool in = c < D;
+  float gam[8], bet[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { gam[j] = in ? gamma[c + j] : 0.f; bet[j] = in ? beta[c + j] : 0.f; }
+  const float invD = 1.f / (float)D;
+  dispatch_act(act, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    for (int row0 = blockIdx.x * U; row0 < N_; row0 += gridDim.x * U) {
+      float f[U][8], s[U], q[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = min(row0 + u, N_ - 1);            // tail rows re-read the last row (results discarded)
+        if (in) ld8_bf16(X + (long)row * ldx + c, f[u]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[u][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) s[u] = ((f[u][0] + f[u][1]) + (f[u][2] + f[u][3])) + ((f[u][4] + f[u][5]) + (f[u][6] + f[u][7]));
+      wg_sum<U>(s, red[0], lane, w);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        s[u] *= invD;                                      // mean
+        q[u] = 0.f;
+        if (in) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = f[u][j] - s[u]; q[u] += d * d; }
+        }
+      }
+      wg_sum<U>(q, red[1], lane, w);                       // (red[0] is rewritten only after this barrier: no race)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + u;
+        if (row >= N_) break;
+        const float rstd = rsqrtf(q[u] * invD + eps);
+        if (stats && t == 0) *reinterpret_cast<float2*>(stats + 2 * (long)row) = make_float2(s[u], rstd);
+        if (in) {
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = act_fwd_c<ACT>((f[u][j] - s[u]) * rstd * gam[j] + bet[j]);
+          st8_bf16(Y + (long)row * ldy + c, o);
+        }
+      }
+    }
+  });
+}
+
+// backward (see layernorm_bwd_kernel for the formulas); TX = float: the LayerNorm input is the fp32 residual stream
+template <int U, typename TX>
+__global__ __launch_bounds__(256) void layernorm_bwd_wg8_kernel(const bf16_t* __restrict__ dY, long lddy, const TX* __restrict__ X, long ldx,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                                const float* __restrict__ stats, const bf16_t* __restrict__ R, long ldr,
+                                                                bf16_t* __restrict__ dX, long lddx, float* __restrict__ partial, int N_, int D) {
+  __shared__ float red[2][2 * U][4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = t * 8;
+  const bool in = c < D;
+  float gam[8], bet[8], dg[8], db[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    gam[j] = in ? gamma[c + j] : 0.f;
+    bet[j] = (in && act != SMX_ACT_NONE) ? beta[c + j] : 0.f;
+    dg[j] = db[j] = 0.f;
+  }
+  const float invD = 1.f / (float)D;
+  int it = 0;
+  dispatch_act(act, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    for (int row0 = blockIdx.x * U; row0 < N_; row0 += gridDim.x * U, ++it) {
+      float g[U][8], xh[U][8], rr[U][8], mean[U], rstd[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = min(row0 + u, N_ - 1);
+        mean[u] = stats[2 * (long)row];
+        rstd[u] = stats[2 * (long)row + 1];
+        if (in) {
+          ld8_bf16(dY + (long)row * lddy + c, g[u]);
+          if constexpr (sizeof(TX) == 4) ld8_f32(reinterpret_cast<const float*>(X) + (long)row * ldx + c, xh[u]);
+          else ld8_bf16(reinterpret_cast<const bf16_t*>(X) + (long)row * ldx + c, xh[u]);
+          if (R) ld8_bf16(R + (long)row * ldr + c, rr[u]);
+        }
+        if (!in || !R) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rr[u][j] = 0.f;
+        }
+        if (!in) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[u][j] = xh[u][j] = 0.f;
+        }
+      }
+      float ss[2 * U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool rok = row0 + u < N_ && in;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xhat = rok ? (xh[u][j] - mean[u]) * rstd[u] : 0.f;
+          float dyn = rok ? g[u][j] : 0.f;
+          if constexpr (ACT != SMX_ACT_NONE) dyn *= act_grad_c<ACT>(xhat * gam[j] + bet[j]);
+          const float gg = dyn * gam[j];
+          xh[u][j] = xhat;
+          g[u][j] = gg;
+          s1 += gg;
+          s2 += gg * xhat;
+          dg[j] += dyn * xhat;
+          db[j] += dyn;
+        }
+        ss[2 * u] = s1; ss[2 * u + 1] = s2;
+      }
+      wg_sum<2 * U>(ss, red[it & 1], lane, w);             // (alternating buffers: ONE barrier per iteration)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + u;
+        if (row >= N_) break;
+        if (in) {
+          const float m1 = ss[2 * u] * invD, m2 = ss[2 * u + 1] * invD;
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = rstd[u] * (g[u][j] - m1 - xh[u][j] * m2) + rr[u][j];
+          st8_bf16(dX + (long)row * lddx + c, o);
+        }
+      }
+    }
+  });
+  if (in) {                                                // ONE partial row pair per workgroup (fixed-order reduction downstream)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      partial[((long)blockIdx.x * 2) * D + c + j] = dg[j];
+      partial[((long)blockIdx.x * 2 + 1) * D + c + j] = db[j];
+    }
+  }
+}
+
 // wide rows (2048 < D <= 4096, e.g. the (F,C) = 40x64 LayerNorm of the conv front-end): one WORKGROUP per row at a
 // time, thread t owns columns t + 256*i; row statistics through an LDS reduction; same partial-row flush as above.
 template <typename T, int CH>
@@ -1308,6 +1495,13 @@ extern "C" int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const fl
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
   auto ok = [&](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) % (4 * es)) == 0 && ld % 4 == 0; };
   const bool vec = D % 4 == 0 && ok(X, ldx) && ok(Y, ldy) && aligned16(gamma) && aligned16(beta);
+  if (vec && dtype == SMX_BF16 && D > SMX_LN_WG8_FROM && D <= 2048 && D % 8 == 0 && aligned16(X) && aligned16(Y) && ldx % 8 == 0 && ldy % 8 == 0) {
+    // mid-width rows: one workgroup per row, 16-byte accesses (layernorm_fwd_wg8_kernel)
+    int blocks = (N + SMX_LN_WG8_UF - 1) / SMX_LN_WG8_UF;
+    if (blocks > SMX_LN_WG8_FBLOCKS) blocks = SMX_LN_WG8_FBLOCKS;
+    hipLaunchKernelGGL((layernorm_fwd_wg8_kernel<SMX_LN_WG8_UF>), dim3(blocks), dim3(256), 0, STREAM, (const bf16_t*)X, ldx, gamma, beta, (bf16_t*)Y, ldy, stats, N, D, eps, act);
+    return check_launch("smx_layernorm_fwd");
+  }
   if (vec && D <= 2048) {
     const int ch = (D + 255) / 256;
     const int U = ch <= 1 ? 4 : (ch <= 2 ? 2 : 1);
@@ -1349,13 +1543,19 @@ extern "C" int smx_layernorm_fwd_x32(int dtype, const float* X, int64_t ldx, con
   return check_launch("smx_layernorm_fwd_x32");
 }
 
+#ifndef SMX_LNB_BLOCKS
+#define SMX_LNB_BLOCKS 1024
+#endif
 static int ln_bwd_blocks(int N) {
   int blocks = (N + 7) / 8;
-  return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+  return blocks > SMX_LNB_BLOCKS ? SMX_LNB_BLOCKS : (blocks < 1 ? 1 : blocks);
 }
 
 #ifndef SMX_LNB_U1
 #define SMX_LNB_U1 2      // rows in flight per wave for D <= 256
+#endif
+#ifndef SMX_LNB_U2
+#define SMX_LNB_U2 1      // ... for 256 < D <= 512 (104 registers = 4 waves per SIMD = the whole 1024-block grid resident; two rows in flight: 75 -> 62 us at 64000 x 512, tools/rowkernels_bench.py)
 #endif
 template <typename T>
 static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma, const float* beta,
@@ -1367,7 +1567,16 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
   if (sec.dX2 && D > 2048) return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd2: the second output needs D <= 2048");
   const int blocks = ln_bwd_blocks(N);
   dim3 grid(blocks);
-#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH, (VW == 4 && CH == 1 ? SMX_LNB_U1 : (CH <= 2 ? 2 : 1))>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D, sec)
+  if constexpr (sizeof(T) == 2) {
+    auto ok16 = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % 16) == 0 && ld % 8 == 0); };
+    if (vec && !sec.dX2 && D > SMX_LN_WG8_FROM && D <= 2048 && D % 8 == 0 && ok16(dY, lddy) && ok16(X, ldx) && ok16(R, ldr) && ok16(dX, lddx)) {
+      hipLaunchKernelGGL((layernorm_bwd_wg8_kernel<SMX_LN_WG8_UB, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, gamma, beta, act, stats,
+                         (const bf16_t*)R, ldr, (bf16_t*)dX, lddx, partial, N, D);
+      if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
+      return check_launch("smx_layernorm_bwd");
+    }
+  }
+#define LN_BWD(VW, CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, VW, CH, (VW == 4 && CH == 1 ? SMX_LNB_U1 : (CH <= 2 ? SMX_LNB_U2 : 1))>), grid, dim3(256), 0, s, (const T*)dY, lddy, (const T*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D, sec)
   if (vec) {
     if (D <= 256) LN_BWD(4, 1);
     else if (D <= 512) LN_BWD(4, 2);
@@ -1426,7 +1635,16 @@ extern "C" int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, c
   dim3 grid(blocks);
   float* partial = reinterpret_cast<float*>(workspace);
   hipStream_t s = STREAM;
-#define LN_BWDX(CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4, CH, (CH == 1 ? SMX_LNB_U1 : (CH <= 2 ? 2 : 1)), float>), grid, dim3(256), 0, s, (const T*)dY, lddy, X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D, sec)
+  {
+    auto ok16 = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % 16) == 0 && ld % 8 == 0); };
+    if (!dX2 && D > SMX_LN_WG8_FROM && D % 8 == 0 && ok16(dY, lddy) && ldx % 8 == 0 && ok16(R, ldr) && ok16(dX, lddx)) {
+      hipLaunchKernelGGL((layernorm_bwd_wg8_kernel<SMX_LN_WG8_UB, float>), grid, dim3(256), 0, s, (const bf16_t*)dY, lddy, X, ldx, gamma, beta, act, stats,
+                         (const bf16_t*)R, ldr, (bf16_t*)dX, lddx, partial, N, D);
+      if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
+      return check_launch("smx_layernorm_bwd2_x32");
+    }
+  }
+#define LN_BWDX(CH) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4, CH, (CH == 1 ? SMX_LNB_U1 : (CH <= 2 ? SMX_LNB_U2 : 1)), float>), grid, dim3(256), 0, s, (const T*)dY, lddy, X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D, sec)
   if (D <= 256) LN_BWDX(1); else if (D <= 512) LN_BWDX(2); else if (D <= 1024) LN_BWDX(4); else LN_BWDX(8);
 #undef LN_BWDX
   if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);

@@ -82,7 +82,8 @@ def test_gemm_strided_views_and_batch(dtype, tol):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
-@pytest.mark.parametrize("D", [256, 144, 30, 512, 2560, 3332, 4096, 2050])   # > 2048: the wide-row kernels (front-end: 40 x 64)
+@pytest.mark.parametrize("D", [256, 144, 30, 512, 2560, 3332, 4096, 2050,     # > 2048: the wide-row kernels (front-end: 40 x 64)
+                               1536, 1032, 2048])                              # 1024 < D <= 2048: workgroup-per-row kernels (bf16)
 def test_layernorm_fwd_bwd(D, dtype, tol):
     L, ops = _ops()
     torch.manual_seed(D)
@@ -104,6 +105,32 @@ def test_layernorm_fwd_bwd(D, dtype, tol):
         dx = ops.layernorm_bwd(dy, x, g, b, stats, dg, db, res, act)
         assert rel_err(dx, xr.grad + res.double()) <= 2 * tol
         assert rel_err(dg, gr.grad) <= 3 * tol and rel_err(db, br.grad) <= 3 * tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [256, 512, 1536, 2048, 200])
+def test_layernorm_of_the_float32_stream(D):
+    """LayerNorm(float32 row) -> bf16 output, and its backward with bf16 gradients next to the float32 input
+    (smx_layernorm_fwd_x32 / smx_layernorm_bwd2_x32: the fp32 residual stream of a bf16 model), every row-width class."""
+    L, ops = _ops()
+    torch.manual_seed(D)
+    N = 1001
+    bf = torch.bfloat16
+    x = torch.randn(N, D, device="cuda") * 2 + 0.5
+    g = torch.randn(D, device="cuda") * 0.3 + 1
+    b = torch.randn(D, device="cuda") * 0.3
+    y, stats = ops.layernorm_fwd(x, g, b, 1e-5, True, out_dtype=bf)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    assert y.dtype == bf and rel_err(y, ref) <= 1e-2
+    dy = torch.randn(N, D, device="cuda").to(bf)
+    res = torch.randn(N, D, device="cuda").to(bf)
+    (ref * dy.double()).sum().backward()
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dx = ops.layernorm_bwd(dy, x, g, b, stats, dg, db, res)
+    assert dx.dtype == bf and rel_err(dx, xr.grad + res.double()) <= 2e-2
+    assert rel_err(dg, gr.grad) <= 3e-2 and rel_err(db, br.grad) <= 3e-2
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])

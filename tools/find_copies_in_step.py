@@ -31,8 +31,16 @@ with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, tor
     step()
     torch.cuda.synchronize()
 cnt = collections.Counter()
+stacks = collections.Counter()
 for ev in prof.events():
     cnt[ev.name] += 1
+    if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy", "aten::fill_", "aten::zero_") and ev.stack:
+        own = [fr for fr in ev.stack if "/repo/" in fr and "find_copies" not in fr][:3]
+        stacks[(ev.name, " <- ".join(own))] += 1
+print("# host-side copy / fill calls of one step by the repo frames that issued them")
+for (n, st), c in stacks.most_common(40):
+    print(f"{c:5d}  {n:18s} {st}")
+print("# all event names")
 for n, c in cnt.most_common(60):
     if not n.startswith("void smx") and "smx::" not in n:
         print(f"{c:5d}  {n[:110]}")
