@@ -284,6 +284,15 @@ int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, const float*
                            const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
                            int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2,
                            float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, const uint64_t* epoch, void* stream);
+/* LayerNorm backward THROUGH the activation that produced the LayerNorm's input: X = zact(Z) (Z the saved pre-activation),
+ *   dZ = zact'(Z) * LNbwd(dY)                      (act must be SMX_ACT_NONE: a LayerNorm without a fused activation of its own)
+ * - the CSGU of the Branchformer's cgMLP normalises the gate half of GELU(channel_proj1(x)) (Branchformer.py:84-96 via the
+ * upstream ConvolutionalSpatialGatingUnit), so the gradient of that half reaches channel_proj1's dZ without the separate
+ * activation-backward pass over it.  bf16, D <= 2048, D % 8 == 0, 16-byte aligned rows (else SMX_EUNSUPPORTED: run
+ * smx_layernorm_bwd + smx_act_mask_bwd).  dgamma / dbeta as in smx_layernorm_bwd (NULL: partial rows stay in `workspace`). */
+int smx_layernorm_bwd_preact(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
+                             const float* beta, int act, const float* stats, const void* Z, int64_t ldz, int zact,
+                             void* dX, int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* stream);
 
 /* Fused GLU + depthwise Conv1d over time (Conformer.py:131-145,317-325):
  *   u[b,t,c] = P[b,t,c] * sigmoid(P[b,t,D+c]);  Y[b,t,c] = bias[c] + sum_j w[c,j] u[b,t+j-(k-1)/2,c]

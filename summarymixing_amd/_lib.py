@@ -96,6 +96,8 @@ SIGNATURES = {
     "smx_layernorm_fwd_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "smx_layernorm_bwd2_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                      c_vp, c_i, c_i, c_vp, c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp, c_vp]),
+    "smx_layernorm_bwd_preact": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_i, c_vp, c_i64,
+                                       c_vp, c_vp, c_i, c_i, c_vp, c_vp]),
     "smx_layernorm_bwd_workspace": (c_sz, [c_i, c_i]),
     "smx_layernorm_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                 c_vp, c_i, c_i, c_vp, c_vp]),

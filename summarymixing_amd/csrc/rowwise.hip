@@ -700,9 +700,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #ifndef SMX_LN_WG8_UF
 #define SMX_LN_WG8_UF 2        // rows in flight per workgroup, forward
 #endif
-#ifndef SMX_LN_WG8_UB
-#define SMX_LN_WG8_UB 1        // ... backward (one row: 100 registers, the whole grid resident; 32000 x 1536: 115 -> 92 us with two rows, 62 us with one)
-#endif
 #ifndef SMX_LN_WG8_FBLOCKS
 #define SMX_LN_WG8_FBLOCKS 2048
 #endif
@@ -798,15 +795,34 @@ __global__ __launch_bounds__(256) void layernorm_fwd_wg8_kernel(const bf16_t* __
   });
 }
 
-// backward (see layernorm_bwd_kernel for the formulas); TX = float: the LayerNorm input is the fp32 residual stream
-template <int U, typename TX>
-__global__ __launch_bounds__(256) void layernorm_bwd_wg8_kernel(const bf16_t* __restrict__ dY, long lddy, const TX* __restrict__ X, long ldx,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                                const float* __restrict__ stats, const bf16_t* __restrict__ R, long ldr,
-                                                                bf16_t* __restrict__ dX, long lddx, float* __restrict__ partial, int N_, int D) {
-  __shared__ float red[2][2 * U][4];
+// backward (see layernorm_bwd_kernel for the formulas); TX = float: the LayerNorm input is the fp32 residual stream.
+// Software-pipelined over the rows of the workgroup: the operands of row i + 1 are requested before row i is reduced, and stay
+// PACKED (the 16 bytes as loaded) until they are consumed - 4 registers per bf16 tensor and row instead of 8, unpacked once for
+// the row sums and once more for the outputs.  With one row in flight and nothing prefetched the kernel ran at the latency
+// bound of 4 workgroups x 9 KB per CU (4.7 TB/s plain, 3.6 TB/s with the extra Z stream of PRE).
+// PRE (smx_layernorm_bwd_preact): the LayerNorm input is X = zact(Z); the kernel then emits the gradient w.r.t. Z,
+// dX * zact'(Z), from the registers that hold dX - the consumer's activation-backward pass over this tensor is gone.
+template <typename TX>
+struct LnRaw {
+  uint4 dy, r, z;
+  uint4 x0, x1;                                            // (bf16 x: x0 only)
+  float mean, rstd;
+};
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <bool PRE, typename TX>
+__global__ __launch_bounds__(256, 4) void layernorm_bwd_wg8_kernel(const bf16_t* __restrict__ dY, long lddy, const TX* __restrict__ X, long ldx,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                                   const float* __restrict__ stats, const bf16_t* __restrict__ R, long ldr,
+                                                                   bf16_t* __restrict__ dX, long lddx, float* __restrict__ partial, int N_, int D,
+                                                                   const bf16_t* __restrict__ Zp, long ldz, int zact) {
+  __shared__ float red[2][2][4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = t * 8;
   const bool in = c < D;
+  const int cc = in ? c : 0;                               // (idle threads re-read column 0; their results are masked)
   float gam[8], bet[8], dg[8], db[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -815,66 +831,89 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wg8_kernel(const bf16_t* __
     dg[j] = db[j] = 0.f;
   }
   const float invD = 1.f / (float)D;
-  int it = 0;
-  dispatch_act(act, [&](auto act_tag) {
+  auto fetch = [&](int row, LnRaw<TX>& q) {
+    q.mean = stats[2 * (long)row];
+    q.rstd = stats[2 * (long)row + 1];
+    q.dy = *reinterpret_cast<const uint4*>(dY + (long)row * lddy + cc);
+    if constexpr (sizeof(TX) == 4) {
+      const float* xp = reinterpret_cast<const float*>(X) + (long)row * ldx + cc;
+      q.x0 = *reinterpret_cast<const uint4*>(xp);
+      q.x1 = *reinterpret_cast<const uint4*>(xp + 4);
+    } else {
+      q.x0 = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(X) + (long)row * ldx + cc);
+    }
+    if constexpr (!PRE) {
+      if (R) q.r = *reinterpret_cast<const uint4*>(R + (long)row * ldr + cc);   // (uniform; the PRE variant has no residual gradient)
+    }
+    if constexpr (PRE) q.z = *reinterpret_cast<const uint4*>(Zp + (long)row * ldz + cc);
+  };
+  auto xhat8 = [&](const LnRaw<TX>& q, float (&xh)[8]) {
+    if constexpr (sizeof(TX) == 4) {
+      const uint32_t wv[8] = {q.x0.x, q.x0.y, q.x0.z, q.x0.w, q.x1.x, q.x1.y, q.x1.z, q.x1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xh[j] = (__uint_as_float(wv[j]) - q.mean) * q.rstd;
+    } else {
+      unpack8(q.x0, xh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xh[j] = (xh[j] - q.mean) * q.rstd;
+    }
+  };
+  auto body = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
-    for (int row0 = blockIdx.x * U; row0 < N_; row0 += gridDim.x * U, ++it) {
-      float g[U][8], xh[U][8], rr[U][8], mean[U], rstd[U];
+    LnRaw<TX> cur, nxt;
+    int row = blockIdx.x, it = 0;
+    if (row < N_) fetch(row, cur);
+    for (; row < N_; row += gridDim.x, ++it) {
+      const int rn = row + gridDim.x;
+      if (rn < N_) fetch(rn, nxt);                         // the next row is in flight while this one is reduced
+      float g[8], xh[8];
+      unpack8(cur.dy, g);
+      xhat8(cur, xh);
+      float ss[2] = {0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int row = min(row0 + u, N_ - 1);
-        mean[u] = stats[2 * (long)row];
-        rstd[u] = stats[2 * (long)row + 1];
-        if (in) {
-          ld8_bf16(dY + (long)row * lddy + c, g[u]);
-          if constexpr (sizeof(TX) == 4) ld8_f32(reinterpret_cast<const float*>(X) + (long)row * ldx + c, xh[u]);
-          else ld8_bf16(reinterpret_cast<const bf16_t*>(X) + (long)row * ldx + c, xh[u]);
-          if (R) ld8_bf16(R + (long)row * ldr + c, rr[u]);
-        }
-        if (!in || !R) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) rr[u][j] = 0.f;
-        }
-        if (!in) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) g[u][j] = xh[u][j] = 0.f;
-        }
+      for (int j = 0; j < 8; ++j) {
+        float dyn = in ? g[j] : 0.f;
+        if constexpr (ACT != SMX_ACT_NONE) dyn *= act_grad_c<ACT>(xh[j] * gam[j] + bet[j]);
+        const float xq = in ? xh[j] : 0.f;
+        const float gg = dyn * gam[j];
+        ss[0] += gg;
+        ss[1] += gg * xq;
+        dg[j] += dyn * xq;
+        db[j] += dyn;
       }
-      float ss[2 * U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool rok = row0 + u < N_ && in;
-        float s1 = 0.f, s2 = 0.f;
+      wg_sum<2>(ss, red[it & 1], lane, w);                 // (alternating buffers: ONE barrier per row)
+      if (in) {
+        const float m1 = ss[0] * invD, m2 = ss[1] * invD;
+        float o[8];
+        unpack8(cur.dy, g);                                // (unpacked again instead of kept: 16 registers less across the barrier)
+        xhat8(cur, xh);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float xhat = rok ? (xh[u][j] - mean[u]) * rstd[u] : 0.f;
-          float dyn = rok ? g[u][j] : 0.f;
-          if constexpr (ACT != SMX_ACT_NONE) dyn *= act_grad_c<ACT>(xhat * gam[j] + bet[j]);
-          const float gg = dyn * gam[j];
-          xh[u][j] = xhat;
-          g[u][j] = gg;
-          s1 += gg;
-          s2 += gg * xhat;
-          dg[j] += dyn * xhat;
-          db[j] += dyn;
+          float dyn = g[j];
+          if constexpr (ACT != SMX_ACT_NONE) dyn *= act_grad_c<ACT>(xh[j] * gam[j] + bet[j]);
+          o[j] = cur.rstd * (dyn * gam[j] - m1 - xh[j] * m2);
         }
-        ss[2 * u] = s1; ss[2 * u + 1] = s2;
-      }
-      wg_sum<2 * U>(ss, red[it & 1], lane, w);             // (alternating buffers: ONE barrier per iteration)
+        if constexpr (!PRE) {
+          if (R) {
+            float rr[8];
+            unpack8(cur.r, rr);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int row = row0 + u;
-        if (row >= N_) break;
-        if (in) {
-          const float m1 = ss[2 * u] * invD, m2 = ss[2 * u + 1] * invD;
-          float o[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = rstd[u] * (g[u][j] - m1 - xh[u][j] * m2) + rr[u][j];
-          st8_bf16(dX + (long)row * lddx + c, o);
+            for (int j = 0; j < 8; ++j) o[j] += rr[j];
+          }
         }
+        if constexpr (PRE) {
+          float zz[8];
+          unpack8(cur.z, zz);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] *= act_grad(zact, zz[j]);
+        }
+        st8_bf16(dX + (long)row * lddx + c, o);
       }
+      cur = nxt;
     }
-  });
+  };
+  if constexpr (PRE) body(ActTag<SMX_ACT_NONE>{});           // (the PRE entry point takes a plain LayerNorm only: one instantiation, no spills)
+  else dispatch_act(act, body);
   if (in) {                                                // ONE partial row pair per workgroup (fixed-order reduction downstream)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1570,8 +1609,8 @@ static int ln_bwd_impl(const void* dY, int64_t lddy, const void* X, int64_t ldx,
   if constexpr (sizeof(T) == 2) {
     auto ok16 = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % 16) == 0 && ld % 8 == 0); };
     if (vec && !sec.dX2 && D > SMX_LN_WG8_FROM && D <= 2048 && D % 8 == 0 && ok16(dY, lddy) && ok16(X, ldx) && ok16(R, ldr) && ok16(dX, lddx)) {
-      hipLaunchKernelGGL((layernorm_bwd_wg8_kernel<SMX_LN_WG8_UB, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, gamma, beta, act, stats,
-                         (const bf16_t*)R, ldr, (bf16_t*)dX, lddx, partial, N, D);
+      hipLaunchKernelGGL((layernorm_bwd_wg8_kernel<false, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, gamma, beta, act, stats,
+                         (const bf16_t*)R, ldr, (bf16_t*)dX, lddx, partial, N, D, (const bf16_t*)nullptr, 0, SMX_ACT_NONE);
       if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
       return check_launch("smx_layernorm_bwd");
     }
@@ -1638,8 +1677,8 @@ extern "C" int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, c
   {
     auto ok16 = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % 16) == 0 && ld % 8 == 0); };
     if (!dX2 && D > SMX_LN_WG8_FROM && D % 8 == 0 && ok16(dY, lddy) && ldx % 8 == 0 && ok16(R, ldr) && ok16(dX, lddx)) {
-      hipLaunchKernelGGL((layernorm_bwd_wg8_kernel<SMX_LN_WG8_UB, float>), grid, dim3(256), 0, s, (const bf16_t*)dY, lddy, X, ldx, gamma, beta, act, stats,
-                         (const bf16_t*)R, ldr, (bf16_t*)dX, lddx, partial, N, D);
+      hipLaunchKernelGGL((layernorm_bwd_wg8_kernel<false, float>), grid, dim3(256), 0, s, (const bf16_t*)dY, lddy, X, ldx, gamma, beta, act, stats,
+                         (const bf16_t*)R, ldr, (bf16_t*)dX, lddx, partial, N, D, (const bf16_t*)nullptr, 0, SMX_ACT_NONE);
       if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
       return check_launch("smx_layernorm_bwd2_x32");
     }
@@ -1655,6 +1694,28 @@ extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const 
                                  float* dbeta, int N, int D, void* workspace, void* stream) {
   return smx_layernorm_bwd2(dtype, dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, workspace, nullptr, 0,
                             1.f, nullptr, 0.f, 0, nullptr, stream);
+}
+
+// dZ = zact'(Z) * (LayerNorm backward of dY), for a LayerNorm whose input is X = zact(Z) (the CSGU norm of the cgMLP: X = the gate
+// half of GELU(channel_proj1(.)), Branchformer.py:84-96 of the reference's ConvolutionBranch).  bf16, D <= 2048, D % 8 == 0,
+// 16-byte aligned rows; dgamma / dbeta NULL = the partial rows stay in the workspace (smx_layernorm_bwd_workspace bytes).
+extern "C" int smx_layernorm_bwd_preact(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
+                                        const float* beta, int act, const float* stats, const void* Z, int64_t ldz, int zact,
+                                        void* dX, int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* stream) {
+  SMX_REQUIRE(dY && X && gamma && beta && stats && Z && dX && workspace && D > 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
+              "smx_layernorm_bwd_preact: bad arguments");
+  if (N == 0) return SMX_OK;
+  auto ok16 = [&](const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0 && ld % 8 == 0; };
+  if (act != SMX_ACT_NONE) return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd_preact: a LayerNorm without a fused activation of its own");
+  if (dtype != SMX_BF16 || D > 2048 || D % 8 != 0 || !ok16(dY, lddy) || !ok16(X, ldx) || !ok16(Z, ldz) || !ok16(dX, lddx))
+    return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd_preact: needs bf16, D <= 2048, D %% 8 == 0 and 16-byte aligned rows");
+  const int blocks = ln_bwd_blocks(N);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipStream_t s = STREAM;
+  hipLaunchKernelGGL((layernorm_bwd_wg8_kernel<true, bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)dY, lddy, (const bf16_t*)X, ldx, gamma, beta,
+                     act, stats, (const bf16_t*)nullptr, 0, (bf16_t*)dX, lddx, partial, N, D, (const bf16_t*)Z, ldz, zact);
+  if (dgamma) hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, s, partial, blocks, D, dgamma, dbeta);
+  return check_launch("smx_layernorm_bwd_preact");
 }
 
 extern "C" int smx_layernorm_bwd_blocks(int N) { return ln_bwd_blocks(N); }

@@ -816,11 +816,23 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None, pre=None, o
     else:
         y, stats = ops.layernorm_fwd(x, w.detach(), b.detach(), eps, need_bwd, act, out_dtype=out_dtype)
 
-    def bwd(dy, res=None, out=None, second=None):
+    def bwd(dy, res=None, out=None, second=None, preact=None):
         """second = (alpha, mask, drop): also return alpha * D(dx) * mask, what the NEXT backward block applies first to
-        this gradient (its `pre` attribute) - written from the same registers instead of by a separate pass."""
+        this gradient (its `pre` attribute) - written from the same registers instead of by a separate pass.
+        preact = (z, zact): x = zact(z); return the gradient w.r.t. z (check ops.layernorm_bwd_preact_ok first)."""
         gw = gacc(wp).view(-1) if wp is not None else gacc(w)
         gb = gacc(bp).view(-1) if bp is not None else gacc(b)
+        if preact is not None:
+            assert res is None and second is None
+            N, D = x.shape
+            if _Deferred.enabled and gw is not None and gb is not None:
+                ws = deferred_ws(gw.data_ptr(), L.lib().smx_layernorm_bwd_workspace(N, D), x.device)
+                dz = ops.layernorm_bwd_preact(dy, x, w.detach(), b.detach(), stats, preact[0], preact[1], None, None, act, ws=ws, dx_out=out)
+                nb = L.lib().smx_layernorm_bwd_blocks(N)
+                defer(ws.data_ptr(), gw, 2 * D, nb, 1, D)
+                defer(ws.data_ptr() + 4 * D, gb, 2 * D, nb, 1, D)
+                return dz
+            return ops.layernorm_bwd_preact(dy, x, w.detach(), b.detach(), stats, preact[0], preact[1], gw, gb, act, dx_out=out)
         wide2 = None
         if second is not None and x.shape[1] > 2048:       # the fused second output exists for D <= 2048: do it in separate
             wide2, second = second, None                   # passes, but ALWAYS return the pair the caller unpacks (ADVICE r02)

@@ -8,6 +8,7 @@ BranchformerEncoderLayer :100-334, BranchformerEncoder :337-491) for attention_t
   CSGU(u)  = u1 * dwconv_reflect(LN(u2))                      (upstream ConvolutionalSpatialGatingUnit)
 The concatenation is never materialised: both branches write into the two column halves of one buffer.
 """
+import os
 from typing import Optional
 
 import torch
@@ -21,6 +22,8 @@ from ....nnet.activations import act_code
 from ....nnet.summary_mixing import SummaryMixing
 from ...models.VanillaNN import VanillaNN
 from .Conformer import _LayerNorm
+
+_PREACT_LN = os.environ.get("SMX_PREACT_LN", "1") != "0"   # A/B knob: channel_proj1's activation backward inside the CSGU LayerNorm backward
 
 
 class _CSGUConv(nn.Module):
@@ -173,8 +176,15 @@ class BranchformerEncoderLayer(nn.Module):
                 du = torch.empty_like(u)                   # [d gate | d LN input]: both kernels write their half directly
                 dv, _ = F.dwconv_bwd_deferred(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T,
                                               n, k, False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])
-                bnv(dv, out=du[:, n:])
-                dh2, _ = F.linear_bwd(du, h2, Wpre, zu, act, None, 1.0, F.gacc(Pb["Wpre"]), F.gacc(Pb["bpre"]))
+                if _PREACT_LN and zu is not None and act != L.ACT_NONE and bnv.spec["act"] == L.ACT_NONE and ops.layernorm_bwd_preact_ok(dv, u2, zu[:, n:], du[:, n:]):
+                    # the activation backward of channel_proj1 rides in the CSGU LayerNorm's backward for the normalised half
+                    # (dZ = act'(z) * LNbwd), and runs in place on the gate half only: no pass over the whole (N, csgu) gradient
+                    bnv(dv, out=du[:, n:], preact=(zu[:, n:], act))
+                    ops.act_mask_bwd(du[:, :n], zu[:, :n], None, act, 1.0, du[:, :n], None)
+                    dh2, _ = F.linear_bwd(du, h2, Wpre, None, act, None, 1.0, F.gacc(Pb["Wpre"]), F.gacc(Pb["bpre"]), dz_ready=True)
+                else:
+                    bnv(dv, out=du[:, n:])
+                    dh2, _ = F.linear_bwd(du, h2, Wpre, zu, act, None, 1.0, F.gacc(Pb["Wpre"]), F.gacc(Pb["bpre"]))
                 dx = bn2(dh2, res=dy)
                 # branch 1 backward
                 dh1 = ops.rows2d(bcell(d1.view(B, T, c1)))

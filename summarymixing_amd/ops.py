@@ -375,6 +375,27 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     return dx if second is None else (dx, dx2)
 
 
+def layernorm_bwd_preact_ok(dy, x, z, dx):
+    """Can smx_layernorm_bwd_preact take these views?  (bf16, D <= 2048, D % 8 == 0, 16-byte aligned rows)"""
+    D = x.shape[1]
+    ok = lambda t: t.dtype == torch.bfloat16 and t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) == 1
+    return D <= 2048 and D % 8 == 0 and all(ok(t) for t in (dy, x, z, dx))
+
+
+def layernorm_bwd_preact(dy, x, gamma, beta, stats, z, zact, dgamma, dbeta, act=L.ACT_NONE, ws=None, dx_out=None):
+    """dZ = zact'(z) * LayerNorm-backward(dy) for a LayerNorm whose input is x = zact(z) (smx_layernorm_bwd_preact)."""
+    N, D = x.shape
+    dx = dx_out if dx_out is not None else torch.empty((N, D), dtype=dy.dtype, device=x.device)
+    if ws is None:
+        ws = _workspace(L.lib().smx_layernorm_bwd_workspace(N, D), x.device, slot=2)
+    tok = _pb(f"layernorm_bwd+preact ({N}x{D})", 4 * _es(dy) * N * D)
+    L.check(L.lib().smx_layernorm_bwd_preact(dt(dy), _p(dy), _mat(dy)[1], _p(x), _mat(x)[1], _p(gamma), _p(beta), act, _p(stats),
+                                             _p(z), _mat(z)[1], zact, _p(dx), _mat(dx)[1], _p(dgamma), _p(dbeta), N, D, _p(ws),
+                                             _stream()), "smx_layernorm_bwd_preact")
+    _pe(tok)
+    return dx
+
+
 def dwconv_fwd(p, w, bias, B, T, D, k, glu, pad_mode=L.PAD_ZERO, chunk=0, gate=None, drop=None):
     """drop = (p, seed): inverted dropout of the output (the CSGU's own), fused where the kernel can (rolling CSGU path),
     else a separate in-place smx_dropout with the same mask."""

@@ -108,6 +108,46 @@ def test_layernorm_fwd_bwd(D, dtype, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D,ld", [(1536, 3072), (512, 512), (2048, 2056), (40, 48)])
+@pytest.mark.parametrize("zact", ["gelu", "swish"])
+def test_layernorm_backward_through_the_producing_activation(D, ld, zact):
+    """smx_layernorm_bwd_preact: x = act(z) feeds a LayerNorm; the kernel returns dL/dz = act'(z) * LNbwd(dy) (strided views:
+    the gate half of the cgMLP's (N, 3072) tensors), dgamma / dbeta as the plain backward."""
+    L, ops = _ops()
+    torch.manual_seed(D + ld)
+    N = 1203
+    bf = torch.bfloat16
+    code, fn = (L.ACT_GELU, torch.nn.functional.gelu) if zact == "gelu" else (L.ACT_SWISH, torch.nn.functional.silu)
+    zfull = torch.randn(N, ld, device="cuda").to(bf)
+    z = zfull[:, ld - D:]
+    xfull = fn(zfull.float()).to(bf)
+    x = xfull[:, ld - D:]
+    g = torch.randn(D, device="cuda") * 0.3 + 1
+    b = torch.randn(D, device="cuda") * 0.3
+    y, stats = ops.layernorm_fwd(x, g, b, 1e-5, True)
+    dy = torch.randn(N, D, device="cuda").to(bf)
+    zr = z.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    xr = fn(zr)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    assert rel_err(y, ref) <= 2e-2
+    (ref * dy.double()).sum().backward()
+    out = torch.zeros(N, ld, device="cuda", dtype=bf)
+    dz_view = out[:, ld - D:]
+    assert ops.layernorm_bwd_preact_ok(dy, x, z, dz_view)
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    dz = ops.layernorm_bwd_preact(dy, x, g, b, stats, z, code, dg, db, dx_out=dz_view)
+    assert rel_err(dz, zr.grad) <= 3e-2                  # (x is the bf16 rounding of act(z): the LN statistics see that rounding)
+    assert rel_err(dg, gr.grad) <= 3e-2 and rel_err(db, br.grad) <= 3e-2
+    if ld > D:
+        assert float(out[:, :ld - D].abs().max()) == 0.0     # nothing outside the view was touched
+    # the two-pass path it replaces gives the same values up to one bf16 rounding of the intermediate gradient
+    dx = ops.layernorm_bwd(dy, x, g, b, stats, torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"))
+    two = ops.act_mask_bwd(dx, z, None, code, 1.0, torch.empty_like(dx), None)
+    assert rel_err(dz, two.double()) <= 1e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D", [256, 512, 1536, 2048, 200])
 def test_layernorm_of_the_float32_stream(D):
     """LayerNorm(float32 row) -> bf16 output, and its backward with bf16 gradients next to the float32 input
