@@ -322,7 +322,7 @@ def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
 
 
 def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
-               drop=None, dz_ready=False, up=None, dx_drop=None, ln=None, ln_second=None):
+               drop=None, dz_ready=False, up=None, dx_drop=None, ln=None, ln_second=None, dx_split=None):
     """Backward of y = res + alpha*D(act(x W^T + b + c0))*mask (D = the forward's fused dropout, regenerated from its
     seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate.
     dz_ready: dy already IS dZ (a downstream dgrad epilogue fused this layer's act/dropout/mask backward, see `up`).
@@ -333,7 +333,10 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
     dx_drop = (p, seed): x is the output of a dropout of that seed; its backward rides in the dgrad epilogue.
     ln = the `.spec` of a LayerNorm backward closure whose OUTPUT is x (x = LN(ln["x"])): the dgrad epilogue then runs that
     LayerNorm backward (SMX_EPI_LN_BWD; check ln_fusable first): returns the gradient w.r.t. ln["x"] (+ res_grad), and,
-    with ln_second = (alpha, mask, drop), the pair (dx, alpha * D(dx) * mask)."""
+    with ln_second = (alpha, mask, drop), the pair (dx, alpha * D(dx) * mask).
+    dx_split = [(lo, hi, epilogue kwargs | None), ...]: x is a concatenation whose column ranges go to different consumers;
+    the dgrad then runs as one GEMM per range over the column slice W[:, lo:hi], each with the first elementwise step of ITS
+    consumer in the epilogue (dropout backward, an activation gradient: ops.epilogue keywords); returns the list of outputs."""
     N, M = dy.shape
     K = x.shape[1]
     if drop is not None and drop[0] <= 0.0:
@@ -353,6 +356,14 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
         _wgrad(dz, x, gW, N, M, K, gb if wb else None)
     dx = None
     if need_dx:
+        if dx_split is not None:
+            assert ln is None and up is None and dx_drop is None and res_grad is None and dx_out is None
+            outs = []
+            for lo, hi, ekw in dx_split:
+                o = torch.empty((N, hi - lo), dtype=dy.dtype, device=dy.device)
+                ops.gemm(L.GEMM_NN, dz, W[:, lo:hi], o, N, hi - lo, M, ops.epilogue(**ekw) if ekw else None)
+                outs.append(o)
+            return outs, dz
         dx = dx_out if dx_out is not None else torch.empty((N, K), dtype=dy.dtype, device=dy.device)
         if ln is not None:
             assert up is None and dx_drop is None and K % 64 == 0
@@ -411,9 +422,11 @@ def mlp_fwd(x, layers, act, mask, need_bwd, dtype, last_res=None, last_drop=None
 
 
 def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=None, dz_ready=False, last_drop=None, ln=None,
-            ln_second=None):
+            ln_second=None, dx_split=None):
     """dz_ready: dy already is the LAST layer's dZ and its bias gradient is done (fused upstream, see linear_bwd `up`).
-    last_drop: the dropout mlp_fwd fused into the last layer."""
+    last_drop: the dropout mlp_fwd fused into the last layer.
+    dx_split: handed to the FIRST layer's linear_bwd (a Linear): the input gradient comes back as a list of column ranges."""
+    assert dx_split is None or layers[0]["kind"] == "linear"
     n = len(layers)
     for i in range(n - 1, -1, -1):
         ly = layers[i]
@@ -429,7 +442,7 @@ def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=N
             dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), gacc(ly["b"]), want_dx,
                                res_grad if first else None, dx_out=dx_out if first else None, dz_ready=dz_ready, up=up,
                                drop=last_drop if i == n - 1 else None, ln=ln if first else None,
-                               ln_second=ln_second if first else None)
+                               ln_second=ln_second if first else None, dx_split=dx_split if first else None)
             dz_ready = up is not None
         else:
             Wc = wcast(ly["W"], dtype)

@@ -23,6 +23,7 @@ from ....nnet.summary_mixing import SummaryMixing
 from ...models.VanillaNN import VanillaNN
 from .Conformer import _LayerNorm
 
+_SPLIT_MERGE_DGRAD = os.environ.get("SMX_SPLIT_MERGE_DGRAD", "1") != "0"   # A/B knob: the merge's input gradient as two GEMMs with fused first steps of their consumers
 _PREACT_LN = os.environ.get("SMX_PREACT_LN", "1") != "0"   # A/B knob: channel_proj1's activation backward inside the CSGU LayerNorm backward
 
 
@@ -164,15 +165,29 @@ class BranchformerEncoderLayer(nn.Module):
                 dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
                 if dy.dtype != dtype:
                     dy = ops.cast(dy, dtype)
-                if merge[-1]["kind"] == "linear":
-                    dcat = F.mlp_bwd(dy, merge, act, sv_m, dtype, last_drop=mdrop)
+                cpre = getattr(bcell, "pre", None)         # (1, None, None, zm, act): the cell's first backward step is dy * act'(zm)
+                split = (_SPLIT_MERGE_DGRAD and merge[0]["kind"] == "linear" and merge[-1]["kind"] == "linear" and cpre is not None
+                         and (pd == 0.0 or fuse_y1) and c1 % 8 == 0 and d % 8 == 0)
+                d1z = None
+                if split:
+                    # the merge's input gradient as two GEMMs over the column halves of its first weight: the half that goes to
+                    # the cell leaves the epilogue as the cell's dZ_m = D(.) * act'(z_m) (dropout of the cell output + the cell's
+                    # own first backward step), the cgMLP half with its dropout backward applied - no elementwise pass over either
+                    e1 = dict(act=cpre[4], act_grad_z=cpre[3], drop=(pd, sd1) if pd > 0.0 else None)
+                    e2 = dict(drop=(pd, sd2)) if pd > 0.0 else None
+                    d1z, dgz = F.mlp_bwd(dy, merge, act, sv_m, dtype, last_drop=mdrop, dx_split=[(0, c1, e1), (c1, c1 + d, e2)])
+                    dg, _ = F.linear_bwd(dgz, g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
+                                         dz_ready=True, dx_drop=(pd, sd4) if pd > 0.0 else None)
                 else:
-                    dcat = F.mlp_bwd(ops.dropout(dy, pd, sd3) if pd > 0.0 else dy, merge, act, sv_m, dtype)
-                # the cell's gradient: a contiguous (N, c1) copy either way, the dropout backward rides in it
-                d1 = dcat[:, :c1] if fuse_y1 else (ops.dropout(dcat[:, :c1], pd, sd1) if pd > 0.0 else dcat[:, :c1].contiguous())
-                # branch 2 backward (the dropout backward of its half rides in linear_bwd's activation/mask pass)
-                dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
-                                     drop=(pd, sd2) if pd > 0.0 else None, dx_drop=(pd, sd4) if pd > 0.0 else None)
+                    if merge[-1]["kind"] == "linear":
+                        dcat = F.mlp_bwd(dy, merge, act, sv_m, dtype, last_drop=mdrop)
+                    else:
+                        dcat = F.mlp_bwd(ops.dropout(dy, pd, sd3) if pd > 0.0 else dy, merge, act, sv_m, dtype)
+                    # the cell's gradient: a contiguous (N, c1) copy either way, the dropout backward rides in it
+                    d1 = dcat[:, :c1] if fuse_y1 else (ops.dropout(dcat[:, :c1], pd, sd1) if pd > 0.0 else dcat[:, :c1].contiguous())
+                    # branch 2 backward (the dropout backward of its half rides in linear_bwd's activation/mask pass)
+                    dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
+                                         drop=(pd, sd2) if pd > 0.0 else None, dx_drop=(pd, sd4) if pd > 0.0 else None)
                 du = torch.empty_like(u)                   # [d gate | d LN input]: both kernels write their half directly
                 dv, _ = F.dwconv_bwd_deferred(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T,
                                               n, k, False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])
@@ -187,7 +202,7 @@ class BranchformerEncoderLayer(nn.Module):
                     dh2, _ = F.linear_bwd(du, h2, Wpre, zu, act, None, 1.0, F.gacc(Pb["Wpre"]), F.gacc(Pb["bpre"]))
                 dx = bn2(dh2, res=dy)
                 # branch 1 backward
-                dh1 = ops.rows2d(bcell(d1.view(B, T, c1)))
+                dh1 = ops.rows2d(bcell(d1z.view(B, T, c1), dz_in=d1z) if d1z is not None else bcell(d1.view(B, T, c1)))
                 dx = bn1(dh1, res=dx)
                 return dx.view(B, T, d)
             return y.view(B, T, d), bwd

@@ -265,3 +265,41 @@ def test_dropout_site_count_matches_reference(kind, seeds):
     c0 = ops._drop_state["counter"]
     layer(x)
     assert ops._drop_state["counter"] == c0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("p", [0.0, 0.15])
+def test_branchformer_fused_backward_steps_match_the_separate_passes(dtype, tol, p):
+    """The Branchformer layer's backward with its elementwise first steps inside the producing kernels (merge dgrad as two
+    GEMMs with the dropout / activation backward of their consumers, SMX_SPLIT_MERGE_DGRAD; channel_proj1's activation backward
+    inside the CSGU LayerNorm backward, SMX_PREACT_LN) against the same layer with those steps as separate passes: same
+    seeds = same dropout masks, so output and every gradient agree up to the rounding of one intermediate tensor."""
+    from summarymixing_amd import ops
+    from summarymixing_amd.lobes.models.transformer import Branchformer as BM
+    d, B, T = 64, 3, 70
+    torch.manual_seed(11)
+    layer = BM.BranchformerEncoderLayer(d_model=d, nhead=1, kernel_size=31, activation="gelu", dropout=p, csgu_linear_units=128,
+                                        local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], summary_out_dim=d,
+                                        mode="SummaryMixing").cuda().train()       # (fp32 master weights; the input's dtype is the compute dtype)
+    x0 = torch.randn(B, T, d, device="cuda").to(dtype)
+    r = torch.randn(B, T, d, device="cuda").to(dtype)
+    pad = (torch.arange(T, device="cuda")[None] < torch.tensor([T, 50, 61], device="cuda")[:, None])   # True = valid frame
+    results = []
+    saved = (BM._SPLIT_MERGE_DGRAD, BM._PREACT_LN)
+    try:
+        for fused in (True, False):
+            BM._SPLIT_MERGE_DGRAD = BM._PREACT_LN = fused
+            ops._drop_state["counter"] = 1000                 # the same seeds for both runs
+            layer.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y, _ = layer(x, src_key_padding_mask=pad)
+            (y.float() * r.float()).sum().backward()
+            results.append((y.detach().float(), x.grad.float(), {n: q.grad.float().clone() for n, q in layer.named_parameters() if q.grad is not None}))
+    finally:
+        BM._SPLIT_MERGE_DGRAD, BM._PREACT_LN = saved
+    (ya, gxa, ga), (yb, gxb, gb) = results
+    assert torch.equal(ya, yb)                                # the forward is untouched
+    assert rel_err(gxa, gxb) <= tol
+    assert ga.keys() == gb.keys() and len(ga) > 10
+    for n in ga:
+        assert rel_err(ga[n], gb[n]) <= tol, n
