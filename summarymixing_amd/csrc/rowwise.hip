@@ -1413,6 +1413,12 @@ extern "C" int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const 
   return check_launch("smx_masked_mean_fwd");
 }
 
+#ifndef SMX_BCAST_RPB
+#define SMX_BCAST_RPB 64       // rows per workgroup of the broadcast kernels that also read (act / mask backward)
+#endif
+#ifndef SMX_BCAST_RPB_ST
+#define SMX_BCAST_RPB_ST 128   // ... of the store-only ones (repeat, repeat + dropout)
+#endif
 static int bcast_impl(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B, int T, int D,
                       float drop_p, uint64_t drop_seed, const uint64_t* epoch, const void* Z, int64_t ldz, const uint8_t* mask, int act, void* stream,
                       const char* what) {
@@ -1421,7 +1427,7 @@ static int bcast_impl(int dtype, const float* g, const float* inv_count, void* d
   const int nvec = dtype == SMX_BF16 ? 8 : 4;
   int LPR = 1;
   while (LPR < 64 && LPR * nvec < D) LPR <<= 1;           // lanes per row (power of two)
-  const int DC = (D + LPR * nvec - 1) / (LPR * nvec), RPB = 64;
+  const int DC = (D + LPR * nvec - 1) / (LPR * nvec), RPB = (Z || mask) ? SMX_BCAST_RPB : SMX_BCAST_RPB_ST;
   dim3 grid(DC, (T + RPB - 1) / RPB, B);
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
   const bool vec = vec_ok(dS, ldds, D, nvec, es) && (Z == nullptr || vec_ok(Z, ldz, D, nvec, es));
