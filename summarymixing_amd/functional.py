@@ -102,6 +102,13 @@ class _Deferred:
     side_enabled = os.environ.get("SMX_WGRAD_STREAM", "1") != "0"
     side = {}        # device -> side stream of the slab GEMMs
     side_used = False
+    # SMX_WGRAD_ASYNC=1: the whole weight-gradient tail of a block (slab GEMMs, grouped wgrad, the reduction jobs) runs on the
+    # side stream - also inside a hipGraph capture - and the main stream only waits for it where somebody reads the gradients
+    # (a bucket hook, the end of the autograd block).  For batches that leave the chip underfilled (the recipe's 3750 frames)
+    # the dgrad chain and the weight gradients then share the CUs.  "auto": on below `async_max_rows` frames.
+    async_mode = os.environ.get("SMX_WGRAD_ASYNC", "auto").lower()
+    async_max_rows = 8192
+    async_now = False    # the block whose backward is running took the asynchronous path (set by its first weight gradient)
     # grouped wgrad: the bf16 weight gradients of a block (= encoder layer) whose dims are multiples of 256 are recorded
     # and computed by ONE smx_wgrad_group launch at the end of the block's backward (SMX_WGRAD_GROUP=0: one slab GEMM each)
     group_enabled = os.environ.get("SMX_WGRAD_GROUP", "1") != "0"
@@ -114,6 +121,7 @@ def _evict_workspaces():
     Only called between producers - never while a group launch is being assembled (an eviction from inside
     _launch_groups dropped the only references to workspaces already attached to the launch's items)."""
     flush_deferred()
+    join_side()                                # (an asynchronous reduction may still be reading the workspaces dropped here)
     _Deferred.ws.clear()
     _Deferred.cache.clear()
 
@@ -123,6 +131,7 @@ def deferred_ws(key, nbytes, device, check=True):
     wgrad assembling its items): no flush, no eviction - the caller did both before it started."""
     if check and key in _Deferred.pending:
         flush_deferred()                       # the same parameter twice inside one block: reduce the first use now
+        join_side()                            # (... and finish reading its workspace before the second use rewrites it)
     t = _Deferred.ws.get(key)
     if check and t is None and len(_Deferred.ws) >= 2048:
         _evict_workspaces()
@@ -138,6 +147,28 @@ def defer(src_ptr, dst, src_stride, nsrc, rows, cols, alpha=1.0):
     """dst (a (rows, cols) fp32 view or a flat (cols,) one) += alpha * sum_s src[s*src_stride + i*cols + j]."""
     ldd = dst.stride(0) if dst.dim() == 2 else cols
     _Deferred.jobs.append((src_ptr, dst.data_ptr(), src_stride, ldd, nsrc, rows, cols, alpha))
+
+
+def _async_side(N):
+    """Does the weight-gradient tail of an N-frame block run asynchronously on the side stream?"""
+    if not _Deferred.side_enabled or _Deferred.async_mode in ("0", "off"):
+        return False
+    return _Deferred.async_mode in ("1", "on") or N <= _Deferred.async_max_rows
+
+
+def _side_stream(device):
+    side = _Deferred.side.get(device)
+    if side is None:
+        side = _Deferred.side[device] = torch.cuda.Stream(device=device)
+    return side
+
+
+def join_side():
+    """The main stream waits for everything the side stream was given (no-op when nothing was)."""
+    if _Deferred.side_used:
+        for st in _Deferred.side.values():
+            torch.cuda.current_stream().wait_stream(st)
+        _Deferred.side_used = False
 
 
 def _launch_groups():
@@ -162,13 +193,27 @@ def _launch_groups():
             for it, (dz, x, gW, dbias, _, M, K) in zip(items, chunk):
                 ws = deferred_ws(gW.data_ptr(), lib.smx_wgrad_group_workspace(M, K, splits), dz.device, check=False)
                 it.workspace = ws.data_ptr()
-            ops.wgrad_group(items, len(chunk), n64, splits)
+            dev = chunk[0][0].device
+            if _async_side(N):
+                main, side = torch.cuda.current_stream(), _side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.wgrad_group(items, len(chunk), n64, splits)
+                    for dz, x, gW, dbias, _, M, K in chunk:
+                        if n64 < N:
+                            ops.wgrad(dz[n64:], x[n64:], gW, N - n64, M, K, dbias=dbias)
+                        dz.record_stream(side)
+                        x.record_stream(side)
+                _Deferred.side_used = True
+            else:
+                ops.wgrad_group(items, len(chunk), n64, splits)
+                for dz, x, gW, dbias, _, M, K in chunk:
+                    if n64 < N:
+                        ops.wgrad(dz[n64:], x[n64:], gW, N - n64, M, K, dbias=dbias)
             for it, (dz, x, gW, dbias, _, M, K) in zip(items, chunk):
                 defer(it.workspace, gW, M * K, splits, M, K)
                 if dbias is not None:
                     defer(it.workspace + 4 * splits * M * K, dbias, M, splits, 1, M)
-                if n64 < N:
-                    ops.wgrad(dz[n64:], x[n64:], gW, N - n64, M, K, dbias=dbias)
 
 
 def flush_deferred():
@@ -177,10 +222,9 @@ def flush_deferred():
     if not _Deferred.jobs:
         _Deferred.pending.clear()
         return
-    if _Deferred.side_used:                    # the slab GEMMs of this block ran on the side stream: join it
-        for st in _Deferred.side.values():
-            torch.cuda.current_stream().wait_stream(st)
-        _Deferred.side_used = False
+    run_async = _Deferred.async_now
+    if not run_async:
+        join_side()                            # the slab GEMMs of this block ran on the side stream: join it
     key = tuple(_Deferred.jobs)
     ent = _Deferred.cache.get(key)
     if ent is None:
@@ -197,7 +241,16 @@ def flush_deferred():
         starts_dev = torch.tensor(starts, dtype=torch.int32).to(dev)
         ent = (jobs_dev, starts_dev, len(key), starts[-1])
         _Deferred.cache[key] = ent
-    ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
+    if run_async:
+        # the reduction follows the slab producers on the side stream; the partial rows written on the MAIN stream (LayerNorm,
+        # depthwise conv, column sums) are ordered before it by one event
+        main, side = torch.cuda.current_stream(), _side_stream(ent[0].device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
+        _Deferred.side_used = True
+    else:
+        ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
     _Deferred.jobs = []
     _Deferred.pending.clear()
 
@@ -208,22 +261,23 @@ def _wgrad(dz, x, gW, N, M, K, dbias):
         ops.wgrad(dz, x, gW, N, M, K, dbias=dbias)
         return
     key = gW.data_ptr()
+    if _async_side(N):
+        _Deferred.async_now = True
     if (_Deferred.group_enabled and dz.dtype == torch.bfloat16 and M % 256 == 0 and K % 256 == 0
             and N >= _Deferred.group_min_rows and dz.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
             and dz.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
         if key in _Deferred.pending:
             flush_deferred()                   # the same parameter twice inside one block: finish the first use now
+            join_side()
         _Deferred.pending.add(key)
         _Deferred.group.append((dz, x, gW, dbias, N, M, K))
         return
     ws = deferred_ws(key, L.lib().smx_linear_wgrad_workspace(N, M, K, 1), dz.device)
-    if _Deferred.side_enabled and not torch.cuda.is_current_stream_capturing():
+    if _Deferred.side_enabled and (_async_side(N) or not torch.cuda.is_current_stream_capturing()):
         # the slab GEMM only feeds the deferred reduction: run it on a side stream next to the dgrad chain (its reads
         # overlap the dgrad's epilogue writes instead of queueing behind them)
         main = torch.cuda.current_stream()
-        side = _Deferred.side.get(dz.device)
-        if side is None:
-            side = _Deferred.side[dz.device] = torch.cuda.Stream(device=dz.device)
+        side = _side_stream(dz.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             nslabs, stride, boff = ops.wgrad_partial(dz, x, N, M, K, ws, want_bias=dbias is not None)
@@ -249,6 +303,8 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         dx = ctx.bwd(dy)
         flush_deferred()        # the block's parameter gradients are final before its bucket is all-reduced
+        join_side()             # (asynchronous weight-gradient tail: the main stream meets it here, at the end of the block)
+        _Deferred.async_now = False
         if ctx.done is not None:
             ctx.done()          # e.g. launch this block's gradient-bucket all-reduce (trainer.FlatAdamW)
         return (dx, None, None) + (None,) * ctx.n
@@ -1063,6 +1119,7 @@ def encoder_stack(src, layers, make_layer_run, norm, params, compute_dtype=None)
                 g = b(g)
                 flush_deferred()                       # this layer's parameter gradients are final ...
                 if done is not None:
+                    join_side()                        # (asynchronous tail: the bucket hook reads the gradients)
                     done()                             # ... before its bucket is all-reduced
             return g if g.dtype == xin.dtype else ops.cast(ops.rows2d(g), xin.dtype).view(B, T, d)
         return y.view(B, T, d), bwd
