@@ -162,7 +162,7 @@ int smx_linear_wgrad_partial(int dtype, const void* dZ, int64_t lddz, int64_t st
  * and, with want_bias, bias partials [splits][M_w] (column sums of dZ_w) behind the slabs in the item's workspace
  * (smx_wgrad_group_workspace(M, K, splits) bytes, 16-byte aligned); fold them with smx_reduce_jobs
  * (src = workspace, src_stride = M*K, nsrc = splits; bias: src = workspace + splits*M*K floats, src_stride = M).
- * Every item reduces over the SAME `rows` frames (rows % 64 == 0: peel a tail through smx_linear_wgrad), M and K are
+ * Every item reduces over the SAME `rows` frames (>= 64; the rows % 64 tail is staged zero-filled by the last split), M and K are
  * multiples of 256, operands 16-byte aligned with leading dimensions % 8 == 0.  One 512-thread workgroup per CU owns a
  * (weight, 256 x 256 tile, K slice) item; smx_wgrad_group_splits picks the slice count that fills the chip once.
  * Autograd backward (dW, db) of all the nn.Linear / Conv1d(k=1) modules of a ConformerEncoderLayer /

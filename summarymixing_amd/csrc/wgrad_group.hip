@@ -43,7 +43,8 @@ struct WgItem {
 
 struct WgGroupParams {
   WgItem it[WG_MAX_ITEMS];
-  int nitems, total_tiles, splits, ksteps_per_split, rows;   // rows: multiple of 64 (the host peels the tail)
+  int nitems, total_tiles, splits, ksteps_per_split, rows;   // rows: the multiple of 64 the DMA ring walks
+  int tail;             // 0..63 frames behind `rows`: one or two zero-filled steps of the LAST split's workgroups
   int pingpong;         // SMX_WGROUP_PP: 1 = upper four waves refill before their MFMAs, lower four after; 2 = + a mid-step barrier
   int ablate;           // debug (env SMX_WGROUP_ABLATE): 1 = no MFMA / fragment reads, 2 = no DMA, 4 = DMA never waited for, 8 = no X pieces
   long long* dbg;       // debug (smx_debug_set_timing_buffer): per workgroup [total cycles, cycles in wait+barrier, realtime ticks, niter]
@@ -236,6 +237,50 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
     }
   }
 
+  // ---- ragged tail (rows % 64 frames): the workgroups of the last split stage them with guarded 16-byte loads - zeros
+  // behind the last frame - into the image the DMA would have written, and multiply them like any other stage.  (Peeling the
+  // tail on the host cost one slab GEMM + one reduction per weight: 96 + 96 launches = 12 % of the recipe batch's step for
+  // 38 of its 3750 frames.)
+  if (p.tail > 0 && split == p.splits - 1) {
+#pragma unroll 1
+    for (int ts = 0; ts * BK < p.tail; ++ts) {
+      wg_barrier();                                        // every wave is done with the stage it read last
+      const int kb = p.rows + ts * BK, kmax = p.rows + p.tail;
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) {
+        const int kr = kb + 2 * (wave + 8 * j) + prow;
+        uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+        if (kr < kmax) {
+          va = *reinterpret_cast<const uint4*>(it.A + (long)kr * it.lda + n0 + gsrc);
+          vb = *reinterpret_cast<const uint4*>(it.B + (long)kr * it.ldb + m0 + gsrc);
+        }
+        char* d = smem + wave * 1024 + j * 8192 + lane * 16;
+        *reinterpret_cast<uint4*>(d) = va;
+        *reinterpret_cast<uint4*>(d + OP_BYTES) = vb;
+      }
+      __syncthreads();
+      const char* As = smem;
+      const char* Bs = As + OP_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 fa[2], fb[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = wg_frag(As, wn * 64 + i * 32, l31, hi, kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = wg_frag(Bs, wm * 128 + j * 32, l31, hi, kk);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) wg_sum8(bsum[i][0], bsum[i][1], fa[i]);
+        }
+      }
+    }
+  }
+
   if (p.dbg && t == 0) {
     long long* d = p.dbg + (long)blockIdx.x * 4;
     d[0] = clock64() - t_start; d[1] = t_wait; d[2] = wall_clock64() - r_start; d[3] = niter;
@@ -312,7 +357,7 @@ extern "C" size_t smx_wgrad_group_workspace(int M, int K, int splits) {
 extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items, int nitems, int splits, void* stream) {
   SMX_REQUIRE(dtype == SMX_BF16, "smx_wgrad_group: bf16 only (fp32 weights take smx_linear_wgrad)");
   SMX_REQUIRE(items && nitems >= 1 && nitems <= WG_MAX_ITEMS, "smx_wgrad_group: 1..%d items per launch", WG_MAX_ITEMS);
-  SMX_REQUIRE(rows >= 64 && rows % 64 == 0 && splits >= 1, "smx_wgrad_group: rows must be a positive multiple of 64 (peel the tail)");
+  SMX_REQUIRE(rows >= 64 && splits >= 1, "smx_wgrad_group: at least 64 rows");
   WgGroupParams p;
   memset(&p, 0, sizeof(p));
   int tiles = 0;
@@ -329,8 +374,9 @@ extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items,
     d.tile0 = tiles; d.tiles_m = s.K / WG_TILE; d.want_bias = s.want_bias;
     tiles += (s.M / WG_TILE) * (s.K / WG_TILE);
   }
-  p.nitems = nitems; p.total_tiles = tiles; p.splits = splits; p.rows = rows;
+  p.nitems = nitems; p.total_tiles = tiles; p.splits = splits; p.rows = rows - rows % 64; p.tail = rows % 64;
   const int nk = rows / 64;
+  SMX_REQUIRE(splits <= nk, "smx_wgrad_group: more splits than 64-frame steps");
   p.ksteps_per_split = (nk + splits - 1) / splits;
   const int nwork = tiles * splits, per = (nwork + 7) / 8;
   const int bk_env = cfg().wgroup_bk;                     // (measured in the step: 32 + ping-pong 1)

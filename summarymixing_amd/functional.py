@@ -172,8 +172,8 @@ def join_side():
 
 
 def _launch_groups():
-    """The recorded weight gradients of this block: one smx_wgrad_group launch per (frame count, <= 16 weights); rows
-    beyond the last multiple of 64 frames go through the ordinary wgrad; slabs / bias partials become reduction jobs."""
+    """The recorded weight gradients of this block: one smx_wgrad_group launch per (frame count, <= 16 weights); slabs / bias
+    partials become reduction jobs."""
     recs, _Deferred.group = _Deferred.group, []
     if len(_Deferred.ws) + len(recs) >= 2048:             # eviction check ONCE, before any workspace is attached to an item
         _evict_workspaces()                               # (the group list is already detached: this folds the earlier producers' jobs only)
@@ -182,7 +182,7 @@ def _launch_groups():
         by_n.setdefault(r[4], []).append(r)
     lib = L.lib()
     for N, rs in by_n.items():
-        n64 = N - N % 64
+        n64 = N                                 # (the kernel stages the N % 64 tail frames itself)
         for c0 in range(0, len(rs), L.WGRAD_GROUP_MAX):
             chunk = rs[c0:c0 + L.WGRAD_GROUP_MAX]
             items = (L.WgradItem * len(chunk))()
@@ -200,16 +200,11 @@ def _launch_groups():
                 with torch.cuda.stream(side):
                     ops.wgrad_group(items, len(chunk), n64, splits)
                     for dz, x, gW, dbias, _, M, K in chunk:
-                        if n64 < N:
-                            ops.wgrad(dz[n64:], x[n64:], gW, N - n64, M, K, dbias=dbias)
                         dz.record_stream(side)
                         x.record_stream(side)
                 _Deferred.side_used = True
             else:
                 ops.wgrad_group(items, len(chunk), n64, splits)
-                for dz, x, gW, dbias, _, M, K in chunk:
-                    if n64 < N:
-                        ops.wgrad(dz[n64:], x[n64:], gW, N - n64, M, K, dbias=dbias)
             for it, (dz, x, gW, dbias, _, M, K) in zip(items, chunk):
                 defer(it.workspace, gW, M * K, splits, M, K)
                 if dbias is not None:

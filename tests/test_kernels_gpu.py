@@ -529,7 +529,7 @@ def _wgroup_case(rows, shapes, bias, seed=0, strided=False):
     return max(errs)
 
 
-@pytest.mark.parametrize("rows", [2048, 4160, 64000, 33000])      # 33000 and 4160 % 64 != 0: tail rows through the ordinary wgrad
+@pytest.mark.parametrize("rows", [2048, 4160, 64000, 33000, 3750, 2111, 2049, 2080])   # rows % 64 = 40, 38, 63, 1, 32: the ragged tail inside the kernel
 def test_wgrad_group_conformer_layer_shapes(rows):
     shapes = [(1024, 256), (256, 1024), (1024, 256), (256, 1024), (512, 256), (256, 512), (512, 256), (256, 256)]
     err = _wgroup_case(rows, shapes, [True] * 8)
@@ -539,6 +539,7 @@ def test_wgrad_group_conformer_layer_shapes(rows):
 def test_wgrad_group_strided_operands_mixed_bias_and_single_item():
     assert _wgroup_case(8192, [(512, 512), (256, 768)], [False, True], seed=1, strided=True) < 2e-5
     assert _wgroup_case(16384, [(256, 256)], [True], seed=2) < 2e-5
+    assert _wgroup_case(8192 + 45, [(512, 512), (256, 768)], [True, False], seed=4, strided=True) < 2e-5     # ragged tail, strided views
     # more weights than one launch takes (SMX_WGRAD_GROUP_MAX = 16): split into two launches
     assert _wgroup_case(4096, [(256, 256)] * 18, [True, False] * 9, seed=3) < 2e-5
 

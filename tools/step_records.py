@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One eager training step of a bench.py config with the in-step records on (ops.prof_start): time per record label, and
 for the labels matching argv[2] (a substring) the repo frames that issued the call.
-usage: python tools/step_records.py c4 act_mask_bwd"""
+usage: python tools/step_records.py c4 act_mask_bwd      (BT=10,375 in the environment: another batch size)"""
 import collections
 import os
 import sys
@@ -17,6 +17,8 @@ from summarymixing_amd.trainer import FlatAdamW  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "c2b"
 pat = sys.argv[2] if len(sys.argv) > 2 else None
 cfg = dict(bench.CONFIGS[name])
+if os.environ.get("BT"):                                   # BT=10,375: another batch of the same model
+    cfg["B"], cfg["T"] = (int(v) for v in os.environ["BT"].split(","))
 dev = torch.device("cuda", 0)
 enc = bench.build_encoder(cfg, dev, 0.15)
 opt = FlatAdamW(enc, compute_dtype=torch.bfloat16)
