@@ -1427,7 +1427,9 @@ static int bcast_impl(int dtype, const float* g, const float* inv_count, void* d
   const int nvec = dtype == SMX_BF16 ? 8 : 4;
   int LPR = 1;
   while (LPR < 64 && LPR * nvec < D) LPR <<= 1;           // lanes per row (power of two)
-  const int DC = (D + LPR * nvec - 1) / (LPR * nvec), RPB = (Z || mask) ? SMX_BCAST_RPB : SMX_BCAST_RPB_ST;
+  const int DC = (D + LPR * nvec - 1) / (LPR * nvec);
+  int RPB = (Z || mask) ? SMX_BCAST_RPB : SMX_BCAST_RPB_ST;
+  while (RPB > 8 && (long)DC * ((T + RPB - 1) / RPB) * B < 512) RPB >>= 1;   // small batches: more, shorter workgroups (the recipe's 10 x 375 frames ran on 30)
   dim3 grid(DC, (T + RPB - 1) / RPB, B);
   const size_t es = dtype == SMX_BF16 ? 2 : 4;
   const bool vec = vec_ok(dS, ldds, D, nvec, es) && (Z == nullptr || vec_ok(Z, ldz, D, nvec, es));
@@ -1592,7 +1594,7 @@ extern "C" int smx_layernorm_fwd_x32(int dtype, const float* X, int64_t ldx, con
 #define SMX_LNB_BLOCKS 1024
 #endif
 static int ln_bwd_blocks(int N) {
-  int blocks = (N + 7) / 8;
+  int blocks = (N + 3) / 4;                              // one row per wave and pass when the rows allow it (D <= 512 keeps ONE row in flight)
   return blocks > SMX_LNB_BLOCKS ? SMX_LNB_BLOCKS : (blocks < 1 ? 1 : blocks);
 }
 
