@@ -326,7 +326,7 @@ def ln_next_ok(x, M, ln_next, W=None, res=None):
     """Can the LayerNorm that follows a Linear (its output: N x M) ride in that GEMM's epilogue (SMX_EPI_LN_FWD)?
     W / res: the weight (view) and residual the GEMM will be given - a column slice with an odd offset is not 16-byte aligned
     and the fused instantiation has no scalar path."""
-    return (_LN_FUSE and ln_next is not None and x.dtype == torch.bfloat16 and _vec_ok(x, W, res) and
+    return (_LN_FUSE and ln_next is not None and x.dtype == torch.bfloat16 and x.shape[0] >= _LN_FUSE_MIN_ROWS and _vec_ok(x, W, res) and
             L.lib().smx_gemm_ln_fused_ok(L.BF16, x.shape[0], M, x.shape[1]) == 1)
 
 
@@ -358,6 +358,11 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
 
 
 _LN_FUSE = os.environ.get("SMX_LN_FUSE", "1") != "0"   # A/B knob: LayerNorm backward / forward inside the GEMM epilogues
+# The LayerNorm-fused GEMM runs one 128-row tile per workgroup (the tile holds whole rows): below ~280 tiles the grid leaves
+# CUs idle and each workgroup's serial chain (K loop, four epilogue phases) IS the kernel's duration - 64 us at 16 000 frames
+# against 76 us at 64 000.  Measured on the C2b step (fused / separate kernels, ms): B = 16: 8.30 / 5.97, 32: 9.77 / 8.15,
+# 48: 11.33 / 10.63, 64: 12.97 / 12.56, 80: 15.20 / 15.74, 96: 16.52 / 17.49, 128: 19.11 / 20.24 -> fuse from 36 864 rows.
+_LN_FUSE_MIN_ROWS = int(os.environ.get("SMX_LN_FUSE_MIN_ROWS", "36864"))
 
 
 def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
@@ -368,7 +373,7 @@ def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
     if not (_LN_FUSE and _Deferred.enabled and ln_spec is not None and dtype == torch.bfloat16):
         return False
     x = ln_spec["x"]
-    return (x.shape[1] == K_out and x.shape[0] == N and gacc(ln_spec["gw_param"]) is not None
+    return (x.shape[1] == K_out and x.shape[0] == N and N >= _LN_FUSE_MIN_ROWS and gacc(ln_spec["gw_param"]) is not None
             and L.lib().smx_gemm_ln_fused_ok(L.BF16, N, K_out, reduce) == 1 and _vec_ok(x, W))
 
 

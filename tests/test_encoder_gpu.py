@@ -210,3 +210,43 @@ def test_conformer_encoder_dynchunk_at_width_vs_oracle(dtype, chunk, left):
     ftol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (1e-2, 3e-2)
     assert rel_err(y, ref) <= ftol, rel_err(y, ref)
     assert rel_err(xg.grad, xr.grad) <= gtol, rel_err(xg.grad, xr.grad)
+
+
+def test_layernorm_fusion_threshold_paths_agree():
+    """functional._LN_FUSE_MIN_ROWS: below the threshold a d_model = 256 model runs its LayerNorms as separate kernels next to
+    ordinary GEMM tiles, from it on inside the 128 x 256 GEMM epilogues.  Same model, same batch, both settings: output, dL/dx
+    and every parameter gradient agree to bf16 rounding, and the record list shows that the two runs really took different
+    kernels."""
+    from summarymixing_amd import functional as F, ops
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(3)
+    B, T, d = 4, 300, 256
+    enc = ConformerEncoder(2, d, 1024, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast").cuda()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+    x0 = torch.randn(B, T, d, device="cuda").bfloat16()
+    r = torch.randn(B, T, d, device="cuda")
+    pad = torch.arange(T, device="cuda")[None] < torch.tensor([T, 211, 150, 287], device="cuda")[:, None]
+    saved = F._LN_FUSE_MIN_ROWS
+    runs = []
+    try:
+        for thr in (0, 1 << 30):
+            F._LN_FUSE_MIN_ROWS = thr
+            enc.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            ops.prof_start()
+            y, _ = enc(x, src_key_padding_mask=pad)
+            (y.float() * r).sum().backward()
+            names = [rec[0] for rec in ops.prof_stop()]
+            runs.append((y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in enc.named_parameters()},
+                         sum("+LN" in n for n in names), sum(n.startswith("layernorm") for n in names)))
+    finally:
+        F._LN_FUSE_MIN_ROWS = saved
+    (ya, ga, pa, fused_a, alone_a), (yb, gb, pb, fused_b, alone_b) = runs
+    assert fused_a > 0 and fused_b == 0 and alone_b > alone_a
+    assert rel_err(ya, yb) <= 1e-2 and rel_err(ga, gb) <= 3e-2
+    for n in pa:
+        assert rel_err(pa[n], pb[n]) <= 3e-2, n
