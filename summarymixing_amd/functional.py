@@ -322,11 +322,15 @@ def _vec_ok(*ts):
     return all(t is None or (t.data_ptr() % 16 == 0 and (t.stride(0) * t.element_size()) % 16 == 0) for t in ts)
 
 
+_LN_FUSE_FWD = os.environ.get("SMX_LN_FUSE_FWD", "1") != "0"   # A/B: only the forward (SMX_EPI_LN_FWD) ...
+_LN_FUSE_BWD = os.environ.get("SMX_LN_FUSE_BWD", "1") != "0"   # ... / only the backward (SMX_EPI_LN_BWD) fusion off (C2b B = 128: 19.79 both, 19.90 without the forward, 20.84 without the backward one)
+
+
 def ln_next_ok(x, M, ln_next, W=None, res=None):
     """Can the LayerNorm that follows a Linear (its output: N x M) ride in that GEMM's epilogue (SMX_EPI_LN_FWD)?
     W / res: the weight (view) and residual the GEMM will be given - a column slice with an odd offset is not 16-byte aligned
     and the fused instantiation has no scalar path."""
-    return (_LN_FUSE and ln_next is not None and x.dtype == torch.bfloat16 and x.shape[0] >= _LN_FUSE_MIN_ROWS and _vec_ok(x, W, res) and
+    return (_LN_FUSE and _LN_FUSE_FWD and ln_next is not None and x.dtype == torch.bfloat16 and x.shape[0] >= _LN_FUSE_MIN_ROWS and _vec_ok(x, W, res) and
             L.lib().smx_gemm_ln_fused_ok(L.BF16, x.shape[0], M, x.shape[1]) == 1)
 
 
@@ -370,7 +374,7 @@ def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
     with K_out = the LN width?  (bf16, width 256, deferred parameter reductions on.)  `reduce` is the REAL reduce length of
     that GEMM - the producing Linear's output width (d_ffn, 2 l, 2 d): the fused instantiation has no ragged-K path, so a width
     that is not a multiple of 64 must take the standalone LayerNorm kernel (the check used a constant 64)."""
-    if not (_LN_FUSE and _Deferred.enabled and ln_spec is not None and dtype == torch.bfloat16):
+    if not (_LN_FUSE and _LN_FUSE_BWD and _Deferred.enabled and ln_spec is not None and dtype == torch.bfloat16):
         return False
     x = ln_spec["x"]
     return (x.shape[1] == K_out and x.shape[0] == N and N >= _LN_FUSE_MIN_ROWS and gacc(ln_spec["gw_param"]) is not None

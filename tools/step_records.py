@@ -25,9 +25,16 @@ opt = FlatAdamW(enc, compute_dtype=torch.bfloat16)
 src, wav_len, r, _ = bench.synthetic_batch(cfg, 0, dev, torch.bfloat16)
 
 
+enc_kw = {}
+if os.environ.get("DYNCHUNK"):                             # DYNCHUNK=8,2: a DynChunk training batch (chunk size, left context chunks)
+    from summarymixing_amd.utils.dynamic_chunk_training import DynChunkTrainConfig
+    parts = [int(v) for v in os.environ["DYNCHUNK"].split(",")]
+    enc_kw["dynchunktrain_config"] = DynChunkTrainConfig(parts[0], parts[1] if len(parts) > 1 else None)
+
+
 def step():
     opt.zero_grad()
-    enc(src, wav_len).backward(r)
+    enc(src, wav_len, **enc_kw).backward(r)
     opt.step()
 
 
