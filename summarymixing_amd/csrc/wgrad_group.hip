@@ -323,14 +323,20 @@ static int wg_splits(int rows, int total_tiles) {
     if (s > smax) s = smax;
     return s < 1 ? 1 : s;
   }
+  // Cost model (microseconds; fitted to the rocprof averages of the four bench configs): a round of up to 256 workgroups
+  // walks its 64-frame steps at ~2 us each, and every slice adds one fp32 slab per tile that is written here and read back by
+  // smx_reduce_jobs (2 x 256 KB at ~4 TB/s).  At 64 000 frames the slab term is 1-2 % per slice (the "fill - 1 % per slice" rule
+  // of round 2 picked the same counts: C2b 11, C2a 8); at the recipe's 3750 frames it is 17 % per slice, and five slices
+  // (72 + 32 us) lose to two (measured below).
   const int cus = 256;
+  const double t_step = 2.0, t_slab = 0.131;
   int best = 1;
-  double best_score = -1.0;
+  double best_t = 1e30;
   for (int s = 1; s <= smax && (long)s * total_tiles <= 4L * cus; ++s) {
     const long w = (long)s * total_tiles;
-    const double fill = (double)w / (double)(((w + cus - 1) / cus) * cus);
-    const double score = fill - 0.01 * s;
-    if (score > best_score + 1e-9) { best_score = score; best = s; }
+    const double rounds = (double)((w + cus - 1) / cus);
+    const double t = rounds * (double)((nk + s - 1) / s) * t_step + (double)s * total_tiles * t_slab;
+    if (t < best_t - 1e-9) { best_t = t; best = s; }
   }
   return best;
 }
