@@ -48,9 +48,31 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S
   __shared__ int slo[256], shi[256];
   for (int m = threadIdx.x; m < 256; m += 256) { slo[m] = n_bins; shi[m] = 0; }
   __syncthreads();
-  for (int m = 0; m < n_mels; ++m)
-    for (int f = threadIdx.x; f < n_bins; f += 256)
-      if (fb[(long)m * n_bins + f] != 0.f) { atomicMin(&slo[m], f); atomicMax(&shi[m], f + 1); }
+  // (one wave per filter row, two rows at a time: every load of the pair is in flight before the first compare, limits by wave
+  //  shuffles - the loop over all rows with an LDS atomic behind every load was 160 dependent round trips per workgroup, a
+  //  constant ~60 us in front of the first frame: 94 us of kernel for the recipe batch's 15 000 frames)
+  for (int m0 = 2 * w; m0 < n_mels; m0 += 8) {
+    int l2[2] = {n_bins, n_bins}, h2[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + u;
+      if (m < n_mels) {
+        const float* fr = fb + (long)m * n_bins;
+        for (int f = lane; f < n_bins; f += 64)
+          if (fr[f] != 0.f) { l2[u] = min(l2[u], f); h2[u] = max(h2[u], f + 1); }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { l2[u] = min(l2[u], __shfl_xor(l2[u], off, 64)); h2[u] = max(h2[u], __shfl_xor(h2[u], off, 64)); }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (m0 + u < n_mels) { slo[m0 + u] = l2[u]; shi[m0 + u] = h2[u]; }
+    }
+  }
   __syncthreads();
   int lo[MPL], hi[MPL];
 #pragma unroll
@@ -62,8 +84,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ S
       const float* fr = fb + (long)m * n_bins;
       // the band's weights are the same for every frame: once into LDS (a global load per tap and frame made this kernel
       // latency-bound: 845 us for 256 000 frames)
-      if (w == 0)
-        for (int j = 0; j < MELW; ++j) band[m * MELW + j] = (lo[k] + j < hi[k]) ? fr[lo[k] + j] : 0.f;
+      for (int j = w; j < MELW; j += 4) band[m * MELW + j] = (lo[k] + j < hi[k]) ? fr[lo[k] + j] : 0.f;   // (each wave a quarter of the taps)
     }
   }
   __syncthreads();
@@ -567,29 +588,49 @@ __global__ __launch_bounds__(256) void conv2d_s2_dgrad_kernel(const bf16_t* __re
 }
 
 // ---- InputNormalization (speechbrain.processing.features.InputNormalization, recipe key `normalize`) ---------------
-// per-utterance mean and unbiased std over the valid frames t < len[b] of every feature; grid (ceil(F/64), B), 256
-// threads = 64 features x 4 time groups; two passes over the (small) feature block for a stable variance
+// per-utterance mean and unbiased std over the valid frames t < len[b] of every feature; grid (ceil(F/16), B), 256
+// threads = 16 features x 16 time groups (four loads in flight per thread); two passes over the (small) feature block for a
+// stable variance.  (64 features x 4 time groups walked 375-500 dependent steps per thread on 2 workgroups per utterance:
+// 83 us for the recipe batch's 10 x 1501 frames, the largest launch of its feature pipeline.)
 template <typename T>
 __global__ __launch_bounds__(256) void utt_meanstd_kernel(const T* __restrict__ X, long ldx, int Tmax, int F,
                                                           const int* __restrict__ len, float* __restrict__ mean,
                                                           float* __restrict__ sd, int mean_norm, int std_norm, float eps) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, tg = threadIdx.x >> 6, b = blockIdx.y;
-  const int c = blockIdx.x * 64 + cl;
+  constexpr int CF = 16, TG = 16;
+  __shared__ float red[TG][CF];
+  const int cl = threadIdx.x & (CF - 1), tg = threadIdx.x / CF, b = blockIdx.y;
+  const int c = blockIdx.x * CF + cl;
   const int n = min(max(len[b], 0), Tmax);
-  const T* x = X + (long)b * Tmax * ldx + c;
-  float s = 0.f;
-  if (c < F) for (int t = tg; t < n; t += 4) s += to_f32(x[(long)t * ldx]);
-  red[tg][cl] = s;
+  const T* x = X + (long)b * Tmax * ldx + (c < F ? c : 0);
+  auto fold = [&]() {                                    // the 16 time groups in a fixed order
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < TG; ++g) v += red[g][cl];
+    return v;
+  };
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int t = tg;
+  for (; t + 3 * TG < n; t += 4 * TG) {
+    s0 += to_f32(x[(long)t * ldx]); s1 += to_f32(x[(long)(t + TG) * ldx]);
+    s2 += to_f32(x[(long)(t + 2 * TG) * ldx]); s3 += to_f32(x[(long)(t + 3 * TG) * ldx]);
+  }
+  for (; t < n; t += TG) s0 += to_f32(x[(long)t * ldx]);
+  red[tg][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  const float m = n > 0 ? ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)n : 0.f;
+  const float m = n > 0 ? fold() / (float)n : 0.f;
   __syncthreads();
-  float q = 0.f;
-  if (c < F) for (int t = tg; t < n; t += 4) { const float d = to_f32(x[(long)t * ldx]) - m; q += d * d; }
-  red[tg][cl] = q;
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  t = tg;
+  for (; t + 3 * TG < n; t += 4 * TG) {
+    const float d0 = to_f32(x[(long)t * ldx]) - m, d1 = to_f32(x[(long)(t + TG) * ldx]) - m;
+    const float d2 = to_f32(x[(long)(t + 2 * TG) * ldx]) - m, d3 = to_f32(x[(long)(t + 3 * TG) * ldx]) - m;
+    q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
+  }
+  for (; t < n; t += TG) { const float d = to_f32(x[(long)t * ldx]) - m; q0 += d * d; }
+  red[tg][cl] = (q0 + q1) + (q2 + q3);
   __syncthreads();
   if (tg == 0 && c < F) {
-    const float var = n > 1 ? ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)(n - 1) : __builtin_nanf("");
+    const float var = n > 1 ? fold() / (float)(n - 1) : __builtin_nanf("");
     mean[(long)b * F + c] = mean_norm ? m : 0.f;
     sd[(long)b * F + c] = std_norm ? fmaxf(sqrtf(var), eps) : 1.f;    // torch.max(std, eps): NaN (one frame) propagates
   }
@@ -771,7 +812,7 @@ extern "C" int smx_utt_meanstd(int dtype, const void* X, int64_t ldx, const int3
                                int F, int mean_norm, int std_norm, float eps, void* stream) {
   SMX_REQUIRE(X && len && mean && std && T > 0 && F > 0, "smx_utt_meanstd: bad arguments");
   if (B <= 0) return SMX_OK;
-  dim3 grid((F + 63) / 64, B);
+  dim3 grid((F + 15) / 16, B);
   if (dtype == SMX_BF16) hipLaunchKernelGGL((utt_meanstd_kernel<bf16_t>), grid, dim3(256), 0, STREAM, (const bf16_t*)X, ldx, T, F, len, mean, std, mean_norm, std_norm, eps);
   else hipLaunchKernelGGL((utt_meanstd_kernel<float>), grid, dim3(256), 0, STREAM, (const float*)X, ldx, T, F, len, mean, std, mean_norm, std_norm, eps);
   return check_launch("smx_utt_meanstd");

@@ -13,7 +13,7 @@ from summarymixing_amd.lobes.features import Fbank, InputNormalization          
 from summarymixing_amd.lobes.models.convolution import ConvolutionFrontEnd      # noqa: E402
 
 step_ms = float(sys.argv[1]) if len(sys.argv) > 1 else 19.5
-B, secs = 128, 20
+B, secs = (int(v) for v in os.environ.get("BS", "128,20").split(","))   # BS=10,15: the recipe's 150 s batch
 wav = torch.randn(B, 16000 * secs, device="cuda") * 0.1
 lens = torch.ones(B, device="cuda")
 fb = Fbank(sample_rate=16000, n_fft=512, n_mels=80, win_length=32).cuda()
