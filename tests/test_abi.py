@@ -74,3 +74,28 @@ def test_config_is_read_once_and_queryable():
             del os.environ["SMX_WGROUP_PP"]
         else:
             os.environ["SMX_WGROUP_PP"] = old
+
+
+def test_grouped_wgrad_slice_plan_is_size_aware():
+    """smx_wgrad_group_splits is host logic (no GPU): the slice count comes from a cost model - rounds x 64-frame steps + one
+    written-and-re-read fp32 slab per tile and slice.  At 64 000 frames it keeps the counts tuned in round 2 (C2b layer: 11,
+    C2a layer: 8); at the recipe batch (3750 frames) a slice costs a sixth of the kernel and two beat the five that 'fill the
+    chip'; a ragged frame count plans like its multiple of 64."""
+    from summarymixing_amd import _lib as L
+    lib = L.lib()
+
+    def plan(rows, shapes):
+        items = (L.WgradItem * len(shapes))()
+        for it, (M, K) in zip(items, shapes):
+            it.M, it.K, it.want_bias = M, K, 1
+        return lib.smx_wgrad_group_splits(rows, items, len(shapes))
+    c2b = [(1024, 256), (256, 1024), (1024, 256), (256, 1024), (512, 256), (256, 512), (512, 256), (256, 256)]
+    c2a = [(2048, 512), (512, 2048), (2048, 512), (512, 2048), (1024, 512), (512, 1024), (1024, 512), (512, 512)]
+    assert plan(64000, c2b) == 11
+    assert plan(64000, c2a) == 8
+    assert plan(3750, c2a) == 2
+    assert plan(3750, c2a) == plan(3712, c2a)
+    assert plan(63, c2b) == 0 and plan(64, c2b) == 1          # fewer than 64 frames: not this kernel's job
+    for rows in (64, 700, 3750, 16000, 64000, 240000):
+        s = plan(rows, c2a)
+        assert 1 <= s <= max(1, rows // 64 // 8) or s == 1    # at least 8 steps of 64 frames per slice
