@@ -113,7 +113,9 @@ class _Deferred:
     # and computed by ONE smx_wgrad_group launch at the end of the block's backward (SMX_WGRAD_GROUP=0: one slab GEMM each)
     group_enabled = os.environ.get("SMX_WGRAD_GROUP", "1") != "0"
     group = []       # (dz, x, gW, dbias, N, M, K)
-    group_min_rows = 2048
+    # (from the kernel's minimum of 64 frames: below 2048 the eight slab GEMMs + reductions it replaces are eight latency-bound
+    #  launches - C2b training step at B = 1 x 500: 5.36 -> 4.00 ms, C2a at 2 x 375: 7.11 -> 5.43 ms)
+    group_min_rows = int(os.environ.get("SMX_WGRAD_GROUP_MIN_ROWS", "64"))
 
 
 def _evict_workspaces():

@@ -529,7 +529,8 @@ def _wgroup_case(rows, shapes, bias, seed=0, strided=False):
     return max(errs)
 
 
-@pytest.mark.parametrize("rows", [2048, 4160, 64000, 33000, 3750, 2111, 2049, 2080])   # rows % 64 = 40, 38, 63, 1, 32: the ragged tail inside the kernel
+@pytest.mark.parametrize("rows", [2048, 4160, 64000, 33000, 3750, 2111, 2049, 2080,    # rows % 64 = 40, 38, 63, 1, 32: the ragged tail inside the kernel
+                                  64, 100, 500, 1000])                                # one utterance: a single slice of 1-15 steps
 def test_wgrad_group_conformer_layer_shapes(rows):
     shapes = [(1024, 256), (256, 1024), (1024, 256), (256, 1024), (512, 256), (256, 512), (512, 256), (256, 256)]
     err = _wgroup_case(rows, shapes, [True] * 8)
