@@ -7,12 +7,17 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 # product library contains none of them.  SMX_LIB=<path> makes summarymixing_amd._lib load another build.
 DIAG="${SMX_DIAG:-0}"
 if [[ "$DIAG" == "1" ]]; then OUT="${HERE}/../libsmx_diag.so"; OBJ="${HERE}/obj_diag"; else OUT="${HERE}/../libsmx.so"; OBJ="${HERE}/obj"; fi
+# SMX_VARIANT=<name> SMX_CXXFLAGS="-D..." bash build.sh: an A/B build (libsmx_<name>.so, objects in obj_<name>/; both git-ignored)
+VARIANT="${SMX_VARIANT:-}"
+if [[ -n "$VARIANT" ]]; then OUT="${HERE}/../libsmx_${VARIANT}.so"; OBJ="${HERE}/obj_${VARIANT}"; fi
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # -fno-slp-vectorize: the SLP vectoriser turns adjacent fp32 operations into v_pk_{add,mul,fma}_f32; beside MFMAs a v_pk_fma_f32
 # costs ~14 cycles of issue against ~4 for a v_fma_f32 (tools/experiments/mfma_valu_probe.hip); round 2 found the same in the
 # depthwise-conv FMA chains.  A/B on one box, whole library: C2b step 19.19 / 19.20 -> 19.04 / 19.03 ms.
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -fno-slp-vectorize -Wall -Wno-unused-function)
 [[ "$DIAG" == "1" ]] && FLAGS+=(-DSMX_DIAG)
+# shellcheck disable=SC2206
+[[ -n "${SMX_CXXFLAGS:-}" ]] && FLAGS+=(${SMX_CXXFLAGS})
 mkdir -p "$OBJ"
 pids=()
 for f in capi gemm rowwise dwconv frontend ctc reduce wgrad_group; do

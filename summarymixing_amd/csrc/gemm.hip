@@ -35,6 +35,9 @@ namespace smx {
 #ifndef SMX_NS_KC
 #define SMX_NS_KC 1
 #endif
+#ifndef SMX_DMAB
+#define SMX_DMAB 1          // wide (128 x 256) bf16 tile: weight operand on an LDS-DMA ring, 3 register stages of the activation operand
+#endif
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
@@ -62,7 +65,13 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   constexpr int PH_ROWS = 32 * PH_FRAGS;
   constexpr int NPH = TILE_N / PH_ROWS;
   constexpr int EPI_BYTES = PH_ROWS * (TILE_M * 4 + 16);         // fp32 rows, 16 B row pad
-  constexpr int AB_BYTES = A_BYTES + B_BYTES;
+  // DMAB (wide bf16 tile, aligned operands): the B (weight) operand goes L2 -> LDS by buffer_load ... lds into a ring of two
+  // 32 KB stages (no VGPRs), and the 32 registers that used to stage it hold two more K tiles of the A (activation) operand:
+  // three A tiles = 48 KB of HBM-sourced bytes in flight per workgroup instead of one (the long-K main loop was bound by
+  // bytes in flight / load latency: ~2 us per K tile against 0.45 us of MFMA issue).  16 + 2 x 32 KB = exactly half a CU's LDS.
+  constexpr bool DMAB = SMX_DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0 && (SMX_BUFLD_WIDE != 0);
+  constexpr int DMAB_STAGE = 64 * TILE_M * 2;                    // one K tile of the weight operand (either layout)
+  constexpr int AB_BYTES = DMAB ? A_BYTES + 2 * DMAB_STAGE : A_BYTES + B_BYTES;
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0)) * 4;   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta]
@@ -78,8 +87,12 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wn = wave >> 1, wm = wave & 1;
+#ifdef SMX_DIAG   // per-wave clock stamps (tools/gemm_stamps.py with libsmx_diag.so); the product kernel carries none
   long long* dbgp = p.dbg ? p.dbg + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 : nullptr;
 #define SMX_STAMP(k) do { if (dbgp && lane == 0) dbgp[k] = clock64(); } while (0)
+#else
+#define SMX_STAMP(k) do { } while (0)
+#endif
   SMX_STAMP(0);
   const int l31 = lane & 31, hi = lane >> 5;
 
@@ -180,7 +193,117 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 #pragma unroll
   for (int q = 0; q < CSN; ++q) cs[q] = 0.f;
   const bool do_cs = !A_KC && p.acolsum != nullptr && tile_m == 0;
-  {
+  if constexpr (DMAB) {
+    // ---- main loop, weight operand on the LDS-DMA ring (see DMAB above) ------------------------------------------------
+    // Per K tile kt (slot kt & 1 of the ring, register stage kt % 3):
+    //   registers -> LDS (A tile kt) | wait: this wave's B pieces of tile kt | barrier | request A tile kt + 3 |
+    //   MFMAs | barrier | request B tile kt + 2 into the slot just read.
+    // vmcnt retires in order; the wait for B(kt) names the vector-memory instructions issued after it that may stay
+    // outstanding: A(kt + 2) (4 loads, step kt - 1; in the prologue A(2) goes out BEFORE B(0)) and B(kt + 1) (8 pieces).
+    // B images (what the fragment reads expect): NT - [256 rows][64 k], 16-byte chunk c of row r at position
+    // c ^ ((r >> 1) & 7) as in stage_store; NN - [64 k][256 columns], 512-byte k rows, granule XOR 4 * (k & 3) as in
+    // wgrad_group.hip.  The DMA lands a 1 KB piece linearly (lane i -> +16 i), so the XOR is applied to the SOURCE granule;
+    // piece j of wave w is piece w + 4 j of the stage: its swizzle term does not depend on j (8 rows x 4 j = 32 j rows,
+    // 2 k rows x 4 j = 8 j k rows), so ONE offset register serves all eight and the piece stride is a scalar offset.
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    constexpr int NSA = 3, NPB = DMAB_STAGE / 1024 / 4;                        // A register stages; B pieces per wave and stage (8)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const long span_b = B_KC ? ((long)(p.M - 1) * p.ldb + p.K) : ((long)(p.K - 1) * p.ldb + p.M);
+    const __amdgpu_buffer_rsrc_t rsb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(B), (short)0, (int)(span_b * 2), 0x00020000);
+    uint32_t vb, piece_delta, kstep_bytes;
+    if constexpr (B_KC) {
+      const int row = wave_u * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+      vb = (uint32_t)((((long)(m0 + row)) * p.ldb + c * 8) * 2);
+      piece_delta = (uint32_t)(32 * p.ldb * 2);
+      kstep_bytes = 64 * 2;
+    } else {
+      const int krow = wave_u * 2 + (lane >> 5), g = (lane & 31) ^ ((krow & 3) << 2);
+      vb = (uint32_t)(((long)krow * p.ldb + m0 + g * 8) * 2);
+      piece_delta = (uint32_t)(8 * p.ldb * 2);
+      kstep_bytes = (uint32_t)(64 * p.ldb * 2);
+    }
+    char* Bring = smem + A_BYTES;
+    const int nk = (kend - kbeg) / BK;
+    // Every step issues its requests UNCONDITIONALLY (no branch in the step: hipcc's vmcnt bookkeeping for the register
+    // loads stays exact, and the explicit waits below are constants); a request for a K tile that does not exist gets bit 31
+    // in its offset register - beyond the buffer's range: zeros come back, nothing is fetched.
+    auto issue_b = [&](int kt) {
+      char* dst = Bring + (kt & 1) * DMAB_STAGE + wave_u * 1024;
+      const bool valid = kt < nk && !ab_nold;
+      const uint32_t so = valid ? (uint32_t)(kbeg / 64 + kt) * kstep_bytes : 0u;
+      const uint32_t vbe = vb | (valid ? 0u : 0x80000000u);
+#pragma unroll
+      for (int j = 0; j < NPB; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_vp)(dst + j * 4096), 16, vbe, so + (valid ? j * piece_delta : 0u), 0, 0);
+    };
+    auto load_a_pred = [&](uint4 (&reg)[TILE_N / 32], int kt) {
+      bufa.load_pred(reg, kbeg + kt * BK, kt < nk && !ab_nold);
+    };
+    // registers -> LDS through inline asm: a ds_write the compiler can see makes it wait for EVERY outstanding LDS-DMA piece
+    // first (vmcnt(0): it assumes the DMA and the store may hit the same LDS bytes), which would serialise the ring
+    const uint32_t a_st = (uint32_t)(uintptr_t)As + (uint32_t)((t >> 3) * 128 + (((t & 7) ^ ((t >> 4) & 7)) << 4));
+    auto store_a = [&](const uint4 (&reg)[TILE_N / 32]) {
+      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int i = 0; i < TILE_N / 32; ++i) {
+        const u32v4 d = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a_st), "v"(d), "n"(i * 4096) : "memory");
+      }
+    };
+    uint4 ra[NSA][TILE_N / 32];
+    // request order of the prologue: A(0) A(1) B(0) A(2) B(1) - behind B(0) sit 4 + 8 requests, as behind every later B(kt)
+    // at the start of its step (A(kt + 2) from step kt - 1, then B(kt + 1)): ONE wait constant, no peeled first step
+    load_a_pred(ra[0], 0);
+    load_a_pred(ra[1], 1);
+    issue_b(0);
+    load_a_pred(ra[2], 2);
+    issue_b(1);
+    SMX_STAMP(1);
+    // one K tile; `st` = its register stage (compile time)
+    auto step = [&](int kt, auto st) {
+      constexpr int s_ = decltype(st)::value;
+      store_a(ra[s_]);
+      // this wave's B pieces of tile kt have landed once at most the 12 requests issued after them are outstanding
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      lds_barrier();
+      load_a_pred(ra[s_], kt + NSA);
+      const char* Bst = Bring + (kt & 1) * DMAB_STAGE;
+      if (!ab_nomfma) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          bf16x8 fa[FN], fb[FM];
+#pragma unroll
+          for (int i = 0; i < FN; ++i) fa[i] = frag_kc(As, fpa[i], kk);
+#pragma unroll
+          for (int j = 0; j < FM; ++j) {
+            if constexpr (B_KC) fb[j] = frag_kc(Bst, fpb[j], kk);
+            else fb[j] = frag_tr_swz512(Bst, wm * WM + j * 32, lane, kk);
+          }
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      lds_barrier();
+      issue_b(kt + 2);
+    };
+    // whole groups of NSA steps without an early exit, the nk % NSA remaining steps as straight-line code: with a `break`
+    // inside the unrolled group the 128 accumulator registers met at three loop exits and hipcc spilled them around every
+    // step (584 B of scratch); and no step is conditional before the loop, so the compiler's own vmcnt count for the
+    // register loads (it merges conservatively at joins) stays at the true 24+ requests behind A(kt)
+    const int nfull = nk / NSA * NSA;
+    for (int kt0 = 0; kt0 < nfull; kt0 += NSA) {
+      step(kt0, ActTag<0>{});
+      step(kt0 + 1, ActTag<1>{});
+      step(kt0 + 2, ActTag<2>{});
+    }
+    if (nfull < nk) step(nfull, ActTag<0>{});
+    if (nfull + 1 < nk) step(nfull + 1, ActTag<1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the predicated tail requests: nothing may land in LDS later)
+  } else {
   // NS register stages of BK reduce-elements each are in flight (issue-early / write-late): for the K = 256..512
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
   // about one HBM/L2 round trip for its whole main loop instead of one per K tile (measured: 2.9 K cycles per
@@ -802,8 +925,10 @@ static int launch_dtype(int layout, GemmParams& p, bool vec, hipStream_t s) {
 
 using namespace smx;
 
+#ifdef SMX_DIAG   // diagnostic build only (libsmx_diag.so): the product library has no global mutable state and no debug export
 long long* g_dbg_stamps = nullptr;   // (tools/gemm_stamps.py; the parked tools/experiments/ffn_fused kernel reads it too)
 extern "C" void smx_debug_set_timing_buffer(void* p) { g_dbg_stamps = reinterpret_cast<long long*>(p); }
+#endif
 
 static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,
                      int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K,
@@ -910,7 +1035,9 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   p.epi_simple = 0;
   if (simple_env && !p.e.c0 && !p.e.colsum) p.epi_simple = (p.e.res || (p.e.flags & SMX_EPI_ACT_GRAD)) ? (simple_env >= 2 ? 2 : 0) : 1;
   p.ablate = cfg().gemm_ablate;                          // (0 unless built with -DSMX_DIAG)
+#ifdef SMX_DIAG
   p.dbg = g_dbg_stamps;
+#endif
   p.epoch = p.e.epoch;
   p.acolsum = acolsum;
   p.dthresh = (unsigned)((double)p.e.drop_p * 4294967296.0);

@@ -160,6 +160,18 @@ struct BufStage {
       reg[i] = make_uint4(r.x, r.y, r.z, r.w);
     }
   }
+  // the same, issued whether the K tile exists or not (`valid` uniform): an invalid request carries bit 31 in its offset -
+  // out of the buffer's range, zeros come back and nothing is fetched (branch-free main loops)
+  __device__ __forceinline__ void load_pred(uint4 (&reg)[ROWS / 32], int k0, bool valid) const {
+    const uint32_t soff = valid ? (uint32_t)k0 * kbytes : 0u;
+    const uint32_t inval = valid ? 0u : 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+      const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i] | inval, soff, 0);
+      reg[i] = make_uint4(r.x, r.y, r.z, r.w);
+    }
+  }
 };
 
 // ---- implicit conv-patch operand (C = 64 channels = one tap per BK = 64 reduce elements / per 64-column tile) --------------
@@ -897,6 +909,21 @@ __device__ __forceinline__ bf16x8 frag_tr_swz(const char* lds, int r, int kk, in
   const char* p0 = lds + k * 256 + ((((c >> 3) ^ ((li >> 2) << 2)) << 4) + (c & 7) * 2);
   const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
   const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * 256));
+  const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+  return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
+}
+
+// fragment of a reduce-strided stage with 512-byte k rows (256 columns), granule XOR 4 * (k & 3): the LDS-DMA weight ring of
+// gemm_kernel (NN) - the image of wgrad_group.hip.  cbase = first column of the 32-column fragment.
+__device__ __forceinline__ bf16x8 frag_tr_swz512(const char* lds, int cbase, int lane, int kk) {
+  typedef short short4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) short4_t* lds_s4;
+  const int li = lane & 15, g1 = (lane >> 4) & 1, hi = lane >> 5;
+  const int k = kk * 16 + hi * 8 + (li >> 2);           // (k & 3) == li >> 2; row k + 4 has the same swizzle
+  const int c = cbase + g1 * 16 + (li & 3) * 4;
+  const char* p0 = lds + k * 512 + ((((c >> 3) ^ ((li >> 2) << 2)) << 4) + (c & 7) * 2);
+  const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
+  const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * 512));
   const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
   return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
 }

@@ -168,12 +168,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
 #else
   constexpr bool ab_nowait = false;
 #endif
+#ifdef SMX_DIAG   // (clock stamps for tools/wgroup_stamps.py: diagnostic build only)
   long long t_start = 0, t_wait = 0, r_start = 0;
   if (p.dbg) { t_start = clock64(); r_start = wall_clock64(); }
+#endif
   for (int s = 0; s < NST - 1 && s < niter; ++s) issue(s);
   for (int itn = 0; itn < niter; ++itn) {
+#ifdef SMX_DIAG
     long long tw0 = 0;
     if (p.dbg) tw0 = clock64();
+#endif
     // this wave's pieces of stage `itn` have landed once at most the (2 NPC each) DMA instructions of the younger stages
     // in flight are outstanding (vmcnt retires in order; nothing else uses vector memory in this loop)
     const int ahead = min(NST - 2, niter - 1 - itn);
@@ -184,7 +188,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
     wg_barrier();                                        // ... and everybody's; the stage read last step is free again
     // the refill of the stage that was read last step is issued piecewise between the MFMA groups below (a DMA piece
     // costs 100-200 issue cycles: eight of them in front of the first MFMA left the matrix pipe idle after every barrier)
+#ifdef SMX_DIAG
     if (p.dbg) t_wait += clock64() - tw0;
+#endif
     const bool refill = itn + NST - 1 < niter;
     const char* As = smem + (itn % NST) * STAGE_BYTES;
     const char* Bs = As + OP_BYTES;
@@ -281,10 +287,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
     }
   }
 
+#ifdef SMX_DIAG
   if (p.dbg && t == 0) {
     long long* d = p.dbg + (long)blockIdx.x * 4;
     d[0] = clock64() - t_start; d[1] = t_wait; d[2] = wall_clock64() - r_start; d[3] = niter;
   }
+#endif
   // ---- slab: acc[i][j][g*4 + q] is dW[n0 + wn*64 + i*32 + l31][m0 + wm*128 + j*32 + g*8 + hi*4 + q] ----------------
   float* slab = it.ws + (long)split * it.M * it.K;
 #pragma unroll
@@ -345,8 +353,10 @@ static int wg_splits(int rows, int total_tiles) {
 
 using namespace smx;
 
+#ifdef SMX_DIAG   // diagnostic build only: the product library has no global mutable state and no debug export
 static long long* g_wg_dbg = nullptr;
 extern "C" void smx_debug_set_wgroup_timing_buffer(void* p) { g_wg_dbg = reinterpret_cast<long long*>(p); }
+#endif
 
 extern "C" int smx_wgrad_group_splits(int rows, const smx_wgrad_item* items, int nitems) {
   if (!items || nitems <= 0 || rows < 64) return 0;
@@ -390,7 +400,9 @@ extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items,
   p.ablate = ablate_env;
   const int pp_env = cfg().wgroup_pp;
   p.pingpong = pp_env;
+#ifdef SMX_DIAG
   p.dbg = g_wg_dbg;
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr_done = false;
   if (!attr_done) {

@@ -84,6 +84,7 @@ class FlatAdamW:
             self._shard_p = torch.zeros(total // self.world, dtype=torch.float32, device=dev)
             self._shard_c = torch.zeros(total // self.world, dtype=torch.bfloat16, device=dev) if self._comm is not None else None
         self._reduced = []            # bucket ranges whose collective was launched in this step (rs_ag: the shards to update)
+        self._shard_layout = None     # rs_ag: the bucket ranges of the first sharded update (= who owns which moment elements)
         self._measure, self._exposed = False, []
         # buckets: list of (start, end) element ranges of the flat buffers, in backward-completion order
         self.buckets = buckets or [(0, total)]
@@ -99,11 +100,25 @@ class FlatAdamW:
             ops.L.check(ops.L.lib().smx_cast_from_f32(ops.L.BF16, ops._p(self.flat_p), ops._p(self.shadow), self.total,
                                                       ops._stream()), "smx_cast_from_f32")
 
+    def _full_moments(self):
+        """Complete copies of the two AdamW moment buffers.  reduce="rs_ag": every rank updates only its 1/world shard of each
+        bucket, so the local buffers are current there and stale elsewhere - the shards are all-gathered bucket by bucket
+        (mirroring the weight all-gather of _apply_update) into fresh tensors; a COLLECTIVE in that mode."""
+        m, v = self.exp_avg.clone(), self.exp_avg_sq.clone()
+        if self._collective and self.reduce == "rs_ag" and self._shard_layout:
+            for a, b in self._shard_layout:
+                sa, sb = self._shard(a, b)
+                for full, local in ((m, self.exp_avg), (v, self.exp_avg_sq)):
+                    dist.all_gather_into_tensor(full[a:b], local[sa:sb].contiguous(), group=self.pg)
+        return m, v
+
     def state_dict(self):
-        """Optimizer state for checkpoint / resume (the weights themselves are in module.state_dict())."""
+        """Optimizer state for checkpoint / resume (the weights themselves are in module.state_dict()).  The moments are
+        always COMPLETE, independent of the gradient exchange mode: with reduce="rs_ag" this is a collective call (every rank
+        must make it; any rank may then write the result) and the checkpoint can be resumed under any mode / world size."""
         step = int(self._dev_step.item()) if self._dev_step is not None else self.step_count
-        return {"step": step, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "skipped_steps": self.skipped_steps(), "total": self.total}
+        m, v = self._full_moments()
+        return {"step": step, "exp_avg": m, "exp_avg_sq": v, "skipped_steps": self.skipped_steps(), "total": self.total}
 
     def load_state_dict(self, sd):
         if sd["total"] != self.total:
@@ -284,6 +299,13 @@ class FlatAdamW:
         if sharded:
             covered = sum(b - a for a, b in self._reduced)
             assert covered == self.total, f"rs_ag: the reduced buckets cover {covered} of {self.total} elements"
+            # the bucket ranges decide which rank owns which element's moments: they must not change between steps
+            layout = tuple(sorted(self._reduced))
+            if self._shard_layout is None:
+                self._shard_layout = layout
+            elif layout != self._shard_layout:
+                raise RuntimeError("FlatAdamW(reduce='rs_ag'): the gradient buckets changed between steps - the AdamW moments are "
+                                   "sharded by bucket and would be mixed up (keep ONE bucket plan, or reduce='allreduce')")
             work = [(self._shard(a, b), self._shard_g[a // W:b // W]) for a, b in self._reduced]
         else:
             work = [((0, self.total), self.flat_g)]

@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/smx.h but not exported"
 
 
+def test_library_exports_nothing_undeclared():
+    """The product library's dynamic `smx_*` symbols are exactly the header's: no debug hooks, no undeclared entry points
+    (the clock-stamp setters live in the -DSMX_DIAG build only)."""
+    import subprocess
+    from summarymixing_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("smx_")})
+    assert exported == _declared(), sorted(set(exported) ^ set(_declared()))
+
+
 def test_ctypes_table_matches_header():
     from summarymixing_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()

@@ -255,3 +255,69 @@ def FlatAdamWBase():
     class Opt(_CpuKernels, FlatAdamW):
         pass
     return Opt(_model(), compute_dtype=torch.float32).flat_p.clone()
+
+
+# ---- checkpoint / resume under reduce="rs_ag": the saved moments are complete (round-3 ADVICE) ---------------------------------
+def _worker_resume(rank, world, port, out, phase):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from summarymixing_amd.trainer import FlatAdamW
+
+        class Opt(_CpuKernels, FlatAdamW):
+            pass
+        enc = _model()
+        opt = Opt(enc, lr=1e-2, max_grad_norm=0.5, compute_dtype=torch.float32, reduce="rs_ag")
+        ranges = [opt.param_range(list(l.parameters())) for l in enc.layers]
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(4, 9, 16, generator=g)
+        R = torch.randn(4, 9, 16, generator=g)
+        lens = torch.tensor([9, 5, 7, 9])
+        pad = torch.arange(9)[None] < lens[:, None]
+        sl = slice(rank * 2, rank * 2 + 2)
+
+        def one_step():
+            opt.zero_grad()
+            _oracle_grads_into(enc, X[sl], pad[sl], R[sl])
+            for a, b in reversed(ranges):
+                opt.reduce_bucket_async(a, b)
+            opt.reduce_bucket_async(ranges[-1][1], opt.total)
+            opt.step()
+
+        if phase == "straight":                                  # three steps in one go
+            for _ in range(3):
+                one_step()
+        elif phase == "save":                                    # two steps, then a checkpoint written by RANK 0 ONLY
+            for _ in range(2):
+                one_step()
+            sd = opt.state_dict()                                # (collective: both ranks call it)
+            if rank == 0:
+                torch.save({"opt": sd, "model": enc.state_dict()}, out + ".ckpt")
+        else:                                                    # fresh processes resume from rank 0's file, one more step
+            ck = torch.load(out + ".ckpt")
+            enc.load_state_dict(ck["model"])
+            opt.load_state_dict(ck["opt"])
+            one_step()
+        full = opt.state_dict()
+        torch.save({"params": opt.flat_p.clone(), "exp_avg": full["exp_avg"], "exp_avg_sq": full["exp_avg_sq"]},
+                   out + f".{phase}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_dp2_rs_ag_checkpoint_resume(tmp_path):
+    """A checkpoint saved from rank 0 under reduce='rs_ag' holds the COMPLETE AdamW moments (each rank only updates its
+    shard): resuming from it and taking one more step gives bit-identical weights and moments to three uninterrupted steps."""
+    out = str(tmp_path / "r")
+    for phase in ("straight", "save", "resume"):
+        mp.spawn(_worker_resume, args=(2, _free_port(), out, phase), nprocs=2, join=True)
+    a0, b0, b1 = torch.load(out + ".straight.0"), torch.load(out + ".resume.0"), torch.load(out + ".resume.1")
+    assert torch.equal(b0["params"], b1["params"])
+    for k in ("params", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(a0[k], b0[k]), k
+    # the saved moments are complete: no half of any bucket is still zero
+    ck = torch.load(out + ".ckpt")["opt"]
+    nz = (ck["exp_avg_sq"] != 0).float().mean().item()
+    full = (a0["exp_avg_sq"] != 0).float().mean().item()
+    assert nz > 0.9 * full, (nz, full)

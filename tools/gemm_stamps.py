@@ -29,6 +29,7 @@ elif layout == "NN":
 else:
     x2 = torch.randn(N, M, device="cuda").bfloat16(); g = torch.zeros(K, M, device="cuda")
     fn = lambda: ops.wgrad(x, x2, g, N, K, M)
+assert "diag" in L.LIB_PATH, "run with SMX_LIB=summarymixing_amd/libsmx_diag.so (SMX_DIAG=1 bash summarymixing_amd/csrc/build.sh): the product library carries no stamps"
 lib = L.lib(); lib.smx_debug_set_timing_buffer.argtypes = [ctypes.c_void_p]
 for _ in range(3): fn()
 buf = torch.zeros(8192 * 4 * 8, dtype=torch.int64, device="cuda")
