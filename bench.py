@@ -115,7 +115,7 @@ def time_kernel(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-PMC_FILES = ("r03_pmc_traffic.txt", "r03_pmc_wgrad_group.txt", "r02_pmc_traffic.txt", "r02_pmc_wgrad_group.txt", "r01_pmc_traffic.txt")
+PMC_FILES = ("r04_pmc_traffic.txt", "r04_pmc_wgrad_group.txt", "r03_pmc_traffic.txt", "r03_pmc_wgrad_group.txt", "r02_pmc_traffic.txt", "r02_pmc_wgrad_group.txt", "r01_pmc_traffic.txt")
 PMC_NOTE = ("HBM bytes per launch read from the COMMITTED PMC passes under profiles/ (TCC FETCH_SIZE x2-corrected + "
             "WRITE_SIZE, separate --pmc passes of tools/pmc_traffic.sh / pmc_wgroup.sh on this exact shape) - a constant of the build, "
             "not measured in this run; null when no pass exists for the shape")
@@ -187,6 +187,15 @@ def roofline_step_kernels(step, dtype, top=8):
     top_name, top_e = max(by_name.items(), key=lambda kv: kv[1][3])
     roof = roof_of(top_name + " (in-step average over its launches, HIP events on the launch stream)", top_e, kernels[0])
     roof["traffic"], roof["traffic_note"] = kernels[0].get("traffic"), PMC_NOTE
+    # kernels whose share of the step is within 10 % (relative) of the headline kernel's: which of them leads changes from box
+    # to box (round 3: the grouped wgrad at 0.61 of the roof and the act-grad dgrad at 0.35 were 12.48 % / 12.40 % of the step),
+    # so they are printed next to the headline instead of silently swapping places
+    top_share = kernels[0]["share_of_step_kernel_time"]
+    roof["co_dominant"] = [
+        {"kernel": k["kernel"], "share_of_step_kernel_time": k["share_of_step_kernel_time"], "launch_us": k["in_step_avg_us"],
+         "calls_per_step": k["calls_per_step"], "frac_hbm": k["frac_hbm"], "frac_mfma": k["frac_mfma"],
+         "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "traffic": k.get("traffic")}
+        for k in kernels[1:] if k["share_of_step_kernel_time"] >= 0.9 * top_share]
     # and, for continuity with rounds 1-2, the dominant kernel FAMILY aggregated over all its shapes
     fam, e = max(by_fam.items(), key=lambda kv: kv[1][3])
     fam_roof = roof_of(f"{fam} (all {e[0]} in-step launches of the family)", e, entry(fam, e))

@@ -36,7 +36,7 @@ namespace smx {
 #define SMX_NS_KC 1
 #endif
 #ifndef SMX_DMAB
-#define SMX_DMAB 1          // wide (128 x 256) bf16 tile: weight operand on an LDS-DMA ring, 3 register stages of the activation operand
+#define SMX_DMAB 0          // wide (128 x 256) bf16 tile: the interleaved LDS-DMA main loop (0: the register-staged loop, for A/B builds)
 #endif
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
@@ -65,13 +65,10 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   constexpr int PH_ROWS = 32 * PH_FRAGS;
   constexpr int NPH = TILE_N / PH_ROWS;
   constexpr int EPI_BYTES = PH_ROWS * (TILE_M * 4 + 16);         // fp32 rows, 16 B row pad
-  // DMAB (wide bf16 tile, aligned operands): the B (weight) operand goes L2 -> LDS by buffer_load ... lds into a ring of two
-  // 32 KB stages (no VGPRs), and the 32 registers that used to stage it hold two more K tiles of the A (activation) operand:
-  // three A tiles = 48 KB of HBM-sourced bytes in flight per workgroup instead of one (the long-K main loop was bound by
-  // bytes in flight / load latency: ~2 us per K tile against 0.45 us of MFMA issue).  16 + 2 x 32 KB = exactly half a CU's LDS.
+  // DMAB (wide bf16 tile, aligned operands): the main loop that interleaves everything with the MFMAs (see there): weight
+  // operand by LDS-DMA into a ring of four half-tiles, activation operand through 4 register stages into two LDS buffers.
   constexpr bool DMAB = SMX_DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0 && (SMX_BUFLD_WIDE != 0);
-  constexpr int DMAB_STAGE = 64 * TILE_M * 2;                    // one K tile of the weight operand (either layout)
-  constexpr int AB_BYTES = DMAB ? A_BYTES + 2 * DMAB_STAGE : A_BYTES + B_BYTES;
+  constexpr int AB_BYTES = DMAB ? 2 * (TILE_N * 32 * 2) + 4 * (TILE_M * 32 * 2) : A_BYTES + B_BYTES;   // DMAB: two A buffers + four ring slots of 32 k
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0)) * 4;   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta]
@@ -194,115 +191,157 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   for (int q = 0; q < CSN; ++q) cs[q] = 0.f;
   const bool do_cs = !A_KC && p.acolsum != nullptr && tile_m == 0;
   if constexpr (DMAB) {
-    // ---- main loop, weight operand on the LDS-DMA ring (see DMAB above) ------------------------------------------------
-    // Per K tile kt (slot kt & 1 of the ring, register stage kt % 3):
-    //   registers -> LDS (A tile kt) | wait: this wave's B pieces of tile kt | barrier | request A tile kt + 3 |
-    //   MFMAs | barrier | request B tile kt + 2 into the slot just read.
-    // vmcnt retires in order; the wait for B(kt) names the vector-memory instructions issued after it that may stay
-    // outstanding: A(kt + 2) (4 loads, step kt - 1; in the prologue A(2) goes out BEFORE B(0)) and B(kt + 1) (8 pieces).
-    // B images (what the fragment reads expect): NT - [256 rows][64 k], 16-byte chunk c of row r at position
-    // c ^ ((r >> 1) & 7) as in stage_store; NN - [64 k][256 columns], 512-byte k rows, granule XOR 4 * (k & 3) as in
-    // wgrad_group.hip.  The DMA lands a 1 KB piece linearly (lane i -> +16 i), so the XOR is applied to the SOURCE granule;
-    // piece j of wave w is piece w + 4 j of the stage: its swizzle term does not depend on j (8 rows x 4 j = 32 j rows,
-    // 2 k rows x 4 j = 8 j k rows), so ONE offset register serves all eight and the piece stride is a scalar offset.
+    // ---- main loop of the wide bf16 tile: ONE instruction stream per wave in which everything overlaps the MFMAs ------------
+    // Measured on the register-staged loop (tools/experiments/ablate_shapes.sh, K = 1024 -> 256 at 64 000 frames): stage
+    // stores + barriers alone 13.6 us, + operand loads 23.6, + MFMA 29.1, all three 37.8 - the parts ADD, because a step was
+    // registers -> LDS | barrier | loads issued | MFMAs | barrier, the same on all eight waves of the CU at the same time.
+    // Here a step is 32 reduce elements and has ONE barrier; between its 16 MFMAs a wave (i) requests the weight half-tile
+    // three steps ahead by LDS-DMA into a ring of four 16 KB slots (no VGPRs, no ds_write), (ii) moves the NEXT step's
+    // activation half-tile from registers into the other one of two 8 KB LDS buffers, (iii) refills those registers with the
+    // half-tile NSA steps ahead.  2 x 8 + 4 x 16 KB = 80 KB = exactly half a CU's LDS (two workgroups per CU as before).
+    // LDS images: A and NT-B [rows][32 k] = 64-byte rows, 16-byte chunk c of row r at position c ^ ((r >> 2) & 3) (any 16
+    // rows x one chunk cover the 64 banks once: conflict-free ds_read_b128); NN-B [32 k][256 columns] = 512-byte k rows,
+    // granule XOR 4 * (k & 3) (wgrad_group.hip).  The DMA lands a 1 KB piece linearly (lane i -> +16 i), so the XOR is
+    // applied to the SOURCE granule; piece j of wave w is piece w + 4 j of the half-tile and its swizzle term does not depend
+    // on j (16 rows x 4 j / 2 k rows x 4 j), so ONE offset register serves all four and the piece stride is a scalar offset.
+    // vmcnt retires in order.  Every step issues exactly 4 DMA pieces then 2 register loads (a request for a half-tile that
+    // does not exist carries bit 31 in its offset: out of the buffer's range, zeros, nothing fetched - so the step is
+    // branch-free, hipcc's own vmcnt count for the register loads stays exact and the explicit wait is ONE constant): at the
+    // end of step h the B pieces of step h + 1 (requested first thing in step h - 2) have landed once at most the
+    // 2 + 6 + 6 = 14 younger requests are outstanding.
     typedef __attribute__((address_space(3))) void* lds_vp;
-    constexpr int NSA = 3, NPB = DMAB_STAGE / 1024 / 4;                        // A register stages; B pieces per wave and stage (8)
+    constexpr int HK = 32, NSA = 4, A_HALF = TILE_N * HK * 2, B_HALF = TILE_M * HK * 2, NPB = B_HALF / 1024 / 4;
+    static_assert(A_HALF == 8192 && B_HALF == 16384 && NPB == 4, "128 x 256 tile");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const long span_b = B_KC ? ((long)(p.M - 1) * p.ldb + p.K) : ((long)(p.K - 1) * p.ldb + p.M);
     const __amdgpu_buffer_rsrc_t rsb =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(B), (short)0, (int)(span_b * 2), 0x00020000);
+    const long span_a = (long)(p.N - 1) * p.lda + p.K;
+    const __amdgpu_buffer_rsrc_t rsa =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), (short)0, (int)(span_a * 2), 0x00020000);
     uint32_t vb, piece_delta, kstep_bytes;
     if constexpr (B_KC) {
-      const int row = wave_u * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+      const int row = wave_u * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
       vb = (uint32_t)((((long)(m0 + row)) * p.ldb + c * 8) * 2);
-      piece_delta = (uint32_t)(32 * p.ldb * 2);
-      kstep_bytes = 64 * 2;
+      piece_delta = (uint32_t)(64 * p.ldb * 2);
+      kstep_bytes = HK * 2;
     } else {
       const int krow = wave_u * 2 + (lane >> 5), g = (lane & 31) ^ ((krow & 3) << 2);
       vb = (uint32_t)(((long)krow * p.ldb + m0 + g * 8) * 2);
       piece_delta = (uint32_t)(8 * p.ldb * 2);
-      kstep_bytes = (uint32_t)(64 * p.ldb * 2);
+      kstep_bytes = (uint32_t)(HK * p.ldb * 2);
     }
-    char* Bring = smem + A_BYTES;
-    const int nk = (kend - kbeg) / BK;
-    // Every step issues its requests UNCONDITIONALLY (no branch in the step: hipcc's vmcnt bookkeeping for the register
-    // loads stays exact, and the explicit waits below are constants); a request for a K tile that does not exist gets bit 31
-    // in its offset register - beyond the buffer's range: zeros come back, nothing is fetched.
-    auto issue_b = [&](int kt) {
-      char* dst = Bring + (kt & 1) * DMAB_STAGE + wave_u * 1024;
-      const bool valid = kt < nk && !ab_nold;
-      const uint32_t so = valid ? (uint32_t)(kbeg / 64 + kt) * kstep_bytes : 0u;
+    // A half-tile: 128 rows x 4 chunks = 2 per thread (v = t + 256 i: row v >> 2, chunk v & 3)
+    uint32_t va[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rg = n0 + ((t + 256 * i) >> 2);
+      va[i] = rg < p.N ? (uint32_t)(((long)rg * p.lda + (t & 3) * 8) * 2) : 0x80000000u;
+    }
+    char* Bring = smem + 2 * A_HALF;
+    const int nh = (kend - kbeg) / HK, h0 = kbeg / HK;
+    auto issue_b = [&](int h, int slot) {
+      char* dst = Bring + slot * B_HALF + wave_u * 1024;
+      const bool valid = h < nh && !ab_nold;
+      const uint32_t so = valid ? (uint32_t)(h0 + h) * kstep_bytes : 0u;
       const uint32_t vbe = vb | (valid ? 0u : 0x80000000u);
 #pragma unroll
       for (int j = 0; j < NPB; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_vp)(dst + j * 4096), 16, vbe, so + (valid ? j * piece_delta : 0u), 0, 0);
     };
-    auto load_a_pred = [&](uint4 (&reg)[TILE_N / 32], int kt) {
-      bufa.load_pred(reg, kbeg + kt * BK, kt < nk && !ab_nold);
+    typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+    auto load_ah = [&](u32v4 (&reg)[2], int h) {
+      const bool valid = h < nh && !ab_nold;
+      const uint32_t so = valid ? (uint32_t)(h0 + h) * (HK * 2) : 0u, inval = valid ? 0u : 0x80000000u;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, va[i] | inval, so, 0);
     };
     // registers -> LDS through inline asm: a ds_write the compiler can see makes it wait for EVERY outstanding LDS-DMA piece
     // first (vmcnt(0): it assumes the DMA and the store may hit the same LDS bytes), which would serialise the ring
-    const uint32_t a_st = (uint32_t)(uintptr_t)As + (uint32_t)((t >> 3) * 128 + (((t & 7) ^ ((t >> 4) & 7)) << 4));
-    auto store_a = [&](const uint4 (&reg)[TILE_N / 32]) {
-      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-      for (int i = 0; i < TILE_N / 32; ++i) {
-        const u32v4 d = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
-        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a_st), "v"(d), "n"(i * 4096) : "memory");
-      }
+    const uint32_t a_st = (uint32_t)(uintptr_t)As + (uint32_t)((t >> 2) * 64 + (((t & 3) ^ ((t >> 4) & 3)) << 4));
+    auto store_ah = [&](const u32v4 (&reg)[2], int buf) {
+      const uint32_t ad = a_st + buf * A_HALF;
+      asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(reg[0]) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(ad), "v"(reg[1]) : "memory");
     };
-    uint4 ra[NSA][TILE_N / 32];
-    // request order of the prologue: A(0) A(1) B(0) A(2) B(1) - behind B(0) sit 4 + 8 requests, as behind every later B(kt)
-    // at the start of its step (A(kt + 2) from step kt - 1, then B(kt + 1)): ONE wait constant, no peeled first step
-    load_a_pred(ra[0], 0);
-    load_a_pred(ra[1], 1);
-    issue_b(0);
-    load_a_pred(ra[2], 2);
-    issue_b(1);
+    uint32_t fqa[FN], fqb[FM];                           // loop-invariant fragment addresses (64-byte rows)
+#pragma unroll
+    for (int i = 0; i < FN; ++i) { const int r = wn * WN + i * 32 + l31; fqa[i] = (uint32_t)(r * 64 + ((hi ^ ((r >> 2) & 3)) << 4)); }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) { const int r = wm * WM + j * 32 + l31; fqb[j] = (uint32_t)(r * 64 + ((hi ^ ((r >> 2) & 3)) << 4)); }
+    auto frag32 = [&](const char* lds, uint32_t pre, int kk) {
+      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (pre ^ (uint32_t)(kk << 5))));
+    };
+    u32v4 ra[NSA][2];
+    // prologue = the request stream of "steps -3 .. -1": A(0) A(1) B(0) | B(1) A(2) | B(2) A(3), then A(0) into LDS and A(4)
+    load_ah(ra[0], 0);
+    load_ah(ra[1], 1);
+    issue_b(0, 0);
+    issue_b(1, 1);
+    load_ah(ra[2], 2);
+    issue_b(2, 2);
+    load_ah(ra[3], 3);
+    store_ah(ra[0], 0);
+    load_ah(ra[0], NSA);
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");     // B(0): behind it 4 + 2 + 4 + 2 + 2 requests
+    lds_barrier();
     SMX_STAMP(1);
-    // one K tile; `st` = its register stage (compile time)
-    auto step = [&](int kt, auto st) {
-      constexpr int s_ = decltype(st)::value;
-      store_a(ra[s_]);
-      // this wave's B pieces of tile kt have landed once at most the 12 requests issued after them are outstanding
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      lds_barrier();
-      load_a_pred(ra[s_], kt + NSA);
-      const char* Bst = Bring + (kt & 1) * DMAB_STAGE;
+    // one step of 32 reduce elements; U = h mod 4 (compile time): B slot U, A buffer U & 1, next A in register stage (U + 1) & 3
+    auto step = [&](int h, auto utag) {
+      constexpr int U = decltype(utag)::value;
+      const char* Ab = As + (U & 1) * A_HALF;
+      const char* Bb = Bring + U * B_HALF;
+      bf16x8 fa[2][FN], fb[2][FM];
+#pragma unroll
+      for (int i = 0; i < FN; ++i) fa[0][i] = frag32(Ab, fqa[i], 0);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        if constexpr (B_KC) fb[0][j] = frag32(Bb, fqb[j], 0);
+        else fb[0][j] = frag_tr_swz512(Bb, wm * WM + j * 32, lane, 0);
+      }
+      issue_b(h + 3, (U + 3) & 3);
+#pragma unroll
+      for (int i = 0; i < FN; ++i) fa[1][i] = frag32(Ab, fqa[i], 1);
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        if constexpr (B_KC) fb[1][j] = frag32(Bb, fqb[j], 1);
+        else fb[1][j] = frag_tr_swz512(Bb, wm * WM + j * 32, lane, 1);
+      }
       if (!ab_nomfma) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-          bf16x8 fa[FN], fb[FM];
+        for (int i = 0; i < FN; ++i)
 #pragma unroll
-          for (int i = 0; i < FN; ++i) fa[i] = frag_kc(As, fpa[i], kk);
-#pragma unroll
-          for (int j = 0; j < FM; ++j) {
-            if constexpr (B_KC) fb[j] = frag_kc(Bst, fpb[j], kk);
-            else fb[j] = frag_tr_swz512(Bst, wm * WM + j * 32, lane, kk);
-          }
-#pragma unroll
-          for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
+          for (int j = 0; j < FM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
       }
+      store_ah(ra[(U + 1) & 3], (U + 1) & 1);
+      load_ah(ra[(U + 1) & 3], h + 1 + NSA);
+      if (!ab_nomfma) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
       lds_barrier();
-      issue_b(kt + 2);
     };
-    // whole groups of NSA steps without an early exit, the nk % NSA remaining steps as straight-line code: with a `break`
-    // inside the unrolled group the 128 accumulator registers met at three loop exits and hipcc spilled them around every
-    // step (584 B of scratch); and no step is conditional before the loop, so the compiler's own vmcnt count for the
-    // register loads (it merges conservatively at joins) stays at the true 24+ requests behind A(kt)
-    const int nfull = nk / NSA * NSA;
-    for (int kt0 = 0; kt0 < nfull; kt0 += NSA) {
-      step(kt0, ActTag<0>{});
-      step(kt0 + 1, ActTag<1>{});
-      step(kt0 + 2, ActTag<2>{});
+    // whole groups of four steps without an early exit, then the remaining pair (K % 64 == 0: nh is even) as straight-line
+    // code: with a `break` inside an unrolled group the 128 accumulator registers meet at several loop exits and hipcc
+    // spills them around every step
+    const int nfull = nh / 4 * 4;
+    for (int hb = 0; hb < nfull; hb += 4) {
+      step(hb, ActTag<0>{});
+      step(hb + 1, ActTag<1>{});
+      step(hb + 2, ActTag<2>{});
+      step(hb + 3, ActTag<3>{});
     }
-    if (nfull < nk) step(nfull, ActTag<0>{});
-    if (nfull + 1 < nk) step(nfull + 1, ActTag<1>{});
+    if (nfull < nh) {
+      step(nfull, ActTag<0>{});
+      step(nfull + 1, ActTag<1>{});
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the predicated tail requests: nothing may land in LDS later)
+    lds_barrier();
   } else {
   // NS register stages of BK reduce-elements each are in flight (issue-early / write-late): for the K = 256..512
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays

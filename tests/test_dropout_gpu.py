@@ -6,7 +6,7 @@ import torch
 
 from tests._util import rel_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ln_fuse_mode")]   # (both LayerNorm dispatches: tests/conftest.py)
 
 
 def test_dropout_kernel_statistics_and_determinism():

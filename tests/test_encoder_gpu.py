@@ -6,7 +6,7 @@ import torch
 from tests import _golden as G
 from tests._util import TOL, rel_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ln_fuse_mode")]   # (both LayerNorm dispatches: tests/conftest.py)
 ACT = {"gelu": torch.nn.GELU, "swish": "swish"}
 
 

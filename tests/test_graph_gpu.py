@@ -3,7 +3,7 @@ and the dropout epoch advancing although every captured kernel argument is const
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ln_fuse_mode")]   # (both LayerNorm dispatches: tests/conftest.py)
 
 
 def _setup(dropout):

@@ -557,7 +557,10 @@ def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
         F._wgrad(dz, x, gW, rows, M, K, gb)
         F.flush_deferred()
         outs.append((gW.clone(), gb.clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dW, db = (outs[0][0] - outs[1][0]).abs(), (outs[0][1] - outs[1][1]).abs()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (
+        f"dW: {int((dW > 0).sum())} differ, max {float(dW.max())}, nan {int(torch.isnan(dW).sum())}, rows {(dW > 0).nonzero()[:, 0].unique()[:6].tolist()}, "
+        f"cols {(dW > 0).nonzero()[:, 1].unique()[:6].tolist()}; db: {int((db > 0).sum())} differ, max {float(db.max())}")
     gW2, gb2 = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
     ops.wgrad(dz, x, gW2, rows, M, K, dbias=gb2)        # the per-weight slab GEMM + reduction
     assert rel_err(outs[0][0], gW2) < 1e-5 and rel_err(outs[0][1], gb2) < 1e-5

@@ -7,7 +7,7 @@ import torch
 from oracle import smx_oracle as O
 from tests._util import rel_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ln_fuse_mode")]   # (both LayerNorm dispatches: tests/conftest.py)
 
 
 def test_waveform_to_ctc_loss_matches_oracle_chain():

@@ -5,7 +5,7 @@ import torch
 
 from tests._util import rel_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ln_fuse_mode")]   # (both LayerNorm dispatches: tests/conftest.py)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

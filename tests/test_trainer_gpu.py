@@ -15,7 +15,7 @@ import sys
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ln_fuse_mode")]   # (both LayerNorm dispatches: tests/conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 COMMON = r'''

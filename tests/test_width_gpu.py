@@ -16,7 +16,7 @@ import torch
 
 from tests._util import report, rel_err, rms_rel
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ln_fuse_mode")]   # (both LayerNorm dispatches: tests/conftest.py)
 
 
 def _init(mod, seed):

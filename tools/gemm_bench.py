@@ -95,8 +95,8 @@ def run(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
     ops.prof_start()                                     # the name this launch carries in bench.py's in-step records
     fn()
     rec = ops.prof_stop()
-    if rec:
-        open("/tmp/pmc_name.txt", "w").write(rec[0][0])
+    if rec:   # name AND algorithmic bytes of this launch as bench.py's in-step records carry them (ONE byte model: ops.gemm)
+        open("/tmp/pmc_name.txt", "w").write(f"{rec[0][0]}\n{rec[0][1]:.0f}\n")
     t = time_kernel(fn, iters=20, warm=3)
     fl = 2.0 * N * K * M
     print(f"{layout} N={N:6d} K={K:5d} M={M:5d} {epi:7s} {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s  {nbytes/t/1e9:7.0f} GB/s(alg)", flush=True)

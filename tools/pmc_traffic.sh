@@ -13,10 +13,12 @@ run() {  # name, kernel substring, command...
   python3 - "$name" "$pat" <<'PY'
 import csv, glob, sys, collections
 name, pat = sys.argv[1], sys.argv[2]
-if name.startswith("@"):                       # "@ suffix": the launch's own in-step name (written by tools/gemm_bench.py) + suffix
-    try:
-        name = open("/tmp/pmc_name.txt").read().strip() + " " + name[1:].strip()
-    except OSError:
+if name.startswith("@"):                       # "@ suffix": the launch's own in-step name (written by tools/gemm_bench.py) + suffix,
+    try:                                       # and its algorithmic bytes from the SAME model bench.py uses (ops.gemm's record)
+        rec = open("/tmp/pmc_name.txt").read().split("\n")
+        alg = f"; algorithmic {float(rec[1]) / 1e6:.1f} MB]" if len(rec) > 1 and rec[1].strip() else "]"
+        name = rec[0].strip() + " " + name[1:].strip().rstrip("]") + alg
+    except (OSError, ValueError):
         pass
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -42,10 +44,10 @@ run "gemm NT bf16 64000x1024 . 1024x256 +bias+res+drop, no LayerNorm epilogue [a
 run "dwconv_bwd (128,500,256) k=31 [algorithmic 163.8 MB: 98.3 read, 65.5 write]" dwconv_rolls_bwd python3 "$ROOT/tools/one_dwconv.py"
 run "dwconv_fwd (128,500,256) k=31 [algorithmic 98.3 MB: 65.5 read, 32.8 write]" dwconv_rolls_fwd python3 "$ROOT/tools/one_dwconv.py"
 # ---- round 3: the LayerNorm-fused instantiations on the float32 residual stream (names = the in-step names of bench.py) ----
-run "@ [FFN down-projection -> norm1; algorithmic 328.2 MB]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTln 64000 1024 256
-run "@ [FFN down-projection -> norm2, fp32 LayerNorm output; algorithmic 361.0 MB]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTln2 64000 1024 256
-run "@ [the cell's merge, K = l + s; algorithmic 295.4 MB]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTlnm 64000 512 256
-run "@ [conv-module out-projection; algorithmic 229.9 MB]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTlnc 64000 256 256
-run "@ [dgrad K=1024 + LayerNorm backward, fp32 ln_x; algorithmic 328.2 MB]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NNlnb 64000 1024 256
-run "@ [dgrad K=512 + LayerNorm backward, fp32 ln_x; algorithmic 262.7 MB]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NNlnb 64000 512 256
-run "@ [dgrad K=512 + LayerNorm backward + act-grad second output; algorithmic 295.4 MB]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NNlnb3 64000 512 256
+run "@ [FFN down-projection -> norm1]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTln 64000 1024 256
+run "@ [FFN down-projection -> norm2, fp32 LayerNorm output]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTln2 64000 1024 256
+run "@ [the cell's merge, K = l + s]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTlnm 64000 512 256
+run "@ [conv-module out-projection]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NTlnc 64000 256 256
+run "@ [dgrad K=1024 + LayerNorm backward, fp32 ln_x]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NNlnb 64000 1024 256
+run "@ [dgrad K=512 + LayerNorm backward, fp32 ln_x]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NNlnb 64000 512 256
+run "@ [dgrad K=512 + LayerNorm backward + act-grad second output]" gemm_kernel python3 "$ROOT/tools/one_gemm.py" NNlnb3 64000 512 256

@@ -4,6 +4,11 @@ usage: prof_by_grid.py results.db [steps] [name-substring]"""
 import re, sqlite3, sys
 con = sqlite3.connect(sys.argv[1])
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+# a training profile counts its own steps: one adamw_kernel launch per optimizer step (the warm-up / settle steps a
+# command runs besides its --steps are in the trace too; round 3 divided a C4 trace of 8 steps by the 7 on its command line)
+_n = con.execute("select count(*) from kernels where name like '%adamw_kernel%'").fetchone()[0]
+if _n > 0:
+    steps = _n
 pat = sys.argv[3] if len(sys.argv) > 3 else "gemm_kernel"
 rows = con.execute("select name, grid_x, grid_y, count(*), sum(end-start), avg(end-start) from kernels where name like ? "
                    "group by name, grid_x, grid_y order by 5 desc", (f"%{pat}%",)).fetchall()

@@ -4,6 +4,11 @@ usage: prof_summary.py results.db [steps]   -> markdown-ish table on stdout (com
 import re, sqlite3, sys
 con = sqlite3.connect(sys.argv[1])
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+# a training profile counts its own steps: one adamw_kernel launch per optimizer step (the warm-up / settle steps a
+# command runs besides its --steps are in the trace too; round 3 divided a C4 trace of 8 steps by the 7 on its command line)
+_n = con.execute("select count(*) from kernels where name like '%adamw_kernel%'").fetchone()[0]
+if _n > 0:
+    steps = _n
 rows = con.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
 tot = sum(r[2] for r in rows)
 print(f"total kernel time {tot/1e6:.2f} ms over {steps} steps = {tot/1e6/steps:.2f} ms/step")
