@@ -356,6 +356,58 @@ def cpu_baseline_stack(cfg, cores):
                       f"torch {torch.__version__}, {cores} threads"}
 
 
+def rccl_env():
+    """The RCCL / NCCL / HSA variables this process sees (what shaped the collectives of a multi-GPU run)."""
+    keys = sorted(k for k in os.environ if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE")))
+    return {k: os.environ[k] for k in keys}
+
+
+def want_graph_for(args, cfg, train, dist_run):
+    """The launch mode bench.py would pick (mirrors main()): (hipGraph?, reason)."""
+    want = args.graph == "on" or (args.graph == "auto" and cfg["B"] * cfg["T"] < 40000)
+    if not want:
+        return False, "eager: >= 40000 frames per GPU hide the host launch path behind the kernels"
+    if train and dist_run and args.reduce == "rs_ag":
+        return False, "eager: the sharded update (reduce-scatter / all-gather inside the step) stays out of graphs"
+    if train and dist_run:
+        return True, "two graphs [zero_grad + forward + backward] | ONE eager RCCL all-reduce of the flat gradients | [clip + AdamW]"
+    return True, "one graph of the whole step"
+
+
+def dp_plan(args, world):
+    """The data-parallel plan of `--gpus world` WITHOUT GPUs: model and flat layout on the CPU (same constructor, same
+    parameter order), buckets / shards from summarymixing_amd.trainer.plan_buckets / shard_map."""
+    from summarymixing_amd.trainer import ALIGN, FlatAdamW, plan_buckets, shard_map
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["B"] = args.batch
+    if args.frames:
+        cfg["T"] = args.frames
+    if cfg.get("stack_only"):
+        raise SystemExit("--dry-run-ranks: config c5 is forward-only (no gradient exchange)")
+    enc = build_encoder(cfg, torch.device("cpu"), 0.0)
+    opt = FlatAdamW(enc, compute_dtype=torch.float32)      # (CPU: flat layout only, no kernels)
+    layer_ranges = [opt.param_range(list(l.parameters())) for l in enc.transformer.encoder.layers]
+    buckets = plan_buckets(opt.total, layer_ranges)
+    gsz = 2 if args.grad_dtype == "bf16" else 4
+    shards = shard_map(buckets, world)
+    covered = sum(b - a for a, b, _ in buckets)
+    graph, why = want_graph_for(args, cfg, True, world > 1)
+    gb = opt.total * gsz
+    return {
+        "dry_run_ranks": world, "config": args.config, "per_gpu_batch": cfg["B"], "enc_frames_per_utt": cfg["T"],
+        "parameters": sum(p.numel() for p in opt.params), "flat_elements": opt.total, "align_elements": ALIGN,
+        "reduce": args.reduce, "grad_dtype": args.grad_dtype,
+        "buckets_in_launch_order": [{"name": n, "start": a, "end": b, "wire_dtype_bytes": (b - a) * gsz} for a, b, n in buckets],
+        "buckets_cover_flat_buffer_exactly_once": covered == opt.total and len({(a, b) for a, b, _ in buckets}) == len(buckets),
+        "rs_ag_shards_rank0": shards[0], "rs_ag_shard_elements_per_rank": [sum(b - a for a, b in shards[r]) for r in range(world)],
+        "wire_bytes_per_rank_per_step": (2.0 * (world - 1) / world * gb if args.reduce == "allreduce"
+                                         else (world - 1) / world * (gb + opt.total * 4)),
+        "xgmi_ring_floor_ms_at_153GBps_per_link": (2.0 * (world - 1) / world * gb) / 153e9 * 1e3 if world > 1 else 0.0,
+        "hipgraph": graph, "launch_mode": why, "rccl_env": rccl_env(),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,7 +440,14 @@ def main():
                     help="skip the extra_points of the default line (SURVEY 8d batches: C2b B=64 x 500, C2a B=10 x 375, and the bf16 "
                          "residual stream), each a short child run of this script")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run-ranks", type=int, default=0, metavar="N",
+                    help="no GPU needed: build the model on the CPU, print the N-rank data-parallel plan (gradient buckets in "
+                         "launch order, the rs_ag shard map, bytes on the wire, the hipGraph split decision, the RCCL environment) "
+                         "as one JSON line and exit")
     args = ap.parse_args()
+    if args.dry_run_ranks:
+        print(json.dumps(dp_plan(args, args.dry_run_ranks)))
+        return
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become N ranks (one process per GPU) under torch.distributed.run
@@ -598,7 +657,17 @@ def main():
             torch.distributed.all_reduce(ct, op=torch.distributed.ReduceOp.MAX)
             ce = float(ct.item())
         gb = opt.total * (2 if args.grad_dtype == "bf16" else 4)
-        out["comm"] = {"reduce": args.reduce, "grad_dtype": args.grad_dtype, "buckets": len(enc.transformer.encoder.layers) + 2,
+        ce_ranks = [ce]
+        if world > 1 or force_dist:                       # every rank's own figure (a straggler shows here, not in the max)
+            ca = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            torch.distributed.all_gather(ca, torch.tensor([opt.comm_exposed_ms() if dist_run else 0.0], device=dev, dtype=torch.float64))
+            ce_ranks = [float(c.item()) for c in ca]
+        from summarymixing_amd.trainer import plan_buckets
+        gsz = 2 if args.grad_dtype == "bf16" else 4
+        plan = plan_buckets(opt.total, [opt.param_range(list(l.parameters())) for l in enc.transformer.encoder.layers])
+        out["comm"] = {"reduce": args.reduce, "grad_dtype": args.grad_dtype, "buckets": len(plan),
+                       "bucket_bytes_in_launch_order": [(b - a) * gsz for a, b, _ in plan],
+                       "comm_exposed_ms_per_rank": ce_ranks, "rccl_env": rccl_env(),
                        "gradient_bytes_per_rank": gb,
                        "wire_bytes_per_rank": (2.0 * (world - 1) / world * gb if args.reduce == "allreduce"
                                                else (world - 1) / world * (gb + opt.total * 4)),

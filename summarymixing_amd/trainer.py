@@ -33,6 +33,34 @@ from . import ops
 ALIGN = 64   # elements; keeps every parameter view 256-byte aligned in fp32 and 128-byte in bf16
 
 
+def plan_buckets(total, layer_ranges):
+    """The gradient buckets of one step in the order their collectives are launched: the encoder layers' ranges as their
+    backward passes finish (last layer first), then what lies in front of the first layer (input projection) and behind the
+    last one (final LayerNorm).  Pure function of the flat layout: bench.py --dry-run-ranks prints it without a GPU."""
+    ranges = sorted(layer_ranges)
+    out = [(a, b, f"layer {len(ranges) - 1 - i}") for i, (a, b) in enumerate(reversed(ranges))]
+    if ranges and ranges[0][0] > 0:
+        out.append((0, ranges[0][0], "front (parameters registered before the layers)"))
+    if ranges and ranges[-1][1] < total:
+        out.append((ranges[-1][1], total, "back (parameters registered behind the layers: final LayerNorm, input projection)"))
+    if not ranges:
+        out.append((0, total, "all"))
+    return out
+
+
+def shard_map(buckets, world):
+    """reduce='rs_ag': rank r owns elements [a + r n, a + (r + 1) n), n = (b - a) / world, of every bucket [a, b) - its share of
+    the reduce-scattered gradients, of the AdamW moments and of the update.  -> {rank: [(start, end), ...]}"""
+    out = {r: [] for r in range(world)}
+    for a, b, *_ in buckets:
+        if (b - a) % world:
+            raise ValueError(f"bucket [{a}, {b}) does not divide over {world} ranks (ALIGN = {ALIGN} elements per parameter)")
+        n = (b - a) // world
+        for r in range(world):
+            out[r].append((a + r * n, a + (r + 1) * n))
+    return out
+
+
 class FlatAdamW:
     def __init__(self, module, lr=8e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, max_grad_norm=5.0,
                  compute_dtype=torch.bfloat16, process_group=None, buckets=None, reduce="allreduce", grad_dtype=torch.float32):
