@@ -67,6 +67,8 @@ typedef struct smx_config {
   int32_t ln_tile_rows;     /* rows of the LayerNorm-fused GEMM tile (128; see smx_gemm_ln_tile_rows)        */
   int32_t gemm_ablate, wgroup_ablate, dwroll_ablate;   /* SMX_DIAG builds only                                  */
   int32_t diag_build;       /* 1 when the library was compiled with -DSMX_DIAG                               */
+  int32_t t256;             /* SMX_T256: 256 x 256 GEMM tile (one workgroup per CU, software-pipelined K loop)
+                               0 off, 1 for K >= 2048 (1), 2 for every eligible shape (tests)                  */
 } smx_config;
 int smx_get_config(smx_config* out);
 /* rows per tile of the LayerNorm-fused GEMMs (SMX_EPI_LN_BWD writes ceil(N / rows) partial row pairs into ln_partial) */

@@ -179,7 +179,7 @@ class Config(ctypes.Structure):
                 ("wgroup_blocks", ctypes.c_int32), ("wgroup_bk", ctypes.c_int32), ("wgroup_pp", ctypes.c_int32),
                 ("dwroll", ctypes.c_int32), ("dwroll_csgu", ctypes.c_int32), ("dwroll_seg", ctypes.c_int32), ("ln_tile_rows", ctypes.c_int32),
                 ("gemm_ablate", ctypes.c_int32), ("wgroup_ablate", ctypes.c_int32), ("dwroll_ablate", ctypes.c_int32),
-                ("diag_build", ctypes.c_int32)]
+                ("diag_build", ctypes.c_int32), ("t256", ctypes.c_int32)]
 
 
 def get_config():

@@ -52,6 +52,7 @@ const smx_config& cfg() {
     { const char* e = getenv("SMX_DWROLL_CSGU"); k.dwroll_csgu = (e && e[0] == '0') ? 0 : 1; }
     k.dwroll_seg = env_i("SMX_DWROLL_SEG", 0);
     k.ln_tile_rows = 128;
+    k.t256 = env_i("SMX_T256", 1);
 #ifdef SMX_DIAG
     k.gemm_ablate = env_i("SMX_GEMM_ABLATE", 0);
     k.wgroup_ablate = env_i("SMX_WGROUP_ABLATE", 0);

@@ -21,6 +21,8 @@
 //  * blockIdx is remapped so that the M-tiles that share one A row panel land on the same XCD (same L2).
 //  * TN/wgrad reduces over the (long) frame dimension: split-K over blockIdx.y with fp32 atomics into the
 //    caller-zeroed gradient buffer.
+#include <utility>
+
 #include "gemm_common.h"
 
 namespace smx {
@@ -35,9 +37,45 @@ namespace smx {
 #ifndef SMX_NS_KC
 #define SMX_NS_KC 1
 #endif
+#ifndef SMX_FRAG_PIPE
+#define SMX_FRAG_PIPE 1     // wide bf16 tile: fragment reads interleaved one per MFMA (sched_group_barrier), 0 = hipcc's own order
+#endif
+#ifndef SMX_T256_ABL
+#define SMX_T256_ABL 0
+#endif
 #ifndef SMX_DMAB
 #define SMX_DMAB 0          // wide (128 x 256) bf16 tile: the interleaved LDS-DMA main loop (0: the register-staged loop, for A/B builds)
 #endif
+
+// scheduling groups of one K step of the 256 x 256 tile (see T256P in gemm_kernel): after MFMA number S (sub-step S / MPK, slot
+// S % MPK) at most one fragment read of the NEXT sub-step, a ds_write after every fourth MFMA and a buffer load two MFMAs later
+template <int MASK, int N>
+__device__ __forceinline__ void sched_group() {
+  if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+}
+template <int LO, typename F, int... Is>
+__device__ __forceinline__ void for_seq_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(ActTag<LO + Is>{}), ...);
+}
+// f(ActTag<LO>{}), ..., f(ActTag<HI - 1>{}) - a compile-time loop whose index is a constant inside f
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void for_seq(F&& f) {
+  if constexpr (LO < HI) for_seq_impl<LO>(static_cast<F&&>(f), std::make_integer_sequence<int, HI - LO>{});
+}
+template <int RPK, int MPK, int NKK, int S>
+__device__ __forceinline__ void t256_group_one() {
+  constexpr int kk = S / MPK, q = S % MPK;
+  sched_group<0x008, 1>();
+  constexpr int per = (RPK + MPK - 1) / MPK;              // reads per slot (1; 2 only when a sub-step has more reads than MFMAs)
+  constexpr int left = RPK - q * per;
+  sched_group<0x100, (kk + 1 < NKK && left > 0) ? (left < per ? left : per) : 0>();
+  sched_group<0x200, (q % 4 == 1) ? 1 : 0>();
+  sched_group<0x020, (q % 4 == 3) ? 1 : 0>();
+}
+template <int RPK, int MPK, int NKK, int... S>
+__device__ __forceinline__ void t256_groups(std::integer_sequence<int, S...>) {
+  (t256_group_one<RPK, MPK, NKK, S>(), ...);
+}
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
@@ -47,7 +85,7 @@ namespace smx {
 // GATHER (bf16, 64 x 64 tile): 1 = the A operand of an NT GEMM, 2 = the B operand of a TN GEMM is the implicit patch matrix of a
 // 3 x 3 / stride 2 convolution over 64 channels (GemmParams::g_*): the front-end's second block without im2col.
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0, int GATHER = 0>
-__global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC))) void gemm_kernel(GemmParams p) {
   static_assert(GATHER == 0 || GATHER >= 3 || (sizeof(T) == 2 && VEC && TILE_N == 64 && TILE_M == 64 && LNF == 0), "GATHER 1 / 2: bf16 64 x 64 tile");
   static_assert(GATHER < 3 || (sizeof(T) == 4 && A_KC && B_KC && LNF == 0), "GATHER 3 / 4 (folded DFT frames): float32 NT");
   static_assert(GATHER != 1 || (A_KC && B_KC), "GATHER 1: NT");
@@ -68,7 +106,10 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
   // DMAB (wide bf16 tile, aligned operands): the main loop that interleaves everything with the MFMAs (see there): weight
   // operand by LDS-DMA into a ring of four half-tiles, activation operand through 4 register stages into two LDS buffers.
   constexpr bool DMAB = SMX_DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0 && (SMX_BUFLD_WIDE != 0);
-  constexpr int AB_BYTES = DMAB ? 2 * (TILE_N * 32 * 2) + 4 * (TILE_M * 32 * 2) : A_BYTES + B_BYTES;   // DMAB: two A buffers + four ring slots of 32 k
+  // T256P (256 x 256 bf16 tile, one workgroup of four waves per CU): software-pipelined main loop with double-buffered LDS stages
+  constexpr bool T256P = sizeof(T) == 2 && VEC && A_KC && TILE_N == 256 && TILE_M == 256 && GATHER == 0 && LNF == 0;
+  constexpr int AB_BYTES = DMAB ? 2 * (TILE_N * 32 * 2) + 4 * (TILE_M * 32 * 2)   // DMAB: two A buffers + four ring slots of 32 k
+                                : (T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES);
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0)) * 4;   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta]
@@ -342,6 +383,91 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the predicated tail requests: nothing may land in LDS later)
     lds_barrier();
+  } else if constexpr (T256P) {
+    // ---- 256 x 256 tile: ONE wave per SIMD (128 x 128 outputs = 256 accumulator registers), nobody else hides its latencies,
+    // so the K loop is software-pipelined the way the vendor library's is.  Step h multiplies stage h out of LDS buffer h & 1
+    // and, between its 64 MFMAs, (i) moves stage h + 1 from registers into the OTHER buffer, (ii) refills those registers from
+    // memory (activations two stages ahead, weights - L2 resident - one), (iii) reads the fragments of the next 16-element
+    // sub-step.  One barrier per step.  The instruction order is requested from the scheduler with sched_group_barrier groups:
+    // per MFMA at most one fragment read, every fourth a ds_write, every fourth a buffer load.
+    // Per 64 reduce elements and CU: 64 KB through the vector-memory pipe and into LDS, 128 KB of fragment reads, for
+    // 2048 cycles of MFMA issue per SIMD (two 128 x 256 workgroups: 96 KB / 192 KB for the same flops).
+    char* Abuf = smem;
+    char* Bbuf = smem + 2 * A_BYTES;
+    const int nk = (kend - kbeg) / BK;
+    uint4 ra[2][TILE_N / 32], rb[TILE_M / 32];
+    bufa.load_pred(ra[0], kbeg, nk > 0 );
+    bufa.load_pred(ra[1], kbeg + BK, nk > 1 );
+    bufb.load_pred(rb, kbeg, nk > 0 );
+    stage_store<T, true, TILE_N>(ra[0], Abuf, t);
+    stage_store<T, B_KC, TILE_M>(rb, Bbuf, t);
+    bufa.load_pred(ra[0], kbeg + 2 * BK, nk > 2 );
+    bufb.load_pred(rb, kbeg + BK, nk > 1 );
+    lds_barrier();
+    SMX_STAMP(1);
+    // piece p of a stage = the p-th 16-byte vector of this thread (0..7 activations, 8..15 weights): its LDS address is a base
+    // plus p times a constant (stage_store: v = t + 256 p), so a piece is one ds_write_b128 / one buffer_load_dwordx4
+    const uint32_t a_st = (uint32_t)((t >> 3) * 128 + (((t & 7) ^ ((t >> 4) & 7)) << 4));
+    const uint32_t b_st = B_KC ? a_st : (uint32_t)((t >> 5) * ((TILE_M + 32) * 2) + (t & 31) * 16);
+    constexpr uint32_t A_PIECE = 32 * 128, B_PIECE = B_KC ? 32 * 128 : 8 * (TILE_M + 32) * 2;
+    constexpr int NPA = TILE_N / 32;
+    static_assert(TILE_N / 32 + TILE_M / 32 == 4 * (BK / 16), "one piece after every fourth MFMA");
+    auto step = [&](int h, auto utag) {
+      constexpr int U = decltype(utag)::value;                                      // h & 1
+      constexpr int ABL = SMX_T256_ABL;   // experiment builds: 1 no ds_write, 2 no global loads, 4 no fragment reads, 8 no MFMA, 16 no barrier
+      const char* Ab = Abuf + U * A_BYTES;
+      const char* Bb = Bbuf + U * B_BYTES;
+      char* An = Abuf + (U ^ 1) * A_BYTES;
+      char* Bn = Bbuf + (U ^ 1) * B_BYTES;
+      const uint32_t soa = (h + 3 < nk) ? (uint32_t)(kbeg + (h + 3) * BK) * bufa.kbytes : 0u, ina = (h + 3 < nk) ? 0u : 0x80000000u;
+      const uint32_t sob = (h + 2 < nk) ? (uint32_t)(kbeg + (h + 2) * BK) * bufb.kbytes : 0u, inb = (h + 2 < nk) ? 0u : 0x80000000u;
+      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+      // one piece: stage h + 1 from its register into the other LDS buffer, then the register's refill from memory
+      auto move_piece = [&](auto ptag) {
+        constexpr int P = decltype(ptag)::value;
+        if constexpr (P < NPA) {
+          if constexpr (!(ABL & 1)) *reinterpret_cast<uint4*>(An + a_st + P * A_PIECE) = ra[U ^ 1][P];
+          if constexpr (!(ABL & 2)) {
+            const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufa.rsrc, bufa.voff[P] | ina, soa, 0);
+            ra[U ^ 1][P] = make_uint4(r.x, r.y, r.z, r.w);
+          }
+        } else {
+          constexpr int Q = P - NPA;
+          if constexpr (!(ABL & 1)) *reinterpret_cast<uint4*>(Bn + b_st + Q * B_PIECE) = rb[Q];
+          if constexpr (!(ABL & 2)) {
+            const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufb.rsrc, bufb.voff[Q] | inb, sob, 0);
+            rb[Q] = make_uint4(r.x, r.y, r.z, r.w);
+          }
+        }
+      };
+      // fragment f of sub-step kk: 0..FN-1 activations, FN.. weights
+      bf16x8 fa[2][FN], fb[2][FM];
+      auto read_frag = [&](int kk, int buf, auto ftag) {
+        constexpr int Fi = decltype(ftag)::value;
+        if constexpr (Fi < FN) fa[buf][Fi] = frag_kc(Ab, fpa[Fi], kk);
+        else if constexpr (B_KC) fb[buf][Fi - FN] = frag_kc(Bb, fpb[Fi - FN], kk);
+        else fb[buf][Fi - FN] = frag_bf16<B_KC, TILE_M>(Bb, wm * WM + (Fi - FN) * 32 + l31, kk, hi);
+      };
+      for_seq<0, FN + FM>([&](auto f) { read_frag(0, 0, f); });
+      __builtin_amdgcn_sched_barrier(0);
+      // 64 MFMAs; behind MFMA q of sub-step kk: fragment q of sub-step kk + 1 (q < 8), after every fourth MFMA one piece.
+      // sched_barrier(0) after every MFMA: nothing moves across, the order below IS the instruction stream (left to itself the
+      // scheduler put all 16 ds_writes - behind one s_waitcnt vmcnt(0) - and all 16 loads at the top of the step)
+      for_seq<0, FN * FM * (BK / 16)>([&](auto stag) {
+        constexpr int S = decltype(stag)::value, kk = S / (FN * FM), q = S % (FN * FM), i = q / FM, j = q % FM, cur = kk & 1;
+        if constexpr (ABL & 8) acc[i][j][0] += __builtin_bit_cast(uint4, fa[cur][i]).x * 1e-30f + __builtin_bit_cast(uint4, fb[cur][j]).y * 1e-30f;
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+        if constexpr (kk + 1 < BK / 16 && q < FN + FM) read_frag(kk + 1, cur ^ 1, ActTag<q>{});
+        if constexpr (q % 4 == 1) move_piece(ActTag<kk * 4 + q / 4>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (!(ABL & 16)) lds_barrier();
+    };
+    for (int h = 0; h + 1 < nk; h += 2) {
+      step(h, ActTag<0>{});
+      step(h + 1, ActTag<1>{});
+    }
+    if (nk & 1) step(nk - 1, ActTag<0>{});
   } else {
   // NS register stages of BK reduce-elements each are in flight (issue-early / write-late): for the K = 256..512
   // projections of this model EVERY operand byte of the tile is requested before the first MFMA, so a wave pays
@@ -404,6 +530,21 @@ __global__ __launch_bounds__(256, ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC)) void 
 #pragma unroll
             for (int j = 0; j < FM; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        // Fragment-read pipeline of the wide tile (SMX_FRAG_PIPE): hipcc schedules a K tile as bursts - all fragment reads
+        // of a sub-step, s_waitcnt, its MFMAs - so every 16-element sub-step exposes one LDS round trip (SQ counters of the
+        // K = 2048 -> 512 dgrad: waves issue-stalled 46 %, parked 30 %, the matrix pipe 35 % busy).  The groups below ask the
+        // scheduler for the library order instead: the first sub-step's reads, then ONE read between consecutive MFMAs, so
+        // the reads of sub-step kk + 1 are in flight under the MFMAs of sub-step kk.
+        if constexpr (SMX_FRAG_PIPE && TILE_M == 256 && A_KC) {
+          constexpr int RPK = FN + (B_KC ? FM : 2 * FM), NRD = RPK * (BK / 16), NMF = FN * FM * (BK / 16);
+          __builtin_amdgcn_sched_group_barrier(0x100, RPK, 0);
+#pragma unroll
+          for (int q = 0; q < NRD - RPK; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, NMF - (NRD - RPK) > 0 ? NMF - (NRD - RPK) : 1, 0);
         }
       } else {
         const float* Af = reinterpret_cast<const float*>(As);
@@ -900,8 +1041,17 @@ static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
   return check_launch("smx_gemm");
 }
 
+#ifdef SMX_PGEMM_BUILD   // experiment build: the persistent 256 x 256 LDS-DMA kernel of tools/experiments/pgemm.hip (included below)
+bool pgemm_eligible(const GemmParams& p, bool b_kc);
+int launch_pgemm(GemmParams& p, bool b_kc, hipStream_t s);
+#endif
 template <typename T, bool A_KC, bool B_KC>
 static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
+#ifdef SMX_PGEMM_BUILD
+  if constexpr (sizeof(T) == 2 && A_KC) {
+    if (vec && !(p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_LN_FWD)) && pgemm_eligible(p, B_KC)) return launch_pgemm(p, B_KC, s);
+  }
+#endif
   if (p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_LN_FWD)) {
     // fused LayerNorm: the tile must hold whole rows -> the 128 x 256 tile, whatever the grid size
     if constexpr (sizeof(T) == 2 && A_KC) {
@@ -943,6 +1093,23 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
         (long)(p.N / 128) * (p.M / 128) * p.batch * p.splits >= 256)
       return launch_tn_dma(p, s);
   }
+  // 256 x 256 tile, one workgroup of four waves per CU (128 x 128 per wave, 256 accumulator registers per lane): half the
+  // LDS fragment reads per MFMA and two thirds of the operand staging of two 128 x 256 workgroups - the library's tile for the
+  // long reductions (SMX_T256=1 while it is being measured)
+  if constexpr (sizeof(T) == 2 && A_KC) {
+    // Measured at 64 000 frames against the 128 x 256 tile (tools/experiments/ab_t256.sh): K = 2048 -> 512 dgrad 198 -> 169 us,
+    // forward + bias + dropout + residual 204 -> 195 us, 240 000 x 2048 -> 512 (config 5) 667 -> 623 us; K = 1024 ties or loses
+    // (the single workgroup's epilogue is exposed), so the tile takes K >= 2048 only.  SMX_T256=0 off, 2 = every eligible shape.
+    const int t256 = cfg().t256;
+    if (t256 && vec && !force_small && p.N >= 256 && p.M % 256 == 0 && p.splits == 1 && p.batch == 1 &&
+        p.K >= (t256 >= 2 ? 128 : 2048) && (long)((p.N + 255) / 256) * (p.M / 256) >= (t256 >= 2 ? 1 : 200)) {
+      p.tiles_n = (p.N + 255) / 256;
+      p.tiles_m = p.M / 256;
+      hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 256, 256, true>), dim3(p.tiles_n * p.tiles_m, 1), dim3(256), 0, s, p);
+      if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
+      return check_launch("smx_gemm");
+    }
+  }
   if (wide && !force_small && p.N >= 128 && p.M >= 256 && p.M % 256 == 0 && p.splits == 1 &&
       (long)((p.N + 127) / 128) * (p.M / 256) * p.batch >= 256)
     return launch_tile<T, A_KC, B_KC, 128, 256>(p, vec, s);
@@ -961,6 +1128,10 @@ static int launch_dtype(int layout, GemmParams& p, bool vec, hipStream_t s) {
 }
 
 }  // namespace smx
+
+#ifdef SMX_PGEMM_BUILD
+#include "../../tools/experiments/pgemm.hip"
+#endif
 
 using namespace smx;
 

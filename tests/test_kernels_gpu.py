@@ -439,6 +439,44 @@ def test_gemm_large_ragged_shapes_and_epilogues():
         assert (cs - y.float().sum(0)).abs().max().item() / y.float().sum(0).abs().max().item() < 2e-2, (N, K, M, "colsum")
 
 
+@pytest.mark.parametrize("N", [25600 + 77, 51200])
+def test_gemm_256x256_tile_long_reduction(N):
+    """K = 2048 -> 512 (the FFN down-projection and its input gradient at d_model = 512) takes the 256 x 256 tile by default
+    (one workgroup per CU, software-pipelined K loop, smx_config.t256): NT + bias + dropout-free residual + row mask + saved Z,
+    NN plain and NN with the fused activation gradient + column sums, ragged last row tile - against fp32 torch references."""
+    from summarymixing_amd import _lib as L, ops
+    assert L.get_config()["t256"] >= 1
+    torch.manual_seed(N)
+    K, M = 2048, 512
+    x = torch.randn(N, K, device="cuda").bfloat16()
+    w = (torch.randn(M, K, device="cuda") * 0.02).bfloat16()
+    b = torch.randn(M, device="cuda")
+    mask = (torch.rand(N, device="cuda") > 0.2).to(torch.uint8)
+    res = torch.randn(N, M, device="cuda").bfloat16()
+    zr = x.float() @ w.float().t() + b
+
+    def rel(a, r):
+        return (a.float() - r).abs().max().item() / r.abs().max().item()
+    y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+    z = torch.empty_like(y)
+    ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, z=z, row_mask=mask, res=res, alpha=0.5))
+    assert rel(z, zr) < 1e-2
+    assert rel(y, res.float() + 0.5 * torch.nn.functional.silu(zr) * mask[:, None]) < 1e-2
+    y32 = torch.empty(N, M, device="cuda", dtype=torch.float32)
+    ops.gemm(L.GEMM_NT, x, w, y32, N, M, K, ops.epilogue(bias=b, out_mode=L.OUT_F32))
+    assert rel(y32, zr) < 1e-2
+    wt = w.t().contiguous()                                # NN: (N, K) x (K, M)
+    ops.gemm(L.GEMM_NN, x, wt, y, N, M, K)
+    assert rel(y, x.float() @ wt.float()) < 1e-2
+    zz = torch.randn(N, M, device="cuda").bfloat16()
+    cs = torch.zeros(M, device="cuda")
+    ops.gemm(L.GEMM_NN, x, wt, y, N, M, K, ops.epilogue(act=L.ACT_SWISH, act_grad_z=zz, colsum=cs))
+    zf = zz.float()
+    sg = torch.sigmoid(zf)
+    assert rel(y, (x.float() @ wt.float()) * (sg * (1 + zf * (1 - sg)))) < 1e-2
+    assert (cs - y.float().sum(0)).abs().max().item() / y.float().sum(0).abs().max().item() < 2e-2
+
+
 @pytest.mark.parametrize("N,M,K", [(32768, 512, 256), (32768, 256, 1024), (16384, 1536, 512)])
 def test_wgrad_lds_dma_kernel(N, M, K):
     """Shapes that take the LDS-DMA TN kernel (gemm_tn_dma_kernel: M, K multiples of 128, frames a multiple of 64, at least

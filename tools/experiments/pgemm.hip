@@ -26,7 +26,7 @@
 // certainly issued (a smaller count only waits longer).  So the stores of tile i drain under the MFMAs of tile i + 1.
 #include <stdlib.h>
 
-#include "gemm_common.h"
+// (included at the end of summarymixing_amd/csrc/gemm.hip under -DSMX_PGEMM_BUILD: gemm_common.h is already in)
 
 namespace smx {
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pgemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < PG_NPA; ++j) { glds16(pa[j], dst + j * 8192); pa[j] += PG_BK; }
 #pragma unroll
-    for (int j = 0; j < PG_NPB; ++j) { if (!(p.ablate_rot & 2)) glds16(pb[j], dst + PG_A_BYTES + j * 8192); pb[j] += stepb; }
+    for (int j = 0; j < PG_NPB; ++j) { glds16(pb[j], dst + PG_A_BYTES + j * 8192); pb[j] += stepb; }
     ++issued;
     if (++iss_ks == nk) {
       iss_ks = 0;
@@ -179,10 +179,14 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pgemm_kernel(GemmParams p) {
         settle(side_v);
         side[t] = side_v;
       }
-      if (issued - done < PG_NST && iss_tile < t_hi) issue_next();
+      // ping-pong (p.reg_epi reused as the knob in this experiment build: SMX_PGEMM_PP): waves w and w + 4 share a SIMD; the
+      // upper four issue their DMA pieces BEFORE their MFMAs, the lower four AFTER, so that on every SIMD one wave's
+      // vector-memory issue (~100-180 cycles per piece) runs beside the other wave's matrix work
+      const bool can_issue = issued - done < PG_NST && iss_tile < t_hi;
+      const bool pp = p.reg_epi != 0;
+      if (can_issue && (!pp || wave >= 4)) issue_next();
       const char* As = smem + (done % PG_NST) * PG_STAGE;
       const char* Bs = As + PG_A_BYTES;
-      if (p.ablate_rot & 4) { ++done; continue; }        // debug: DMA + barriers only
 #pragma unroll
       for (int kk = 0; kk < PG_BK / 16; ++kk) {
         bf16x8 fa[2], fb[4];
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(PG_NTHR, 2) void pgemm_kernel(GemmParams p) {
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
       }
+      if (can_issue && pp && wave < 4) issue_next();
       ++done;
     }
 
@@ -267,6 +272,8 @@ bool pgemm_eligible(const GemmParams& p, bool b_kc) {
 }
 
 int launch_pgemm(GemmParams& p, bool b_kc, hipStream_t s) {
+  static const int pp_env = getenv("SMX_PGEMM_PP") ? atoi(getenv("SMX_PGEMM_PP")) : 1;
+  p.reg_epi = pp_env;                                     // (the persistent kernel has no register-domain epilogue: field reused)
   p.tiles_n = (p.N + PG_TN - 1) / PG_TN;
   p.tiles_m = p.M / PG_TM;
   static bool attr_done = false;
