@@ -1098,11 +1098,15 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // long reductions (SMX_T256=1 while it is being measured)
   if constexpr (sizeof(T) == 2 && A_KC) {
     // Measured at 64 000 frames against the 128 x 256 tile (tools/experiments/ab_t256.sh): K = 2048 -> 512 dgrad 198 -> 169 us,
-    // forward + bias + dropout + residual 204 -> 195 us, 240 000 x 2048 -> 512 (config 5) 667 -> 623 us; K = 1024 ties or loses
-    // (the single workgroup's epilogue is exposed), so the tile takes K >= 2048 only.  SMX_T256=0 off, 2 = every eligible shape.
+    // forward + bias + dropout + residual 204 -> 195 us, 240 000 x 2048 -> 512 bias only 667 -> 623 us; K = 1024 ties or loses.
+    // With ONE workgroup per CU nothing runs beside the epilogue, so a heavy one eats the gain: in the steps the fp32-stream
+    // down-projection (reads and writes 4-byte rows) got SLOWER (config 5 forward 61.5 -> 63.0 ms), the plain dgrad faster.
+    // Hence: K >= 2048 and an epilogue without element-wise side inputs (epi_simple == 1) writing dtype T.
+    // SMX_T256=0 off, 2 = every eligible shape (tests).
     const int t256 = cfg().t256;
     if (t256 && vec && !force_small && p.N >= 256 && p.M % 256 == 0 && p.splits == 1 && p.batch == 1 &&
-        p.K >= (t256 >= 2 ? 128 : 2048) && (long)((p.N + 255) / 256) * (p.M / 256) >= (t256 >= 2 ? 1 : 200)) {
+        (t256 >= 2 || (p.K >= 2048 && p.epi_simple == 1 && p.e.out_mode == SMX_OUT_T && !p.e.z)) && p.K >= 128 &&
+        (long)((p.N + 255) / 256) * (p.M / 256) >= (t256 >= 2 ? 1 : 200)) {
       p.tiles_n = (p.N + 255) / 256;
       p.tiles_m = p.M / 256;
       hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 256, 256, true>), dim3(p.tiles_n * p.tiles_m, 1), dim3(256), 0, s, p);

@@ -218,8 +218,12 @@ def flush_deferred():
         _launch_groups()
     if not _Deferred.jobs:
         _Deferred.pending.clear()
+        _Deferred.async_now = False
         return
-    run_async = _Deferred.async_now
+    # asynchronous only for the weight gradients recorded SINCE THE LAST FLUSH: the flag used to survive until the end of the
+    # enclosing autograd block, and forever when _wgrad / flush_deferred were driven outside one - a later, large flush then ran
+    # its reduction on the side stream with nobody joining it (round 4: tests/test_kernels_gpu.py read a gradient half reduced)
+    run_async, _Deferred.async_now = _Deferred.async_now, False
     if not run_async:
         join_side()                            # the slab GEMMs of this block ran on the side stream: join it
     key = tuple(_Deferred.jobs)

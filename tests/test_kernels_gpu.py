@@ -441,9 +441,11 @@ def test_gemm_large_ragged_shapes_and_epilogues():
 
 @pytest.mark.parametrize("N", [25600 + 77, 51200])
 def test_gemm_256x256_tile_long_reduction(N):
-    """K = 2048 -> 512 (the FFN down-projection and its input gradient at d_model = 512) takes the 256 x 256 tile by default
-    (one workgroup per CU, software-pipelined K loop, smx_config.t256): NT + bias + dropout-free residual + row mask + saved Z,
-    NN plain and NN with the fused activation gradient + column sums, ragged last row tile - against fp32 torch references."""
+    """K = 2048 -> 512 (the FFN down-projection's input gradient at d_model = 512) takes the 256 x 256 tile by default when its
+    epilogue has no element-wise side input (one workgroup per CU, software-pipelined K loop, smx_config.t256): NN plain and NT
+    + bias are that path; the heavier epilogues of the same shape (residual, saved Z, activation gradient + column sums) take
+    the 128 x 256 tile (SMX_T256=2 sends them to the big tile too: the CI command of tools/experiments/ab_t256.sh) - all
+    against fp32 torch references, ragged last row tile."""
     from summarymixing_amd import _lib as L, ops
     assert L.get_config()["t256"] >= 1
     torch.manual_seed(N)
@@ -585,6 +587,8 @@ def test_wgrad_group_strided_operands_mixed_bias_and_single_item():
 
 def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
     from summarymixing_amd import functional as F, ops
+    _wgroup_case(4096, [(256, 256)], [True], seed=5)      # a small block first: its asynchronous (side-stream) mode must not leak
+    assert not F._Deferred.async_now                       # into the next flush (round 4: it did, and the reduction below raced)
     torch.manual_seed(4)
     rows, M, K = 20000, 512, 256
     dz = (torch.randn(rows, M, device="cuda") * 0.5).bfloat16()
@@ -594,6 +598,7 @@ def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
         gW, gb = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
         F._wgrad(dz, x, gW, rows, M, K, gb)
         F.flush_deferred()
+        F.join_side()                                      # (the contract: gradients are final after flush_deferred + join_side)
         outs.append((gW.clone(), gb.clone()))
     dW, db = (outs[0][0] - outs[1][0]).abs(), (outs[0][1] - outs[1][1]).abs()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (
