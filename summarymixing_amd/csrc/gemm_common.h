@@ -463,9 +463,15 @@ __device__ __forceinline__ void st_elems_nt(void* p, const float (&v)[CW]) {
 // still no C0 rows and no column sums - known at compile time, so the side-input registers, their zero fills and the feature selects vanish
 // (PMC: 113 VALU instructions per 8-element item in the general instantiation of a bias+Swish+Z epilogue).
 // PHR / NTHR: rows staged per phase and threads of the workgroup (defaults: the 256-thread tiled kernels of gemm.hip).
-template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC, int SIMPLE = 0, int PHR = 0, int NTHR = 256>
+// PFX (float32 residual only: OSZ == 4, SMX_IO_RES_F32): the residual words of THIS phase arrive in `carry` (requested one phase
+// earlier - by epilogue_prefetch_res before the first phase), and as soon as an item's words are consumed the same registers
+// take the request for the same item of the NEXT phase (rows next_nbase + ...; next_nbase < 0: none).  A phase used to open with
+// its side-input requests and wait one full memory round trip for them - behind the previous phase's stores, because vmcnt
+// retires in order - on both workgroups of the CU at the same time; now that round trip runs under the previous phase's math,
+// stores, LayerNorm and barriers, at no extra registers (the words were dead from their use to the end of the phase).
+template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC, int SIMPLE = 0, int PHR = 0, int NTHR = 256, bool PFX = false>
 __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, const float* side, int ph, int nbase,
-                                               int m0, int bz, int split, int t) {
+                                               int m0, int bz, int split, int t, uint32_t* carry = nullptr, int next_nbase = -1) {
   constexpr int WN = PHR ? PHR : (TILE_M > 128 ? 32 : TILE_N / 2);   // rows staged per phase (phase_rows() of the kernel)
   constexpr int STG_LD = TILE_M * 4 + 16;
   constexpr int CW = 16 / OSZ;                          // output columns per item (16 bytes)
@@ -504,7 +510,12 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
     // kernel without side inputs, one per phase with a residual, one per batch with C0. ----
     constexpr int NB = NIT < 2 ? NIT : 2;
     uint32_t sw[NIT][SWR];
-    if (rf32) {
+    if constexpr (PFX) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k)
+#pragma unroll
+        for (int q = 0; q < SWR; ++q) sw[k][q] = carry[k * SWR + q];
+    } else if (rf32) {
       if constexpr (OSZ == 4) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -621,6 +632,15 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
         if constexpr (OSZ == 4) {
 #pragma unroll
           for (int q = 0; q < CW; ++q) v[q] += __uint_as_float(sw[k][q]);
+          if constexpr (PFX) {
+            if (next_nbase >= 0) {                       // (uniform) this item's registers are free: request the next phase's row
+              const int n2 = min(next_nbase + r0 + k * RSTEP, p.N - 1);
+              uint32_t w_[SWR];
+              ld_words<SWR>(Sbf + (long)n2 * lds_ + m, w_);
+#pragma unroll
+              for (int q = 0; q < SWR; ++q) carry[k * SWR + q] = w_[q];
+            }
+          }
         }
       } else if (Sb && !ag) {
         float rf[CW];
@@ -674,6 +694,22 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
         else reinterpret_cast<uint16_t*>(Cb)[(long)n * p.ldc + m + q] = (uint16_t)f32_to_bf16_bits(v);
       }
     }
+  }
+}
+
+// the float32 residual words of the first phase (see PFX above): thread t owns 4 columns of rows r0 + 4 k, k < 8
+template <int TILE_M, int NTHR = 256>
+__device__ __forceinline__ void epilogue_prefetch_res(const GemmParams& p, int nbase, int m0, int bz, int t, uint32_t* carry) {
+  constexpr int CW = 4, CPR = TILE_M / CW, RSTEP = NTHR / CPR, NIT = 32 / RSTEP;
+  const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
+  const float* Sbf = reinterpret_cast<const float*>(p.e.res) + (long)bz * p.sC;
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int n = min(nbase + r0 + k * RSTEP, p.N - 1);
+    uint32_t w_[CW];
+    ld_words<CW>(Sbf + (long)n * p.e.ldr + m, w_);
+#pragma unroll
+    for (int q = 0; q < CW; ++q) carry[k * CW + q] = w_[q];
   }
 }
 

@@ -2,7 +2,7 @@
 # Re-measure everything profiles/ holds for this round (run on the GPU box through gpurun; outputs land in
 # gpurun_out/refresh/, copy them into profiles/ afterwards):  gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03 v2'
 set -uo pipefail
-R="${1:-r03}"; TAG="${2:-vX}"
+R="${1:-r04}"; TAG="${2:-vX}"
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/refresh"; mkdir -p "$OUT"
 cd "$ROOT"
