@@ -43,6 +43,9 @@ namespace smx {
 #ifndef SMX_FRAG_PIPE
 #define SMX_FRAG_PIPE 1     // wide bf16 tile: fragment reads interleaved one per MFMA (sched_group_barrier), 0 = hipcc's own order
 #endif
+#ifndef SMX_T256_DMA
+#define SMX_T256_DMA 0      // 256 x 256 tile: 1 = weights on an LDS-DMA ring (one __shared__ array per slot) + three activation register stages; measured SLOWER than both operands through registers (NT 2048 -> 512: 156.5 -> 168.9 us, NN 164.5 -> 175.7): opt-in
+#endif
 #ifndef SMX_T256_ABL
 #define SMX_T256_ABL 0
 #endif
@@ -111,16 +114,25 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   constexpr bool DMAB = SMX_DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0 && (SMX_BUFLD_WIDE != 0);
   // T256P (256 x 256 bf16 tile, one workgroup of four waves per CU): software-pipelined main loop with double-buffered LDS stages
   constexpr bool T256P = sizeof(T) == 2 && VEC && A_KC && TILE_N == 256 && TILE_M == 256 && GATHER == 0 && LNF == 0;
+  // T256D: the same tile with the weights on an LDS-DMA ring of three stages (a SEPARATE __shared__ array: hipcc then knows
+  // that the activation stores into `smem` cannot hit it and does not wait vmcnt(0) in front of them) and the freed
+  // registers as a third activation stage
+  constexpr bool T256D = T256P && SMX_T256_DMA;
   constexpr int AB_BYTES = DMAB ? 2 * (TILE_N * 32 * 2) + 4 * (TILE_M * 32 * 2)   // DMAB: two A buffers + four ring slots of 32 k
-                                : (T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES);
+                                : (T256D ? 2 * A_BYTES : (T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES));
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0)) * 4;   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta]
   // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) operand stage, fenced by one extra barrier
-  constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536;
+  constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536 || T256D;
   static_assert(!ALIAS_SIDE || EPI_BYTES + RED_BYTES + SIDE_BYTES + 64 <= SMEM_BYTES, "epilogue arrays do not fit");
   __shared__ __attribute__((aligned(16))) char smem[ALIAS_SIDE ? SMEM_BYTES : SMEM_BYTES + RED_BYTES + SIDE_BYTES];
+  // (T256D: the weight ring - one array per slot, so that hipcc's LDS-DMA alias tracking sees that the slot being refilled is
+  //  not the slot being read: with one array it put s_waitcnt vmcnt(0) in front of the fragment reads)
+  __shared__ __attribute__((aligned(16))) char bring0[T256D ? 64 * TILE_M * 2 : 16];
+  __shared__ __attribute__((aligned(16))) char bring1[T256D ? 64 * TILE_M * 2 : 16];
+  __shared__ __attribute__((aligned(16))) char bring2[T256D ? 64 * TILE_M * 2 : 16];
   float* red = reinterpret_cast<float*>(smem + (ALIAS_SIDE ? (EPI_BYTES + 63) / 64 * 64 : SMEM_BYTES));
   float* side = red + TILE_M;
   char* As = smem;
@@ -386,6 +398,92 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the predicated tail requests: nothing may land in LDS later)
     lds_barrier();
+  } else if constexpr (T256D) {
+    // ---- 256 x 256 tile, weights by LDS-DMA.  Per step h (64 reduce elements): MFMAs on activation buffer h & 1 and ring slot
+    // h % 3; in the first 16 MFMA slots the 8 DMA pieces of weight stage h + 2 (slot (h + 2) % 3, read last in step h - 1), in the
+    // remaining slots the 8 activation pieces of stage h + 1: register stage (h + 1) % 3 -> LDS buffer (h + 1) & 1, then the
+    // refill of that register from stage h + 4.  In flight: weights two stages, activations three.  vmcnt retires in order: at
+    // the end of step h the pieces of B(h + 1) (first thing in step h - 1) have landed once at most the 8 + 16 requests behind
+    // them are outstanding; requests for stages that do not exist carry bit 31 in their offset (zeros, nothing fetched), so a
+    // step is branch-free and the compiler's own vmcnt for the register stages stays exact.  Period lcm(2, 3) = 6 steps.
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+    constexpr int BST = 64 * TILE_M * 2, NPB = BST / 1024 / 4, NPA = TILE_N / 32;      // 32 KB ring stage, 8 pieces per wave
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const long span_b = B_KC ? ((long)(p.M - 1) * p.ldb + p.K) : ((long)(p.K - 1) * p.ldb + p.M);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(B), (short)0, (int)(span_b * 2), 0x00020000);
+    uint32_t vb, piece_delta, kstep_bytes;
+    if constexpr (B_KC) {                                  // piece = 8 rows x 128 B; chunk XOR (row >> 1) & 7 applied to the source
+      const int row = wave_u * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+      vb = (uint32_t)((((long)(m0 + row)) * p.ldb + c * 8) * 2);
+      piece_delta = (uint32_t)(32 * p.ldb * 2);
+      kstep_bytes = 64 * 2;
+    } else {                                               // piece = 2 k rows x 512 B; granule XOR 4 * (k & 3)
+      const int krow = wave_u * 2 + (lane >> 5), g = (lane & 31) ^ ((krow & 3) << 2);
+      vb = (uint32_t)(((long)krow * p.ldb + m0 + g * 8) * 2);
+      piece_delta = (uint32_t)(8 * p.ldb * 2);
+      kstep_bytes = (uint32_t)(64 * p.ldb * 2);
+    }
+    const int nk = (kend - kbeg) / BK;
+    char* Abuf = smem;
+    auto dma_piece = [&](int h, auto slot_tag, auto jtag) __attribute__((always_inline)) {   // piece wave + 4 j of weight stage h -> ring slot
+      constexpr int J = decltype(jtag)::value, SLOT = decltype(slot_tag)::value;
+      char* ring = SLOT == 0 ? bring0 : (SLOT == 1 ? bring1 : bring2);
+      const bool valid = h < nk;
+      const uint32_t so = valid ? (uint32_t)(kbeg / 64 + h) * kstep_bytes + J * piece_delta : 0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_vp)(ring + wave_u * 1024 + J * 4096), 16,
+                                               vb | (valid ? 0u : 0x80000000u), so, 0, 0);
+    };
+    const uint32_t a_st = (uint32_t)((t >> 3) * 128 + (((t & 7) ^ ((t >> 4) & 7)) << 4));
+    constexpr uint32_t A_PIECE = 32 * 128;
+    uint4 ra[3][NPA];
+    bufa.load_pred(ra[0], kbeg, nk > 0);
+    bufa.load_pred(ra[1], kbeg + BK, nk > 1);
+    bufa.load_pred(ra[2], kbeg + 2 * BK, nk > 2);
+    for_seq<0, NPB>([&](auto j) __attribute__((always_inline)) { dma_piece(0, ActTag<0>{}, j); });
+    for_seq<0, NPB>([&](auto j) __attribute__((always_inline)) { dma_piece(1, ActTag<1>{}, j); });
+    stage_store<T, true, TILE_N>(ra[0], Abuf, t);
+    bufa.load_pred(ra[0], kbeg + 3 * BK, nk > 3);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // B(0): behind it the 8 pieces of B(1) and the 8 loads of A(3)
+    lds_barrier();
+    SMX_STAMP(1);
+    auto step = [&](int h, auto utag) __attribute__((always_inline)) {
+      constexpr int U = decltype(utag)::value;                                      // h % 6
+      constexpr int AB_ = U & 1, SL = U % 3, RS = (U + 1) % 3;                      // LDS buffer, ring slot, register stage of A(h + 1)
+      const char* Ab = Abuf + AB_ * A_BYTES;
+      const char* Bb = SL == 0 ? bring0 : (SL == 1 ? bring1 : bring2);
+      char* An = Abuf + (AB_ ^ 1) * A_BYTES;
+      const uint32_t soa = (h + 4 < nk) ? (uint32_t)(kbeg + (h + 4) * BK) * bufa.kbytes : 0u, ina = (h + 4 < nk) ? 0u : 0x80000000u;
+      bf16x8 fa[2][FN], fb[2][FM];
+      auto read_frag = [&](int kk, int buf, auto ftag) __attribute__((always_inline)) {
+        constexpr int Fi = decltype(ftag)::value;
+        if constexpr (Fi < FN) fa[buf][Fi] = frag_kc(Ab, fpa[Fi], kk);
+        else if constexpr (B_KC) fb[buf][Fi - FN] = frag_kc(Bb, fpb[Fi - FN], kk);
+        else fb[buf][Fi - FN] = frag_tr_swz512(Bb, wm * WM + (Fi - FN) * 32, lane, kk);
+      };
+      for_seq<0, FN + FM>([&](auto f) __attribute__((always_inline)) { read_frag(0, 0, f); });
+      __builtin_amdgcn_sched_barrier(0);
+      for_seq<0, FN * FM * (BK / 16)>([&](auto stag) __attribute__((always_inline)) {
+        constexpr int S = decltype(stag)::value, kk = S / (FN * FM), q = S % (FN * FM), i = q / FM, j = q % FM, cur = kk & 1;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+        if constexpr (kk + 1 < BK / 16 && q < FN + FM) read_frag(kk + 1, cur ^ 1, ActTag<q>{});
+        if constexpr (S < 2 * NPB && (S & 1) == 1) dma_piece(h + 2, ActTag<(SL + 2) % 3>{}, ActTag<S / 2>{});
+        if constexpr (S >= 17 && (S - 17) % 6 == 0 && (S - 17) / 6 < NPA) {
+          constexpr int P = (S - 17) / 6;
+          *reinterpret_cast<uint4*>(An + a_st + P * A_PIECE) = ra[RS][P];
+          const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufa.rsrc, bufa.voff[P] | ina, soa, 0);
+          ra[RS][P] = make_uint4(r.x, r.y, r.z, r.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // B(h + 1): behind it 8 activation loads of step h - 1 and this step's 16
+      lds_barrier();
+    };
+    const int nfull = nk / 6 * 6;
+    for (int h = 0; h < nfull; h += 6) for_seq<0, 6>([&](auto u) __attribute__((always_inline)) { step(h + decltype(u)::value, u); });
+    for_seq<0, 5>([&](auto u) __attribute__((always_inline)) { if (nfull + decltype(u)::value < nk) step(nfull + decltype(u)::value, u); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the predicated tail requests: nothing may land in LDS later)
+    lds_barrier();
   } else if constexpr (T256P) {
     // ---- 256 x 256 tile: ONE wave per SIMD (128 x 128 outputs = 256 accumulator registers), nobody else hides its latencies,
     // so the K loop is software-pipelined the way the vendor library's is.  Step h multiplies stage h out of LDS buffer h & 1
@@ -415,7 +513,7 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
     constexpr uint32_t A_PIECE = 32 * 128, B_PIECE = B_KC ? 32 * 128 : 8 * (TILE_M + 32) * 2;
     constexpr int NPA = TILE_N / 32;
     static_assert(TILE_N / 32 + TILE_M / 32 == 4 * (BK / 16), "one piece after every fourth MFMA");
-    auto step = [&](int h, auto utag) {
+    auto step = [&](int h, auto utag) __attribute__((always_inline)) {
       constexpr int U = decltype(utag)::value;                                      // h & 1
       constexpr int ABL = SMX_T256_ABL;   // experiment builds: 1 no ds_write, 2 no global loads, 4 no fragment reads, 8 no MFMA, 16 no barrier
       const char* Ab = Abuf + U * A_BYTES;
@@ -426,7 +524,7 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
       const uint32_t sob = (h + 2 < nk) ? (uint32_t)(kbeg + (h + 2) * BK) * bufb.kbytes : 0u, inb = (h + 2 < nk) ? 0u : 0x80000000u;
       typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
       // one piece: stage h + 1 from its register into the other LDS buffer, then the register's refill from memory
-      auto move_piece = [&](auto ptag) {
+      auto move_piece = [&](auto ptag) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;
         if constexpr (P < NPA) {
           if constexpr (!(ABL & 1)) *reinterpret_cast<uint4*>(An + a_st + P * A_PIECE) = ra[U ^ 1][P];
@@ -445,18 +543,18 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
       };
       // fragment f of sub-step kk: 0..FN-1 activations, FN.. weights
       bf16x8 fa[2][FN], fb[2][FM];
-      auto read_frag = [&](int kk, int buf, auto ftag) {
+      auto read_frag = [&](int kk, int buf, auto ftag) __attribute__((always_inline)) {
         constexpr int Fi = decltype(ftag)::value;
         if constexpr (Fi < FN) fa[buf][Fi] = frag_kc(Ab, fpa[Fi], kk);
         else if constexpr (B_KC) fb[buf][Fi - FN] = frag_kc(Bb, fpb[Fi - FN], kk);
         else fb[buf][Fi - FN] = frag_bf16<B_KC, TILE_M>(Bb, wm * WM + (Fi - FN) * 32 + l31, kk, hi);
       };
-      for_seq<0, FN + FM>([&](auto f) { read_frag(0, 0, f); });
+      for_seq<0, FN + FM>([&](auto f) __attribute__((always_inline)) { read_frag(0, 0, f); });
       __builtin_amdgcn_sched_barrier(0);
       // 64 MFMAs; behind MFMA q of sub-step kk: fragment q of sub-step kk + 1 (q < 8), after every fourth MFMA one piece.
       // sched_barrier(0) after every MFMA: nothing moves across, the order below IS the instruction stream (left to itself the
       // scheduler put all 16 ds_writes - behind one s_waitcnt vmcnt(0) - and all 16 loads at the top of the step)
-      for_seq<0, FN * FM * (BK / 16)>([&](auto stag) {
+      for_seq<0, FN * FM * (BK / 16)>([&](auto stag) __attribute__((always_inline)) {
         constexpr int S = decltype(stag)::value, kk = S / (FN * FM), q = S % (FN * FM), i = q / FM, j = q % FM, cur = kk & 1;
         if constexpr (ABL & 8) acc[i][j][0] += __builtin_bit_cast(uint4, fa[cur][i]).x * 1e-30f + __builtin_bit_cast(uint4, fb[cur][j]).y * 1e-30f;
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
