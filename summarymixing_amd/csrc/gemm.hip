@@ -43,6 +43,9 @@ namespace smx {
 #ifndef SMX_FRAG_PIPE
 #define SMX_FRAG_PIPE 1     // wide bf16 tile: fragment reads interleaved one per MFMA (sched_group_barrier), 0 = hipcc's own order
 #endif
+#ifndef SMX_WIDE_PIPE
+#define SMX_WIDE_PIPE 1     // 128 x 256 bf16 tile: explicit software pipeline in 32-element steps (0: the serial register-staged loop)
+#endif
 #ifndef SMX_T256_DMA
 #define SMX_T256_DMA 0      // 256 x 256 tile: 1 = weights on an LDS-DMA ring (one __shared__ array per slot) + three activation register stages; measured SLOWER than both operands through registers (NT 2048 -> 512: 156.5 -> 168.9 us, NN 164.5 -> 175.7): opt-in
 #endif
@@ -118,6 +121,10 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   // that the activation stores into `smem` cannot hit it and does not wait vmcnt(0) in front of them) and the freed
   // registers as a third activation stage
   constexpr bool T256D = T256P && SMX_T256_DMA;
+  // W128P: the 128 x 256 tile (two workgroups per CU, every LayerNorm-fused epilogue) with the same explicit software pipeline
+  // in 32-element steps: both operands double-buffered in LDS (2 x 24 KB = the one 48 KB stage of the serial loop)
+  constexpr bool W128P = SMX_WIDE_PIPE && !DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0 &&
+                         (SMX_BUFLD_WIDE != 0);
   constexpr int AB_BYTES = DMAB ? 2 * (TILE_N * 32 * 2) + 4 * (TILE_M * 32 * 2)   // DMAB: two A buffers + four ring slots of 32 k
                                 : (T256D ? 2 * A_BYTES : (T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES));
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
@@ -398,6 +405,106 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the predicated tail requests: nothing may land in LDS later)
     lds_barrier();
+  } else if constexpr (W128P) {
+    // ---- 128 x 256 tile, explicit software pipeline (the structure that worked on the 256 x 256 tile, T256P below), 32 reduce
+    // elements per step: step h multiplies half-stage h out of LDS buffer h & 1 and, between its 16 MFMAs, moves half-stage
+    // h + 1 from registers into the other buffer (2 + 4 ds_write_b128), refills those registers (activations two steps ahead,
+    // weights one) and reads the second sub-step's fragments.  ONE barrier per step; sched_barrier(0) after every MFMA pins the
+    // order.  LDS images of a half-stage: reduce-contiguous operands [rows][32 k] = 64-byte rows, 16-byte chunk c of row r at
+    // position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128); the reduce-strided weights of NN as they lie, [32 k][256 + 32].
+    typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+    constexpr int HK = 32, AH = TILE_N * HK * 2, BH = B_KC ? TILE_M * HK * 2 : HK * (TILE_M + 32) * 2, NPA = 2, NPBW = 4;
+    static_assert(2 * (AH + BH) <= AB_BYTES, "two half-stage pairs fit the serial loop's stage");
+    char* Abuf = smem;
+    char* Bbuf = smem + 2 * AH;
+    const int nh = (kend - kbeg) / HK;
+    // this thread's pieces: v = t + 256 i
+    uint32_t va[NPA], vbw[NPBW];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int rg = n0 + ((t + 256 * i) >> 2);
+      va[i] = rg < p.N ? (uint32_t)(((long)rg * p.lda + (t & 3) * 8) * 2) : 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < NPBW; ++i) {
+      if constexpr (B_KC) {
+        const int rg = m0 + ((t + 256 * i) >> 2);
+        vbw[i] = rg < p.M ? (uint32_t)(((long)rg * p.ldb + (t & 3) * 8) * 2) : 0x80000000u;
+      } else {
+        const int cg = m0 + (t & 31) * 8;
+        vbw[i] = cg < p.M ? (uint32_t)(((long)((t >> 5) + 8 * i) * p.ldb + cg) * 2) : 0x80000000u;
+      }
+    }
+    const uint32_t a_st = (uint32_t)((t >> 2) * 64 + (((t & 3) ^ ((t >> 4) & 3)) << 4));
+    const uint32_t b_st = B_KC ? a_st : (uint32_t)((t >> 5) * ((TILE_M + 32) * 2) + (t & 31) * 16);
+    constexpr uint32_t A_PIECE = 64 * 64, B_PIECE = B_KC ? 64 * 64 : 8 * (TILE_M + 32) * 2;
+    const uint32_t kba = HK * 2, kbb = B_KC ? HK * 2 : (uint32_t)(HK * p.ldb * 2);   // bytes per half-stage along k
+    auto ld_a = [&](int h, auto itag) __attribute__((always_inline)) {
+      constexpr int I = decltype(itag)::value;
+      const bool v_ = h < nh;
+      const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufa.rsrc, va[I] | (v_ ? 0u : 0x80000000u), v_ ? (uint32_t)(kbeg / HK + h) * kba : 0u, 0);
+      return make_uint4(r.x, r.y, r.z, r.w);
+    };
+    auto ld_b = [&](int h, auto itag) __attribute__((always_inline)) {
+      constexpr int I = decltype(itag)::value;
+      const bool v_ = h < nh;
+      const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufb.rsrc, vbw[I] | (v_ ? 0u : 0x80000000u), v_ ? (uint32_t)(kbeg / HK + h) * kbb : 0u, 0);
+      return make_uint4(r.x, r.y, r.z, r.w);
+    };
+    uint32_t fqa[FN], fqb[FM];                           // loop-invariant fragment addresses (64-byte rows)
+#pragma unroll
+    for (int i = 0; i < FN; ++i) { const int r = wn * WN + i * 32 + l31; fqa[i] = (uint32_t)(r * 64 + ((hi ^ ((r >> 2) & 3)) << 4)); }
+#pragma unroll
+    for (int j = 0; j < FM; ++j) { const int r = wm * WM + j * 32 + l31; fqb[j] = (uint32_t)(r * 64 + ((hi ^ ((r >> 2) & 3)) << 4)); }
+    uint4 ra[2][NPA], rb[NPBW];
+    for_seq<0, NPA>([&](auto i) __attribute__((always_inline)) { ra[0][decltype(i)::value] = ld_a(0, i); });
+    for_seq<0, NPA>([&](auto i) __attribute__((always_inline)) { ra[1][decltype(i)::value] = ld_a(1, i); });
+    for_seq<0, NPBW>([&](auto i) __attribute__((always_inline)) { rb[decltype(i)::value] = ld_b(0, i); });
+    for_seq<0, NPA>([&](auto i) __attribute__((always_inline)) { *reinterpret_cast<uint4*>(Abuf + a_st + decltype(i)::value * A_PIECE) = ra[0][decltype(i)::value]; });
+    for_seq<0, NPBW>([&](auto i) __attribute__((always_inline)) { *reinterpret_cast<uint4*>(Bbuf + b_st + decltype(i)::value * B_PIECE) = rb[decltype(i)::value]; });
+    for_seq<0, NPA>([&](auto i) __attribute__((always_inline)) { ra[0][decltype(i)::value] = ld_a(2, i); });
+    for_seq<0, NPBW>([&](auto i) __attribute__((always_inline)) { rb[decltype(i)::value] = ld_b(1, i); });
+    lds_barrier();
+    SMX_STAMP(1);
+    auto step = [&](int h, auto utag) __attribute__((always_inline)) {
+      constexpr int U = decltype(utag)::value;                                      // h & 1
+      const char* Ab = Abuf + U * AH;
+      const char* Bb = Bbuf + U * BH;
+      char* An = Abuf + (U ^ 1) * AH;
+      char* Bn = Bbuf + (U ^ 1) * BH;
+      bf16x8 fa[2][FN], fb[2][FM];
+      auto read_frag = [&](int kk, int buf, auto ftag) __attribute__((always_inline)) {
+        constexpr int Fi = decltype(ftag)::value;
+        if constexpr (Fi < FN) fa[buf][Fi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Ab + (fqa[Fi] ^ (uint32_t)(kk << 5))));
+        else if constexpr (B_KC) fb[buf][Fi - FN] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bb + (fqb[Fi - FN] ^ (uint32_t)(kk << 5))));
+        else fb[buf][Fi - FN] = frag_bf16<B_KC, TILE_M>(Bb, wm * WM + (Fi - FN) * 32 + l31, kk, hi);
+      };
+      auto move_piece = [&](auto ptag) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value;
+        if constexpr (P < NPA) {
+          *reinterpret_cast<uint4*>(An + a_st + P * A_PIECE) = ra[U ^ 1][P];
+          ra[U ^ 1][P] = ld_a(h + 3, ActTag<P>{});
+        } else {
+          *reinterpret_cast<uint4*>(Bn + b_st + (P - NPA) * B_PIECE) = rb[P - NPA];
+          rb[P - NPA] = ld_b(h + 2, ActTag<P - NPA>{});
+        }
+      };
+      for_seq<0, FN + FM>([&](auto f) __attribute__((always_inline)) { read_frag(0, 0, f); });
+      __builtin_amdgcn_sched_barrier(0);
+      for_seq<0, FN * FM * 2>([&](auto stag) __attribute__((always_inline)) {
+        constexpr int S = decltype(stag)::value, kk = S / (FN * FM), q = S % (FN * FM), i = q / FM, j = q % FM;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+        if constexpr (kk == 0 && q < FN + FM) read_frag(1, 1, ActTag<q>{});
+        if constexpr (S >= 2 && S % 2 == 0 && (S - 2) / 2 < NPA + NPBW) move_piece(ActTag<(S - 2) / 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      lds_barrier();
+    };
+    for (int h = 0; h + 1 < nh; h += 2) {
+      step(h, ActTag<0>{});
+      step(h + 1, ActTag<1>{});
+    }
+    if (nh & 1) step(nh - 1, ActTag<0>{});
   } else if constexpr (T256D) {
     // ---- 256 x 256 tile, weights by LDS-DMA.  Per step h (64 reduce elements): MFMAs on activation buffer h & 1 and ring slot
     // h % 3; in the first 16 MFMA slots the 8 DMA pieces of weight stage h + 2 (slot (h + 2) % 3, read last in step h - 1), in the
