@@ -44,7 +44,7 @@ namespace smx {
 #define SMX_FRAG_PIPE 1     // wide bf16 tile: fragment reads interleaved one per MFMA (sched_group_barrier), 0 = hipcc's own order
 #endif
 #ifndef SMX_WIDE_PIPE
-#define SMX_WIDE_PIPE 1     // 128 x 256 bf16 tile: explicit software pipeline in 32-element steps (0: the serial register-staged loop)
+#define SMX_WIDE_PIPE 1     // explicit software pipeline in 32-element steps: 1 = 128 x 256 bf16 tile; 2 = and the 128 x 128 tile (measured: +-2 %, steps 19.62 -> 19.84 / 50.46 -> 50.72 ms: three workgroups per CU already interleave, and K = 256 has four steps); 0 = the serial register-staged loops
 #endif
 #ifndef SMX_T256_DMA
 #define SMX_T256_DMA 0      // 256 x 256 tile: 1 = weights on an LDS-DMA ring (one __shared__ array per slot) + three activation register stages; measured SLOWER than both operands through registers (NT 2048 -> 512: 156.5 -> 168.9 us, NN 164.5 -> 175.7): opt-in
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   constexpr bool T256D = T256P && SMX_T256_DMA;
   // W128P: the 128 x 256 tile (two workgroups per CU, every LayerNorm-fused epilogue) with the same explicit software pipeline
   // in 32-element steps: both operands double-buffered in LDS (2 x 24 KB = the one 48 KB stage of the serial loop)
-  constexpr bool W128P = SMX_WIDE_PIPE && !DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0 &&
-                         (SMX_BUFLD_WIDE != 0);
+  constexpr bool W128P = SMX_WIDE_PIPE && !DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && GATHER == 0 &&
+                         ((TILE_M == 256 && SMX_BUFLD_WIDE != 0) || (TILE_M == 128 && SMX_WIDE_PIPE >= 2));
   constexpr int AB_BYTES = DMAB ? 2 * (TILE_N * 32 * 2) + 4 * (TILE_M * 32 * 2)   // DMAB: two A buffers + four ring slots of 32 k
                                 : (T256D ? 2 * A_BYTES : (T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES));
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
     // order.  LDS images of a half-stage: reduce-contiguous operands [rows][32 k] = 64-byte rows, 16-byte chunk c of row r at
     // position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128); the reduce-strided weights of NN as they lie, [32 k][256 + 32].
     typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
-    constexpr int HK = 32, AH = TILE_N * HK * 2, BH = B_KC ? TILE_M * HK * 2 : HK * (TILE_M + 32) * 2, NPA = 2, NPBW = 4;
+    constexpr int HK = 32, AH = TILE_N * HK * 2, BH = B_KC ? TILE_M * HK * 2 : HK * (TILE_M + 32) * 2, NPA = TILE_N / 64, NPBW = TILE_M / 64;
+    constexpr int RC = TILE_M / 8;                        // 16-byte chunks per k row of a reduce-strided weight half-stage
     static_assert(2 * (AH + BH) <= AB_BYTES, "two half-stage pairs fit the serial loop's stage");
     char* Abuf = smem;
     char* Bbuf = smem + 2 * AH;
@@ -431,13 +432,13 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
         const int rg = m0 + ((t + 256 * i) >> 2);
         vbw[i] = rg < p.M ? (uint32_t)(((long)rg * p.ldb + (t & 3) * 8) * 2) : 0x80000000u;
       } else {
-        const int cg = m0 + (t & 31) * 8;
-        vbw[i] = cg < p.M ? (uint32_t)(((long)((t >> 5) + 8 * i) * p.ldb + cg) * 2) : 0x80000000u;
+        const int cg = m0 + (t % RC) * 8;
+        vbw[i] = cg < p.M ? (uint32_t)(((long)(t / RC + (256 / RC) * i) * p.ldb + cg) * 2) : 0x80000000u;
       }
     }
     const uint32_t a_st = (uint32_t)((t >> 2) * 64 + (((t & 3) ^ ((t >> 4) & 3)) << 4));
-    const uint32_t b_st = B_KC ? a_st : (uint32_t)((t >> 5) * ((TILE_M + 32) * 2) + (t & 31) * 16);
-    constexpr uint32_t A_PIECE = 64 * 64, B_PIECE = B_KC ? 64 * 64 : 8 * (TILE_M + 32) * 2;
+    const uint32_t b_st = B_KC ? a_st : (uint32_t)((t / RC) * ((TILE_M + 32) * 2) + (t % RC) * 16);
+    constexpr uint32_t A_PIECE = 64 * 64, B_PIECE = B_KC ? 64 * 64 : (256 / RC) * (TILE_M + 32) * 2;
     const uint32_t kba = HK * 2, kbb = B_KC ? HK * 2 : (uint32_t)(HK * p.ldb * 2);   // bytes per half-stage along k
     auto ld_a = [&](int h, auto itag) __attribute__((always_inline)) {
       constexpr int I = decltype(itag)::value;
@@ -495,7 +496,12 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
         constexpr int S = decltype(stag)::value, kk = S / (FN * FM), q = S % (FN * FM), i = q / FM, j = q % FM;
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
         if constexpr (kk == 0 && q < FN + FM) read_frag(1, 1, ActTag<q>{});
-        if constexpr (S >= 2 && S % 2 == 0 && (S - 2) / 2 < NPA + NPBW) move_piece(ActTag<(S - 2) / 2>{});
+        // piece p goes behind MFMA slot (p + 1) * NSL / (NP + 1): spread over the step, none behind the last MFMA
+        constexpr int NSL = FN * FM * 2, NP = NPA + NPBW;
+        for_seq<0, NP>([&](auto pt) __attribute__((always_inline)) {
+          constexpr int P = decltype(pt)::value;
+          if constexpr ((P + 1) * NSL / (NP + 1) == S) move_piece(pt);
+        });
         __builtin_amdgcn_sched_barrier(0);
       });
       lds_barrier();
