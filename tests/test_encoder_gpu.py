@@ -133,9 +133,23 @@ def test_encoder_wrapper_golden(name, dtype):
     with torch.no_grad():
         y = enc(src.cuda().to(dtype), a["wav_len"].cuda(), **kw)
     # bf16: 1e-2 (north_star) with the float32 residual stream.  The Branchformer golden (d = 32, csgu 96: a bf16 GEMM over K = 32
-    # has no averaging) measures 2.0e-2; at the CommonVoice widths the same layer holds 1e-2 (tests/test_width_gpu.py)
-    tol = 1e-3 if dtype == torch.float32 else (3e-2 if meta["encoder_module"] == "branchformer" else 1e-2)
-    assert rel_err(y, a["y"]) <= tol, rel_err(y, a["y"])
+    # has no averaging) measures 2.0e-2 - and that is the floor of the PRECISION, not of this implementation: the reference's own
+    # bf16 mode (the oracle under torch.autocast(bfloat16) on the CPU: Linear / conv in bf16, LayerNorm / sums in float32, the
+    # recipe's `precision: bf16`) is as far from its float32 result on this input.  The bar for that golden is therefore
+    # max(1e-2, 1.25 x the autocast oracle's own error); at the CommonVoice widths the layer holds 1e-2 (tests/test_width_gpu.py).
+    err = rel_err(y, a["y"])
+    tol = 1e-3 if dtype == torch.float32 else 1e-2
+    if dtype == torch.bfloat16 and meta["encoder_module"] == "branchformer":
+        from oracle import smx_oracle as O
+        sd32 = {k: v.float() for k, v in sd.items()}
+        with torch.no_grad(), torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+            yo = O.asr_encode(src.float(), a["wav_len"], sd32, meta["encoder_module"], meta["act"], meta["mode"], meta["local_proj_out_dim"],
+                              tuple(meta["dynchunk"]) if meta["dynchunk"] else None)
+        floor = rel_err(yo.float(), a["y"])
+        from tests._util import report
+        report(name + "_bf16_vs_autocast_floor", {"ours_maxrel": err, "reference_autocast_bf16_maxrel": floor})
+        tol = max(tol, 1.25 * floor)
+    assert err <= tol, (err, tol)
 
 
 def test_padded_content_quirk_is_reproduced():
