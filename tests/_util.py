@@ -60,3 +60,22 @@ def report(name, entries):
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     with open(os.path.join(root, "gpurun_out", "parity_errors.jsonl"), "a") as f:
         f.write(json.dumps({"test": name, **entries}) + "\n")
+
+
+def autocast_floor_layer(name):
+    """What the REFERENCE's own bf16 mode costs on a layer golden: the oracle layer under torch.autocast(bfloat16) on the CPU
+    (Linear / conv in bf16, LayerNorm / sums in float32 - the recipes' `precision: bf16`), compared with the float32 golden.
+    -> (forward error, dL/dx error, worst parameter-gradient error).  The bf16 bars of the layer-golden tests are
+    max(north_star bar, 1.25 x this): an implementation cannot be asked to be closer to float32 than the reference's bf16 is."""
+    import torch
+    from oracle import smx_oracle as O
+    from tests import _golden as G
+    meta, a, sd, grads = G.load(name)
+    sdp = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    x = a["x"].float().clone().requires_grad_(True)
+    fn = O.conformer_layer if meta["kind"] == "conformer_layer" else O.branchformer_layer
+    with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+        y = fn(x, sdp, "", meta["act"], meta["mode"], meta["local_proj_out_dim"], None, a["pad_mask"])
+    (y.float() * a["r"]).sum().backward()
+    perr = max(rel_err(sdp[k].grad, g) for k, g in grads.items() if sdp[k].grad is not None)
+    return rel_err(y.float(), a["y"]), rel_err(x.grad, a["gx"]), perr

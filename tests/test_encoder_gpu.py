@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from tests import _golden as G
-from tests._util import TOL, rel_err
+from tests._util import TOL, autocast_floor_layer, rel_err
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ln_fuse_mode")]   # (both LayerNorm dispatches: tests/conftest.py)
 ACT = {"gelu": torch.nn.GELU, "swish": "swish"}
@@ -36,8 +36,9 @@ def test_conformer_layer_golden(name, dtype):
     assert rel_err(x.grad, a["gx"]) <= gtol, rel_err(x.grad, a["gx"])
     params = dict(layer.named_parameters())
     # parameter gradients: the GRADIENT stream stays bf16 (only the forward stream is float32), and these goldens sum over 2 x 23
-    # frames only - 5e-2 for bf16 (measured worst: 3.3e-2 on a LayerNorm gamma); dL/dx above holds the 3e-2 bar
-    ptol = gtol if dtype == torch.float32 else 5e-2
+    # frames only.  bf16 bar: max(3e-2, 1.25 x the worst parameter-gradient error of the reference's own bf16 autocast on this
+    # golden) - measured floors 3.4e-2 (swish) / 4.5e-2 (gelu), this build 3.3e-2 worst; dL/dx above holds the 3e-2 bar
+    ptol = gtol if dtype == torch.float32 else max(gtol, 1.25 * autocast_floor_layer(name)[2])
     for k, g in grads.items():
         assert rel_err(params[k].grad, g) <= ptol, (k, rel_err(params[k].grad, g))
 
@@ -84,13 +85,16 @@ def test_branchformer_layer_golden(dtype):
     layer.cuda().eval()      # (the cell keeps its default global_dropout = 0.1 in train(), as the reference: Branchformer.py:209-218)
     x = a["x"].cuda().to(dtype).requires_grad_(True)
     y, _ = layer(x, src_key_padding_mask=a["pad_mask"].cuda())
-    ftol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (1e-2, 5e-2)      # (float32 stream; parameter gradients over 2 x 23 frames)
+    # float32 stream.  bf16 gradients: 3e-2 for dL/dx; parameter gradients (sums over 2 x 23 frames) max(3e-2, 1.25 x the worst
+    # parameter-gradient error of the reference's own bf16 autocast on this golden: 2.8e-2 measured)
+    ftol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (1e-2, 3e-2)
+    ptol = gtol if dtype == torch.float32 else max(gtol, 1.25 * autocast_floor_layer("g5_branchformer_layer")[2])
     assert rel_err(y, a["y"]) <= ftol, rel_err(y, a["y"])
     (y.float() * a["r"].cuda()).sum().backward()
     assert rel_err(x.grad, a["gx"]) <= gtol, rel_err(x.grad, a["gx"])
     params = dict(layer.named_parameters())
     for k, g in grads.items():
-        assert rel_err(params[k].grad, g) <= gtol, (k, rel_err(params[k].grad, g))
+        assert rel_err(params[k].grad, g) <= ptol, (k, rel_err(params[k].grad, g))
 
 
 def _asr(meta, sd, input_size):
