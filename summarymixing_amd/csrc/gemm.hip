@@ -62,15 +62,6 @@ template <int MASK, int N>
 __device__ __forceinline__ void sched_group() {
   if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
 }
-template <int LO, typename F, int... Is>
-__device__ __forceinline__ void for_seq_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(ActTag<LO + Is>{}), ...);
-}
-// f(ActTag<LO>{}), ..., f(ActTag<HI - 1>{}) - a compile-time loop whose index is a constant inside f
-template <int LO, int HI, typename F>
-__device__ __forceinline__ void for_seq(F&& f) {
-  if constexpr (LO < HI) for_seq_impl<LO>(static_cast<F&&>(f), std::make_integer_sequence<int, HI - LO>{});
-}
 template <int RPK, int MPK, int NKK, int S>
 __device__ __forceinline__ void t256_group_one() {
   constexpr int kk = S / MPK, q = S % MPK;

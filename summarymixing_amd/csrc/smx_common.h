@@ -1,5 +1,6 @@
 // smx_common.h — shared device/host helpers for the gfx950 kernels of libsmx.so.
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -163,6 +164,15 @@ __device__ __forceinline__ float act_grad_c(float v) {
   else return 1.f;
 }
 template <int V> struct ActTag { static constexpr int value = V; };
+template <int LO, typename F, int... Is>
+__device__ __forceinline__ void for_seq_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(ActTag<LO + Is>{}), ...);
+}
+// f(ActTag<LO>{}), ..., f(ActTag<HI - 1>{}) - a compile-time loop whose index is a constant inside f
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void for_seq(F&& f) {
+  if constexpr (LO < HI) for_seq_impl<LO>(static_cast<F&&>(f), std::make_integer_sequence<int, HI - LO>{});
+}
 template <typename F>
 __device__ __forceinline__ void dispatch_act(int act, F&& f) {
   switch (act) {

@@ -172,8 +172,71 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
   long long t_start = 0, t_wait = 0, r_start = 0;
   if (p.dbg) { t_start = clock64(); r_start = wall_clock64(); }
 #endif
+#ifndef SMX_WGROUP_PIPE
+#define SMX_WGROUP_PIPE 0   // 1 = explicit software pipeline of the 32-frame stages (measured neutral: C2b layer 261 -> 265 us, C2a layer 815 -> 819, steps unchanged; only the 3750-frame C2a launch gains, 104 -> 65 us); 0 = the barrier | fragment burst | MFMA loop below
+#endif
+  // ---- software-pipelined stages (BK = 32, ring of four; product path) ----------------------------------------------------
+  // The loop below opens every stage with a barrier and a burst of fragment reads whose latency nobody hides (all eight waves
+  // are in the same place).  Here the barrier that admits stage itn + 1 sits in the MIDDLE of stage itn: the first sub-step's 8
+  // MFMAs run with the second sub-step's fragment reads between them, then wait (own pieces of stage itn + 1) + barrier, then
+  // the second sub-step's MFMAs with the refill of the freed slot (stage itn + 3) and the fragments of stage itn + 1's first
+  // sub-step between them - the matrix pipe never sees a stage boundary.  sched_barrier(0) after every MFMA pins that order
+  // (what hipcc makes of an unpinned version: gemm.hip, T256P).
+  bool piped = false;
+  if constexpr (SMX_WGROUP_PIPE && BK == 32) {
+    piped = !ab_nomfma && !ab_nodma && !ab_nowait && niter > 0;
+    if (piped) {
+      bf16x8 fa[2][2], fb[2][4];
+      auto read_frag = [&](const char* As, const char* Bs, int kk, int buf, auto ftag) __attribute__((always_inline)) {
+        constexpr int Fi = decltype(ftag)::value;
+        if constexpr (Fi < 2) fa[buf][Fi] = wg_frag(As, wn * 64 + Fi * 32, l31, hi, kk);
+        else fb[buf][Fi - 2] = wg_frag(Bs, wm * 128 + (Fi - 2) * 32, l31, hi, kk);
+      };
+      for (int s = 0; s < NST - 1 && s < niter; ++s) issue(s);
+      if (niter >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
+      else if (niter == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wg_barrier();
+      for_seq<0, 6>([&](auto f) __attribute__((always_inline)) { read_frag(smem, smem + OP_BYTES, 0, 0, f); });
+      for (int itn = 0; itn < niter; ++itn) {
+        const char* As = smem + (itn % NST) * STAGE_BYTES;
+        const char* Bs = As + OP_BYTES;
+        const char* An = smem + ((itn + 1) % NST) * STAGE_BYTES;
+        const bool more = itn + 1 < niter, refill = itn + NST - 1 < niter;
+        __builtin_amdgcn_sched_barrier(0);
+        // first sub-step: fragments in buffer 0; between the MFMAs the second sub-step's fragments -> buffer 1
+        for_seq<0, 8>([&](auto st) __attribute__((always_inline)) {
+          constexpr int S = decltype(st)::value, i = S / 4, j = S % 4;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
+          if constexpr (S < 6) read_frag(As, Bs, 1, 1, ActTag<S>{});
+          if constexpr (S == 6 || S == 7) { if (do_cs) wg_sum8(bsum[S - 6][0], bsum[S - 6][1], fa[0][S - 6]); }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        // stage itn + 1 admitted: this wave's pieces of it have landed when at most the pieces of stage itn + 2 are
+        // outstanding; behind the barrier everybody's have, and everybody is past stage itn - 1: its slot takes stage itn + 3
+        if (more) {
+          if (itn + 2 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for_seq<0, 8>([&](auto st) __attribute__((always_inline)) {
+          constexpr int S = decltype(st)::value, i = S / 4, j = S % 4;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
+          if constexpr (S < 6) { if (more) read_frag(An, An + OP_BYTES, 0, 0, ActTag<S>{}); }
+          if constexpr (S == 1) { if (refill) issue_part(itn + NST - 1, ActTag<0>{}, ActTag<1>{}); }
+          if constexpr (S == 3) { if (refill) issue_part(itn + NST - 1, ActTag<1>{}, ActTag<1>{}); }
+          if constexpr (S == 6 || S == 7) { if (do_cs) wg_sum8(bsum[S - 6][0], bsum[S - 6][1], fa[1][S - 6]); }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    }
+  }
+  if (!piped) {
   for (int s = 0; s < NST - 1 && s < niter; ++s) issue(s);
-  for (int itn = 0; itn < niter; ++itn) {
+  }
+  for (int itn = 0; itn < niter && !piped; ++itn) {
 #ifdef SMX_DIAG
     long long tw0 = 0;
     if (p.dbg) tw0 = clock64();
