@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ LP,
       if (first[k]) {
         float sum = es[2 * k + 1];
         for (int j = nxt[k]; j >= 0; j = nxt[j]) sum += es[2 * j + 1];
-        acc[tg[k]] = sum;                                  // (a label equal to `blank` cannot occur in the targets)
+        if (tg[k] != blank) acc[tg[k]] = sum;              // (a label equal to `blank` is invalid input, as for torch's ctc_loss:
+                                                           //  it is ignored here instead of racing with the blank sum below)
       }
     }
   }
@@ -340,7 +341,8 @@ extern "C" int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, 
   const size_t shm = 2 * (size_t)Lmax * sizeof(float);
   float* alpha = reinterpret_cast<float*>(workspace);
   int* chain = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + ctc_alpha_bytes(B, T, Smax));
-  SMX_REQUIRE(((size_t)V + Lmax) * sizeof(float) <= 64 * 1024, "smx_ctc_loss_bwd: V + 2 Smax + 1 = %d floats do not fit the 64 KB of LDS", V + Lmax);
+  // (dynamic LDS next to the kernel's 64 bytes of static reduction scratch)
+  SMX_REQUIRE(((size_t)V + Lmax) * sizeof(float) + 64 <= 64 * 1024, "smx_ctc_loss_bwd: V + 2 Smax + 1 = %d floats (+ 64 B) do not fit the 64 KB of LDS", V + Lmax);
   hipLaunchKernelGGL(ctc_chain_kernel, dim3(B), dim3(256), 0, STREAM, targets, Smax, tgt_len, chain);
 #define CTC_BETA(TT, KS_) hipLaunchKernelGGL((ctc_beta_kernel<TT, KS_>), dim3(B), dim3(256), shm, STREAM, (const TT*)log_probs, ldlp, T, V, targets, Smax, in_len, tgt_len, blank, alpha, Lmax)
 #define CTC_BETA_T(TT) do { if (Lmax <= 256) CTC_BETA(TT, 1); else if (Lmax <= 512) CTC_BETA(TT, 2); else if (Lmax <= 1024) CTC_BETA(TT, 4); else if (Lmax <= 2048) CTC_BETA(TT, 8); else if (Lmax <= 4096) CTC_BETA(TT, 16); else CTC_BETA(TT, 32); } while (0)
