@@ -97,6 +97,7 @@ class _Deferred:
     enabled = os.environ.get("SMX_DEFER_REDUCE", "1") != "0"
     jobs = []        # (src_ptr, dst_ptr, src_stride, ldd, nsrc, rows, cols, alpha)
     pending = set()  # workspace keys written since the last flush
+    side_pending = set()   # keys whose workspaces an ASYNCHRONOUS flush may still be reading on the side stream (until join_side)
     ws = {}          # key -> persistent uint8 workspace
     cache = {}       # tuple(jobs) -> (jobs_dev, starts_dev, njobs, total_blocks)
     side_enabled = os.environ.get("SMX_WGRAD_STREAM", "1") != "0"
@@ -134,6 +135,8 @@ def deferred_ws(key, nbytes, device, check=True):
     if check and key in _Deferred.pending:
         flush_deferred()                       # the same parameter twice inside one block: reduce the first use now
         join_side()                            # (... and finish reading its workspace before the second use rewrites it)
+    elif key in _Deferred.side_pending:        # tied weights across blocks: an earlier, asynchronous flush may still be reading
+        join_side()                            # this workspace on the side stream
     t = _Deferred.ws.get(key)
     if check and t is None and len(_Deferred.ws) >= 2048:
         _evict_workspaces()
@@ -171,6 +174,7 @@ def join_side():
         for st in _Deferred.side.values():
             torch.cuda.current_stream().wait_stream(st)
         _Deferred.side_used = False
+    _Deferred.side_pending.clear()
 
 
 def _launch_groups():
@@ -250,6 +254,7 @@ def flush_deferred():
         with torch.cuda.stream(side):
             ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
         _Deferred.side_used = True
+        _Deferred.side_pending |= _Deferred.pending
     else:
         ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
     _Deferred.jobs = []
@@ -270,6 +275,8 @@ def _wgrad(dz, x, gW, N, M, K, dbias):
         if key in _Deferred.pending:
             flush_deferred()                   # the same parameter twice inside one block: finish the first use now
             join_side()
+        elif key in _Deferred.side_pending:
+            join_side()                        # (tied weights across blocks, asynchronous tail still running)
         _Deferred.pending.add(key)
         _Deferred.group.append((dz, x, gW, dbias, N, M, K))
         return

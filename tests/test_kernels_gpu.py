@@ -609,6 +609,26 @@ def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
     assert rel_err(outs[0][0], gW2) < 1e-5 and rel_err(outs[0][1], gb2) < 1e-5
 
 
+def test_wgrad_tied_weight_across_asynchronous_flushes():
+    """The same gradient buffer (a weight shared by two blocks) fed by two small blocks whose weight-gradient tails run on the side
+    stream: the second block must not rewrite the slab workspace while the first block's reduction may still be reading it."""
+    from summarymixing_amd import functional as F
+    torch.manual_seed(11)
+    rows, M, K = 2048, 256, 256                            # <= async_max_rows: asynchronous tail
+    gW, gb = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
+    ref, refb = torch.zeros(M, K, dtype=torch.float64, device="cuda"), torch.zeros(M, dtype=torch.float64, device="cuda")
+    for _ in range(6):
+        dz = (torch.randn(rows, M, device="cuda") * 0.5).bfloat16()
+        x = torch.randn(rows, K, device="cuda").bfloat16()
+        F._wgrad(dz, x, gW, rows, M, K, gb)
+        F.flush_deferred()                                 # (no join: the next block starts while this tail is in flight)
+        ref += dz.double().t() @ x.double()
+        refb += dz.double().sum(0)
+    F.join_side()
+    assert not F._Deferred.side_pending
+    assert rel_err(gW, ref) < 1e-5 and rel_err(gb, refb) < 1e-5
+
+
 # ---- LayerNorm fused into the 128 x 256 GEMM epilogue (SMX_EPI_LN_BWD / SMX_EPI_LN_FWD) -------------------------------
 @pytest.mark.parametrize("N,K", [(4096, 1024), (33000 + 77, 512), (200, 256)])
 def test_gemm_epilogue_layernorm_backward(N, K):
