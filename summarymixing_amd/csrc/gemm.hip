@@ -38,7 +38,7 @@ namespace smx {
 #define SMX_NS_KC 1
 #endif
 #ifndef SMX_RES_PREFETCH
-#define SMX_RES_PREFETCH 0  // LayerNorm-forward epilogues: float32 residual rows requested one phase ahead in the registers that held the previous ones. Measured: 83.8 -> 114.8 us (NT 1024 -> 256 + LN): 32 more registers live across the phase spill 35 (pointer reloads from scratch inside the item loops); 0 = off
+#define SMX_RES_PREFETCH 0  // LayerNorm-forward epilogues, float32 residual rows requested one phase ahead: 1 = in the registers that held the previous ones (32 more registers live across the phase: 35 spilled, NT 1024 -> 256 + LN 83.8 -> 114.8 us); 2 = by LDS-DMA into a per-lane private 32 KB slot (own __shared__ array, reads through inline asm, explicit vmcnt that counts the phase's stores: no spills added, 82.6 -> 88.2 us, step 19.49 -> 19.58 ms); 0 = at the phase's start (product)
 #endif
 #ifndef SMX_FRAG_PIPE
 #define SMX_FRAG_PIPE 1     // wide bf16 tile: fragment reads interleaved one per MFMA (sched_group_barrier), 0 = hipcc's own order
@@ -123,9 +123,14 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0)) * 4;   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta]
   // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) operand stage, fenced by one extra barrier
-  constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536 || T256D;
+  constexpr bool RESPL = SMX_RES_PREFETCH == 2 && LNF == 2 && sizeof(T) == 2 && VEC && B_KC && TILE_N == 128;
+  constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536 || T256D || RESPL;
   static_assert(!ALIAS_SIDE || EPI_BYTES + RED_BYTES + SIDE_BYTES + 64 <= SMEM_BYTES, "epilogue arrays do not fit");
   __shared__ __attribute__((aligned(16))) char smem[ALIAS_SIDE ? SMEM_BYTES : SMEM_BYTES + RED_BYTES + SIDE_BYTES];
+  // RESPL: the float32 residual rows of the LayerNorm-forward epilogue arrive by LDS-DMA one phase ahead (ResPrefetch in
+  // gemm_common.h) in their own 32 KB array; with the epilogue's small arrays aliased into the dead operand stage the block is
+  // 48 + 32 KB = exactly half a CU's LDS
+  __shared__ __attribute__((aligned(16))) char pfslot[RESPL ? 32768 : 16];
   // (T256D: the weight ring - one array per slot, so that hipcc's LDS-DMA alias tracking sees that the slot being refilled is
   //  not the slot being read: with one array it put s_waitcnt vmcnt(0) in front of the fragment reads)
   __shared__ __attribute__((aligned(16))) char bring0[T256D ? 64 * TILE_M * 2 : 16];
@@ -931,7 +936,25 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
     }
   }
   // float32 residual of the LayerNorm-forward kernels: requested one phase ahead (PFX in gemm_common.h)
-  constexpr bool RESPF = SMX_RES_PREFETCH && LNF == 2 && sizeof(T) == 2 && VEC;
+  constexpr bool RESPF = SMX_RES_PREFETCH == 1 && LNF == 2 && sizeof(T) == 2 && VEC;
+  // (SMX_RES_PREFETCH == 2: through LDS - RESPL, declared with the kernel's shared arrays)
+  ResPrefetch rpf;
+  bool respl = false;
+  if constexpr (RESPL) {
+    respl = osz == 4 && p.epi_simple == 2 && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr && !(e.flags & SMX_EPI_ACT_GRAD) &&
+            (long)p.N * e.ldr * 4 < (1L << 31);
+    if (respl) {
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+      rpf.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e.res), (short)0, (int)(((long)(p.N - 1) * e.ldr + p.M) * 4), 0x00020000);
+      rpf.slot = pfslot + wave_u * 8192;
+      rpf.row_bytes = (uint32_t)(e.ldr * 4);
+      rpf.voff = (uint32_t)(((long)(n0 + wave_u) * e.ldr + m0 + lane * 4) * 4);       // row r0 = wave (64 threads = one 256-column row)
+      // stores of one phase behind the request: 8 outputs (+ 8 saved pre-activations) + 4 LayerNorm rows (x 2 when they are
+      // float32) + 4 statistics; a tile with rows beyond N skips some of them: it waits for everything
+      rpf.nwait = (n0 + TILE_N <= p.N) ? 8 + (e.z ? 8 : 0) + ((e.io_flags & SMX_IO_LNFY_F32) ? 8 : 4) + (e.lnf_stats ? 4 : 0) : 0;
+      res_prefetch_issue(rpf, 0, 4);
+    }
+  }
   uint32_t rescarry[RESPF ? 32 : 1];
   const bool respf = RESPF && osz == 4 && p.epi_simple == 2 && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr &&
                      !(e.flags & SMX_EPI_ACT_GRAD);
@@ -969,8 +992,15 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
       else epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     } else if (VEC && p.epi_simple == 1) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     else if (VEC && p.epi_simple == 2 && sizeof(T) == 2) {
-      if constexpr (RESPF) {
-        if (respf) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2, 0, 256, true>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t, rescarry,
+      if constexpr (RESPL) {
+        if (respl) {
+          ResPrefetch pf_ = rpf;
+          if (ph == 0) pf_.nwait = 0;                      // (first phase: gamma / beta loads and nothing else sit behind the request)
+          epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2, 0, 256, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t, nullptr,
+                                                                ph + 1 < NPH ? row_in_tile + PH_ROWS : -1, &pf_);
+        } else epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
+      } else if constexpr (RESPF) {
+        if (respf) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2, 0, 256, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t, rescarry,
                                                                             ph + 1 < NPH ? n0 + row_in_tile + PH_ROWS : -1);
         else epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
       } else {
