@@ -11,7 +11,7 @@ import bench  # noqa: E402
 from summarymixing_amd.trainer import FlatAdamW  # noqa: E402
 
 cfg = dict(bench.CONFIGS["c2b"])
-cfg["B"] = 32
+cfg["B"] = int(os.environ.get("B", "32"))
 dev = torch.device("cuda", 0)
 enc = bench.build_encoder(cfg, dev, 0.15)
 opt = FlatAdamW(enc, compute_dtype=torch.bfloat16)
@@ -34,7 +34,7 @@ cnt = collections.Counter()
 stacks = collections.Counter()
 for ev in prof.events():
     cnt[ev.name] += 1
-    if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy", "aten::fill_", "aten::zero_") and ev.stack:
+    if (ev.name.startswith("hipMemcpy") or ev.name.startswith("hipMemset") or "Memcpy" in ev.name or ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy", "aten::fill_", "aten::zero_")) and ev.stack:
         own = [fr for fr in ev.stack if "/repo/" in fr and "find_copies" not in fr][:3]
         stacks[(ev.name, " <- ".join(own))] += 1
 print("# host-side copy / fill calls of one step by the repo frames that issued them")

@@ -16,3 +16,14 @@ print(f"{'%':>6} {'calls/step':>10} {'avg us':>9} {'min us':>8} {'max us':>8}  k
 for r in rows[:28]:
     n = re.sub(r"smx::", "", r[0]); n = re.sub(r"\(.*\)$", "", n); n = re.sub(r"^void ", "", n)
     print(f"{r[2]/tot*100:6.1f} {r[1]/steps:10.1f} {r[3]/1e3:9.1f} {r[4]/1e3:8.1f} {r[5]/1e3:8.1f}  {n[:100]}")
+# launches BEFORE the first kernel of the first step belong to the model set-up (parameters copied into the flat fp32 / bf16 buffers
+# by FlatAdamW: one __amd_rocclr_copyBuffer per parameter): say so, because calls/step above divides them by the step count
+try:
+    t0 = con.execute("select min(start) from kernels where name like '%gemm_kernel%' or name like '%layernorm%'").fetchone()[0]
+    pre = con.execute("select count(*), sum(end-start) from kernels where start < ?", (t0,)).fetchone()
+    cp = con.execute("select count(*) from kernels where name like '%copyBuffer%'").fetchone()[0]
+    cp_pre = con.execute("select count(*) from kernels where name like '%copyBuffer%' and start < ?", (t0,)).fetchone()[0]
+    print(f"# set-up (before the first step's first kernel): {pre[0]} launches, {(pre[1] or 0)/1e6:.2f} ms; __amd_rocclr_copyBuffer: {cp_pre} of {cp} launches are set-up "
+          f"(= {(cp - cp_pre) / steps:.1f} per step)")
+except Exception:
+    pass
