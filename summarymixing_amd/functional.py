@@ -53,7 +53,7 @@ def wcast(param, dtype):
     return sh
 
 
-_WGRAD_BIAS = os.environ.get("SMX_NO_WGRAD_BIAS") != "1"     # A/B knob: bias gradients as a by-product of the wgrad GEMM
+_WGRAD_BIAS = True   # (round 4: the SMX_NO_WGRAD_BIAS A/B knob is gone)     # A/B knob: bias gradients as a by-product of the wgrad GEMM
 
 # Residual-stream dtype of a bf16 model.  "fp32" (default) = torch autocast semantics, what the reference's `precision: bf16`
 # means (…transducer.yaml:61): Linear inputs / outputs in bf16, the residual adds (Conformer.py:507,530,532-536) and the
@@ -335,8 +335,8 @@ def _vec_ok(*ts):
     return all(t is None or (t.data_ptr() % 16 == 0 and (t.stride(0) * t.element_size()) % 16 == 0) for t in ts)
 
 
-_LN_FUSE_FWD = os.environ.get("SMX_LN_FUSE_FWD", "1") != "0"   # A/B: only the forward (SMX_EPI_LN_FWD) ...
-_LN_FUSE_BWD = os.environ.get("SMX_LN_FUSE_BWD", "1") != "0"   # ... / only the backward (SMX_EPI_LN_BWD) fusion off (C2b B = 128: 19.79 both, 19.90 without the forward, 20.84 without the backward one)
+_LN_FUSE_FWD = True   # (round 4: SMX_LN_FUSE_FWD / _BWD A/B knobs removed; SMX_LN_FUSE switches both)   # A/B: only the forward (SMX_EPI_LN_FWD) ...
+_LN_FUSE_BWD = True   # ... / only the backward (SMX_EPI_LN_BWD) fusion off (C2b B = 128: 19.79 both, 19.90 without the forward, 20.84 without the backward one)
 
 
 def ln_next_ok(x, M, ln_next, W=None, res=None):

@@ -14,8 +14,8 @@ from .. import ops
 
 
 import os
-_FOLDED_DFT = os.environ.get("SMX_FBANK_FOLDED_DFT", "1") != "0"              # A/B knob: cosine / sine halves of half the length
-_IMPLICIT_FRAMES = os.environ.get("SMX_FBANK_IMPLICIT_FRAMES", "1") != "0"   # A/B knob: the DFT GEMM reads the waveform in place
+_FOLDED_DFT = True              # A/B knob: cosine / sine halves of half the length
+_IMPLICIT_FRAMES = True   # A/B knob: the DFT GEMM reads the waveform in place
 
 
 class Fbank(nn.Module):

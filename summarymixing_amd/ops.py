@@ -565,7 +565,7 @@ def ctc_bwd(lp2, targets, in_len, tgt_len, B, T, blank, nll, gscale, ws):
     return g
 
 
-_CSGU_DROP_FUSE = os.environ.get("SMX_CSGU_DROP_FUSE", "1") != "0"     # (read once, like the library's own knobs)
+_CSGU_DROP_FUSE = True   # (round 4: A/B knob SMX_CSGU_DROP_FUSE removed)     # (read once, like the library's own knobs)
 _STEP_COUNTER = None          # the training loop's device step counter (held HERE, in the Python host; libsmx has no such state)
 
 
