@@ -37,6 +37,9 @@ namespace smx {
 #ifndef SMX_NS_KC
 #define SMX_NS_KC 1
 #endif
+#ifndef SMX_SIDE_PREFETCH
+#define SMX_SIDE_PREFETCH 0 // 1 = 128 x 128 bf16 tile: the side words of both epilogue phases requested before the first phase (measured: act-grad dgrad 86.9 -> 94.8 us, C2b 19.56 -> 19.98 ms: 7 registers spill at the 168-register budget); 0 = each phase requests its own
+#endif
 #ifndef SMX_RES_PREFETCH
 #define SMX_RES_PREFETCH 0  // LayerNorm-forward epilogues, float32 residual rows requested one phase ahead: 1 = in the registers that held the previous ones (32 more registers live across the phase: 35 spilled, NT 1024 -> 256 + LN 83.8 -> 114.8 us); 2 = by LDS-DMA into a per-lane private 32 KB slot (own __shared__ array, reads through inline asm, explicit vmcnt that counts the phase's stores: no spills added, 82.6 -> 88.2 us, step 19.49 -> 19.58 ms); 0 = at the phase's start (product)
 #endif
@@ -1053,6 +1056,34 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   // (PMC WRITE_SIZE 350 MB for 262 MB of output).
   auto run_phases = [&](auto osz_tag, auto lvl_tag) {
     constexpr int OSZ_ = decltype(osz_tag)::value, LVL_ = decltype(lvl_tag)::value;
+    // SIDEPF (128 x 128 bf16 tile, one element-type side input: the act-grad dgrad's saved pre-activation, a bf16 residual): the
+    // side words of BOTH phases are requested here, before the first accumulator dump - in the 32 registers the operand stages
+    // just vacated.  vmcnt retires in order and counts stores: the second phase used to request its words behind the first
+    // phase's stores and wait for those to drain plus a full round trip; now no load of the epilogue sits behind a store.
+    if constexpr (SMX_SIDE_PREFETCH && LVL_ == 2 && OSZ_ == 2 && TILE_N == 128 && TILE_M == 128 && sizeof(T) == 2 && VEC && NPH == 2) {
+      uint32_t sc0[16], sc1[16];
+      epilogue_prefetch_side16<T, TILE_M>(p, n0, m0, bz, t, sc0);
+      epilogue_prefetch_side16<T, TILE_M>(p, n0 + PH_ROWS, m0, bz, t, sc1);
+      for_seq<0, 2>([&](auto pht) __attribute__((always_inline)) {
+        constexpr int ph = decltype(pht)::value;
+        lds_barrier();
+        if (wn == ph) {                                    // (PH_ROWS == WN: wave row ph owns the phase's rows)
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(smem + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                    make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        }
+        lds_barrier();
+        SMX_STAMP(3 + 2 * ph);
+        epilogue_phase<T, OSZ_, TILE_N, TILE_M, VEC, LVL_, 0, 256, 1>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, split, t, ph == 0 ? sc0 : sc1, -1);
+        SMX_STAMP(4 + 2 * ph);
+      });
+      return;
+    }
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
       lds_barrier();

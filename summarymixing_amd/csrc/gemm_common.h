@@ -761,6 +761,31 @@ __device__ __forceinline__ void epilogue_prefetch_res(const GemmParams& p, int n
   }
 }
 
+// the element-type side words (residual, or the saved pre-activation of a fused act-grad) of ONE phase of the 128 x 128 tile's
+// bf16 epilogue (OSZ == 2: 8-column items, thread t owns columns (t % 16) * 8 of rows t / 16 + 16 k, k < 4), requested before
+// the phase loop so that no load of the epilogue is ever issued behind a store (PFX == 1 consumption, no reload)
+template <typename T, int TILE_M>
+__device__ __forceinline__ void epilogue_prefetch_side16(const GemmParams& p, int nbase, int m0, int bz, int t, uint32_t (&carry)[16]) {
+  constexpr int CW = 8, CPR = TILE_M / CW, RSTEP = 256 / CPR, NIT = 64 / RSTEP, SW = CW * (int)sizeof(T) / 4;
+  static_assert(NIT * SW == 16, "128-column bf16 tile");
+  const smx_epilogue& e = p.e;
+  const bool ag = (e.flags & SMX_EPI_ACT_GRAD) != 0;
+  const T* Sb = ag ? reinterpret_cast<const T*>(e.z) : (e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr);
+  const long lds_ = ag ? e.ldz : e.ldr;
+  const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) carry[q] = 0u;
+  if (Sb == nullptr || m >= p.M) return;
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int n = min(nbase + r0 + k * RSTEP, p.N - 1);
+    uint32_t w_[SW];
+    ld_words<SW>(Sb + (long)n * lds_ + m, w_);
+#pragma unroll
+    for (int q = 0; q < SW; ++q) carry[k * SW + q] = w_[q];
+  }
+}
+
 // column sums of a reduce-strided (KS) operand stage: a thread's vectors all cover the SAME columns (256 threads are
 // a multiple of the chunks per k row), so it keeps one partial sum per column it owns.  Used by the wgrad GEMM: the
 // column sums of dZ are the bias gradient, a by-product of tiles the kernel stages anyway.
