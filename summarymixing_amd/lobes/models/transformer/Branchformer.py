@@ -93,9 +93,10 @@ class BranchformerEncoderLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def make_run(self, B, T, m8, src_mask, compute_dtype=None):
-        if SP.enabled():
-            raise NotImplementedError("sequence-parallel mode does not cover the Branchformer: the CSGU's reflect-padded "
-                                      "depthwise convolution has no halo exchange")
+        sp = SP.enabled()       # time axis sharded over the ranks: the CSGU's depthwise conv gets halos (below), the cell its all-reduce
+        if sp and self.training and self.p_drop > 0.0:
+            raise NotImplementedError("sequence-parallel mode is dropout-free: the fused dropout masks are indexed by the LOCAL "
+                                      "frame row, every shard would draw the same mask")
         act = self.act
         pd = self.p_drop if self.training else 0.0
         cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask,
@@ -136,8 +137,31 @@ class BranchformerEncoderLayer(nn.Module):
             wd = Pb["wd"].detach().reshape(n, k)
             # (the CSGU's own dropout on x1 * conv(x2), upstream CSGU.forward, rides in the kernel where it can)
             sd4 = ops.new_dropout_seed() if pd > 0.0 else None
-            g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1,
-                               drop=(pd, sd4) if pd > 0.0 else None)
+            if sp:
+                # sequence-parallel: the conv input v = LN(u2) of the (k-1)/2 frames either side comes from the neighbour ranks
+                # (one small all-gather, sequence_parallel.exchange_halos); at the two ends of the WHOLE sequence the halo rows
+                # hold the reflected frames (Branchformer.py:31-97 pads by reflection), so a zero-padded conv over the extended
+                # shard equals the reflect-padded conv over the whole sequence; only the centre T rows go on
+                H = (k - 1) // 2
+                if T <= H:
+                    raise ValueError(f"sequence-parallel shards need more than {H} frames per rank (got {T})")
+                Te = T + 2 * H
+                first_rank, last_rank = SP.rank() == 0, SP.rank() == SP.world() - 1
+                v3 = v.view(B, T, n)
+                lh, rh = SP.exchange_halos(v3[:, :H], v3[:, T - H:])
+                if first_rank:
+                    lh = v3[:, 1:H + 1].flip(1)            # frame -j = frame j
+                if last_rank:
+                    rh = v3[:, T - 1 - H:T - 1].flip(1)    # frame T-1+j = frame T-1-j
+                ve = torch.cat([lh, v3, rh], 1).contiguous().view(B * Te, n)
+                u1e = torch.zeros((B, Te, n), dtype=u.dtype, device=dev)
+                u1e[:, H:H + T] = u1.reshape(B, T, n)
+                u1e = u1e.view(B * Te, n)
+                ge = ops.dwconv_fwd(ve, wd, Pb["bd"].detach(), B, Te, n, k, False, L.PAD_ZERO, 0, gate=u1e)
+                g = ge.view(B, Te, n)[:, H:H + T].contiguous().view(N, n)
+            else:
+                g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1,
+                                   drop=(pd, sd4) if pd > 0.0 else None)
             # both branches land in one (N, c1 + d) buffer = the merge input (no torch.cat)
             if cat is None:
                 cat = torch.empty((N, c1 + d), dtype=dtype, device=dev)
@@ -189,8 +213,30 @@ class BranchformerEncoderLayer(nn.Module):
                     dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
                                          drop=(pd, sd2) if pd > 0.0 else None, dx_drop=(pd, sd4) if pd > 0.0 else None)
                 du = torch.empty_like(u)                   # [d gate | d LN input]: both kernels write their half directly
-                dv, _ = F.dwconv_bwd_deferred(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T,
-                                              n, k, False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])
+                if sp:
+                    # the transposed exchange: gradients of the halo rows go back to the ranks that own those frames, gradients
+                    # of the reflected rows at the sequence ends fold back onto their source frames
+                    dge = torch.zeros((B, Te, n), dtype=dg.dtype, device=dev)     # (the halo OUTPUTS were dropped: zero gradient)
+                    dge[:, H:H + T] = dg.view(B, T, n)
+                    dve, dgate_e = ops.dwconv_bwd(dge.view(B * Te, n), ve, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k),
+                                                  F.gacc(Pb["bd"]), B, Te, n, k, False, L.PAD_ZERO, 0, gate=u1e)
+                    dve3 = dve.view(B, Te, n)
+                    dv3 = dve3[:, H:H + T].contiguous()
+                    gl, gr = dve3[:, :H], dve3[:, Te - H:]
+                    if first_rank:
+                        dv3[:, 1:H + 1] += gl.flip(1)
+                        gl = torch.zeros_like(gl)
+                    if last_rank:
+                        dv3[:, T - 1 - H:T - 1] += gr.flip(1)
+                        gr = torch.zeros_like(gr)
+                    g_first, g_last = SP.return_halo_grads(gl.contiguous(), gr.contiguous())
+                    dv3[:, :H] += g_first
+                    dv3[:, T - H:] += g_last
+                    dv = dv3.view(N, n)
+                    du[:, :n] = dgate_e.view(B, Te, n)[:, H:H + T].reshape(N, n)
+                else:
+                    dv, _ = F.dwconv_bwd_deferred(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T,
+                                                  n, k, False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])
                 if _PREACT_LN and zu is not None and act != L.ACT_NONE and bnv.spec["act"] == L.ACT_NONE and ops.layernorm_bwd_preact_ok(dv, u2, zu[:, n:], du[:, n:]):
                     # the activation backward of channel_proj1 rides in the CSGU LayerNorm's backward for the normalised half
                     # (dZ = act'(z) * LNbwd), and runs in place on the gate half only: no pass over the whole (N, csgu) gradient

@@ -15,8 +15,15 @@ Rank r of the group holds frames [r*T_loc, (r+1)*T_loc) of every utterance (equa
 tail and mark it in the padding mask).  Parameter gradients come out as per-rank PARTIAL SUMS over the rank's frames:
 reduce them with reduce_gradients() (SUM over the group) before the optimizer.
 
-Supported: ConformerEncoder / ConformerEncoderLayer with the per-utterance mean (modes SummaryMixing, -fast, -lite), no
-DynChunk mask.  Anything else raises NotImplementedError.  Host-side plumbing only: the arithmetic stays in libsmx.
+  * (round 4) the CSGU's depthwise convolution of the Branchformer's cgMLP branch (k = 31, REFLECT padding, Branchformer.py:31-97):
+    the halo is taken on the conv INPUT LN(x2) itself (no per-frame recomputation), and at the two ends of the WHOLE sequence
+    the halo rows are filled with the reflected frames, so a zero-padded conv over the extended shard equals the reflect-padded
+    conv over the whole sequence; backward: halo gradients back to their owners, reflected rows' gradients folded onto their
+    source frames.
+
+Supported: ConformerEncoder(Layer) and BranchformerEncoder(Layer) with the per-utterance mean (modes SummaryMixing, -fast,
+-lite), dropout-free, no DynChunk mask / expdecay.  Anything else raises NotImplementedError.  Host-side plumbing only: the
+arithmetic stays in libsmx.
 """
 import contextlib
 

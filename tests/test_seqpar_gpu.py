@@ -27,8 +27,15 @@ torch.cuda.set_device(0)
 mode, drop_ok = os.environ["SMX_MODE"], True
 d, B, T = 64, 3, 96
 torch.manual_seed(5)
-enc = ConformerEncoder(2, d, 128, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
-                       local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode=mode)
+if os.environ.get("SMX_ENC") == "branchformer":
+    from summarymixing_amd.lobes.models.transformer.Branchformer import BranchformerEncoder
+    enc = BranchformerEncoder(2, d, 1, kernel_size=31, activation=torch.nn.GELU, dropout=0.0, attention_type="SummaryMixing",
+                              csgu_linear_units=128, local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d],
+                              summary_out_dim=d, mode=mode)
+    enc.eval()     # (the cell keeps its default global_dropout = 0.1 in train(), as the reference; the sharded mode is dropout-free)
+else:
+    enc = ConformerEncoder(2, d, 128, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode=mode)
 with torch.no_grad():
     for n, p in enc.named_parameters():
         if p.dim() > 1:
@@ -78,12 +85,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(mode, nomask=False):
+def _run(mode, nomask=False, enc="conformer"):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   SMX_ROOT=ROOT, SMX_MODE=mode, SMX_NOMASK="1" if nomask else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   SMX_ROOT=ROOT, SMX_MODE=mode, SMX_NOMASK="1" if nomask else "0", SMX_ENC=enc, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -106,3 +113,11 @@ def test_sequence_parallel_matches_unsharded(mode):
 
 def test_sequence_parallel_no_padding_mask():
     _run("SummaryMixing-fast", nomask=True)
+
+
+@pytest.mark.parametrize("nomask", [False, True])
+def test_sequence_parallel_branchformer(nomask):
+    """The Branchformer over two time shards: the CSGU's reflect-padded depthwise convolution gets its neighbours' frames as halos
+    and the reflected frames at the two ends of the whole sequence (Branchformer.py:31-97); outputs, input gradients and summed
+    parameter gradients equal the unsharded encoder's."""
+    _run("SummaryMixing", nomask=nomask, enc="branchformer")
