@@ -568,6 +568,43 @@ class DynChunkMask:
         return m
 
 
+def _expdecay_seqpar(x, out, B, T, decay, reverse=False):
+    """The expdecay summary with the time axis sharded over the sequence group: x / out are this rank's (B*T, D) rows of
+    a (B, world*T, D) sequence.  (M x)_t = f_t + g_t - x_t is two recurrences, so the rows of a shard see the other shards
+    only through ONE (B, D) state per direction: the local O(T) kernel (fp32, its LOCAL denominators multiplied back out)
+    gives the local numerators; their first / last rows are the states leaving the shard (g at row 0, f at row T-1), one
+    all-gather of (2, B, D) per rank carries them, and the states entering add decay^(t+1) f_in + decay^(T-t) g_in.
+    The denominators rowsum(M) are closed forms of the GLOBAL frame index (rowwise.hip ed_inv_den, float64 here).
+    reverse: M (x / rowsum(M)), the transposed operator (M is symmetric)."""
+    W, r = SP.world(), SP.rank()
+    g = float(decay)
+    t = torch.arange(T, device=x.device, dtype=torch.float64)
+
+    def den(tt, TT):
+        return (2.0 - g ** (tt + 1.0) - g ** (TT - tt)) / (1.0 - g) - 1.0
+    den_loc, den_glob = den(t, float(T)).float()[None, :, None], den(t + r * T, float(W * T)).float()[None, :, None]
+    x3 = x.float().view(B, T, -1)
+    if reverse:
+        x3 = x3 / den_glob
+    num = torch.empty_like(x3)
+    ops.expdecay_mean(x3.view(B * T, -1), num.view(B * T, -1), B, T, decay)
+    num *= den_loc
+    ends = SP._all_gather(torch.stack([num[:, T - 1], num[:, 0]]))             # per rank: (f leaving right, g leaving left)
+    gT = g ** T
+    f_in = torch.zeros_like(ends[0][0])
+    for q in range(r):                                                          # f entering = f_{q} + decay^T f entering q
+        f_in = ends[q][0] + gT * f_in
+    g_in = torch.zeros_like(f_in)
+    for q in range(W - 1, r, -1):
+        g_in = ends[q][1] + gT * g_in
+    wf, wg = (g ** (t + 1.0)).float()[None, :, None], (g ** (T - t)).float()[None, :, None]
+    num += wf * f_in[:, None, :] + wg * g_in[:, None, :]
+    if not reverse:
+        num /= den_glob
+    out.view(B, T, -1).copy_(num)
+    return out
+
+
 def _dense_pool_fwd(s, B, T, Wn):
     """sbar[b] = Wn (T,T) @ s[b]  (Wn already row-normalised, compute dtype)."""
     D = s.shape[1]
@@ -673,12 +710,16 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         # ---- summary ------------------------------------------------------------------------------
         inv = None
         sp = SP.enabled()
-        if sp and pool_kind != "mean":
-            raise NotImplementedError("sequence-parallel mode supports the per-utterance mean only (no sum_mask / expdecay)")
+        if sp and pool_kind not in ("mean", "expdecay"):
+            raise NotImplementedError("sequence-parallel mode supports the per-utterance mean and the mask-free expdecay "
+                                      "summary only (no sum_mask)")
         if sp and p_drop > 0.0:
             raise NotImplementedError("sequence-parallel mode is dropout-free: the fused dropout masks are indexed by the "
                                       "LOCAL frame row, every shard would draw the same mask")
-        if sp:
+        if sp and pool_kind == "expdecay":
+            sbar = torch.empty((N, sdim), dtype=dtype, device=dev)
+            _expdecay_seqpar(s, sbar, B, T, decay)
+        elif sp:
             # time axis sharded over the group: local partial sums + valid-frame counts, ONE all-reduce, then the mean
             ssum, _ = ops.masked_mean(s, mask, B, T, scale=False)
             cnt = (mask.view(B, T).sum(1, dtype=torch.float32) if mask is not None
@@ -835,7 +876,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 elif pool_kind == "chunk":
                     ops.chunk_mean(dsd, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
                 elif pool_kind == "expdecay":
-                    ops.expdecay_mean(dsd, ds_out, B, T, decay, reverse=True)
+                    (_expdecay_seqpar if SP.enabled() else ops.expdecay_mean)(dsd, ds_out, B, T, decay, reverse=True)
                 else:
                     _dense_pool_bwd(dsd, B, T, Wn, ds_out)
             elif pool_kind == "mean":
@@ -862,7 +903,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 if pool_kind == "chunk":
                     ops.chunk_mean(dsb, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
                 elif pool_kind == "expdecay":
-                    ops.expdecay_mean(dsb, ds_out, B, T, decay, reverse=True)
+                    (_expdecay_seqpar if SP.enabled() else ops.expdecay_mean)(dsb, ds_out, B, T, decay, reverse=True)
                 else:
                     _dense_pool_bwd(dsb, B, T, Wn, ds_out)
             if mode == "SummaryMixing-fast":

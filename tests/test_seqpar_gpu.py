@@ -53,7 +53,7 @@ if os.environ.get("SMX_NOMASK") == "1":
 xf = x.clone().requires_grad_(True)
 y, _ = enc(xf, src_key_padding_mask=pad)
 (y * r).sum().backward()
-gfull = {n: p.grad.clone() for n, p in enc.named_parameters()}
+gfull = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}   # (expdecay: frozen decay constant)
 dxf = xf.grad.clone()
 for p in enc.parameters():
     p.grad = None
@@ -72,8 +72,8 @@ def close(a, b, what, tol=2e-4):
 
 close(yl.detach(), y_ref, "output")
 close(xl.grad, dx_ref, "input gradient")
-for n, p in enc.named_parameters():
-    close(p.grad, gfull[n], "grad " + n, 5e-4)
+for n, g in gfull.items():
+    close(dict(enc.named_parameters())[n].grad, g, "grad " + n, 5e-4)
 dist.barrier()
 print(f"rank {rank} OK")
 '''
@@ -121,3 +121,11 @@ def test_sequence_parallel_branchformer(nomask):
     and the reflected frames at the two ends of the whole sequence (Branchformer.py:31-97); outputs, input gradients and summed
     parameter gradients equal the unsharded encoder's."""
     _run("SummaryMixing", nomask=nomask, enc="branchformer")
+
+
+@pytest.mark.parametrize("nomask", [False, True])
+def test_sequence_parallel_expdecay(nomask):
+    """SummaryMixing-expdecay over two time shards (summary_mixing.py:316-365 without sum_mask): the two-sided exponential
+    filter crosses the shard boundary through one (B, D) state per direction, the denominators use the global frame index
+    (functional._expdecay_seqpar); forward and both transposed uses in the backward equal the unsharded encoder's."""
+    _run("SummaryMixing-expdecay", nomask=nomask)
