@@ -214,20 +214,41 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   // epilogue side vector of this thread (requested first, parked in ONE register across the main loop, published to
   // LDS before the epilogue): t < TILE_M -> bias[m0 + t], then TILE_N row factors row_mask[n] * alpha
   constexpr int NSIDE = (TILE_M + TILE_N + 255) / 256;
-  float side_v[NSIDE];
+  // Narrow tiles (SIDE_RAW): the RAW loaded words stay parked - bias bits and mask byte in SEPARATE registers - and are
+  // converted where they are published: converting here, or letting the two divergent branches write one register, made every
+  // workgroup wait for that round trip, s_waitcnt vmcnt(0), before it requested its first operand tile (what a small grid - the
+  // recipe batch's 472 workgroups - cannot hide).  The 256-wide tiles have no register to spare for it (the 256 x 256 tile: 16 ->
+  // 147 spilled registers) and keep the converted value in ONE register.
+  constexpr bool SIDE_RAW = TILE_M <= 128;
+  float side_b[NSIDE];
+  uint32_t side_m[SIDE_RAW ? NSIDE : 1];
 #pragma unroll
   for (int i = 0; i < NSIDE; ++i) {
-    const int si = t + 256 * i;
-    side_v[i] = 0.f;
-    if (p.e.out_mode != SMX_OUT_ATOMIC_F32) {
-      if (si < TILE_M) {
-        if (p.e.bias && m0 + si < p.M) side_v[i] = p.e.bias[(long)bz * p.e.bias_batch_stride + m0 + si];
-      } else if (si < TILE_M + TILE_N) {
-        const int n = n0 + si - TILE_M;
-        side_v[i] = ((p.e.row_mask && n < p.N) ? (p.e.row_mask[n] ? 1.f : 0.f) : 1.f) * p.e.alpha;
+    const int si = t + 256 * i, n = n0 + si - TILE_M;
+    const bool on = p.e.out_mode != SMX_OUT_ATOMIC_F32;
+    if constexpr (SIDE_RAW) {
+      side_b[i] = (on && si < TILE_M && p.e.bias && m0 + si < p.M) ? p.e.bias[(long)bz * p.e.bias_batch_stride + m0 + si] : 0.f;
+      side_m[i] = (on && si >= TILE_M && si < TILE_M + TILE_N && p.e.row_mask && n < p.N) ? (uint32_t)p.e.row_mask[n] : 1u;
+    } else {
+      side_b[i] = 0.f;
+      if (on) {
+        if (si < TILE_M) {
+          if (p.e.bias && m0 + si < p.M) side_b[i] = p.e.bias[(long)bz * p.e.bias_batch_stride + m0 + si];
+        } else if (si < TILE_M + TILE_N) {
+          side_b[i] = ((p.e.row_mask && n < p.N) ? (p.e.row_mask[n] ? 1.f : 0.f) : 1.f) * p.e.alpha;
+        }
       }
     }
   }
+  auto side_value = [&](int i) __attribute__((always_inline)) -> float {
+    if constexpr (SIDE_RAW) {
+      if (p.e.out_mode == SMX_OUT_ATOMIC_F32) return 0.f;
+      asm volatile("" : "+v"(side_m[i]));                // (keeps hipcc from moving the compare up behind the load)
+      return t + 256 * i < TILE_M ? side_b[i] : (side_m[i] ? p.e.alpha : 0.f);
+    } else {
+      return side_b[i];
+    }
+  };
 
   f32x16 acc[FN][FM];
 #pragma unroll
@@ -839,7 +860,7 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
       // (j, g), the 4 columns wm*64 + j*32 + g*8 + hi*4 .. +3.
       constexpr int SB = TILE_M * 2 + 8;                  // staged bf16 row: 264 B (66 dwords: 2-way conflicts at worst)
       lds_barrier();                                      // every wave is done reading the operand stage
-      if (t < TILE_M + TILE_N) side[t] = side_v[0];
+      if (t < TILE_M + TILE_N) side[t] = side_value(0);
       lds_barrier();
       const uint32_t dthresh = p.dthresh;
       const float dscale = p.dscale;
@@ -922,7 +943,7 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   if constexpr (ALIAS_SIDE) lds_barrier();               // every wave is done reading the operand ring
 #pragma unroll
   for (int i = 0; i < NSIDE; ++i)
-    if (t + 256 * i < TILE_M + TILE_N) side[t + 256 * i] = side_v[i];   // (visible after the first barrier below)
+    if (t + 256 * i < TILE_M + TILE_N) side[t + 256 * i] = side_value(i);   // (visible after the first barrier below)
   if constexpr (TILE_M > 128) {
   // (wide tile: 128 accumulator registers - duplicating the loop per variant spills there; the choice stays inside)
   // LayerNorm fused into the epilogue (LNF; the tile holds whole rows: M == TILE_M == 256): gamma / beta are parked in
