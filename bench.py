@@ -12,6 +12,8 @@ collective is the bucketed gradient all-reduce (RCCL over xGMI).
 
 `python bench.py --gpus N` without a torchrun environment re-launches itself under torch.distributed.run with N ranks
 (and fails loudly when fewer than N GPUs are visible).  --scaling strong keeps the GLOBAL batch fixed (B / N per rank).
+--grad-accum G: one step = one OPTIMIZER step over G micro-batches (the recipe: 4 x 150 s), --accum sequential (G forward +
+backward passes accumulate, the reference's fit_batch) or fused (trainer.fuse_microbatches: ONE batch, same gradients).
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
   "roofline":     roofline of the DOMINANT kernel family of the step (largest share of the in-step kernel time; the
@@ -435,6 +437,11 @@ def main():
                     help="gradient exchange of the data-parallel step (trainer.FlatAdamW): one all-reduce per layer bucket, or "
                          "reduce-scatter + sharded AdamW + all-gather of the weights")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradients on the wire (xGMI)")
+    ap.add_argument("--grad-accum", type=int, default=1, metavar="G",
+                    help="micro-batches per optimizer step (the recipe: grad_accumulation_factor 4 x max_batch_len 150 s)")
+    ap.add_argument("--accum", default="sequential", choices=["sequential", "fused"],
+                    help="sequential: G forward+backward passes accumulate, one update (the reference's fit_batch); fused: the G "
+                         "micro-batches run as ONE batch (trainer.fuse_microbatches: same gradients, sized for 288 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-points", action="store_true",
                     help="skip the extra_points of the default line (SURVEY 8d batches: C2b B=64 x 500, C2a B=10 x 375, and the bf16 "
@@ -510,21 +517,34 @@ def main():
         if world > 1 or force_dist:   # one gradient bucket per encoder layer, reduced as soon as its backward is done
             for layer in enc.transformer.encoder.layers:
                 rng = opt.param_range(list(layer.parameters()))
-                layer._on_bwd_done = (lambda r=rng: opt.reduce_bucket_async(*r))
+                layer._on_bwd_done = (lambda r=rng: opt.reduce_bucket_async(*r) if accum["last"] else None)
     else:
         enc.eval()
-    src, wav_len, r, valid_frames = synthetic_batch(cfg, rank, dev, dtype)
+    G = max(1, args.grad_accum)
+    micro = [synthetic_batch(cfg, rank * G + g, dev, dtype) for g in range(G)]
+    valid_frames = sum(m[3] for m in micro)
+    if G > 1 and args.accum == "fused":
+        from summarymixing_amd.trainer import fuse_microbatches
+        src_f, wl_f = fuse_microbatches([(m[0], m[1]) for m in micro])
+        micro = [(src_f, wl_f, torch.cat([m[2] for m in micro]), valid_frames)]
+    src, wav_len, r = micro[0][:3]
+    accum = {"last": True}
     enc_kw = {}
     if args.dynchunk:
         from summarymixing_amd.utils.dynamic_chunk_training import DynChunkTrainConfig
         parts = [int(x) for x in args.dynchunk.split(",")]
         enc_kw["dynchunktrain_config"] = DynChunkTrainConfig(parts[0], parts[1] if len(parts) > 1 else None)
 
+    def fwd_bwd_all():
+        # (gradient accumulation: the kernels ADD into the flat gradient buffer; the bucket hooks fire on the last micro-batch)
+        opt.zero_grad()
+        for g, (s_, wl_, r_, _) in enumerate(micro):
+            accum["last"] = g == len(micro) - 1
+            enc(s_, wl_, **enc_kw).backward(r_)
+
     def step():
         if train:
-            opt.zero_grad()
-            y = enc(src, wav_len, **enc_kw)
-            y.backward(r)
+            fwd_bwd_all()
             if world > 1 or force_dist:   # parameters outside the layer buckets (input Linear, final LN)
                 first = opt.param_range(list(enc.transformer.encoder.layers[0].parameters()))[0]
                 last = opt.param_range(list(enc.transformer.encoder.layers[-1].parameters()))[1]
@@ -551,7 +571,7 @@ def main():
     # epoch live in a device counter, so replays still advance them (include/smx.h: smx_step_counter_add).
     run, graph_note = step, "eager"
     dist_run = world > 1 or force_dist
-    want_graph = args.graph == "on" or (args.graph == "auto" and cfg["B"] * cfg["T"] < 40000)
+    want_graph = args.graph == "on" or (args.graph == "auto" and micro[0][0].shape[0] * cfg["T"] < 40000)
     if want_graph and train and dist_run and args.reduce == "rs_ag":
         want_graph = False                                # (the sharded update holds collectives: kept out of graphs)
     if want_graph and train and dist_run:
@@ -564,9 +584,7 @@ def main():
             for layer in enc.transformer.encoder.layers:
                 layer._on_bwd_done = None
 
-            def fwd_bwd():
-                opt.zero_grad()
-                enc(src, wav_len, **enc_kw).backward(r)
+            fwd_bwd = fwd_bwd_all
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -626,7 +644,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
 
-    frames_per_step = cfg["B"] * cfg["T"] * world
+    frames_per_step = cfg["B"] * cfg["T"] * world * G
     value = frames_per_step * args.steps / dt
     out = {
         "metric": "encoder frames/s (whole node), " + ("LibriSpeech Conformer-SummaryMixing" if cfg["kind"] == "conformer"
@@ -636,6 +654,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": cfg["name"] + (" training step (fwd+bwd+grad-clip+AdamW)" if train else " forward"),
                    "per_gpu_batch": cfg["B"], "enc_frames_per_utt": cfg["T"], "global_batch": global_B,
+                   "grad_accumulation": ({"micro_batches": G, "mode": args.accum,
+                                          "utterances_per_launch": int(micro[0][0].shape[0])} if G > 1 else None),
                    "padded_frames_per_step": frames_per_step, "valid_frames_rank0": valid_frames,
                    "input": f"(B,T,{cfg['input']}) N(0,1), wav_len U(0.5,1), zero padded",
                    "dropout": (args.dropout if train else 0.0), "parallelism": f"dp{world}", "init": "xavier_normal seed 3407",

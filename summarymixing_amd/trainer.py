@@ -33,6 +33,43 @@ from . import ops
 ALIGN = 64   # elements; keeps every parameter view 256-byte aligned in fp32 and 128-byte in bf16
 
 
+def fuse_microbatches(batches, pad_to_longest=False):
+    """Gradient accumulation without the loop: the G micro-batches of one optimizer step as ONE batch.
+
+    The reference accumulates `grad_accumulation_factor` forward + backward passes per update (recipes/LibriSpeech/ASR/
+    transducer/hparams/conformer_summarymixing_transducer.yaml:65-66, 113-126: 4 x max_batch_len 150 s, "works well for 3090
+    24GB GPU, adapt it to your needs").  No operator of the encoder path couples utterances (LayerNorm per frame, the
+    padding-masked mean and the depthwise convolution per utterance), so for micro-batches of the SAME padded length the summed
+    gradients are the gradients of their concatenation along the batch axis (tests/test_accum_gpu.py: 1e-6 in fp32, the order of
+    the fp32 sums over frames is all that differs) - and 4 x 3750 frames fill an MI355X where 3750 leave it launch- and
+    latency-bound (bench.py --grad-accum 4 --accum fused: 0.53 -> 0.92 M frames/s).
+
+    pad_to_longest=True also fuses micro-batches of DIFFERENT padded lengths by zero-padding the shorter ones.  That is not the
+    same function: the reference's convolution module masks its OUTPUT, not the depthwise convolution's input (Conformer.py:
+    327-331), so the last (k-1)/2 frames of an utterance see whatever follows it - zeros at the end of the tensor, LayerNorm /
+    bias values of padded frames otherwise.  The reference has exactly this dependence on what a dynamic batch holds; fusing
+    changes which utterances end at the tensor's end, nothing else.
+
+    batches: [(src (B_i, T_i, F), wav_len (B_i,) relative lengths), ...].  Returns (src (sum B_i, max T_i, F) zero padded,
+    wav_len relative to max T_i: round(wav_len * T) gives every utterance the frame count it had)."""
+    if not batches:
+        raise ValueError("fuse_microbatches: no micro-batch")
+    T = max(int(s.shape[1]) for s, _ in batches)
+    srcs, lens = [], []
+    for s, wl in batches:
+        if s.dim() != 3 or wl.shape[0] != s.shape[0]:
+            raise ValueError("fuse_microbatches: expected (B, T, F) features with (B,) relative lengths")
+        Ti = int(s.shape[1])
+        if Ti < T:
+            if not pad_to_longest:
+                raise ValueError(f"fuse_microbatches: padded lengths differ ({Ti} vs {T} frames); pad_to_longest=True fuses them "
+                                 "anyway (see the docstring: the convolution's edge frames then see padding instead of the tensor's end)")
+            s = torch.nn.functional.pad(s, (0, 0, 0, T - Ti))
+        srcs.append(s)
+        lens.append(torch.round(wl.double() * Ti) / T)
+    return torch.cat(srcs, 0), torch.cat(lens).to(batches[0][1].dtype)
+
+
 def plan_buckets(total, layer_ranges):
     """The gradient buckets of one step in the order their collectives are launched: the encoder layers' ranges as their
     backward passes finish (last layer first), then what lies in front of the first layer (input projection) and behind the
