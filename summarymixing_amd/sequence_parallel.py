@@ -21,8 +21,13 @@ reduce them with reduce_gradients() (SUM over the group) before the optimizer.
     conv over the whole sequence; backward: halo gradients back to their owners, reflected rows' gradients folded onto their
     source frames.
 
+  * (round 4) SummaryMixing-expdecay without sum_mask (summary_mixing.py:316-365): the two-sided exponential filter crosses a
+    shard boundary through ONE (B, D) state per direction - an all-gather of (2, B, D) per rank, rank-1 corrections
+    decay^(t+1) f_in + decay^(T-t) g_in on the local numerators, denominators from the global frame index
+    (functional._expdecay_seqpar; forward and the backward's transposed operator).
+
 Supported: ConformerEncoder(Layer) and BranchformerEncoder(Layer) with the per-utterance mean (modes SummaryMixing, -fast,
--lite), dropout-free, no DynChunk mask / expdecay.  Anything else raises NotImplementedError.  Host-side plumbing only: the
+-lite) or the mask-free expdecay summary, dropout-free, no DynChunk mask.  Anything else raises NotImplementedError.  Host-side plumbing only: the
 arithmetic stays in libsmx.
 """
 import contextlib
