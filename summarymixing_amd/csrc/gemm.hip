@@ -1386,8 +1386,12 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // width (M == 256: the activation panel is fetched exactly once and 500 tiles fill the 512 slots in one round at
   // 64000 frames) or when the reduction is long enough for the doubled MFMA-per-LDS-read ratio to matter.
   // Measured at 64000 frames: (K=1024, M=256) NT 77 -> 59 us, NN 65 -> 55 us; (K=256, M=1024) 99 -> 103 us (not used).
+  // Round 4, d_model = 512 (M = 512: two column tiles per row panel, so the panel is fetched twice either way): K = 512 .. 1536 on
+  // the 128 x 128 tile instead - twice the workgroups per launch - is C5 forward 62.64 -> 61.87 ms, C2a 51.4 -> 51.1, C4 40.9 -> 40.75
+  // (SMX_GEMM_WIDE=0 / 1024 / 2048 A/B on one box, twice); K = 2048 is a tie and stays wide.  SMX_GEMM_WIDE=<k >= 2>: that minimum K.
   const int wide_env = cfg().gemm_wide;
-  const bool wide = wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 512 && p.M <= 512));
+  const bool wide = wide_env >= 2 ? (p.M == 256 || (p.K >= wide_env && p.M <= 512))     // (experiment: SMX_GEMM_WIDE=<min K>)
+                                  : wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 2048 && p.M <= 512));
   // wgrad-shaped TN GEMMs with both operands on the LDS-DMA ring (gemm_tn_dma_kernel).  SMX_TN_DMA=0 disables it.
   const int tn_dma_env = cfg().tn_dma;
   if constexpr (sizeof(T) == 2 && !A_KC && !B_KC) {
