@@ -568,6 +568,58 @@ class DynChunkMask:
         return m
 
 
+def _chunk_mean_seqpar(x, out, B, T, chunk, left, reverse=False):
+    """The Dynamic Chunk Training summary (chunk c averages the chunks [c - left, c], all earlier ones with left = None:
+    summary_mixing.py:224-235 with the mask of TransformerASR.py:85-110) with the time axis sharded over the sequence group.
+    Shards hold whole chunks (T % chunk == 0), so a window reaches into other shards only through chunk SUMS: the local kernel
+    (fp32, its local window sizes multiplied back out) gives the local part of every window sum; left = None adds the totals of
+    all earlier shards (one all-gather of (B, D)), a finite left the last `left` chunk sums of the previous shard ((B, left, D);
+    needs left <= chunks per shard); the denominators count the chunks of the GLOBAL window.
+    reverse: the transposed operator M^T (x / rowsum(M)) - the same exchange towards the LATER shards."""
+    W, r = SP.world(), SP.rank()
+    if T % chunk != 0:
+        raise ValueError(f"sequence-parallel Dynamic Chunk Training: the frames per rank ({T}) must be a multiple of the chunk size ({chunk})")
+    C = T // chunk
+    if left is not None and left > C:
+        raise NotImplementedError(f"sequence-parallel Dynamic Chunk Training: left context {left} chunks > {C} chunks per rank")
+    dev = x.device
+    D = x.shape[1]
+    c_loc = torch.arange(C, device=dev)
+    c_glob = c_loc + r * C
+
+    def win(c):                                               # frames in the window of chunk c
+        return ((c if left is None else c.clamp(max=left)) + 1).float() * chunk
+    den_loc, den_glob = win(c_loc)[None, :, None, None], win(c_glob)[None, :, None, None]
+    x4 = x.float().view(B, C, chunk, D)
+    if reverse:
+        x4 = x4 / den_glob * den_loc                          # (the kernel divides by its local window sizes)
+    num = torch.empty((B * T, D), dtype=torch.float32, device=dev)
+    ops.chunk_mean(x4.reshape(B * T, D), num, B, T, chunk, left, reverse=reverse)
+    num = num.view(B, C, chunk, D)
+    if not reverse:
+        num *= den_loc
+    # chunk sums that cross the shard boundary (forward: from earlier shards; transposed: from later ones)
+    src = x4 / den_loc if reverse else x4                     # (transposed: sums of g / den_glob)
+    if left is None:
+        tot = SP._all_gather(src.sum((1, 2)))                 # (B, D) per rank
+        others = range(r + 1, W) if reverse else range(r)
+        add = sum((tot[q] for q in others), torch.zeros_like(tot[0]))
+        num += add[:, None, None, :]
+    elif left > 0:
+        edge = src[:, :left].sum(2) if reverse else src[:, C - left:].sum(2)      # (B, left, D): what the neighbour's windows reach
+        edges = SP._all_gather(edge.contiguous())
+        if reverse and r < W - 1:
+            pre = edges[r + 1].cumsum(1)                      # chunks [0, i] of the next shard
+            num[:, C - left:] += pre[:, :, None, :]           # local chunk C - left + i reaches the next shard's chunks [0, i]
+        elif not reverse and r > 0:
+            suf = edges[r - 1].flip(1).cumsum(1).flip(1)      # chunks [C - left + i, C) of the previous shard
+            num[:, :left] += suf[:, :, None, :]               # local chunk i reaches back to the previous shard's chunk C - left + i
+    if not reverse:
+        num /= den_glob
+    out.view(B, C, chunk, D).copy_(num)
+    return out
+
+
 def _expdecay_seqpar(x, out, B, T, decay, reverse=False):
     """The expdecay summary with the time axis sharded over the sequence group: x / out are this rank's (B*T, D) rows of
     a (B, world*T, D) sequence.  (M x)_t = f_t + g_t - x_t is two recurrences, so the rows of a shard see the other shards
@@ -710,15 +762,18 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         # ---- summary ------------------------------------------------------------------------------
         inv = None
         sp = SP.enabled()
-        if sp and pool_kind not in ("mean", "expdecay"):
-            raise NotImplementedError("sequence-parallel mode supports the per-utterance mean and the mask-free expdecay "
-                                      "summary only (no sum_mask)")
+        if sp and pool_kind not in ("mean", "expdecay", "chunk"):
+            raise NotImplementedError("sequence-parallel mode supports the per-utterance mean, the Dynamic Chunk Training mask and "
+                                      "the mask-free expdecay summary (no dense sum_mask)")
         if sp and p_drop > 0.0:
             raise NotImplementedError("sequence-parallel mode is dropout-free: the fused dropout masks are indexed by the "
                                       "LOCAL frame row, every shard would draw the same mask")
         if sp and pool_kind == "expdecay":
             sbar = torch.empty((N, sdim), dtype=dtype, device=dev)
             _expdecay_seqpar(s, sbar, B, T, decay)
+        elif sp and pool_kind == "chunk":
+            sbar = torch.empty((N, sdim), dtype=dtype, device=dev)
+            _chunk_mean_seqpar(s, sbar, B, T, sm.chunk_size, sm.left_context)
         elif sp:
             # time axis sharded over the group: local partial sums + valid-frame counts, ONE all-reduce, then the mean
             ssum, _ = ops.masked_mean(s, mask, B, T, scale=False)
@@ -874,7 +929,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                     dsbar, _ = ops.masked_mean(dsd, None, B, T, scale=False)               # sum over time
                     bcast_ds(dsbar)
                 elif pool_kind == "chunk":
-                    ops.chunk_mean(dsd, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
+                    (_chunk_mean_seqpar if SP.enabled() else ops.chunk_mean)(dsd, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
                 elif pool_kind == "expdecay":
                     (_expdecay_seqpar if SP.enabled() else ops.expdecay_mean)(dsd, ds_out, B, T, decay, reverse=True)
                 else:
@@ -901,7 +956,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 dsb = torch.empty((N, sdim), dtype=dtype, device=dev)
                 ops.gemm(L.GEMM_NN, dzm, Ws, dsb, N, sdim, s_out, None)
                 if pool_kind == "chunk":
-                    ops.chunk_mean(dsb, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
+                    (_chunk_mean_seqpar if SP.enabled() else ops.chunk_mean)(dsb, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
                 elif pool_kind == "expdecay":
                     (_expdecay_seqpar if SP.enabled() else ops.expdecay_mean)(dsb, ds_out, B, T, decay, reverse=True)
                 else:
@@ -1088,19 +1143,26 @@ def _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual,
     """conv_module_fwd with the time axis sharded (sequence_parallel.py): the (k-1)/2 frames either side come from the
     neighbour ranks as halos of the module INPUT; LN / pointwise conv / GLU are recomputed on them, the depthwise conv
     runs on the extended sequence and only the centre T frames go on.  At the two ends of the whole sequence the halo
-    must act as the conv's zero padding, i.e. zero AFTER the GLU: the pointwise output rows there are cleared."""
-    if chunk:
-        raise NotImplementedError("sequence-parallel mode does not support the Dynamic Chunk Convolution")
+    must act as the conv's zero padding, i.e. zero AFTER the GLU: the pointwise output rows there are cleared.
+    Dynamic Chunk Convolution (chunk > 0, Conformer.py:190-313): a frame never reads beyond its own chunk, and shards hold whole
+    chunks, so there is no right halo; the left halo is rounded up to whole chunks so that the chunk grid of the extended
+    sequence is the grid of the whole one."""
     d = x.shape[1]
     k = P["wd"].shape[-1]
     H = (k - 1) // 2
-    if T < H:
-        raise ValueError(f"sequence-parallel shards need at least {H} frames per rank (got {T})")
-    Te = T + 2 * H
+    if chunk:
+        if T % chunk != 0:
+            raise ValueError(f"sequence-parallel Dynamic Chunk Convolution: the frames per rank ({T}) must be a multiple of the chunk size ({chunk})")
+        Hl, Hr = (H + chunk - 1) // chunk * chunk, 0
+    else:
+        Hl = Hr = H
+    if T < Hl:
+        raise ValueError(f"sequence-parallel shards need at least {Hl} frames per rank (got {T})")
+    Te = T + Hl + Hr
     first_rank, last_rank = SP.rank() == 0, SP.rank() == SP.world() - 1
     x3 = x.view(B, T, d)
-    lh, rh = SP.exchange_halos(x3[:, :H], x3[:, T - H:])
-    xe = torch.cat([lh, x3, rh], 1).view(B * Te, d)
+    lh, rh = SP.exchange_halos(x3[:, :Hl], x3[:, T - Hl:])
+    xe = torch.cat([lh, x3, rh] if Hr else [lh, x3], 1).view(B * Te, d)
     h, ln1_b = ln_fwd(xe, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd)
     Wp = wcast(P["Wp"], dtype).view(2 * d, d)
     p_, _ = linear_fwd(h, Wp, P["bp"])
@@ -1108,13 +1170,13 @@ def _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual,
     def clear_ends(t2, width):
         t3 = t2.view(B, Te, width)
         if first_rank:
-            t3[:, :H].zero_()
-        if last_rank:
-            t3[:, Te - H:].zero_()
+            t3[:, :Hl].zero_()
+        if last_rank and Hr:
+            t3[:, Te - Hr:].zero_()
     clear_ends(p_, 2 * d)
     wd = P["wd"].detach().reshape(d, k)
-    ce = ops.dwconv_fwd(p_, wd, P["bd"].detach() if P["bd"] is not None else None, B, Te, d, k, True, L.PAD_ZERO, 0)
-    c = ce.view(B, Te, d)[:, H:H + T].contiguous().view(B * T, d)
+    ce = ops.dwconv_fwd(p_, wd, P["bd"].detach() if P["bd"] is not None else None, B, Te, d, k, True, L.PAD_ZERO, chunk or 0)
+    c = ce.view(B, Te, d)[:, Hl:Hl + T].contiguous().view(B * T, d)
     a, ln2_b = ln_fwd(c, P["ln2_w"], P["ln2_b"], 1e-5, need_bwd, act)
     Wo = wcast(P["Wo"], dtype)
     dr = (p, ops.new_dropout_seed()) if p > 0.0 else None
@@ -1127,17 +1189,19 @@ def _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual,
         da, _ = linear_bwd(dy, a, Wo, None, L.ACT_NONE, mask, 1.0, gacc(P["Wo"]), gacc(P["bo"]), drop=dr)
         dc = ln2_b(da)
         dce = torch.zeros((B, Te, d), dtype=dtype, device=x.device)       # the halo outputs were dropped: zero gradient
-        dce[:, H:H + T] = dc.view(B, T, d)
+        dce[:, Hl:Hl + T] = dc.view(B, T, d)
         gwd = gacc(P["wd"])
         dp, _ = ops.dwconv_bwd(dce.view(B * Te, d), p_, wd, P["bd"].detach() if P["bd"] is not None else None,
-                               gwd.view(d, k), gacc(P["bd"]), B, Te, d, k, True, L.PAD_ZERO, 0)
+                               gwd.view(d, k), gacc(P["bd"]), B, Te, d, k, True, L.PAD_ZERO, chunk or 0)
         clear_ends(dp, 2 * d)                                             # nothing flows into the zero padding
         dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
         dxe = ln1_b(dh).view(B, Te, d)
-        g_first, g_last = SP.return_halo_grads(dxe[:, :H], dxe[:, Te - H:])
-        dx = dxe[:, H:H + T].contiguous()
-        dx[:, :H] += g_first
-        dx[:, T - H:] += g_last
+        g_lh = dxe[:, :Hl]
+        g_first, g_last = SP.return_halo_grads(g_lh, dxe[:, Te - Hr:] if Hr else torch.zeros_like(g_lh))
+        dx = dxe[:, Hl:Hl + T].contiguous()
+        if Hr:
+            dx[:, :Hr] += g_first
+        dx[:, T - Hl:] += g_last
         dx = dx.view(B * T, d)
         if residual:
             dx = ops.axpby(1.0, dx, 1.0, dy)

@@ -26,8 +26,15 @@ reduce them with reduce_gradients() (SUM over the group) before the optimizer.
     decay^(t+1) f_in + decay^(T-t) g_in on the local numerators, denominators from the global frame index
     (functional._expdecay_seqpar; forward and the backward's transposed operator).
 
+  * (round 4) Dynamic Chunk Training (Conformer.py:190-313, TransformerASR.py:85-110; shards of whole chunks, T_loc % chunk == 0):
+    the chunked convolution never reads beyond a frame's own chunk, so it needs no right halo and a LEFT halo rounded up to whole
+    chunks (the chunk grid of the extended shard is the global one); the chunk-window mean crosses a shard boundary through chunk
+    SUMS only - the last `left` chunk sums of the previous shard, or the totals of all earlier shards with unlimited left
+    context (functional._chunk_mean_seqpar; the transposed operator sends the same sums the other way).
+
 Supported: ConformerEncoder(Layer) and BranchformerEncoder(Layer) with the per-utterance mean (modes SummaryMixing, -fast,
--lite) or the mask-free expdecay summary, dropout-free, no DynChunk mask.  Anything else raises NotImplementedError.  Host-side plumbing only: the
+-lite), the mask-free expdecay summary or a DynChunk mask (Conformer), dropout-free.  A dense (T, T) sum_mask raises
+NotImplementedError.  Host-side plumbing only: the
 arithmetic stays in libsmx.
 """
 import contextlib

@@ -50,8 +50,18 @@ pad = (torch.arange(T)[None] < lens[:, None]).cuda()
 if os.environ.get("SMX_NOMASK") == "1":
     pad = None
 
+kw_full, kw_loc = {}, {}
+if os.environ.get("SMX_DYNCHUNK"):
+    from summarymixing_amd import functional as F
+    from summarymixing_amd.utils.dynamic_chunk_training import DynChunkTrainConfig
+    cs, lc = os.environ["SMX_DYNCHUNK"].split(",")
+    cs, lc = int(cs), (None if lc == "all" else int(lc))
+    cfg = DynChunkTrainConfig(cs, lc)
+    kw_full = dict(src_mask=F.DynChunkMask(T, cs, lc), dynchunktrain_config=cfg)
+    kw_loc = dict(src_mask=F.DynChunkMask(T // world, cs, lc), dynchunktrain_config=cfg)
+
 xf = x.clone().requires_grad_(True)
-y, _ = enc(xf, src_key_padding_mask=pad)
+y, _ = enc(xf, src_key_padding_mask=pad, **kw_full)
 (y * r).sum().backward()
 gfull = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}   # (expdecay: frozen decay constant)
 dxf = xf.grad.clone()
@@ -61,7 +71,7 @@ for p in enc.parameters():
 with SP.sequence_parallel():
     xl = SP.shard(x).requires_grad_(True)
     pl = SP.shard(pad) if pad is not None else None
-    yl, _ = enc(xl, src_key_padding_mask=pl)
+    yl, _ = enc(xl, src_key_padding_mask=pl, **kw_loc)
     (yl * SP.shard(r)).sum().backward()
     SP.reduce_gradients(list(enc.parameters()))
     y_ref, dx_ref = SP.shard(y.detach()), SP.shard(dxf)
@@ -85,12 +95,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(mode, nomask=False, enc="conformer"):
+def _run(mode, nomask=False, enc="conformer", dynchunk=""):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   SMX_ROOT=ROOT, SMX_MODE=mode, SMX_NOMASK="1" if nomask else "0", SMX_ENC=enc, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   SMX_ROOT=ROOT, SMX_MODE=mode, SMX_NOMASK="1" if nomask else "0", SMX_ENC=enc, SMX_DYNCHUNK=dynchunk, HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -129,3 +139,15 @@ def test_sequence_parallel_expdecay(nomask):
     filter crosses the shard boundary through one (B, D) state per direction, the denominators use the global frame index
     (functional._expdecay_seqpar); forward and both transposed uses in the backward equal the unsharded encoder's."""
     _run("SummaryMixing-expdecay", nomask=nomask)
+
+
+@pytest.mark.parametrize("dynchunk", ["8,2", "16,all", "12,1", "8,0", "24,2"])
+def test_sequence_parallel_dynchunk(dynchunk):
+    """Dynamic Chunk Training over two time shards of 48 frames (Conformer.py:190-313 chunked convolution: left halo of whole
+    chunks, no right halo; summary_mixing.py:224-235 with the mask of TransformerASR.py:85-110: chunk sums of the previous /
+    next shard, or the totals of all earlier / later ones with unlimited left context) equals the unsharded encoder."""
+    _run("SummaryMixing-fast", dynchunk=dynchunk)
+
+
+def test_sequence_parallel_dynchunk_full_mode_no_mask():
+    _run("SummaryMixing", nomask=True, dynchunk="16,1")
