@@ -35,7 +35,7 @@ const smx_config& cfg() {
   static const smx_config c = [] {
     smx_config k;
     memset(&k, 0, sizeof(k));
-    k.gemm_tile64 = getenv("SMX_GEMM_TILE64") ? 1 : 0;
+    k.gemm_tile64 = env_i("SMX_GEMM_TILE64", 0) != 0 ? 1 : 0;
     k.gemm_wide = env_i("SMX_GEMM_WIDE", -1);
     k.tn_dma = env_i("SMX_TN_DMA", 1);
     k.nt_z = env_i("SMX_NT_Z", 1);
