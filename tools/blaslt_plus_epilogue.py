@@ -4,7 +4,9 @@ epilogues replace, at the four GEMM shapes that lead the C2b step (64 000 frames
 to the fused smx_gemm launch doing the same work.  The unfused passes are this repo's own standalone kernels (the best
 single-pass implementation available here), so the comparison isolates FUSION, not kernel quality.
 
-    python tools/blaslt_plus_epilogue.py > profiles/r03_blaslt_plus_epilogue.txt"""
+    python tools/blaslt_plus_epilogue.py > profiles/r03_blaslt_plus_epilogue.txt
+    D=512 F=2048 python tools/blaslt_plus_epilogue.py > profiles/r04_blaslt_plus_epilogue_d512.txt   (the recipe width: the LayerNorm
+    is a separate launch there, "fused" = the fused GEMM launch + the standalone LayerNorm kernel, as the product runs it)"""
 import os
 import sys
 
@@ -15,7 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import time_kernel                                  # noqa: E402
 from summarymixing_amd import _lib as L, ops                    # noqa: E402
 
-N, d, f = 64000, 256, 1024
+N, d, f = 64000, int(os.environ.get("D", 256)), int(os.environ.get("F", 1024))
+LNF = d == 256          # LayerNorm inside the GEMM epilogue (row-complete 128 x 256 tile)
 dev = "cuda"
 rnd = lambda *s: (torch.rand(*s, device=dev) * 2 - 1)
 x, h = rnd(N, d).bfloat16(), rnd(N, f).bfloat16()
@@ -43,7 +46,7 @@ def up_pass():
 p1 = T(up_pass)
 zb, ab = torch.empty(N, f, device=dev, dtype=torch.bfloat16), torch.empty(N, f, device=dev, dtype=torch.bfloat16)
 fu = T(lambda: ops.gemm(L.GEMM_NT, x, W1, ab, N, f, d, ops.epilogue(bias=b1, act=L.ACT_SWISH, z=zb, drop=(0.15, 7))))
-print(f"  {'NT 256->1024 + bias + Swish + Z + dropout':66s} {lin:9.1f} {p1:8.1f} {lin + p1:8.1f} {fu:8.1f} {fu / (lin + p1):9.2f}")
+print(f"  {f'NT {d}->{f} + bias + Swish + Z + dropout':66s} {lin:9.1f} {p1:8.1f} {lin + p1:8.1f} {fu:8.1f} {fu / (lin + p1):9.2f}")
 
 # 2) act-grad dgrad: dz = D(g * Swish'(z)), g = dy W2
 mm = T(lambda: torch.matmul(dy, W2))
@@ -52,7 +55,7 @@ dz = torch.empty_like(g)
 p2 = T(lambda: ops.act_mask_bwd(g, z, None, L.ACT_SWISH, 1.0, dz, None, None, 0, (0.15, 7)))
 dzb = torch.empty(N, f, device=dev, dtype=torch.bfloat16)
 fu = T(lambda: ops.gemm(L.GEMM_NN, dy, W2, dzb, N, f, d, ops.epilogue(act=L.ACT_SWISH, act_grad_z=z, drop=(0.15, 7))))
-print(f"  {'NN 256->1024 + act-grad(z) + dropout':66s} {mm:9.1f} {p2:8.1f} {mm + p2:8.1f} {fu:8.1f} {fu / (mm + p2):9.2f}")
+print(f"  {f'NN {d}->{f} + act-grad(z) + dropout':66s} {mm:9.1f} {p2:8.1f} {mm + p2:8.1f} {fu:8.1f} {fu / (mm + p2):9.2f}")
 
 # 3) FFN down-projection + residual (float32 stream) + dropout + LayerNorm of the new stream tensor
 lin = T(lambda: tF.linear(h, W2, b2.bfloat16()))
@@ -69,9 +72,15 @@ def down_pass():
 
 p3 = T(down_pass)
 outs, hy, st = torch.empty(N, d, device=dev), torch.empty(N, d, device=dev, dtype=torch.bfloat16), torch.empty(N, 2, device=dev)
-fu = T(lambda: ops.gemm(L.GEMM_NT, h, W2, outs, N, d, f, ops.epilogue(bias=b2, res=res32, alpha=0.5, drop=(0.15, 9), out_mode=L.OUT_F32,
-                                                                    ln_fwd=(gam, bet, hy, st, 1e-5, L.ACT_NONE))))
-print(f"  {'NT 1024->256 + bias + dropout + fp32 residual + LayerNorm':66s} {lin:9.1f} {p3:8.1f} {lin + p3:8.1f} {fu:8.1f} {fu / (lin + p3):9.2f}")
+if LNF:
+    fu = T(lambda: ops.gemm(L.GEMM_NT, h, W2, outs, N, d, f, ops.epilogue(bias=b2, res=res32, alpha=0.5, drop=(0.15, 9), out_mode=L.OUT_F32,
+                                                                        ln_fwd=(gam, bet, hy, st, 1e-5, L.ACT_NONE))))
+else:
+    def down_fused():
+        ops.gemm(L.GEMM_NT, h, W2, outs, N, d, f, ops.epilogue(bias=b2, res=res32, alpha=0.5, drop=(0.15, 9), out_mode=L.OUT_F32))
+        ops.layernorm_fwd(outs, gam, bet, 1e-5, True, L.ACT_NONE, out_dtype=torch.bfloat16)
+    fu = T(down_fused)
+print(f"  {f'NT {f}->{d} + bias + dropout + fp32 residual + LayerNorm':66s} {lin:9.1f} {p3:8.1f} {lin + p3:8.1f} {fu:8.1f} {fu / (lin + p3):9.2f}")
 
 # 4) dgrad of the up-projection + LayerNorm backward (+ residual gradient)
 dzu = rnd(N, f).bfloat16()
@@ -84,5 +93,13 @@ p4 = T(lambda: ops.layernorm_bwd(gh, xs, gam, bet, stats, dg, db, dy, L.ACT_NONE
 tr = L.lib().smx_gemm_ln_tile_rows()
 ws = torch.zeros(((N + tr - 1) // tr) * 2 * d, device=dev)
 dxo = torch.empty(N, d, device=dev, dtype=torch.bfloat16)
-fu = T(lambda: ops.gemm(L.GEMM_NN, dzu, W1, dxo, N, d, f, ops.epilogue(res=dy, ln_bwd=(xs, stats, gam, ws, None, None, None, True))))
-print(f"  {'NN 1024->256 + LayerNorm backward (fp32 rows) + residual gradient':66s} {mm:9.1f} {p4:8.1f} {mm + p4:8.1f} {fu:8.1f} {fu / (mm + p4):9.2f}")
+if LNF:
+    fu = T(lambda: ops.gemm(L.GEMM_NN, dzu, W1, dxo, N, d, f, ops.epilogue(res=dy, ln_bwd=(xs, stats, gam, ws, None, None, None, True))))
+else:
+    ghb = torch.empty(N, d, device=dev, dtype=torch.bfloat16)
+
+    def dgrad_fused():
+        ops.gemm(L.GEMM_NN, dzu, W1, ghb, N, d, f)
+        ops.layernorm_bwd(ghb, xs, gam, bet, stats, dg, db, dy, L.ACT_NONE)
+    fu = T(dgrad_fused)
+print(f"  {f'NN {f}->{d} + LayerNorm backward (fp32 rows) + residual gradient':66s} {mm:9.1f} {p4:8.1f} {mm + p4:8.1f} {fu:8.1f} {fu / (mm + p4):9.2f}")
