@@ -725,6 +725,9 @@ def extra_points():
     pts = []
     runs = (("C2b B=64 x T=500 (SURVEY 8d saturating batch)", ["--config", "c2b", "--batch", "64"], {}),
             ("C2a recipe batch B=10 x T=375 (150 s of audio, ...transducer.yaml:116)", ["--config", "c2a", "--batch", "10", "--frames", "375"], {}),
+            ("C2a recipe OPTIMIZER step: 4 micro-batches of 10 x 375 (grad_accumulation_factor 4, ...transducer.yaml:65-66) as one fused "
+             "batch (trainer.fuse_microbatches); ms_per_step is per optimizer step",
+             ["--config", "c2a", "--batch", "10", "--frames", "375", "--grad-accum", "4", "--accum", "fused"], {}),
             ("C2b B=128 x T=500 on the bf16 residual stream (SMX_RESIDUAL=bf16, rounds 1-2)", ["--config", "c2b"], {"SMX_RESIDUAL": "bf16"}))
     for label, extra, env in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "4", "--no-cpu-baseline", "--no-roofline",
