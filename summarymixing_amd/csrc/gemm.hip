@@ -1389,6 +1389,8 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // Round 4, d_model = 512 (M = 512: two column tiles per row panel, so the panel is fetched twice either way): K = 512 .. 1536 on
   // the 128 x 128 tile instead - twice the workgroups per launch - is C5 forward 62.64 -> 61.87 ms, C2a 51.4 -> 51.1, C4 40.9 -> 40.75
   // (SMX_GEMM_WIDE=0 / 1024 / 2048 A/B on one box, twice); K = 2048 is a tie and stays wide.  SMX_GEMM_WIDE=<k >= 2>: that minimum K.
+  // (Also measured and NOT taken: the wide tile for the up-projection shapes M >= 1024 - C5 +0.3 ms, C2a +1.1, C2b +0.7 -, the pipelined
+  //  main loop on the 128 x 128 tile, -DSMX_WIDE_PIPE=2 - C2a +0.6, C5 +2.4, C4 +1.0 -, two register stages, -DSMX_NS_KC=2 - +0.1..0.3.)
   const int wide_env = cfg().gemm_wide;
   const bool wide = wide_env >= 2 ? (p.M == 256 || (p.K >= wide_env && p.M <= 512))     // (experiment: SMX_GEMM_WIDE=<min K>)
                                   : wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 2048 && p.M <= 512));

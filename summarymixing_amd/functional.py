@@ -601,13 +601,13 @@ def _chunk_mean_seqpar(x, out, B, T, chunk, left, reverse=False):
     # chunk sums that cross the shard boundary (forward: from earlier shards; transposed: from later ones)
     src = x4 / den_loc if reverse else x4                     # (transposed: sums of g / den_glob)
     if left is None:
-        tot = SP._all_gather(src.sum((1, 2)))                 # (B, D) per rank
+        tot = SP.all_gather(src.sum((1, 2)))                 # (B, D) per rank
         others = range(r + 1, W) if reverse else range(r)
         add = sum((tot[q] for q in others), torch.zeros_like(tot[0]))
         num += add[:, None, None, :]
     elif left > 0:
         edge = src[:, :left].sum(2) if reverse else src[:, C - left:].sum(2)      # (B, left, D): what the neighbour's windows reach
-        edges = SP._all_gather(edge.contiguous())
+        edges = SP.all_gather(edge.contiguous())
         if reverse and r < W - 1:
             pre = edges[r + 1].cumsum(1)                      # chunks [0, i] of the next shard
             num[:, C - left:] += pre[:, :, None, :]           # local chunk C - left + i reaches the next shard's chunks [0, i]
@@ -641,7 +641,7 @@ def _expdecay_seqpar(x, out, B, T, decay, reverse=False):
     num = torch.empty_like(x3)
     ops.expdecay_mean(x3.view(B * T, -1), num.view(B * T, -1), B, T, decay)
     num *= den_loc
-    ends = SP._all_gather(torch.stack([num[:, T - 1], num[:, 0]]))             # per rank: (f leaving right, g leaving left)
+    ends = SP.all_gather(torch.stack([num[:, T - 1], num[:, 0]]))             # per rank: (f leaving right, g leaving left)
     gT = g ** T
     f_in = torch.zeros_like(ends[0][0])
     for q in range(r):                                                          # f entering = f_{q} + decay^T f entering q

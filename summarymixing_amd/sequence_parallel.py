@@ -95,6 +95,11 @@ def all_reduce_sum(t):
     return t
 
 
+def all_gather(t):
+    """Every rank's copy of a small tensor (list indexed by rank; host-staged under gloo)."""
+    return _all_gather(t)
+
+
 def _all_gather(t):
     w = _State.world
     if _host_staged() and t.is_cuda:
