@@ -517,7 +517,7 @@ def main():
         if world > 1 or force_dist:   # one gradient bucket per encoder layer, reduced as soon as its backward is done
             for layer in enc.transformer.encoder.layers:
                 rng = opt.param_range(list(layer.parameters()))
-                layer._on_bwd_done = (lambda r=rng: opt.reduce_bucket_async(*r) if accum["last"] else None)
+                layer._on_bwd_done = (lambda r=rng: opt.reduce_bucket_async(*r))
     else:
         enc.eval()
     G = max(1, args.grad_accum)
@@ -528,7 +528,6 @@ def main():
         src_f, wl_f = fuse_microbatches([(m[0], m[1]) for m in micro])
         micro = [(src_f, wl_f, torch.cat([m[2] for m in micro]), valid_frames)]
     src, wav_len, r = micro[0][:3]
-    accum = {"last": True}
     enc_kw = {}
     if args.dynchunk:
         from summarymixing_amd.utils.dynamic_chunk_training import DynChunkTrainConfig
@@ -536,11 +535,13 @@ def main():
         enc_kw["dynchunktrain_config"] = DynChunkTrainConfig(parts[0], parts[1] if len(parts) > 1 else None)
 
     def fwd_bwd_all():
-        # (gradient accumulation: the kernels ADD into the flat gradient buffer; the bucket hooks fire on the last micro-batch)
+        # (gradient accumulation: the kernels ADD into the flat gradient buffer; the bucket hooks fire on the last micro-batch only)
         opt.zero_grad()
-        for g, (s_, wl_, r_, _) in enumerate(micro):
-            accum["last"] = g == len(micro) - 1
-            enc(s_, wl_, **enc_kw).backward(r_)
+        with opt.no_sync():
+            for s_, wl_, r_, _ in micro[:-1]:
+                enc(s_, wl_, **enc_kw).backward(r_)
+        s_, wl_, r_, _ = micro[-1]
+        enc(s_, wl_, **enc_kw).backward(r_)
 
     def step():
         if train:

@@ -22,6 +22,7 @@ its cost is the bytes on the wire):
                       clip and AdamW stay fp32).
 comm_exposed_ms() reports how long the compute stream stood waiting for the collectives (bench.py prints it).
 """
+import contextlib
 import os
 
 import torch
@@ -149,6 +150,7 @@ class FlatAdamW:
             self._shard_p = torch.zeros(total // self.world, dtype=torch.float32, device=dev)
             self._shard_c = torch.zeros(total // self.world, dtype=torch.bfloat16, device=dev) if self._comm is not None else None
         self._reduced = []            # bucket ranges whose collective was launched in this step (rs_ag: the shards to update)
+        self._no_sync = False         # inside no_sync(): bucket hooks launch nothing (gradient accumulation)
         self._shard_layout = None     # rs_ag: the bucket ranges of the first sharded update (= who owns which moment elements)
         self._measure, self._exposed = False, []
         # buckets: list of (start, end) element ranges of the flat buffers, in backward-completion order
@@ -238,7 +240,7 @@ class FlatAdamW:
     def reduce_bucket_async(self, start, end):
         """Launch the collective of one gradient bucket (called right after its producer's backward): an all-reduce, or -
         reduce="rs_ag" - a reduce-scatter that leaves this rank's 1/world shard of the summed bucket in the shard buffer."""
-        if not self._collective:
+        if not self._collective or self._no_sync:
             return
         W = self.world
         assert (end - start) % W == 0, "bucket length must divide by the world size"
@@ -253,6 +255,23 @@ class FlatAdamW:
             work = dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._pending.append(work)
         self._reduced.append((start, end))
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation under data parallelism (the role of torch DDP's no_sync; the reference's fit_batch wraps the
+        first grad_accumulation_factor - 1 micro-batches in it, core.py): inside, the bucket hooks launch NO collective - the
+        kernels keep adding into the flat gradient buffer - and the micro-batch that runs outside reduces the accumulated sums.
+
+            opt.zero_grad()
+            with opt.no_sync():
+                for x in micro[:-1]: model(x).backward(...)
+            model(micro[-1]).backward(...)      # bucket hooks fire here
+            opt.step()"""
+        prev, self._no_sync = self._no_sync, True
+        try:
+            yield
+        finally:
+            self._no_sync = prev
 
     def _finish_reduce(self):
         """Wait for the launched collectives (the compute stream waits, not the host) and bring bf16 results back to fp32."""

@@ -119,6 +119,73 @@ def test_dp2_gradient_equivalence_and_update(tmp_path):
     torch.testing.assert_close(got["params"], opt.flat_p, rtol=1e-4, atol=5e-5)
 
 
+def _worker_accum(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from summarymixing_amd.trainer import FlatAdamW
+
+        class Opt(_CpuUpdate, FlatAdamW):
+            pass
+        enc = _model()
+        opt = Opt(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=torch.float32)
+        ranges = [opt.param_range(list(l.parameters())) for l in enc.layers]
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(4, 9, 16, generator=g)
+        R = torch.randn(4, 9, 16, generator=g)
+        lens = torch.tensor([9, 5, 7, 9])
+        pad = torch.arange(9)[None] < lens[:, None]
+
+        def hooks():                                              # what the block hooks + bench.py's tail do per backward pass
+            for a, b in reversed(ranges):
+                opt.reduce_bucket_async(a, b)
+            opt.reduce_bucket_async(ranges[-1][1], opt.total)
+        opt.zero_grad()
+        with opt.no_sync():                                       # micro-batch 1 of this rank's shard: nothing on the wire
+            i = rank * 2
+            _oracle_grads_into(enc, X[i:i + 1], pad[i:i + 1], R[i:i + 1])
+            hooks()
+            assert not opt._pending and not opt._reduced
+        _oracle_grads_into(enc, X[i + 1:i + 2], pad[i + 1:i + 2], R[i + 1:i + 2])
+        hooks()                                                   # micro-batch 2: the accumulated sums are reduced
+        assert len(opt._pending) == len(ranges) + 1
+        for w in opt._pending:
+            w.wait()
+        summed = opt.flat_g.clone()
+        opt.step()
+        if rank == 0:
+            torch.save({"summed": summed, "params": opt.flat_p.clone()}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp2_gradient_accumulation_under_no_sync(tmp_path):
+    """FlatAdamW.no_sync(): two micro-batches per rank, collectives only behind the second; the reduced gradients are the
+    full-batch gradients (the role of DDP's no_sync in the reference's fit_batch with grad_accumulation_factor > 1)."""
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_accum, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    from summarymixing_amd.trainer import FlatAdamW
+
+    class Opt(_CpuUpdate, FlatAdamW):
+        pass
+    enc = _model()
+    opt = Opt(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=torch.float32)
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(4, 9, 16, generator=g)
+    R = torch.randn(4, 9, 16, generator=g)
+    lens = torch.tensor([9, 5, 7, 9])
+    pad = torch.arange(9)[None] < lens[:, None]
+    opt.zero_grad()
+    for i in range(4):           # (one utterance at a time: the conv module's edge frames see the padding of their own micro-batch)
+        _oracle_grads_into(enc, X[i:i + 1], pad[i:i + 1], R[i:i + 1])
+    torch.testing.assert_close(got["summed"], opt.flat_g, rtol=1e-5, atol=1e-6)
+    opt.flat_g.mul_(0.5)
+    opt.step()
+    torch.testing.assert_close(got["params"], opt.flat_p, rtol=1e-4, atol=5e-5)
+
+
 def test_flat_views_alias_parameters():
     from summarymixing_amd.trainer import FlatAdamW
 

@@ -88,7 +88,20 @@ opt = FlatAdamW(enc, lr=1e-2, max_grad_norm=5.0, compute_dtype=dtype, reduce=red
 assert opt.world == world and opt._collective
 hooks(enc, opt)
 sl = slice(rank * B // world, (rank + 1) * B // world)            # this rank's utterances
-one_step(enc, opt, X[sl].to(dtype), PAD[sl], R[sl].to(dtype), True)
+if os.environ.get("SMX_ACCUM") == "1":
+    # gradient accumulation: the rank's shard as two micro-batches of one utterance, bucket hooks silent inside no_sync()
+    xs, ps, rs = X[sl].to(dtype), PAD[sl], R[sl].to(dtype)
+    opt.zero_grad()
+    with opt.no_sync():
+        y, _ = enc(xs[:1], src_key_padding_mask=ps[:1])
+        y.backward(rs[:1])
+        assert not opt._pending and not opt._reduced, "a collective was launched inside no_sync()"
+    y, _ = enc(xs[1:], src_key_padding_mask=ps[1:])
+    y.backward(rs[1:])
+    tail(enc, opt)
+    opt.step()
+else:
+    one_step(enc, opt, X[sl].to(dtype), PAD[sl], R[sl].to(dtype), True)
 
 def close(a, b, what, tol):
     err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
@@ -225,6 +238,14 @@ def _launch(script, world, extra):
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_two_ranks_hip_backward_through_buckets_equals_single_process(dtype):
     _launch(DP_WORKER, 2, {"SMX_DTYPE": dtype})
+
+
+@pytest.mark.parametrize("reduce", ["allreduce", "rs_ag"])
+def test_two_ranks_gradient_accumulation_under_no_sync(reduce):
+    """Gradient accumulation under data parallelism (FlatAdamW.no_sync, the role of DDP's no_sync in the reference's fit_batch):
+    every rank runs its shard as two micro-batches, the bucket hooks launch nothing during the first and reduce the accumulated
+    sums behind the second; gradients and updated weights equal the single-process step on the whole batch."""
+    _launch(DP_WORKER, 2, {"SMX_DTYPE": "fp32", "SMX_REDUCE": reduce, "SMX_ACCUM": "1"})
 
 
 @pytest.mark.parametrize("reduce,grad_dtype", [("rs_ag", "fp32"), ("allreduce", "bf16"), ("rs_ag", "bf16")])
