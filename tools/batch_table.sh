@@ -9,3 +9,5 @@ echo "# C2a (12 L, d_model 512), the recipe's 150 s batch and single utterances"
 one --config c2a --batch 10 --frames 375
 one --config c2a --batch 1 --frames 375
 one --config c2a --mode forward --batch 1 --frames 375
+echo "# the recipe's optimizer step: grad_accumulation_factor micro-batches of 10 x 375, accumulated one after the other / fused into one batch"
+for g in 2 4 8; do one --config c2a --batch 10 --frames 375 --grad-accum $g --accum sequential; one --config c2a --batch 10 --frames 375 --grad-accum $g --accum fused; done
