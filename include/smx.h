@@ -270,6 +270,13 @@ int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const float* gamma,
  * backward with a float32 X (dY, R, dX, dX2 dtype `dtype`): torch.nn.LayerNorm under autocast. */
 int smx_layernorm_fwd_x32(int dtype, const float* X, int64_t ldx, const float* gamma, const float* beta, void* Y,
                           int64_t ldy, float* stats, int N, int D, float eps, int act, void* stream);
+/* Two LayerNorms in ONE pass over the float32 residual stream: Y1 = LN1(X) (float32: the layer-final norm2, Conformer.py:536 -
+ * the next layer's stream input) and Y2 = LN2(Y1) (dtype2: the LayerNorm of the next layer's first feed-forward module,
+ * Conformer.py:458-459,507); stats1 / stats2 (N,2) = (mean, rstd), optional.  Equal to smx_layernorm_fwd (fp32) followed by
+ * smx_layernorm_fwd_x32 to an ulp; Y1 is not re-read and is stored with the non-temporal hint.  D % 4 == 0, D <= 2048, 16-byte aligned rows (SMX_EUNSUPPORTED otherwise). */
+int smx_layernorm_fwd_pair_x32(int dtype2, const float* X, int64_t ldx, const float* gamma1, const float* beta1, float eps1,
+                               float* Y1, int64_t ldy1, float* stats1, const float* gamma2, const float* beta2, float eps2,
+                               void* Y2, int64_t ldy2, float* stats2, int N, int D, void* stream);
 size_t smx_layernorm_bwd_workspace(int N, int D);
 int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const void* X, int64_t ldx, const float* gamma,
                       const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,

@@ -94,6 +94,7 @@ SIGNATURES = {
     "smx_expdecay_mean_bwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_f, c_vp, c_vp]),
     "smx_layernorm_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
     "smx_layernorm_fwd_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i, c_i, c_f, c_i, c_vp]),
+    "smx_layernorm_fwd_pair_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_f, c_vp, c_i64, c_vp, c_vp, c_vp, c_f, c_vp, c_i64, c_vp, c_i, c_i, c_vp]),
     "smx_layernorm_bwd2_x32": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
                                      c_vp, c_i, c_i, c_vp, c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_layernorm_bwd_preact": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_i, c_vp, c_i64,

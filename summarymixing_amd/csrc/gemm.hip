@@ -1547,6 +1547,13 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   const long nt_bytes = cfg().nt_bytes;
   const int nt_z = cfg().nt_z;
   p.nt = (nt_z ? 1 : 0) | (((long)N * M * (long)cs * batch >= nt_bytes) ? 2 : 0);
+#ifndef SMX_LNF_NT
+#define SMX_LNF_NT 1
+#endif
+  // With a LayerNorm appended (SMX_EPI_LN_FWD) the next kernel reads the LayerNorm output, not C: C (the float32 stream tensor, or
+  // the pre-norm tensor the backward pass wants) is streamed whatever its size, so that it does not push the LayerNorm output out
+  // of the Infinity Cache (the same finding as smx_layernorm_fwd_pair_x32, rowwise.hip).
+  if (SMX_LNF_NT && (p.e.flags & SMX_EPI_LN_FWD)) p.nt |= 2;
   // register-domain epilogue (gemm_kernel): 0 off, 1 every eligible epilogue, 2 (default) only without a saved Z - measured
   // at 64000 frames: bias-only K=256 -> M=1024 102 -> 77 us, NN+bias 91 -> 71 us, but bias+Swish+Z 99 -> 99 us; training
   // steps unchanged with either setting, forward-only steps -2 % (C2b) / -4 % (C5)

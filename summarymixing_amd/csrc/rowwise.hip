@@ -561,6 +561,107 @@ __global__ __launch_bounds__(256) void layernorm_fwd_fast(const TX* __restrict__
   });
 }
 
+// Two LayerNorms in one pass over the float32 residual stream (round 4): y1 = LN1(x) (float32: the layer-final norm2 of
+// a Conformer layer, Conformer.py:536 = the next layer's stream input) and y2 = LN2(y1) (dtype T2: the LayerNorm in front of
+// the next layer's first feed-forward module, Conformer.py:458-459,507).  y1 never comes back from memory for the second
+// statistics.  Same lane / chunk layout and the same reduction trees as layernorm_fwd_fast, so both outputs equal those of
+// two separate launches to an ulp.
+template <typename T2, int CH, int U>
+__global__ __launch_bounds__(256) void layernorm_fwd_pair_fast(const float* __restrict__ X, long ldx, const float* __restrict__ gamma1,
+                                                               const float* __restrict__ beta1, float eps1, float* __restrict__ Y1,
+                                                               long ldy1, float* __restrict__ stats1,
+                                                               const float* __restrict__ gamma2, const float* __restrict__ beta2,
+                                                               float eps2, T2* __restrict__ Y2, long ldy2, float* __restrict__ stats2,
+                                                               int N_, int D) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float g1[CH][4], b1[CH][4], g2[CH][4], b2[CH][4];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = (lane + 64 * i) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g1[i][j] = b1[i][j] = g2[i][j] = b2[i][j] = 0.f;
+    if (c < D) {
+      load4<float>(gamma1 + c, g1[i]); load4<float>(beta1 + c, b1[i]);
+      load4<float>(gamma2 + c, g2[i]); load4<float>(beta2 + c, b2[i]);
+    }
+  }
+  const float invD = 1.f / (float)D;
+  auto row_sum = [&](float (&v)[U]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] += __shfl_xor(v[u], off, 64);
+  };
+  for (int row0 = (blockIdx.x * 4 + w) * U; row0 < N_; row0 += gridDim.x * 4 * U) {
+    float f[U][CH][4], s[U], q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = min(row0 + u, N_ - 1);
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < D) load4<float>(X + (long)row * ldx + c, f[u][i]);
+        else f[u][i][0] = f[u][i][1] = f[u][i][2] = f[u][i][3] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {               // pass 0: LN1 (f <- y1, stored), pass 1: LN2 of the registers
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        s[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) s[u] += (f[u][i][0] + f[u][i][1]) + (f[u][i][2] + f[u][i][3]);
+      }
+      row_sum(s);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        s[u] *= invD;
+        q[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          if ((lane + 64 * i) * 4 < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = f[u][i][j] - s[u]; q[u] += d * d; }
+          }
+        }
+      }
+      row_sum(q);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + u;
+        const bool live = row < N_;
+        const float rstd = rsqrtf(q[u] * invD + (pass == 0 ? eps1 : eps2));
+        float* st = pass == 0 ? stats1 : stats2;
+        if (live && st && lane == 0) *reinterpret_cast<float2*>(st + 2 * (long)row) = make_float2(s[u], rstd);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int c = (lane + 64 * i) * 4;
+          if (c < D) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              o[j] = (f[u][i][j] - s[u]) * rstd * (pass == 0 ? g1[i][j] : g2[i][j]) + (pass == 0 ? b1[i][j] : b2[i][j]);
+            if (pass == 0) {
+              if (live) {
+                // non-temporal: the stream tensor is next read by a residual epilogue several kernels later, Y2 by the very next
+                // GEMM - with an ordinary store the 131 MB of Y1 pushed Y2 out of the 256 MB Infinity Cache at 64000 x 512
+                // (that GEMM 220 -> 257 us, the C2a step +0.35 ms; with the hint -0.35 ms against two launches)
+                typedef uint32_t u32x4n __attribute__((ext_vector_type(4)));
+                u32x4n uu = {__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])};
+                __builtin_nontemporal_store(uu, reinterpret_cast<u32x4n*>(Y1 + (long)row * ldy1 + c));
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) f[u][i][j] = o[j];
+            } else if (live) {
+              store4<T2>(Y2 + (long)row * ldy2 + c, o);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // bwd: dx = R + rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*act'(LN(x))*gamma.  Blocks stride over rows;
 // gamma/beta of the lane's columns live in registers for the whole kernel, U rows are in flight per wave (all
 // their loads issued before any reduction), dgamma/dbeta partial sums stay in registers until one atomic flush.
@@ -1588,6 +1689,28 @@ extern "C" int smx_layernorm_fwd_x32(int dtype, const float* X, int64_t ldx, con
   if (ch <= 1) LN_FWDX(1, 4); else if (ch <= 2) LN_FWDX(2, 2); else if (ch <= 4) LN_FWDX(4, 1); else LN_FWDX(8, 1);
 #undef LN_FWDX
   return check_launch("smx_layernorm_fwd_x32");
+}
+
+extern "C" int smx_layernorm_fwd_pair_x32(int dtype2, const float* X, int64_t ldx, const float* gamma1, const float* beta1, float eps1,
+                                          float* Y1, int64_t ldy1, float* stats1, const float* gamma2, const float* beta2,
+                                          float eps2, void* Y2, int64_t ldy2, float* stats2, int N, int D, void* stream) {
+  SMX_REQUIRE(X && Y1 && Y2 && gamma1 && beta1 && gamma2 && beta2 && N >= 0 && D > 0, "smx_layernorm_fwd_pair_x32: bad arguments");
+  SMX_REQUIRE(dtype2 == SMX_BF16 || dtype2 == SMX_F32, "smx_layernorm_fwd_pair_x32: bad dtype");
+  if (N == 0) return SMX_OK;
+  const bool vec = D % 4 == 0 && D <= 2048 && aligned16(X) && ldx % 4 == 0 && aligned16(Y1) && ldy1 % 4 == 0 &&
+                   (dtype2 == SMX_BF16 ? aligned8(Y2) : aligned16(Y2)) && ldy2 % 4 == 0 && aligned16(gamma1) && aligned16(beta1) &&
+                   aligned16(gamma2) && aligned16(beta2);
+  if (!vec) return fail(SMX_EUNSUPPORTED, "smx_layernorm_fwd_pair_x32: needs D %% 4 == 0, D <= 2048 and aligned rows");
+  const int ch = (D + 255) / 256;
+  const int U = ch <= 1 ? 4 : (ch <= 2 ? 2 : 1);          // (the launch geometry of layernorm_fwd_fast: bit-identical sums)
+  int blocks = (N + 4 * U - 1) / (4 * U);
+  if (blocks > 2048) blocks = 2048;
+#define LN_PAIR(TT, CH_, U_) hipLaunchKernelGGL((layernorm_fwd_pair_fast<TT, CH_, U_>), dim3(blocks), dim3(256), 0, STREAM, X, ldx, gamma1, beta1, eps1, Y1, ldy1, stats1, gamma2, beta2, eps2, (TT*)Y2, ldy2, stats2, N, D)
+#define LN_PAIR_T(TT) do { if (ch <= 1) LN_PAIR(TT, 1, 4); else if (ch <= 2) LN_PAIR(TT, 2, 2); else if (ch <= 4) LN_PAIR(TT, 4, 1); else LN_PAIR(TT, 8, 1); } while (0)
+  if (dtype2 == SMX_BF16) LN_PAIR_T(bf16_t); else LN_PAIR_T(float);
+#undef LN_PAIR_T
+#undef LN_PAIR
+  return check_launch("smx_layernorm_fwd_pair_x32");
 }
 
 #ifndef SMX_LNB_BLOCKS

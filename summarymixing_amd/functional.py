@@ -380,6 +380,9 @@ _LN_FUSE = os.environ.get("SMX_LN_FUSE", "1") != "0"   # A/B knob: LayerNorm bac
 # against 76 us at 64 000.  Measured on the C2b step (fused / separate kernels, ms): B = 16: 8.30 / 5.97, 32: 9.77 / 8.15,
 # 48: 11.33 / 10.63, 64: 12.97 / 12.56, 80: 15.20 / 15.74, 96: 16.52 / 17.49, 128: 19.11 / 20.24 -> fuse from 36 864 rows.
 _LN_FUSE_MIN_ROWS = int(os.environ.get("SMX_LN_FUSE_MIN_ROWS", "36864"))
+# norm2 of a Conformer layer + the first LayerNorm of the next layer in ONE pass over the float32 stream (smx_layernorm_fwd_pair_x32;
+# SMX_LN_PAIR=0: two launches - the A/B switch of round 4)
+_LN_PAIR = os.environ.get("SMX_LN_PAIR", "1") != "0"
 
 
 def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
@@ -1224,8 +1227,15 @@ def encoder_stack(src, layers, make_layer_run, norm, params, compute_dtype=None)
         if x.dtype != stream:
             x = ops.cast(ops.rows2d(x), stream).view(B, T, d)
         bwds = []
-        for layer in layers:
-            x, b = make_layer_run(layer, compute)(x, need)
+        pair = _LN_PAIR and make_layer_run.__code__.co_argcount >= 3     # (the Conformer stack: norm2 + the next layer's first LayerNorm)
+        pre = None
+        for i, layer in enumerate(layers):
+            if pair:
+                r = make_layer_run(layer, compute, layers[i + 1] if i + 1 < len(layers) else None)
+                x, b = r(x, need, pre_ln=pre)
+                pre = getattr(r, "post_next", None)
+            else:
+                x, b = make_layer_run(layer, compute)(x, need)
             bwds.append((b, getattr(layer, "_on_bwd_done", None)))
         y, bn = ln_fwd(ops.rows2d(x), norm.weight, norm.bias, norm.eps, need, out_dtype=compute)
         if not need:

@@ -108,9 +108,12 @@ class ConformerEncoderLayer(nn.Module):
         self.norm2 = _LayerNorm(d_model)
         self.drop = nn.Dropout(dropout)
 
-    def make_run(self, B, T, m8, src_mask, chunk, compute_dtype=None):
+    def make_run(self, B, T, m8, src_mask, chunk, compute_dtype=None, next_layer=None):
         """compute_dtype: dtype of the GEMM operands when the incoming stream x3 is the float32 residual stream of a bf16
-        model (functional.RESIDUAL_F32); None = everything in x3.dtype."""
+        model (functional.RESIDUAL_F32); None = everything in x3.dtype.
+        next_layer: the layer that consumes this one's output inside an encoder stack.  Its first LayerNorm (ffn_module1's) then
+        runs in the same pass as this layer's norm2 where the shapes allow (ops.layernorm_fwd_pair: one read of the float32 stream
+        for both); `run.post_next` = (LN(y), stats) | None is what the stack hands to the next layer's run as `pre_ln`."""
         d_act = self.act
         P1, P2 = _ffn_params(self.ffn_module1), _ffn_params(self.ffn_module2)
         Pc = self.convolution_module.params()
@@ -119,12 +122,15 @@ class ConformerEncoderLayer(nn.Module):
         cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask,
                           self.mha_layer.global_dropout if self.training else 0.0)
 
-        def run(x3, need):
+        Pn = _ffn_params(next_layer.ffn_module1) if next_layer is not None else None
+
+        def run(x3, need, pre_ln=None):
             dtype = compute_dtype or x3.dtype
             x = ops.rows2d(x3)
+            run.post_next = None
             # every LayerNorm that follows a Linear of width d_model = 256 runs in that GEMM's epilogue (`post` = its output and
             # statistics, None when the shape does not qualify and the consumer runs the LayerNorm kernel itself)
-            y1, b1, post1 = F.ffn_module_fwd(x, P1, d_act, need, dtype, p=pd, ln_next=(n1.weight, n1.bias, n1.eps))   # :507
+            y1, b1, post1 = F.ffn_module_fwd(x, P1, d_act, need, dtype, p=pd, pre_ln=pre_ln, ln_next=(n1.weight, n1.bias, n1.eps))   # :507
             h, bn1 = F.ln_fwd(y1, n1.weight, n1.bias, n1.eps, need, pre=post1, out_dtype=dtype)         # :510
             y2_3, bcell, post2 = cell(h.view(B, T, -1), need, res=y1, ln_next=(Pc["ln1_w"], Pc["ln1_b"], 1e-5))   # :512-530
             y2 = ops.rows2d(y2_3)
@@ -132,6 +138,11 @@ class ConformerEncoderLayer(nn.Module):
                                                  ln_next=(P2["ln_w"], P2["ln_b"], 1e-5))                          # :532-534
             # (norm2's output is the layer output = the next layer's residual stream: stream dtype, 4th element of ln_next)
             y4, bf2, post4 = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd, pre_ln=post3, ln_next=(n2.weight, n2.bias, n2.eps, True))
+            if post4 is None and Pn is not None and y4.dtype != dtype and ops.layernorm_pair_ok(y4, dtype):
+                # norm2 and the next layer's first LayerNorm in one pass over the float32 stream (equal to two launches to an ulp)
+                y5_, st1, hn, st2 = ops.layernorm_fwd_pair(y4, n2.weight.detach(), n2.bias.detach(), n2.eps, Pn["ln_w"].detach(),
+                                                           Pn["ln_b"].detach(), 1e-5, need, dtype)
+                post4, run.post_next = (y5_, st1), (hn, st2)
             y5, bn2 = F.ln_fwd(y4, n2.weight, n2.bias, n2.eps, need, pre=post4)        # :536
             if not need:
                 return y5.view(B, T, -1), None
@@ -208,6 +219,6 @@ class ConformerEncoder(nn.Module):
         chunk = dynchunktrain_config.chunk_size if dynchunktrain_config is not None else 0
         # compute dtype: what the caller says (TransformerASR.encode hands over the float32 stream of a bf16 model), else the input's
         out = F.encoder_stack(src, list(self.layers),
-                              lambda layer, compute: layer.make_run(B, T, m8, src_mask, chunk, compute_dtype=compute),
+                              lambda layer, compute, nxt=None: layer.make_run(B, T, m8, src_mask, chunk, compute_dtype=compute, next_layer=nxt),
                               self.norm.norm, list(self.parameters()), _compute_dtype)
         return out, [None] * len(self.layers)

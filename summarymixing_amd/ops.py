@@ -346,6 +346,28 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE, out_dtype=Non
     return y, stats
 
 
+def layernorm_pair_ok(x, out_dtype):
+    """Can smx_layernorm_fwd_pair_x32 take this float32 stream tensor?"""
+    return (x.dtype == torch.float32 and x.is_cuda and x.shape[1] % 4 == 0 and x.shape[1] <= 2048 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and out_dtype in (torch.bfloat16, torch.float32))
+
+
+def layernorm_fwd_pair(x, gamma1, beta1, eps1, gamma2, beta2, eps2, want_stats, out_dtype):
+    """(y1, stats1, y2, stats2): y1 = LN1(x) float32, y2 = LN2(y1) in out_dtype, one pass over the float32 stream x
+    (smx_layernorm_fwd_pair_x32: the layer-final norm2 + the next layer's first LayerNorm)."""
+    N, D = x.shape
+    y1 = torch.empty((N, D), dtype=torch.float32, device=x.device)
+    y2 = torch.empty((N, D), dtype=out_dtype, device=x.device)
+    st1 = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    st2 = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    px, ldx = _mat(x)
+    tok = _pb(f"layernorm_fwd_pair ({N}x{D})", N * D * (4 + 4 + _es(y2)))
+    L.check(L.lib().smx_layernorm_fwd_pair_x32(dt(y2), px, ldx, _p(gamma1), _p(beta1), eps1, _p(y1), D, _p(st1), _p(gamma2), _p(beta2),
+                                               eps2, _p(y2), D, _p(st2), N, D, _stream()), "smx_layernorm_fwd_pair_x32")
+    _pe(tok)
+    return y1, st1, y2, st2
+
+
 def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE, ws=None, dx_out=None, second=None):
     """ws: caller-owned workspace; with dgamma = dbeta = None the partial rows stay in it for a deferred reduce_jobs.
     dx_out: optional (N, D) destination view (e.g. a column slice of a wider buffer).

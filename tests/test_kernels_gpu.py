@@ -749,3 +749,27 @@ def test_chunked_dwconv_backward_is_bit_reproducible(chunk, D, k):
     y1 = ops.dwconv_fwd(p, w, bias, B, T, D, k, True, L.PAD_ZERO, chunk).clone()
     y2 = ops.dwconv_fwd(p, w, bias, B, T, D, k, True, L.PAD_ZERO, chunk)
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("N,D", [(1, 64), (37, 144), (1000, 256), (3750, 512), (513, 1024), (70, 2048)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_layernorm_pair_equals_two_launches(N, D, out_dtype):
+    """smx_layernorm_fwd_pair_x32 (norm2 of a Conformer layer + the next layer's first LayerNorm, Conformer.py:536 + :458-459, in one
+    pass over the float32 stream) against smx_layernorm_fwd followed by smx_layernorm_fwd_x32 (outputs and statistics to an ulp)
+    and against torch's LayerNorm."""
+    from summarymixing_amd import ops
+    torch.manual_seed(N + D)
+    x = (torch.randn(N, D, device="cuda") * 3 + 0.7)
+    g1, b1 = torch.randn(D, device="cuda") * 0.3 + 1, torch.randn(D, device="cuda") * 0.2
+    g2, b2 = torch.randn(D, device="cuda") * 0.3 + 1, torch.randn(D, device="cuda") * 0.2
+    assert ops.layernorm_pair_ok(x, out_dtype)
+    y1, s1, y2, s2 = ops.layernorm_fwd_pair(x, g1, b1, 1e-5, g2, b2, 1e-6, True, out_dtype)
+    r1, t1 = ops.layernorm_fwd(x, g1, b1, 1e-5, True)
+    r2, t2 = ops.layernorm_fwd(r1, g2, b2, 1e-6, True, out_dtype=out_dtype)
+    # (the two code paths contract their multiply-adds differently under -ffast-math: equal to an ulp, not bit for bit)
+    assert rel_err(y1, r1) < 1e-6 and rel_err(s1, t1) < 1e-6 and rel_err(s2, t2) < 1e-6
+    assert rel_err(y2, r2) < (1e-6 if out_dtype == torch.float32 else 2.0 ** -7)
+    ref1 = torch.nn.functional.layer_norm(x.double(), (D,), g1.double(), b1.double(), 1e-5)
+    ref2 = torch.nn.functional.layer_norm(ref1, (D,), g2.double(), b2.double(), 1e-6)
+    assert rel_err(y1, ref1) < 1e-5
+    assert rel_err(y2, ref2) < (1e-5 if out_dtype == torch.float32 else 8e-3)
