@@ -50,6 +50,8 @@ struct WgGroupParams {
   long long* dbg;       // debug (smx_debug_set_timing_buffer): per workgroup [total cycles, cycles in wait+barrier, realtime ticks, niter]
 };
 
+// (round 4: the `nt` hint on this load - operand rows streamed past the caches so that the slabs survive for smx_reduce_jobs - was
+//  measured: C2b step -0.08 ms, C2a +1.0 ms (its tiles re-read the row panels through L2) and some small shapes 20x slower: not taken)
 __device__ __forceinline__ void wg_glds16(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
