@@ -324,3 +324,42 @@ def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch):
         if e > worst[1]:
             worst = (n, e)
     assert worst[1] <= 3e-2, worst
+
+
+@pytest.mark.parametrize("d", [144, 512])
+def test_layernorm_pair_in_the_stack_equals_two_launches(d, monkeypatch):
+    """ConformerEncoder on the float32 stream: norm2 + the next layer's first LayerNorm in one launch (functional._LN_PAIR,
+    smx_layernorm_fwd_pair_x32) against the two-launch path - outputs, dL/dx and every parameter gradient (the two paths differ
+    by an ulp of the LayerNorm outputs)."""
+    from summarymixing_amd import functional as F
+    from summarymixing_amd import ops
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(d)
+    B, T = 3, 70
+    enc = ConformerEncoder(3, d, 2 * d, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast").cuda()
+    x = torch.randn(B, T, d, device="cuda").bfloat16()
+    r = torch.randn(B, T, d, device="cuda").bfloat16()
+    pad = (torch.arange(T)[None] < torch.tensor([T, 41, 63])[:, None]).cuda()
+    calls = []
+    real = ops.layernorm_fwd_pair
+    monkeypatch.setattr(ops, "layernorm_fwd_pair", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def run(pair):
+        monkeypatch.setattr(F, "_LN_PAIR", pair)
+        for p in enc.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        y, _ = enc(xg, src_key_padding_mask=pad)
+        (y * r).sum().backward()
+        F.flush_deferred()
+        F.join_side()
+        torch.cuda.synchronize()
+        return y.detach().float(), xg.grad.float(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    y1, g1, p1 = run(True)
+    assert len(calls) == 2, "two layer boundaries of a 3-layer stack take the pair kernel"
+    y0, g0, p0 = run(False)
+    assert len(calls) == 2
+    assert rel_err(y1, y0) < 1e-2 and rel_err(g1, g0) < 2e-2
+    for n in p0:
+        assert rel_err(p1[n], p0[n]) < 2e-2, n
