@@ -13,7 +13,6 @@ from .. import _lib as L
 from .. import ops
 
 
-import os
 _FOLDED_DFT = True              # A/B knob: cosine / sine halves of half the length
 _IMPLICIT_FRAMES = True   # A/B knob: the DFT GEMM reads the waveform in place
 

@@ -6,7 +6,6 @@ views ``(rows, cols)`` with unit stride along cols; the row stride is the leadin
 """
 import ctypes
 
-import os
 
 import torch
 
