@@ -53,7 +53,7 @@ typedef struct smx_config {
   int32_t tn_dma;           /* SMX_TN_DMA: wgrad (TN) GEMM on the LDS-DMA ring (1)                           */
   int32_t nt_z;             /* SMX_NT_Z: non-temporal stores for saved pre-activations (1)                   */
   int64_t nt_bytes;         /* SMX_NT_BYTES: outputs at least this large are streamed past the caches (96 MB) */
-  int32_t reg_epi;          /* SMX_REG_EPI: register-domain epilogue 0 off, 1 always, 2 without a saved Z (2) */
+  int32_t reg_epi;          /* SMX_REG_EPI: register-domain epilogue 0 off, 1 always, 2 without a saved Z (0) */
   int32_t epi_simple;       /* SMX_EPI_SIMPLE: specialised epilogue instantiations 0 / 1 / 2 (2)             */
   int32_t wgrad_blocks;     /* SMX_WGRAD_BLOCKS: workgroup target of the per-weight wgrad (0 = 384)          */
   int32_t wgrad_min_rows;   /* SMX_WGRAD_MIN_ROWS: frames per split-K slice at least (0 = 512)               */

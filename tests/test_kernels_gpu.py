@@ -773,3 +773,37 @@ def test_layernorm_pair_equals_two_launches(N, D, out_dtype):
     ref2 = torch.nn.functional.layer_norm(ref1, (D,), g2.double(), b2.double(), 1e-6)
     assert rel_err(y1, ref1) < 1e-5
     assert rel_err(y2, ref2) < (1e-5 if out_dtype == torch.float32 else 8e-3)
+
+
+def test_register_epilogue_opt_in_still_matches():
+    """SMX_REG_EPI=1 (the register-domain epilogue, default of rounds 2-3, off since round 4) is read once per process: a child
+    process runs side-input-free GEMMs through it against a float64 reference."""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["SMX_ROOT"])
+from summarymixing_amd import _lib as L, ops
+assert L.get_config()["reg_epi"] == 1
+torch.manual_seed(0)
+for N, K, M in ((1000, 256, 512), (4096, 512, 256), (333, 1024, 1024)):
+    x = torch.randn(N, K, device="cuda").bfloat16()
+    w = (torch.randn(M, K, device="cuda") * 0.05).bfloat16()
+    b = torch.randn(M, device="cuda")
+    y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH))
+    ref = torch.nn.functional.silu(x.double() @ w.double().t() + b.double())
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, (N, K, M, err)
+    wn = (torch.randn(K, M, device="cuda") * 0.05).bfloat16()
+    ops.gemm(L.GEMM_NN, x, wn, y, N, M, K)
+    ref = x.double() @ wn.double()
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, (N, K, M, err)
+print("OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SMX_REG_EPI="1", SMX_ROOT=root), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
