@@ -100,7 +100,11 @@ class _Deferred:
     side_pending = set()   # keys whose workspaces an ASYNCHRONOUS flush may still be reading on the side stream (until join_side)
     ws = {}          # key -> persistent uint8 workspace
     cache = {}       # tuple(jobs) -> (jobs_dev, starts_dev, njobs, total_blocks)
-    side_enabled = os.environ.get("SMX_WGRAD_STREAM", "1") != "0"
+    # SMX_WGRAD_STREAM=1: slab GEMMs (and, with SMX_WGRAD_ASYNC, the whole weight-gradient tail) on a side stream.  OFF by default
+    # since the end of round 4: re-measured on the final kernels the main-stream order wins at every size (one utterance 3.94 ->
+    # 3.56 ms, B = 8 x 500 4.86 -> 4.62, recipe batch 7.34 -> 7.23, C2b 19.79 -> 19.63, C2a 50.8 -> 50.4; tools/experiments/
+    # knob_resweep{4,5}.sh) - in round 3, before the flush ordering was fixed, it had been worth 2.6 % of the recipe batch.
+    side_enabled = os.environ.get("SMX_WGRAD_STREAM", "0") != "0"
     side = {}        # device -> side stream of the slab GEMMs
     side_used = False
     # SMX_WGRAD_ASYNC=1: the whole weight-gradient tail of a block (slab GEMMs, grouped wgrad, the reduction jobs) runs on the

@@ -270,11 +270,13 @@ def test_layernorm_fusion_threshold_paths_agree():
         assert rel_err(pa[n], pb[n]) <= 3e-2, n
 
 
-def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch):
+@pytest.mark.parametrize("side", [False, True])
+def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch, side):
     """The recipe's own batch shape (10 utterances x 375 frames = 3750 frames, …transducer.yaml:112-126) on the dispatch a user
     gets there: separate LayerNorm kernels (below the fusion threshold: the fixture's lnfuse_default; lnfuse_always runs the same
     batch through the LayerNorm-fused GEMMs), ONE grouped weight-gradient launch per layer whose 3750 %
-    64 = 38-frame ragged tail is staged inside the kernel, the whole weight-gradient tail on the side stream.  bf16 (the grouped
+    64 = 38-frame ragged tail is staged inside the kernel; side = True: the whole weight-gradient tail on the side stream
+    (SMX_WGRAD_STREAM=1, the default of round 3, opt-in since the end of round 4).  bf16 (the grouped
     kernel's dtype), two layers at d = 256 / d_ffn = 1024 (every weight a multiple of 256): output, dL/dx and EVERY parameter
     gradient against the fp64 oracle's autograd."""
     from oracle import smx_oracle as O
@@ -301,6 +303,7 @@ def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch):
     ref = O.conformer_encoder(xr, sd, "", "swish", "SummaryMixing-fast", d, None, pad)
     (ref * r.double()).sum().backward()
 
+    monkeypatch.setattr(F._Deferred, "side_enabled", side)
     calls = []
     real = ops.wgrad_group
     monkeypatch.setattr(ops, "wgrad_group", lambda items, n, rows, splits: (calls.append((n, rows, splits, torch.cuda.current_stream())),
@@ -315,7 +318,7 @@ def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch):
     torch.cuda.synchronize()
     # the path under test really ran: one grouped launch per layer over all 3750 frames (ragged tail inside), off the main stream
     assert len(calls) == 2 and all(c[1] == B * T for c in calls), calls
-    assert all(c[3] != main for c in calls), "the weight-gradient tail of a 3750-frame block runs on the side stream"
+    assert all((c[3] != main) == side for c in calls), "side stream used exactly when it is switched on"
     assert rel_err(y, ref) <= 1e-2, rel_err(y, ref)
     assert rel_err(xg.grad, xr.grad) <= 3e-2, rel_err(xg.grad, xr.grad)
     worst = ("", 0.0)

@@ -95,7 +95,8 @@ def test_asynchronous_weight_gradient_tail_is_bit_identical():
     from summarymixing_amd import functional as F
     from summarymixing_amd.lobes.models.transformer.TransformerASR import EncoderWrapper, TransformerASR
     from summarymixing_amd.trainer import FlatAdamW
-    saved = F._Deferred.async_mode
+    saved, saved_side = F._Deferred.async_mode, F._Deferred.side_enabled
+    F._Deferred.side_enabled = True          # (the side stream is opt-in since round 4: SMX_WGRAD_STREAM=1)
     finals = []
     try:
         for mode in ("0", "1"):
@@ -129,5 +130,5 @@ def test_asynchronous_weight_gradient_tail_is_bit_identical():
             finally:
                 opt.use_device_step_counter(False)
     finally:
-        F._Deferred.async_mode = saved
+        F._Deferred.async_mode, F._Deferred.side_enabled = saved, saved_side
     assert torch.equal(finals[0], finals[1])

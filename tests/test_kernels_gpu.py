@@ -585,8 +585,9 @@ def test_wgrad_group_strided_operands_mixed_bias_and_single_item():
     assert _wgroup_case(4096, [(256, 256)] * 18, [True, False] * 9, seed=3) < 2e-5
 
 
-def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
+def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path(monkeypatch):
     from summarymixing_amd import functional as F, ops
+    monkeypatch.setattr(F._Deferred, "side_enabled", True)     # (SMX_WGRAD_STREAM=1: the opt-in side stream / asynchronous tail)
     _wgroup_case(4096, [(256, 256)], [True], seed=5)      # a small block first: its asynchronous (side-stream) mode must not leak
     assert not F._Deferred.async_now                       # into the next flush (round 4: it did, and the reduction below raced)
     torch.manual_seed(4)
@@ -609,10 +610,12 @@ def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
     assert rel_err(outs[0][0], gW2) < 1e-5 and rel_err(outs[0][1], gb2) < 1e-5
 
 
-def test_wgrad_tied_weight_across_asynchronous_flushes():
+def test_wgrad_tied_weight_across_asynchronous_flushes(monkeypatch):
     """The same gradient buffer (a weight shared by two blocks) fed by two small blocks whose weight-gradient tails run on the side
-    stream: the second block must not rewrite the slab workspace while the first block's reduction may still be reading it."""
+    stream (SMX_WGRAD_STREAM=1, opt-in since round 4): the second block must not rewrite the slab workspace while the first block's
+    reduction may still be reading it."""
     from summarymixing_amd import functional as F
+    monkeypatch.setattr(F._Deferred, "side_enabled", True)
     torch.manual_seed(11)
     rows, M, K = 2048, 256, 256                            # <= async_max_rows: asynchronous tail
     gW, gb = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
