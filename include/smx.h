@@ -48,22 +48,6 @@ const char* smx_last_error(void);
  * to the measured-best setting; the SMX_* variable that overrides it is named in the comment.  Ablation switches
  * (SMX_GEMM_ABLATE, SMX_WGROUP_ABLATE, SMX_DWROLL_ABLATE) only exist in builds with -DSMX_DIAG and read 0 otherwise. */
 typedef struct smx_config {
-  int32_t gemm_tile64;      /* SMX_GEMM_TILE64: force the 64 x 64 tile (0)                                   */
-  int32_t gemm_wide;        /* SMX_GEMM_WIDE: -1 auto, 0 / 1 force the 128 x 256 tile off / on               */
-  int32_t tn_dma;           /* SMX_TN_DMA: wgrad (TN) GEMM on the LDS-DMA ring (1)                           */
-  int32_t nt_z;             /* SMX_NT_Z: non-temporal stores for saved pre-activations (1)                   */
-  int64_t nt_bytes;         /* SMX_NT_BYTES: outputs at least this large are streamed past the caches (96 MB) */
-  int32_t reg_epi;          /* SMX_REG_EPI: register-domain epilogue 0 off, 1 always, 2 without a saved Z (0) */
-  int32_t epi_simple;       /* SMX_EPI_SIMPLE: specialised epilogue instantiations 0 / 1 / 2 (2)             */
-  int32_t wgrad_blocks;     /* SMX_WGRAD_BLOCKS: workgroup target of the per-weight wgrad (0 = 384)          */
-  int32_t wgrad_min_rows;   /* SMX_WGRAD_MIN_ROWS: frames per split-K slice at least (0 = 512)               */
-  int32_t pool_blocks;      /* SMX_POOL_BLOCKS: workgroup target of the masked-sum pool kernel (512)         */
-  int32_t wgroup_blocks;    /* SMX_WGROUP_BLOCKS: workgroup target of the grouped wgrad (0 = one per CU)     */
-  int32_t wgroup_bk;        /* SMX_WGROUP_BK: frames per ring stage of the grouped wgrad, 32 or 64 (32)      */
-  int32_t wgroup_pp;        /* SMX_WGROUP_PP: ping-pong issue order 0 / 1 / 2 (1)                            */
-  int32_t dwroll;           /* SMX_DWROLL: rolling register-window depthwise conv (1)                        */
-  int32_t dwroll_csgu;      /* SMX_DWROLL_CSGU: ... for the CSGU form (1)                                    */
-  int32_t dwroll_seg;       /* SMX_DWROLL_SEG: frames per wave segment (0 = auto)                            */
   int32_t ln_tile_rows;     /* rows of the LayerNorm-fused GEMM tile (128; see smx_gemm_ln_tile_rows)        */
   int32_t gemm_ablate, wgroup_ablate, dwroll_ablate;   /* SMX_DIAG builds only                                  */
   int32_t diag_build;       /* 1 when the library was compiled with -DSMX_DIAG                               */

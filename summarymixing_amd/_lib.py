@@ -174,11 +174,7 @@ def lib():
 
 class Config(ctypes.Structure):
     """smx_config of include/smx.h: the knobs the library read from the environment once."""
-    _fields_ = [("gemm_tile64", ctypes.c_int32), ("gemm_wide", ctypes.c_int32), ("tn_dma", ctypes.c_int32), ("nt_z", ctypes.c_int32),
-                ("nt_bytes", ctypes.c_int64), ("reg_epi", ctypes.c_int32), ("epi_simple", ctypes.c_int32),
-                ("wgrad_blocks", ctypes.c_int32), ("wgrad_min_rows", ctypes.c_int32), ("pool_blocks", ctypes.c_int32),
-                ("wgroup_blocks", ctypes.c_int32), ("wgroup_bk", ctypes.c_int32), ("wgroup_pp", ctypes.c_int32),
-                ("dwroll", ctypes.c_int32), ("dwroll_csgu", ctypes.c_int32), ("dwroll_seg", ctypes.c_int32), ("ln_tile_rows", ctypes.c_int32),
+    _fields_ = [("ln_tile_rows", ctypes.c_int32),
                 ("gemm_ablate", ctypes.c_int32), ("wgroup_ablate", ctypes.c_int32), ("dwroll_ablate", ctypes.c_int32),
                 ("diag_build", ctypes.c_int32), ("t256", ctypes.c_int32)]
 

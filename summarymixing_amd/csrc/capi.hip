@@ -29,28 +29,11 @@ int check_launch(const char* what) {
 
 namespace smx {
 static int env_i(const char* n, int dflt) { const char* e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; }
-static long env_l(const char* n, long dflt) { const char* e = getenv(n); return (e && e[0]) ? atol(e) : dflt; }
 const smx_config& cfg() {
   // function-local static: initialised exactly once (thread-safe), on the first call of any entry point that needs a knob
   static const smx_config c = [] {
     smx_config k;
     memset(&k, 0, sizeof(k));
-    k.gemm_tile64 = env_i("SMX_GEMM_TILE64", 0) != 0 ? 1 : 0;
-    k.gemm_wide = env_i("SMX_GEMM_WIDE", -1);
-    k.tn_dma = env_i("SMX_TN_DMA", 1);
-    k.nt_z = env_i("SMX_NT_Z", 1);
-    k.nt_bytes = env_l("SMX_NT_BYTES", 96L << 20);
-    k.reg_epi = env_i("SMX_REG_EPI", 0);     // (round 4: off - re-swept on the pipelined main loops: every config 0.3-2.7 % faster without)
-    k.epi_simple = env_i("SMX_EPI_SIMPLE", 2);
-    k.wgrad_blocks = env_i("SMX_WGRAD_BLOCKS", 0);
-    k.wgrad_min_rows = env_i("SMX_WGRAD_MIN_ROWS", 0);
-    k.pool_blocks = (int)env_l("SMX_POOL_BLOCKS", 512);
-    k.wgroup_blocks = env_i("SMX_WGROUP_BLOCKS", 0);
-    k.wgroup_bk = env_i("SMX_WGROUP_BK", 32);
-    k.wgroup_pp = env_i("SMX_WGROUP_PP", 1);
-    { const char* e = getenv("SMX_DWROLL"); k.dwroll = (e && e[0] == '0') ? 0 : 1; }
-    { const char* e = getenv("SMX_DWROLL_CSGU"); k.dwroll_csgu = (e && e[0] == '0') ? 0 : 1; }
-    k.dwroll_seg = env_i("SMX_DWROLL_SEG", 0);
     k.ln_tile_rows = 128;
     k.t256 = env_i("SMX_T256", 1);
 #ifdef SMX_DIAG

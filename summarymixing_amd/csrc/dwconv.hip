@@ -573,11 +573,10 @@ using namespace smx;
 // does a rolling register-window path (dwconv_roll.h) take this call?  1 = GLU + zero padding (bf16 and fp32),
 // 2 = CSGU gate + reflect padding (bf16)
 static int roll_kind(int dtype, int T, int D, int k, int glu, int pad_mode, int chunk, bool has_gate) {
-  if (!roll_enabled() || k != 31 || D % 64 != 0) return 0;
+  if (k != 31 || D % 64 != 0) return 0;
   // (Dynamic Chunk Convolution, chunk > 0, is part of the GLU kernels)
   if (glu && !has_gate && pad_mode == SMX_PAD_ZERO) return 1;
-  const int csgu = cfg().dwroll_csgu;
-  if (chunk <= 0 && csgu && !glu && has_gate && pad_mode == SMX_PAD_REFLECT && dtype == SMX_BF16 && T > 15) return 2;
+  if (chunk <= 0 && !glu && has_gate && pad_mode == SMX_PAD_REFLECT && dtype == SMX_BF16 && T > 15) return 2;
   return 0;
 }
 

@@ -835,21 +835,11 @@ __global__ __launch_bounds__(64) void dwconv_csgu_fold_kernel(DwParams p) {
 
 // time segment per wave: 128 frames (8 steps; 30 halo rows = 1.23x) unless that leaves the chip short of waves
 inline void roll_geometry(int B, int T, int D, int* seg, int* nseg, int* gy) {
-  static int forced = -1;
-  if (forced < 0) forced = cfg().dwroll_seg;
-  int s = forced > 0 ? (forced + 15) / 16 * 16 : 128;
-  if (forced <= 0) {
-    while (s > 32 && (long)B * ((T + s - 1) / s) * (D / 64) < 2048) s >>= 1;    // < 2 waves per SIMD: shorter segments
-  }
+  int s = 128;
+  while (s > 32 && (long)B * ((T + s - 1) / s) * (D / 64) < 2048) s >>= 1;    // < 2 waves per SIMD: shorter segments
   *seg = s;
   *nseg = (T + s - 1) / s;
   *gy = (int)(((long)B * *nseg + 3) / 4);
-}
-
-inline bool roll_enabled() {
-  static int on = -1;
-  if (on < 0) on = cfg().dwroll;
-  return on == 1;
 }
 
 }  // namespace smx

@@ -28,57 +28,10 @@
 namespace smx {
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
-#ifndef SMX_OCC
-#define SMX_OCC 3
-#endif
-#ifndef SMX_NS_SMALL
-#define SMX_NS_SMALL 4      // register stages in flight of the 64 x 64 tile (latency-bound small grids: see the main loop)
-#endif
-#ifndef SMX_NS_KC
-#define SMX_NS_KC 1
-#endif
-#ifndef SMX_SIDE_PREFETCH
-#define SMX_SIDE_PREFETCH 0 // 1 = 128 x 128 bf16 tile: the side words of both epilogue phases requested before the first phase (measured: act-grad dgrad 86.9 -> 94.8 us, C2b 19.56 -> 19.98 ms: 7 registers spill at the 168-register budget); 0 = each phase requests its own
-#endif
-#ifndef SMX_RES_PREFETCH
-#define SMX_RES_PREFETCH 0  // LayerNorm-forward epilogues, float32 residual rows requested one phase ahead: 1 = in the registers that held the previous ones (32 more registers live across the phase: 35 spilled, NT 1024 -> 256 + LN 83.8 -> 114.8 us); 2 = by LDS-DMA into a per-lane private 32 KB slot (own __shared__ array, reads through inline asm, explicit vmcnt that counts the phase's stores: no spills added, 82.6 -> 88.2 us, step 19.49 -> 19.58 ms); 0 = at the phase's start (product)
-#endif
-#ifndef SMX_FRAG_PIPE
-#define SMX_FRAG_PIPE 1     // wide bf16 tile: fragment reads interleaved one per MFMA (sched_group_barrier), 0 = hipcc's own order
-#endif
-#ifndef SMX_WIDE_PIPE
-#define SMX_WIDE_PIPE 1     // explicit software pipeline in 32-element steps: 1 = 128 x 256 bf16 tile; 2 = and the 128 x 128 tile (measured: +-2 %, steps 19.62 -> 19.84 / 50.46 -> 50.72 ms: three workgroups per CU already interleave, and K = 256 has four steps); 0 = the serial register-staged loops
-#endif
-#ifndef SMX_T256_DMA
-#define SMX_T256_DMA 0      // 256 x 256 tile: 1 = weights on an LDS-DMA ring (one __shared__ array per slot) + three activation register stages; measured SLOWER than both operands through registers (NT 2048 -> 512: 156.5 -> 168.9 us, NN 164.5 -> 175.7): opt-in
-#endif
-#ifndef SMX_T256_ABL
-#define SMX_T256_ABL 0
-#endif
-#ifndef SMX_DMAB
-#define SMX_DMAB 0          // wide (128 x 256) bf16 tile: the interleaved LDS-DMA main loop (0: the register-staged loop, for A/B builds)
-#endif
-
-// scheduling groups of one K step of the 256 x 256 tile (see T256P in gemm_kernel): after MFMA number S (sub-step S / MPK, slot
-// S % MPK) at most one fragment read of the NEXT sub-step, a ds_write after every fourth MFMA and a buffer load two MFMAs later
-template <int MASK, int N>
-__device__ __forceinline__ void sched_group() {
-  if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
-}
-template <int RPK, int MPK, int NKK, int S>
-__device__ __forceinline__ void t256_group_one() {
-  constexpr int kk = S / MPK, q = S % MPK;
-  sched_group<0x008, 1>();
-  constexpr int per = (RPK + MPK - 1) / MPK;              // reads per slot (1; 2 only when a sub-step has more reads than MFMAs)
-  constexpr int left = RPK - q * per;
-  sched_group<0x100, (kk + 1 < NKK && left > 0) ? (left < per ? left : per) : 0>();
-  sched_group<0x200, (q % 4 == 1) ? 1 : 0>();
-  sched_group<0x020, (q % 4 == 3) ? 1 : 0>();
-}
-template <int RPK, int MPK, int NKK, int... S>
-__device__ __forceinline__ void t256_groups(std::integer_sequence<int, S...>) {
-  (t256_group_one<RPK, MPK, NKK, S>(), ...);
-}
+// tuning constants of the register-staged tiles (swept in rounds 1-4)
+constexpr int kOcc = 3;        // workgroups per CU of the 128 x 128 / 64 x 64 tiles (168-register budget)
+constexpr int kNsSmall = 4;    // register stages in flight of the 64 x 64 tile (latency-bound small grids: see the main loop)
+constexpr int kNsKc = 1;       // ... of the 128 x 128 tile
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.
@@ -88,7 +41,7 @@ __device__ __forceinline__ void t256_groups(std::integer_sequence<int, S...>) {
 // GATHER (bf16, 64 x 64 tile): 1 = the A operand of an NT GEMM, 2 = the B operand of a TN GEMM is the implicit patch matrix of a
 // 3 x 3 / stride 2 convolution over 64 channels (GemmParams::g_*): the front-end's second block without im2col.
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0, int GATHER = 0>
-__global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) ? 2 : SMX_OCC))) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) ? 2 : kOcc))) void gemm_kernel(GemmParams p) {
   static_assert(GATHER == 0 || GATHER >= 3 || (sizeof(T) == 2 && VEC && TILE_N == 64 && TILE_M == 64 && LNF == 0), "GATHER 1 / 2: bf16 64 x 64 tile");
   static_assert(GATHER < 3 || (sizeof(T) == 4 && A_KC && B_KC && LNF == 0), "GATHER 3 / 4 (folded DFT frames): float32 NT");
   static_assert(GATHER != 1 || (A_KC && B_KC), "GATHER 1: NT");
@@ -106,39 +59,20 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   constexpr int PH_ROWS = 32 * PH_FRAGS;
   constexpr int NPH = TILE_N / PH_ROWS;
   constexpr int EPI_BYTES = PH_ROWS * (TILE_M * 4 + 16);         // fp32 rows, 16 B row pad
-  // DMAB (wide bf16 tile, aligned operands): the main loop that interleaves everything with the MFMAs (see there): weight
-  // operand by LDS-DMA into a ring of four half-tiles, activation operand through 4 register stages into two LDS buffers.
-  constexpr bool DMAB = SMX_DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0 && (SMX_BUFLD_WIDE != 0);
   // T256P (256 x 256 bf16 tile, one workgroup of four waves per CU): software-pipelined main loop with double-buffered LDS stages
   constexpr bool T256P = sizeof(T) == 2 && VEC && A_KC && TILE_N == 256 && TILE_M == 256 && GATHER == 0 && LNF == 0;
-  // T256D: the same tile with the weights on an LDS-DMA ring of three stages (a SEPARATE __shared__ array: hipcc then knows
-  // that the activation stores into `smem` cannot hit it and does not wait vmcnt(0) in front of them) and the freed
-  // registers as a third activation stage
-  constexpr bool T256D = T256P && SMX_T256_DMA;
   // W128P: the 128 x 256 tile (two workgroups per CU, every LayerNorm-fused epilogue) with the same explicit software pipeline
   // in 32-element steps: both operands double-buffered in LDS (2 x 24 KB = the one 48 KB stage of the serial loop)
-  constexpr bool W128P = SMX_WIDE_PIPE && !DMAB && sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && GATHER == 0 &&
-                         ((TILE_M == 256 && SMX_BUFLD_WIDE != 0) || (TILE_M == 128 && SMX_WIDE_PIPE >= 2));
-  constexpr int AB_BYTES = DMAB ? 2 * (TILE_N * 32 * 2) + 4 * (TILE_M * 32 * 2)   // DMAB: two A buffers + four ring slots of 32 k
-                                : (T256D ? 2 * A_BYTES : (T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES));
+  constexpr bool W128P = sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0;
+  constexpr int AB_BYTES = T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES;
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0)) * 4;   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta]
   // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) operand stage, fenced by one extra barrier
-  constexpr bool RESPL = SMX_RES_PREFETCH == 2 && LNF == 2 && sizeof(T) == 2 && VEC && B_KC && TILE_N == 128;
-  constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536 || T256D || RESPL;
+  constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536;
   static_assert(!ALIAS_SIDE || EPI_BYTES + RED_BYTES + SIDE_BYTES + 64 <= SMEM_BYTES, "epilogue arrays do not fit");
   __shared__ __attribute__((aligned(16))) char smem[ALIAS_SIDE ? SMEM_BYTES : SMEM_BYTES + RED_BYTES + SIDE_BYTES];
-  // RESPL: the float32 residual rows of the LayerNorm-forward epilogue arrive by LDS-DMA one phase ahead (ResPrefetch in
-  // gemm_common.h) in their own 32 KB array; with the epilogue's small arrays aliased into the dead operand stage the block is
-  // 48 + 32 KB = exactly half a CU's LDS
-  __shared__ __attribute__((aligned(16))) char pfslot[RESPL ? 32768 : 16];
-  // (T256D: the weight ring - one array per slot, so that hipcc's LDS-DMA alias tracking sees that the slot being refilled is
-  //  not the slot being read: with one array it put s_waitcnt vmcnt(0) in front of the fragment reads)
-  __shared__ __attribute__((aligned(16))) char bring0[T256D ? 64 * TILE_M * 2 : 16];
-  __shared__ __attribute__((aligned(16))) char bring1[T256D ? 64 * TILE_M * 2 : 16];
-  __shared__ __attribute__((aligned(16))) char bring2[T256D ? 64 * TILE_M * 2 : 16];
   float* red = reinterpret_cast<float*>(smem + (ALIAS_SIDE ? (EPI_BYTES + 63) / 64 * 64 : SMEM_BYTES));
   float* side = red + TILE_M;
   char* As = smem;
@@ -188,7 +122,7 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   const T* B = reinterpret_cast<const T*>(p.B) + (long)bz * p.sB;
   // operand stage loads: buffer loads with once-computed offsets for the aligned bf16 kernels (BufStage), else the
   // generic guarded loads
-  constexpr bool BUFLD = sizeof(T) == 2 && VEC && (SMX_BUFLD_WIDE || TILE_M <= 128);
+  constexpr bool BUFLD = sizeof(T) == 2 && VEC;
   BufStage<T, A_KC, TILE_N> bufa;
   BufStage<T, B_KC, TILE_M> bufb;
   GatherStageKC<GATHER == 1 ? TILE_N : 32> gka;
@@ -273,159 +207,7 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
 #pragma unroll
   for (int q = 0; q < CSN; ++q) cs[q] = 0.f;
   const bool do_cs = !A_KC && p.acolsum != nullptr && tile_m == 0;
-  if constexpr (DMAB) {
-    // ---- main loop of the wide bf16 tile: ONE instruction stream per wave in which everything overlaps the MFMAs ------------
-    // Measured on the register-staged loop (tools/experiments/ablate_shapes.sh, K = 1024 -> 256 at 64 000 frames): stage
-    // stores + barriers alone 13.6 us, + operand loads 23.6, + MFMA 29.1, all three 37.8 - the parts ADD, because a step was
-    // registers -> LDS | barrier | loads issued | MFMAs | barrier, the same on all eight waves of the CU at the same time.
-    // Here a step is 32 reduce elements and has ONE barrier; between its 16 MFMAs a wave (i) requests the weight half-tile
-    // three steps ahead by LDS-DMA into a ring of four 16 KB slots (no VGPRs, no ds_write), (ii) moves the NEXT step's
-    // activation half-tile from registers into the other one of two 8 KB LDS buffers, (iii) refills those registers with the
-    // half-tile NSA steps ahead.  2 x 8 + 4 x 16 KB = 80 KB = exactly half a CU's LDS (two workgroups per CU as before).
-    // LDS images: A and NT-B [rows][32 k] = 64-byte rows, 16-byte chunk c of row r at position c ^ ((r >> 2) & 3) (any 16
-    // rows x one chunk cover the 64 banks once: conflict-free ds_read_b128); NN-B [32 k][256 columns] = 512-byte k rows,
-    // granule XOR 4 * (k & 3) (wgrad_group.hip).  The DMA lands a 1 KB piece linearly (lane i -> +16 i), so the XOR is
-    // applied to the SOURCE granule; piece j of wave w is piece w + 4 j of the half-tile and its swizzle term does not depend
-    // on j (16 rows x 4 j / 2 k rows x 4 j), so ONE offset register serves all four and the piece stride is a scalar offset.
-    // vmcnt retires in order.  Every step issues exactly 4 DMA pieces then 2 register loads (a request for a half-tile that
-    // does not exist carries bit 31 in its offset: out of the buffer's range, zeros, nothing fetched - so the step is
-    // branch-free, hipcc's own vmcnt count for the register loads stays exact and the explicit wait is ONE constant): at the
-    // end of step h the B pieces of step h + 1 (requested first thing in step h - 2) have landed once at most the
-    // 2 + 6 + 6 = 14 younger requests are outstanding.
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    constexpr int HK = 32, NSA = 4, A_HALF = TILE_N * HK * 2, B_HALF = TILE_M * HK * 2, NPB = B_HALF / 1024 / 4;
-    static_assert(A_HALF == 8192 && B_HALF == 16384 && NPB == 4, "128 x 256 tile");
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const long span_b = B_KC ? ((long)(p.M - 1) * p.ldb + p.K) : ((long)(p.K - 1) * p.ldb + p.M);
-    const __amdgpu_buffer_rsrc_t rsb =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(B), (short)0, (int)(span_b * 2), 0x00020000);
-    const long span_a = (long)(p.N - 1) * p.lda + p.K;
-    const __amdgpu_buffer_rsrc_t rsa =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), (short)0, (int)(span_a * 2), 0x00020000);
-    uint32_t vb, piece_delta, kstep_bytes;
-    if constexpr (B_KC) {
-      const int row = wave_u * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-      vb = (uint32_t)((((long)(m0 + row)) * p.ldb + c * 8) * 2);
-      piece_delta = (uint32_t)(64 * p.ldb * 2);
-      kstep_bytes = HK * 2;
-    } else {
-      const int krow = wave_u * 2 + (lane >> 5), g = (lane & 31) ^ ((krow & 3) << 2);
-      vb = (uint32_t)(((long)krow * p.ldb + m0 + g * 8) * 2);
-      piece_delta = (uint32_t)(8 * p.ldb * 2);
-      kstep_bytes = (uint32_t)(HK * p.ldb * 2);
-    }
-    // A half-tile: 128 rows x 4 chunks = 2 per thread (v = t + 256 i: row v >> 2, chunk v & 3)
-    uint32_t va[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rg = n0 + ((t + 256 * i) >> 2);
-      va[i] = rg < p.N ? (uint32_t)(((long)rg * p.lda + (t & 3) * 8) * 2) : 0x80000000u;
-    }
-    char* Bring = smem + 2 * A_HALF;
-    const int nh = (kend - kbeg) / HK, h0 = kbeg / HK;
-    auto issue_b = [&](int h, int slot) {
-      char* dst = Bring + slot * B_HALF + wave_u * 1024;
-      const bool valid = h < nh && !ab_nold;
-      const uint32_t so = valid ? (uint32_t)(h0 + h) * kstep_bytes : 0u;
-      const uint32_t vbe = vb | (valid ? 0u : 0x80000000u);
-#pragma unroll
-      for (int j = 0; j < NPB; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_vp)(dst + j * 4096), 16, vbe, so + (valid ? j * piece_delta : 0u), 0, 0);
-    };
-    typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
-    auto load_ah = [&](u32v4 (&reg)[2], int h) {
-      const bool valid = h < nh && !ab_nold;
-      const uint32_t so = valid ? (uint32_t)(h0 + h) * (HK * 2) : 0u, inval = valid ? 0u : 0x80000000u;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, va[i] | inval, so, 0);
-    };
-    // registers -> LDS through inline asm: a ds_write the compiler can see makes it wait for EVERY outstanding LDS-DMA piece
-    // first (vmcnt(0): it assumes the DMA and the store may hit the same LDS bytes), which would serialise the ring
-    const uint32_t a_st = (uint32_t)(uintptr_t)As + (uint32_t)((t >> 2) * 64 + (((t & 3) ^ ((t >> 4) & 3)) << 4));
-    auto store_ah = [&](const u32v4 (&reg)[2], int buf) {
-      const uint32_t ad = a_st + buf * A_HALF;
-      asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(reg[0]) : "memory");
-      asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(ad), "v"(reg[1]) : "memory");
-    };
-    uint32_t fqa[FN], fqb[FM];                           // loop-invariant fragment addresses (64-byte rows)
-#pragma unroll
-    for (int i = 0; i < FN; ++i) { const int r = wn * WN + i * 32 + l31; fqa[i] = (uint32_t)(r * 64 + ((hi ^ ((r >> 2) & 3)) << 4)); }
-#pragma unroll
-    for (int j = 0; j < FM; ++j) { const int r = wm * WM + j * 32 + l31; fqb[j] = (uint32_t)(r * 64 + ((hi ^ ((r >> 2) & 3)) << 4)); }
-    auto frag32 = [&](const char* lds, uint32_t pre, int kk) {
-      return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (pre ^ (uint32_t)(kk << 5))));
-    };
-    u32v4 ra[NSA][2];
-    // prologue = the request stream of "steps -3 .. -1": A(0) A(1) B(0) | B(1) A(2) | B(2) A(3), then A(0) into LDS and A(4)
-    load_ah(ra[0], 0);
-    load_ah(ra[1], 1);
-    issue_b(0, 0);
-    issue_b(1, 1);
-    load_ah(ra[2], 2);
-    issue_b(2, 2);
-    load_ah(ra[3], 3);
-    store_ah(ra[0], 0);
-    load_ah(ra[0], NSA);
-    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");     // B(0): behind it 4 + 2 + 4 + 2 + 2 requests
-    lds_barrier();
-    SMX_STAMP(1);
-    // one step of 32 reduce elements; U = h mod 4 (compile time): B slot U, A buffer U & 1, next A in register stage (U + 1) & 3
-    auto step = [&](int h, auto utag) {
-      constexpr int U = decltype(utag)::value;
-      const char* Ab = As + (U & 1) * A_HALF;
-      const char* Bb = Bring + U * B_HALF;
-      bf16x8 fa[2][FN], fb[2][FM];
-#pragma unroll
-      for (int i = 0; i < FN; ++i) fa[0][i] = frag32(Ab, fqa[i], 0);
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        if constexpr (B_KC) fb[0][j] = frag32(Bb, fqb[j], 0);
-        else fb[0][j] = frag_tr_swz512(Bb, wm * WM + j * 32, lane, 0);
-      }
-      issue_b(h + 3, (U + 3) & 3);
-#pragma unroll
-      for (int i = 0; i < FN; ++i) fa[1][i] = frag32(Ab, fqa[i], 1);
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        if constexpr (B_KC) fb[1][j] = frag32(Bb, fqb[j], 1);
-        else fb[1][j] = frag_tr_swz512(Bb, wm * WM + j * 32, lane, 1);
-      }
-      if (!ab_nomfma) {
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-          for (int j = 0; j < FM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
-      }
-      store_ah(ra[(U + 1) & 3], (U + 1) & 1);
-      load_ah(ra[(U + 1) & 3], h + 1 + NSA);
-      if (!ab_nomfma) {
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-          for (int j = 0; j < FM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-      lds_barrier();
-    };
-    // whole groups of four steps without an early exit, then the remaining pair (K % 64 == 0: nh is even) as straight-line
-    // code: with a `break` inside an unrolled group the 128 accumulator registers meet at several loop exits and hipcc
-    // spills them around every step
-    const int nfull = nh / 4 * 4;
-    for (int hb = 0; hb < nfull; hb += 4) {
-      step(hb, ActTag<0>{});
-      step(hb + 1, ActTag<1>{});
-      step(hb + 2, ActTag<2>{});
-      step(hb + 3, ActTag<3>{});
-    }
-    if (nfull < nh) {
-      step(nfull, ActTag<0>{});
-      step(nfull + 1, ActTag<1>{});
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the predicated tail requests: nothing may land in LDS later)
-    lds_barrier();
-  } else if constexpr (W128P) {
+  if constexpr (W128P) {
     // ---- 128 x 256 tile, explicit software pipeline (the structure that worked on the 256 x 256 tile, T256P below), 32 reduce
     // elements per step: step h multiplies half-stage h out of LDS buffer h & 1 and, between its 16 MFMAs, moves half-stage
     // h + 1 from registers into the other buffer (2 + 4 ds_write_b128), refills those registers (activations two steps ahead,
@@ -531,92 +313,6 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
       step(h + 1, ActTag<1>{});
     }
     if (nh & 1) step(nh - 1, ActTag<0>{});
-  } else if constexpr (T256D) {
-    // ---- 256 x 256 tile, weights by LDS-DMA.  Per step h (64 reduce elements): MFMAs on activation buffer h & 1 and ring slot
-    // h % 3; in the first 16 MFMA slots the 8 DMA pieces of weight stage h + 2 (slot (h + 2) % 3, read last in step h - 1), in the
-    // remaining slots the 8 activation pieces of stage h + 1: register stage (h + 1) % 3 -> LDS buffer (h + 1) & 1, then the
-    // refill of that register from stage h + 4.  In flight: weights two stages, activations three.  vmcnt retires in order: at
-    // the end of step h the pieces of B(h + 1) (first thing in step h - 1) have landed once at most the 8 + 16 requests behind
-    // them are outstanding; requests for stages that do not exist carry bit 31 in their offset (zeros, nothing fetched), so a
-    // step is branch-free and the compiler's own vmcnt for the register stages stays exact.  Period lcm(2, 3) = 6 steps.
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
-    constexpr int BST = 64 * TILE_M * 2, NPB = BST / 1024 / 4, NPA = TILE_N / 32;      // 32 KB ring stage, 8 pieces per wave
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const long span_b = B_KC ? ((long)(p.M - 1) * p.ldb + p.K) : ((long)(p.K - 1) * p.ldb + p.M);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(B), (short)0, (int)(span_b * 2), 0x00020000);
-    uint32_t vb, piece_delta, kstep_bytes;
-    if constexpr (B_KC) {                                  // piece = 8 rows x 128 B; chunk XOR (row >> 1) & 7 applied to the source
-      const int row = wave_u * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
-      vb = (uint32_t)((((long)(m0 + row)) * p.ldb + c * 8) * 2);
-      piece_delta = (uint32_t)(32 * p.ldb * 2);
-      kstep_bytes = 64 * 2;
-    } else {                                               // piece = 2 k rows x 512 B; granule XOR 4 * (k & 3)
-      const int krow = wave_u * 2 + (lane >> 5), g = (lane & 31) ^ ((krow & 3) << 2);
-      vb = (uint32_t)(((long)krow * p.ldb + m0 + g * 8) * 2);
-      piece_delta = (uint32_t)(8 * p.ldb * 2);
-      kstep_bytes = (uint32_t)(64 * p.ldb * 2);
-    }
-    const int nk = (kend - kbeg) / BK;
-    char* Abuf = smem;
-    auto dma_piece = [&](int h, auto slot_tag, auto jtag) __attribute__((always_inline)) {   // piece wave + 4 j of weight stage h -> ring slot
-      constexpr int J = decltype(jtag)::value, SLOT = decltype(slot_tag)::value;
-      char* ring = SLOT == 0 ? bring0 : (SLOT == 1 ? bring1 : bring2);
-      const bool valid = h < nk;
-      const uint32_t so = valid ? (uint32_t)(kbeg / 64 + h) * kstep_bytes + J * piece_delta : 0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_vp)(ring + wave_u * 1024 + J * 4096), 16,
-                                               vb | (valid ? 0u : 0x80000000u), so, 0, 0);
-    };
-    const uint32_t a_st = (uint32_t)((t >> 3) * 128 + (((t & 7) ^ ((t >> 4) & 7)) << 4));
-    constexpr uint32_t A_PIECE = 32 * 128;
-    uint4 ra[3][NPA];
-    bufa.load_pred(ra[0], kbeg, nk > 0);
-    bufa.load_pred(ra[1], kbeg + BK, nk > 1);
-    bufa.load_pred(ra[2], kbeg + 2 * BK, nk > 2);
-    for_seq<0, NPB>([&](auto j) __attribute__((always_inline)) { dma_piece(0, ActTag<0>{}, j); });
-    for_seq<0, NPB>([&](auto j) __attribute__((always_inline)) { dma_piece(1, ActTag<1>{}, j); });
-    stage_store<T, true, TILE_N>(ra[0], Abuf, t);
-    bufa.load_pred(ra[0], kbeg + 3 * BK, nk > 3);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // B(0): behind it the 8 pieces of B(1) and the 8 loads of A(3)
-    lds_barrier();
-    SMX_STAMP(1);
-    auto step = [&](int h, auto utag) __attribute__((always_inline)) {
-      constexpr int U = decltype(utag)::value;                                      // h % 6
-      constexpr int AB_ = U & 1, SL = U % 3, RS = (U + 1) % 3;                      // LDS buffer, ring slot, register stage of A(h + 1)
-      const char* Ab = Abuf + AB_ * A_BYTES;
-      const char* Bb = SL == 0 ? bring0 : (SL == 1 ? bring1 : bring2);
-      char* An = Abuf + (AB_ ^ 1) * A_BYTES;
-      const uint32_t soa = (h + 4 < nk) ? (uint32_t)(kbeg + (h + 4) * BK) * bufa.kbytes : 0u, ina = (h + 4 < nk) ? 0u : 0x80000000u;
-      bf16x8 fa[2][FN], fb[2][FM];
-      auto read_frag = [&](int kk, int buf, auto ftag) __attribute__((always_inline)) {
-        constexpr int Fi = decltype(ftag)::value;
-        if constexpr (Fi < FN) fa[buf][Fi] = frag_kc(Ab, fpa[Fi], kk);
-        else if constexpr (B_KC) fb[buf][Fi - FN] = frag_kc(Bb, fpb[Fi - FN], kk);
-        else fb[buf][Fi - FN] = frag_tr_swz512(Bb, wm * WM + (Fi - FN) * 32, lane, kk);
-      };
-      for_seq<0, FN + FM>([&](auto f) __attribute__((always_inline)) { read_frag(0, 0, f); });
-      __builtin_amdgcn_sched_barrier(0);
-      for_seq<0, FN * FM * (BK / 16)>([&](auto stag) __attribute__((always_inline)) {
-        constexpr int S = decltype(stag)::value, kk = S / (FN * FM), q = S % (FN * FM), i = q / FM, j = q % FM, cur = kk & 1;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
-        if constexpr (kk + 1 < BK / 16 && q < FN + FM) read_frag(kk + 1, cur ^ 1, ActTag<q>{});
-        if constexpr (S < 2 * NPB && (S & 1) == 1) dma_piece(h + 2, ActTag<(SL + 2) % 3>{}, ActTag<S / 2>{});
-        if constexpr (S >= 17 && (S - 17) % 6 == 0 && (S - 17) / 6 < NPA) {
-          constexpr int P = (S - 17) / 6;
-          *reinterpret_cast<uint4*>(An + a_st + P * A_PIECE) = ra[RS][P];
-          const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufa.rsrc, bufa.voff[P] | ina, soa, 0);
-          ra[RS][P] = make_uint4(r.x, r.y, r.z, r.w);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // B(h + 1): behind it 8 activation loads of step h - 1 and this step's 16
-      lds_barrier();
-    };
-    const int nfull = nk / 6 * 6;
-    for (int h = 0; h < nfull; h += 6) for_seq<0, 6>([&](auto u) __attribute__((always_inline)) { step(h + decltype(u)::value, u); });
-    for_seq<0, 5>([&](auto u) __attribute__((always_inline)) { if (nfull + decltype(u)::value < nk) step(nfull + decltype(u)::value, u); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the predicated tail requests: nothing may land in LDS later)
-    lds_barrier();
   } else if constexpr (T256P) {
     // ---- 256 x 256 tile: ONE wave per SIMD (128 x 128 outputs = 256 accumulator registers), nobody else hides its latencies,
     // so the K loop is software-pipelined the way the vendor library's is.  Step h multiplies stage h out of LDS buffer h & 1
@@ -648,7 +344,6 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
     static_assert(TILE_N / 32 + TILE_M / 32 == 4 * (BK / 16), "one piece after every fourth MFMA");
     auto step = [&](int h, auto utag) __attribute__((always_inline)) {
       constexpr int U = decltype(utag)::value;                                      // h & 1
-      constexpr int ABL = SMX_T256_ABL;   // experiment builds: 1 no ds_write, 2 no global loads, 4 no fragment reads, 8 no MFMA, 16 no barrier
       const char* Ab = Abuf + U * A_BYTES;
       const char* Bb = Bbuf + U * B_BYTES;
       char* An = Abuf + (U ^ 1) * A_BYTES;
@@ -660,18 +355,14 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
       auto move_piece = [&](auto ptag) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;
         if constexpr (P < NPA) {
-          if constexpr (!(ABL & 1)) *reinterpret_cast<uint4*>(An + a_st + P * A_PIECE) = ra[U ^ 1][P];
-          if constexpr (!(ABL & 2)) {
-            const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufa.rsrc, bufa.voff[P] | ina, soa, 0);
-            ra[U ^ 1][P] = make_uint4(r.x, r.y, r.z, r.w);
-          }
+          *reinterpret_cast<uint4*>(An + a_st + P * A_PIECE) = ra[U ^ 1][P];
+          const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufa.rsrc, bufa.voff[P] | ina, soa, 0);
+          ra[U ^ 1][P] = make_uint4(r.x, r.y, r.z, r.w);
         } else {
           constexpr int Q = P - NPA;
-          if constexpr (!(ABL & 1)) *reinterpret_cast<uint4*>(Bn + b_st + Q * B_PIECE) = rb[Q];
-          if constexpr (!(ABL & 2)) {
-            const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufb.rsrc, bufb.voff[Q] | inb, sob, 0);
-            rb[Q] = make_uint4(r.x, r.y, r.z, r.w);
-          }
+          *reinterpret_cast<uint4*>(Bn + b_st + Q * B_PIECE) = rb[Q];
+          const u32v4 r = __builtin_amdgcn_raw_buffer_load_b128(bufb.rsrc, bufb.voff[Q] | inb, sob, 0);
+          rb[Q] = make_uint4(r.x, r.y, r.z, r.w);
         }
       };
       // fragment f of sub-step kk: 0..FN-1 activations, FN.. weights
@@ -689,13 +380,12 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
       // scheduler put all 16 ds_writes - behind one s_waitcnt vmcnt(0) - and all 16 loads at the top of the step)
       for_seq<0, FN * FM * (BK / 16)>([&](auto stag) __attribute__((always_inline)) {
         constexpr int S = decltype(stag)::value, kk = S / (FN * FM), q = S % (FN * FM), i = q / FM, j = q % FM, cur = kk & 1;
-        if constexpr (ABL & 8) acc[i][j][0] += __builtin_bit_cast(uint4, fa[cur][i]).x * 1e-30f + __builtin_bit_cast(uint4, fb[cur][j]).y * 1e-30f;
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
         if constexpr (kk + 1 < BK / 16 && q < FN + FM) read_frag(kk + 1, cur ^ 1, ActTag<q>{});
         if constexpr (q % 4 == 1) move_piece(ActTag<kk * 4 + q / 4>{});
         __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (!(ABL & 16)) lds_barrier();
+      lds_barrier();
     };
     for (int h = 0; h + 1 < nk; h += 2) {
       step(h, ActTag<0>{});
@@ -710,7 +400,7 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   // The 64 x 64 tile runs when the grid is too small to fill the chip with big tiles (the recipe batch of 3750 frames:
   // 472 workgroups, ~2 per CU): nothing hides a workgroup's own round trips there, one stage in flight cost 0.6 us per
   // K tile (17 - 20 us for K = 2048).  Its 16 accumulator registers leave room for 4 stages (64 registers).
-  constexpr int NS = A_KC ? ((TILE_N == 64 && TILE_M == 64) ? SMX_NS_SMALL : (TILE_M > 128 ? 1 : SMX_NS_KC))
+  constexpr int NS = A_KC ? ((TILE_N == 64 && TILE_M == 64) ? kNsSmall : (TILE_M > 128 ? 1 : kNsKc))
                           : (TILE_M > 128 ? 1 : 2);              // (two stages of a 128x256 tile pair would spill)
   uint4 ra[NS][TILE_N / 32], rb[NS][TILE_M / 32];
 #pragma unroll
@@ -764,21 +454,6 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
 #pragma unroll
             for (int j = 0; j < FM; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        // Fragment-read pipeline of the wide tile (SMX_FRAG_PIPE): hipcc schedules a K tile as bursts - all fragment reads
-        // of a sub-step, s_waitcnt, its MFMAs - so every 16-element sub-step exposes one LDS round trip (SQ counters of the
-        // K = 2048 -> 512 dgrad: waves issue-stalled 46 %, parked 30 %, the matrix pipe 35 % busy).  The groups below ask the
-        // scheduler for the library order instead: the first sub-step's reads, then ONE read between consecutive MFMAs, so
-        // the reads of sub-step kk + 1 are in flight under the MFMAs of sub-step kk.
-        if constexpr (SMX_FRAG_PIPE && TILE_M == 256 && A_KC) {
-          constexpr int RPK = FN + (B_KC ? FM : 2 * FM), NRD = RPK * (BK / 16), NMF = FN * FM * (BK / 16);
-          __builtin_amdgcn_sched_group_barrier(0x100, RPK, 0);
-#pragma unroll
-          for (int q = 0; q < NRD - RPK; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, NMF - (NRD - RPK) > 0 ? NMF - (NRD - RPK) : 1, 0);
         }
       } else {
         const float* Af = reinterpret_cast<const float*>(As);
@@ -851,93 +526,6 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
     }
     return;
   }
-  if constexpr (sizeof(T) == 2 && TILE_N == 128 && TILE_M == 128 && VEC) {
-    if (p.reg_epi) {
-      // ---- register-domain epilogue (bias / activation / row mask / dropout / saved Z only; bf16 output) -------------
-      // The math runs on the accumulator fragments of all four waves at once; what goes through LDS is the finished bf16
-      // tile (128 x 128 x 2 B, ONE phase per output instead of two fp32 half-tile phases), and the copy-out loop is a
-      // plain 16-byte LDS -> global copy.  Lane (l31, hi) of wave (wn, wm) owns rows wn*64 + i*32 + l31 and, per
-      // (j, g), the 4 columns wm*64 + j*32 + g*8 + hi*4 .. +3.
-      constexpr int SB = TILE_M * 2 + 8;                  // staged bf16 row: 264 B (66 dwords: 2-way conflicts at worst)
-      lds_barrier();                                      // every wave is done reading the operand stage
-      if (t < TILE_M + TILE_N) side[t] = side_value(0);
-      lds_barrier();
-      const uint32_t dthresh = p.dthresh;
-      const float dscale = p.dscale;
-      const uint64_t dseed = dthresh ? epoch_seed(e.drop_seed, p.epoch) : 0;
-      const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
-      T* Cb = reinterpret_cast<T*>(p.C) + (long)bz * p.sC;
-      T* Zb = e.z ? reinterpret_cast<T*>(e.z) + (long)bz * p.sC : nullptr;
-      auto copy_out = [&](T* dst, long ld, bool nt) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int it = t + 256 * k, r = it >> 4, c = (it & 15) * 8;
-          const uint2 lo = *reinterpret_cast<const uint2*>(smem + r * SB + c * 2);
-          const uint2 hi2 = *reinterpret_cast<const uint2*>(smem + r * SB + c * 2 + 8);
-          if (n0 + r < p.N && m0 + c < p.M) {
-            u32x4_t u = {lo.x, lo.y, hi2.x, hi2.y};
-            u32x4_t* gp = reinterpret_cast<u32x4_t*>(dst + (long)(n0 + r) * ld + m0 + c);
-            if (nt) __builtin_nontemporal_store(u, gp); else *gp = u;
-          }
-        }
-      };
-      // z = acc + bias (in place)
-#pragma unroll
-      for (int j = 0; j < FM; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b4 = *reinterpret_cast<const float4*>(side + wm * WM + j * 32 + g * 8 + hi * 4);
-#pragma unroll
-          for (int i = 0; i < FN; ++i) {
-            acc[i][j][g * 4] += b4.x; acc[i][j][g * 4 + 1] += b4.y; acc[i][j][g * 4 + 2] += b4.z; acc[i][j][g * 4 + 3] += b4.w;
-          }
-        }
-      if (Zb) {
-#pragma unroll
-        for (int i = 0; i < FN; ++i)
-#pragma unroll
-          for (int j = 0; j < FM; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<uint2*>(smem + (wn * WN + i * 32 + l31) * SB + (wm * WM + j * 32 + g * 8 + hi * 4) * 2) =
-                  make_uint2(pack_bf16x2(acc[i][j][g * 4], acc[i][j][g * 4 + 1]), pack_bf16x2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]));
-        lds_barrier();
-        copy_out(Zb, e.ldz, p.nt & 1);
-        lds_barrier();
-      }
-      float mk[FN];
-#pragma unroll
-      for (int i = 0; i < FN; ++i) mk[i] = has_mk ? side[TILE_M + wn * WN + i * 32 + l31] : 1.f;
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        const int n = n0 + wn * WN + i * 32 + l31;
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float v[4] = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
-            switch (e.act) {
-              case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 4>(v); break;
-              case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 4>(v); break;
-              case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 4>(v); break;
-              case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 4>(v); break;
-              default: break;
-            }
-            const int m = m0 + wm * WM + j * 32 + g * 8 + hi * 4;
-            if (dthresh && m < p.drop_cols) {
-              dropout_apply<4>(v, dseed, (uint64_t)n * p.drop_cols + m, dthresh, dscale);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] *= mk[i];
-            *reinterpret_cast<uint2*>(smem + (wn * WN + i * 32 + l31) * SB + (wm * WM + j * 32 + g * 8 + hi * 4) * 2) =
-                make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-          }
-      }
-      lds_barrier();
-      copy_out(Cb, p.ldc, p.nt & 2);
-      return;
-    }
-  }
   constexpr int STG_LD = TILE_M * 4 + 16;               // bytes per staged fp32 row (16 B pad: conflict-free b128)
   const int osz = (e.out_mode == SMX_OUT_T) ? (int)sizeof(T) : 4;
   if constexpr (ALIAS_SIDE) lds_barrier();               // every wave is done reading the operand ring
@@ -958,32 +546,6 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
 #pragma unroll
       for (int q = 0; q < 8; ++q) dgam[q] = dbet[q] = 0.f;
     }
-  }
-  // float32 residual of the LayerNorm-forward kernels: requested one phase ahead (PFX in gemm_common.h)
-  constexpr bool RESPF = SMX_RES_PREFETCH == 1 && LNF == 2 && sizeof(T) == 2 && VEC;
-  // (SMX_RES_PREFETCH == 2: through LDS - RESPL, declared with the kernel's shared arrays)
-  ResPrefetch rpf;
-  bool respl = false;
-  if constexpr (RESPL) {
-    respl = osz == 4 && p.epi_simple == 2 && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr && !(e.flags & SMX_EPI_ACT_GRAD) &&
-            (long)p.N * e.ldr * 4 < (1L << 31);
-    if (respl) {
-      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-      rpf.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(e.res), (short)0, (int)(((long)(p.N - 1) * e.ldr + p.M) * 4), 0x00020000);
-      rpf.slot = pfslot + wave_u * 8192;
-      rpf.row_bytes = (uint32_t)(e.ldr * 4);
-      rpf.voff = (uint32_t)(((long)(n0 + wave_u) * e.ldr + m0 + lane * 4) * 4);       // row r0 = wave (64 threads = one 256-column row)
-      // stores of one phase behind the request: 8 outputs (+ 8 saved pre-activations) + 4 LayerNorm rows (x 2 when they are
-      // float32) + 4 statistics; a tile with rows beyond N skips some of them: it waits for everything
-      rpf.nwait = (n0 + TILE_N <= p.N) ? 8 + (e.z ? 8 : 0) + ((e.io_flags & SMX_IO_LNFY_F32) ? 8 : 4) + (e.lnf_stats ? 4 : 0) : 0;
-      res_prefetch_issue(rpf, 0, 4);
-    }
-  }
-  uint32_t rescarry[RESPF ? 32 : 1];
-  const bool respf = RESPF && osz == 4 && p.epi_simple == 2 && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr &&
-                     !(e.flags & SMX_EPI_ACT_GRAD);
-  if constexpr (RESPF) {
-    if (respf) epilogue_prefetch_res<TILE_M>(p, n0, m0, bz, t, rescarry);
   }
 #pragma unroll 1
   for (int ph = 0; ph < NPH; ++ph) {
@@ -1015,22 +577,7 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
       else if (VEC && p.epi_simple == 2) epilogue_phase<T, 2, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
       else epilogue_phase<T, 2, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     } else if (VEC && p.epi_simple == 1) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
-    else if (VEC && p.epi_simple == 2 && sizeof(T) == 2) {
-      if constexpr (RESPL) {
-        if (respl) {
-          ResPrefetch pf_ = rpf;
-          if (ph == 0) pf_.nwait = 0;                      // (first phase: gamma / beta loads and nothing else sit behind the request)
-          epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2, 0, 256, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t, nullptr,
-                                                                ph + 1 < NPH ? row_in_tile + PH_ROWS : -1, &pf_);
-        } else epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
-      } else if constexpr (RESPF) {
-        if (respf) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2, 0, 256, 1>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t, rescarry,
-                                                                            ph + 1 < NPH ? n0 + row_in_tile + PH_ROWS : -1);
-        else epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
-      } else {
-        epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
-      }
-    }
+    else if (VEC && p.epi_simple == 2 && sizeof(T) == 2) epilogue_phase<T, 4, TILE_N, TILE_M, VEC, 2>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     else epilogue_phase<T, 4, TILE_N, TILE_M, VEC>(p, smem, side, ph, n0 + row_in_tile, m0, bz, split, t);
     if (e.colsum) {
       // column sums of this phase's outputs (the bias gradient of a fused backward): every item was written back to
@@ -1077,34 +624,6 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
   // (PMC WRITE_SIZE 350 MB for 262 MB of output).
   auto run_phases = [&](auto osz_tag, auto lvl_tag) {
     constexpr int OSZ_ = decltype(osz_tag)::value, LVL_ = decltype(lvl_tag)::value;
-    // SIDEPF (128 x 128 bf16 tile, one element-type side input: the act-grad dgrad's saved pre-activation, a bf16 residual): the
-    // side words of BOTH phases are requested here, before the first accumulator dump - in the 32 registers the operand stages
-    // just vacated.  vmcnt retires in order and counts stores: the second phase used to request its words behind the first
-    // phase's stores and wait for those to drain plus a full round trip; now no load of the epilogue sits behind a store.
-    if constexpr (SMX_SIDE_PREFETCH && LVL_ == 2 && OSZ_ == 2 && TILE_N == 128 && TILE_M == 128 && sizeof(T) == 2 && VEC && NPH == 2) {
-      uint32_t sc0[16], sc1[16];
-      epilogue_prefetch_side16<T, TILE_M>(p, n0, m0, bz, t, sc0);
-      epilogue_prefetch_side16<T, TILE_M>(p, n0 + PH_ROWS, m0, bz, t, sc1);
-      for_seq<0, 2>([&](auto pht) __attribute__((always_inline)) {
-        constexpr int ph = decltype(pht)::value;
-        lds_barrier();
-        if (wn == ph) {                                    // (PH_ROWS == WN: wave row ph owns the phase's rows)
-#pragma unroll
-          for (int i = 0; i < FN; ++i)
-#pragma unroll
-            for (int j = 0; j < FM; ++j)
-#pragma unroll
-              for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(smem + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
-                    make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-        }
-        lds_barrier();
-        SMX_STAMP(3 + 2 * ph);
-        epilogue_phase<T, OSZ_, TILE_N, TILE_M, VEC, LVL_, 0, 256, 1>(p, smem, side, ph, n0 + ph * PH_ROWS, m0, bz, split, t, ph == 0 ? sc0 : sc1, -1);
-        SMX_STAMP(4 + 2 * ph);
-      });
-      return;
-    }
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
       lds_barrier();
@@ -1172,14 +691,12 @@ __global__ __launch_bounds__(256, (TILE_N == 256 ? 1 : ((TILE_M > 128 || !A_KC) 
 // Bias gradient (column sums of dZ): one extra MFMA per fragment against a constant all-ones B fragment in the waves
 // that own output columns 0..63 of the first column tile - no LDS reads, no VALU.
 
-#ifndef SMX_TN_BK
-#define SMX_TN_BK 64      // k rows per LDS-DMA stage of the wgrad kernel (64: ring of 2; 32: ring of 4 - measured 3-5 % slower)
-#endif
+constexpr int kTnBk = 64;      // k rows per LDS-DMA stage of the wgrad kernel (64: ring of 2; 32: ring of 4 - measured 3-5 % slower)
 __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(GemmParams p) {
   typedef bf16_t T;
   // ring of NST thin stages (BK k rows each): the DMA of stage it + NST - 1 is issued while stage it is multiplied, i.e.
   // a prefetch distance of (NST - 1) * BK frames in the same 64 KB of LDS
-  constexpr int BK = SMX_TN_BK, NST = 128 / BK, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
+  constexpr int BK = kTnBk, NST = 128 / BK, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
   constexpr int OP_BYTES = BK * TILE * 2, STAGE_BYTES = 2 * OP_BYTES;
   constexpr int NPC = BK / 16;                          // 1 KB pieces per wave, operand and stage
   static_assert(BK == 64 || BK == 32, "ring of 2 x 64 or 4 x 32 k rows");
@@ -1344,17 +861,8 @@ static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
   return check_launch("smx_gemm");
 }
 
-#ifdef SMX_PGEMM_BUILD   // experiment build: the persistent 256 x 256 LDS-DMA kernel of tools/experiments/pgemm.hip (included below)
-bool pgemm_eligible(const GemmParams& p, bool b_kc);
-int launch_pgemm(GemmParams& p, bool b_kc, hipStream_t s);
-#endif
 template <typename T, bool A_KC, bool B_KC>
 static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
-#ifdef SMX_PGEMM_BUILD
-  if constexpr (sizeof(T) == 2 && A_KC) {
-    if (vec && !(p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_LN_FWD)) && pgemm_eligible(p, B_KC)) return launch_pgemm(p, B_KC, s);
-  }
-#endif
   if (p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_LN_FWD)) {
     // fused LayerNorm: the tile must hold whole rows -> the 128 x 256 tile, whatever the grid size
     if constexpr (sizeof(T) == 2 && A_KC) {
@@ -1381,7 +889,7 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
 
   // big tiles once they alone fill the chip (256 CUs x 2 resident blocks); otherwise 64x64 for more blocks
   long big = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * p.batch * p.splits;
-  const int force_small = cfg().gemm_tile64;             // experiment knob
+  constexpr int force_small = 0;
   // wide 128 x 256 tile (2 workgroups per CU, 128 accumulator registers per lane): when it covers the whole output
   // width (M == 256: the activation panel is fetched exactly once and 500 tiles fill the 512 slots in one round at
   // 64000 frames) or when the reduction is long enough for the doubled MFMA-per-LDS-read ratio to matter.
@@ -1391,13 +899,10 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
   // (SMX_GEMM_WIDE=0 / 1024 / 2048 A/B on one box, twice); K = 2048 is a tie and stays wide.  SMX_GEMM_WIDE=<k >= 2>: that minimum K.
   // (Also measured and NOT taken: the wide tile for the up-projection shapes M >= 1024 - C5 +0.3 ms, C2a +1.1, C2b +0.7 -, the pipelined
   //  main loop on the 128 x 128 tile, -DSMX_WIDE_PIPE=2 - C2a +0.6, C5 +2.4, C4 +1.0 -, two register stages, -DSMX_NS_KC=2 - +0.1..0.3.)
-  const int wide_env = cfg().gemm_wide;
-  const bool wide = wide_env >= 2 ? (p.M == 256 || (p.K >= wide_env && p.M <= 512))     // (experiment: SMX_GEMM_WIDE=<min K>)
-                                  : wide_env >= 0 ? wide_env != 0 : (p.M == 256 || (p.K >= 2048 && p.M <= 512));
-  // wgrad-shaped TN GEMMs with both operands on the LDS-DMA ring (gemm_tn_dma_kernel).  SMX_TN_DMA=0 disables it.
-  const int tn_dma_env = cfg().tn_dma;
+  const bool wide = p.M == 256 || (p.K >= 2048 && p.M <= 512);
+  // wgrad-shaped TN GEMMs with both operands on the LDS-DMA ring (gemm_tn_dma_kernel)
   if constexpr (sizeof(T) == 2 && !A_KC && !B_KC) {
-    if (tn_dma_env && vec && p.N % 128 == 0 && p.M % 128 == 0 && p.K % 64 == 0 && p.kchunk % 64 == 0 && p.K >= 64 &&
+    if (vec && p.N % 128 == 0 && p.M % 128 == 0 && p.K % 64 == 0 && p.kchunk % 64 == 0 && p.K >= 64 &&
         p.e.out_mode != SMX_OUT_ATOMIC_F32 && !p.e.colsum && !p.e.res && !p.e.c0 && !p.e.z && !p.ablate &&
         (long)(p.N / 128) * (p.M / 128) * p.batch * p.splits >= 256)
       return launch_tn_dma(p, s);
@@ -1441,10 +946,6 @@ static int launch_dtype(int layout, GemmParams& p, bool vec, hipStream_t s) {
 }
 
 }  // namespace smx
-
-#ifdef SMX_PGEMM_BUILD
-#include "../../tools/experiments/pgemm.hip"
-#endif
 
 using namespace smx;
 
@@ -1544,26 +1045,14 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   // Store policy.  Z (the pre-activation saved for the backward pass) is not read again for a long time: always
   // streamed past the caches.  The output C is consumed by the next kernel: streamed only when it is too large to
   // survive in the 256 MB MALL anyway (measured: FFN up-projection at 64000 frames 118 -> 96 us, no change at 32000).
-  const long nt_bytes = cfg().nt_bytes;
-  const int nt_z = cfg().nt_z;
-  p.nt = (nt_z ? 1 : 0) | (((long)N * M * (long)cs * batch >= nt_bytes) ? 2 : 0);
-#ifndef SMX_LNF_NT
-#define SMX_LNF_NT 1
-#endif
+  constexpr long nt_bytes = 96L << 20;                      // (re-swept in round 4: 50 / 140 / 280 MB lose 0.1-0.9 ms per step)
+  p.nt = 1 | (((long)N * M * (long)cs * batch >= nt_bytes) ? 2 : 0);
   // With a LayerNorm appended (SMX_EPI_LN_FWD) the next kernel reads the LayerNorm output, not C: C (the float32 stream tensor, or
   // the pre-norm tensor the backward pass wants) is streamed whatever its size, so that it does not push the LayerNorm output out
   // of the Infinity Cache (the same finding as smx_layernorm_fwd_pair_x32, rowwise.hip).
-  if (SMX_LNF_NT && (p.e.flags & SMX_EPI_LN_FWD)) p.nt |= 2;
-  // register-domain epilogue (gemm_kernel): 0 off, 1 every eligible epilogue, 2 (default) only without a saved Z - measured
-  // at 64000 frames: bias-only K=256 -> M=1024 102 -> 77 us, NN+bias 91 -> 71 us, but bias+Swish+Z 99 -> 99 us; training
-  // steps unchanged with either setting, forward-only steps -2 % (C2b) / -4 % (C5)
-  const int reg_epi_env = cfg().reg_epi;
-  p.reg_epi = reg_epi_env && (reg_epi_env != 2 || p.e.z == nullptr) && dtype == SMX_BF16 && p.e.out_mode == SMX_OUT_T && !p.e.res && !p.e.c0 && !p.e.colsum &&
-              !(p.e.flags & SMX_EPI_ACT_GRAD) && splits == 1 && p.epi_lds && M % 8 == 0 &&
-              (p.e.z == nullptr || (aligned16(p.e.z) && p.e.ldz % 8 == 0)) && aligned16(C) && ldc % 8 == 0 && strideC % 8 == 0;
-  const int simple_env = cfg().epi_simple;
-  p.epi_simple = 0;
-  if (simple_env && !p.e.c0 && !p.e.colsum) p.epi_simple = (p.e.res || (p.e.flags & SMX_EPI_ACT_GRAD)) ? (simple_env >= 2 ? 2 : 0) : 1;
+  if (p.e.flags & SMX_EPI_LN_FWD) p.nt |= 2;
+  // epilogue instantiation: 1 = no element-wise side input, 2 = one (residual / saved pre-activation), 0 = general (C0 rows, column sums)
+  p.epi_simple = (p.e.c0 || p.e.colsum) ? 0 : ((p.e.res || (p.e.flags & SMX_EPI_ACT_GRAD)) ? 2 : 1);
   p.ablate = cfg().gemm_ablate;                          // (0 unless built with -DSMX_DIAG)
 #ifdef SMX_DIAG
   p.dbg = g_dbg_stamps;
@@ -1710,16 +1199,14 @@ static int wgrad_splits(int rows, int M, int K, int batch) {
   // workgroups to aim for: exactly two per CU.  640 (2.5 per CU) leaves half the CUs with a third workgroup and the
   // launch takes as long as those; measured at 64000 frames: 71 -> 66 us (1024x256), 42 -> 35 us (256x256).
   // (The wide 128x256 tile does not help here: 2.5x slower with two register stages (spills), 71 vs 66 us with one.)
-  const int target_env = cfg().wgrad_blocks;
   // (with the LDS-DMA kernel and the wgrads on a side stream next to the dgrad chain, 384 = 1.5 per CU is the better
   // target for the step: C2b 27.04 -> 26.56 ms; fewer, longer splits also mean less slab traffic for the reduction)
-  const long target = target_env > 0 ? target_env : 384;
+  const long target = 384;
   long s = (target + tiles - 1) / tiles;
   // a whole split lives on one XCD (XCD x owns splits x, x + 8, ..): a split count that is not a multiple of 8 leaves
   // XCDs idle (6 splits of a 3072 x 512 weight: 236 us; 8 splits: 199 us)
   if (s >= 4) s = (s + 7) / 8 * 8;
-  const int min_rows_env = cfg().wgrad_min_rows;
-  const int min_rows = min_rows_env > 0 ? min_rows_env : 512;   // frames per split: fewer, longer splits when the batch is small (slab traffic)
+  const int min_rows = 512;   // frames per split: fewer, longer splits when the batch is small (slab traffic)
   long smax = (rows + min_rows - 1) / min_rows;
   if (s > smax) s = smax;
   return (int)(s < 1 ? 1 : s);

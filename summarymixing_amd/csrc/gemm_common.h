@@ -28,7 +28,6 @@ struct GemmParams {
   long long* dbg;   // debug: per-wave s_memtime stamps (smx_debug_set_timing_buffer)
   int nt;       // non-temporal store hints: 1 = saved pre-activation Z, 2 = the output C
   int epi_simple;  // no element-wise side input, no column sums: the SIMPLE instantiation of epilogue_phase
-  int reg_epi;  // epilogue without element-wise side inputs: math on the accumulator fragments, bf16 staging (gemm_kernel)
   int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
   // implicit 3x3 / stride 2 / reflect-pad-1 patch matrix (gemm_kernel<..., GATHER>): the operand "rows x 9 C" is never
   // materialised - row n = (b, t2, f2), columns [tap * 64, tap * 64 + 64) = the 64 channels of input pixel
@@ -126,9 +125,6 @@ __device__ __forceinline__ void stage_load(uint4 (&reg)[ROWS / 32], const T* bas
 // check is the hardware's (out-of-range rows / k rows return zeros): the main loop's loads need no VALU at all.
 // Requirements (checked on the host, else the generic path): operand span < 2 GB; for a reduce-contiguous operand
 // K % 64 == 0 (a k tail inside a row would read the next row instead of zeros).
-#ifndef SMX_BUFLD_WIDE
-#define SMX_BUFLD_WIDE 1
-#endif
 template <typename T, bool KC, int ROWS>
 struct BufStage {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -463,43 +459,9 @@ __device__ __forceinline__ void st_elems_nt(void* p, const float (&v)[CW]) {
 // still no C0 rows and no column sums - known at compile time, so the side-input registers, their zero fills and the feature selects vanish
 // (PMC: 113 VALU instructions per 8-element item in the general instantiation of a bias+Swish+Z epilogue).
 // PHR / NTHR: rows staged per phase and threads of the workgroup (defaults: the 256-thread tiled kernels of gemm.hip).
-// PFX == 2: the float32 residual rows of a phase arrive by LDS-DMA in a per-lane private slot (no registers while in flight):
-// item k of lane l of wave w sits at slot + w * 8 KB + k * 1 KB + 16 l - each lane reads back exactly the 16 bytes it requested,
-// so no barrier is involved, only this wave's vmcnt.  `slot` is a SEPARATE __shared__ array of the kernel: hipcc's LDS-DMA alias
-// tracking then leaves the staging rows' ds_writes alone (in one array with them it waits vmcnt(0) in front of each).
-struct ResPrefetch {
-  __amdgpu_buffer_rsrc_t rs;       // the residual tensor (range check: rows >= N come back as zeros)
-  char* slot;                      // this wave's 8 KB (wave-uniform)
-  uint32_t voff;                   // byte offset of (row r0, this lane's 4 columns)
-  uint32_t row_bytes;              // ldr * 4
-  int nwait;                       // vector-memory instructions this wave issues per phase BEHIND the request (its stores)
-};
-__device__ __forceinline__ void res_prefetch_issue(const ResPrefetch& pf, int nbase_rows_from_tile0, int rstep) {
-  typedef __attribute__((address_space(3))) void* lds_vp;
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(pf.rs, (lds_vp)(pf.slot + k * 1024), 16, pf.voff,
-                                             (uint32_t)(nbase_rows_from_tile0 + k * rstep) * pf.row_bytes, 0, 0);
-}
-__device__ __forceinline__ void wait_vm_le(int n) {     // wait until at most n (rounded DOWN to a multiple of 4) are outstanding
-#define SMX_W(N) case N / 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); break;
-  switch (min(n, 60) >> 2) {
-    SMX_W(0) SMX_W(4) SMX_W(8) SMX_W(12) SMX_W(16) SMX_W(20) SMX_W(24) SMX_W(28) SMX_W(32) SMX_W(36) SMX_W(40) SMX_W(44) SMX_W(48) SMX_W(52) SMX_W(56) SMX_W(60)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef SMX_W
-}
-
-// PFX (float32 residual only: OSZ == 4, SMX_IO_RES_F32): the residual words of THIS phase arrive in `carry` (requested one phase
-// earlier - by epilogue_prefetch_res before the first phase), and as soon as an item's words are consumed the same registers
-// take the request for the same item of the NEXT phase (rows next_nbase + ...; next_nbase < 0: none).  A phase used to open with
-// its side-input requests and wait one full memory round trip for them - behind the previous phase's stores, because vmcnt
-// retires in order - on both workgroups of the CU at the same time; now that round trip runs under the previous phase's math,
-// stores, LayerNorm and barriers, at no extra registers (the words were dead from their use to the end of the phase).
-template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC, int SIMPLE = 0, int PHR = 0, int NTHR = 256, int PFX = 0>
+template <typename T, int OSZ, int TILE_N, int TILE_M, bool EVEC, int SIMPLE = 0, int PHR = 0, int NTHR = 256>
 __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* smem, const float* side, int ph, int nbase,
-                                               int m0, int bz, int split, int t, uint32_t* carry = nullptr, int next_nbase = -1,
-                                               const ResPrefetch* pf = nullptr) {
+                                               int m0, int bz, int split, int t) {
   constexpr int WN = PHR ? PHR : (TILE_M > 128 ? 32 : TILE_N / 2);   // rows staged per phase (phase_rows() of the kernel)
   constexpr int STG_LD = TILE_M * 4 + 16;
   constexpr int CW = 16 / OSZ;                          // output columns per item (16 bytes)
@@ -538,26 +500,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
     // kernel without side inputs, one per phase with a residual, one per batch with C0. ----
     constexpr int NB = NIT < 2 ? NIT : 2;
     uint32_t sw[NIT][SWR];
-    if constexpr (PFX == 2) {
-      static_assert(OSZ == 4 && NIT == 8 && SWR == 4, "LDS residual prefetch: float32 rows, 8 items per thread");
-      wait_vm_le(pf->nwait);                              // this wave's request for THIS phase has landed
-      // the reads go through inline asm: in front of a VISIBLE ds_read of the DMA's array hipcc waits vmcnt(0) inside this
-      // loop (it cannot count across the back edge) - and with it for the previous phase's stores to drain
-      typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
-      const uint32_t sl = (uint32_t)(uintptr_t)pf->slot + (t & 63) * 16;
-      u32v4 w8[NIT];
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w8[k]) : "v"(sl), "n"(k * 1024) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w8[0]), "+v"(w8[1]), "+v"(w8[2]), "+v"(w8[3]), "+v"(w8[4]), "+v"(w8[5]), "+v"(w8[6]), "+v"(w8[7])::"memory");
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) { sw[k][0] = w8[k].x; sw[k][1] = w8[k].y; sw[k][2] = w8[k].z; sw[k][3] = w8[k].w; }
-      if (next_nbase >= 0) res_prefetch_issue(*pf, next_nbase, RSTEP);   // (uniform) the slot is read: it takes the next phase's rows
-    } else if constexpr (PFX == 1) {
-#pragma unroll
-      for (int k = 0; k < NIT; ++k)
-#pragma unroll
-        for (int q = 0; q < SWR; ++q) sw[k][q] = carry[k * SWR + q];
-    } else if (rf32) {
+    if (rf32) {
       if constexpr (OSZ == 4) {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -697,21 +640,6 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
       if (p.nt & 2) st_elems_nt<OutT, CW>(Cb + ((long)n * p.ldc + m) * OSZ, v); else st_elems<OutT, CW>(Cb + ((long)n * p.ldc + m) * OSZ, v);
     }
     }
-    if constexpr (PFX == 1) {
-      // every item of this phase is stored: the side-input registers are dead until the next phase - request its rows now, so the
-      // round trip runs under the LayerNorm part, the barriers and the accumulator dump that follow (v1 of this prefetch issued
-      // each request right behind its item's use, INSIDE the loop above: +32 registers live there, 35 spilled, 84 -> 115 us)
-      if (next_nbase >= 0) {                             // (uniform)
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-          const int n2 = min(next_nbase + r0 + k * RSTEP, p.N - 1);
-          uint32_t w_[SWR];
-          ld_words<SWR>(Sbf + (long)n2 * lds_ + m, w_);
-#pragma unroll
-          for (int q = 0; q < SWR; ++q) carry[k * SWR + q] = w_[q];
-        }
-      }
-    }
   } else {
     // ragged / unaligned shapes: one element at a time (rolled loops, run-time activation)
     const int nv = min(CW, p.M - m);
@@ -742,47 +670,6 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
         else reinterpret_cast<uint16_t*>(Cb)[(long)n * p.ldc + m + q] = (uint16_t)f32_to_bf16_bits(v);
       }
     }
-  }
-}
-
-// the float32 residual words of the first phase (see PFX above): thread t owns 4 columns of rows r0 + 4 k, k < 8
-template <int TILE_M, int NTHR = 256>
-__device__ __forceinline__ void epilogue_prefetch_res(const GemmParams& p, int nbase, int m0, int bz, int t, uint32_t* carry) {
-  constexpr int CW = 4, CPR = TILE_M / CW, RSTEP = NTHR / CPR, NIT = 32 / RSTEP;
-  const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
-  const float* Sbf = reinterpret_cast<const float*>(p.e.res) + (long)bz * p.sC;
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const int n = min(nbase + r0 + k * RSTEP, p.N - 1);
-    uint32_t w_[CW];
-    ld_words<CW>(Sbf + (long)n * p.e.ldr + m, w_);
-#pragma unroll
-    for (int q = 0; q < CW; ++q) carry[k * CW + q] = w_[q];
-  }
-}
-
-// the element-type side words (residual, or the saved pre-activation of a fused act-grad) of ONE phase of the 128 x 128 tile's
-// bf16 epilogue (OSZ == 2: 8-column items, thread t owns columns (t % 16) * 8 of rows t / 16 + 16 k, k < 4), requested before
-// the phase loop so that no load of the epilogue is ever issued behind a store (PFX == 1 consumption, no reload)
-template <typename T, int TILE_M>
-__device__ __forceinline__ void epilogue_prefetch_side16(const GemmParams& p, int nbase, int m0, int bz, int t, uint32_t (&carry)[16]) {
-  constexpr int CW = 8, CPR = TILE_M / CW, RSTEP = 256 / CPR, NIT = 64 / RSTEP, SW = CW * (int)sizeof(T) / 4;
-  static_assert(NIT * SW == 16, "128-column bf16 tile");
-  const smx_epilogue& e = p.e;
-  const bool ag = (e.flags & SMX_EPI_ACT_GRAD) != 0;
-  const T* Sb = ag ? reinterpret_cast<const T*>(e.z) : (e.res ? reinterpret_cast<const T*>(e.res) + (long)bz * p.sC : nullptr);
-  const long lds_ = ag ? e.ldz : e.ldr;
-  const int c = (t % CPR) * CW, m = m0 + c, r0 = t / CPR;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) carry[q] = 0u;
-  if (Sb == nullptr || m >= p.M) return;
-#pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const int n = min(nbase + r0 + k * RSTEP, p.N - 1);
-    uint32_t w_[SW];
-    ld_words<SW>(Sb + (long)n * lds_ + m, w_);
-#pragma unroll
-    for (int q = 0; q < SW; ++q) carry[k * SW + q] = w_[q];
   }
 }
 

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void masked_sum_stage2(const float* partial, c
 
 static void mm_plan(int B, int T, int D, int nvec, int& DC, int& TS, int& TR) {
   DC = (D + 64 * nvec - 1) / (64 * nvec);
-  const long target = cfg().pool_blocks;
+  const long target = 512;                                 // workgroup target (swept 256 / 512 / 1024 / 2048: +-0.1 % of a step)
   long want = (target + (long)B * DC - 1) / ((long)B * DC);   // ~1024 workgroups (4 per CU) when the rows allow it
   long maxts = (T + 127) / 128;                             // >= 128 rows per block (32 per wave)
   TS = (int)(want < 1 ? 1 : (want > maxts ? maxts : want));

@@ -45,7 +45,6 @@ struct WgGroupParams {
   WgItem it[WG_MAX_ITEMS];
   int nitems, total_tiles, splits, ksteps_per_split, rows;   // rows: the multiple of 64 the DMA ring walks
   int tail;             // 0..63 frames behind `rows`: one or two zero-filled steps of the LAST split's workgroups
-  int pingpong;         // SMX_WGROUP_PP: 1 = upper four waves refill before their MFMAs, lower four after; 2 = + a mid-step barrier
   int ablate;           // debug (env SMX_WGROUP_ABLATE): 1 = no MFMA / fragment reads, 2 = no DMA, 4 = DMA never waited for, 8 = no X pieces
   long long* dbg;       // debug (smx_debug_set_timing_buffer): per workgroup [total cycles, cycles in wait+barrier, realtime ticks, niter]
 };
@@ -174,71 +173,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
   long long t_start = 0, t_wait = 0, r_start = 0;
   if (p.dbg) { t_start = clock64(); r_start = wall_clock64(); }
 #endif
-#ifndef SMX_WGROUP_PIPE
-#define SMX_WGROUP_PIPE 0   // 1 = explicit software pipeline of the 32-frame stages (measured neutral: C2b layer 261 -> 265 us, C2a layer 815 -> 819, steps unchanged; only the 3750-frame C2a launch gains, 104 -> 65 us); 0 = the barrier | fragment burst | MFMA loop below
-#endif
-  // ---- software-pipelined stages (BK = 32, ring of four; product path) ----------------------------------------------------
-  // The loop below opens every stage with a barrier and a burst of fragment reads whose latency nobody hides (all eight waves
-  // are in the same place).  Here the barrier that admits stage itn + 1 sits in the MIDDLE of stage itn: the first sub-step's 8
-  // MFMAs run with the second sub-step's fragment reads between them, then wait (own pieces of stage itn + 1) + barrier, then
-  // the second sub-step's MFMAs with the refill of the freed slot (stage itn + 3) and the fragments of stage itn + 1's first
-  // sub-step between them - the matrix pipe never sees a stage boundary.  sched_barrier(0) after every MFMA pins that order
-  // (what hipcc makes of an unpinned version: gemm.hip, T256P).
-  bool piped = false;
-  if constexpr (SMX_WGROUP_PIPE && BK == 32) {
-    piped = !ab_nomfma && !ab_nodma && !ab_nowait && niter > 0;
-    if (piped) {
-      bf16x8 fa[2][2], fb[2][4];
-      auto read_frag = [&](const char* As, const char* Bs, int kk, int buf, auto ftag) __attribute__((always_inline)) {
-        constexpr int Fi = decltype(ftag)::value;
-        if constexpr (Fi < 2) fa[buf][Fi] = wg_frag(As, wn * 64 + Fi * 32, l31, hi, kk);
-        else fb[buf][Fi - 2] = wg_frag(Bs, wm * 128 + (Fi - 2) * 32, l31, hi, kk);
-      };
-      for (int s = 0; s < NST - 1 && s < niter; ++s) issue(s);
-      if (niter >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
-      else if (niter == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      wg_barrier();
-      for_seq<0, 6>([&](auto f) __attribute__((always_inline)) { read_frag(smem, smem + OP_BYTES, 0, 0, f); });
-      for (int itn = 0; itn < niter; ++itn) {
-        const char* As = smem + (itn % NST) * STAGE_BYTES;
-        const char* Bs = As + OP_BYTES;
-        const char* An = smem + ((itn + 1) % NST) * STAGE_BYTES;
-        const bool more = itn + 1 < niter, refill = itn + NST - 1 < niter;
-        __builtin_amdgcn_sched_barrier(0);
-        // first sub-step: fragments in buffer 0; between the MFMAs the second sub-step's fragments -> buffer 1
-        for_seq<0, 8>([&](auto st) __attribute__((always_inline)) {
-          constexpr int S = decltype(st)::value, i = S / 4, j = S % 4;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
-          if constexpr (S < 6) read_frag(As, Bs, 1, 1, ActTag<S>{});
-          if constexpr (S == 6 || S == 7) { if (do_cs) wg_sum8(bsum[S - 6][0], bsum[S - 6][1], fa[0][S - 6]); }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-        // stage itn + 1 admitted: this wave's pieces of it have landed when at most the pieces of stage itn + 2 are
-        // outstanding; behind the barrier everybody's have, and everybody is past stage itn - 1: its slot takes stage itn + 3
-        if (more) {
-          if (itn + 2 < niter) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        for_seq<0, 8>([&](auto st) __attribute__((always_inline)) {
-          constexpr int S = decltype(st)::value, i = S / 4, j = S % 4;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
-          if constexpr (S < 6) { if (more) read_frag(An, An + OP_BYTES, 0, 0, ActTag<S>{}); }
-          if constexpr (S == 1) { if (refill) issue_part(itn + NST - 1, ActTag<0>{}, ActTag<1>{}); }
-          if constexpr (S == 3) { if (refill) issue_part(itn + NST - 1, ActTag<1>{}, ActTag<1>{}); }
-          if constexpr (S == 6 || S == 7) { if (do_cs) wg_sum8(bsum[S - 6][0], bsum[S - 6][1], fa[1][S - 6]); }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
-    }
-  }
-  if (!piped) {
   for (int s = 0; s < NST - 1 && s < niter; ++s) issue(s);
-  }
-  for (int itn = 0; itn < niter && !piped; ++itn) {
+  for (int itn = 0; itn < niter; ++itn) {
 #ifdef SMX_DIAG
     long long tw0 = 0;
     if (p.dbg) tw0 = clock64();
@@ -260,12 +196,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
     const char* As = smem + (itn % NST) * STAGE_BYTES;
     const char* Bs = As + OP_BYTES;
     if (ab_nomfma) { if (refill) issue(itn + NST - 1); continue; }
-    // ping-pong (p.pingpong): waves w and w + 4 share a SIMD; the upper four issue the whole refill BEFORE their MFMAs, the
-    // lower four AFTER theirs, so that on every SIMD one wave's DMA issue runs beside the other wave's matrix work
-    const bool pp = p.pingpong != 0, pp2 = p.pingpong == 2;
-    if (pp && wave >= 4) {
+    // ping-pong: waves w and w + 4 share a SIMD; the upper four issue the whole refill BEFORE their MFMAs, the lower four
+    // AFTER theirs, so that on every SIMD one wave's DMA issue runs beside the other wave's matrix work
+    if (wave >= 4) {
       if (refill) issue(itn + NST - 1);
-      if (pp2) __builtin_amdgcn_s_barrier();             // (mid-step barrier: the lower four have finished their MFMAs)
     }
     bf16x8 fa[2][2], fb[2][4];                           // fragments double-buffered over the 16-frame sub-steps
 #pragma unroll
@@ -290,20 +224,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
 #pragma unroll
         for (int i = 0; i < 2; ++i) wg_sum8(bsum[i][0], bsum[i][1], fa[cur][i]);
       }
-      if (refill && !pp) {
-        if constexpr (BK == 64) {                        // NPC = 4: one piece pair per sub-step
-          if (kk == 0) issue_part(itn + NST - 1, ActTag<0>{}, ActTag<1>{});
-          else if (kk == 1) issue_part(itn + NST - 1, ActTag<1>{}, ActTag<1>{});
-          else if (kk == 2) issue_part(itn + NST - 1, ActTag<2>{}, ActTag<1>{});
-          else issue_part(itn + NST - 1, ActTag<3>{}, ActTag<1>{});
-        } else {                                         // NPC = 2, two sub-steps
-          if (kk == 0) issue_part(itn + NST - 1, ActTag<0>{}, ActTag<1>{});
-          else issue_part(itn + NST - 1, ActTag<1>{}, ActTag<1>{});
-        }
-      }
     }
-    if (pp && wave < 4) {
-      if (pp2) __builtin_amdgcn_s_barrier();
+    if (wave < 4) {
       if (refill) issue(itn + NST - 1);
     }
   }
@@ -387,15 +309,9 @@ static int wg_splits(int rows, int total_tiles) {
   // (C2b layer) x 11 = 253 fills one round; 92 tiles (d_model 512) x 2 = 184 leaves 28 % of the chip idle, x 3 = 276 needs a
   // second round for 20 workgroups, x 8 = 736 fills 2.9 rounds (C2a step 49.4 -> 48.7 ms).  Every extra slice costs one more
   // fp32 slab per tile (written, read back by smx_reduce_jobs): score = fill of the last round - 1 % per slice.
-  const int target_env = cfg().wgroup_blocks;
   if (total_tiles < 1) total_tiles = 1;
   const int nk = rows / 64;
   const int smax = nk / 8 > 0 ? nk / 8 : 1;                        // at least 8 K steps (512 frames) per slice
-  if (target_env > 0) {
-    int s = target_env / total_tiles;
-    if (s > smax) s = smax;
-    return s < 1 ? 1 : s;
-  }
   // Cost model (microseconds; fitted to the rocprof averages of the four bench configs): a round of up to 256 workgroups
   // walks its 64-frame steps at ~2 us each, and every slice adds one fp32 slab per tile that is written here and read back by
   // smx_reduce_jobs (2 x 256 KB at ~4 TB/s).  At 64 000 frames the slab term is 1-2 % per slice (the "fill - 1 % per slice" rule
@@ -460,23 +376,19 @@ extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items,
   SMX_REQUIRE(splits <= nk, "smx_wgrad_group: more splits than 64-frame steps");
   p.ksteps_per_split = (nk + splits - 1) / splits;
   const int nwork = tiles * splits, per = (nwork + 7) / 8;
-  const int bk_env = cfg().wgroup_bk;                     // (measured in the step: 32 + ping-pong 1)
   const int ablate_env = cfg().wgroup_ablate;             // (0 unless built with -DSMX_DIAG)
   p.ablate = ablate_env;
-  const int pp_env = cfg().wgroup_pp;
-  p.pingpong = pp_env;
 #ifdef SMX_DIAG
   p.dbg = g_wg_dbg;
 #endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess)
       return fail(SMX_ELAUNCH, "smx_wgrad_group: cannot reserve 128 KB of LDS");
     attr_done = true;
   }
-  if (bk_env == 32) hipLaunchKernelGGL(wgrad_group_kernel<32>, dim3(8 * per), dim3(512), 131072, s, p);
-  else hipLaunchKernelGGL(wgrad_group_kernel<64>, dim3(8 * per), dim3(512), 131072, s, p);
+  // 32-frame ring stages (ring of four) with the ping-pong refill order: the measured best of {32, 64} x {none, ping-pong, + mid-step barrier}
+  hipLaunchKernelGGL(wgrad_group_kernel<32>, dim3(8 * per), dim3(512), 131072, s, p);
   return check_launch("smx_wgrad_group");
 }

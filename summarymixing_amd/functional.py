@@ -97,30 +97,15 @@ class _Deferred:
     enabled = os.environ.get("SMX_DEFER_REDUCE", "1") != "0"
     jobs = []        # (src_ptr, dst_ptr, src_stride, ldd, nsrc, rows, cols, alpha)
     pending = set()  # workspace keys written since the last flush
-    side_pending = set()   # keys whose workspaces an ASYNCHRONOUS flush may still be reading on the side stream (until join_side)
     ws = {}          # key -> persistent uint8 workspace
     cache = {}       # tuple(jobs) -> (jobs_dev, starts_dev, njobs, total_blocks)
-    # SMX_WGRAD_STREAM=1: slab GEMMs (and, with SMX_WGRAD_ASYNC, the whole weight-gradient tail) on a side stream.  OFF by default
-    # since the end of round 4: re-measured on the final kernels the main-stream order wins at every size (one utterance 3.94 ->
-    # 3.56 ms, B = 8 x 500 4.86 -> 4.62, recipe batch 7.34 -> 7.23, C2b 19.79 -> 19.63, C2a 50.8 -> 50.4; tools/experiments/
-    # knob_resweep{4,5}.sh) - in round 3, before the flush ordering was fixed, it had been worth 2.6 % of the recipe batch.
-    side_enabled = os.environ.get("SMX_WGRAD_STREAM", "0") != "0"
-    side = {}        # device -> side stream of the slab GEMMs
-    side_used = False
-    # SMX_WGRAD_ASYNC=1: the whole weight-gradient tail of a block (slab GEMMs, grouped wgrad, the reduction jobs) runs on the
-    # side stream - also inside a hipGraph capture - and the main stream only waits for it where somebody reads the gradients
-    # (a bucket hook, the end of the autograd block).  For batches that leave the chip underfilled (the recipe's 3750 frames)
-    # the dgrad chain and the weight gradients then share the CUs.  "auto": on below `async_max_rows` frames.
-    async_mode = os.environ.get("SMX_WGRAD_ASYNC", "auto").lower()
-    async_max_rows = 8192
-    async_now = False    # the block whose backward is running took the asynchronous path (set by its first weight gradient)
     # grouped wgrad: the bf16 weight gradients of a block (= encoder layer) whose dims are multiples of 256 are recorded
     # and computed by ONE smx_wgrad_group launch at the end of the block's backward (SMX_WGRAD_GROUP=0: one slab GEMM each)
     group_enabled = os.environ.get("SMX_WGRAD_GROUP", "1") != "0"
     group = []       # (dz, x, gW, dbias, N, M, K)
     # (from the kernel's minimum of 64 frames: below 2048 the eight slab GEMMs + reductions it replaces are eight latency-bound
     #  launches - C2b training step at B = 1 x 500: 5.36 -> 4.00 ms, C2a at 2 x 375: 7.11 -> 5.43 ms)
-    group_min_rows = int(os.environ.get("SMX_WGRAD_GROUP_MIN_ROWS", "64"))
+    group_min_rows = 64
 
 
 def _evict_workspaces():
@@ -128,7 +113,6 @@ def _evict_workspaces():
     Only called between producers - never while a group launch is being assembled (an eviction from inside
     _launch_groups dropped the only references to workspaces already attached to the launch's items)."""
     flush_deferred()
-    join_side()                                # (an asynchronous reduction may still be reading the workspaces dropped here)
     _Deferred.ws.clear()
     _Deferred.cache.clear()
 
@@ -138,9 +122,6 @@ def deferred_ws(key, nbytes, device, check=True):
     wgrad assembling its items): no flush, no eviction - the caller did both before it started."""
     if check and key in _Deferred.pending:
         flush_deferred()                       # the same parameter twice inside one block: reduce the first use now
-        join_side()                            # (... and finish reading its workspace before the second use rewrites it)
-    elif key in _Deferred.side_pending:        # tied weights across blocks: an earlier, asynchronous flush may still be reading
-        join_side()                            # this workspace on the side stream (ADVICE r03)
     t = _Deferred.ws.get(key)
     if check and t is None and len(_Deferred.ws) >= 2048:
         _evict_workspaces()
@@ -156,29 +137,6 @@ def defer(src_ptr, dst, src_stride, nsrc, rows, cols, alpha=1.0):
     """dst (a (rows, cols) fp32 view or a flat (cols,) one) += alpha * sum_s src[s*src_stride + i*cols + j]."""
     ldd = dst.stride(0) if dst.dim() == 2 else cols
     _Deferred.jobs.append((src_ptr, dst.data_ptr(), src_stride, ldd, nsrc, rows, cols, alpha))
-
-
-def _async_side(N):
-    """Does the weight-gradient tail of an N-frame block run asynchronously on the side stream?"""
-    if not _Deferred.side_enabled or _Deferred.async_mode in ("0", "off"):
-        return False
-    return _Deferred.async_mode in ("1", "on") or N <= _Deferred.async_max_rows
-
-
-def _side_stream(device):
-    side = _Deferred.side.get(device)
-    if side is None:
-        side = _Deferred.side[device] = torch.cuda.Stream(device=device)
-    return side
-
-
-def join_side():
-    """The main stream waits for everything the side stream was given (no-op when nothing was)."""
-    if _Deferred.side_used:
-        for st in _Deferred.side.values():
-            torch.cuda.current_stream().wait_stream(st)
-        _Deferred.side_used = False
-    _Deferred.side_pending.clear()
 
 
 def _launch_groups():
@@ -203,18 +161,7 @@ def _launch_groups():
             for it, (dz, x, gW, dbias, _, M, K) in zip(items, chunk):
                 ws = deferred_ws(gW.data_ptr(), lib.smx_wgrad_group_workspace(M, K, splits), dz.device, check=False)
                 it.workspace = ws.data_ptr()
-            dev = chunk[0][0].device
-            if _async_side(N):
-                main, side = torch.cuda.current_stream(), _side_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    ops.wgrad_group(items, len(chunk), n64, splits)
-                    for dz, x, gW, dbias, _, M, K in chunk:
-                        dz.record_stream(side)
-                        x.record_stream(side)
-                _Deferred.side_used = True
-            else:
-                ops.wgrad_group(items, len(chunk), n64, splits)
+            ops.wgrad_group(items, len(chunk), n64, splits)
             for it, (dz, x, gW, dbias, _, M, K) in zip(items, chunk):
                 defer(it.workspace, gW, M * K, splits, M, K)
                 if dbias is not None:
@@ -226,14 +173,7 @@ def flush_deferred():
         _launch_groups()
     if not _Deferred.jobs:
         _Deferred.pending.clear()
-        _Deferred.async_now = False
         return
-    # asynchronous only for the weight gradients recorded SINCE THE LAST FLUSH: the flag used to survive until the end of the
-    # enclosing autograd block, and forever when _wgrad / flush_deferred were driven outside one - a later, large flush then ran
-    # its reduction on the side stream with nobody joining it (round 4: tests/test_kernels_gpu.py read a gradient half reduced)
-    run_async, _Deferred.async_now = _Deferred.async_now, False
-    if not run_async:
-        join_side()                            # the slab GEMMs of this block ran on the side stream: join it
     key = tuple(_Deferred.jobs)
     ent = _Deferred.cache.get(key)
     if ent is None:
@@ -250,17 +190,7 @@ def flush_deferred():
         starts_dev = torch.tensor(starts, dtype=torch.int32).to(dev)
         ent = (jobs_dev, starts_dev, len(key), starts[-1])
         _Deferred.cache[key] = ent
-    if run_async:
-        # the reduction follows the slab producers on the side stream; the partial rows written on the MAIN stream (LayerNorm,
-        # depthwise conv, column sums) are ordered before it by one event
-        main, side = torch.cuda.current_stream(), _side_stream(ent[0].device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
-        _Deferred.side_used = True
-        _Deferred.side_pending |= _Deferred.pending
-    else:
-        ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
+    ops.reduce_jobs(ent[0], ent[1], ent[2], ent[3])
     _Deferred.jobs = []
     _Deferred.pending.clear()
 
@@ -271,33 +201,16 @@ def _wgrad(dz, x, gW, N, M, K, dbias):
         ops.wgrad(dz, x, gW, N, M, K, dbias=dbias)
         return
     key = gW.data_ptr()
-    if _async_side(N):
-        _Deferred.async_now = True
     if (_Deferred.group_enabled and dz.dtype == torch.bfloat16 and M % 256 == 0 and K % 256 == 0
             and N >= _Deferred.group_min_rows and dz.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
             and dz.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
         if key in _Deferred.pending:
             flush_deferred()                   # the same parameter twice inside one block: finish the first use now
-            join_side()
-        elif key in _Deferred.side_pending:
-            join_side()                        # (tied weights across blocks, asynchronous tail still running)
         _Deferred.pending.add(key)
         _Deferred.group.append((dz, x, gW, dbias, N, M, K))
         return
     ws = deferred_ws(key, L.lib().smx_linear_wgrad_workspace(N, M, K, 1), dz.device)
-    if _Deferred.side_enabled and (_async_side(N) or not torch.cuda.is_current_stream_capturing()):
-        # the slab GEMM only feeds the deferred reduction: run it on a side stream next to the dgrad chain (its reads
-        # overlap the dgrad's epilogue writes instead of queueing behind them)
-        main = torch.cuda.current_stream()
-        side = _side_stream(dz.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            nslabs, stride, boff = ops.wgrad_partial(dz, x, N, M, K, ws, want_bias=dbias is not None)
-        dz.record_stream(side)
-        x.record_stream(side)
-        _Deferred.side_used = True
-    else:
-        nslabs, stride, boff = ops.wgrad_partial(dz, x, N, M, K, ws, want_bias=dbias is not None)
+    nslabs, stride, boff = ops.wgrad_partial(dz, x, N, M, K, ws, want_bias=dbias is not None)
     defer(ws.data_ptr(), gW, stride, nslabs, M, K)
     if dbias is not None:
         defer(ws.data_ptr() + 4 * boff, dbias, M, nslabs, 1, M)
@@ -315,8 +228,6 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         dx = ctx.bwd(dy)
         flush_deferred()        # the block's parameter gradients are final before its bucket is all-reduced
-        join_side()             # (asynchronous weight-gradient tail: the main stream meets it here, at the end of the block)
-        _Deferred.async_now = False
         if ctx.done is not None:
             ctx.done()          # e.g. launch this block's gradient-bucket all-reduce (trainer.FlatAdamW)
         return (dx, None, None) + (None,) * ctx.n
@@ -385,8 +296,8 @@ _LN_FUSE = os.environ.get("SMX_LN_FUSE", "1") != "0"   # A/B knob: LayerNorm bac
 # 48: 11.33 / 10.63, 64: 12.97 / 12.56, 80: 15.20 / 15.74, 96: 16.52 / 17.49, 128: 19.11 / 20.24 -> fuse from 36 864 rows.
 _LN_FUSE_MIN_ROWS = int(os.environ.get("SMX_LN_FUSE_MIN_ROWS", "36864"))
 # norm2 of a Conformer layer + the first LayerNorm of the next layer in ONE pass over the float32 stream (smx_layernorm_fwd_pair_x32;
-# SMX_LN_PAIR=0: two launches - the A/B switch of round 4)
-_LN_PAIR = os.environ.get("SMX_LN_PAIR", "1") != "0"
+# tests switch it off to compare with the two-launch path)
+_LN_PAIR = True
 
 
 def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
@@ -1255,7 +1166,6 @@ def encoder_stack(src, layers, make_layer_run, norm, params, compute_dtype=None)
                 g = b(g)
                 flush_deferred()                       # this layer's parameter gradients are final ...
                 if done is not None:
-                    join_side()                        # (asynchronous tail: the bucket hook reads the gradients)
                     done()                             # ... before its bucket is all-reduced
             return g if g.dtype == xin.dtype else ops.cast(ops.rows2d(g), xin.dtype).view(B, T, d)
         return y.view(B, T, d), bwd

@@ -17,7 +17,7 @@ from ... import ops
 
 import os
 _FUSED_BLOCK1 = True      # A/B knob: smx_conv1_ln_fwd / _bwd instead of im2col + Linear + LayerNorm
-_DIRECT_CONV2 = os.environ.get("SMX_CONV_DIRECT", "1") != "0"            # A/B knob: forward / wgrad GEMMs gather from the input, no im2col
+_DIRECT_CONV2 = True            # A/B knob: forward / wgrad GEMMs gather from the input, no im2col
 _DIRECT_DGRAD = True      # A/B knob: smx_conv2d_s2_dgrad instead of GEMM + col2im
 
 

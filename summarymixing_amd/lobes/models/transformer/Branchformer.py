@@ -23,8 +23,8 @@ from ....nnet.summary_mixing import SummaryMixing
 from ...models.VanillaNN import VanillaNN
 from .Conformer import _LayerNorm
 
-_SPLIT_MERGE_DGRAD = os.environ.get("SMX_SPLIT_MERGE_DGRAD", "1") != "0"   # A/B knob: the merge's input gradient as two GEMMs with fused first steps of their consumers
-_PREACT_LN = os.environ.get("SMX_PREACT_LN", "1") != "0"   # A/B knob: channel_proj1's activation backward inside the CSGU LayerNorm backward
+_SPLIT_MERGE_DGRAD = True   # A/B knob: the merge's input gradient as two GEMMs with fused first steps of their consumers
+_PREACT_LN = True   # A/B knob: channel_proj1's activation backward inside the CSGU LayerNorm backward
 
 
 class _CSGUConv(nn.Module):

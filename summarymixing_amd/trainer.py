@@ -324,7 +324,6 @@ class FlatAdamW:
 
     def step(self, reduce_all=False):
         F.flush_deferred()          # (no-op unless a backward ran outside functional.block)
-        F.join_side()
         if not (self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing()):
             self._rebind_grads()
         if self._collective:

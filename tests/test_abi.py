@@ -73,17 +73,17 @@ def test_config_is_read_once_and_queryable():
     of the environment does not reach the library (no getenv on any call path)."""
     from summarymixing_amd import _lib
     before = _lib.get_config()
-    assert before["epi_simple"] == int(os.environ.get("SMX_EPI_SIMPLE", 2)) and before["wgroup_bk"] in (32, 64)
+    assert before["t256"] == int(os.environ.get("SMX_T256", 1)) and before["ln_tile_rows"] == 128
     assert before["diag_build"] == 0 and before["gemm_ablate"] == 0 and before["wgroup_ablate"] == 0 and before["dwroll_ablate"] == 0
-    old = os.environ.get("SMX_WGROUP_PP")
-    os.environ["SMX_WGROUP_PP"] = "2" if before["wgroup_pp"] != 2 else "0"
+    old = os.environ.get("SMX_T256")
+    os.environ["SMX_T256"] = "2" if before["t256"] != 2 else "0"
     try:
         assert _lib.get_config() == before
     finally:
         if old is None:
-            del os.environ["SMX_WGROUP_PP"]
+            del os.environ["SMX_T256"]
         else:
-            os.environ["SMX_WGROUP_PP"] = old
+            os.environ["SMX_T256"] = old
 
 
 def test_grouped_wgrad_slice_plan_is_size_aware():

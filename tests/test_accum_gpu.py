@@ -48,7 +48,6 @@ def test_accumulated_gradients_equal_the_fused_batch(dtype, tol, kind):
         enc(x, wl).backward(r)
     from summarymixing_amd import functional as F
     F.flush_deferred()
-    F.join_side()
     torch.cuda.synchronize()
     g_seq = opt.flat_g.clone()
 
@@ -57,7 +56,6 @@ def test_accumulated_gradients_equal_the_fused_batch(dtype, tol, kind):
     opt.zero_grad()
     enc(xs, wls).backward(rs)
     F.flush_deferred()
-    F.join_side()
     torch.cuda.synchronize()
     g_fused = opt.flat_g.clone()
     assert float(g_seq.abs().max()) > 0

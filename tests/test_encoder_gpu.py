@@ -270,13 +270,11 @@ def test_layernorm_fusion_threshold_paths_agree():
         assert rel_err(pa[n], pb[n]) <= 3e-2, n
 
 
-@pytest.mark.parametrize("side", [False, True])
-def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch, side):
+def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch):
     """The recipe's own batch shape (10 utterances x 375 frames = 3750 frames, …transducer.yaml:112-126) on the dispatch a user
     gets there: separate LayerNorm kernels (below the fusion threshold: the fixture's lnfuse_default; lnfuse_always runs the same
     batch through the LayerNorm-fused GEMMs), ONE grouped weight-gradient launch per layer whose 3750 %
-    64 = 38-frame ragged tail is staged inside the kernel; side = True: the whole weight-gradient tail on the side stream
-    (SMX_WGRAD_STREAM=1, the default of round 3, opt-in since the end of round 4).  bf16 (the grouped
+    64 = 38-frame ragged tail is staged inside the kernel.  bf16 (the grouped
     kernel's dtype), two layers at d = 256 / d_ffn = 1024 (every weight a multiple of 256): output, dL/dx and EVERY parameter
     gradient against the fp64 oracle's autograd."""
     from oracle import smx_oracle as O
@@ -303,7 +301,6 @@ def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch, side)
     ref = O.conformer_encoder(xr, sd, "", "swish", "SummaryMixing-fast", d, None, pad)
     (ref * r.double()).sum().backward()
 
-    monkeypatch.setattr(F._Deferred, "side_enabled", side)
     calls = []
     real = ops.wgrad_group
     monkeypatch.setattr(ops, "wgrad_group", lambda items, n, rows, splits: (calls.append((n, rows, splits, torch.cuda.current_stream())),
@@ -314,11 +311,10 @@ def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch, side)
     y, _ = enc(xg, src_key_padding_mask=pad.cuda())
     (y.float() * r.cuda()).sum().backward()
     F.flush_deferred()
-    F.join_side()
     torch.cuda.synchronize()
-    # the path under test really ran: one grouped launch per layer over all 3750 frames (ragged tail inside), off the main stream
+    # the path under test really ran: one grouped launch per layer over all 3750 frames (ragged tail inside), on the main stream
     assert len(calls) == 2 and all(c[1] == B * T for c in calls), calls
-    assert all((c[3] != main) == side for c in calls), "side stream used exactly when it is switched on"
+    assert all(c[3] == main for c in calls)
     assert rel_err(y, ref) <= 1e-2, rel_err(y, ref)
     assert rel_err(xg.grad, xr.grad) <= 3e-2, rel_err(xg.grad, xr.grad)
     worst = ("", 0.0)
@@ -356,7 +352,6 @@ def test_layernorm_pair_in_the_stack_equals_two_launches(d, monkeypatch):
         y, _ = enc(xg, src_key_padding_mask=pad)
         (y * r).sum().backward()
         F.flush_deferred()
-        F.join_side()
         torch.cuda.synchronize()
         return y.detach().float(), xg.grad.float(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
     y1, g1, p1 = run(True)

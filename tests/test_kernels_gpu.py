@@ -442,10 +442,12 @@ def test_gemm_large_ragged_shapes_and_epilogues():
 @pytest.mark.parametrize("N", [25600 + 77, 51200])
 def test_gemm_256x256_tile_long_reduction(N):
     """K = 2048 -> 512 (the FFN down-projection's input gradient at d_model = 512) takes the 256 x 256 tile by default when its
-    epilogue has no element-wise side input (one workgroup per CU, software-pipelined K loop, smx_config.t256): NN plain and NT
-    + bias are that path; the heavier epilogues of the same shape (residual, saved Z, activation gradient + column sums) take
-    the 128 x 256 tile (SMX_T256=2 sends them to the big tile too: the CI command of tools/experiments/ab_t256.sh) - all
-    against fp32 torch references, ragged last row tile."""
+    epilogue has no element-wise side input and writes dtype T (one workgroup per CU, software-pipelined K loop,
+    smx_config.t256): NN plain and NT + bias + row mask + dropout with a bf16 output are that path (the NT / B_KC variant of the
+    pipeline and its epilogue on a 256-row tile); the float32-output NT call and the heavier epilogues of the same shape
+    (residual, saved Z, activation gradient + column sums) take the 128 x 256 tile by default - the child process of
+    test_gemm_256x256_tile_every_eligible_shape (SMX_T256=2) sends those to the big tile too.  All against fp32 torch
+    references, ragged last row tile."""
     from summarymixing_amd import _lib as L, ops
     assert L.get_config()["t256"] >= 1
     torch.manual_seed(N)
@@ -467,6 +469,19 @@ def test_gemm_256x256_tile_long_reduction(N):
     y32 = torch.empty(N, M, device="cuda", dtype=torch.float32)
     ops.gemm(L.GEMM_NT, x, w, y32, N, M, K, ops.epilogue(bias=b, out_mode=L.OUT_F32))
     assert rel(y32, zr) < 1e-2
+    # the 256 x 256 tile's NT variant: bias (+ row mask, + dropout), bf16 output, no element-wise side input
+    ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(bias=b, row_mask=mask))
+    assert rel(y, zr * mask[:, None]) < 1e-2
+    yd = torch.empty_like(y)
+    ops.gemm(L.GEMM_NT, x, w, yd, N, M, K, ops.epilogue(bias=b, row_mask=mask, drop=(0.25, 4242)))
+    kept = yd != 0
+    live = (mask[:, None] != 0) & (zr.abs() > 1e-3)
+    rate = 1.0 - float((kept & live).sum()) / float(live.sum())
+    assert abs(rate - 0.25) < 5e-3, rate                   # the counter-based mask at its rate ...
+    assert rel(torch.where(kept, yd.float() * 0.75, zr * mask[:, None]), zr * mask[:, None]) < 1e-2   # ... survivors scaled by 1 / (1 - p)
+    yd2 = torch.empty_like(y)
+    ops.gemm(L.GEMM_NT, x, w, yd2, N, M, K, ops.epilogue(bias=b, row_mask=mask, drop=(0.25, 4242)))
+    assert torch.equal(yd, yd2)                            # ... and a pure function of (seed, element)
     wt = w.t().contiguous()                                # NN: (N, K) x (K, M)
     ops.gemm(L.GEMM_NN, x, wt, y, N, M, K)
     assert rel(y, x.float() @ wt.float()) < 1e-2
@@ -585,11 +600,9 @@ def test_wgrad_group_strided_operands_mixed_bias_and_single_item():
     assert _wgroup_case(4096, [(256, 256)] * 18, [True, False] * 9, seed=3) < 2e-5
 
 
-def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path(monkeypatch):
+def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path():
     from summarymixing_amd import functional as F, ops
-    monkeypatch.setattr(F._Deferred, "side_enabled", True)     # (SMX_WGRAD_STREAM=1: the opt-in side stream / asynchronous tail)
-    _wgroup_case(4096, [(256, 256)], [True], seed=5)      # a small block first: its asynchronous (side-stream) mode must not leak
-    assert not F._Deferred.async_now                       # into the next flush (round 4: it did, and the reduction below raced)
+    _wgroup_case(4096, [(256, 256)], [True], seed=5)      # a small block first (its workspace / job table must not leak into the next flush)
     torch.manual_seed(4)
     rows, M, K = 20000, 512, 256
     dz = (torch.randn(rows, M, device="cuda") * 0.5).bfloat16()
@@ -598,8 +611,7 @@ def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path(monkeypatch):
     for _ in range(2):
         gW, gb = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
         F._wgrad(dz, x, gW, rows, M, K, gb)
-        F.flush_deferred()
-        F.join_side()                                      # (the contract: gradients are final after flush_deferred + join_side)
+        F.flush_deferred()                                 # (the contract: gradients are final after flush_deferred)
         outs.append((gW.clone(), gb.clone()))
     dW, db = (outs[0][0] - outs[1][0]).abs(), (outs[0][1] - outs[1][1]).abs()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (
@@ -610,25 +622,21 @@ def test_wgrad_group_is_bit_reproducible_and_matches_the_slab_path(monkeypatch):
     assert rel_err(outs[0][0], gW2) < 1e-5 and rel_err(outs[0][1], gb2) < 1e-5
 
 
-def test_wgrad_tied_weight_across_asynchronous_flushes(monkeypatch):
-    """The same gradient buffer (a weight shared by two blocks) fed by two small blocks whose weight-gradient tails run on the side
-    stream (SMX_WGRAD_STREAM=1, opt-in since round 4): the second block must not rewrite the slab workspace while the first block's
-    reduction may still be reading it."""
+def test_wgrad_tied_weight_across_flushes():
+    """The same gradient buffer (a weight shared by two blocks) fed by several small blocks, one flush each: the slab workspace is
+    reused, the reductions accumulate."""
     from summarymixing_amd import functional as F
-    monkeypatch.setattr(F._Deferred, "side_enabled", True)
     torch.manual_seed(11)
-    rows, M, K = 2048, 256, 256                            # <= async_max_rows: asynchronous tail
+    rows, M, K = 2048, 256, 256
     gW, gb = torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda")
     ref, refb = torch.zeros(M, K, dtype=torch.float64, device="cuda"), torch.zeros(M, dtype=torch.float64, device="cuda")
     for _ in range(6):
         dz = (torch.randn(rows, M, device="cuda") * 0.5).bfloat16()
         x = torch.randn(rows, K, device="cuda").bfloat16()
         F._wgrad(dz, x, gW, rows, M, K, gb)
-        F.flush_deferred()                                 # (no join: the next block starts while this tail is in flight)
+        F.flush_deferred()
         ref += dz.double().t() @ x.double()
         refb += dz.double().sum(0)
-    F.join_side()
-    assert not F._Deferred.side_pending
     assert rel_err(gW, ref) < 1e-5 and rel_err(gb, refb) < 1e-5
 
 
@@ -778,9 +786,10 @@ def test_layernorm_pair_equals_two_launches(N, D, out_dtype):
     assert rel_err(y2, ref2) < (1e-5 if out_dtype == torch.float32 else 8e-3)
 
 
-def test_register_epilogue_opt_in_still_matches():
-    """SMX_REG_EPI=1 (the register-domain epilogue, default of rounds 2-3, off since round 4) is read once per process: a child
-    process runs side-input-free GEMMs through it against a float64 reference."""
+def test_gemm_256x256_tile_every_eligible_shape():
+    """SMX_T256=2 (read once per process, hence a child): EVERY eligible shape takes the 256 x 256 tile - the residual, saved
+    pre-activation, float32-output, activation-gradient and column-sum epilogues on a 256-row tile with a ragged tail, NT and
+    NN, K = 512 and K = 2048, against float64 references."""
     import os
     import subprocess
     import sys
@@ -788,25 +797,37 @@ def test_register_epilogue_opt_in_still_matches():
 import os, sys, torch
 sys.path.insert(0, os.environ["SMX_ROOT"])
 from summarymixing_amd import _lib as L, ops
-assert L.get_config()["reg_epi"] == 1
+assert L.get_config()["t256"] == 2
 torch.manual_seed(0)
-for N, K, M in ((1000, 256, 512), (4096, 512, 256), (333, 1024, 1024)):
+rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max())
+for N, K, M in ((25600 + 77, 2048, 512), (1000, 512, 256), (4096 + 5, 512, 768)):
     x = torch.randn(N, K, device="cuda").bfloat16()
-    w = (torch.randn(M, K, device="cuda") * 0.05).bfloat16()
+    w = (torch.randn(M, K, device="cuda") * 0.03).bfloat16()
     b = torch.randn(M, device="cuda")
-    y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
-    ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH))
-    ref = torch.nn.functional.silu(x.double() @ w.double().t() + b.double())
-    err = float((y.double() - ref).abs().max() / ref.abs().max())
-    assert err < 1e-2, (N, K, M, err)
-    wn = (torch.randn(K, M, device="cuda") * 0.05).bfloat16()
-    ops.gemm(L.GEMM_NN, x, wn, y, N, M, K)
-    ref = x.double() @ wn.double()
-    err = float((y.double() - ref).abs().max() / ref.abs().max())
-    assert err < 1e-2, (N, K, M, err)
+    mask = (torch.rand(N, device="cuda") > 0.2).to(torch.uint8)
+    res = torch.randn(N, M, device="cuda").bfloat16()
+    res32 = torch.randn(N, M, device="cuda")
+    zr = x.double() @ w.double().t() + b.double()
+    y, z = torch.empty(N, M, device="cuda", dtype=torch.bfloat16), torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(L.GEMM_NT, x, w, y, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, z=z, row_mask=mask, res=res, alpha=0.5))
+    assert rel(z, zr) < 1e-2, (N, K, M, "Z")
+    assert rel(y, res.double() + 0.5 * torch.nn.functional.silu(zr) * mask[:, None]) < 1e-2, (N, K, M, "NT res + swish + Z")
+    y32 = torch.empty(N, M, device="cuda", dtype=torch.float32)
+    ops.gemm(L.GEMM_NT, x, w, y32, N, M, K, ops.epilogue(bias=b, res=res32, alpha=0.5, out_mode=L.OUT_F32))
+    assert rel(y32, res32.double() + 0.5 * zr) < 1e-2, (N, K, M, "NT fp32 residual stream")
+    wt = w.t().contiguous()
+    ops.gemm(L.GEMM_NN, x, wt, y, N, M, K, ops.epilogue(res=res))
+    assert rel(y, x.double() @ wt.double() + res.double()) < 1e-2, (N, K, M, "NN res")
+    zz = torch.randn(N, M, device="cuda").bfloat16()
+    cs = torch.zeros(M, device="cuda")
+    ops.gemm(L.GEMM_NN, x, wt, y, N, M, K, ops.epilogue(act=L.ACT_SWISH, act_grad_z=zz, colsum=cs))
+    zf = zz.double(); sg = torch.sigmoid(zf)
+    assert rel(y, (x.double() @ wt.double()) * (sg * (1 + zf * (1 - sg)))) < 1e-2, (N, K, M, "act-grad")
+    ysum = y.double().sum(0)
+    assert float((cs.double() - ysum).abs().max() / ysum.abs().max()) < 2e-2, (N, K, M, "colsum")
 print("OK")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SMX_REG_EPI="1", SMX_ROOT=root), capture_output=True,
+    p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SMX_T256="2", SMX_ROOT=root), capture_output=True,
                        text=True, timeout=300)
     assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]

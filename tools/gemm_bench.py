@@ -10,7 +10,8 @@ from summarymixing_amd import _lib as L, ops  # noqa: E402
 from bench import time_kernel  # noqa: E402
 
 
-def run(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
+def build(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
+    """-> (launch closure, algorithmic bytes per launch) of one smx_gemm shape + epilogue."""
     x = torch.randn(N, K, device="cuda").to(dtype)
     es = 2 if dtype == torch.bfloat16 else 4
     if layout == "NT":
@@ -92,6 +93,11 @@ def run(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
         g = torch.zeros(K, M, device="cuda")
         fn = lambda: ops.wgrad(x, x2, g, N, K, M)
         nbytes = (N * K + N * M) * es + K * M * 4
+    return fn, nbytes
+
+
+def run(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
+    fn, nbytes = build(N, K, M, layout, dtype, epi)
     ops.prof_start()                                     # the name this launch carries in bench.py's in-step records
     fn()
     rec = ops.prof_stop()
