@@ -36,6 +36,10 @@ struct GemmParams {
   long g_npix;                        // B * g_T * g_F
 };
 
+// the LayerNorm-fused row-complete tiles (gemm_ln256.hip / gemm_ln512.hip)
+int launch_ln_fused_256(GemmParams& p, bool b_kc, hipStream_t s);
+int launch_ln_fused_512(GemmParams& p, bool b_kc, hipStream_t s);
+
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<bf16_t> { static constexpr int BK = 64; static constexpr int VPT = 8; };
 template <> struct ElemTraits<float>  { static constexpr int BK = 32; static constexpr int VPT = 4; };
@@ -692,13 +696,20 @@ __device__ __forceinline__ void stage_colsum(const uint4 (&reg)[ROWS / 32], floa
 }
 
 
-// ---- LayerNorm fused into the epilogue of a row-complete tile (TILE_M = 256 = the LayerNorm width, 256 threads, 32 staged
-// rows per phase): thread t owns the 8 columns c = (t % 32) * 8 of rows r0 + 8 k (r0 = t / 32, k < 4), so the 32 lanes of a
-// half wave hold one row and row reductions are five xor-shuffles inside the half wave. ----
+// ---- LayerNorm fused into the epilogue of a row-complete tile (TILE_M = W = the LayerNorm width, 256 or 512; 256 threads, 32
+// staged rows per phase): thread t owns the 8 columns c = (t % LPR) * 8 of rows r0 + RSTEP k (LPR = W / 8 lanes per row, r0 =
+// t / LPR, RSTEP = 256 / LPR), so the 32 lanes of a half wave (W = 256) or the 64 lanes of a wave (W = 512) hold one row and
+// row reductions are five / six xor-shuffles. ----
 __device__ __forceinline__ float half_wave_sum(float v) {
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+template <int W>
+__device__ __forceinline__ float ln_row_sum(float v) {
+  static_assert(W == 256 || W == 512, "LayerNorm-fused tiles: 256 or 512 columns");
+  if constexpr (W == 512) v += __shfl_xor(v, 32, 64);
+  return half_wave_sum(v);
 }
 
 // SMX_EPI_LN_BWD: staged rows = g (gradient of the LayerNorm output).  dX = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
@@ -707,13 +718,15 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // variants with a fused activation of the LayerNorm and / or an activation gradient in the second output - a separate
 // instantiation, they cost ~20 registers the plain one does not have)
 // XF32: the LayerNorm input ln_x is float32 (SMX_IO_LNX_F32, fp32 residual stream); everything else stays dtype T
-template <typename T, bool EXT, bool XF32 = false>
+template <typename T, bool EXT, bool XF32 = false, int W = 256>
 __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const char* smem, const float* lng, int nbase0, int t,
                                                      float (&dgam)[8], float (&dbet)[8]) {
-  constexpr int STG_LD = 256 * 4 + 16, NIT = 2, RSTEP = 8, SW = 8 * (int)sizeof(T) / 4, SWX = XF32 ? 8 : SW;
+  constexpr int LPR = W / 8, RSTEP = 256 / LPR, NIT = 16 / RSTEP;   // (W = 256: two rows in flight per thread, W = 512: four)
+  constexpr int STG_LD = W * 4 + 16, SW = 8 * (int)sizeof(T) / 4, SWX = XF32 ? 8 : SW;
+  constexpr float INVW = 1.f / W;
   typedef typename std::conditional<XF32, float, T>::type XT;
   const smx_epilogue& e = p.e;
-  const int c = (t & 31) * 8, r0 = t >> 5;
+  const int c = (t % LPR) * 8, r0 = t / LPR;
   const XT* X = reinterpret_cast<const XT*>(e.ln_x);
   const T* R = reinterpret_cast<const T*>(e.res);
   float gam[8];
@@ -784,7 +797,7 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
     if (EXT && lact != SMX_ACT_NONE) {                   // (uniform; beta sits behind gamma in LDS)
       float ag[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) ag[q] = (xh[q] - st[k].x) * st[k].y * gam[q] + lng[256 + c + q];
+      for (int q = 0; q < 8; ++q) ag[q] = (xh[q] - st[k].x) * st[k].y * gam[q] + lng[W + c + q];
       switch (lact) {
         case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, 8>(v, ag); break;
         case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, 8>(v, ag); break;
@@ -803,8 +816,8 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
       s1 += v[q];
       s2 += v[q] * xh[q];
     }
-    s1 = half_wave_sum(s1) * (1.f / 256.f);
-    s2 = half_wave_sum(s2) * (1.f / 256.f);
+    s1 = ln_row_sum<W>(s1) * INVW;
+    s2 = ln_row_sum<W>(s2) * INVW;
     if (!rok) continue;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = st[k].y * (v[q] - s1 - xh[q] * s2) + rf[q];
@@ -824,7 +837,7 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
           default: break;
         }
       }
-      if (thresh2) dropout_apply<8>(v, seed2, (uint64_t)n * 256 + c, thresh2, scale2);
+      if (thresh2) dropout_apply<8>(v, seed2, (uint64_t)n * W + c, thresh2, scale2);
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] *= mk;
       st_elems<T, 8>(reinterpret_cast<T*>(e.ln_dx2) + (long)n * e.ln_lddx2 + c, v);
@@ -835,15 +848,16 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
 
 // SMX_EPI_LN_FWD: the ordinary epilogue_phase has written the finished output values back to their staged slots (each
 // thread re-reads its own items: no barrier); lnf_y = act(LN(row) * gamma + beta), lnf_stats = (mean, rstd).
-template <typename T>
+template <typename T, int W = 256>
 __device__ __forceinline__ void epilogue_phase_lnfwd(const GemmParams& p, const char* smem, const float* lng, int nbase, int t) {
-  constexpr int STG_LD = 256 * 4 + 16, NIT = 4, RSTEP = 8;
+  constexpr int LPR = W / 8, RSTEP = 256 / LPR, NIT = 32 / RSTEP, STG_LD = W * 4 + 16;
+  constexpr float INVW = 1.f / W;
   const smx_epilogue& e = p.e;
-  const int c = (t & 31) * 8, r0 = t >> 5;
+  const int c = (t % LPR) * 8, r0 = t / LPR;
   float gam[8], bet[8];
 #pragma unroll
   for (int q4 = 0; q4 < 2; ++q4) {
-    const float4 g4 = *reinterpret_cast<const float4*>(lng + c + 4 * q4), b4 = *reinterpret_cast<const float4*>(lng + 256 + c + 4 * q4);
+    const float4 g4 = *reinterpret_cast<const float4*>(lng + c + 4 * q4), b4 = *reinterpret_cast<const float4*>(lng + W + c + 4 * q4);
     gam[4 * q4] = g4.x; gam[4 * q4 + 1] = g4.y; gam[4 * q4 + 2] = g4.z; gam[4 * q4 + 3] = g4.w;
     bet[4 * q4] = b4.x; bet[4 * q4 + 1] = b4.y; bet[4 * q4 + 2] = b4.z; bet[4 * q4 + 3] = b4.w;
   }
@@ -859,11 +873,11 @@ __device__ __forceinline__ void epilogue_phase_lnfwd(const GemmParams& p, const 
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) s += v[q];
-    const float mean = half_wave_sum(s) * (1.f / 256.f);
+    const float mean = ln_row_sum<W>(s) * INVW;
     float qq = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) { v[q] -= mean; qq += v[q] * v[q]; }
-    const float rstd = rsqrtf(half_wave_sum(qq) * (1.f / 256.f) + e.lnf_eps);
+    const float rstd = rsqrtf(ln_row_sum<W>(qq) * INVW + e.lnf_eps);
     if (n >= p.N) continue;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = v[q] * rstd * gam[q] + bet[q];
@@ -881,7 +895,7 @@ __device__ __forceinline__ void epilogue_phase_lnfwd(const GemmParams& p, const 
     } else {
       st_elems<T, 8>(reinterpret_cast<T*>(e.lnf_y) + (long)n * e.lnf_ldy + c, v);
     }
-    if (e.lnf_stats && (t & 31) == 0) *reinterpret_cast<float2*>(e.lnf_stats + 2 * (long)n) = make_float2(mean, rstd);
+    if (e.lnf_stats && (t % LPR) == 0) *reinterpret_cast<float2*>(e.lnf_stats + 2 * (long)n) = make_float2(mean, rstd);
   }
 }
 
@@ -909,19 +923,20 @@ __device__ __forceinline__ bf16x8 frag_tr_swz(const char* lds, int r, int kk, in
   return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
 }
 
-// fragment of a reduce-strided stage with 512-byte k rows (256 columns), granule XOR 4 * (k & 3): the LDS-DMA weight ring of
-// gemm_kernel (NN) - the image of wgrad_group.hip.  cbase = first column of the 32-column fragment.
-__device__ __forceinline__ bf16x8 frag_tr_swz512(const char* lds, int cbase, int lane, int kk) {
+// fragment of a reduce-strided stage with RB-byte k rows (RB / 2 columns, no pad), 16-byte granule g of row k stored at granule
+// g ^ (4 * (k & 3)) - the image of wgrad_group.hip: the four k rows a 16-lane group of ds_read_b64_tr_b16 touches land on four
+// disjoint bank quadruples whatever the row length (RB a multiple of 256 B).  cbase = first column of the 32-column fragment.
+template <int RB>
+__device__ __forceinline__ bf16x8 frag_tr_swz_rb(const char* lds, int cbase, int lane, int kk) {
   typedef short short4_t __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) short4_t* lds_s4;
   const int li = lane & 15, g1 = (lane >> 4) & 1, hi = lane >> 5;
   const int k = kk * 16 + hi * 8 + (li >> 2);           // (k & 3) == li >> 2; row k + 4 has the same swizzle
   const int c = cbase + g1 * 16 + (li & 3) * 4;
-  const char* p0 = lds + k * 512 + ((((c >> 3) ^ ((li >> 2) << 2)) << 4) + (c & 7) * 2);
+  const char* p0 = lds + k * RB + ((((c >> 3) ^ ((li >> 2) << 2)) << 4) + (c & 7) * 2);
   const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
-  const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * 512));
+  const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * RB));
   const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
   return __builtin_bit_cast(bf16x8, make_uint4(ua.x, ua.y, ub.x, ub.y));
 }
-
 }  // namespace smx

@@ -640,14 +640,15 @@ def test_wgrad_tied_weight_across_flushes():
     assert rel_err(gW, ref) < 1e-5 and rel_err(gb, refb) < 1e-5
 
 
-# ---- LayerNorm fused into the 128 x 256 GEMM epilogue (SMX_EPI_LN_BWD / SMX_EPI_LN_FWD) -------------------------------
-@pytest.mark.parametrize("N,K", [(4096, 1024), (33000 + 77, 512), (200, 256)])
-def test_gemm_epilogue_layernorm_backward(N, K):
-    """dgrad GEMM whose epilogue runs the LayerNorm backward (rows complete in the 128 x 256 tile): dX, the second output
+# ---- LayerNorm fused into the row-complete GEMM epilogues (SMX_EPI_LN_BWD / SMX_EPI_LN_FWD): 128 x 256 tile (d_model = 256, two
+# workgroups per CU) and 128 x 512 tile (d_model = 512, one workgroup per CU on the software-pipelined main loop) ------------------
+@pytest.mark.parametrize("D", [256, 512])
+@pytest.mark.parametrize("N,K", [(4096, 1024), (33000 + 77, 512), (200, 256), (2000 + 13, 2048)])
+def test_gemm_epilogue_layernorm_backward(N, K, D):
+    """dgrad GEMM whose epilogue runs the LayerNorm backward (rows complete in the tile): dX, the second output
     alpha * D(dX) * mask, and the per-tile dgamma / dbeta partial rows against fp64 torch math."""
     from summarymixing_amd import _lib as L, ops
     torch.manual_seed(N)
-    D = 256
     dz = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
     W = (torch.randn(K, D, device="cuda") * 0.05).bfloat16()           # NN: dh = dz @ W
     x = torch.randn(N, D, device="cuda").bfloat16()
@@ -680,12 +681,12 @@ def test_gemm_epilogue_layernorm_backward(N, K):
     assert rel_err(dx2, torch.where(keep, ref / 0.75, torch.zeros_like(ref))) < 1e-2
 
 
-@pytest.mark.parametrize("N,K,act", [(4096, 1024, 0), (33000 + 77, 512, 2), (200, 256, 0)])
-def test_gemm_epilogue_layernorm_forward(N, K, act):
+@pytest.mark.parametrize("D", [256, 512])
+@pytest.mark.parametrize("N,K,act", [(4096, 1024, 0), (33000 + 77, 512, 2), (200, 256, 0), (2000 + 13, 2048, 0)])
+def test_gemm_epilogue_layernorm_forward(N, K, act, D):
     """NT GEMM + bias + residual whose epilogue appends y = act(LN(C)) and the row statistics."""
     from summarymixing_amd import _lib as L, ops
     torch.manual_seed(N + 1)
-    D = 256
     a = torch.randn(N, K, device="cuda").bfloat16()
     W = (torch.randn(D, K, device="cuda") * 0.05).bfloat16()
     b = torch.randn(D, device="cuda")
@@ -704,12 +705,58 @@ def test_gemm_epilogue_layernorm_forward(N, K, act):
     assert rel_err(stats[:, 0], mean[:, 0]) < 1e-3 and rel_err(stats[:, 1], (var + 1e-5).rsqrt()[:, 0]) < 1e-3
 
 
-def test_gemm_epilogue_layernorm_backward_with_activations():
+@pytest.mark.parametrize("D", [256, 512])
+@pytest.mark.parametrize("N,K", [(4096 + 9, 1024), (300, 2048)])
+@pytest.mark.parametrize("layout", ["NT", "NN"])
+def test_gemm_epilogue_layernorm_float32_stream(N, K, layout, D):
+    """The autocast forms (float32 residual stream next to bf16 operands), both weight layouts: forward = Linear + bias +
+    dropout-free alpha + float32 residual -> float32 stream tensor, LayerNorm appended (bf16 for the next GEMM, or float32 when
+    the LayerNorm output is itself the stream: norm2); backward = dgrad + LayerNorm backward with a float32 LayerNorm input."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(N + K + D)
+    a = torch.randn(N, K, device="cuda").bfloat16()
+    W = (torch.randn(D, K, device="cuda") * 0.05).bfloat16()                 # (D, K): NT weight; NN takes its transpose (K, D)
+    Wop, lay = (W, L.GEMM_NT) if layout == "NT" else (W.t().contiguous(), L.GEMM_NN)
+    b = torch.randn(D, device="cuda")
+    res = torch.randn(N, D, device="cuda")
+    gamma, beta = torch.randn(D, device="cuda") * 0.5 + 1.0, torch.randn(D, device="cuda") * 0.1
+    cref = res.double() + 0.5 * (a.double() @ W.double().t() + b.double())
+    mean, var = cref.mean(1, keepdim=True), cref.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    yref = (cref - mean) * rstd * gamma.double() + beta.double()
+    for ydt in (torch.bfloat16, torch.float32):
+        c = torch.empty(N, D, device="cuda")
+        y = torch.empty(N, D, device="cuda", dtype=ydt)
+        stats = torch.empty(N, 2, device="cuda")
+        ops.gemm(lay, a, Wop, c, N, D, K, ops.epilogue(bias=b, res=res, alpha=0.5, out_mode=L.OUT_F32, ln_fwd=(gamma, beta, y, stats, 1e-5, L.ACT_NONE)))
+        assert rel_err(c, cref) < 1e-2 and rel_err(y, yref) < 1e-2, (ydt, rel_err(c, cref), rel_err(y, yref))
+        assert rel_err(stats[:, 0], mean[:, 0]) < 2e-3 and rel_err(stats[:, 1], rstd[:, 0]) < 2e-3
+    # backward: the LayerNorm input is the float32 stream, gradients bf16
+    x32 = torch.randn(N, D, device="cuda") * 2 + 0.3
+    xd = x32.double()
+    mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    st = torch.cat([mean, rstd], 1).float().contiguous()
+    rg = torch.randn(N, D, device="cuda").bfloat16()
+    tr = L.lib().smx_gemm_ln_tile_rows()
+    partial = torch.zeros((N + tr - 1) // tr, 2, D, device="cuda")
+    dx = torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(lay, a, Wop, dx, N, D, K, ops.epilogue(res=rg, ln_bwd=(x32, st, gamma, partial, None, None, None, True)))
+    g = a.double() @ W.double().t()
+    xh = (xd - mean) * rstd
+    gg = g * gamma.double()
+    ref = rstd * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)) + rg.double()
+    assert rel_err(dx, ref) < 1e-2, rel_err(dx, ref)
+    assert rel_err(partial[:, 0].sum(0), (g * xh).sum(0)) < 2e-3 and rel_err(partial[:, 1].sum(0), g.sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("D", [256, 512])
+def test_gemm_epilogue_layernorm_backward_with_activations(D):
     """The extended instantiation: the LayerNorm had a fused activation (y = swish(LN(x)), conv module LN2) and the second
     output carries the consumer's activation backward (dX2 = dX * swish'(z), the cell's merge)."""
     from summarymixing_amd import _lib as L, ops
     torch.manual_seed(11)
-    N, K, D = 3000, 256, 256
+    N, K = 3000, 256
     dz = (torch.randn(N, K, device="cuda") * 0.5).bfloat16()
     W = (torch.randn(K, D, device="cuda") * 0.05).bfloat16()
     x = torch.randn(N, D, device="cuda").bfloat16()
@@ -786,10 +833,12 @@ def test_layernorm_pair_equals_two_launches(N, D, out_dtype):
     assert rel_err(y2, ref2) < (1e-5 if out_dtype == torch.float32 else 8e-3)
 
 
-def test_gemm_256x256_tile_every_eligible_shape():
+@pytest.mark.parametrize("mode", ["2", "3"])
+def test_gemm_256x256_tile_every_eligible_shape(mode):
     """SMX_T256=2 (read once per process, hence a child): EVERY eligible shape takes the 256 x 256 tile - the residual, saved
     pre-activation, float32-output, activation-gradient and column-sum epilogues on a 256-row tile with a ragged tail, NT and
-    NN, K = 512 and K = 2048, against float64 references."""
+    NN, K = 512 and K = 2048, against float64 references.  SMX_T256=3: the M = 512 shapes of the same list on the row-complete
+    128 x 512 tile of the LayerNorm-fused kernels (its plain-epilogue instantiation)."""
     import os
     import subprocess
     import sys
@@ -797,10 +846,10 @@ def test_gemm_256x256_tile_every_eligible_shape():
 import os, sys, torch
 sys.path.insert(0, os.environ["SMX_ROOT"])
 from summarymixing_amd import _lib as L, ops
-assert L.get_config()["t256"] == 2
+assert L.get_config()["t256"] == int(os.environ["SMX_T256"])
 torch.manual_seed(0)
 rel = lambda a, r: float((a.double() - r).abs().max() / r.abs().max())
-for N, K, M in ((25600 + 77, 2048, 512), (1000, 512, 256), (4096 + 5, 512, 768)):
+for N, K, M in ((25600 + 77, 2048, 512), (1000, 512, 256), (4096 + 5, 512, 768), (300, 128, 512), (5000 + 3, 1024, 512)):
     x = torch.randn(N, K, device="cuda").bfloat16()
     w = (torch.randn(M, K, device="cuda") * 0.03).bfloat16()
     b = torch.randn(M, device="cuda")
@@ -828,6 +877,6 @@ for N, K, M in ((25600 + 77, 2048, 512), (1000, 512, 256), (4096 + 5, 512, 768))
 print("OK")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SMX_T256="2", SMX_ROOT=root), capture_output=True,
+    p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SMX_T256=mode, SMX_ROOT=root), capture_output=True,
                        text=True, timeout=300)
     assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
