@@ -16,12 +16,15 @@ collective is the bucketed gradient all-reduce (RCCL over xGMI).
 backward passes accumulate, the reference's fit_batch) or fused (trainer.fuse_microbatches: ONE batch, same gradients).
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
-  "roofline":     roofline of the DOMINANT kernel family of the step (largest share of the in-step kernel time; the
-                  wgrad slab GEMM at the default config), aggregated over its launches inside one instrumented step:
-                  algorithmic bytes / HIP-event time on the stream each launch ran on.  At d_model <= 512 every GEMM of
-                  this model sits below the bf16 ridge (~312 flop/B), so the bound reported is HBM; the MFMA fraction
-                  is given alongside,
-  "roofline_kernels": the top kernels (family + shape) of that instrumented step: calls/step, in-step avg us,
+  "roofline":     roofline of the DOMINANT KERNEL of the step: the kernel symbol (template instantiation, as rocprofv3 --stats
+                  names it; GEMMs: asked of the library, smx_gemm_plan_query) with the largest share of the in-step kernel time,
+                  averaged over all its launches inside one instrumented step: algorithmic bytes / HIP-event time on the stream
+                  each launch ran on; its shapes, `traffic` (committed PMC passes, call-weighted) and the co-dominant symbols
+                  ride along.  At d_model <= 512 every GEMM of this model sits below the bf16 ridge (~312 flop/B), so the bound
+                  reported is HBM; the MFMA fraction is given alongside,
+  "roofline_symbols": the same figures for the top symbols; "roofline_family": the gemm_kernel template as a whole,
+  "roofline_step": the whole step: sum of the algorithmic bytes / flops of EVERY launch over the timed ms_per_step,
+  "roofline_kernels": the top launches by shape + epilogue of that instrumented step: calls/step, in-step avg us,
                   algorithmic bytes per launch, fraction of the HBM roof, share of the step's kernel time,
   "roofline_isolated": the FFN up-projection GEMM and the dominant wgrad shape timed back to back in isolation,
   "roofline_pool": HBM roofline of the masked-mean pool kernel at the long-utterance point (config 5),
@@ -143,22 +146,22 @@ def pmc_traffic_bytes(tag):
     return None
 
 
-def roofline_step_kernels(step, dtype, top=8):
+def roofline_step_kernels(step, dtype, ms_per_step, top=8):
     """One instrumented (eager) step: every libsmx launch bracketed by HIP events on its own stream (ops._PROF).
-    -> (roofline of the dominant kernel family, top kernels by in-step time)."""
+    -> (roofline of the DOMINANT KERNEL SYMBOL - the instantiation a profiler lists first by share of the step's kernel time -,
+        top launches by shape, per-symbol table, roofline of the gemm_kernel template as a whole, whole-step roofline)."""
     from summarymixing_amd import ops
     step()                                   # settle allocations of the eager path
     torch.cuda.synchronize()
     ops.prof_start()
     step()
-    recs = ops.prof_stop()
+    recs = ops.prof_stop(symbols=True)
     es = 2 if dtype == torch.bfloat16 else 4
     mfma_peak = 2500.0 if es == 2 else 157.3
     total_ms = sum(r[3] for r in recs) or 1e-9
-    by_name, by_fam = {}, {}
-    for name, nb, fl, ms in recs:
-        fam = name.split(" (")[0].split(" dW")[0]
-        for d, k in ((by_name, name), (by_fam, fam)):
+    by_name, by_sym = {}, {}
+    for name, nb, fl, ms, sym in recs:
+        for d, k in ((by_name, name), (by_sym, sym)):
             e = d.setdefault(k, [0, 0.0, 0.0, 0.0])
             e[0] += 1; e[1] += nb; e[2] += fl; e[3] += ms
 
@@ -174,6 +177,7 @@ def roofline_step_kernels(step, dtype, top=8):
         tag = full.split(" +")[0].split(":")[0].strip()
         k["traffic"] = (pmc_traffic_bytes(full + " [") or
                         pmc_traffic_bytes("wgrad_group bf16 (8 weights" if tag.startswith("wgrad_group bf16 (8 weights") else tag))
+    symbols = [entry(k, e) for k, e in sorted(by_sym.items(), key=lambda kv: -kv[1][3])[:top]]
 
     def roof_of(label, e, d):
         intensity = e[2] / max(e[1], 1.0)
@@ -185,23 +189,35 @@ def roofline_step_kernels(step, dtype, top=8):
                 "launch_us": d["in_step_avg_us"], "calls_per_step": e[0], "share_of_step_kernel_time": d["share_of_step_kernel_time"],
                 "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "arithmetic_intensity_flop_per_byte": intensity,
                 "mfma_TFLOPs": d["mfma_TFLOPs"], "mfma_frac": d["frac_mfma"], "step_kernel_time_ms": total_ms}
-    # headline: the ONE kernel (symbol family + shape + epilogue) with the largest share of the step's kernel time
-    top_name, top_e = max(by_name.items(), key=lambda kv: kv[1][3])
-    roof = roof_of(top_name + " (in-step average over its launches, HIP events on the launch stream)", top_e, kernels[0])
-    roof["traffic"], roof["traffic_note"] = kernels[0].get("traffic"), PMC_NOTE
-    # kernels whose share of the step is within 10 % (relative) of the headline kernel's: which of them leads changes from box
-    # to box (round 3: the grouped wgrad at 0.61 of the roof and the act-grad dgrad at 0.35 were 12.48 % / 12.40 % of the step),
-    # so they are printed next to the headline instead of silently swapping places
-    top_share = kernels[0]["share_of_step_kernel_time"]
-    roof["co_dominant"] = [
-        {"kernel": k["kernel"], "share_of_step_kernel_time": k["share_of_step_kernel_time"], "launch_us": k["in_step_avg_us"],
-         "calls_per_step": k["calls_per_step"], "frac_hbm": k["frac_hbm"], "frac_mfma": k["frac_mfma"],
-         "algorithmic_bytes_per_launch": k["algorithmic_bytes_per_launch"], "traffic": k.get("traffic")}
-        for k in kernels[1:] if k["share_of_step_kernel_time"] >= 0.9 * top_share]
-    # and, for continuity with rounds 1-2, the dominant kernel FAMILY aggregated over all its shapes
-    fam, e = max(by_fam.items(), key=lambda kv: kv[1][3])
-    fam_roof = roof_of(f"{fam} (all {e[0]} in-step launches of the family)", e, entry(fam, e))
-    return roof, kernels, fam_roof
+    # headline: the kernel SYMBOL (the template instantiation rocprofv3 --stats lists first) with the largest share of the step's
+    # kernel time, averaged over all its launches (its shapes differ: algorithmic bytes and duration are launch averages)
+    top_sym, top_e = max(by_sym.items(), key=lambda kv: kv[1][3])
+    roof = roof_of(top_sym + " (in-step average over its launches, HIP events on the launch stream)", top_e, symbols[0])
+    shapes = sorted(((n, e) for n, e in by_name.items() if any(r[0] == n and r[4] == top_sym for r in recs)), key=lambda kv: -kv[1][3])
+    roof["shapes"] = [{"launch": n.strip(), "calls_per_step": e[0], "in_step_avg_us": e[3] * 1e3 / e[0], "algorithmic_bytes_per_launch": e[1] / e[0],
+                       "traffic": pmc_traffic_bytes(n.strip() + " [")} for n, e in shapes]
+    tr = [(sh["traffic"], sh["calls_per_step"]) for sh in roof["shapes"]]
+    roof["traffic"] = (sum(t * c for t, c in tr) / sum(c for _, c in tr)) if tr and all(t for t, _ in tr) else None
+    roof["traffic_note"] = PMC_NOTE + "; call-weighted mean over the symbol's shapes"
+    # symbols whose share is within 10 % (relative) of the headline's are listed next to it (which of two close ones leads changes
+    # from box to box), and every other symbol of the top of the table follows in `roofline_symbols`
+    top_share = symbols[0]["share_of_step_kernel_time"]
+    roof["co_dominant"] = [dict(k) for k in symbols[1:] if k["share_of_step_kernel_time"] >= 0.9 * top_share]
+    # the gemm_kernel TEMPLATE as a whole (every instantiation, every shape): the family view of rounds 1-4
+    fe = [0, 0.0, 0.0, 0.0]
+    for k, e in by_sym.items():
+        if k.startswith("gemm_kernel<"):
+            for i in range(4):
+                fe[i] += e[i]
+    fam_roof = roof_of(f"gemm_kernel<...> template (all {fe[0]} in-step launches of its instantiations)", fe, entry("gemm_kernel", fe)) if fe[0] else None
+    # the whole step: every launch's algorithmic bytes and flops over the TIMED step (not the instrumented one)
+    tb, tf = sum(r[1] for r in recs), sum(r[2] for r in recs)
+    step_roof = {"ms_per_step": ms_per_step, "launches": len(recs), "algorithmic_bytes": tb, "flops": tf,
+                 "hbm_GBps_algorithmic": tb / (ms_per_step * 1e-3) / 1e9, "frac_hbm": tb / (ms_per_step * 1e-3) / 1e9 / 8000.0,
+                 "mfma_TFLOPs": tf / (ms_per_step * 1e-3) / 1e12, "frac_mfma": tf / (ms_per_step * 1e-3) / 1e12 / mfma_peak,
+                 "note": "sum over every libsmx launch of one step (ops.gemm / row-kernel byte models, SURVEY 8(d)) / the timed ms_per_step; "
+                         "peaks 8000 GB/s and the dense MFMA peak of the dtype"}
+    return roof, kernels, symbols, fam_roof, step_roof
 
 
 def roofline_wgrad(cfg, dtype):
@@ -697,7 +713,8 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             if train and world == 1 and not force_dist:
-                out["roofline"], out["roofline_kernels"], out["roofline_family"] = roofline_step_kernels(step, dtype)
+                (out["roofline"], out["roofline_kernels"], out["roofline_symbols"], out["roofline_family"],
+                 out["roofline_step"]) = roofline_step_kernels(step, dtype, dt / args.steps * 1e3)
                 out["roofline_isolated"] = [roofline_wgrad(cfg, dtype), roofline_gemm(cfg, dtype)]
             else:
                 out["roofline"] = roofline_gemm(cfg, dtype)

@@ -123,6 +123,13 @@ size_t smx_gemm_colsum_workspace(int N, int M);
 int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb,
              int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K, int batch, int splits,
              const smx_epilogue* epi, void* stream);
+/* Which kernel would smx_gemm launch for these arguments?  Same checks, same dispatch, no launch: fills `plan` with the template
+ * arguments of the instantiation as a profiler prints them - gemm_kernel<T, a_kc, b_kc, tile_n, tile_m, vec, lnf, gather>
+ * (kernel 0) or gemm_tn_dma_kernel (kernel 1).  bench.py groups its in-step records by this symbol. */
+typedef struct smx_gemm_plan { int32_t kernel, a_kc, b_kc, tile_n, tile_m, vec, lnf, gather; } smx_gemm_plan;
+int smx_gemm_plan_query(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb,
+                        int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K, int batch, int splits,
+                        const smx_epilogue* epi, smx_gemm_plan* plan);
 
 /* Weight gradient of a (batched) Linear: dW[b] (M x K) += alpha * dZ[b]^T X[b], reducing over `rows` frames
  * (dZ (rows, M), X (rows, K), both row-major).  Split-K over the frame dimension into fp32 slabs in `workspace`

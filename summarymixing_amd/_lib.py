@@ -39,6 +39,11 @@ class WgradItem(ctypes.Structure):
 WGRAD_GROUP_MAX = 16
 
 
+class GemmPlan(ctypes.Structure):
+    """smx_gemm_plan of include/smx.h: the instantiation smx_gemm would launch (smx_gemm_plan_query)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("kernel", "a_kc", "b_kc", "tile_n", "tile_m", "vec", "lnf", "gather")]
+
+
 class Epilogue(ctypes.Structure):
     _fields_ = [("bias", c_vp), ("bias_batch_stride", c_i64),
                 ("c0", c_vp), ("ldc0", c_i64), ("c0_mode", ctypes.c_int32), ("c0_div", ctypes.c_int32),
@@ -64,6 +69,8 @@ SIGNATURES = {
     "smx_last_error": (ctypes.c_char_p, []),
     "smx_gemm": (c_i, [c_i, c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i,
                        ctypes.POINTER(Epilogue), c_vp]),
+    "smx_gemm_plan_query": (c_i, [c_i, c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i, c_i, c_i, c_i, c_i,
+                                  ctypes.POINTER(Epilogue), ctypes.POINTER(GemmPlan)]),
     "smx_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
     "smx_gemm_ln_fused_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "smx_linear_wgrad_workspace": (c_sz, [c_i, c_i, c_i, c_i]),

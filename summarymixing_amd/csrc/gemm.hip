@@ -198,6 +198,7 @@ static int launch_tn_dma(GemmParams& p, hipStream_t s) {
   p.tiles_m = p.M / 128;
   dim3 grid(p.tiles_n * p.tiles_m, p.batch);
   if (p.splits > 1) grid = dim3(8 * p.tiles_n * p.tiles_m * p.batch * ((p.splits + 7) / 8), 1);
+  if (plan_only(p, 1, false, false, 128, 128, true, 0, 0)) return SMX_OK;
   hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(256), 0, s, p);
   return check_launch("smx_gemm");
 }
@@ -209,6 +210,7 @@ static int launch_tile(GemmParams& p, bool vec, hipStream_t s) {
   p.tiles_m = (p.M + TM - 1) / TM;
   dim3 grid(p.tiles_n * p.tiles_m, p.batch);
   if (p.splits > 1) grid = dim3(8 * p.tiles_n * p.tiles_m * p.batch * ((p.splits + 7) / 8), 1);
+  if (plan_only(p, 0, A_KC, B_KC, TN, TM, vec, 0, 0)) return SMX_OK;
   if (vec) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, TN, TM, true>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, TN, TM, false>), grid, dim3(256), 0, s, p);
   if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
@@ -270,6 +272,7 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
         (long)((p.N + 255) / 256) * (p.M / 256) >= (t256 >= 2 ? 1 : 200)) {
       p.tiles_n = (p.N + 255) / 256;
       p.tiles_m = p.M / 256;
+      if (plan_only(p, 0, A_KC, B_KC, 256, 256, true, 0, 0)) return SMX_OK;
       hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, 256, 256, true>), dim3(p.tiles_n * p.tiles_m, 1), dim3(256), 0, s, p);
       if (p.e.colsum) launch_colsum_partials(reinterpret_cast<const float*>(p.e.workspace), p.tiles_n, p.M, p.e.colsum, s);
       return check_launch("smx_gemm");
@@ -304,7 +307,7 @@ extern "C" void smx_debug_set_timing_buffer(void* p) { g_dbg_stamps = reinterpre
 static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B,
                      int64_t ldb, int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K,
                      int batch, int splits, int64_t split_stride, const smx_epilogue* epi, void* stream,
-                     float* acolsum = nullptr, const int* conv = nullptr) {
+                     float* acolsum = nullptr, const int* conv = nullptr, smx_gemm_plan* plan = nullptr) {
   // conv = {T, F}: the K-contiguous operand A (NT) / the reduce-strided operand B (TN) is the implicit 3x3-stride-2 patch matrix
   // of the channels-last tensor (batches, T, F, 64) behind that pointer (bf16, 64 channels: gemm_kernel<..., GATHER>)
   SMX_REQUIRE(A && B && C, "smx_gemm: null operand");
@@ -406,6 +409,7 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
 #endif
   p.epoch = p.e.epoch;
   p.acolsum = acolsum;
+  p.plan = plan;
   p.dthresh = (unsigned)((double)p.e.drop_p * 4294967296.0);
   SMX_REQUIRE(p.e.drop_cols >= 0 && p.e.drop_cols <= M && p.e.drop_cols % 8 == 0, "smx_gemm: drop_cols must be a multiple of 8 in [0, M]");
   p.drop_cols = p.e.drop_cols > 0 ? p.e.drop_cols : M;
@@ -421,6 +425,7 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
     p.tiles_n = (p.N + 127) / 128;
     p.tiles_m = (p.M + 127) / 128;
     dim3 grid(p.tiles_n * p.tiles_m, p.batch);
+    if (plan_only(p, 0, true, true, 128, 128, true, 0, conv[0] == -3 ? 3 : 4)) return SMX_OK;
     if (conv[0] == -3) hipLaunchKernelGGL((gemm_kernel<float, true, true, 128, 128, true, 0, 3>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<float, true, true, 128, 128, true, 0, 4>), grid, dim3(256), 0, s, p);
     return check_launch("smx_gemm (folded DFT operand)");
@@ -438,6 +443,7 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
     p.tiles_m = (p.M + 63) / 64;
     dim3 grid(p.tiles_n * p.tiles_m, 1);
     if (p.splits > 1) grid = dim3(8 * p.tiles_n * p.tiles_m * ((p.splits + 7) / 8), 1);
+    if (plan_only(p, 0, layout == SMX_GEMM_NT, layout == SMX_GEMM_NT, 64, 64, true, 0, layout == SMX_GEMM_NT ? 1 : 2)) return SMX_OK;
     if (layout == SMX_GEMM_NT) hipLaunchKernelGGL((gemm_kernel<bf16_t, true, true, 64, 64, true, 0, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, 64, 64, true, 0, 2>), grid, dim3(256), 0, s, p);
     return check_launch("smx_gemm (implicit conv operand)");
@@ -460,6 +466,16 @@ extern "C" int smx_gemm(int layout, int dtype, const void* A, int64_t lda, int64
                         int batch, int splits, const smx_epilogue* epi, void* stream) {
   return gemm_impl(layout, dtype, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, N, M, K, batch, splits, 0, epi,
                    stream);
+}
+
+extern "C" int smx_gemm_plan_query(int layout, int dtype, const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb,
+                                   int64_t strideB, void* C, int64_t ldc, int64_t strideC, int N, int M, int K, int batch, int splits,
+                                   const smx_epilogue* epi, smx_gemm_plan* plan) {
+  SMX_REQUIRE(plan, "smx_gemm_plan_query: null plan");
+  memset(plan, 0, sizeof(*plan));
+  plan->kernel = -1;                                     // (nothing to launch: N == 0 or M == 0)
+  return gemm_impl(layout, dtype, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, N, M, K, batch, splits, 0, epi, nullptr, nullptr,
+                   nullptr, plan);
 }
 
 // ---- weight gradient: dW[b] (M x K) += alpha * dZ[b]^T X[b], reduce over `rows` frames ------------------------

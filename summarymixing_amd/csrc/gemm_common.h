@@ -29,12 +29,20 @@ struct GemmParams {
   int nt;       // non-temporal store hints: 1 = saved pre-activation Z, 2 = the output C
   int epi_simple;  // no element-wise side input, no column sums: the SIMPLE instantiation of epilogue_phase
   int ablate;   // debug (env SMX_GEMM_ABLATE): 1 = no epilogue stores, 2 = no MFMA, 4 = no global loads
+  smx_gemm_plan* plan;   // smx_gemm_plan_query: the dispatch records the instantiation here instead of launching it
   // implicit 3x3 / stride 2 / reflect-pad-1 patch matrix (gemm_kernel<..., GATHER>): the operand "rows x 9 C" is never
   // materialised - row n = (b, t2, f2), columns [tap * 64, tap * 64 + 64) = the 64 channels of input pixel
   // (reflect(2 t2 + dt - 1), reflect(2 f2 + df - 1)) of the channels-last tensor (B, g_T, g_F, 64)
   int g_T, g_F, g_T2, g_F2, gather;   // gather: 0 none, 1 A operand (NT), 2 B operand (TN)
   long g_npix;                        // B * g_T * g_F
 };
+
+// every launch site of the GEMM dispatch: `if (plan_only(p, ...)) return SMX_OK;` in front of its hipLaunchKernelGGL
+inline bool plan_only(GemmParams& p, int kernel, bool a_kc, bool b_kc, int tn, int tm, bool vec, int lnf, int gather) {
+  if (!p.plan) return false;
+  *p.plan = smx_gemm_plan{kernel, a_kc, b_kc, tn, tm, vec, lnf, gather};
+  return true;
+}
 
 // the LayerNorm-fused row-complete tiles (gemm_ln256.hip / gemm_ln512.hip)
 int launch_ln_fused_256(GemmParams& p, bool b_kc, hipStream_t s);
@@ -699,17 +707,13 @@ __device__ __forceinline__ void stage_colsum(const uint4 (&reg)[ROWS / 32], floa
 // ---- LayerNorm fused into the epilogue of a row-complete tile (TILE_M = W = the LayerNorm width, 256 or 512; 256 threads, 32
 // staged rows per phase): thread t owns the 8 columns c = (t % LPR) * 8 of rows r0 + RSTEP k (LPR = W / 8 lanes per row, r0 =
 // t / LPR, RSTEP = 256 / LPR), so the 32 lanes of a half wave (W = 256) or the 64 lanes of a wave (W = 512) hold one row and
-// row reductions are five / six xor-shuffles. ----
-__device__ __forceinline__ float half_wave_sum(float v) {
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// a row reduction stays inside the half wave / the wave. ----
+// (the sums run on the DPP path, smx_common.h: no LDS round trips)
 template <int W>
 __device__ __forceinline__ float ln_row_sum(float v) {
   static_assert(W == 256 || W == 512, "LayerNorm-fused tiles: 256 or 512 columns");
-  if constexpr (W == 512) v += __shfl_xor(v, 32, 64);
-  return half_wave_sum(v);
+  if constexpr (W == 512) return wave_sum_dpp(v);
+  else return half_wave_sum_dpp(v);
 }
 
 // SMX_EPI_LN_BWD: staged rows = g (gradient of the LayerNorm output).  dX = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
@@ -861,41 +865,179 @@ __device__ __forceinline__ void epilogue_phase_lnfwd(const GemmParams& p, const 
     gam[4 * q4] = g4.x; gam[4 * q4 + 1] = g4.y; gam[4 * q4 + 2] = g4.z; gam[4 * q4 + 3] = g4.w;
     bet[4 * q4] = b4.x; bet[4 * q4 + 1] = b4.y; bet[4 * q4 + 2] = b4.z; bet[4 * q4 + 3] = b4.w;
   }
+  // BR rows at a time: their reductions are independent dependency chains (one workgroup per CU on the 512-wide tile: nobody else
+  // hides them); the 256-wide kernels, two per CU at the 256-register budget, keep one row live
+  constexpr int BR = W == 512 ? 4 : 1;
 #pragma unroll
-  for (int k = 0; k < NIT; ++k) {
-    const int r = r0 + k * RSTEP, n = nbase + r;
-    float v[8];
+  for (int kb = 0; kb < NIT; kb += BR) {
+    float v[BR][8], mean[BR], rstd[BR];
 #pragma unroll
-    for (int q4 = 0; q4 < 2; ++q4) {
-      const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
-      v[4 * q4] = a4.x; v[4 * q4 + 1] = a4.y; v[4 * q4 + 2] = a4.z; v[4 * q4 + 3] = a4.w;
+    for (int k = 0; k < BR; ++k) {
+      const int r = r0 + (kb + k) * RSTEP;
+#pragma unroll
+      for (int q4 = 0; q4 < 2; ++q4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
+        v[k][4 * q4] = a4.x; v[k][4 * q4 + 1] = a4.y; v[k][4 * q4 + 2] = a4.z; v[k][4 * q4 + 3] = a4.w;
+      }
     }
-    float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += v[q];
-    const float mean = ln_row_sum<W>(s) * INVW;
-    float qq = 0.f;
+    for (int k = 0; k < BR; ++k) {
+      float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { v[q] -= mean; qq += v[q] * v[q]; }
-    const float rstd = rsqrtf(ln_row_sum<W>(qq) * INVW + e.lnf_eps);
-    if (n >= p.N) continue;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = v[q] * rstd * gam[q] + bet[q];
-    switch (e.lnf_act) {
-      case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 8>(v); break;
-      case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 8>(v); break;
-      case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(v); break;
-      case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 8>(v); break;
-      default: break;
+      for (int q = 0; q < 8; ++q) s += v[k][q];
+      mean[k] = ln_row_sum<W>(s) * INVW;
     }
-    if (e.io_flags & SMX_IO_LNFY_F32) {                  // (uniform) the LayerNorm output IS the fp32 residual stream (norm2)
-      float* yp = reinterpret_cast<float*>(e.lnf_y) + (long)n * e.lnf_ldy + c;
-      *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
-      st_elems<T, 8>(reinterpret_cast<T*>(e.lnf_y) + (long)n * e.lnf_ldy + c, v);
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+      float qq = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { v[k][q] -= mean[k]; qq += v[k][q] * v[k][q]; }
+      rstd[k] = rsqrtf(ln_row_sum<W>(qq) * INVW + e.lnf_eps);
     }
-    if (e.lnf_stats && (t % LPR) == 0) *reinterpret_cast<float2*>(e.lnf_stats + 2 * (long)n) = make_float2(mean, rstd);
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+      const int n = nbase + r0 + (kb + k) * RSTEP;
+      if (n >= p.N) continue;
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y[q] = v[k][q] * rstd[k] * gam[q] + bet[q];
+      switch (e.lnf_act) {
+        case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 8>(y); break;
+        case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 8>(y); break;
+        case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(y); break;
+        case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 8>(y); break;
+        default: break;
+      }
+      if (e.io_flags & SMX_IO_LNFY_F32) {                  // (uniform) the LayerNorm output IS the fp32 residual stream (norm2)
+        float* yp = reinterpret_cast<float*>(e.lnf_y) + (long)n * e.lnf_ldy + c;
+        *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
+        *reinterpret_cast<float4*>(yp + 4) = make_float4(y[4], y[5], y[6], y[7]);
+      } else {
+        st_elems<T, 8>(reinterpret_cast<T*>(e.lnf_y) + (long)n * e.lnf_ldy + c, y);
+      }
+      if (e.lnf_stats && (t % LPR) == 0) *reinterpret_cast<float2*>(e.lnf_stats + 2 * (long)n) = make_float2(mean[k], rstd[k]);
+    }
+  }
+}
+
+// ---- 128 x 512 tile, LayerNorm forward on the float32 residual stream (SMX_IO_RES_F32, float32 C), ONE pass per phase -------------
+// The generic pair above (epilogue_phase with 4-column float32 items, write-back to the staged slots, barrier, epilogue_phase_lnfwd
+// with 8-column items) costs a second LDS round trip and a barrier per phase, and with ONE workgroup per CU nothing else runs
+// meanwhile.  Here thread t owns the 8 columns c = (t & 63) * 8 of rows r0 + 4 k (r0 = t >> 6, k < 8: a wave = a row) for the bias /
+// activation / dropout / mask / residual part AND the LayerNorm: the finished values never leave the registers, the row statistics
+// are two DPP sums per row.  The residual rows of the phase are requested BEFORE the accumulator dump (ln512_request_res), so their
+// round trip runs under the dump and its two barriers.  Eligibility (checked by the kernel, else the generic pair): SIMPLE == 2
+// epilogue (bias / activation / saved Z / dropout / row factors / one residual), float32 residual and output.
+__device__ __forceinline__ void ln512_request_res(const GemmParams& p, int nbase, int t, uint32_t (&rw)[8][8]) {
+  const float* R = reinterpret_cast<const float*>(p.e.res);
+  const int c = (t & 63) * 8, r0 = t >> 6;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long n = min(nbase + r0 + 4 * k, p.N - 1);
+    const uint4 a_ = *reinterpret_cast<const uint4*>(R + n * p.e.ldr + c), b_ = *reinterpret_cast<const uint4*>(R + n * p.e.ldr + c + 4);
+    rw[k][0] = a_.x; rw[k][1] = a_.y; rw[k][2] = a_.z; rw[k][3] = a_.w; rw[k][4] = b_.x; rw[k][5] = b_.y; rw[k][6] = b_.z; rw[k][7] = b_.w;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, const char* smem, const float* side, const float* lng, int ph,
+                                                        int nbase, int t, uint32_t (&rw)[8][8]) {
+  constexpr int W = 512, STG_LD = W * 4 + 16, BR = 4;
+  constexpr float INVW = 1.f / W;
+  const smx_epilogue& e = p.e;
+  const int c = (t & 63) * 8, r0 = t >> 6;
+  const uint32_t dthresh = p.dthresh;
+  const float dscale = p.dscale;
+  const uint64_t dseed = dthresh ? epoch_seed(e.drop_seed, p.epoch) : 0;
+  const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
+  const bool do_drop = dthresh && c < p.drop_cols;         // (drop_cols is a multiple of 8: an item is wholly inside or outside)
+  const float* mkrow = side + W + ph * 32;
+  T* Zb = e.z ? reinterpret_cast<T*>(e.z) : nullptr;
+  float* Cb = reinterpret_cast<float*>(p.C);
+  float gam[8], bet[8], bia[8];
+#pragma unroll
+  for (int q4 = 0; q4 < 2; ++q4) {
+    const float4 g4 = *reinterpret_cast<const float4*>(lng + c + 4 * q4), b4 = *reinterpret_cast<const float4*>(lng + W + c + 4 * q4);
+    const float4 s4 = *reinterpret_cast<const float4*>(side + c + 4 * q4);
+    gam[4 * q4] = g4.x; gam[4 * q4 + 1] = g4.y; gam[4 * q4 + 2] = g4.z; gam[4 * q4 + 3] = g4.w;
+    bet[4 * q4] = b4.x; bet[4 * q4 + 1] = b4.y; bet[4 * q4 + 2] = b4.z; bet[4 * q4 + 3] = b4.w;
+    bia[4 * q4] = s4.x; bia[4 * q4 + 1] = s4.y; bia[4 * q4 + 2] = s4.z; bia[4 * q4 + 3] = s4.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) settle(rw[k][q]);         // the phase's residual rows have landed: no load below, the stores stream
+#pragma unroll
+  for (int kb = 0; kb < 8; kb += BR) {
+    float v[BR][8], mean[BR], rstd[BR];
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+      const int r = r0 + 4 * (kb + k), n = nbase + r;
+#pragma unroll
+      for (int q4 = 0; q4 < 2; ++q4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
+        v[k][4 * q4] = a4.x; v[k][4 * q4 + 1] = a4.y; v[k][4 * q4 + 2] = a4.z; v[k][4 * q4 + 3] = a4.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[k][q] += bia[q];       // (zeros when there is no bias)
+      if (Zb && n < p.N) { if (p.nt & 1) st_elems_nt<T, 8>(Zb + (long)n * e.ldz + c, v[k]); else st_elems<T, 8>(Zb + (long)n * e.ldz + c, v[k]); }
+      switch (e.act) {
+        case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 8>(v[k]); break;
+        case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 8>(v[k]); break;
+        case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(v[k]); break;
+        case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 8>(v[k]); break;
+        default: break;
+      }
+      if (do_drop) dropout_apply<8>(v[k], dseed, (uint64_t)n * p.drop_cols + c, dthresh, dscale);
+      if (has_mk) {
+        const float mk = mkrow[r];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[k][q] *= mk;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[k][q] += __uint_as_float(rw[kb + k][q]);
+      if (n < p.N) {
+        float* cp = Cb + (long)n * p.ldc + c;
+        if (p.nt & 2) { st_elems_nt<float, 4>(cp, reinterpret_cast<const float(&)[4]>(v[k][0])); st_elems_nt<float, 4>(cp + 4, reinterpret_cast<const float(&)[4]>(v[k][4])); }
+        else { st_elems<float, 4>(cp, reinterpret_cast<const float(&)[4]>(v[k][0])); st_elems<float, 4>(cp + 4, reinterpret_cast<const float(&)[4]>(v[k][4])); }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[k][q];
+      mean[k] = wave_sum_dpp(s) * INVW;
+    }
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+      float qq = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { v[k][q] -= mean[k]; qq += v[k][q] * v[k][q]; }
+      rstd[k] = rsqrtf(wave_sum_dpp(qq) * INVW + e.lnf_eps);
+    }
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+      const int n = nbase + r0 + 4 * (kb + k);
+      if (n >= p.N) continue;
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y[q] = v[k][q] * rstd[k] * gam[q] + bet[q];
+      switch (e.lnf_act) {
+        case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 8>(y); break;
+        case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 8>(y); break;
+        case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(y); break;
+        case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 8>(y); break;
+        default: break;
+      }
+      if (e.io_flags & SMX_IO_LNFY_F32) {                  // (uniform) the LayerNorm output IS the fp32 residual stream (norm2)
+        float* yp = reinterpret_cast<float*>(e.lnf_y) + (long)n * e.lnf_ldy + c;
+        *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
+        *reinterpret_cast<float4*>(yp + 4) = make_float4(y[4], y[5], y[6], y[7]);
+      } else {
+        st_elems<T, 8>(reinterpret_cast<T*>(e.lnf_y) + (long)n * e.lnf_ldy + c, y);
+      }
+      if (e.lnf_stats && (t & 63) == 0) *reinterpret_cast<float2*>(e.lnf_stats + 2 * (long)n) = make_float2(mean[k], rstd[k]);
+    }
   }
 }
 

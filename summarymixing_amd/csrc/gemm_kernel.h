@@ -556,10 +556,18 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
       for (int q = 0; q < 8; ++q) dgam[q] = dbet[q] = 0.f;
     }
   }
+  // ROW512 + LayerNorm forward on the float32 stream: the one-pass phase of gemm_common.h (epilogue_phase_ln512fwd)
+  constexpr bool LN512F = ROW512 && LNF == 2;
+  const bool ln512f = LN512F && osz == 4 && p.epi_simple == 2 && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr &&
+                      !(e.flags & SMX_EPI_ACT_GRAD) && p.batch == 1;
+  uint32_t resw[LN512F ? 8 : 1][8];
 #pragma unroll 1
   for (int ph = 0; ph < NPH; ++ph) {
-    lds_barrier();
     const int row_in_tile = ph * PH_ROWS;
+    if constexpr (LN512F) {
+      if (ln512f) ln512_request_res(p, n0 + row_in_tile, t, resw);   // (in flight under the dump and its barriers)
+    }
+    lds_barrier();
     if (wn == row_in_tile / WN) {                         // the wave row that owns these accumulator rows
       const int i0 = (row_in_tile % WN) / 32;              // first 32-row fragment of the phase
 #pragma unroll
@@ -577,6 +585,12 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
     }
     lds_barrier();
     if (ph < 2) SMX_STAMP(3 + 2 * ph);
+    if constexpr (LN512F) {
+      if (ln512f) {
+        epilogue_phase_ln512fwd<T>(p, smem, side, lng, ph, n0 + row_in_tile, t, resw);
+        continue;
+      }
+    }
     if constexpr (LNB) {                                  // the LayerNorm backward replaces the ordinary epilogue
       epilogue_phase_lnbwd<T, (LNF & 3) == 3, (LNF & 4) != 0, TILE_M>(p, smem, lng, n0 + row_in_tile, t, dgam, dbet);
       continue;

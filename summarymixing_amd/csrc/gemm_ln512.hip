@@ -14,6 +14,7 @@ static int launch_ln(GemmParams& p, hipStream_t s) {
   const dim3 grid(p.tiles_n), block(256);
   const bool lnb = (p.e.flags & SMX_EPI_LN_BWD) != 0, lnf = (p.e.flags & SMX_EPI_LN_FWD) != 0, xf32 = (p.e.io_flags & SMX_IO_LNX_F32) != 0;
   const bool ext = lnb && (p.e.lnf_act != SMX_ACT_NONE || p.e.z);
+  if (plan_only(p, 0, true, B_KC, 128, 512, true, ext ? (xf32 ? 7 : 3) : (lnb ? (xf32 ? 5 : 1) : (lnf ? 2 : 0)), 0)) return SMX_OK;
   if (ext && xf32) hipLaunchKernelGGL((gemm_kernel<T, true, B_KC, 128, 512, true, 7>), grid, block, 0, s, p);
   else if (ext) hipLaunchKernelGGL((gemm_kernel<T, true, B_KC, 128, 512, true, 3>), grid, block, 0, s, p);
   else if (lnb && xf32) hipLaunchKernelGGL((gemm_kernel<T, true, B_KC, 128, 512, true, 5>), grid, block, 0, s, p);

@@ -249,7 +249,40 @@ const smx_config& cfg();                                 // the knobs of include
 __device__ __forceinline__ uint64_t epoch_seed(uint64_t seed, const uint64_t* ep) {
   return ep ? seed ^ (ep[0] * 0x9E3779B97F4A7C15ull) : seed;
 }
-// 64-lane wave reductions
+// ---- cross-lane sums on the DPP path.  __shfl_xor compiles to ds_bpermute_b32 on gfx950: every butterfly stage is a round trip
+// through the LDS crossbar (~100 cycles of dependent latency, an LDS issue slot per lane pair), six of them per 64-lane sum.  The
+// data-parallel-primitive modifiers of the VALU do the same inside the register file: two quad permutes, row_half_mirror and
+// row_mirror leave the sum of each 16-lane row in all of its lanes; row_bcast15 / row_bcast31 carry the row sums up the wave
+// (lane 31 = lanes 0-31, lane 63 = the whole wave) and v_readlane hands the total back as a wave-uniform scalar.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_take(float v) {     // lanes of the rows in ROW_MASK: the permuted source; the others: 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {    // every lane: the sum over its row of 16 lanes
+  v += dpp_take<0xB1>(v);                                // quad_perm [1, 0, 3, 2]
+  v += dpp_take<0x4E>(v);                                // quad_perm [2, 3, 0, 1]
+  v += dpp_take<0x141>(v);                               // row_half_mirror
+  v += dpp_take<0x140>(v);                               // row_mirror
+  return v;
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {   // (lane: a constant) wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// sum over the 32 lanes of this lane's half wave (both halves at once), in every lane
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+  v = row16_sum(v);
+  v += dpp_take<0x142, 0xa>(v);                          // row_bcast15 into rows 1 and 3: lanes 31 / 63 hold the half sums
+  const float lo = lane_value(v, 31), hi = lane_value(v, 63);
+  return (threadIdx.x & 32) ? hi : lo;
+}
+// sum over all 64 lanes, wave-uniform
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum(v);
+  v += dpp_take<0x142, 0xa>(v);                          // row_bcast15: rows 1, 3 += rows 0, 2
+  v += dpp_take<0x143, 0xc>(v);                          // row_bcast31: rows 2, 3 += lane 31 (= rows 0 + 1)
+  return lane_value(v, 63);
+}
+// 64-lane wave reductions (the butterfly form: every lane ends with the same bits whatever its position)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

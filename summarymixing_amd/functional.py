@@ -1127,8 +1127,11 @@ def _conv_module_fwd_sp(x, P, act, mask, B, T, need_bwd, dtype, chunk, residual,
     return y, bwd
 
 
-def encoder_stack(src, layers, make_layer_run, norm, params, compute_dtype=None):
+def encoder_stack(src, layers, make_layer_run, norm, params, compute_dtype=None, pair_next=False):
     """A whole encoder stack (layers + final LayerNorm) as ONE autograd block.  make_layer_run(layer, compute) -> run(x3, need).
+    pair_next=True (the Conformer stack): make_layer_run(layer, compute, next_layer) -> run(x3, need, pre_ln=, with_post=True)
+    returning (y, bwd, post) - a layer's norm2 and the next layer's first LayerNorm run in one launch and `post` = that second
+    LayerNorm's (output, statistics) is handed to the next layer as `pre_ln`.
     compute: dtype of the GEMM operands (default: the input's); the residual stream between the layers is
     stream_dtype(compute) - float32 for a bf16 model by default.  The gradient between two layers never visits autograd (it
     would cast the bf16 gradient of a float32 stream tensor with one aten kernel per layer); every layer's parameter-gradient
@@ -1142,13 +1145,11 @@ def encoder_stack(src, layers, make_layer_run, norm, params, compute_dtype=None)
         if x.dtype != stream:
             x = ops.cast(ops.rows2d(x), stream).view(B, T, d)
         bwds = []
-        pair = _LN_PAIR and make_layer_run.__code__.co_argcount >= 3     # (the Conformer stack: norm2 + the next layer's first LayerNorm)
+        pair = _LN_PAIR and pair_next
         pre = None
         for i, layer in enumerate(layers):
             if pair:
-                r = make_layer_run(layer, compute, layers[i + 1] if i + 1 < len(layers) else None)
-                x, b = r(x, need, pre_ln=pre)
-                pre = getattr(r, "post_next", None)
+                x, b, pre = make_layer_run(layer, compute, layers[i + 1] if i + 1 < len(layers) else None)(x, need, pre_ln=pre, with_post=True)
             else:
                 x, b = make_layer_run(layer, compute)(x, need)
             bwds.append((b, getattr(layer, "_on_bwd_done", None)))

@@ -56,8 +56,49 @@ class ConvolutionBranch(nn.Module):
         self.pre_channel_proj = nn.Linear(input_size, linear_units)
         self.post_channel_proj = nn.Linear(linear_units // 2, input_size)
         self.act = act_code(activation)
+        self.p_drop = float(dropout)                       # (the CSGU's own dropout on x1 * conv(x2), upstream CSGU.forward)
         self.csgu = ConvolutionalSpatialGatingUnit(linear_units, kernel_size, dropout, use_linear_after_conv,
                                                    gate_activation)
+
+    def forward(self, x):
+        """x (B, T, D) -> post_channel_proj(CSGU(act(pre_channel_proj(x)))) (reference Branchformer.py:86-97), standalone: the
+        same kernels the fused layer path runs (projection GEMMs with fused bias / activation, LayerNorm, the rolling CSGU
+        depthwise-conv kernel with its gate and dropout), forward and backward.  BranchformerEncoderLayer does NOT call this - it
+        takes params() and fuses the branch with its neighbours (make_run)."""
+        B, T, d = x.shape
+        Pb = self.params()
+        act = self.act
+        pd = self.p_drop if self.training else 0.0
+
+        def run(x3, need):
+            dtype = x3.dtype
+            xr = ops.rows2d(x3 if x3.is_contiguous() else x3.contiguous())
+            Wpre, Wpost = F.wcast(Pb["Wpre"], dtype), F.wcast(Pb["Wpost"], dtype)
+            u, zu = F.linear_fwd(xr, Wpre, Pb["bpre"], act, None, save_z=need)       # (N, linear_units)
+            n = u.shape[1] // 2
+            u1, u2 = u[:, :n], u[:, n:]
+            v, bnv = F.ln_fwd(u2, Pb["ln_w"], Pb["ln_b"], 1e-5, need)
+            k = Pb["wd"].shape[-1]
+            wd = Pb["wd"].detach().reshape(n, k)
+            sd = ops.new_dropout_seed() if pd > 0.0 else None
+            g = ops.dwconv_fwd(v, wd, Pb["bd"].detach(), B, T, n, k, False, L.PAD_REFLECT, 0, gate=u1,
+                               drop=(pd, sd) if pd > 0.0 else None)
+            y, _ = F.linear_fwd(g, Wpost, Pb["bpost"])
+            if not need:
+                return y.view(B, T, d), None
+
+            def bwd(dy3):
+                dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
+                dg, _ = F.linear_bwd(dy, g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
+                                     dx_drop=(pd, sd) if pd > 0.0 else None)
+                du = torch.empty_like(u)                   # [d gate | d LN input]
+                dv, _ = F.dwconv_bwd_deferred(dg, v, wd, Pb["bd"].detach(), F.gacc(Pb["wd"]).view(n, k), F.gacc(Pb["bd"]), B, T,
+                                              n, k, False, L.PAD_REFLECT, 0, gate=u1, dgate_out=du[:, :n])
+                bnv(dv, out=du[:, n:])
+                dx, _ = F.linear_bwd(du, xr, Wpre, zu, act, None, 1.0, F.gacc(Pb["Wpre"]), F.gacc(Pb["bpre"]))
+                return dx.view(B, T, d)
+            return y.view(B, T, d), bwd
+        return F.block(x, run, list(self.parameters()))
 
     def params(self):
         return {"Wpre": self.pre_channel_proj.weight, "bpre": self.pre_channel_proj.bias,

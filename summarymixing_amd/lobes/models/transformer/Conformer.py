@@ -113,7 +113,8 @@ class ConformerEncoderLayer(nn.Module):
         model (functional.RESIDUAL_F32); None = everything in x3.dtype.
         next_layer: the layer that consumes this one's output inside an encoder stack.  Its first LayerNorm (ffn_module1's) then
         runs in the same pass as this layer's norm2 where the shapes allow (ops.layernorm_fwd_pair: one read of the float32 stream
-        for both); `run.post_next` = (LN(y), stats) | None is what the stack hands to the next layer's run as `pre_ln`."""
+        for both); run(..., with_post=True) then returns a third value, (LN(y), stats) | None, which the stack hands to the next
+        layer's run as `pre_ln`."""
         d_act = self.act
         P1, P2 = _ffn_params(self.ffn_module1), _ffn_params(self.ffn_module2)
         Pc = self.convolution_module.params()
@@ -124,10 +125,10 @@ class ConformerEncoderLayer(nn.Module):
 
         Pn = _ffn_params(next_layer.ffn_module1) if next_layer is not None else None
 
-        def run(x3, need, pre_ln=None):
+        def run(x3, need, pre_ln=None, with_post=False):
             dtype = compute_dtype or x3.dtype
             x = ops.rows2d(x3)
-            run.post_next = None
+            post_next = None
             # every LayerNorm that follows a Linear of width d_model = 256 runs in that GEMM's epilogue (`post` = its output and
             # statistics, None when the shape does not qualify and the consumer runs the LayerNorm kernel itself)
             y1, b1, post1 = F.ffn_module_fwd(x, P1, d_act, need, dtype, p=pd, pre_ln=pre_ln, ln_next=(n1.weight, n1.bias, n1.eps))   # :507
@@ -138,14 +139,15 @@ class ConformerEncoderLayer(nn.Module):
                                                  ln_next=(P2["ln_w"], P2["ln_b"], 1e-5))                          # :532-534
             # (norm2's output is the layer output = the next layer's residual stream: stream dtype, 4th element of ln_next)
             y4, bf2, post4 = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd, pre_ln=post3, ln_next=(n2.weight, n2.bias, n2.eps, True))
-            if post4 is None and Pn is not None and y4.dtype != dtype and ops.layernorm_pair_ok(y4, dtype):
+            if (post4 is None and Pn is not None and y4.dtype != dtype and
+                    ops.layernorm_pair_ok(y4, dtype, n2.weight, n2.bias, Pn["ln_w"], Pn["ln_b"])):
                 # norm2 and the next layer's first LayerNorm in one pass over the float32 stream (equal to two launches to an ulp)
                 y5_, st1, hn, st2 = ops.layernorm_fwd_pair(y4, n2.weight.detach(), n2.bias.detach(), n2.eps, Pn["ln_w"].detach(),
                                                            Pn["ln_b"].detach(), 1e-5, need, dtype)
-                post4, run.post_next = (y5_, st1), (hn, st2)
+                post4, post_next = (y5_, st1), (hn, st2)
             y5, bn2 = F.ln_fwd(y4, n2.weight, n2.bias, n2.eps, need, pre=post4)        # :536
             if not need:
-                return y5.view(B, T, -1), None
+                return (y5.view(B, T, -1), None, post_next) if with_post else (y5.view(B, T, -1), None)
 
             def bwd(dy3):
                 dy = ops.rows2d(dy3 if dy3.is_contiguous() else dy3.contiguous())
@@ -174,7 +176,7 @@ class ConformerEncoderLayer(nn.Module):
                     dh = ops.rows2d(bcell(d2.view(B, T, -1), dz_in=d2z))
                     d1, d1z = bn1(dh, res=d2, second=b1.pre)                           # skip gradient fused
                 return b1(d1, dz_in=d1z).view(B, T, -1)
-            return y5.view(B, T, -1), bwd
+            return (y5.view(B, T, -1), bwd, post_next) if with_post else (y5.view(B, T, -1), bwd)
         return run
 
     def forward(self, x, src_mask: Optional[torch.Tensor] = None, src_key_padding_mask: Optional[torch.Tensor] = None,
@@ -220,5 +222,5 @@ class ConformerEncoder(nn.Module):
         # compute dtype: what the caller says (TransformerASR.encode hands over the float32 stream of a bf16 model), else the input's
         out = F.encoder_stack(src, list(self.layers),
                               lambda layer, compute, nxt=None: layer.make_run(B, T, m8, src_mask, chunk, compute_dtype=compute, next_layer=nxt),
-                              self.norm.norm, list(self.parameters()), _compute_dtype)
+                              self.norm.norm, list(self.parameters()), _compute_dtype, pair_next=True)
         return out, [None] * len(self.layers)

@@ -40,28 +40,31 @@ def prof_start():
     _PROF = []
 
 
-def prof_stop():
-    """-> list of (name, algorithmic bytes, flops, milliseconds); synchronises the device."""
+def prof_stop(symbols=False):
+    """-> list of (name, algorithmic bytes, flops, milliseconds); synchronises the device.  symbols=True: a fifth field, the
+    kernel symbol as a profiler prints it (GEMMs: the instantiation smx_gemm_plan_query reports; other launches: their family)."""
     global _PROF
     recs, _PROF = _PROF, None
     torch.cuda.synchronize()
-    return [(n, b, f, e0.elapsed_time(e1)) for n, b, f, e0, e1 in recs]
+    if symbols:
+        return [(r[0], r[1], r[2], r[3].elapsed_time(r[4]), r[5] if len(r) > 5 and r[5] else r[0].split(" (")[0].split(" dW")[0]) for r in recs]
+    return [(r[0], r[1], r[2], r[3].elapsed_time(r[4])) for r in recs]
 
 
-def _pb(name, nbytes, flops=0.0):
+def _pb(name, nbytes, flops=0.0, sym=None):
     if _PROF is None:
         return None
     st = torch.cuda.current_stream()
     e0 = torch.cuda.Event(enable_timing=True)
     e0.record(st)
-    return (name, float(nbytes), float(flops), e0, st)
+    return (name, float(nbytes), float(flops), e0, st, sym)
 
 
 def _pe(tok):
     if tok is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record(tok[4])
-        _PROF.append(tok[:4] + (e1,))
+        _PROF.append(tok[:4] + (e1, tok[5]))
 
 
 def _es(t):
@@ -157,6 +160,24 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
     return e
 
 
+def gemm_symbol(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1, lda=None, ldb=None, ldc=None):
+    """The kernel symbol smx_gemm launches for these arguments, spelled as rocprofv3 prints it (smx_gemm_plan_query: the same
+    checks and dispatch as the launch itself, nothing launched)."""
+    pa, la = _mat(a)
+    pb, lb = _mat(b)
+    pc, lc = _mat(c)
+    plan = L.GemmPlan()
+    L.check(L.lib().smx_gemm_plan_query(layout, dt(a), pa, lda or la, sa, pb, ldb or lb, sb, pc, ldc or lc, sc, N, M, K, batch, splits,
+                                        ctypes.byref(epi if epi is not None else epilogue()), ctypes.byref(plan)), "smx_gemm_plan_query")
+    if plan.kernel == 1:
+        return "gemm_tn_dma_kernel"
+    if plan.kernel != 0:
+        return None
+    tb = lambda v: "true" if v else "false"
+    return (f"gemm_kernel<{'bf16_t' if a.dtype == torch.bfloat16 else 'float'}, {tb(plan.a_kc)}, {tb(plan.b_kc)}, {plan.tile_n}, "
+            f"{plan.tile_m}, {tb(plan.vec)}, {plan.lnf}, {plan.gather}>")
+
+
 def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1, lda=None, ldb=None, ldc=None):
     """C (N x M) = epi(op(A) op(B)); a/b/c are 2-D views of batch 0 (batch strides in elements)."""
     pa, la = _mat(a)
@@ -182,7 +203,8 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
                                       ("+Z", epi.z and not (epi.flags & L.EPI_ACT_GRAD)), ("+actgrad(z)", epi.flags & L.EPI_ACT_GRAD),
                                       ("+res", epi.res), ("+c0", epi.c0), ("+mask", epi.row_mask), ("+drop", epi.drop_p > 0)) if on)
         tok = _pb(f"gemm {('NT', 'NN', 'TN')[layout]} {'bf16' if es == 2 else 'f32'} ({N}x{K})x({K}x{M}){'' if batch == 1 else ' x%d' % batch} {tag}",
-                  nb, 2.0 * N * M * K * batch)
+                  nb, 2.0 * N * M * K * batch,
+                  gemm_symbol(layout, a, b, c, N, M, K, epi, batch, sa, sb, sc, splits, lda, ldb, ldc))
     L.check(L.lib().smx_gemm(layout, dt(a), pa, lda or la, sa, pb, ldb or lb, sb, pc, ldc or lc, sc, N, M, K, batch,
                              splits, ctypes.byref(epi), _stream()), "smx_gemm")
     _pe(tok)
@@ -229,7 +251,7 @@ def wgrad_group(items, nitems, rows, splits):
         nb = sum((items[i].M + items[i].K) * rows * 2 + 4 * items[i].M * items[i].K for i in range(nitems))
         fl = sum(2.0 * rows * items[i].M * items[i].K for i in range(nitems))
         tok = _pb(f"wgrad_group bf16 ({nitems} weights: " + " ".join(f"{items[i].M}x{items[i].K}" for i in range(nitems)) +
-                  f") over {rows} frames", nb, fl)
+                  f") over {rows} frames", nb, fl, "wgrad_group_kernel<32>")
     L.check(L.lib().smx_wgrad_group(L.BF16, rows, items, nitems, splits, _stream()), "smx_wgrad_group")
     _pe(tok)
 
@@ -345,10 +367,13 @@ def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE, out_dtype=Non
     return y, stats
 
 
-def layernorm_pair_ok(x, out_dtype):
-    """Can smx_layernorm_fwd_pair_x32 take this float32 stream tensor?"""
+def layernorm_pair_ok(x, out_dtype, *affine):
+    """Can smx_layernorm_fwd_pair_x32 take this float32 stream tensor - and these gamma / beta vectors?  The kernel reads all four
+    with 16-byte loads and returns SMX_EUNSUPPORTED for an unaligned one (a parameter that is a view at an odd offset of a flat
+    buffer): checked here so that the caller takes the two-launch path instead of failing."""
     return (x.dtype == torch.float32 and x.is_cuda and x.shape[1] % 4 == 0 and x.shape[1] <= 2048 and x.stride(1) == 1
-            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and out_dtype in (torch.bfloat16, torch.float32))
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and out_dtype in (torch.bfloat16, torch.float32)
+            and all(v.is_contiguous() and v.data_ptr() % 16 == 0 for v in affine))
 
 
 def layernorm_fwd_pair(x, gamma1, beta1, eps1, gamma2, beta2, eps2, want_stats, out_dtype):

@@ -5,8 +5,9 @@ to the fused smx_gemm launch doing the same work.  The unfused passes are this r
 single-pass implementation available here), so the comparison isolates FUSION, not kernel quality.
 
     python tools/blaslt_plus_epilogue.py > profiles/r03_blaslt_plus_epilogue.txt
-    D=512 F=2048 python tools/blaslt_plus_epilogue.py > profiles/r04_blaslt_plus_epilogue_d512.txt   (the recipe width: the LayerNorm
-    is a separate launch there, "fused" = the fused GEMM launch + the standalone LayerNorm kernel, as the product runs it)"""
+    D=512 F=2048 python tools/blaslt_plus_epilogue.py > profiles/r05_blaslt_plus_epilogue_d512.txt   (the recipe width; round 4: the
+    LayerNorm was a separate launch there - SMX_LN_FUSE=0 reproduces that: "fused" = the fused GEMM launch + the standalone
+    LayerNorm kernel; round 5: the row-complete 128 x 512 tile)"""
 import os
 import sys
 
@@ -18,7 +19,7 @@ from bench import time_kernel                                  # noqa: E402
 from summarymixing_amd import _lib as L, ops                    # noqa: E402
 
 N, d, f = 64000, int(os.environ.get("D", 256)), int(os.environ.get("F", 1024))
-LNF = d == 256          # LayerNorm inside the GEMM epilogue (row-complete 128 x 256 tile)
+LNF = L.lib().smx_gemm_ln_fused_ok(L.BF16, N, d, f) == 1 and os.environ.get("SMX_LN_FUSE", "1") != "0"   # LayerNorm inside the GEMM epilogue (row-complete 128 x 256 / 128 x 512 tile)
 dev = "cuda"
 rnd = lambda *s: (torch.rand(*s, device=dev) * 2 - 1)
 x, h = rnd(N, d).bfloat16(), rnd(N, f).bfloat16()
