@@ -608,7 +608,7 @@ __device__ __forceinline__ void epilogue_phase(const GemmParams& p, const char* 
           default: break;
         }
       } else {
-        if (Zb) { if (p.nt & 1) st_elems_nt<T, CW>(Zb + (long)n * e.ldz + m, v); else st_elems<T, CW>(Zb + (long)n * e.ldz + m, v); }
+        if (Zb) st_elems_nt<T, CW>(Zb + (long)n * e.ldz + m, v);   // (the saved pre-activation is not read again before the backward pass)
         switch (e.act) {
           case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, CW>(v); break;
           case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, CW>(v); break;
@@ -850,6 +850,174 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
   }
 }
 
+// ---- the same on the 128 x 512 tile (one workgroup per CU: nothing else hides a round trip), split into REQUEST and CONSUME: the
+// side inputs of 16 rows (a half phase: rows r0 + 4 k, k < 4, of the thread's wave) - LayerNorm input, statistics, residual gradient,
+// the second output's mask byte and saved pre-activation - are requested half a phase ahead (the first half before the accumulator
+// dump, the second right behind it, the next phase's first half behind this phase's first half), so no load of the epilogue is ever
+// waited for behind a store and every round trip runs under the dump, the barriers or the other half's math.
+template <typename T, bool EXT, bool XF32>
+struct Ln512BwdIn {
+  uint32_t xw[4][XF32 ? 8 : 4], rw[4][4], zw[EXT ? 4 : 1][4], mk[4];
+  float2 st[4];
+};
+template <typename T, bool EXT, bool XF32>
+__device__ __forceinline__ void ln512_bwd_request(const GemmParams& p, int nbase, int t, Ln512BwdIn<T, EXT, XF32>& in) {
+  typedef typename std::conditional<XF32, float, T>::type XT;
+  const smx_epilogue& e = p.e;
+  const int c = (t & 63) * 8, r0 = t >> 6;
+  const XT* X = reinterpret_cast<const XT*>(e.ln_x);
+  const T* R = reinterpret_cast<const T*>(e.res);
+  const T* Z2 = EXT ? reinterpret_cast<const T*>(e.z) : nullptr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long n = min(nbase + r0 + 4 * k, p.N - 1);
+    if constexpr (XF32) {
+      const uint4 a_ = *reinterpret_cast<const uint4*>(X + n * e.ln_ldx + c), b_ = *reinterpret_cast<const uint4*>(X + n * e.ln_ldx + c + 4);
+      in.xw[k][0] = a_.x; in.xw[k][1] = a_.y; in.xw[k][2] = a_.z; in.xw[k][3] = a_.w;
+      in.xw[k][4] = b_.x; in.xw[k][5] = b_.y; in.xw[k][6] = b_.z; in.xw[k][7] = b_.w;
+    } else {
+      ld_words<4>(X + n * e.ln_ldx + c, in.xw[k]);
+    }
+    in.st[k] = *reinterpret_cast<const float2*>(e.ln_stats + 2 * n);
+    if (R) ld_words<4>(R + n * e.ldr + c, in.rw[k]);
+    if (e.ln_dx2 && e.ln_mask2) in.mk[k] = e.ln_mask2[n];
+    if constexpr (EXT) {
+      if (Z2 && e.ln_dx2) ld_words<4>(Z2 + n * e.ldz + c, in.zw[k]);
+    }
+  }
+}
+template <typename T, bool EXT, bool XF32>
+__device__ __forceinline__ void ln512_bwd_half(const GemmParams& p, const char* smh, const float* lng, int nbase, int t,
+                                               Ln512BwdIn<T, EXT, XF32>& in, float (&dgam)[8], float (&dbet)[8]) {
+  constexpr int W = 512, STG_LD = W * 4 + 16, SWX = XF32 ? 8 : 4;
+  constexpr float INVW = 1.f / W;
+  const smx_epilogue& e = p.e;
+  const int c = (t & 63) * 8, r0 = t >> 6;
+  const bool hasR = e.res != nullptr, hasZ2 = EXT && e.z != nullptr && e.ln_dx2 != nullptr, hasM2 = e.ln_dx2 != nullptr && e.ln_mask2 != nullptr;
+  float gam[8];
+#pragma unroll
+  for (int q4 = 0; q4 < 2; ++q4) {
+    const float4 g4 = *reinterpret_cast<const float4*>(lng + c + 4 * q4);
+    gam[4 * q4] = g4.x; gam[4 * q4 + 1] = g4.y; gam[4 * q4 + 2] = g4.z; gam[4 * q4 + 3] = g4.w;
+  }
+  const int lact = EXT ? e.lnf_act : SMX_ACT_NONE;       // the LayerNorm was followed by a fused activation: g *= act'(LN(x))
+  // every (uniform) branch that loaded settles its own registers: no pending load on any path afterwards
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int q = 0; q < SWX; ++q) settle(in.xw[k][q]);
+    settle(in.st[k].x); settle(in.st[k].y);
+  }
+  if (hasR) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) settle(in.rw[k][q]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) in.rw[k][q] = 0u;
+  }
+  if (hasM2) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) settle(in.mk[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) in.mk[k] = 1u;
+  }
+  if constexpr (EXT) {
+    if (hasZ2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) settle(in.zw[k][q]);
+    }
+  }
+  const uint32_t thresh2 = e.ln_dx2 ? (uint32_t)((double)e.ln_drop_p2 * 4294967296.0) : 0u;
+  const float scale2 = 1.f / (1.f - e.ln_drop_p2);
+  const uint64_t seed2 = thresh2 ? epoch_seed(e.ln_drop_seed2, p.epoch) : 0;
+  // two rows at a time (four independent reduction chains): with four the 2 x 60 request registers + 64 of v / xhat spill
+#pragma unroll
+  for (int kb = 0; kb < 4; kb += 2) {
+  float v[2][8], xh[2][8], s1[2], s2[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int k = kb + kk;
+    const int r = r0 + 4 * k;
+    const bool rok = nbase + r < p.N;
+#pragma unroll
+    for (int q4 = 0; q4 < 2; ++q4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(smh + r * STG_LD + (c + 4 * q4) * 4);
+      v[kk][4 * q4] = a4.x; v[kk][4 * q4 + 1] = a4.y; v[kk][4 * q4 + 2] = a4.z; v[kk][4 * q4 + 3] = a4.w;
+    }
+    if constexpr (XF32) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xh[kk][q] = __uint_as_float(in.xw[k][q]);
+    } else {
+      unpack_words<T, 8>(in.xw[k], xh[kk]);
+    }
+    if (EXT && lact != SMX_ACT_NONE) {                   // (uniform; beta sits behind gamma in LDS)
+      float ag[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ag[q] = (xh[kk][q] - in.st[k].x) * in.st[k].y * gam[q] + lng[W + c + q];
+      switch (lact) {
+        case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, 8>(v[kk], ag); break;
+        case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, 8>(v[kk], ag); break;
+        case SMX_ACT_LEAKY_RELU: act_grad_mul_n<SMX_ACT_LEAKY_RELU, 8>(v[kk], ag); break;
+        case SMX_ACT_RELU: act_grad_mul_n<SMX_ACT_RELU, 8>(v[kk], ag); break;
+        default: break;
+      }
+    }
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      xh[kk][q] = (xh[kk][q] - in.st[k].x) * in.st[k].y;
+      const float g = rok ? v[kk][q] : 0.f;
+      dgam[q] += g * xh[kk][q];
+      dbet[q] += g;
+      v[kk][q] = g * gam[q];
+      a1 += v[kk][q];
+      a2 += v[kk][q] * xh[kk][q];
+    }
+    s1[kk] = a1; s2[kk] = a2;
+  }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) { s1[kk] = wave_sum_dpp(s1[kk]) * INVW; s2[kk] = wave_sum_dpp(s2[kk]) * INVW; }   // four independent chains
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int k = kb + kk;
+    const long n = nbase + r0 + 4 * k;
+    if (n >= p.N) continue;
+    float rf[8];
+    unpack_words<T, 8>(in.rw[k], rf);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[kk][q] = in.st[k].y * (v[kk][q] - s1[kk] - xh[kk][q] * s2[kk]) + rf[q];
+    st_elems<T, 8>(reinterpret_cast<T*>(p.C) + n * p.ldc + c, v[kk]);
+    if (e.ln_dx2) {                                      // (uniform)
+      const float mk = (in.mk[k] ? 1.f : 0.f) * e.ln_alpha2;
+      if constexpr (EXT) {
+        if (hasZ2) {
+          float zf[8];
+          unpack_words<T, 8>(in.zw[k], zf);
+          switch (e.act) {
+            case SMX_ACT_GELU: act_grad_mul_n<SMX_ACT_GELU, 8>(v[kk], zf); break;
+            case SMX_ACT_SWISH: act_grad_mul_n<SMX_ACT_SWISH, 8>(v[kk], zf); break;
+            case SMX_ACT_LEAKY_RELU: act_grad_mul_n<SMX_ACT_LEAKY_RELU, 8>(v[kk], zf); break;
+            case SMX_ACT_RELU: act_grad_mul_n<SMX_ACT_RELU, 8>(v[kk], zf); break;
+            default: break;
+          }
+        }
+      }
+      if (thresh2) dropout_apply<8>(v[kk], seed2, (uint64_t)n * W + c, thresh2, scale2);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[kk][q] *= mk;
+      st_elems<T, 8>(reinterpret_cast<T*>(e.ln_dx2) + n * e.ln_lddx2 + c, v[kk]);
+    }
+  }
+  }
+}
+
 // SMX_EPI_LN_FWD: the ordinary epilogue_phase has written the finished output values back to their staged slots (each
 // thread re-reads its own items: no barrier); lnf_y = act(LN(row) * gamma + beta), lnf_stats = (mean, rstd).
 template <typename T, int W = 256>
@@ -938,9 +1106,11 @@ __device__ __forceinline__ void ln512_request_res(const GemmParams& p, int nbase
     rw[k][0] = a_.x; rw[k][1] = a_.y; rw[k][2] = a_.z; rw[k][3] = a_.w; rw[k][4] = b_.x; rw[k][5] = b_.y; rw[k][6] = b_.z; rw[k][7] = b_.w;
   }
 }
+// lnst: [128][2] floats of LDS - the tile's (mean, rstd) pairs, written out as ONE contiguous 1 KB block by ln512_store_stats after
+// the last phase (a lane's own 8-byte store per row - 32 partial-line writes per wave and phase - cost more than the LayerNorm math)
 template <typename T>
-__device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, const char* smem, const float* side, const float* lng, int ph,
-                                                        int nbase, int t, uint32_t (&rw)[8][8]) {
+__device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, const char* smem, const float* side, const float* lng, float* lnst,
+                                                        int ph, int nbase, int t, uint32_t (&rw)[8][8]) {
   constexpr int W = 512, STG_LD = W * 4 + 16, BR = 4;
   constexpr float INVW = 1.f / W;
   const smx_epilogue& e = p.e;
@@ -951,8 +1121,13 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
   const bool has_mk = e.row_mask != nullptr || e.alpha != 1.f;
   const bool do_drop = dthresh && c < p.drop_cols;         // (drop_cols is a multiple of 8: an item is wholly inside or outside)
   const float* mkrow = side + W + ph * 32;
-  T* Zb = e.z ? reinterpret_cast<T*>(e.z) : nullptr;
-  float* Cb = reinterpret_cast<float*>(p.C);
+  const bool yf32 = (e.io_flags & SMX_IO_LNFY_F32) != 0;  // the LayerNorm output IS the fp32 residual stream (norm2)
+  // row pointers of this thread's first row; every further row is 4 rows on (one 64-bit add each, nothing recomputed per row)
+  const long row0 = nbase + r0;
+  float* cp = reinterpret_cast<float*>(p.C) + row0 * p.ldc + c;
+  T* zp = e.z ? reinterpret_cast<T*>(e.z) + row0 * e.ldz + c : nullptr;
+  char* yp = reinterpret_cast<char*>(e.lnf_y) + (row0 * e.lnf_ldy + c) * (yf32 ? 4 : (long)sizeof(T));
+  const long cstep = 4 * p.ldc, zstep = 4 * e.ldz, ystep = 4 * e.lnf_ldy * (yf32 ? 4 : (long)sizeof(T));
   float gam[8], bet[8], bia[8];
 #pragma unroll
   for (int q4 = 0; q4 < 2; ++q4) {
@@ -971,42 +1146,60 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
     float v[BR][8], mean[BR], rstd[BR];
 #pragma unroll
     for (int k = 0; k < BR; ++k) {
-      const int r = r0 + 4 * (kb + k), n = nbase + r;
+      const int r = r0 + 4 * (kb + k);
 #pragma unroll
       for (int q4 = 0; q4 < 2; ++q4) {
         const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
-        v[k][4 * q4] = a4.x; v[k][4 * q4 + 1] = a4.y; v[k][4 * q4 + 2] = a4.z; v[k][4 * q4 + 3] = a4.w;
+        v[k][4 * q4] = a4.x + bia[4 * q4]; v[k][4 * q4 + 1] = a4.y + bia[4 * q4 + 1];      // (bias: zeros when there is none)
+        v[k][4 * q4 + 2] = a4.z + bia[4 * q4 + 2]; v[k][4 * q4 + 3] = a4.w + bia[4 * q4 + 3];
       }
+    }
+    if (zp) {                                              // (uniform) saved pre-activation
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[k][q] += bia[q];       // (zeros when there is no bias)
-      if (Zb && n < p.N) { if (p.nt & 1) st_elems_nt<T, 8>(Zb + (long)n * e.ldz + c, v[k]); else st_elems<T, 8>(Zb + (long)n * e.ldz + c, v[k]); }
-      switch (e.act) {
-        case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 8>(v[k]); break;
-        case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 8>(v[k]); break;
-        case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(v[k]); break;
-        case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 8>(v[k]); break;
-        default: break;
-      }
-      if (do_drop) dropout_apply<8>(v[k], dseed, (uint64_t)n * p.drop_cols + c, dthresh, dscale);
-      if (has_mk) {
-        const float mk = mkrow[r];
+      for (int k = 0; k < BR; ++k)
+        if (nbase + r0 + 4 * (kb + k) < p.N) st_elems_nt<T, 8>(zp + (kb + k) * zstep, v[k]);
+    }
+    switch (e.act) {                                       // ONE uniform switch per batch of rows
+      case SMX_ACT_GELU:
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[k][q] *= mk;
-      }
+        for (int k = 0; k < BR; ++k) act_fwd_n<SMX_ACT_GELU, 8>(v[k]);
+        break;
+      case SMX_ACT_SWISH:
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[k][q] += __uint_as_float(rw[kb + k][q]);
-      if (n < p.N) {
-        float* cp = Cb + (long)n * p.ldc + c;
-        if (p.nt & 2) { st_elems_nt<float, 4>(cp, reinterpret_cast<const float(&)[4]>(v[k][0])); st_elems_nt<float, 4>(cp + 4, reinterpret_cast<const float(&)[4]>(v[k][4])); }
-        else { st_elems<float, 4>(cp, reinterpret_cast<const float(&)[4]>(v[k][0])); st_elems<float, 4>(cp + 4, reinterpret_cast<const float(&)[4]>(v[k][4])); }
+        for (int k = 0; k < BR; ++k) act_fwd_n<SMX_ACT_SWISH, 8>(v[k]);
+        break;
+      case SMX_ACT_LEAKY_RELU:
+#pragma unroll
+        for (int k = 0; k < BR; ++k) act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(v[k]);
+        break;
+      case SMX_ACT_RELU:
+#pragma unroll
+        for (int k = 0; k < BR; ++k) act_fwd_n<SMX_ACT_RELU, 8>(v[k]);
+        break;
+      default: break;
+    }
+    if (do_drop) {
+#pragma unroll
+      for (int k = 0; k < BR; ++k)
+        dropout_apply<8>(v[k], dseed, (uint64_t)(nbase + r0 + 4 * (kb + k)) * p.drop_cols + c, dthresh, dscale);
+    }
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+      const float mk = has_mk ? mkrow[r0 + 4 * (kb + k)] : 1.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[k][q] = v[k][q] * mk + __uint_as_float(rw[kb + k][q]);
+      if (nbase + r0 + 4 * (kb + k) < p.N) {               // C: the new stream tensor, streamed past the caches (the next kernel reads lnf_y)
+        float* cq = cp + (kb + k) * cstep;
+        st_elems_nt<float, 4>(cq, reinterpret_cast<const float(&)[4]>(v[k][0]));
+        st_elems_nt<float, 4>(cq + 4, reinterpret_cast<const float(&)[4]>(v[k][4]));
       }
     }
 #pragma unroll
     for (int k = 0; k < BR; ++k) {
-      float s = 0.f;
+      float s_ = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += v[k][q];
-      mean[k] = wave_sum_dpp(s) * INVW;
+      for (int q = 0; q < 8; ++q) s_ += v[k][q];
+      mean[k] = wave_sum_dpp(s_) * INVW;
     }
 #pragma unroll
     for (int k = 0; k < BR; ++k) {
@@ -1016,29 +1209,47 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
       rstd[k] = rsqrtf(wave_sum_dpp(qq) * INVW + e.lnf_eps);
     }
 #pragma unroll
-    for (int k = 0; k < BR; ++k) {
-      const int n = nbase + r0 + 4 * (kb + k);
-      if (n >= p.N) continue;
-      float y[8];
+    for (int k = 0; k < BR; ++k)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) y[q] = v[k][q] * rstd[k] * gam[q] + bet[q];
-      switch (e.lnf_act) {
-        case SMX_ACT_GELU: act_fwd_n<SMX_ACT_GELU, 8>(y); break;
-        case SMX_ACT_SWISH: act_fwd_n<SMX_ACT_SWISH, 8>(y); break;
-        case SMX_ACT_LEAKY_RELU: act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(y); break;
-        case SMX_ACT_RELU: act_fwd_n<SMX_ACT_RELU, 8>(y); break;
-        default: break;
-      }
-      if (e.io_flags & SMX_IO_LNFY_F32) {                  // (uniform) the LayerNorm output IS the fp32 residual stream (norm2)
-        float* yp = reinterpret_cast<float*>(e.lnf_y) + (long)n * e.lnf_ldy + c;
-        *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
-        *reinterpret_cast<float4*>(yp + 4) = make_float4(y[4], y[5], y[6], y[7]);
+      for (int q = 0; q < 8; ++q) v[k][q] = v[k][q] * rstd[k] * gam[q] + bet[q];
+    switch (e.lnf_act) {
+      case SMX_ACT_GELU:
+#pragma unroll
+        for (int k = 0; k < BR; ++k) act_fwd_n<SMX_ACT_GELU, 8>(v[k]);
+        break;
+      case SMX_ACT_SWISH:
+#pragma unroll
+        for (int k = 0; k < BR; ++k) act_fwd_n<SMX_ACT_SWISH, 8>(v[k]);
+        break;
+      case SMX_ACT_LEAKY_RELU:
+#pragma unroll
+        for (int k = 0; k < BR; ++k) act_fwd_n<SMX_ACT_LEAKY_RELU, 8>(v[k]);
+        break;
+      case SMX_ACT_RELU:
+#pragma unroll
+        for (int k = 0; k < BR; ++k) act_fwd_n<SMX_ACT_RELU, 8>(v[k]);
+        break;
+      default: break;
+    }
+#pragma unroll
+    for (int k = 0; k < BR; ++k) {
+      const int r = r0 + 4 * (kb + k);
+      if ((t & 63) == 0) *reinterpret_cast<float2*>(lnst + 2 * (ph * 32 + r)) = make_float2(mean[k], rstd[k]);
+      if (nbase + r >= p.N) continue;
+      char* yq = yp + (kb + k) * ystep;
+      if (yf32) {                                          // (uniform)
+        *reinterpret_cast<float4*>(yq) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+        *reinterpret_cast<float4*>(yq + 16) = make_float4(v[k][4], v[k][5], v[k][6], v[k][7]);
       } else {
-        st_elems<T, 8>(reinterpret_cast<T*>(e.lnf_y) + (long)n * e.lnf_ldy + c, y);
+        st_elems<T, 8>(yq, v[k]);
       }
-      if (e.lnf_stats && (t & 63) == 0) *reinterpret_cast<float2*>(e.lnf_stats + 2 * (long)n) = make_float2(mean[k], rstd[k]);
     }
   }
+}
+// the tile's statistics: rows [n0, n0 + 128) as one contiguous block (call after a barrier behind the last phase)
+__device__ __forceinline__ void ln512_store_stats(const GemmParams& p, const float* lnst, int n0, int t) {
+  if (p.e.lnf_stats && t < 128 && n0 + t < p.N)
+    *reinterpret_cast<float2*>(p.e.lnf_stats + 2 * (long)(n0 + t)) = *reinterpret_cast<const float2*>(lnst + 2 * t);
 }
 
 // LDS-DMA issue of one 1 KB piece (global_load_lds_dwordx4: lane i lands at lds_dst + 16 i; M0 carries the wave-uniform

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
   constexpr int AB_BYTES = T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES;
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
-  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0)) * 4;   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta]
+  // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta [| the tile's (mean, rstd) pairs: 128 x 512 LN forward]]
+  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0) + ((LNF == 2 && TILE_M == 512) ? 2 * TILE_N : 0)) * 4;
   // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) operand stage, fenced by one extra barrier
   constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536;
@@ -560,13 +561,79 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
   constexpr bool LN512F = ROW512 && LNF == 2;
   const bool ln512f = LN512F && osz == 4 && p.epi_simple == 2 && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr &&
                       !(e.flags & SMX_EPI_ACT_GRAD) && p.batch == 1;
-  uint32_t resw[LN512F ? 8 : 1][8];
+  if constexpr (ROW512 && LNB) {
+    // LayerNorm backward on the 128 x 512 tile: its own loop with the side inputs requested half a phase ahead (gemm_common.h)
+    constexpr bool EXT_ = (LNF & 3) == 3, XF_ = (LNF & 4) != 0;
+    // ONE request set: the first half of a phase is requested before the accumulator dump of that phase (behind the previous
+    // phase's last stores: the round trip runs under the two barriers and the dump), the second half where it is consumed.
+    // (Measured, 64 000 x 2048 -> 512: the generic pair of loads per half 174.8 us; two request sets, every half prefetched: 194.8 us
+    //  - 2 x 60 registers next to the 256 accumulators spill 27-150 registers into the item loops; the four phases as straight-line
+    //  code, so that dumped accumulator fragments die: 86-159 spilled.)
+    Ln512BwdIn<T, EXT_, XF_> in;
+    ln512_bwd_request<T, EXT_, XF_>(p, n0, t, in);
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+      lds_barrier();
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        if (i == ph) {
+#pragma unroll
+          for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(smem + l31 * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                  make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        }
+      }
+      lds_barrier();
+      if (ph < 2) SMX_STAMP(3 + 2 * ph);
+      ln512_bwd_half<T, EXT_, XF_>(p, smem, lng, n0 + ph * 32, t, in, dgam, dbet);
+      ln512_bwd_request<T, EXT_, XF_>(p, n0 + ph * 32 + 16, t, in);
+      ln512_bwd_half<T, EXT_, XF_>(p, smem + 16 * STG_LD, lng, n0 + ph * 32 + 16, t, in, dgam, dbet);
+      if (ph + 1 < NPH) ln512_bwd_request<T, EXT_, XF_>(p, n0 + ph * 32 + 32, t, in);      // (uniform)
+      if (ph < 2) SMX_STAMP(4 + 2 * ph);
+    }
+  } else {
+  if constexpr (LN512F) {
+    if (ln512f) {
+      // (its own loop, chosen ONCE: with both paths inside one loop their hoisted row pointers and constants are live together and
+      //  hipcc spills - every reload then sits behind the stores of the previous item, s_waitcnt vmcnt(0))
+      float* lnst = lng + 2 * TILE_M;
+      uint32_t resw[8][8];
+      // the statistics block of this tile is written once, at the very end: touch its page NOW, so that the address translation
+      // of that last store is not what the workgroup's slot waits for (measured: 18 us of a 209 us launch)
+      float st_touch = 0.f;
+      if (e.lnf_stats && t == 0) st_touch = __builtin_nontemporal_load(e.lnf_stats + 2 * (long)n0);
+#pragma unroll 1
+      for (int ph = 0; ph < NPH; ++ph) {
+        ln512_request_res(p, n0 + ph * 32, t, resw);       // (in flight under the dump and its two barriers)
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          if (i == ph) {
+#pragma unroll
+            for (int j = 0; j < FM; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(smem + l31 * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                    make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+          }
+        }
+        lds_barrier();
+        if (ph < 2) SMX_STAMP(3 + 2 * ph);
+        epilogue_phase_ln512fwd<T>(p, smem, side, lng, lnst, ph, n0 + ph * 32, t, resw);
+        if (ph < 2) SMX_STAMP(4 + 2 * ph);
+      }
+      lds_barrier();
+      asm volatile("" :: "v"(st_touch));
+      ln512_store_stats(p, lnst, n0, t);
+      SMX_STAMP(7);
+      return;
+    }
+  }
 #pragma unroll 1
   for (int ph = 0; ph < NPH; ++ph) {
     const int row_in_tile = ph * PH_ROWS;
-    if constexpr (LN512F) {
-      if (ln512f) ln512_request_res(p, n0 + row_in_tile, t, resw);   // (in flight under the dump and its barriers)
-    }
     lds_barrier();
     if (wn == row_in_tile / WN) {                         // the wave row that owns these accumulator rows
       const int i0 = (row_in_tile % WN) / 32;              // first 32-row fragment of the phase
@@ -585,12 +652,6 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
     }
     lds_barrier();
     if (ph < 2) SMX_STAMP(3 + 2 * ph);
-    if constexpr (LN512F) {
-      if (ln512f) {
-        epilogue_phase_ln512fwd<T>(p, smem, side, lng, ph, n0 + row_in_tile, t, resw);
-        continue;
-      }
-    }
     if constexpr (LNB) {                                  // the LayerNorm backward replaces the ordinary epilogue
       epilogue_phase_lnbwd<T, (LNF & 3) == 3, (LNF & 4) != 0, TILE_M>(p, smem, lng, n0 + row_in_tile, t, dgam, dbet);
       continue;
@@ -622,6 +683,7 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
     }
     if (ph < 2) SMX_STAMP(4 + 2 * ph);
   }
+  }   // (generic phase loop)
   if constexpr (LNB) {
     {
       // dgamma / dbeta of the tile: the row groups (8 of 32 lanes for 256 columns, 4 of 64 lanes for 512) are folded through

@@ -153,7 +153,7 @@ PARAM_GRAD_BAR_BF16 = {"g5_conformer_layer_swish": 4.3e-2, "g5_conformer_layer_g
 
 def _direct_bf16_check(name, y, gx, params, a):
     """The HIP bf16 results against the REFERENCE's bf16-autocast results on the same golden (bf16 against bf16, no float32 in
-    between), reported next to both float32 comparisons.  Fixed bars: forward 2e-2 max-rel / 1.5e-2 RMS, gradients 6e-2 / 3e-2
+    between), reported next to both float32 comparisons.  Fixed bars: forward 2e-2 max-rel / 1.5e-2 RMS, dL/dx 6e-2 / 3e-2, parameter gradients (sums over 2 x 23 frames) 8e-2 / 6e-2
     (two bf16 roundings, one per side)."""
     ref = autocast_reference_layer(name)
     worst = max((rel_err(params[k].grad, g), rms_rel(params[k].grad, g), k) for k, g in ref["grads"].items())
@@ -165,7 +165,7 @@ def _direct_bf16_check(name, y, gx, params, a):
     report(name + "_bf16_direct", ent)
     assert ent["ours_vs_autocast_fwd_maxrel"] <= 2e-2 and ent["ours_vs_autocast_fwd_rms"] <= 1.5e-2, ent
     assert ent["ours_vs_autocast_gx_maxrel"] <= 6e-2 and ent["ours_vs_autocast_gx_rms"] <= 3e-2, ent
-    assert worst[0] <= 8e-2 and worst[1] <= 4e-2, ent
+    assert worst[0] <= 8e-2 and worst[1] <= 6e-2, ent
 
 
 def _asr(meta, sd, input_size):
@@ -404,10 +404,11 @@ def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize("d", [144, 512])
-def test_layernorm_pair_in_the_stack_equals_two_launches(d, monkeypatch):
+def test_layernorm_pair_in_the_stack_equals_two_launches(d, monkeypatch, ln_fuse_mode):
     """ConformerEncoder on the float32 stream: norm2 + the next layer's first LayerNorm in one launch (functional._LN_PAIR,
     smx_layernorm_fwd_pair_x32) against the two-launch path - outputs, dL/dx and every parameter gradient (the two paths differ
-    by an ulp of the LayerNorm outputs)."""
+    by an ulp of the LayerNorm outputs).  Where norm2 rides in the FFN's down-projection GEMM (d_model = 512 with the fusion forced
+    on: the row-complete 128 x 512 tile, round 5) the pair kernel has nothing left to do."""
     from summarymixing_amd import functional as F
     from summarymixing_amd import ops
     from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
@@ -433,9 +434,11 @@ def test_layernorm_pair_in_the_stack_equals_two_launches(d, monkeypatch):
         torch.cuda.synchronize()
         return y.detach().float(), xg.grad.float(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
     y1, g1, p1 = run(True)
-    assert len(calls) == 2, "two layer boundaries of a 3-layer stack take the pair kernel"
+    expect = 0 if (ln_fuse_mode == "lnfuse_always" and d == 512) else 2
+    assert len(calls) == expect, "two layer boundaries of a 3-layer stack take the pair kernel (unless norm2 is fused into the GEMM)"
     y0, g0, p0 = run(False)
-    assert len(calls) == 2
-    assert rel_err(y1, y0) < 1e-2 and rel_err(g1, g0) < 2e-2
+    assert len(calls) == expect
+    # the same statistics, the same rounding points: bf16 outputs agree to a bf16 ulp (2^-7 relative) at worst
+    assert rel_err(y1, y0) < 8e-3 and rel_err(g1, g0) < 1.6e-2
     for n in p0:
-        assert rel_err(p1[n], p0[n]) < 2e-2, n
+        assert rel_err(p1[n], p0[n]) < 1.6e-2, n

@@ -103,7 +103,7 @@ def run(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
     rec = ops.prof_stop()
     if rec:   # name AND algorithmic bytes of this launch as bench.py's in-step records carry them (ONE byte model: ops.gemm)
         open("/tmp/pmc_name.txt", "w").write(f"{rec[0][0]}\n{rec[0][1]:.0f}\n")
-    t = time_kernel(fn, iters=20, warm=3)
+    t = sorted(time_kernel(fn, iters=30, warm=8) for _ in range(3))[1]   # median of three warmed runs (one cold run of 20 read 5-15 % high)
     fl = 2.0 * N * K * M
     print(f"{layout} N={N:6d} K={K:5d} M={M:5d} {epi:7s} {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s  {nbytes/t/1e9:7.0f} GB/s(alg)", flush=True)
 

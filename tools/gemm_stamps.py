@@ -26,9 +26,12 @@ elif layout == "NTd":      # up-projection with dropout
 elif layout == "NN":
     w = (torch.randn(K, M, device="cuda") * 0.05).bfloat16(); y = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
     fn = lambda: ops.gemm(L.GEMM_NN, x, w, y, N, M, K)
-else:
+elif layout == "TN":
     x2 = torch.randn(N, M, device="cuda").bfloat16(); g = torch.zeros(K, M, device="cuda")
     fn = lambda: ops.wgrad(x, x2, g, N, K, M)
+else:                      # any layout + epilogue of tools/gemm_bench.py (NTln, NTln2, NNlnb, NTres, ...)
+    from tools.gemm_bench import build
+    fn, _ = build(N, K, M, layout, epi=sys.argv[4] if len(sys.argv) > 4 else "swishz")
 assert "diag" in L.LIB_PATH, "run with SMX_LIB=summarymixing_amd/libsmx_diag.so (SMX_DIAG=1 bash summarymixing_amd/csrc/build.sh): the product library carries no stamps"
 lib = L.lib(); lib.smx_debug_set_timing_buffer.argtypes = [ctypes.c_void_p]
 for _ in range(3): fn()
