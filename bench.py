@@ -34,6 +34,7 @@ Prints ONE JSON line (rank 0) with the driver contract fields plus
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -374,6 +375,16 @@ def cpu_baseline_stack(cfg, cores):
                       f"torch {torch.__version__}, {cores} threads"}
 
 
+def gpu_topology():
+    """One line per GPU pair class as rocm-smi reports it (link type / hops), once, for the record of a multi-GPU run."""
+    try:
+        r = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=20)
+        lines = [ln.strip() for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("=")]
+        return lines[:12]
+    except Exception as ex:                                # noqa: BLE001 - the topology is a note, never a failure
+        return [f"rocm-smi unavailable: {type(ex).__name__}"]
+
+
 def rccl_env():
     """The RCCL / NCCL / HSA variables this process sees (what shaped the collectives of a multi-GPU run)."""
     keys = sorted(k for k in os.environ if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE")))
@@ -499,6 +510,7 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")     # RCCL prints its version line once (stderr) - kept with the run's log
         dist.init_process_group("nccl", device_id=dev)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
@@ -660,6 +672,20 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    replica_check = None
+    if (world > 1 or force_dist) and opt is not None:
+        # data-parallel self-check, AFTER the timed region: every rank's parameters must be bit-identical (same init, the same
+        # all-reduced gradients, the same update) - each rank contributes a checksum of its flat fp32 master buffer (sum and sum
+        # of squares in float64 + the first / last elements), rank 0 compares
+        fp = opt.flat_p.double()
+        mine = torch.stack([fp.sum(), (fp * fp).sum(), fp[0], fp[-1], torch.tensor(float(opt.total), device=dev, dtype=torch.float64)])
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allc, mine)
+        same = all(torch.equal(c, allc[0]) for c in allc)
+        replica_check = {"ranks": world, "identical_parameters": bool(same), "checksum_rank0": [float(v) for v in allc[0][:2]]}
+        if rank == 0 and not same:
+            raise SystemExit(f"bench.py: data-parallel replicas DIVERGED after {args.steps + args.warmup} steps: "
+                             + "; ".join(f"rank {i}: {[float(v) for v in c]}" for i, c in enumerate(allc)))
 
     frames_per_step = cfg["B"] * cfg["T"] * world * G
     value = frames_per_step * args.steps / dt
@@ -710,6 +736,10 @@ def main():
                                                else (world - 1) / world * (gb + opt.total * 4)),
                        "comm_exposed_ms": ce}
         out["comm_exposed_ms"] = ce
+        if replica_check is not None:
+            out["comm"]["replica_check"] = replica_check
+            out["comm"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None
+            out["comm"]["topology"] = gpu_topology()
     if rank == 0:
         if not args.no_roofline:
             if train and world == 1 and not force_dist:

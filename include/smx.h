@@ -93,6 +93,10 @@ typedef struct smx_epilogue {
   int32_t io_flags;    int32_t pad_;
   /* device step counter mixed into this call's fused dropout seed (see smx_step_counter_add), or NULL */
   const uint64_t* epoch;
+  /* SMX_EPI_LN_FWD, optional SECOND LayerNorm of the first one's output (a Conformer layer's norm2 followed by the next layer's
+   * first LayerNorm, Conformer.py:536 / :507): lnf2_y (dtype T) = LN2(lnf_y values before rounding), lnf2_stats = (mean, rstd).
+   * Only where smx_gemm_ln_pair_ok says so (the 128 x 512 tile on the float32 stream); NULL lnf2_y = off. */
+  const float* lnf2_gamma; const float* lnf2_beta; void* lnf2_y; int64_t lnf2_ldy; float* lnf2_stats; float lnf2_eps; int32_t pad2_;
 } smx_epilogue;
 enum { SMX_IO_RES_F32 = 1, SMX_IO_LNX_F32 = 2, SMX_IO_LNFY_F32 = 4 };
 /* flags.  SMX_EPI_ACT_GRAD turns the epilogue into the BACKWARD of an upstream activation layer: z is then a
@@ -113,6 +117,9 @@ enum { SMX_IO_RES_F32 = 1, SMX_IO_LNX_F32 = 2, SMX_IO_LNFY_F32 = 4 };
  * writes C (bias, residual, dropout, mask ... as usual), then lnf_y = act(LN(C) * gamma + beta) and lnf_stats. */
 enum { SMX_EPI_C0_POST = 1, SMX_EPI_ACT_GRAD = 2, SMX_EPI_LN_BWD = 4, SMX_EPI_LN_FWD = 8 };
 int smx_gemm_ln_fused_ok(int dtype, int N, int M, int K);
+/* ... and can that epilogue run a SECOND LayerNorm on the first one's output (smx_epilogue.lnf2_*)?  Needs, besides the shape, the
+ * float32 residual stream form of the call: SMX_OUT_F32, SMX_IO_RES_F32 residual, no C0 / column sums (else SMX_EUNSUPPORTED). */
+int smx_gemm_ln_pair_ok(int dtype, int N, int M, int K);
 size_t smx_gemm_colsum_workspace(int N, int M);
 
 /* Batched strided MFMA GEMM  C[b] (N x M) = epilogue( op(A[b]) . op(B[b]) ), reduce length K.

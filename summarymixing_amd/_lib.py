@@ -60,7 +60,9 @@ class Epilogue(ctypes.Structure):
                 ("lnf_gamma", c_vp), ("lnf_beta", c_vp), ("lnf_y", c_vp), ("lnf_ldy", c_i64), ("lnf_stats", c_vp),
                 ("lnf_eps", c_f), ("lnf_act", ctypes.c_int32),
                 ("io_flags", ctypes.c_int32), ("pad_", ctypes.c_int32),
-                ("epoch", c_vp)]
+                ("epoch", c_vp),
+                ("lnf2_gamma", c_vp), ("lnf2_beta", c_vp), ("lnf2_y", c_vp), ("lnf2_ldy", c_i64), ("lnf2_stats", c_vp),
+                ("lnf2_eps", c_f), ("pad2_", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/smx.h one to one (tests/test_abi.py checks the export list)
@@ -73,6 +75,7 @@ SIGNATURES = {
                                   ctypes.POINTER(Epilogue), ctypes.POINTER(GemmPlan)]),
     "smx_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
     "smx_gemm_ln_fused_ok": (c_i, [c_i, c_i, c_i, c_i]),
+    "smx_gemm_ln_pair_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "smx_linear_wgrad_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_linear_wgrad": (c_i, [c_i, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i, c_i, c_i, c_i,
                                c_f, c_vp, c_vp]),

@@ -389,6 +389,13 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
   if (p.e.flags & SMX_EPI_LN_FWD)
     SMX_REQUIRE(p.e.lnf_gamma && p.e.lnf_beta && p.e.lnf_y && aligned16(p.e.lnf_y) && p.e.lnf_ldy % 8 == 0 &&
                 !(p.e.flags & (SMX_EPI_LN_BWD | SMX_EPI_ACT_GRAD)), "smx_gemm: SMX_EPI_LN_FWD needs lnf_gamma / lnf_beta / lnf_y");
+  if (p.e.lnf2_y) {
+    SMX_REQUIRE((p.e.flags & SMX_EPI_LN_FWD) && p.e.lnf2_gamma && p.e.lnf2_beta && aligned16(p.e.lnf2_y) && p.e.lnf2_ldy % 8 == 0,
+                "smx_gemm: lnf2_* (second LayerNorm) goes with SMX_EPI_LN_FWD and needs gamma / beta / an aligned output");
+    if (!(smx_gemm_ln_pair_ok(dtype, N, M, K) && p.e.out_mode == SMX_OUT_F32 && (p.e.io_flags & SMX_IO_RES_F32) && p.e.res && !p.e.c0 &&
+          !p.e.colsum && batch == 1 && splits == 1))
+      return fail(SMX_EUNSUPPORTED, "smx_gemm: the second LayerNorm (lnf2_*) needs M == 512 and the float32-stream epilogue (smx_gemm_ln_pair_ok)");
+  }
   if (p.e.colsum)
     SMX_REQUIRE(p.e.workspace && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
                 "smx_gemm: colsum needs a workspace (smx_gemm_colsum_workspace), batch == 1, splits == 1");
@@ -454,6 +461,10 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
 
 extern "C" int smx_gemm_ln_fused_ok(int dtype, int N, int M, int K) {
   return dtype == SMX_BF16 && (M == 256 || M == 512) && N >= 128 && K > 0 && K % 64 == 0;
+}
+
+extern "C" int smx_gemm_ln_pair_ok(int dtype, int N, int M, int K) {
+  return smx_gemm_ln_fused_ok(dtype, N, M, K) && M == 512;
 }
 
 extern "C" size_t smx_gemm_colsum_workspace(int N, int M) {

@@ -1110,7 +1110,7 @@ __device__ __forceinline__ void ln512_request_res(const GemmParams& p, int nbase
 // the last phase (a lane's own 8-byte store per row - 32 partial-line writes per wave and phase - cost more than the LayerNorm math)
 template <typename T>
 __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, const char* smem, const float* side, const float* lng, float* lnst,
-                                                        int ph, int nbase, int t, uint32_t (&rw)[8][8]) {
+                                                        const float* lng2, int ph, int nbase, int t, uint32_t (&rw)[8][8]) {
   constexpr int W = 512, STG_LD = W * 4 + 16, BR = 4;
   constexpr float INVW = 1.f / W;
   const smx_epilogue& e = p.e;
@@ -1244,12 +1244,48 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
         st_elems<T, 8>(yq, v[k]);
       }
     }
+    if (e.lnf2_y) {
+      // (uniform) the SECOND LayerNorm, of the values just stored (a layer's norm2 -> the next layer's first LayerNorm): they are
+      // still in the registers, two more sums per row
+      float g2[8], b2[8];
+#pragma unroll
+      for (int q4 = 0; q4 < 2; ++q4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(lng2 + c + 4 * q4), b4 = *reinterpret_cast<const float4*>(lng2 + W + c + 4 * q4);
+        g2[4 * q4] = g4.x; g2[4 * q4 + 1] = g4.y; g2[4 * q4 + 2] = g4.z; g2[4 * q4 + 3] = g4.w;
+        b2[4 * q4] = b4.x; b2[4 * q4 + 1] = b4.y; b2[4 * q4 + 2] = b4.z; b2[4 * q4 + 3] = b4.w;
+      }
+#pragma unroll
+      for (int k = 0; k < BR; ++k) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_ += v[k][q];
+        mean[k] = wave_sum_dpp(s_) * INVW;
+      }
+#pragma unroll
+      for (int k = 0; k < BR; ++k) {
+        float qq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v[k][q] -= mean[k]; qq += v[k][q] * v[k][q]; }
+        rstd[k] = rsqrtf(wave_sum_dpp(qq) * INVW + e.lnf2_eps);
+      }
+#pragma unroll
+      for (int k = 0; k < BR; ++k) {
+        const int r = r0 + 4 * (kb + k);
+        if ((t & 63) == 0) *reinterpret_cast<float2*>(lnst + 256 + 2 * (ph * 32 + r)) = make_float2(mean[k], rstd[k]);
+        if (nbase + r >= p.N) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[k][q] = v[k][q] * rstd[k] * g2[q] + b2[q];
+        st_elems<T, 8>(reinterpret_cast<T*>(e.lnf2_y) + (long)(nbase + r) * e.lnf2_ldy + c, v[k]);
+      }
+    }
   }
 }
 // the tile's statistics: rows [n0, n0 + 128) as one contiguous block (call after a barrier behind the last phase)
 __device__ __forceinline__ void ln512_store_stats(const GemmParams& p, const float* lnst, int n0, int t) {
   if (p.e.lnf_stats && t < 128 && n0 + t < p.N)
     *reinterpret_cast<float2*>(p.e.lnf_stats + 2 * (long)(n0 + t)) = *reinterpret_cast<const float2*>(lnst + 2 * t);
+  if (p.e.lnf2_y && p.e.lnf2_stats && t >= 128 && n0 + t - 128 < p.N)
+    *reinterpret_cast<float2*>(p.e.lnf2_stats + 2 * (long)(n0 + t - 128)) = *reinterpret_cast<const float2*>(lnst + 2 * t);
 }
 
 // LDS-DMA issue of one 1 KB piece (global_load_lds_dwordx4: lane i lands at lds_dst + 16 i; M0 carries the wave-uniform

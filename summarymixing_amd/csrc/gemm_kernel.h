@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
   constexpr int AB_BYTES = T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES;
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
-  // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta [| the tile's (mean, rstd) pairs: 128 x 512 LN forward]]
-  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0) + ((LNF == 2 && TILE_M == 512) ? 2 * TILE_N : 0)) * 4;
+  // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta [128 x 512 LN forward: | the tile's (mean, rstd) pairs of
+  // both LayerNorms | gamma | beta of the second LayerNorm]]
+  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0) + ((LNF == 2 && TILE_M == 512) ? 4 * TILE_N + 2 * TILE_M : 0)) * 4;
   // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) operand stage, fenced by one extra barrier
   constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536;
@@ -598,7 +599,12 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
     if (ln512f) {
       // (its own loop, chosen ONCE: with both paths inside one loop their hoisted row pointers and constants are live together and
       //  hipcc spills - every reload then sits behind the stores of the previous item, s_waitcnt vmcnt(0))
-      float* lnst = lng + 2 * TILE_M;
+      float* lnst = lng + 2 * TILE_M;                      // [2][128][2]: statistics of the LayerNorm and of the optional second one
+      float* lng2 = lnst + 4 * TILE_N;                     // gamma | beta of the second LayerNorm
+      if (e.lnf2_y) {                                      // (uniform; visible behind the first barrier of the loop)
+#pragma unroll
+        for (int cc = t; cc < TILE_M; cc += 256) { lng2[cc] = e.lnf2_gamma[cc]; lng2[TILE_M + cc] = e.lnf2_beta[cc]; }
+      }
       uint32_t resw[8][8];
       // the statistics block of this tile is written once, at the very end: touch its page NOW, so that the address translation
       // of that last store is not what the workgroup's slot waits for (measured: 18 us of a 209 us launch)
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
         }
         lds_barrier();
         if (ph < 2) SMX_STAMP(3 + 2 * ph);
-        epilogue_phase_ln512fwd<T>(p, smem, side, lng, lnst, ph, n0 + ph * 32, t, resw);
+        epilogue_phase_ln512fwd<T>(p, smem, side, lng, lnst, lng2, ph, n0 + ph * 32, t, resw);
         if (ph < 2) SMX_STAMP(4 + 2 * ph);
       }
       lds_barrier();

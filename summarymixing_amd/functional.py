@@ -250,14 +250,22 @@ def _vec_ok(*ts):
     return all(t is None or (t.data_ptr() % 16 == 0 and (t.stride(0) * t.element_size()) % 16 == 0) for t in ts)
 
 
-_LN_FUSE_FWD = True   # (round 4: SMX_LN_FUSE_FWD / _BWD A/B knobs removed; SMX_LN_FUSE switches both)   # A/B: only the forward (SMX_EPI_LN_FWD) ...
-_LN_FUSE_BWD = True   # ... / only the backward (SMX_EPI_LN_BWD) fusion off (C2b B = 128: 19.79 both, 19.90 without the forward, 20.84 without the backward one)
+# SMX_LN_FUSE = 1 (default) both directions, 0 none, "fwd" / "bwd": only the forward (SMX_EPI_LN_FWD) / only the backward (SMX_EPI_LN_BWD)
+# fusion (C2b B = 128: 19.79 both, 19.90 without the forward, 20.84 without the backward one)
+_LN_FUSE_FWD = os.environ.get("SMX_LN_FUSE", "1").lower() != "bwd"
+_LN_FUSE_BWD = os.environ.get("SMX_LN_FUSE", "1").lower() != "fwd"
 
 
-def ln_next_ok(x, M, ln_next, W=None, res=None):
-    """Can the LayerNorm that follows a Linear (its output: N x M) ride in that GEMM's epilogue (SMX_EPI_LN_FWD)?
+def ln_next_ok(x, M, ln_next, W=None, res=None, training=True):
+    """Can - and should - the LayerNorm that follows a Linear (its output: N x M) ride in that GEMM's epilogue (SMX_EPI_LN_FWD)?
     W / res: the weight (view) and residual the GEMM will be given - a column slice with an odd offset is not 16-byte aligned
-    and the fused instantiation has no scalar path."""
+    and the fused instantiation has no scalar path.
+    training: at M = 512 the row-complete tile is ONE workgroup per CU, whose epilogue nothing overlaps; in a training step the
+    fusion still wins (C2a 49.2 -> 48.4 ms, each direction ~0.75 ms), in a forward-only pass the standalone LayerNorm (a pure
+    stream at 5.9 TB/s, paired with the next layer's) is faster (C5 forward 60.2 vs 62.0 ms fused, C2a forward 16.97 vs 17.25;
+    tools/experiments/ab_lnfuse_d512.sh): not fused there."""
+    if M > 256 and not training:
+        return False
     return (_LN_FUSE and _LN_FUSE_FWD and ln_next is not None and x.dtype == torch.bfloat16 and x.shape[0] >= _LN_FUSE_MIN_ROWS and _vec_ok(x, W, res) and
             L.lib().smx_gemm_ln_fused_ok(L.BF16, x.shape[0], M, x.shape[1]) == 1)
 
@@ -265,8 +273,10 @@ def ln_next_ok(x, M, ln_next, W=None, res=None):
 def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, c0=None, c0_mode=L.C0_NONE,
                c0_div=0, save_z=False, out=None, out_f32=False, drop=None, c0_post=False, ln_next=None, ln_post=None,
                drop_cols=0):
-    """ln_next = (gamma, beta, eps, act, want_stats): the LayerNorm that follows this Linear runs in the GEMM epilogue
-    (check ln_next_ok first); ln_post (a list) receives (LN output, stats | None)."""
+    """ln_next = (gamma, beta, eps, act, want_stats[, stream_out[, pair]]): the LayerNorm that follows this Linear runs in the GEMM
+    epilogue (check ln_next_ok first); ln_post (a list) receives (LN output, stats | None).  pair = (gamma2, beta2, eps2): a second
+    LayerNorm of the first one's output in the same epilogue (check ln_pair_ok); ln_post then receives a second entry,
+    (LN2 output in x.dtype, stats2 | None)."""
     N, K = x.shape
     M = W.shape[0]
     if res is not None and res.dtype == torch.float32 and x.dtype != torch.float32:
@@ -274,7 +284,7 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
     if out is None:
         out = torch.empty((N, M), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
-    lnf = None
+    lnf = lnf2 = None
     if ln_next is not None:
         g, b, eps, lact, want_stats = ln_next[:5]
         # ln_next[5] = True: the LayerNorm output is itself the stream (the layer-final norm2): stream dtype, else GEMM input dtype
@@ -282,9 +292,15 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
         st = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
         lnf = (g.detach(), b.detach(), hy, st, eps, lact)
         ln_post.append((hy, st))
+        if len(ln_next) > 6 and ln_next[6] is not None:
+            g2, b2, eps2 = ln_next[6]
+            hy2 = torch.empty((N, M), dtype=x.dtype, device=x.device)
+            st2 = torch.empty((N, 2), dtype=torch.float32, device=x.device) if want_stats else None
+            lnf2 = (g2.detach(), b2.detach(), hy2, st2, eps2)
+            ln_post.append((hy2, st2))
     e = ops.epilogue(bias=bias, c0=c0, c0_mode=c0_mode, c0_div=c0_div, act=act, z=z, row_mask=mask, res=res,
                      alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post, ln_fwd=lnf,
-                     drop_cols=drop_cols)
+                     drop_cols=drop_cols, ln_fwd2=lnf2)
     ops.gemm(L.GEMM_NT, x, W, out, N, M, K, e)
     return out, z
 
@@ -751,13 +767,13 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             else:
                 ops.dropout(sbar, p_drop, s2, out=cat[:, lw:])
             sbar_t = None
-            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(cat, Wm.shape[0], ln_next, Wm, res)) else None
+            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(cat, Wm.shape[0], ln_next, Wm, res, need_bwd)) else None
             y, zm = linear_fwd(cat, Wm, mg["b"], act, None, res=res, save_z=need_bwd, ln_next=lnn, ln_post=post, out=out,
                                drop=out_drop)
         elif pool_kind == "mean":
             sbar_t = ops.cast(sbar, dtype)                                         # (B, sdim) in compute dtype
             c0, _ = linear_fwd(sbar_t, Ws, None, out_f32=True)                     # (B, s_out) fp32
-            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(local, Wl.shape[0], ln_next, Wl, res)) else None
+            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(local, Wl.shape[0], ln_next, Wl, res, need_bwd)) else None
             y, zm = linear_fwd(local, Wl, mg["b"], act, None, res=res, c0=c0, c0_mode=L.C0_GROUP, c0_div=T,
                                save_z=need_bwd, ln_next=lnn, ln_post=post, out=out, drop=out_drop)
         else:
@@ -973,23 +989,35 @@ def dwconv_bwd_deferred(dy, p_, wd, bd, gwd, gbd, B, T, D, k, glu, pad_mode, chu
     return dp, dg
 
 
-def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln_next=None):
+def ln_pair_ok(x, M, res, affine):
+    """Can the epilogue that runs a LayerNorm behind this Linear (ln_next_ok holds) also run a SECOND LayerNorm on its output
+    (smx_gemm_ln_pair_ok: the 128 x 512 tile, float32 residual stream)?"""
+    return (_LN_PAIR and res is not None and res.dtype == torch.float32 and x.dtype == torch.bfloat16 and
+            L.lib().smx_gemm_ln_pair_ok(L.BF16, x.shape[0], M, x.shape[1]) == 1 and
+            all(v.is_contiguous() and v.data_ptr() % 16 == 0 for v in affine))
+
+
+def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln_next=None, ln_pair=None):
     """y = x + alpha * D2(W2 D1(act(W1 LN(x) + b1)) + b2)   (Conformer.py:458-472,507,536; D = dropout, p = 0 in eval).
     With p == 0 the second Linear's epilogue carries the residual and alpha (no extra pass).
     pre_ln = (LN(x), stats) when the producer of x already ran this module's LayerNorm in its epilogue; ln_next = (gamma,
     beta, eps) of the LayerNorm that follows the module: it runs in the second Linear's epilogue where possible, and a
-    third value (LN(y), stats) | None is returned."""
+    third value (LN(y), stats) | None is returned.  ln_pair = (gamma2, beta2, eps2): the LayerNorm that follows THAT one (the next
+    layer's first); where the epilogue can run both, a fourth value (LN2(LN(y)), stats2) | None is returned."""
     h, ln_b = ln_fwd(x, P["ln_w"], P["ln_b"], 1e-5, need_bwd, pre=pre_ln, out_dtype=dtype)
     W1, W2 = wcast(P["W1"], dtype), wcast(P["W2"], dtype)
     d1 = (p, ops.new_dropout_seed()) if p > 0.0 else None       # both dropouts are fused into the GEMM epilogues
     d2 = (p, ops.new_dropout_seed()) if p > 0.0 else None
     a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1)
     post = []
-    lnn = ((ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) + tuple(ln_next[3:4])) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x)) else None
+    lnn = ((ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) + tuple(ln_next[3:4])) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x, need_bwd)) else None
+    if lnn is not None and ln_pair and len(lnn) > 5 and ln_pair_ok(a, W2.shape[0], x, ln_pair[:2]):
+        lnn = lnn + (ln_pair,)
     y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2, ln_next=lnn, ln_post=post)
-    post = post[0] if post else None
+    post, post2 = (post[0] if post else None), (post[1] if len(post) > 1 else None)
+    ret = lambda b: ((y, b, post, post2) if ln_pair is not None else (y, b, post)) if ln_next is not None else (y, b)
     if not need_bwd:
-        return (y, None, post) if ln_next is not None else (y, None)
+        return ret(None)
 
     def bwd(dy, dz_in=None, second=None):
         """dz_in: alpha * D2(dy) already computed by the producer of dy (see `pre`); second: forwarded to the module's own
@@ -1008,7 +1036,7 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
         dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True)
         return ln_b(dh, res=dy, second=second)
     bwd.pre = (alpha, None, d2)          # what this block does first to its incoming gradient: alpha * D2(dy)
-    return (y, bwd, post) if ln_next is not None else (y, bwd)
+    return ret(bwd)
 
 def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=True, p=0.0, pre_ln=None, ln_next=None):
     """y = [x +] mask * Linear(act(LN(dwconv(GLU(pw(LN(x)))))))   (Conformer.py:314-331,532-534).
@@ -1028,7 +1056,7 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
     Wo = wcast(P["Wo"], dtype)
     dr = (p, ops.new_dropout_seed()) if p > 0.0 else None   # Linear -> Dropout -> * mask (+ x): one epilogue
     post = []
-    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, Wo.shape[0], ln_next, Wo, x if residual else None)) else None
+    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, Wo.shape[0], ln_next, Wo, x if residual else None, need_bwd)) else None
     y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None, drop=dr, ln_next=lnn, ln_post=post)
     post = post[0] if post else None
     if not need_bwd:

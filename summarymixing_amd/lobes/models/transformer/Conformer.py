@@ -138,7 +138,9 @@ class ConformerEncoderLayer(nn.Module):
             y3, bconv, post3 = F.conv_module_fwd(y2, Pc, d_act, m8, B, T, need, dtype, chunk, p=pd, pre_ln=post2,
                                                  ln_next=(P2["ln_w"], P2["ln_b"], 1e-5))                          # :532-534
             # (norm2's output is the layer output = the next layer's residual stream: stream dtype, 4th element of ln_next)
-            y4, bf2, post4 = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd, pre_ln=post3, ln_next=(n2.weight, n2.bias, n2.eps, True))
+            # (inside a stack: where norm2 rides in the second FFN's down-projection, the NEXT layer's first LayerNorm can ride with it)
+            y4, bf2, post4, post_next = F.ffn_module_fwd(y3, P2, d_act, need, dtype, p=pd, pre_ln=post3, ln_next=(n2.weight, n2.bias, n2.eps, True),
+                                                         ln_pair=(Pn["ln_w"], Pn["ln_b"], 1e-5) if Pn is not None else ())
             if (post4 is None and Pn is not None and y4.dtype != dtype and
                     ops.layernorm_pair_ok(y4, dtype, n2.weight, n2.bias, Pn["ln_w"], Pn["ln_b"])):
                 # norm2 and the next layer's first LayerNorm in one pass over the float32 stream (equal to two launches to an ulp)

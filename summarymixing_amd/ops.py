@@ -93,7 +93,7 @@ def rows2d(x):
 
 def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, out_mode=L.OUT_T, z=None,
              row_mask=None, res=None, alpha=1.0, bias_batch_stride=0, drop=None, c0_post=False, act_grad_z=None,
-             colsum=None, ln_bwd=None, ln_fwd=None, drop_cols=0):
+             colsum=None, ln_bwd=None, ln_fwd=None, drop_cols=0, ln_fwd2=None):
     """Build an smx_epilogue.  act_grad_z: the saved pre-activation of the UPSTREAM layer (SMX_EPI_ACT_GRAD: the GEMM
     then emits alpha * D(acc * act'(z)) * mask, i.e. the upstream dZ); colsum: fp32 [M] accumulator of the output's
     column sums (the upstream bias gradient), workspace attached by gemm()."""
@@ -157,6 +157,15 @@ def epilogue(bias=None, c0=None, c0_mode=L.C0_NONE, c0_div=0, act=L.ACT_NONE, ou
         e.lnf_stats = stats.data_ptr() if stats is not None else None
         e.lnf_eps, e.lnf_act = eps, lact
         e.flags |= L.EPI_LN_FWD
+    if ln_fwd2 is not None:
+        # (gamma2, beta2, y2, stats2 | None, eps2): a SECOND LayerNorm of the first one's output (smx_epilogue.lnf2_*; check
+        # smx_gemm_ln_pair_ok first)
+        assert ln_fwd is not None
+        gamma2, beta2, y2, stats2, eps2 = ln_fwd2
+        e.lnf2_gamma, e.lnf2_beta = gamma2.data_ptr(), beta2.data_ptr()
+        e.lnf2_y, e.lnf2_ldy = y2.data_ptr(), _mat(y2)[1]
+        e.lnf2_stats = stats2.data_ptr() if stats2 is not None else None
+        e.lnf2_eps = eps2
     return e
 
 

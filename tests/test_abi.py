@@ -50,8 +50,8 @@ def test_version_and_error_string_need_no_gpu():
 
 def test_epilogue_struct_layout_matches_header():
     from summarymixing_amd import _lib
-    assert ctypes.sizeof(_lib.Epilogue) == 272  # 34 x 8 bytes (round 3: + io_flags, pad_, epoch), see include/smx.h smx_epilogue
-    assert _lib.Epilogue.io_flags.offset == 256 and _lib.Epilogue.epoch.offset == 264
+    assert ctypes.sizeof(_lib.Epilogue) == 320  # 40 x 8 bytes (round 3: + io_flags, pad_, epoch; round 5: + lnf2_*), see include/smx.h smx_epilogue
+    assert _lib.Epilogue.io_flags.offset == 256 and _lib.Epilogue.epoch.offset == 264 and _lib.Epilogue.lnf2_eps.offset == 312
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

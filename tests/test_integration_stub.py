@@ -29,7 +29,7 @@ def _stub_namespace():
 def test_stub_structure_matches_the_library():
     from summarymixing_amd import _lib
     ns = _stub_namespace()
-    assert ctypes.sizeof(ns["Epi"]) == ctypes.sizeof(_lib.Epilogue) == 272
+    assert ctypes.sizeof(ns["Epi"]) == ctypes.sizeof(_lib.Epilogue) == 320
     for name in ("bias", "c0", "ldc0", "c0_mode", "c0_div", "act", "out_mode", "row_mask", "alpha", "flags", "io_flags", "epoch"):
         assert getattr(ns["Epi"], name).offset == getattr(_lib.Epilogue, name).offset, name
     assert (ns["SMX_BF16"], ns["SWISH"], ns["C0_GROUP"], ns["OUT_F32"]) == (_lib.BF16, _lib.ACT_SWISH, _lib.C0_GROUP, _lib.OUT_F32)

@@ -750,6 +750,41 @@ def test_gemm_epilogue_layernorm_float32_stream(N, K, layout, D):
     assert rel_err(partial[:, 0].sum(0), (g * xh).sum(0)) < 2e-3 and rel_err(partial[:, 1].sum(0), g.sum(0)) < 2e-3
 
 
+@pytest.mark.parametrize("N,K", [(4096 + 9, 2048), (300, 512)])
+def test_gemm_epilogue_layernorm_pair(N, K):
+    """A Conformer layer's norm2 AND the next layer's first LayerNorm in the down-projection's epilogue (smx_epilogue.lnf2_*, the
+    128 x 512 tile on the float32 stream): C, y1 = LN1(C) (float32: the stream), y2 = LN2(y1) (bf16) and both statistics against
+    float64; the shapes that cannot take it answer smx_gemm_ln_pair_ok = 0 and the call fails loudly."""
+    from summarymixing_amd import _lib as L, ops
+    torch.manual_seed(N + K)
+    D = 512
+    assert L.lib().smx_gemm_ln_pair_ok(L.BF16, N, D, K) == 1 and L.lib().smx_gemm_ln_pair_ok(L.BF16, N, 256, K) == 0
+    a = torch.randn(N, K, device="cuda").bfloat16()
+    W = (torch.randn(D, K, device="cuda") * 0.05).bfloat16()
+    b = torch.randn(D, device="cuda")
+    res = torch.randn(N, D, device="cuda")
+    g1, b1 = torch.randn(D, device="cuda") * 0.5 + 1.0, torch.randn(D, device="cuda") * 0.1
+    g2, b2 = torch.randn(D, device="cuda") * 0.5 + 1.0, torch.randn(D, device="cuda") * 0.1
+    c, y1 = torch.empty(N, D, device="cuda"), torch.empty(N, D, device="cuda")
+    y2 = torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
+    s1, s2 = torch.empty(N, 2, device="cuda"), torch.empty(N, 2, device="cuda")
+    e = ops.epilogue(bias=b, res=res, alpha=0.5, drop=None, out_mode=L.OUT_F32, ln_fwd=(g1, b1, y1, s1, 1e-5, L.ACT_NONE),
+                     ln_fwd2=(g2, b2, y2, s2, 1e-5))
+    ops.gemm(L.GEMM_NT, a, W, c, N, D, K, e)
+    cref = res.double() + 0.5 * (a.double() @ W.double().t() + b.double())
+    m1, v1 = cref.mean(1, keepdim=True), cref.var(1, unbiased=False, keepdim=True)
+    y1r = (cref - m1) * (v1 + 1e-5).rsqrt() * g1.double() + b1.double()
+    m2, v2 = y1r.mean(1, keepdim=True), y1r.var(1, unbiased=False, keepdim=True)
+    y2r = (y1r - m2) * (v2 + 1e-5).rsqrt() * g2.double() + b2.double()
+    assert rel_err(c, cref) < 1e-2 and rel_err(y1, y1r) < 1e-2 and rel_err(y2, y2r) < 1.5e-2, (rel_err(c, cref), rel_err(y1, y1r), rel_err(y2, y2r))
+    assert rel_err(s1[:, 0], m1[:, 0]) < 2e-3 and rel_err(s1[:, 1], (v1 + 1e-5).rsqrt()[:, 0]) < 2e-3
+    assert rel_err(s2[:, 0], m2[:, 0]) < 2e-2 and rel_err(s2[:, 1], (v2 + 1e-5).rsqrt()[:, 0]) < 2e-3
+    # not the float32-stream form (bf16 residual and output): refused, not silently skipped
+    cb, rb = torch.empty(N, D, device="cuda", dtype=torch.bfloat16), res.bfloat16()
+    with pytest.raises(RuntimeError):
+        ops.gemm(L.GEMM_NT, a, W, cb, N, D, K, ops.epilogue(bias=b, res=rb, ln_fwd=(g1, b1, y2, s1, 1e-5, L.ACT_NONE), ln_fwd2=(g2, b2, y2, s2, 1e-5)))
+
+
 @pytest.mark.parametrize("D", [256, 512])
 def test_gemm_epilogue_layernorm_backward_with_activations(D):
     """The extended instantiation: the LayerNorm had a fused activation (y = swish(LN(x)), conv module LN2) and the second
