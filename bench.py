@@ -623,9 +623,11 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g_a, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_a):
+            # (thread_local: the RCCL watchdog thread polls the events of the warm-up collectives with hipEventQuery - in the default
+            #  global capture mode that call from ANOTHER thread aborts the process while a capture is open)
+            with torch.cuda.graph(g_a, capture_error_mode="thread_local"):
                 fwd_bwd()
-            with torch.cuda.graph(g_b):
+            with torch.cuda.graph(g_b, capture_error_mode="thread_local"):
                 opt.update_only()
 
             def run():
