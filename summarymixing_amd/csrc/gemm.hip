@@ -394,7 +394,7 @@ static int gemm_impl(int layout, int dtype, const void* A, int64_t lda, int64_t 
                 "smx_gemm: lnf2_* (second LayerNorm) goes with SMX_EPI_LN_FWD and needs gamma / beta / an aligned output");
     if (!(smx_gemm_ln_pair_ok(dtype, N, M, K) && p.e.out_mode == SMX_OUT_F32 && (p.e.io_flags & SMX_IO_RES_F32) && p.e.res && !p.e.c0 &&
           !p.e.colsum && batch == 1 && splits == 1))
-      return fail(SMX_EUNSUPPORTED, "smx_gemm: the second LayerNorm (lnf2_*) needs M == 512 and the float32-stream epilogue (smx_gemm_ln_pair_ok)");
+      return fail(SMX_EUNSUPPORTED, "smx_gemm: the second LayerNorm (lnf2_*) needs a row-complete tile and the float32-stream epilogue (smx_gemm_ln_pair_ok)");
   }
   if (p.e.colsum)
     SMX_REQUIRE(p.e.workspace && batch == 1 && splits == 1 && p.e.out_mode != SMX_OUT_ATOMIC_F32,
@@ -464,7 +464,7 @@ extern "C" int smx_gemm_ln_fused_ok(int dtype, int N, int M, int K) {
 }
 
 extern "C" int smx_gemm_ln_pair_ok(int dtype, int N, int M, int K) {
-  return smx_gemm_ln_fused_ok(dtype, N, M, K) && M == 512;
+  return smx_gemm_ln_fused_ok(dtype, N, M, K);
 }
 
 extern "C" size_t smx_gemm_colsum_workspace(int N, int M) {

@@ -1088,33 +1088,37 @@ __device__ __forceinline__ void epilogue_phase_lnfwd(const GemmParams& p, const 
   }
 }
 
-// ---- 128 x 512 tile, LayerNorm forward on the float32 residual stream (SMX_IO_RES_F32, float32 C), ONE pass per phase -------------
+// ---- LayerNorm forward on the float32 residual stream (SMX_IO_RES_F32, float32 C) in ONE pass per phase (row-complete tiles of
+// W = 256 or 512 columns) -------------------------------------------------------------------------------------------------------
 // The generic pair above (epilogue_phase with 4-column float32 items, write-back to the staged slots, barrier, epilogue_phase_lnfwd
-// with 8-column items) costs a second LDS round trip and a barrier per phase, and with ONE workgroup per CU nothing else runs
-// meanwhile.  Here thread t owns the 8 columns c = (t & 63) * 8 of rows r0 + 4 k (r0 = t >> 6, k < 8: a wave = a row) for the bias /
-// activation / dropout / mask / residual part AND the LayerNorm: the finished values never leave the registers, the row statistics
-// are two DPP sums per row.  The residual rows of the phase are requested BEFORE the accumulator dump (ln512_request_res), so their
-// round trip runs under the dump and its two barriers.  Eligibility (checked by the kernel, else the generic pair): SIMPLE == 2
-// epilogue (bias / activation / saved Z / dropout / row factors / one residual), float32 residual and output.
-__device__ __forceinline__ void ln512_request_res(const GemmParams& p, int nbase, int t, uint32_t (&rw)[8][8]) {
+// with 8-column items) costs a second LDS round trip and a barrier per phase.  Here thread t owns the 8 columns c = (t % LPR) * 8 of
+// rows r0 + RSTEP k (LPR = W / 8 lanes per row: a half wave or a wave = a row) for the bias / activation / dropout / mask / residual
+// part AND the LayerNorm: the finished values never leave the registers, the row statistics are two DPP sums per row.  The residual
+// rows of the phase are requested BEFORE the accumulator dump (ln1p_request_res), so their round trip runs under the dump and its
+// two barriers.  Eligibility (checked by the kernel, else the generic pair): SIMPLE == 2 epilogue (bias / activation / saved Z /
+// dropout / row factors / one residual), float32 residual and output.
+template <int W>
+__device__ __forceinline__ void ln1p_request_res(const GemmParams& p, int nbase, int t, uint32_t (&rw)[W / 64][8]) {
+  constexpr int LPR = W / 8, RSTEP = 256 / LPR, NIT = 32 / RSTEP;
   const float* R = reinterpret_cast<const float*>(p.e.res);
-  const int c = (t & 63) * 8, r0 = t >> 6;
+  const int c = (t % LPR) * 8, r0 = t / LPR;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const long n = min(nbase + r0 + 4 * k, p.N - 1);
+  for (int k = 0; k < NIT; ++k) {
+    const long n = min(nbase + r0 + RSTEP * k, p.N - 1);
     const uint4 a_ = *reinterpret_cast<const uint4*>(R + n * p.e.ldr + c), b_ = *reinterpret_cast<const uint4*>(R + n * p.e.ldr + c + 4);
     rw[k][0] = a_.x; rw[k][1] = a_.y; rw[k][2] = a_.z; rw[k][3] = a_.w; rw[k][4] = b_.x; rw[k][5] = b_.y; rw[k][6] = b_.z; rw[k][7] = b_.w;
   }
 }
-// lnst: [128][2] floats of LDS - the tile's (mean, rstd) pairs, written out as ONE contiguous 1 KB block by ln512_store_stats after
-// the last phase (a lane's own 8-byte store per row - 32 partial-line writes per wave and phase - cost more than the LayerNorm math)
-template <typename T>
-__device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, const char* smem, const float* side, const float* lng, float* lnst,
-                                                        const float* lng2, int ph, int nbase, int t, uint32_t (&rw)[8][8]) {
-  constexpr int W = 512, STG_LD = W * 4 + 16, BR = 4;
+// lnst: [2][128][2] floats of LDS - the tile's (mean, rstd) pairs (of the LayerNorm and of the optional second one), written out as
+// contiguous 1 KB blocks by ln1p_store_stats after the last phase
+template <typename T, int W>
+__device__ __forceinline__ void epilogue_phase_ln1p(const GemmParams& p, const char* smem, const float* side, const float* lng, float* lnst,
+                                                    const float* lng2, int ph, int nbase, int t, uint32_t (&rw)[W / 64][8]) {
+  constexpr int LPR = W / 8, RSTEP = 256 / LPR, NIT = 32 / RSTEP, STG_LD = W * 4 + 16;
+  constexpr int BR = W == 512 ? 4 : 2;                   // rows in flight (the 256-wide kernels run two per CU at the 256-register budget)
   constexpr float INVW = 1.f / W;
   const smx_epilogue& e = p.e;
-  const int c = (t & 63) * 8, r0 = t >> 6;
+  const int c = (t % LPR) * 8, r0 = t / LPR;
   const uint32_t dthresh = p.dthresh;
   const float dscale = p.dscale;
   const uint64_t dseed = dthresh ? epoch_seed(e.drop_seed, p.epoch) : 0;
@@ -1122,12 +1126,12 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
   const bool do_drop = dthresh && c < p.drop_cols;         // (drop_cols is a multiple of 8: an item is wholly inside or outside)
   const float* mkrow = side + W + ph * 32;
   const bool yf32 = (e.io_flags & SMX_IO_LNFY_F32) != 0;  // the LayerNorm output IS the fp32 residual stream (norm2)
-  // row pointers of this thread's first row; every further row is 4 rows on (one 64-bit add each, nothing recomputed per row)
+  // row pointers of this thread's first row; every further row is RSTEP rows on (one 64-bit add each, nothing recomputed per row)
   const long row0 = nbase + r0;
   float* cp = reinterpret_cast<float*>(p.C) + row0 * p.ldc + c;
   T* zp = e.z ? reinterpret_cast<T*>(e.z) + row0 * e.ldz + c : nullptr;
   char* yp = reinterpret_cast<char*>(e.lnf_y) + (row0 * e.lnf_ldy + c) * (yf32 ? 4 : (long)sizeof(T));
-  const long cstep = 4 * p.ldc, zstep = 4 * e.ldz, ystep = 4 * e.lnf_ldy * (yf32 ? 4 : (long)sizeof(T));
+  const long cstep = RSTEP * p.ldc, zstep = RSTEP * e.ldz, ystep = RSTEP * e.lnf_ldy * (yf32 ? 4 : (long)sizeof(T));
   float gam[8], bet[8], bia[8];
 #pragma unroll
   for (int q4 = 0; q4 < 2; ++q4) {
@@ -1138,15 +1142,15 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
     bia[4 * q4] = s4.x; bia[4 * q4 + 1] = s4.y; bia[4 * q4 + 2] = s4.z; bia[4 * q4 + 3] = s4.w;
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < NIT; ++k)
 #pragma unroll
     for (int q = 0; q < 8; ++q) settle(rw[k][q]);         // the phase's residual rows have landed: no load below, the stores stream
 #pragma unroll
-  for (int kb = 0; kb < 8; kb += BR) {
+  for (int kb = 0; kb < NIT; kb += BR) {
     float v[BR][8], mean[BR], rstd[BR];
 #pragma unroll
     for (int k = 0; k < BR; ++k) {
-      const int r = r0 + 4 * (kb + k);
+      const int r = r0 + RSTEP * (kb + k);
 #pragma unroll
       for (int q4 = 0; q4 < 2; ++q4) {
         const float4 a4 = *reinterpret_cast<const float4*>(smem + r * STG_LD + (c + 4 * q4) * 4);
@@ -1157,7 +1161,7 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
     if (zp) {                                              // (uniform) saved pre-activation
 #pragma unroll
       for (int k = 0; k < BR; ++k)
-        if (nbase + r0 + 4 * (kb + k) < p.N) st_elems_nt<T, 8>(zp + (kb + k) * zstep, v[k]);
+        if (nbase + r0 + RSTEP * (kb + k) < p.N) st_elems_nt<T, 8>(zp + (kb + k) * zstep, v[k]);
     }
     switch (e.act) {                                       // ONE uniform switch per batch of rows
       case SMX_ACT_GELU:
@@ -1181,14 +1185,14 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
     if (do_drop) {
 #pragma unroll
       for (int k = 0; k < BR; ++k)
-        dropout_apply<8>(v[k], dseed, (uint64_t)(nbase + r0 + 4 * (kb + k)) * p.drop_cols + c, dthresh, dscale);
+        dropout_apply<8>(v[k], dseed, (uint64_t)(nbase + r0 + RSTEP * (kb + k)) * p.drop_cols + c, dthresh, dscale);
     }
 #pragma unroll
     for (int k = 0; k < BR; ++k) {
-      const float mk = has_mk ? mkrow[r0 + 4 * (kb + k)] : 1.f;
+      const float mk = has_mk ? mkrow[r0 + RSTEP * (kb + k)] : 1.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[k][q] = v[k][q] * mk + __uint_as_float(rw[kb + k][q]);
-      if (nbase + r0 + 4 * (kb + k) < p.N) {               // C: the new stream tensor, streamed past the caches (the next kernel reads lnf_y)
+      if (nbase + r0 + RSTEP * (kb + k) < p.N) {               // C: the new stream tensor, streamed past the caches (the next kernel reads lnf_y)
         float* cq = cp + (kb + k) * cstep;
         st_elems_nt<float, 4>(cq, reinterpret_cast<const float(&)[4]>(v[k][0]));
         st_elems_nt<float, 4>(cq + 4, reinterpret_cast<const float(&)[4]>(v[k][4]));
@@ -1199,14 +1203,14 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
       float s_ = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) s_ += v[k][q];
-      mean[k] = wave_sum_dpp(s_) * INVW;
+      mean[k] = ln_row_sum<W>(s_) * INVW;
     }
 #pragma unroll
     for (int k = 0; k < BR; ++k) {
       float qq = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { v[k][q] -= mean[k]; qq += v[k][q] * v[k][q]; }
-      rstd[k] = rsqrtf(wave_sum_dpp(qq) * INVW + e.lnf_eps);
+      rstd[k] = rsqrtf(ln_row_sum<W>(qq) * INVW + e.lnf_eps);
     }
 #pragma unroll
     for (int k = 0; k < BR; ++k)
@@ -1233,8 +1237,8 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
     }
 #pragma unroll
     for (int k = 0; k < BR; ++k) {
-      const int r = r0 + 4 * (kb + k);
-      if ((t & 63) == 0) *reinterpret_cast<float2*>(lnst + 2 * (ph * 32 + r)) = make_float2(mean[k], rstd[k]);
+      const int r = r0 + RSTEP * (kb + k);
+      if ((t % LPR) == 0) *reinterpret_cast<float2*>(lnst + 2 * (ph * 32 + r)) = make_float2(mean[k], rstd[k]);
       if (nbase + r >= p.N) continue;
       char* yq = yp + (kb + k) * ystep;
       if (yf32) {                                          // (uniform)
@@ -1259,19 +1263,19 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
         float s_ = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_ += v[k][q];
-        mean[k] = wave_sum_dpp(s_) * INVW;
+        mean[k] = ln_row_sum<W>(s_) * INVW;
       }
 #pragma unroll
       for (int k = 0; k < BR; ++k) {
         float qq = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { v[k][q] -= mean[k]; qq += v[k][q] * v[k][q]; }
-        rstd[k] = rsqrtf(wave_sum_dpp(qq) * INVW + e.lnf2_eps);
+        rstd[k] = rsqrtf(ln_row_sum<W>(qq) * INVW + e.lnf2_eps);
       }
 #pragma unroll
       for (int k = 0; k < BR; ++k) {
-        const int r = r0 + 4 * (kb + k);
-        if ((t & 63) == 0) *reinterpret_cast<float2*>(lnst + 256 + 2 * (ph * 32 + r)) = make_float2(mean[k], rstd[k]);
+        const int r = r0 + RSTEP * (kb + k);
+        if ((t % LPR) == 0) *reinterpret_cast<float2*>(lnst + 256 + 2 * (ph * 32 + r)) = make_float2(mean[k], rstd[k]);
         if (nbase + r >= p.N) continue;
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[k][q] = v[k][q] * rstd[k] * g2[q] + b2[q];
@@ -1281,7 +1285,7 @@ __device__ __forceinline__ void epilogue_phase_ln512fwd(const GemmParams& p, con
   }
 }
 // the tile's statistics: rows [n0, n0 + 128) as one contiguous block (call after a barrier behind the last phase)
-__device__ __forceinline__ void ln512_store_stats(const GemmParams& p, const float* lnst, int n0, int t) {
+__device__ __forceinline__ void ln1p_store_stats(const GemmParams& p, const float* lnst, int n0, int t) {
   if (p.e.lnf_stats && t < 128 && n0 + t < p.N)
     *reinterpret_cast<float2*>(p.e.lnf_stats + 2 * (long)(n0 + t)) = *reinterpret_cast<const float2*>(lnst + 2 * t);
   if (p.e.lnf2_y && p.e.lnf2_stats && t >= 128 && n0 + t - 128 < p.N)

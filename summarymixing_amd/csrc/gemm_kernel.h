@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
   constexpr int AB_BYTES = T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES;
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
-  // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta [128 x 512 LN forward: | the tile's (mean, rstd) pairs of
-  // both LayerNorms | gamma | beta of the second LayerNorm]]
-  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0) + ((LNF == 2 && TILE_M == 512) ? 4 * TILE_N + 2 * TILE_M : 0)) * 4;
+  // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta [LN forward: | the tile's (mean, rstd) pairs of both
+  // LayerNorms | gamma | beta of the second LayerNorm]]
+  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0) + (LNF == 2 ? 4 * TILE_N + 2 * TILE_M : 0)) * 4;
   // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) operand stage, fenced by one extra barrier
   constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536;
@@ -558,8 +558,8 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
       for (int q = 0; q < 8; ++q) dgam[q] = dbet[q] = 0.f;
     }
   }
-  // ROW512 + LayerNorm forward on the float32 stream: the one-pass phase of gemm_common.h (epilogue_phase_ln512fwd)
-  constexpr bool LN512F = ROW512 && LNF == 2;
+  // LayerNorm forward on the float32 stream: the one-pass phase of gemm_common.h (epilogue_phase_ln1p), both row-complete tiles
+  constexpr bool LN512F = LNF == 2;
   const bool ln512f = LN512F && osz == 4 && p.epi_simple == 2 && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr &&
                       !(e.flags & SMX_EPI_ACT_GRAD) && p.batch == 1;
   if constexpr (ROW512 && LNB) {
@@ -605,34 +605,36 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
 #pragma unroll
         for (int cc = t; cc < TILE_M; cc += 256) { lng2[cc] = e.lnf2_gamma[cc]; lng2[TILE_M + cc] = e.lnf2_beta[cc]; }
       }
-      uint32_t resw[8][8];
+      uint32_t resw[TILE_M / 64][8];
       // the statistics block of this tile is written once, at the very end: touch its page NOW, so that the address translation
       // of that last store is not what the workgroup's slot waits for (measured: 18 us of a 209 us launch)
       float st_touch = 0.f;
       if (e.lnf_stats && t == 0) st_touch = __builtin_nontemporal_load(e.lnf_stats + 2 * (long)n0);
 #pragma unroll 1
       for (int ph = 0; ph < NPH; ++ph) {
-        ln512_request_res(p, n0 + ph * 32, t, resw);       // (in flight under the dump and its two barriers)
+        ln1p_request_res<TILE_M>(p, n0 + ph * 32, t, resw);   // (in flight under the dump and its two barriers)
         lds_barrier();
+        if (wn == (ph * 32) / WN) {                        // the wave row that owns these accumulator rows (128 x 512: every wave)
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-          if (i == ph) {
+          for (int i = 0; i < FN; ++i) {
+            if (i == ((ph * 32) % WN) / 32) {
 #pragma unroll
-            for (int j = 0; j < FM; ++j)
+              for (int j = 0; j < FM; ++j)
 #pragma unroll
-              for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(smem + l31 * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
-                    make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+                for (int g = 0; g < 4; ++g)
+                  *reinterpret_cast<float4*>(smem + l31 * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                      make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+            }
           }
         }
         lds_barrier();
         if (ph < 2) SMX_STAMP(3 + 2 * ph);
-        epilogue_phase_ln512fwd<T>(p, smem, side, lng, lnst, lng2, ph, n0 + ph * 32, t, resw);
+        epilogue_phase_ln1p<T, TILE_M>(p, smem, side, lng, lnst, lng2, ph, n0 + ph * 32, t, resw);
         if (ph < 2) SMX_STAMP(4 + 2 * ph);
       }
       lds_barrier();
       asm volatile("" :: "v"(st_touch));
-      ln512_store_stats(p, lnst, n0, t);
+      ln1p_store_stats(p, lnst, n0, t);
       SMX_STAMP(7);
       return;
     }

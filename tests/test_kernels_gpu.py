@@ -750,15 +750,15 @@ def test_gemm_epilogue_layernorm_float32_stream(N, K, layout, D):
     assert rel_err(partial[:, 0].sum(0), (g * xh).sum(0)) < 2e-3 and rel_err(partial[:, 1].sum(0), g.sum(0)) < 2e-3
 
 
+@pytest.mark.parametrize("D", [256, 512])
 @pytest.mark.parametrize("N,K", [(4096 + 9, 2048), (300, 512)])
-def test_gemm_epilogue_layernorm_pair(N, K):
+def test_gemm_epilogue_layernorm_pair(N, K, D):
     """A Conformer layer's norm2 AND the next layer's first LayerNorm in the down-projection's epilogue (smx_epilogue.lnf2_*, the
-    128 x 512 tile on the float32 stream): C, y1 = LN1(C) (float32: the stream), y2 = LN2(y1) (bf16) and both statistics against
-    float64; the shapes that cannot take it answer smx_gemm_ln_pair_ok = 0 and the call fails loudly."""
+    row-complete tiles on the float32 stream): C, y1 = LN1(C) (float32: the stream), y2 = LN2(y1) (bf16) and both statistics against
+    float64; the shapes that cannot take it answer smx_gemm_ln_pair_ok = 0 and a call that is not the float32-stream form fails loudly."""
     from summarymixing_amd import _lib as L, ops
     torch.manual_seed(N + K)
-    D = 512
-    assert L.lib().smx_gemm_ln_pair_ok(L.BF16, N, D, K) == 1 and L.lib().smx_gemm_ln_pair_ok(L.BF16, N, 256, K) == 0
+    assert L.lib().smx_gemm_ln_pair_ok(L.BF16, N, D, K) == 1 and L.lib().smx_gemm_ln_pair_ok(L.BF16, N, 384, K) == 0
     a = torch.randn(N, K, device="cuda").bfloat16()
     W = (torch.randn(D, K, device="cuda") * 0.05).bfloat16()
     b = torch.randn(D, device="cuda")
