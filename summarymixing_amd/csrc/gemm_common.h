@@ -850,27 +850,28 @@ __device__ __forceinline__ void epilogue_phase_lnbwd(const GemmParams& p, const 
   }
 }
 
-// ---- the same on the 128 x 512 tile (one workgroup per CU: nothing else hides a round trip), split into REQUEST and CONSUME: the
-// side inputs of 16 rows (a half phase: rows r0 + 4 k, k < 4, of the thread's wave) - LayerNorm input, statistics, residual gradient,
-// the second output's mask byte and saved pre-activation - are requested half a phase ahead (the first half before the accumulator
-// dump, the second right behind it, the next phase's first half behind this phase's first half), so no load of the epilogue is ever
-// waited for behind a store and every round trip runs under the dump, the barriers or the other half's math.
-template <typename T, bool EXT, bool XF32>
-struct Ln512BwdIn {
-  uint32_t xw[4][XF32 ? 8 : 4], rw[4][4], zw[EXT ? 4 : 1][4], mk[4];
-  float2 st[4];
+// ---- the same, split into REQUEST and CONSUME: the side inputs of 16 rows (a half phase: rows r0 + RSTEP k, k < NH, of the thread's
+// half wave / wave) - LayerNorm input, statistics, residual gradient, the second output's mask byte and saved pre-activation - go
+// into ONE register set; the first half of a phase is requested BEFORE the accumulator dump of that phase, so its round trip runs
+// under the dump and its barriers, and the mask / pre-activation of the second output are no longer loaded behind the dX store.
+template <typename T, bool EXT, bool XF32, int W>
+struct LnBwdIn {
+  static constexpr int NH = 16 / (256 / (W / 8));         // rows of a half phase per thread (W = 256: 2, W = 512: 4)
+  uint32_t xw[NH][XF32 ? 8 : 4], rw[NH][4], zw[EXT ? NH : 1][4], mk[NH];
+  float2 st[NH];
 };
-template <typename T, bool EXT, bool XF32>
-__device__ __forceinline__ void ln512_bwd_request(const GemmParams& p, int nbase, int t, Ln512BwdIn<T, EXT, XF32>& in) {
+template <typename T, bool EXT, bool XF32, int W>
+__device__ __forceinline__ void ln_bwd_request(const GemmParams& p, int nbase, int t, LnBwdIn<T, EXT, XF32, W>& in) {
   typedef typename std::conditional<XF32, float, T>::type XT;
+  constexpr int LPR = W / 8, RSTEP = 256 / LPR, NH = 16 / RSTEP;
   const smx_epilogue& e = p.e;
-  const int c = (t & 63) * 8, r0 = t >> 6;
+  const int c = (t % LPR) * 8, r0 = t / LPR;
   const XT* X = reinterpret_cast<const XT*>(e.ln_x);
   const T* R = reinterpret_cast<const T*>(e.res);
   const T* Z2 = EXT ? reinterpret_cast<const T*>(e.z) : nullptr;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const long n = min(nbase + r0 + 4 * k, p.N - 1);
+  for (int k = 0; k < NH; ++k) {
+    const long n = min(nbase + r0 + RSTEP * k, p.N - 1);
     if constexpr (XF32) {
       const uint4 a_ = *reinterpret_cast<const uint4*>(X + n * e.ln_ldx + c), b_ = *reinterpret_cast<const uint4*>(X + n * e.ln_ldx + c + 4);
       in.xw[k][0] = a_.x; in.xw[k][1] = a_.y; in.xw[k][2] = a_.z; in.xw[k][3] = a_.w;
@@ -886,13 +887,13 @@ __device__ __forceinline__ void ln512_bwd_request(const GemmParams& p, int nbase
     }
   }
 }
-template <typename T, bool EXT, bool XF32>
-__device__ __forceinline__ void ln512_bwd_half(const GemmParams& p, const char* smh, const float* lng, int nbase, int t,
-                                               Ln512BwdIn<T, EXT, XF32>& in, float (&dgam)[8], float (&dbet)[8]) {
-  constexpr int W = 512, STG_LD = W * 4 + 16, SWX = XF32 ? 8 : 4;
+template <typename T, bool EXT, bool XF32, int W>
+__device__ __forceinline__ void ln_bwd_half(const GemmParams& p, const char* smh, const float* lng, int nbase, int t,
+                                            LnBwdIn<T, EXT, XF32, W>& in, float (&dgam)[8], float (&dbet)[8]) {
+  constexpr int LPR = W / 8, RSTEP = 256 / LPR, NH = 16 / RSTEP, STG_LD = W * 4 + 16, SWX = XF32 ? 8 : 4;
   constexpr float INVW = 1.f / W;
   const smx_epilogue& e = p.e;
-  const int c = (t & 63) * 8, r0 = t >> 6;
+  const int c = (t % LPR) * 8, r0 = t / LPR;
   const bool hasR = e.res != nullptr, hasZ2 = EXT && e.z != nullptr && e.ln_dx2 != nullptr, hasM2 = e.ln_dx2 != nullptr && e.ln_mask2 != nullptr;
   float gam[8];
 #pragma unroll
@@ -903,33 +904,33 @@ __device__ __forceinline__ void ln512_bwd_half(const GemmParams& p, const char* 
   const int lact = EXT ? e.lnf_act : SMX_ACT_NONE;       // the LayerNorm was followed by a fused activation: g *= act'(LN(x))
   // every (uniform) branch that loaded settles its own registers: no pending load on any path afterwards
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < NH; ++k) {
 #pragma unroll
     for (int q = 0; q < SWX; ++q) settle(in.xw[k][q]);
     settle(in.st[k].x); settle(in.st[k].y);
   }
   if (hasR) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NH; ++k)
 #pragma unroll
       for (int q = 0; q < 4; ++q) settle(in.rw[k][q]);
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NH; ++k)
 #pragma unroll
       for (int q = 0; q < 4; ++q) in.rw[k][q] = 0u;
   }
   if (hasM2) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) settle(in.mk[k]);
+    for (int k = 0; k < NH; ++k) settle(in.mk[k]);
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) in.mk[k] = 1u;
+    for (int k = 0; k < NH; ++k) in.mk[k] = 1u;
   }
   if constexpr (EXT) {
     if (hasZ2) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < NH; ++k)
 #pragma unroll
         for (int q = 0; q < 4; ++q) settle(in.zw[k][q]);
     }
@@ -939,12 +940,12 @@ __device__ __forceinline__ void ln512_bwd_half(const GemmParams& p, const char* 
   const uint64_t seed2 = thresh2 ? epoch_seed(e.ln_drop_seed2, p.epoch) : 0;
   // two rows at a time (four independent reduction chains): with four the 2 x 60 request registers + 64 of v / xhat spill
 #pragma unroll
-  for (int kb = 0; kb < 4; kb += 2) {
+  for (int kb = 0; kb < NH; kb += 2) {
   float v[2][8], xh[2][8], s1[2], s2[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     const int k = kb + kk;
-    const int r = r0 + 4 * k;
+    const int r = r0 + RSTEP * k;
     const bool rok = nbase + r < p.N;
 #pragma unroll
     for (int q4 = 0; q4 < 2; ++q4) {
@@ -983,11 +984,11 @@ __device__ __forceinline__ void ln512_bwd_half(const GemmParams& p, const char* 
     s1[kk] = a1; s2[kk] = a2;
   }
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) { s1[kk] = wave_sum_dpp(s1[kk]) * INVW; s2[kk] = wave_sum_dpp(s2[kk]) * INVW; }   // four independent chains
+  for (int kk = 0; kk < 2; ++kk) { s1[kk] = ln_row_sum<W>(s1[kk]) * INVW; s2[kk] = ln_row_sum<W>(s2[kk]) * INVW; }   // four independent chains
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     const int k = kb + kk;
-    const long n = nbase + r0 + 4 * k;
+    const long n = nbase + r0 + RSTEP * k;
     if (n >= p.N) continue;
     float rf[8];
     unpack_words<T, 8>(in.rw[k], rf);

@@ -563,35 +563,39 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
   const bool ln512f = LN512F && osz == 4 && p.epi_simple == 2 && (e.io_flags & SMX_IO_RES_F32) != 0 && e.res != nullptr &&
                       !(e.flags & SMX_EPI_ACT_GRAD) && p.batch == 1;
   if constexpr (ROW512 && LNB) {
-    // LayerNorm backward on the 128 x 512 tile: its own loop with the side inputs requested half a phase ahead (gemm_common.h)
+    // LayerNorm backward on the 128 x 512 tile: its own loop with the first half's side inputs requested ahead of the dump
+    // (gemm_common.h).  NOT on the 128 x 256 tile: its 128 accumulators live in the arch VGPRs of a 256-register budget, the request
+    // set spills 28-60 registers there (C2b step, same box: 17.74 -> 20.0 ms) - it keeps the generic phase below.
     constexpr bool EXT_ = (LNF & 3) == 3, XF_ = (LNF & 4) != 0;
     // ONE request set: the first half of a phase is requested before the accumulator dump of that phase (behind the previous
     // phase's last stores: the round trip runs under the two barriers and the dump), the second half where it is consumed.
     // (Measured, 64 000 x 2048 -> 512: the generic pair of loads per half 174.8 us; two request sets, every half prefetched: 194.8 us
     //  - 2 x 60 registers next to the 256 accumulators spill 27-150 registers into the item loops; the four phases as straight-line
     //  code, so that dumped accumulator fragments die: 86-159 spilled.)
-    Ln512BwdIn<T, EXT_, XF_> in;
-    ln512_bwd_request<T, EXT_, XF_>(p, n0, t, in);
+    LnBwdIn<T, EXT_, XF_, TILE_M> in;
+    ln_bwd_request<T, EXT_, XF_, TILE_M>(p, n0, t, in);
 #pragma unroll 1
     for (int ph = 0; ph < NPH; ++ph) {
       lds_barrier();
+      if (wn == (ph * 32) / WN) {                          // the wave row that owns these accumulator rows (128 x 512: every wave)
 #pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        if (i == ph) {
+        for (int i = 0; i < FN; ++i) {
+          if (i == ((ph * 32) % WN) / 32) {
 #pragma unroll
-          for (int j = 0; j < FM; ++j)
+            for (int j = 0; j < FM; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<float4*>(smem + l31 * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
-                  make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+              for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(smem + l31 * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                    make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+          }
         }
       }
       lds_barrier();
       if (ph < 2) SMX_STAMP(3 + 2 * ph);
-      ln512_bwd_half<T, EXT_, XF_>(p, smem, lng, n0 + ph * 32, t, in, dgam, dbet);
-      ln512_bwd_request<T, EXT_, XF_>(p, n0 + ph * 32 + 16, t, in);
-      ln512_bwd_half<T, EXT_, XF_>(p, smem + 16 * STG_LD, lng, n0 + ph * 32 + 16, t, in, dgam, dbet);
-      if (ph + 1 < NPH) ln512_bwd_request<T, EXT_, XF_>(p, n0 + ph * 32 + 32, t, in);      // (uniform)
+      ln_bwd_half<T, EXT_, XF_, TILE_M>(p, smem, lng, n0 + ph * 32, t, in, dgam, dbet);
+      ln_bwd_request<T, EXT_, XF_, TILE_M>(p, n0 + ph * 32 + 16, t, in);
+      ln_bwd_half<T, EXT_, XF_, TILE_M>(p, smem + 16 * STG_LD, lng, n0 + ph * 32 + 16, t, in, dgam, dbet);
+      if (ph + 1 < NPH) ln_bwd_request<T, EXT_, XF_, TILE_M>(p, n0 + ph * 32 + 32, t, in);      // (uniform)
       if (ph < 2) SMX_STAMP(4 + 2 * ph);
     }
   } else {
