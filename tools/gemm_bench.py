@@ -37,6 +37,14 @@ def build(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
         e = ops.epilogue(bias=b, res=r, alpha=0.5, drop=(0.15, 99))
         fn = lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e)
         nbytes = (N * K + M * K + 2 * N * M) * es
+    elif layout == "NTres32":  # forward Linear + bias + float32 residual -> float32 stream tensor (eval: no dropout; the unfused down-projection)
+        w = (torch.randn(M, K, device="cuda") * 0.05).to(dtype)
+        y = torch.empty(N, M, device="cuda", dtype=torch.float32)
+        r = torch.randn(N, M, device="cuda")
+        b = torch.randn(M, device="cuda")
+        e = ops.epilogue(bias=b, res=r, alpha=0.5, out_mode=L.OUT_F32)
+        fn = lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e)
+        nbytes = (N * K + M * K) * es + N * M * 8
     elif layout in ("NTln", "NTln2"):   # Linear + bias + dropout + alpha + float32 residual -> float32 stream tensor, LayerNorm appended
         # (FFN down-projection K = 4d / merge, conv out-projection K = d of a Conformer layer on the float32 residual stream;
         #  NTln2: the LayerNorm output is the stream itself - the layer-final norm2 - and float32 as well)

@@ -2,7 +2,7 @@
 # Re-measure everything profiles/ holds for this round (run on the GPU box through gpurun; outputs land in
 # gpurun_out/refresh/, copy them into profiles/ afterwards):  gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03 v2'
 set -uo pipefail
-R="${1:-r04}"; TAG="${2:-vX}"
+R="${1:-r05}"; TAG="${2:-vX}"
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/refresh"; mkdir -p "$OUT"
 cd "$ROOT"
@@ -31,6 +31,11 @@ STEPS=7 prof "${R}_fwd_c5_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- pytho
 STEPS=25 prof "${R}_step_c2a_recipe_batch_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --config c2a --batch 10 --frames 375 --steps 20 --warmup 5   (25 steps; the recipe's batch of 150 s: 3750 frames, hipGraph replay)" python "$ROOT/bench.py" --config c2a --batch 10 --frames 375 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline
 STEPS=7 prof "${R}_step_c2b_dynchunk_8_2_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --dynchunk 8,2 --steps 5 --warmup 2   (7 steps; C2b with DynChunk chunk 8, left context 2 chunks)" python "$ROOT/bench.py" --dynchunk 8,2 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline
 STEPS=1 prof "${R}_frontend_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python tools/frontend_bench.py   (waveform -> fbank -> InputNormalization -> CNN fwd / fwd+bwd at B = 128 x 20 s; per-call averages are the figures, the 'step' total covers all timed repetitions)" python "$ROOT/tools/frontend_bench.py"
+STEPS=25 prof "${R}_step_c2b_b1_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --batch 1 --steps 20 --warmup 5   (25 steps; C2b, ONE utterance of 500 frames, hipGraph replay)" python "$ROOT/bench.py" --batch 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra-points
+python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-extra-points 2>/dev/null | tail -1 > "$OUT/${R}_bench_b1.json"
+python bench.py --config c2a --batch 10 --frames 375 --grad-accum 4 --accum fused --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/${R}_bench_c2a_recipe_accum4_fused.json"
+python tools/blaslt_plus_epilogue.py > "$OUT/${R}_blaslt_plus_epilogue.txt" 2>/dev/null
+D=512 F=2048 python tools/blaslt_plus_epilogue.py > "$OUT/${R}_blaslt_plus_epilogue_d512.txt" 2>/dev/null
 STEPS=8 prof "${R}_wgrad_group_isolated.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 layer   (8 launches: the 8 weight gradients of a C2b layer, 64000 frames, isolated back to back; algorithmic 983 + 1.4 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 layer
 STEPS=8 prof "${R}_wgrad_group_one_1024x256.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 one   (8 launches: dW(1024x256) alone over 64000 frames; algorithmic 164.9 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 one
 # counter passes last and only on request (PMC=1): after them the box has been seen to lose its device for the next process
