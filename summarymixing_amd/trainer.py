@@ -179,17 +179,42 @@ class FlatAdamW:
                     dist.all_gather_into_tensor(full[a:b], local[sa:sb].contiguous(), group=self.pg)
         return m, v
 
-    def state_dict(self):
-        """Optimizer state for checkpoint / resume (the weights themselves are in module.state_dict()).  The moments are
-        always COMPLETE, independent of the gradient exchange mode: with reduce="rs_ag" this is a collective call (every rank
-        must make it; any rank may then write the result) and the checkpoint can be resumed under any mode / world size."""
+    def state_dict(self, gather=True):
+        """Optimizer state for checkpoint / resume (the weights themselves are in module.state_dict()).
+
+        gather=True (default): the moments are COMPLETE, independent of the gradient exchange mode, and the checkpoint resumes
+        under any mode / world size.  With reduce="rs_ag" that makes this call a COLLECTIVE (an all-gather per bucket): EVERY
+        rank must make it - the usual `if rank == 0: save(opt.state_dict())` deadlocks; call it on all ranks and let any one
+        of them write the result.
+
+        gather=False: no communication.  Under "rs_ag" the result holds only what this rank owns ("owned": its element ranges;
+        the moments elsewhere are stale), is marked "complete": False, and load_state_dict accepts it only on the same rank of
+        the same world size and bucket layout - the per-rank checkpoint file idiom.  In every other mode it is the same as
+        gather=True."""
         step = int(self._dev_step.item()) if self._dev_step is not None else self.step_count
-        m, v = self._full_moments()
-        return {"step": step, "exp_avg": m, "exp_avg_sq": v, "skipped_steps": self.skipped_steps(), "total": self.total}
+        sd = {"step": step, "skipped_steps": self.skipped_steps(), "total": self.total, "complete": True}
+        sharded = bool(self._collective and self.reduce == "rs_ag" and self._shard_layout)
+        if gather or not sharded:
+            sd["exp_avg"], sd["exp_avg_sq"] = self._full_moments()
+        else:
+            sd["exp_avg"], sd["exp_avg_sq"] = self.exp_avg.clone(), self.exp_avg_sq.clone()
+            sd.update(complete=False, rank=self.rank, world=self.world,
+                      owned=[self._shard(a, b) for a, b in self._shard_layout], layout=list(self._shard_layout))
+        return sd
 
     def load_state_dict(self, sd):
         if sd["total"] != self.total:
             raise ValueError(f"FlatAdamW.load_state_dict: flat size {sd['total']} != {self.total} (different model?)")
+        if not sd.get("complete", True):
+            layout = tuple(tuple(r) for r in sd.get("layout", ()))
+            mine = (self.reduce == "rs_ag" and sd.get("rank") == self.rank and sd.get("world") == self.world
+                    and self._shard_layout in (None, layout))
+            if not mine:
+                raise ValueError("FlatAdamW.load_state_dict: a state_dict(gather=False) shard of rank "
+                                 f"{sd.get('rank')} / world {sd.get('world')} only resumes on that rank of the same world "
+                                 "size and bucket layout under reduce='rs_ag'; save with gather=True (a collective) for a "
+                                 "portable checkpoint")
+            self._shard_layout = layout        # the next step checks its buckets against the checkpoint's ownership map
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])

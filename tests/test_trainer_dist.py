@@ -360,6 +360,20 @@ def _worker_resume(rank, world, port, out, phase):
             sd = opt.state_dict()                                # (collective: both ranks call it)
             if rank == 0:
                 torch.save({"opt": sd, "model": enc.state_dict()}, out + ".ckpt")
+        elif phase == "save_local":                              # two steps, then one file PER RANK, no communication
+            for _ in range(2):
+                one_step()
+            sd = opt.state_dict(gather=False)
+            assert not sd["complete"] and sd["rank"] == rank and sum(b - a for a, b in sd["owned"]) == opt.total // world
+            torch.save({"opt": sd, "model": enc.state_dict()}, out + f".ckpt{rank}")
+        elif phase == "resume_local":
+            ck = torch.load(out + f".ckpt{rank}")
+            other = torch.load(out + f".ckpt{1 - rank}")
+            with pytest.raises(ValueError, match="only resumes on that rank"):
+                opt.load_state_dict(other["opt"])
+            enc.load_state_dict(ck["model"])
+            opt.load_state_dict(ck["opt"])
+            one_step()
         else:                                                    # fresh processes resume from rank 0's file, one more step
             ck = torch.load(out + ".ckpt")
             enc.load_state_dict(ck["model"])
@@ -388,3 +402,10 @@ def test_dp2_rs_ag_checkpoint_resume(tmp_path):
     nz = (ck["exp_avg_sq"] != 0).float().mean().item()
     full = (a0["exp_avg_sq"] != 0).float().mean().item()
     assert nz > 0.9 * full, (nz, full)
+    # the non-collective per-rank idiom (state_dict(gather=False)): same trajectory, and a foreign shard is refused
+    for phase in ("save_local", "resume_local"):
+        mp.spawn(_worker_resume, args=(2, _free_port(), out, phase), nprocs=2, join=True)
+    c0, c1 = torch.load(out + ".resume_local.0"), torch.load(out + ".resume_local.1")
+    assert torch.equal(c0["params"], c1["params"])
+    for k in ("params", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(a0[k], c0[k]), k
