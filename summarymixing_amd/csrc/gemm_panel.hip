@@ -1,0 +1,93 @@
+// gemm_panel.hip — C-ABI of the panel-resident GEMM (gemm_panel.h): smx_weight_pack, smx_gemm_panel, the forward instantiations.
+// (The act-grad instantiations live in gemm_panel_bwd.hip: a translation unit of its own, compiled next to this one.)
+#include "gemm_panel.h"
+
+namespace smx {
+
+// One wave per 1 KB fragment: 32 output columns x 16 reduce elements in MFMA operand order - lane (c = lane & 31, hi = lane >> 5)
+// holds B[m = cb * 32 + c][k = kk * 16 + hi * 8 .. + 8] - stored lane-major at ((cb * KS + kk) * 64 + lane) * 16 bytes.
+// transposed = 0: W is (M, K), reduce-contiguous (a Linear's weight in its forward);
+// transposed = 1: W is (K, M), the same Linear's weight seen from its dgrad (B[m][k] = W[k][m]).
+__global__ __launch_bounds__(256) void weight_pack_kernel(const uint16_t* __restrict__ W, long ldw, int transposed, int M, int K, uint4* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hi = lane >> 5;
+  const int KS = K >> 4;
+  const long frag = (long)blockIdx.x * 4 + wave;          // = cb * KS + kk  (4 consecutive kk per block: 128-byte row segments)
+  if (frag >= (long)(M >> 5) * KS) return;
+  const int cb = (int)(frag / KS), kk = (int)(frag % KS);
+  const int m = cb * 32 + c, k0 = kk * 16 + hi * 8;
+  uint4 v;
+  if (!transposed) {
+    v = *reinterpret_cast<const uint4*>(W + (long)m * ldw + k0);
+  } else {
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      w[q] = (uint32_t)W[(long)(k0 + 2 * q) * ldw + m] | ((uint32_t)W[(long)(k0 + 2 * q + 1) * ldw + m] << 16);
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  out[frag * 64 + lane] = v;
+}
+
+int launch_panel_fwd(const PanelParams& p, int K, int act, hipStream_t s) { return launch_panel_mode<0>(p, K, act, s); }
+
+}  // namespace smx
+
+using namespace smx;
+
+extern "C" int smx_gemm_panel_ok(int dtype, int N, int M, int K) {
+  return dtype == SMX_BF16 && (K == 256 || K == 512) && N >= 1 && M >= 64 && M % 64 == 0 && (long)N * M * 2 < (1L << 31);
+}
+
+extern "C" size_t smx_weight_pack_bytes(int M, int K) { return (M > 0 && K > 0) ? (size_t)M * (size_t)K * 2 : 0; }
+
+extern "C" int smx_weight_pack(int dtype, const void* W, int64_t ldw, int transposed, int M, int K, void* packed, void* stream) {
+  SMX_REQUIRE(W && packed, "smx_weight_pack: null pointer");
+  SMX_REQUIRE(dtype == SMX_BF16, "smx_weight_pack: bf16 only");
+  SMX_REQUIRE(M > 0 && K > 0 && M % 32 == 0 && K % 16 == 0, "smx_weight_pack: M %% 32 == 0 and K %% 16 == 0 (got M=%d K=%d)", M, K);
+  SMX_REQUIRE(aligned16(packed), "smx_weight_pack: the packed image must be 16-byte aligned");
+  if (!transposed) SMX_REQUIRE(aligned16(W) && ldw % 8 == 0 && ldw >= K, "smx_weight_pack: (M, K) weight rows must be 16-byte aligned");
+  else SMX_REQUIRE(ldw >= M, "smx_weight_pack: bad leading dimension");
+  const long nfrag = (long)(M / 32) * (K / 16);
+  hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const uint16_t*>(W), (long)ldw, transposed, M, K, reinterpret_cast<uint4*>(packed));
+  return check_launch("smx_weight_pack");
+}
+
+extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void* Wpacked, void* C, int64_t ldc, int N, int M, int K,
+                              const smx_epilogue* epi, void* stream) {
+  SMX_REQUIRE(A && Wpacked && C, "smx_gemm_panel: null operand");
+  SMX_REQUIRE(N >= 0 && M >= 0 && K >= 0, "smx_gemm_panel: bad sizes N=%d M=%d K=%d", N, M, K);
+  if (N == 0 || M == 0) return SMX_OK;
+  if (!smx_gemm_panel_ok(dtype, N, M, K)) return fail(SMX_EUNSUPPORTED, "smx_gemm_panel: bf16, K = 256 / 512, M %% 64 == 0, output < 2 GB (smx_gemm_panel_ok)");
+  smx_epilogue e;
+  if (epi) e = *epi;
+  else { memset(&e, 0, sizeof(e)); e.alpha = 1.f; }
+  const bool ag = (e.flags & SMX_EPI_ACT_GRAD) != 0;
+  if (e.c0 || e.c0_mode != SMX_C0_NONE || e.row_mask || e.res || e.colsum || e.alpha != 1.f || e.out_mode != SMX_OUT_T ||
+      (e.flags & ~SMX_EPI_ACT_GRAD) || e.io_flags || e.lnf2_y || (ag && e.bias) ||
+      !(e.act == SMX_ACT_NONE || e.act == SMX_ACT_SWISH || e.act == SMX_ACT_GELU || e.act == SMX_ACT_RELU) ||
+      (e.drop_cols != 0 && e.drop_cols != M))
+    return fail(SMX_EUNSUPPORTED, "smx_gemm_panel: epilogue = bias, activation (none / Swish / GELU / ReLU), saved Z, dropout, or SMX_EPI_ACT_GRAD; use smx_gemm");
+  SMX_REQUIRE(!ag || e.z, "smx_gemm_panel: SMX_EPI_ACT_GRAD needs z (input)");
+  SMX_REQUIRE(e.drop_p >= 0.f && e.drop_p < 1.f, "smx_gemm_panel: 0 <= drop_p < 1");
+  SMX_REQUIRE(aligned16(A) && lda % 8 == 0 && lda >= K && aligned16(Wpacked) && aligned16(C) && ldc % 8 == 0 && ldc >= M &&
+                  (!e.z || (aligned16(e.z) && e.ldz % 8 == 0 && e.ldz >= M)) && (!e.bias || aligned16(e.bias)),
+              "smx_gemm_panel: operands must be 16-byte aligned with leading dimensions %% 8 == 0");
+  SMX_REQUIRE(((long)N - 1) * lda * 2 + (long)K * 2 < (1L << 31) && (!e.z || (long)N * e.ldz * 2 < (1L << 31)),
+              "smx_gemm_panel: operand spans must stay below 2 GB");
+  PanelParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda;
+  p.Bp = Wpacked;
+  p.C = reinterpret_cast<bf16_t*>(C); p.ldc = ldc;
+  p.Z = reinterpret_cast<bf16_t*>(e.z); p.ldz = e.ldz;
+  p.bias = e.bias;
+  p.N = N; p.M = M;
+  p.dthresh = (unsigned)((double)e.drop_p * 4294967296.0);
+  p.dscale = 1.f / (1.f - e.drop_p);
+  p.seed = e.drop_seed; p.epoch = e.epoch;
+  // store policy of smx_gemm: the output is streamed once it cannot survive in the Infinity Cache anyway
+  p.nt = ((long)N * M * 2 >= (96L << 20)) ? 2 : 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return ag ? launch_panel_actgrad(p, K, e.act, s) : launch_panel_fwd(p, K, e.act, s);
+}

@@ -220,6 +220,43 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
     return c
 
 
+def weight_pack(W, transposed=False, out=None):
+    """MFMA-fragment-order image of a bf16 weight for gemm_panel (smx_weight_pack).  W: (M, K) [transposed=False: the weight of a
+    forward Linear] or (K, M) [transposed=True: the weight of the Linear whose dgrad dH = dY W is computed]."""
+    assert W.dtype == torch.bfloat16 and W.dim() == 2
+    M, K = (W.shape[1], W.shape[0]) if transposed else (W.shape[0], W.shape[1])
+    if out is None:
+        out = torch.empty((M * K,), dtype=torch.bfloat16, device=W.device)
+    pw, lw = _mat(W)
+    tok = _pb(f"weight_pack ({M}x{K}){' T' if transposed else ''}", 4.0 * M * K)
+    L.check(L.lib().smx_weight_pack(L.BF16, pw, lw, 1 if transposed else 0, M, K, _p(out), _stream()), "smx_weight_pack")
+    _pe(tok)
+    return out
+
+
+def gemm_panel_ok(a, M, K):
+    return a.dtype == torch.bfloat16 and L.lib().smx_gemm_panel_ok(L.BF16, a.shape[0], M, K) == 1
+
+
+def gemm_panel(a, wp, c, N, M, K, epi=None):
+    """C (N x M) = epi(A Wp) on the panel-resident kernel (smx_gemm_panel): A (N, K) bf16, wp = weight_pack(...)."""
+    pa, la = _mat(a)
+    pc, lc = _mat(c)
+    if epi is None:
+        epi = epilogue()
+    tok = None
+    if _PROF is not None:
+        ag = bool(epi.flags & L.EPI_ACT_GRAD)
+        nb = (N * K + M * K) * 2 + (2 if epi.z else 0) * N * M + N * M * 2
+        tag = "".join(t for t, on in (("+bias", epi.bias), ("+act", epi.act != L.ACT_NONE and not ag), ("+Z", epi.z and not ag),
+                                      ("+actgrad(z)", ag), ("+drop", epi.drop_p > 0)) if on)
+        tok = _pb(f"gemm panel bf16 ({N}x{K})x({K}x{M}) {tag}", nb, 2.0 * N * M * K,
+                  f"gemm_panel_kernel<{K}, {1 if ag else 0}, {epi.act}>")
+    L.check(L.lib().smx_gemm_panel(L.BF16, pa, la, _p(wp), pc, lc, N, M, K, ctypes.byref(epi), _stream()), "smx_gemm_panel")
+    _pe(tok)
+    return c
+
+
 def wgrad(dz, x, gW, rows, M, K, batch=1, sz=0, sx=0, sw=0, lddz=None, ldx=None, lddw=None, alpha=1.0, dbias=None):
     """gW[b] (M x K) += alpha * dz[b]^T x[b]  (slab split-K + fixed-order reduction; see smx_linear_wgrad).
     dbias (fp32 (batch, M), contiguous): += alpha * column sums of dz from the same launch (needs K % 4 == 0)."""

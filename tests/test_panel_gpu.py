@@ -1,0 +1,110 @@
+"""The panel-resident GEMM (smx_gemm_panel + smx_weight_pack, csrc/gemm_panel.h) against float64 torch math and against the
+tiled smx_gemm doing the same work: FFN up-projection forward (bias, activation, saved pre-activation, dropout) and the act-grad
+dgrad of the down-projection (Conformer.py:458-472 and its autograd backward)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from summarymixing_amd import _lib as L, ops      # noqa: E402
+from tests._util import rel_err                   # noqa: E402
+
+ACTS = {L.ACT_NONE: (lambda v: v), L.ACT_SWISH: torch.nn.functional.silu, L.ACT_GELU: torch.nn.functional.gelu,
+        L.ACT_RELU: torch.relu}
+
+
+def _mk(N, M, K, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g) * 2 - 1
+    return rnd(N, K).bfloat16(), (rnd(M, K) * (2.0 / K ** 0.5)).bfloat16(), rnd(M) * 0.3
+
+
+@pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (128, 512, 256), (1, 64, 256), (700, 2048, 512), (391, 1536, 512), (2500, 3072, 512)])
+@pytest.mark.parametrize("act", [L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU, L.ACT_NONE])
+def test_panel_forward_matches_float64(N, M, K, act):
+    x, W, b = _mk(N, M, K)
+    assert ops.gemm_panel_ok(x, M, K)
+    wp = ops.weight_pack(W)
+    out, z = torch.full((N, M), 7.0, device="cuda").bfloat16(), torch.full((N, M), 7.0, device="cuda").bfloat16()
+    ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(bias=b, act=act, z=z))
+    zr = x.double() @ W.double().t() + b.double()
+    assert rel_err(z, zr) < 1e-2
+    # the activation runs on the bf16-rounded pre-activation (autocast semantics): exact against the kernel's own Z up to rounding
+    assert rel_err(out, ACTS[act](z.double())) < 5e-3
+    assert rel_err(out, ACTS[act](zr)) < 1e-2
+    # ... and against the tiled kernel (activation on the float32 accumulator there)
+    o2, z2 = torch.empty_like(out), torch.empty_like(z)
+    ops.gemm(L.GEMM_NT, x, W, o2, N, M, K, ops.epilogue(bias=b, act=act, z=z2))
+    assert rel_err(z, z2) < 4e-3 and rel_err(out, o2) < 8e-3
+    # no bias / no saved Z
+    o3 = torch.empty_like(out)
+    ops.gemm_panel(x, wp, o3, N, M, K, ops.epilogue(act=act))
+    assert rel_err(o3, ACTS[act](x.double() @ W.double().t())) < 1e-2
+
+
+@pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (5, 128, 256), (700, 2048, 512), (2500, 3072, 512)])
+@pytest.mark.parametrize("act", [L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU])
+def test_panel_actgrad_matches_float64(N, M, K, act):
+    dy, Wt, _ = _mk(N, M, K, seed=1)           # Wt (M, K) = W2^T
+    W2 = Wt.t().contiguous()                   # (K, M): the down-projection's weight as its dgrad sees it
+    z = (torch.rand(N, M, device="cuda") * 6 - 3).bfloat16()
+    wp = ops.weight_pack(W2, transposed=True)
+    assert torch.equal(wp, ops.weight_pack(Wt))                      # the packing kernel's transposition
+    dz = torch.full((N, M), 7.0, device="cuda").bfloat16()
+    ops.gemm_panel(dy, wp, dz, N, M, K, ops.epilogue(act=act, act_grad_z=z))
+    zd = z.double().requires_grad_(True)
+    (ACTS[act](zd)).sum().backward()
+    ref = (dy.double() @ W2.double()) * zd.grad
+    assert rel_err(dz, ref) < 1.2e-2
+    d2 = torch.empty_like(dz)
+    ops.gemm(L.GEMM_NN, dy, W2, d2, N, M, K, ops.epilogue(act=act, act_grad_z=z))
+    assert rel_err(dz, d2) < 1.2e-2
+
+
+@pytest.mark.parametrize("K,M", [(256, 1024), (512, 2048)])
+def test_panel_dropout_mask_is_the_tiled_kernels(K, M):
+    """Same seed -> the same keep decisions as smx_gemm (the backward of a layer may run on either kernel)."""
+    N = 777
+    x, W, b = _mk(N, M, K, seed=2)
+    wp = ops.weight_pack(W)
+    o1, o2 = torch.empty(N, M, device="cuda", dtype=torch.bfloat16), torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_panel(x, wp, o1, N, M, K, ops.epilogue(bias=b, act=L.ACT_NONE, drop=(0.15, 1234)))
+    ops.gemm(L.GEMM_NT, x, W, o2, N, M, K, ops.epilogue(bias=b, act=L.ACT_NONE, drop=(0.15, 1234)))
+    assert torch.equal(o1 == 0, o2 == 0)
+    assert 0.13 < float((o1 == 0).float().mean()) < 0.17
+    assert rel_err(o1, o2) < 8e-3
+    # act-grad form: the same mask again
+    z = (torch.rand(N, M, device="cuda") * 6 - 3).bfloat16()
+    dy = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
+    d1, d2 = torch.empty_like(o1), torch.empty_like(o1)
+    W2 = W.t().contiguous()
+    ops.gemm_panel(dy, ops.weight_pack(W2, transposed=True), d1, N, M, K, ops.epilogue(act=L.ACT_SWISH, act_grad_z=z, drop=(0.15, 1234)))
+    ops.gemm(L.GEMM_NN, dy, W2, d2, N, M, K, ops.epilogue(act=L.ACT_SWISH, act_grad_z=z, drop=(0.15, 1234)))
+    assert torch.equal((d1 == 0) | (d2 == 0), o1 == 0) or float(((d1 == 0) != (o1 == 0)).float().mean()) < 1e-3   # (exact zeros of the product aside)
+    assert rel_err(d1, d2) < 1.2e-2
+
+
+def test_panel_strided_views_and_padding_rows_untouched():
+    """Column slices as operands (leading dimension > width); rows beyond N of the output buffer are not written."""
+    N, M, K = 300, 512, 256
+    big_x = (torch.rand(N, K + 64, device="cuda") * 2 - 1).bfloat16()
+    x = big_x[:, 64:]
+    _, W, b = _mk(N, M, K, seed=3)
+    big_o = torch.full((N + 50, M + 128), 3.0, device="cuda").bfloat16()
+    out = big_o[:N, 128:]
+    ops.gemm_panel(x, ops.weight_pack(W), out, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH))
+    ref = torch.nn.functional.silu(x.double() @ W.double().t() + b.double())
+    assert rel_err(out, ref) < 1e-2
+    assert bool((big_o[N:] == 3.0).all()) and bool((big_o[:, :128] == 3.0).all())
+
+
+def test_panel_refuses_what_it_cannot_do():
+    N, M, K = 256, 512, 256
+    x, W, b = _mk(N, M, K)
+    out = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+    wp = ops.weight_pack(W)
+    with pytest.raises(RuntimeError):
+        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(bias=b, res=out))
+    with pytest.raises(RuntimeError):
+        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(bias=b, alpha=0.5))
+    assert not ops.gemm_panel_ok(x, M, 384) and not ops.gemm_panel_ok(x, 96, K) and not ops.gemm_panel_ok(x.float(), M, K)
