@@ -139,22 +139,24 @@ int smx_gemm_plan_query(int layout, int dtype, const void* A, int64_t lda, int64
                         const smx_epilogue* epi, smx_gemm_plan* plan);
 
 /* Panel-resident GEMM for the SHORT reductions with WIDE outputs of an encoder layer (bf16, K = 256 or 512, M % 64 == 0):
- *   forward      C = D(act(A Wp + bias)), optionally saving the pre-activation Z      (epi: bias, act, z, drop_*)
+ *   forward      C = D(act(A Wp + bias)), optionally saving the pre-activation Z      (epi: act, z, drop_*; bias: packed, below)
  *   act-grad     C = D((A Wp) * act'(Z))                                             (epi: SMX_EPI_ACT_GRAD, z = input, act, drop_*)
  * i.e. the FFN up-projection  nn.Linear(d_model, d_ffn) + activation + dropout  (Conformer.py:458-472, Branchformer.py:142-157)
  * and the first half of the autograd backward of the down-projection that follows it (dH = dY W2, then the activation / dropout
  * backward), the two output-bound GEMMs of every encoder layer.  A 128-row panel of A stays in LDS for all M columns and
  * the weight is read in MFMA fragment order straight into registers, so it must be PRE-PACKED:
- *   smx_weight_pack(W, transposed = 0): W is the (M, K) weight of the forward;
- *   smx_weight_pack(W, transposed = 1): W is the (K, M) weight of the Linear whose dgrad this is (dH = dY W: reduce-strided).
- * The packed image has smx_weight_pack_bytes(M, K) bytes (16-byte aligned) and must be re-packed whenever W changes.
+ *   smx_weight_pack(W, transposed = 0, bias): W is the (M, K) weight of the forward, bias its fp32 [M] bias or NULL;
+ *   smx_weight_pack(W, transposed = 1, NULL): W is the (K, M) weight of the Linear whose dgrad this is (dH = dY W: reduce-strided).
+ * The bias travels INSIDE the packed image (one more fragment per 32 columns, split into a bf16 high and low part: exact to
+ * 2^-17 relative), so smx_gemm_panel takes no epi->bias.  The image has smx_weight_pack_bytes(M, K) bytes (16-byte aligned) and
+ * must be re-packed whenever W or the bias change.
  * Same arithmetic as smx_gemm with the same epilogue fields (fp32 accumulation, the same dropout mask for the same seed), except
  * that the activation / its gradient is evaluated on the bf16-ROUNDED pre-activation / product (torch autocast semantics: the
- * Linear's output is a bf16 tensor).  Any other epilogue field (residual, C0, row mask, alpha != 1, LayerNorm, fp32 output,
+ * Linear's output is a bf16 tensor).  Any other epilogue field (bias, residual, C0, row mask, alpha != 1, LayerNorm, fp32 output,
  * column sums) returns SMX_EUNSUPPORTED: use smx_gemm.  smx_gemm_panel_ok: can these sizes take the panel path at all? */
 int smx_gemm_panel_ok(int dtype, int N, int M, int K);
 size_t smx_weight_pack_bytes(int M, int K);
-int smx_weight_pack(int dtype, const void* W, int64_t ldw, int transposed, int M, int K, void* packed, void* stream);
+int smx_weight_pack(int dtype, const void* W, int64_t ldw, int transposed, const float* bias, int M, int K, void* packed, void* stream);
 int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void* Wpacked, void* C, int64_t ldc, int N, int M, int K,
                    const smx_epilogue* epi, void* stream);
 

@@ -76,7 +76,7 @@ SIGNATURES = {
     "smx_gemm_colsum_workspace": (c_sz, [c_i, c_i]),
     "smx_gemm_panel_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "smx_weight_pack_bytes": (c_sz, [c_i, c_i]),
-    "smx_weight_pack": (c_i, [c_i, c_vp, c_i64, c_i, c_i, c_i, c_vp, c_vp]),
+    "smx_weight_pack": (c_i, [c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_vp, c_vp]),
     "smx_gemm_panel": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_vp]),
     "smx_gemm_ln_fused_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "smx_gemm_ln_pair_ok": (c_i, [c_i, c_i, c_i, c_i]),

@@ -14,7 +14,9 @@
 //  * every wave owns 128 rows x 64 columns at a time (128 accumulator registers) and walks its own column chunks (wave w:
 //    chunks w, w + 8, ...) with NO workgroup barrier after the panel load: two waves share a SIMD, so one wave's epilogue
 //    (VALU: activation, dropout hash, conversions; stores) runs under the other wave's MFMAs;
-//  * epilogue per 32-row block: accumulators (+ bias, which is the accumulator's INITIAL value) -> bf16 -> a wave-private 4 KB
+//  * the bias rides in the packed image as one more fragment per column block (reduce slots 0 / 1 = the bf16 high and low parts
+//    of the float32 bias, against a constant activation fragment of ones: exact to 2^-17): no bias load in the kernel at all;
+//  * epilogue per 32-row block: accumulators -> bf16 -> a wave-private 4 KB
 //    LDS scratch (transposition only: ds_write_b64 in, ds_read_b128 out, no barrier) -> whole 128-byte row segments per store.
 //    The activation is evaluated on the bf16-rounded pre-activation (what torch autocast does: the Linear's output IS bf16);
 //    the act-grad form requests its 16 saved pre-activation items into the B ring's registers during the last 8 steps of the
@@ -27,16 +29,78 @@ namespace smx {
 
 struct PanelParams {
   const bf16_t* A; long lda;          // (N, K) activations, reduce-contiguous
-  const void* Bp;                     // packed weight: [M / 32][K / 16][64 lanes][8 bf16]
+  const void* Bp;                     // packed weight: [M / 32][K / 16 + 1][64 lanes][8 bf16] (the last fragment of a block: the bias)
   bf16_t* C; long ldc;                // (N, M) output
   bf16_t* Z; long ldz;                // MODE 0: saved pre-activation (output, may be null); MODE 1: the saved pre-activation (input)
-  const float* bias;                  // MODE 0: [M] or null
   int N, M;
   unsigned dthresh; float dscale; uint64_t seed; const uint64_t* epoch;
   int nt;                             // 2: stream C past the caches
+  long long* dbg;                     // -DSMX_DIAG only: per-wave clock stamps (tools/panel_stamps.py)
 };
 
 typedef uint32_t pg_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef SMX_PANEL_ABL        // experiment builds only (tools/experiments/panel_variant.sh): 1 = no epilogue, 2 = no MFMA, 4 = no weight loads, 8 = no fragment reads
+#define SMX_PANEL_ABL 0
+#endif
+
+// ---- asynchronous buffer loads the COMPILER DOES NOT COUNT, waited for by hand.  hipcc's s_waitcnt insertion merges the two
+// predecessors of the chunk loop's header by taking the stricter count: the first chunk arrives with nothing behind its weight
+// ring, every later chunk with the previous chunk's 16-32 stores behind it - so a compiler-counted ring load is waited for with
+// vmcnt(<= 15) on every chunk, i.e. behind ALL those stores (vmcnt retires in order): a full write drain per chunk, measured as
+// 30-50 % of the kernel.  Here the loads are inline asm (invisible to that pass) and every consumer is preceded by an explicit
+// s_waitcnt whose count includes the stores known to be in between (panel_wait: the asm takes the registers as in-out operands,
+// so their consumer cannot be scheduled above it).
+__device__ __forceinline__ pg_u32x4 panel_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  pg_u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+  return r;
+}
+__device__ __forceinline__ void panel_ld(uint4& dst, uint32_t voff, pg_u32x4 rs, uint32_t soff) {
+  if constexpr ((SMX_PANEL_ABL & 4) != 0) { asm volatile("" : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w)); return; }
+  pg_u32x4 r;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+  dst = make_uint4(r.x, r.y, r.z, r.w);
+}
+template <int N>
+__device__ __forceinline__ void panel_wait(uint4& a) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) : "n"(N) : "memory");
+}
+// ... with S stores of the previous chunk between the load and now (uniform S in {0, 16, 32})
+template <int N>
+__device__ __forceinline__ void panel_wait_s(uint4& a, int S) {
+  if (S == 0) panel_wait<N>(a);
+  else if (S == 16) panel_wait<N + 16>(a);
+  else panel_wait<N + 32>(a);
+}
+
+// act(v) * s with the scale folded into the activation's own arithmetic (s = the inverted-dropout scale, inv_s = 1 / s; both 1
+// without dropout): Swish x / ((1 + e^-x) / s) costs what the unscaled form costs, GELU folds s into its 0.5
+template <int ACT>
+__device__ __forceinline__ float panel_act_scaled(float v, float s, float inv_s) {
+  if constexpr (ACT == SMX_ACT_SWISH) {
+    return v * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(-1.4426950408889634f * v), inv_s, inv_s));
+  } else if constexpr (ACT == SMX_ACT_GELU) {
+    float e;
+    const float hs = 0.5f * s;
+    return v * fmaf(gelu_parts(v, e), hs, hs);
+  } else if constexpr (ACT == SMX_ACT_RELU) {
+    return fmaxf(v, 0.f) * s;
+  } else {
+    return v * s;
+  }
+}
+// The keep decisions of dropout_apply<8> (smx_common.h) for 8 consecutive elements whose first index is 2 * p0 (p0 a multiple of
+// 4, pair indices below 2^32: N * M < 2^30 here), bit for bit: the seed / high-word mix `hm0` is a kernel constant, and
+// (p0 + q) ^ hm = (p0 ^ hm) ^ q for q < 4.  Survivors are NOT scaled (the caller folded the scale into the values).
+__device__ __forceinline__ void panel_dropout8(float (&v)[8], uint32_t hm0, uint32_t p0, uint32_t t16) {
+  const uint32_t ph = p0 ^ hm0 ^ pair_hi_mix(p0);
+#pragma unroll
+  for (int q2 = 0; q2 < 4; ++q2) {
+    const uint32_t h = mix32_1(ph ^ (uint32_t)q2);
+    v[2 * q2] = (h & 0xffffu) >= t16 ? v[2 * q2] : 0.f;
+    v[2 * q2 + 1] = (h >> 16) >= t16 ? v[2 * q2 + 1] : 0.f;
+  }
+}
 
 template <int K, int MODE, int ACT>
 __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
@@ -47,8 +111,26 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (wave-uniform for the compiler: scalar ring offsets, no waterfall loops)
   const int n0 = blockIdx.x * 128;
+#ifdef SMX_DIAG   // per-wave clock stamps: [0] start, [1] panel in LDS, [2 + 2 r] main loop of chunk round r done, [3 + 2 r] its epilogue
+  long long* dbgp = p.dbg ? p.dbg + ((long)blockIdx.x * 8 + (t >> 6)) * 16 : nullptr;
+#define SMX_PSTAMP(k) do { if (dbgp && lane == 0 && (k) < 16) dbgp[k] = clock64(); } while (0)
+#else
+#define SMX_PSTAMP(k) do { } while (0)
+#endif
+  SMX_PSTAMP(0);
 
-  // ---- the panel: 128 rows x K -> LDS, 16-byte chunk c of row r at chunk position c ^ (r & 15) ----
+  const pg_u32x4 rb_rs = panel_rsrc(p.Bp, (uint32_t)((long)p.M * (K + 16) * 2));
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  // ---- B ring: fragment (column block c * 2 + j, step kk) = 1 KB at ((c * 2 + j) * (KS + 1) + kk) * 1024, lane-major; step KS = the bias.  The chunk's base
+  // rides in the VECTOR offset (range-checked: a chunk beyond the last one reads zeros, no memory touched), step and j are constants.
+  uint4 rb[PF][2], bfrag[2];
+  auto ld_b = [&](uint4& dst, uint32_t voff, int kk, int j) __attribute__((always_inline)) {
+    panel_ld(dst, voff, rb_rs, (uint32_t)(j * (KS + 1) + kk) * 1024u);
+  };
+  auto chunk_voff = [&](int c) __attribute__((always_inline)) -> uint32_t { return lane16 + (uint32_t)c * (uint32_t)(2 * (KS + 1) * 1024); };
+
+  // ---- the panel: 128 rows x K -> LDS, 16-byte chunk c of row r at chunk position c ^ (r & 15); the first chunk's weight ring is
+  // requested behind the panel's loads, ahead of the barrier ----
   {
     constexpr int CPR = K / 8, NA = 128 * CPR / 512;
     const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), (short)0,
@@ -61,6 +143,12 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
       const pg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ra_rs, off, 0, 0);
       ra[i] = make_uint4(r.x, r.y, r.z, r.w);
     }
+    {
+      const uint32_t bv = chunk_voff(wave);
+      if constexpr (MODE == 0) { ld_b(bfrag[0], bv, KS, 0); ld_b(bfrag[1], bv, KS, 1); }   // (ahead of the ring: 16 loads behind them, as in every later chunk)
+#pragma unroll
+      for (int s = 0; s < PF; ++s) { ld_b(rb[s][0], bv, s, 0); ld_b(rb[s][1], bv, s, 1); }
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int v = t + 512 * i, row = v / CPR, c = v % CPR;
@@ -68,101 +156,116 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     }
   }
   __syncthreads();
+  SMX_PSTAMP(1);
 
-  const __amdgpu_buffer_rsrc_t rb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Bp), (short)0, (int)((long)p.M * K * 2), 0x00020000);
   // C and Z (MODE 0: saved pre-activation out, may be null; MODE 1: in) as buffer resources: rows >= N are out of range, so the
   // padded rows of the last panel are dropped (stores) / read as zeros (loads) by the hardware
   const __amdgpu_buffer_rsrc_t rc_rs = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)((((long)p.N - 1) * p.ldc + p.M) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rz_rs = __builtin_amdgcn_make_buffer_rsrc(p.Z ? p.Z : p.C, (short)0, (int)((((long)p.N - 1) * (p.Z ? p.ldz : p.ldc) + p.M) * 2), 0x00020000);
+  const pg_u32x4 rzl_rs = panel_rsrc(p.Z ? p.Z : p.C, (uint32_t)((((long)p.N - 1) * (p.Z ? p.ldz : p.ldc) + p.M) * 2));   // (MODE 1 loads)
   const uint32_t ldc2 = (uint32_t)p.ldc * 2u, ldz2 = (uint32_t)p.ldz * 2u;
-  const uint32_t lane16 = (uint32_t)lane * 16u;
+  // stores of one chunk's epilogue (between a chunk's ring requests and their consumers from the second chunk on)
+  const int nst = MODE == 1 ? 16 : (p.Z ? 32 : 16);
+  int sprev = 0;
   // fragment address of this lane in the panel: row l31 (+ 32 i), chunk (kk * 2 + hi) ^ (l31 & 15) = base ^ (kk << 5)
   const uint32_t a_base = (uint32_t)(l31 * ROWB + ((hi ^ (l31 & 15)) << 4));
   char* scr = smem + A_BYTES + wave * SCR;
+  // dropout: the seed / high-word part of the hash is a kernel constant (pair indices < 2^32), the scale is folded into the values
   const uint64_t dseed = p.dthresh ? epoch_seed(p.seed, p.epoch) : 0;
+  const uint32_t hm0 = mix32((uint32_t)dseed) ^ (uint32_t)(dseed >> 32), t16 = p.dthresh >> 16;
+  const float dsc = p.dthresh ? p.dscale : 1.f, dinv = p.dthresh ? 1.f / p.dscale : 1.f;
   const int nch = p.M >> 6;
 
 #pragma unroll 1
   for (int ch = wave; ch < nch; ch += 8) {
-    // ---- accumulators start at the bias (MODE 0) ----
+    // ---- accumulators: MODE 0 starts them at the bias (8 MFMAs of the packed bias fragment against the ones fragment, C = 0),
+    // MODE 1 lets the first step's MFMAs write them (C = 0): no zero fill, no bias load ----
     f32x16 acc[4][2];
-    if (MODE == 0 && p.bias) {
+    if constexpr (MODE == 0) {
+      uint32_t one0 = hi ? 0u : 0x3f803f80u, zr = 0u;                      // reduce slots 0 and 1 = 1.0, the rest 0
+      asm volatile("" : "+v"(one0), "+v"(zr));                          // (rebuilt per chunk: four registers that would otherwise be spilled across the loop)
+      const uint4 ones = make_uint4(one0, zr, zr, zr);
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      panel_wait_s<16>(bfrag[0], sprev);                     // (both fragments: 16 ring loads + the previous chunk's stores behind them)
+      panel_wait_s<16>(bfrag[1], sprev);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch * 64 + j * 32 + g * 8 + hi * 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[i][j][g * 4] = b4.x; acc[i][j][g * 4 + 1] = b4.y; acc[i][j][g * 4 + 2] = b4.z; acc[i][j][g * 4 + 3] = b4.w;
-          }
-        }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int i = 0; i < 4; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfrag[j]), __builtin_bit_cast(bf16x8, ones), zero, 0, 0, 0);
     }
-    // ---- B ring: fragment (column block ch * 2 + j, step kk) = 1 KB at ((ch * 2 + j) * KS + kk) * 1024, lane-major ----
-    const uint32_t bs0 = (uint32_t)(ch * 2) * (uint32_t)(KS * 1024);
-    // this lane's byte offsets of (row n0 + (lane >> 3), columns ch * 64 + (lane & 7) * 8 ..) in C / Z and its dropout index there
+    // this lane's byte offsets of (row n0 + (lane >> 3), columns ch * 64 + (lane & 7) * 8 ..) in C / Z, its dropout pair index there,
+    // the next chunk's ring base
     uint32_t c_off0 = (uint32_t)(((long)(n0 + (lane >> 3)) * p.ldc + ch * 64 + (lane & 7) * 8) * 2);
     uint32_t z_off0 = (uint32_t)(((long)(n0 + (lane >> 3)) * p.ldz + ch * 64 + (lane & 7) * 8) * 2);
-    uint64_t d_idx0 = (uint64_t)(n0 + (lane >> 3)) * (uint64_t)p.M + (uint64_t)(ch * 64 + (lane & 7) * 8);
+    uint32_t d_p0 = ((uint32_t)(n0 + (lane >> 3)) * (uint32_t)p.M + (uint32_t)(ch * 64 + (lane & 7) * 8)) >> 1;   // (N * M < 2^30)
+    uint32_t b_next = chunk_voff(ch + 8);
     // (opaque: else the loop-invariant part of all 16 item offsets of the epilogue is hoisted out of the chunk loop - 50 registers)
-    asm volatile("" : "+v"(c_off0), "+v"(z_off0), "+v"(d_idx0));
-    uint4 rb[PF][2];
-    auto ld_b = [&](int kk, int j) __attribute__((always_inline)) -> uint4 {
-      const pg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rb_rs, lane16, bs0 + (uint32_t)(j * KS + kk) * 1024u, 0);
-      return make_uint4(r.x, r.y, r.z, r.w);
-    };
+    asm volatile("" : "+v"(c_off0), "+v"(z_off0), "+v"(d_p0), "+v"(b_next));
     // MODE 1: item q (0..15) of the chunk's saved pre-activation: rows i * 32 + pp * 8 + (lane >> 3) (q = i * 4 + pp), 8 columns
-    auto ld_z = [&](int q) __attribute__((always_inline)) -> uint4 {
-      const pg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rz_rs, z_off0 + (uint32_t)((q >> 2) * 32 + (q & 3) * 8) * ldz2, 0, 0);
-      return make_uint4(r.x, r.y, r.z, r.w);
+    auto ld_z = [&](uint4& dst, int q) __attribute__((always_inline)) {
+      panel_ld(dst, z_off0 + (uint32_t)((q >> 2) * 32 + (q & 3) * 8) * ldz2, rzl_rs, 0u);
     };
-#pragma unroll
-    for (int s = 0; s < PF; ++s) { rb[s][0] = ld_b(s, 0); rb[s][1] = ld_b(s, 1); }
 
-    // ---- main loop: KS steps of 16 reduce elements, 8 MFMAs each ----
-    uint4 fa[2][4];
-    auto rd_a = [&](int kk, int buf) __attribute__((always_inline)) {
-      const uint32_t a = a_base ^ (uint32_t)(kk << 5);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[buf][i] = *reinterpret_cast<const uint4*>(smem + a + i * 32 * ROWB);
-    };
-    (void)rd_a;
+    // ---- main loop: KS steps of 16 reduce elements, 8 MFMAs each; the ring holds this chunk's first PF steps already ----
+    uint4 fa[4];
     // (opaque per chunk: otherwise every step's fragment address - loop invariant - is hoisted out of the chunk loop, 64 live registers)
     uint32_t a_cur = a_base;
     asm volatile("" : "+v"(a_cur));
-    {
-      const uint32_t a = a_cur;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const uint4*>(smem + a + i * 32 * ROWB);
-    }
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 32 * ROWB);
     __builtin_amdgcn_sched_barrier(0);
     // The instruction order IS the source order (sched_barrier(0) after every MFMA; left to itself the scheduler hoists the fragment
-    // reads and ring refills of many steps to the top and spills 90-150 registers): behind MFMA m of a step the next step's
-    // activation fragment m (m < 4), behind MFMAs 4 and 7 the two refills of the ring slot the step is consuming (weight-fragment major order: fragment 0 is free after MFMA 3).
+    // reads and ring refills of many steps to the top and spills 90-150 registers).  Activation-fragment major: MFMA 2 i + j
+    // multiplies activation fragment i by weight fragment j, so fragment i is free behind MFMA 2 i + 1 and its ONE register set is
+    // re-read for the next step right there (7 MFMAs ahead of its next use); the ring slot is refilled behind MFMAs 6 and 7.
+    // The last PF steps refill with the NEXT chunk's first steps (MODE 0: ahead of this chunk's stores - vmcnt retires in order and
+    // counts stores) or with this chunk's saved pre-activation items (MODE 1).
     for_seq<0, KS>([&](auto ktag) __attribute__((always_inline)) {
-      constexpr int kk = decltype(ktag)::value, cur = kk & 1, slot = kk % PF;
+      constexpr int kk = decltype(ktag)::value, slot = kk % PF;
       const uint32_t an = a_cur ^ (uint32_t)((kk + 1) << 5);
+      // this step's weight fragments: requested PF steps ago, 14 ring requests behind the second one (+ the previous chunk's stores
+      // while the fragments come from the ring the previous chunk primed)
+      if constexpr (kk < PF) { panel_wait_s<14>(rb[slot][0], sprev); panel_wait_s<14>(rb[slot][1], sprev); }
+      else { panel_wait<14>(rb[slot][0]); panel_wait<14>(rb[slot][1]); }
       for_seq<0, 8>([&](auto mtag) __attribute__((always_inline)) {
-        constexpr int mm = decltype(mtag)::value, j = mm >> 2, i = mm & 3;   // (weight fragment 0 is free behind MFMA 3)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb[slot][j]), __builtin_bit_cast(bf16x8, fa[cur][i]), acc[i][j], 0, 0, 0);
-        if constexpr (kk + 1 < KS && mm < 4) fa[cur ^ 1][mm] = *reinterpret_cast<const uint4*>(smem + an + mm * 32 * ROWB);
-        if constexpr (mm == 4 || mm == 7) {
-          constexpr int jj = mm == 4 ? 0 : 1;
-          if constexpr (kk + PF < KS) rb[slot][jj] = ld_b(kk + PF, jj);
-          else if constexpr (MODE == 1) rb[slot][jj] = ld_z(2 * slot + jj);
+        constexpr int mm = decltype(mtag)::value, i = mm >> 1, j = mm & 1;
+        if constexpr ((SMX_PANEL_ABL & 2) != 0) {
+          if constexpr (MODE == 1 && kk == 0) { for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f; }
+          asm volatile("" : "+v"(rb[slot][j].x), "+v"(fa[i].x), "+v"(acc[i][j]));
+        } else if constexpr (MODE == 1 && kk == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb[slot][j]), __builtin_bit_cast(bf16x8, fa[i]), zero, 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb[slot][j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+        }
+        if constexpr (kk + 1 < KS && j == 1 && (SMX_PANEL_ABL & 8) == 0) fa[i] = *reinterpret_cast<const uint4*>(smem + an + i * 32 * ROWB);
+        // the next chunk's bias fragments: at the head of the tail, AHEAD of the tail's ring requests (16 loads behind them)
+        if constexpr (MODE == 0 && kk == KS - PF && mm == 3) { ld_b(bfrag[0], b_next, KS, 0); ld_b(bfrag[1], b_next, KS, 1); }
+        if constexpr (mm >= 6) {
+          constexpr int jj = mm - 6;
+          if constexpr (kk + PF < KS) ld_b(rb[slot][jj], b_next - (uint32_t)(16 * (KS + 1) * 1024), kk + PF, jj);
+          else if constexpr (MODE == 1) ld_z(rb[slot][jj], 2 * slot + jj);
+          else ld_b(rb[slot][jj], b_next, kk + PF - KS, jj);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
     });
 
     // ---- epilogue, 32 rows at a time through the wave's own scratch ----
+    pg_u32x4 outv[MODE == 1 ? 16 : 1];
+    // (scratch addresses rebuilt here, per chunk: hoisted out of the chunk loop they are 12 registers live across the main loop)
+    uint32_t s_wr = (uint32_t)(l31 * 128 + hi * 8), s_x = (uint32_t)(l31 & 7), s_rd = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4));
+    asm volatile("" : "+v"(s_wr), "+v"(s_x), "+v"(s_rd));
+    SMX_PSTAMP(2 + 2 * (ch >> 3));
+    if constexpr ((SMX_PANEL_ABL & 1) != 0) {
+      float sabl = 0.f;
+      for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sabl += acc[i][j][e];
+      if (sabl == 123.456f) p.C[0].v = 1;
+      if constexpr (MODE == 1) { for (int s = 0; s < PF; ++s) { if (rb[s][0].x == 0x12345u) p.C[1].v = 1; ld_b(rb[s][0], b_next, s, 0); ld_b(rb[s][1], b_next, s, 1); } }
+      sprev = 0;
+      continue;
+    }
     for_seq<0, 4>([&](auto itag) __attribute__((always_inline)) {
       constexpr int i = decltype(itag)::value;
 #pragma unroll
@@ -172,37 +275,63 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
           uint2 w;
           w.x = pack_bf16x2(acc[i][j][g * 4], acc[i][j][g * 4 + 1]);
           w.y = pack_bf16x2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
-          *reinterpret_cast<uint2*>(scr + l31 * 128 + (((j * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = w;
+          *reinterpret_cast<uint2*>(scr + s_wr + (((uint32_t)(j * 4 + g) ^ s_x) << 4)) = w;
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (MODE == 1) {   // items 4 i .. 4 i + 3 of the saved pre-activation: requested in order, 12 - 4 i requests behind the last
+#pragma unroll
+        for (int q = 4 * i; q < 4 * i + 4; ++q) panel_wait<12 - 4 * i>(rb[q >> 1][q & 1]);
+      }
       for_seq<0, 4>([&](auto ptag) __attribute__((always_inline)) {
         constexpr int pp = decltype(ptag)::value;
         constexpr int rstep = i * 32 + pp * 8;               // rows below this lane's first row (n0 + (lane >> 3))
-        const uint4 zz = *reinterpret_cast<const uint4*>(scr + (pp * 8 + (lane >> 3)) * 128 + (((lane & 7) ^ (lane >> 3)) << 4));
+        const uint4 zz = *reinterpret_cast<const uint4*>(scr + s_rd + pp * 8 * 128);
         float v[8];
         { const uint32_t w_[4] = {zz.x, zz.y, zz.z, zz.w}; unpack_words<bf16_t, 8>(w_, v); }
         // stores: buffer offsets = the chunk's lane offset + a wave-uniform row step; rows >= N fall outside the resource
         const uint32_t coff = c_off0 + (uint32_t)rstep * ldc2;
-        const uint64_t didx = d_idx0 + (uint64_t)((long)rstep * p.M);
+        (void)coff;
         if constexpr (MODE == 0) {
           if (p.Z) {
             const pg_u32x4 zu = {zz.x, zz.y, zz.z, zz.w};
             __builtin_amdgcn_raw_buffer_store_b128(zu, rz_rs, z_off0 + (uint32_t)rstep * ldz2, 0, 2);   // (nt: not read again before the backward pass)
           }
-          act_fwd_n<ACT, 8>(v);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = panel_act_scaled<ACT>(v[q], dsc, dinv);
         } else {
           constexpr int q = i * 4 + pp;
           float zf[8];
           { const uint32_t w_[4] = {rb[q >> 1][q & 1].x, rb[q >> 1][q & 1].y, rb[q >> 1][q & 1].z, rb[q >> 1][q & 1].w}; unpack_words<bf16_t, 8>(w_, zf); }
-          act_grad_mul_n<ACT, 8>(v, zf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= act_grad_c<ACT>(zf[e]) * dsc;
         }
-        if (p.dthresh) dropout_apply<8>(v, dseed, didx, p.dthresh, p.dscale);
+        if (p.dthresh) panel_dropout8(v, hm0, d_p0 + (uint32_t)(rstep / 2) * (uint32_t)p.M, t16);
         const pg_u32x4 cu = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        if (p.nt & 2) __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 2);
-        else __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 0);
+        if constexpr (MODE == 1) {
+          outv[i * 4 + pp] = cu;                           // (stored behind the next chunk's ring requests, below)
+        } else {
+          if (p.nt & 2) __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 2);
+          else __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 0);
+        }
       });
     });
+    if constexpr (MODE == 1) {
+      // The ring held the pre-activation items, so the next chunk's first steps can only be requested now - but still AHEAD of this
+      // chunk's stores (vmcnt retires in order and counts stores: a load behind them is consumable only once they have drained).
+      // The 16 finished items wait in the registers the accumulators and the items left free.
+#pragma unroll
+      for (int s = 0; s < PF; ++s) { ld_b(rb[s][0], b_next, s, 0); ld_b(rb[s][1], b_next, s, 1); }
+      for_seq<0, 16>([&](auto qtag) __attribute__((always_inline)) {
+        constexpr int q = decltype(qtag)::value;
+        const uint32_t coff = c_off0 + (uint32_t)((q >> 2) * 32 + (q & 3) * 8) * ldc2;
+        if (p.nt & 2) __builtin_amdgcn_raw_buffer_store_b128(outv[q], rc_rs, coff, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128(outv[q], rc_rs, coff, 0, 0);
+      });
+    }
+    sprev = nst;
+    SMX_PSTAMP(3 + 2 * (ch >> 3));
   }
+#undef SMX_PSTAMP
 }
 
 // host side: one launcher per mode (gemm_panel.hip: forward, gemm_panel_bwd.hip: act-grad), K and the activation by switch

@@ -5,18 +5,26 @@
 namespace smx {
 
 // One wave per 1 KB fragment: 32 output columns x 16 reduce elements in MFMA operand order - lane (c = lane & 31, hi = lane >> 5)
-// holds B[m = cb * 32 + c][k = kk * 16 + hi * 8 .. + 8] - stored lane-major at ((cb * KS + kk) * 64 + lane) * 16 bytes.
+// holds B[m = cb * 32 + c][k = kk * 16 + hi * 8 .. + 8] - stored lane-major at ((cb * (KS + 1) + kk) * 64 + lane) * 16 bytes.
 // transposed = 0: W is (M, K), reduce-contiguous (a Linear's weight in its forward);
 // transposed = 1: W is (K, M), the same Linear's weight seen from its dgrad (B[m][k] = W[k][m]).
-__global__ __launch_bounds__(256) void weight_pack_kernel(const uint16_t* __restrict__ W, long ldw, int transposed, int M, int K, uint4* __restrict__ out) {
+// Fragment kk = KS of a column block is the bias: reduce slot 0 = bf16(b), slot 1 = bf16(b - slot 0), the rest 0 (zeros without a bias).
+__global__ __launch_bounds__(256) void weight_pack_kernel(const uint16_t* __restrict__ W, long ldw, int transposed, const float* __restrict__ bias,
+                                                          int M, int K, uint4* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hi = lane >> 5;
   const int KS = K >> 4;
-  const long frag = (long)blockIdx.x * 4 + wave;          // = cb * KS + kk  (4 consecutive kk per block: 128-byte row segments)
-  if (frag >= (long)(M >> 5) * KS) return;
-  const int cb = (int)(frag / KS), kk = (int)(frag % KS);
+  const long frag = (long)blockIdx.x * 4 + wave;          // = cb * (KS + 1) + kk  (4 consecutive kk per block: 128-byte row segments)
+  if (frag >= (long)(M >> 5) * (KS + 1)) return;
+  const int cb = (int)(frag / (KS + 1)), kk = (int)(frag % (KS + 1));
   const int m = cb * 32 + c, k0 = kk * 16 + hi * 8;
-  uint4 v;
-  if (!transposed) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (kk == KS) {
+    if (bias && hi == 0) {
+      const float b = bias[m];
+      const uint32_t bh = f32_to_bf16_bits(b);
+      v.x = bh | (f32_to_bf16_bits(b - bf16_bits_to_f32(bh)) << 16);
+    }
+  } else if (!transposed) {
     v = *reinterpret_cast<const uint4*>(W + (long)m * ldw + k0);
   } else {
     uint32_t w[4];
@@ -33,23 +41,26 @@ int launch_panel_fwd(const PanelParams& p, int K, int act, hipStream_t s) { retu
 }  // namespace smx
 
 using namespace smx;
+#ifdef SMX_DIAG
+extern long long* g_dbg_stamps;   // gemm.hip (smx_debug_set_timing_buffer)
+#endif
 
 extern "C" int smx_gemm_panel_ok(int dtype, int N, int M, int K) {
   return dtype == SMX_BF16 && (K == 256 || K == 512) && N >= 1 && M >= 64 && M % 64 == 0 && (long)N * M * 2 < (1L << 31);
 }
 
-extern "C" size_t smx_weight_pack_bytes(int M, int K) { return (M > 0 && K > 0) ? (size_t)M * (size_t)K * 2 : 0; }
+extern "C" size_t smx_weight_pack_bytes(int M, int K) { return (M > 0 && K > 0) ? (size_t)M * (size_t)(K + 16) * 2 : 0; }
 
-extern "C" int smx_weight_pack(int dtype, const void* W, int64_t ldw, int transposed, int M, int K, void* packed, void* stream) {
+extern "C" int smx_weight_pack(int dtype, const void* W, int64_t ldw, int transposed, const float* bias, int M, int K, void* packed, void* stream) {
   SMX_REQUIRE(W && packed, "smx_weight_pack: null pointer");
   SMX_REQUIRE(dtype == SMX_BF16, "smx_weight_pack: bf16 only");
   SMX_REQUIRE(M > 0 && K > 0 && M % 32 == 0 && K % 16 == 0, "smx_weight_pack: M %% 32 == 0 and K %% 16 == 0 (got M=%d K=%d)", M, K);
   SMX_REQUIRE(aligned16(packed), "smx_weight_pack: the packed image must be 16-byte aligned");
   if (!transposed) SMX_REQUIRE(aligned16(W) && ldw % 8 == 0 && ldw >= K, "smx_weight_pack: (M, K) weight rows must be 16-byte aligned");
   else SMX_REQUIRE(ldw >= M, "smx_weight_pack: bad leading dimension");
-  const long nfrag = (long)(M / 32) * (K / 16);
+  const long nfrag = (long)(M / 32) * (K / 16 + 1);
   hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const uint16_t*>(W), (long)ldw, transposed, M, K, reinterpret_cast<uint4*>(packed));
+                     reinterpret_cast<const uint16_t*>(W), (long)ldw, transposed, bias, M, K, reinterpret_cast<uint4*>(packed));
   return check_launch("smx_weight_pack");
 }
 
@@ -64,14 +75,14 @@ extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void*
   else { memset(&e, 0, sizeof(e)); e.alpha = 1.f; }
   const bool ag = (e.flags & SMX_EPI_ACT_GRAD) != 0;
   if (e.c0 || e.c0_mode != SMX_C0_NONE || e.row_mask || e.res || e.colsum || e.alpha != 1.f || e.out_mode != SMX_OUT_T ||
-      (e.flags & ~SMX_EPI_ACT_GRAD) || e.io_flags || e.lnf2_y || (ag && e.bias) ||
+      (e.flags & ~SMX_EPI_ACT_GRAD) || e.io_flags || e.lnf2_y || e.bias ||
       !(e.act == SMX_ACT_NONE || e.act == SMX_ACT_SWISH || e.act == SMX_ACT_GELU || e.act == SMX_ACT_RELU) ||
       (e.drop_cols != 0 && e.drop_cols != M))
-    return fail(SMX_EUNSUPPORTED, "smx_gemm_panel: epilogue = bias, activation (none / Swish / GELU / ReLU), saved Z, dropout, or SMX_EPI_ACT_GRAD; use smx_gemm");
+    return fail(SMX_EUNSUPPORTED, "smx_gemm_panel: epilogue = activation (none / Swish / GELU / ReLU), saved Z, dropout, or SMX_EPI_ACT_GRAD (the bias belongs to smx_weight_pack); use smx_gemm");
   SMX_REQUIRE(!ag || e.z, "smx_gemm_panel: SMX_EPI_ACT_GRAD needs z (input)");
   SMX_REQUIRE(e.drop_p >= 0.f && e.drop_p < 1.f, "smx_gemm_panel: 0 <= drop_p < 1");
   SMX_REQUIRE(aligned16(A) && lda % 8 == 0 && lda >= K && aligned16(Wpacked) && aligned16(C) && ldc % 8 == 0 && ldc >= M &&
-                  (!e.z || (aligned16(e.z) && e.ldz % 8 == 0 && e.ldz >= M)) && (!e.bias || aligned16(e.bias)),
+                  (!e.z || (aligned16(e.z) && e.ldz % 8 == 0 && e.ldz >= M)),
               "smx_gemm_panel: operands must be 16-byte aligned with leading dimensions %% 8 == 0");
   SMX_REQUIRE(((long)N - 1) * lda * 2 + (long)K * 2 < (1L << 31) && (!e.z || (long)N * e.ldz * 2 < (1L << 31)),
               "smx_gemm_panel: operand spans must stay below 2 GB");
@@ -81,13 +92,15 @@ extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void*
   p.Bp = Wpacked;
   p.C = reinterpret_cast<bf16_t*>(C); p.ldc = ldc;
   p.Z = reinterpret_cast<bf16_t*>(e.z); p.ldz = e.ldz;
-  p.bias = e.bias;
   p.N = N; p.M = M;
   p.dthresh = (unsigned)((double)e.drop_p * 4294967296.0);
   p.dscale = 1.f / (1.f - e.drop_p);
   p.seed = e.drop_seed; p.epoch = e.epoch;
   // store policy of smx_gemm: the output is streamed once it cannot survive in the Infinity Cache anyway
   p.nt = ((long)N * M * 2 >= (96L << 20)) ? 2 : 0;
+#ifdef SMX_DIAG
+  p.dbg = g_dbg_stamps;
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return ag ? launch_panel_actgrad(p, K, e.act, s) : launch_panel_fwd(p, K, e.act, s);
 }

@@ -53,6 +53,53 @@ def wcast(param, dtype):
     return sh
 
 
+# ---- packed weight images of the panel-resident GEMM (ops.gemm_panel / smx_weight_pack): per (parameter, orientation), re-packed
+# when the weight changed.  Unmanaged parameters: torch's version counter (+ the bias's).  Trainer-managed bf16 shadows are rewritten
+# behind torch's back by smx_adamw_step, so the trainer bumps an epoch (weights_changed) after every update / checkpoint load.
+# The image is re-packed INTO THE SAME BUFFER: its address stays valid for captured hipGraphs (whose captured step contains the
+# pack launches - the epoch differs at capture time because the step before ended with an optimizer update).
+_WEPOCH = [0]
+_packed = {}   # (id(param), transposed) -> (weakref(param), stamp, packed image)
+
+
+def weights_changed():
+    """Trainer hook: the managed bf16 shadows / fp32 biases were rewritten in place (optimizer step, checkpoint load)."""
+    _WEPOCH[0] += 1
+
+
+def wpacked(param, dtype, transposed=False, bias=None):
+    """Packed image (ops.weight_pack) of a Linear's weight parameter [+ fp32 bias parameter] in the compute dtype."""
+    W = wcast(param, dtype)
+    ent = _shadow.get(id(param))
+    if ent is not None and ent[0]() is param and ent[1] == "managed":
+        stamp = ("m", _WEPOCH[0])
+    else:
+        stamp = ("v", param._version, param.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()))
+    key = (id(param), transposed)
+    c = _packed.get(key)
+    if c is not None and c[0]() is param and c[1] == stamp:
+        return c[2]
+    if len(_packed) > 4096:
+        for k in [k for k, v in _packed.items() if v[0]() is None]:
+            del _packed[k]
+    out = c[2] if (c is not None and c[0]() is param) else None
+    out = ops.weight_pack(W, transposed, None if bias is None else bias.detach(), out)
+    _packed[key] = (weakref.ref(param), stamp, out)
+    return out
+
+
+# The panel-resident GEMM takes the output-bound Linears with a short reduction (K = 256 / 512: FFN up-projection and the act-grad
+# dgrad of the down-projection) from this many rows on (one 128-row panel per CU: below ~half the chip the tiled kernels win).
+_PANEL = os.environ.get("SMX_PANEL", "1") != "0"
+_PANEL_MIN_ROWS = int(os.environ.get("SMX_PANEL_MIN_ROWS", "24576"))
+_PANEL_ACTS = (L.ACT_NONE, L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU)
+
+
+def panel_ok(x, M, K, act):
+    return (_PANEL and x.dtype == torch.bfloat16 and act in _PANEL_ACTS and x.shape[0] >= _PANEL_MIN_ROWS and _vec_ok(x) and
+            ops.gemm_panel_ok(x, M, K))
+
+
 _WGRAD_BIAS = True   # (round 4: the SMX_NO_WGRAD_BIAS A/B knob is gone)     # A/B knob: bias gradients as a by-product of the wgrad GEMM
 
 # Residual-stream dtype of a bf16 model.  "fp32" (default) = torch autocast semantics, what the reference's `precision: bf16`
@@ -272,7 +319,7 @@ def ln_next_ok(x, M, ln_next, W=None, res=None, training=True):
 
 def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, c0=None, c0_mode=L.C0_NONE,
                c0_div=0, save_z=False, out=None, out_f32=False, drop=None, c0_post=False, ln_next=None, ln_post=None,
-               drop_cols=0):
+               drop_cols=0, wparam=None):
     """ln_next = (gamma, beta, eps, act, want_stats[, stream_out[, pair]]): the LayerNorm that follows this Linear runs in the GEMM
     epilogue (check ln_next_ok first); ln_post (a list) receives (LN output, stats | None).  pair = (gamma2, beta2, eps2): a second
     LayerNorm of the first one's output in the same epilogue (check ln_pair_ok); ln_post then receives a second entry,
@@ -284,6 +331,11 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
     if out is None:
         out = torch.empty((N, M), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
+    # wparam = the fp32 parameter behind W: bias / activation / saved Z / dropout only -> the panel-resident kernel on its packed image
+    if (wparam is not None and mask is None and res is None and c0 is None and alpha == 1.0 and not out_f32 and ln_next is None and
+            drop_cols == 0 and out.dtype == x.dtype and panel_ok(x, M, K, act) and _vec_ok(out, z)):
+        ops.gemm_panel(x, wpacked(wparam, x.dtype, False, bias), out, N, M, K, ops.epilogue(act=act, z=z, drop=drop))
+        return out, z
     lnf = lnf2 = None
     if ln_next is not None:
         g, b, eps, lact, want_stats = ln_next[:5]
@@ -329,7 +381,7 @@ def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
 
 
 def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
-               drop=None, dz_ready=False, up=None, dx_drop=None, ln=None, ln_second=None, dx_split=None):
+               drop=None, dz_ready=False, up=None, dx_drop=None, ln=None, ln_second=None, dx_split=None, wparam=None):
     """Backward of y = res + alpha*D(act(x W^T + b + c0))*mask (D = the forward's fused dropout, regenerated from its
     seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate.
     dz_ready: dy already IS dZ (a downstream dgrad epilogue fused this layer's act/dropout/mask backward, see `up`).
@@ -389,6 +441,11 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
         if up is not None:
             assert res_grad is None
             z_up, act_up, mask_up, alpha_up, drop_up, gb_up = up
+            # wparam = the fp32 parameter behind W (M, K): the act-grad dgrad on the panel-resident kernel, W packed transposed
+            if (wparam is not None and mask_up is None and alpha_up == 1.0 and gb_up is None and dx.dtype == dz.dtype and
+                    panel_ok(dz, K, M, act_up) and _vec_ok(dx, z_up)):
+                ops.gemm_panel(dz, wpacked(wparam, dz.dtype, True), dx, N, K, M, ops.epilogue(act=act_up, act_grad_z=z_up, drop=drop_up))
+                return dx, dz
             e = ops.epilogue(act=act_up, act_grad_z=z_up, row_mask=mask_up, alpha=alpha_up, drop=drop_up, colsum=gb_up)
         else:
             assert dx_drop is None or res_grad is None
@@ -1008,7 +1065,7 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
     W1, W2 = wcast(P["W1"], dtype), wcast(P["W2"], dtype)
     d1 = (p, ops.new_dropout_seed()) if p > 0.0 else None       # both dropouts are fused into the GEMM epilogues
     d2 = (p, ops.new_dropout_seed()) if p > 0.0 else None
-    a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1)
+    a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1, wparam=P["W1"])
     post = []
     lnn = ((ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) + tuple(ln_next[3:4])) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x, need_bwd)) else None
     if lnn is not None and ln_pair and len(lnn) > 5 and ln_pair_ok(a, W2.shape[0], x, ln_pair[:2]):
@@ -1025,10 +1082,10 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
         # the second Linear's dgrad epilogue applies D1 and act'(z1): it emits dZ1 directly; db1 comes out of W1's wgrad
         if dz_in is not None:
             dz1, _ = linear_bwd(dz_in, a, W2, None, L.ACT_NONE, None, 1.0, gacc(P["W2"]), gacc(P["b2"]), dz_ready=True,
-                                up=(z1, act, None, 1.0, d1, None))
+                                up=(z1, act, None, 1.0, d1, None), wparam=P["W2"])
         else:
             dz1, _ = linear_bwd(dy, a, W2, None, L.ACT_NONE, None, alpha, gacc(P["W2"]), gacc(P["b2"]), drop=d2,
-                                up=(z1, act, None, 1.0, d1, None))
+                                up=(z1, act, None, 1.0, d1, None), wparam=P["W2"])
         if ln_fusable(ln_b.spec, h.shape[0], h.shape[1], dtype, W1.shape[0], W1):     # the LayerNorm backward rides in the dgrad epilogue
             out, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True, res_grad=dy,
                                 ln=ln_b.spec, ln_second=second)

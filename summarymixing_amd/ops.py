@@ -220,16 +220,18 @@ def gemm(layout, a, b, c, N, M, K, epi=None, batch=1, sa=0, sb=0, sc=0, splits=1
     return c
 
 
-def weight_pack(W, transposed=False, out=None):
-    """MFMA-fragment-order image of a bf16 weight for gemm_panel (smx_weight_pack).  W: (M, K) [transposed=False: the weight of a
-    forward Linear] or (K, M) [transposed=True: the weight of the Linear whose dgrad dH = dY W is computed]."""
+def weight_pack(W, transposed=False, bias=None, out=None):
+    """MFMA-fragment-order image of a bf16 weight (+ its fp32 bias) for gemm_panel (smx_weight_pack).  W: (M, K) [transposed=False: the
+    weight of a forward Linear] or (K, M) [transposed=True: the weight of the Linear whose dgrad dH = dY W is computed]."""
     assert W.dtype == torch.bfloat16 and W.dim() == 2
     M, K = (W.shape[1], W.shape[0]) if transposed else (W.shape[0], W.shape[1])
     if out is None:
-        out = torch.empty((M * K,), dtype=torch.bfloat16, device=W.device)
+        out = torch.empty((L.lib().smx_weight_pack_bytes(M, K) // 2,), dtype=torch.bfloat16, device=W.device)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == M
     pw, lw = _mat(W)
     tok = _pb(f"weight_pack ({M}x{K}){' T' if transposed else ''}", 4.0 * M * K)
-    L.check(L.lib().smx_weight_pack(L.BF16, pw, lw, 1 if transposed else 0, M, K, _p(out), _stream()), "smx_weight_pack")
+    L.check(L.lib().smx_weight_pack(L.BF16, pw, lw, 1 if transposed else 0, _p(bias), M, K, _p(out), _stream()), "smx_weight_pack")
     _pe(tok)
     return out
 
@@ -248,7 +250,7 @@ def gemm_panel(a, wp, c, N, M, K, epi=None):
     if _PROF is not None:
         ag = bool(epi.flags & L.EPI_ACT_GRAD)
         nb = (N * K + M * K) * 2 + (2 if epi.z else 0) * N * M + N * M * 2
-        tag = "".join(t for t, on in (("+bias", epi.bias), ("+act", epi.act != L.ACT_NONE and not ag), ("+Z", epi.z and not ag),
+        tag = "".join(t for t, on in (("+act", epi.act != L.ACT_NONE and not ag), ("+Z", epi.z and not ag),
                                       ("+actgrad(z)", ag), ("+drop", epi.drop_p > 0)) if on)
         tok = _pb(f"gemm panel bf16 ({N}x{K})x({K}x{M}) {tag}", nb, 2.0 * N * M * K,
                   f"gemm_panel_kernel<{K}, {1 if ag else 0}, {epi.act}>")

@@ -166,6 +166,7 @@ class FlatAdamW:
         if self.shadow is not None and self.flat_p.is_cuda:
             ops.L.check(ops.L.lib().smx_cast_from_f32(ops.L.BF16, ops._p(self.flat_p), ops._p(self.shadow), self.total,
                                                       ops._stream()), "smx_cast_from_f32")
+        F.weights_changed()           # (packed weight images of the panel GEMM are stale now)
 
     def _full_moments(self):
         """Complete copies of the two AdamW moment buffers.  reduce="rs_ag": every rank updates only its 1/world shard of each
@@ -394,6 +395,7 @@ class FlatAdamW:
 
     def _k_adamw(self, a, b, g, gscale, clip):
         """AdamW on flat elements [a, b) with the gradient tensor g (b - a elements)."""
+        F.weights_changed()           # (the bf16 shadows / fp32 biases change in place: packed weight images are stale)
         ops.adamw_step(self.flat_p[a:b], g, self.exp_avg[a:b], self.exp_avg_sq[a:b],
                        self.shadow[a:b] if self.shadow is not None else None, self.lr, self.betas[0], self.betas[1], self.eps,
                        self.wd, 0 if self._dev_step is not None else self.step_count, gscale, clip)

@@ -24,9 +24,9 @@ def _mk(N, M, K, seed=0):
 def test_panel_forward_matches_float64(N, M, K, act):
     x, W, b = _mk(N, M, K)
     assert ops.gemm_panel_ok(x, M, K)
-    wp = ops.weight_pack(W)
+    wp = ops.weight_pack(W, bias=b)
     out, z = torch.full((N, M), 7.0, device="cuda").bfloat16(), torch.full((N, M), 7.0, device="cuda").bfloat16()
-    ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(bias=b, act=act, z=z))
+    ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(act=act, z=z))
     zr = x.double() @ W.double().t() + b.double()
     assert rel_err(z, zr) < 1e-2
     # the activation runs on the bf16-rounded pre-activation (autocast semantics): exact against the kernel's own Z up to rounding
@@ -35,10 +35,11 @@ def test_panel_forward_matches_float64(N, M, K, act):
     # ... and against the tiled kernel (activation on the float32 accumulator there)
     o2, z2 = torch.empty_like(out), torch.empty_like(z)
     ops.gemm(L.GEMM_NT, x, W, o2, N, M, K, ops.epilogue(bias=b, act=act, z=z2))
-    assert rel_err(z, z2) < 4e-3 and rel_err(out, o2) < 8e-3
+    e1, e2 = rel_err(z, z2), rel_err(out, o2)
+    assert e1 < 8e-3 and e2 < 1.2e-2, (e1, e2)           # (one bf16 ulp of the largest element: the two kernels round different sums)
     # no bias / no saved Z
     o3 = torch.empty_like(out)
-    ops.gemm_panel(x, wp, o3, N, M, K, ops.epilogue(act=act))
+    ops.gemm_panel(x, ops.weight_pack(W), o3, N, M, K, ops.epilogue(act=act))
     assert rel_err(o3, ACTS[act](x.double() @ W.double().t())) < 1e-2
 
 
@@ -66,9 +67,9 @@ def test_panel_dropout_mask_is_the_tiled_kernels(K, M):
     """Same seed -> the same keep decisions as smx_gemm (the backward of a layer may run on either kernel)."""
     N = 777
     x, W, b = _mk(N, M, K, seed=2)
-    wp = ops.weight_pack(W)
+    wp = ops.weight_pack(W, bias=b)
     o1, o2 = torch.empty(N, M, device="cuda", dtype=torch.bfloat16), torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
-    ops.gemm_panel(x, wp, o1, N, M, K, ops.epilogue(bias=b, act=L.ACT_NONE, drop=(0.15, 1234)))
+    ops.gemm_panel(x, wp, o1, N, M, K, ops.epilogue(act=L.ACT_NONE, drop=(0.15, 1234)))
     ops.gemm(L.GEMM_NT, x, W, o2, N, M, K, ops.epilogue(bias=b, act=L.ACT_NONE, drop=(0.15, 1234)))
     assert torch.equal(o1 == 0, o2 == 0)
     assert 0.13 < float((o1 == 0).float().mean()) < 0.17
@@ -92,7 +93,7 @@ def test_panel_strided_views_and_padding_rows_untouched():
     _, W, b = _mk(N, M, K, seed=3)
     big_o = torch.full((N + 50, M + 128), 3.0, device="cuda").bfloat16()
     out = big_o[:N, 128:]
-    ops.gemm_panel(x, ops.weight_pack(W), out, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH))
+    ops.gemm_panel(x, ops.weight_pack(W, bias=b), out, N, M, K, ops.epilogue(act=L.ACT_SWISH))
     ref = torch.nn.functional.silu(x.double() @ W.double().t() + b.double())
     assert rel_err(out, ref) < 1e-2
     assert bool((big_o[N:] == 3.0).all()) and bool((big_o[:, :128] == 3.0).all())
@@ -104,7 +105,9 @@ def test_panel_refuses_what_it_cannot_do():
     out = torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
     wp = ops.weight_pack(W)
     with pytest.raises(RuntimeError):
-        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(bias=b, res=out))
+        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(res=out))
     with pytest.raises(RuntimeError):
-        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(bias=b, alpha=0.5))
+        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(bias=b))
+    with pytest.raises(RuntimeError):
+        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(alpha=0.5))
     assert not ops.gemm_panel_ok(x, M, 384) and not ops.gemm_panel_ok(x, 96, K) and not ops.gemm_panel_ok(x.float(), M, K)

@@ -30,17 +30,17 @@ for _ in range(60):
     torch.matmul(_wa, _wb)
 del _wa, _wb
 zb, ab = torch.empty(N, f, device=dev, dtype=torch.bfloat16), torch.empty(N, f, device=dev, dtype=torch.bfloat16)
-wp1, wp2 = ops.weight_pack(W1), ops.weight_pack(W2, transposed=True)
+wp1, wp2 = ops.weight_pack(W1, bias=b1), ops.weight_pack(W2, transposed=True)
 print(f"# panel vs tiled, N = {N}, d = {d}, d_ffn = {f}, bf16, dropout 0.15 (us; GB/s = algorithmic bytes / time)")
 for name, drop in (("", None), (" + dropout", (0.15, 7))):
     nb = (N * d + f * d) * 2 + 2 * N * f * 2
     t0 = T(lambda: ops.gemm(L.GEMM_NT, x, W1, ab, N, f, d, ops.epilogue(bias=b1, act=L.ACT_SWISH, z=zb, drop=drop)))
-    t1 = T(lambda: ops.gemm_panel(x, wp1, ab, N, f, d, ops.epilogue(bias=b1, act=L.ACT_SWISH, z=zb, drop=drop)))
+    t1 = T(lambda: ops.gemm_panel(x, wp1, ab, N, f, d, ops.epilogue(act=L.ACT_SWISH, z=zb, drop=drop)))
     print(f"  up-projection + bias + Swish + Z{name:12s} tiled {t0:7.1f}  panel {t1:7.1f}  ratio {t1 / t0:5.2f}   {nb / t1 * 1e-3:7.0f} GB/s")
     t0 = T(lambda: ops.gemm(L.GEMM_NN, dy, W2, ab, N, f, d, ops.epilogue(act=L.ACT_SWISH, act_grad_z=z, drop=drop)))
     t1 = T(lambda: ops.gemm_panel(dy, wp2, ab, N, f, d, ops.epilogue(act=L.ACT_SWISH, act_grad_z=z, drop=drop)))
     print(f"  act-grad dgrad (Swish'){name:21s} tiled {t0:7.1f}  panel {t1:7.1f}  ratio {t1 / t0:5.2f}   {nb / t1 * 1e-3:7.0f} GB/s")
 t0 = T(lambda: ops.gemm(L.GEMM_NT, x, W1, ab, N, f, d, ops.epilogue(bias=b1)))
-t1 = T(lambda: ops.gemm_panel(x, wp1, ab, N, f, d, ops.epilogue(bias=b1)))
+t1 = T(lambda: ops.gemm_panel(x, wp1, ab, N, f, d, ops.epilogue()))
 print(f"  bias only (one output)                       tiled {t0:7.1f}  panel {t1:7.1f}  ratio {t1 / t0:5.2f}")
-print(f"  weight_pack ({f}x{d}): {T(lambda: ops.weight_pack(W1, out=wp1)):.1f} us, transposed: {T(lambda: ops.weight_pack(W2, transposed=True, out=wp2)):.1f} us")
+print(f"  weight_pack ({f}x{d}): {T(lambda: ops.weight_pack(W1, bias=b1, out=wp1)):.1f} us, transposed: {T(lambda: ops.weight_pack(W2, transposed=True, out=wp2)):.1f} us")
