@@ -43,34 +43,17 @@ typedef uint32_t pg_u32x4 __attribute__((ext_vector_type(4)));
 #define SMX_PANEL_ABL 0
 #endif
 
-// ---- asynchronous buffer loads the COMPILER DOES NOT COUNT, waited for by hand.  hipcc's s_waitcnt insertion merges the two
-// predecessors of the chunk loop's header by taking the stricter count: the first chunk arrives with nothing behind its weight
-// ring, every later chunk with the previous chunk's 16-32 stores behind it - so a compiler-counted ring load is waited for with
-// vmcnt(<= 15) on every chunk, i.e. behind ALL those stores (vmcnt retires in order): a full write drain per chunk, measured as
-// 30-50 % of the kernel.  Here the loads are inline asm (invisible to that pass) and every consumer is preceded by an explicit
-// s_waitcnt whose count includes the stores known to be in between (panel_wait: the asm takes the registers as in-out operands,
-// so their consumer cannot be scheduled above it).
-__device__ __forceinline__ pg_u32x4 panel_rsrc(const void* base, uint32_t bytes) {
-  const uint64_t a = reinterpret_cast<uint64_t>(base);
-  pg_u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
-  return r;
-}
-__device__ __forceinline__ void panel_ld(uint4& dst, uint32_t voff, pg_u32x4 rs, uint32_t soff) {
+// ---- weight / pre-activation loads.  Every chunk requests its own ring at its head, BEHIND the previous chunk's stores (vmcnt
+// retires in order and counts stores, so the first fragments wait for that write drain; the partner wave of the SIMD runs
+// meanwhile).  Two ways around that drain were built and measured at no gain (+-2 %, inside the box-to-box spread): requesting
+// the next chunk's ring in the tail of the main loop needs either loads the compiler does not count (inline asm + hand-placed
+// s_waitcnt - the register allocator then copies the asm outputs before the data has arrived: nondeterministic garbage at
+// full-chip sizes) or dummy stores that make both predecessors of the loop header look alike to hipcc's waitcnt merge (spills
+// the ring at K = 256).
+__device__ __forceinline__ void panel_ld(uint4& dst, uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff) {
   if constexpr ((SMX_PANEL_ABL & 4) != 0) { asm volatile("" : "+v"(dst.x), "+v"(dst.y), "+v"(dst.z), "+v"(dst.w)); return; }
-  pg_u32x4 r;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+  const pg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
   dst = make_uint4(r.x, r.y, r.z, r.w);
-}
-template <int N>
-__device__ __forceinline__ void panel_wait(uint4& a) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) : "n"(N) : "memory");
-}
-// ... with S stores of the previous chunk between the load and now (uniform S in {0, 16, 32})
-template <int N>
-__device__ __forceinline__ void panel_wait_s(uint4& a, int S) {
-  if (S == 0) panel_wait<N>(a);
-  else if (S == 16) panel_wait<N + 16>(a);
-  else panel_wait<N + 32>(a);
 }
 
 // act(v) * s with the scale folded into the activation's own arithmetic (s = the inverted-dropout scale, inv_s = 1 / s; both 1
@@ -119,7 +102,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
 #endif
   SMX_PSTAMP(0);
 
-  const pg_u32x4 rb_rs = panel_rsrc(p.Bp, (uint32_t)((long)p.M * (K + 16) * 2));
+  const __amdgpu_buffer_rsrc_t rb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Bp), (short)0, (int)((long)p.M * (K + 16) * 2), 0x00020000);
   const uint32_t lane16 = (uint32_t)lane * 16u;
   // ---- B ring: fragment (column block c * 2 + j, step kk) = 1 KB at ((c * 2 + j) * (KS + 1) + kk) * 1024, lane-major; step KS = the bias.  The chunk's base
   // rides in the VECTOR offset (range-checked: a chunk beyond the last one reads zeros, no memory touched), step and j are constants.
@@ -129,8 +112,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   };
   auto chunk_voff = [&](int c) __attribute__((always_inline)) -> uint32_t { return lane16 + (uint32_t)c * (uint32_t)(2 * (KS + 1) * 1024); };
 
-  // ---- the panel: 128 rows x K -> LDS, 16-byte chunk c of row r at chunk position c ^ (r & 15); the first chunk's weight ring is
-  // requested behind the panel's loads, ahead of the barrier ----
+  // ---- the panel: 128 rows x K -> LDS, 16-byte chunk c of row r at chunk position c ^ (r & 15) ----
   {
     constexpr int CPR = K / 8, NA = 128 * CPR / 512;
     const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), (short)0,
@@ -138,16 +120,10 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     uint4 ra[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int v = t + 512 * i, row = v / CPR, c = v % CPR, n = n0 + row;
-      const uint32_t off = n < p.N ? (uint32_t)(((long)n * p.lda + c * 8) * 2) : 0x80000000u;
+      const int v = t + 512 * i, row = v / CPR, c = v % CPR, n = min(n0 + row, p.N - 1);   // (rows beyond N: row N - 1 again, their outputs are dropped)
+      const uint32_t off = (uint32_t)(((long)n * p.lda + c * 8) * 2);
       const pg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ra_rs, off, 0, 0);
       ra[i] = make_uint4(r.x, r.y, r.z, r.w);
-    }
-    {
-      const uint32_t bv = chunk_voff(wave);
-      if constexpr (MODE == 0) { ld_b(bfrag[0], bv, KS, 0); ld_b(bfrag[1], bv, KS, 1); }   // (ahead of the ring: 16 loads behind them, as in every later chunk)
-#pragma unroll
-      for (int s = 0; s < PF; ++s) { ld_b(rb[s][0], bv, s, 0); ld_b(rb[s][1], bv, s, 1); }
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -162,11 +138,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   // padded rows of the last panel are dropped (stores) / read as zeros (loads) by the hardware
   const __amdgpu_buffer_rsrc_t rc_rs = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)((((long)p.N - 1) * p.ldc + p.M) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rz_rs = __builtin_amdgcn_make_buffer_rsrc(p.Z ? p.Z : p.C, (short)0, (int)((((long)p.N - 1) * (p.Z ? p.ldz : p.ldc) + p.M) * 2), 0x00020000);
-  const pg_u32x4 rzl_rs = panel_rsrc(p.Z ? p.Z : p.C, (uint32_t)((((long)p.N - 1) * (p.Z ? p.ldz : p.ldc) + p.M) * 2));   // (MODE 1 loads)
   const uint32_t ldc2 = (uint32_t)p.ldc * 2u, ldz2 = (uint32_t)p.ldz * 2u;
-  // stores of one chunk's epilogue (between a chunk's ring requests and their consumers from the second chunk on)
-  const int nst = MODE == 1 ? 16 : (p.Z ? 32 : 16);
-  int sprev = 0;
   // fragment address of this lane in the panel: row l31 (+ 32 i), chunk (kk * 2 + hi) ^ (l31 & 15) = base ^ (kk << 5)
   const uint32_t a_base = (uint32_t)(l31 * ROWB + ((hi ^ (l31 & 15)) << 4));
   char* scr = smem + A_BYTES + wave * SCR;
@@ -178,6 +150,12 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
 
 #pragma unroll 1
   for (int ch = wave; ch < nch; ch += 8) {
+    // ---- this chunk's weight ring (first PF steps) and bias fragments ----
+    uint32_t b_cur = chunk_voff(ch);
+    asm volatile("" : "+v"(b_cur));
+#pragma unroll
+    for (int s = 0; s < PF; ++s) { ld_b(rb[s][0], b_cur, s, 0); ld_b(rb[s][1], b_cur, s, 1); }
+    if constexpr (MODE == 0) { ld_b(bfrag[0], b_cur, KS, 0); ld_b(bfrag[1], b_cur, KS, 1); }
     // ---- accumulators: MODE 0 starts them at the bias (8 MFMAs of the packed bias fragment against the ones fragment, C = 0),
     // MODE 1 lets the first step's MFMAs write them (C = 0): no zero fill, no bias load ----
     f32x16 acc[4][2];
@@ -186,25 +164,22 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
       asm volatile("" : "+v"(one0), "+v"(zr));                          // (rebuilt per chunk: four registers that would otherwise be spilled across the loop)
       const uint4 ones = make_uint4(one0, zr, zr, zr);
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      panel_wait_s<16>(bfrag[0], sprev);                     // (both fragments: 16 ring loads + the previous chunk's stores behind them)
-      panel_wait_s<16>(bfrag[1], sprev);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfrag[j]), __builtin_bit_cast(bf16x8, ones), zero, 0, 0, 0);
     }
-    // this lane's byte offsets of (row n0 + (lane >> 3), columns ch * 64 + (lane & 7) * 8 ..) in C / Z, its dropout pair index there,
-    // the next chunk's ring base
+    // this lane's byte offsets of (row n0 + (lane >> 3), columns ch * 64 + (lane & 7) * 8 ..) in C / Z, its dropout pair index there
     uint32_t c_off0 = (uint32_t)(((long)(n0 + (lane >> 3)) * p.ldc + ch * 64 + (lane & 7) * 8) * 2);
     uint32_t z_off0 = (uint32_t)(((long)(n0 + (lane >> 3)) * p.ldz + ch * 64 + (lane & 7) * 8) * 2);
     uint32_t d_p0 = ((uint32_t)(n0 + (lane >> 3)) * (uint32_t)p.M + (uint32_t)(ch * 64 + (lane & 7) * 8)) >> 1;   // (N * M < 2^30)
-    uint32_t b_next = chunk_voff(ch + 8);
     // (opaque: else the loop-invariant part of all 16 item offsets of the epilogue is hoisted out of the chunk loop - 50 registers)
-    asm volatile("" : "+v"(c_off0), "+v"(z_off0), "+v"(d_p0), "+v"(b_next));
+    asm volatile("" : "+v"(c_off0), "+v"(z_off0), "+v"(d_p0));
     // MODE 1: item q (0..15) of the chunk's saved pre-activation: rows i * 32 + pp * 8 + (lane >> 3) (q = i * 4 + pp), 8 columns
+    const uint32_t z_last = (uint32_t)(((long)(p.N - 1) * p.ldz + ch * 64 + (lane & 7) * 8) * 2);   // (rows beyond N read row N - 1 again: their outputs are dropped)
     auto ld_z = [&](uint4& dst, int q) __attribute__((always_inline)) {
-      panel_ld(dst, z_off0 + (uint32_t)((q >> 2) * 32 + (q & 3) * 8) * ldz2, rzl_rs, 0u);
+      panel_ld(dst, min(z_off0 + (uint32_t)((q >> 2) * 32 + (q & 3) * 8) * ldz2, z_last), rz_rs, 0u);
     };
 
     // ---- main loop: KS steps of 16 reduce elements, 8 MFMAs each; the ring holds this chunk's first PF steps already ----
@@ -219,15 +194,10 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     // reads and ring refills of many steps to the top and spills 90-150 registers).  Activation-fragment major: MFMA 2 i + j
     // multiplies activation fragment i by weight fragment j, so fragment i is free behind MFMA 2 i + 1 and its ONE register set is
     // re-read for the next step right there (7 MFMAs ahead of its next use); the ring slot is refilled behind MFMAs 6 and 7.
-    // The last PF steps refill with the NEXT chunk's first steps (MODE 0: ahead of this chunk's stores - vmcnt retires in order and
-    // counts stores) or with this chunk's saved pre-activation items (MODE 1).
+    // MODE 1: the last PF steps refill the ring's registers with this chunk's 16 saved pre-activation items (ahead of its stores).
     for_seq<0, KS>([&](auto ktag) __attribute__((always_inline)) {
       constexpr int kk = decltype(ktag)::value, slot = kk % PF;
       const uint32_t an = a_cur ^ (uint32_t)((kk + 1) << 5);
-      // this step's weight fragments: requested PF steps ago, 14 ring requests behind the second one (+ the previous chunk's stores
-      // while the fragments come from the ring the previous chunk primed)
-      if constexpr (kk < PF) { panel_wait_s<14>(rb[slot][0], sprev); panel_wait_s<14>(rb[slot][1], sprev); }
-      else { panel_wait<14>(rb[slot][0]); panel_wait<14>(rb[slot][1]); }
       for_seq<0, 8>([&](auto mtag) __attribute__((always_inline)) {
         constexpr int mm = decltype(mtag)::value, i = mm >> 1, j = mm & 1;
         if constexpr ((SMX_PANEL_ABL & 2) != 0) {
@@ -240,20 +210,16 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb[slot][j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
         }
         if constexpr (kk + 1 < KS && j == 1 && (SMX_PANEL_ABL & 8) == 0) fa[i] = *reinterpret_cast<const uint4*>(smem + an + i * 32 * ROWB);
-        // the next chunk's bias fragments: at the head of the tail, AHEAD of the tail's ring requests (16 loads behind them)
-        if constexpr (MODE == 0 && kk == KS - PF && mm == 3) { ld_b(bfrag[0], b_next, KS, 0); ld_b(bfrag[1], b_next, KS, 1); }
         if constexpr (mm >= 6) {
           constexpr int jj = mm - 6;
-          if constexpr (kk + PF < KS) ld_b(rb[slot][jj], b_next - (uint32_t)(16 * (KS + 1) * 1024), kk + PF, jj);
+          if constexpr (kk + PF < KS) ld_b(rb[slot][jj], b_cur, kk + PF, jj);
           else if constexpr (MODE == 1) ld_z(rb[slot][jj], 2 * slot + jj);
-          else ld_b(rb[slot][jj], b_next, kk + PF - KS, jj);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
     });
 
     // ---- epilogue, 32 rows at a time through the wave's own scratch ----
-    pg_u32x4 outv[MODE == 1 ? 16 : 1];
     // (scratch addresses rebuilt here, per chunk: hoisted out of the chunk loop they are 12 registers live across the main loop)
     uint32_t s_wr = (uint32_t)(l31 * 128 + hi * 8), s_x = (uint32_t)(l31 & 7), s_rd = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4));
     asm volatile("" : "+v"(s_wr), "+v"(s_x), "+v"(s_rd));
@@ -262,8 +228,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
       float sabl = 0.f;
       for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sabl += acc[i][j][e];
       if (sabl == 123.456f) p.C[0].v = 1;
-      if constexpr (MODE == 1) { for (int s = 0; s < PF; ++s) { if (rb[s][0].x == 0x12345u) p.C[1].v = 1; ld_b(rb[s][0], b_next, s, 0); ld_b(rb[s][1], b_next, s, 1); } }
-      sprev = 0;
+      if constexpr (MODE == 1) { for (int s = 0; s < PF; ++s) if (rb[s][0].x == 0x12345u) p.C[1].v = 1; }
       continue;
     }
     for_seq<0, 4>([&](auto itag) __attribute__((always_inline)) {
@@ -278,10 +243,6 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
           *reinterpret_cast<uint2*>(scr + s_wr + (((uint32_t)(j * 4 + g) ^ s_x) << 4)) = w;
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if constexpr (MODE == 1) {   // items 4 i .. 4 i + 3 of the saved pre-activation: requested in order, 12 - 4 i requests behind the last
-#pragma unroll
-        for (int q = 4 * i; q < 4 * i + 4; ++q) panel_wait<12 - 4 * i>(rb[q >> 1][q & 1]);
-      }
       for_seq<0, 4>([&](auto ptag) __attribute__((always_inline)) {
         constexpr int pp = decltype(ptag)::value;
         constexpr int rstep = i * 32 + pp * 8;               // rows below this lane's first row (n0 + (lane >> 3))
@@ -290,7 +251,6 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
         { const uint32_t w_[4] = {zz.x, zz.y, zz.z, zz.w}; unpack_words<bf16_t, 8>(w_, v); }
         // stores: buffer offsets = the chunk's lane offset + a wave-uniform row step; rows >= N fall outside the resource
         const uint32_t coff = c_off0 + (uint32_t)rstep * ldc2;
-        (void)coff;
         if constexpr (MODE == 0) {
           if (p.Z) {
             const pg_u32x4 zu = {zz.x, zz.y, zz.z, zz.w};
@@ -307,28 +267,10 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
         }
         if (p.dthresh) panel_dropout8(v, hm0, d_p0 + (uint32_t)(rstep / 2) * (uint32_t)p.M, t16);
         const pg_u32x4 cu = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-        if constexpr (MODE == 1) {
-          outv[i * 4 + pp] = cu;                           // (stored behind the next chunk's ring requests, below)
-        } else {
-          if (p.nt & 2) __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 2);
-          else __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 0);
-        }
+        if (p.nt & 2) __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 0);
       });
     });
-    if constexpr (MODE == 1) {
-      // The ring held the pre-activation items, so the next chunk's first steps can only be requested now - but still AHEAD of this
-      // chunk's stores (vmcnt retires in order and counts stores: a load behind them is consumable only once they have drained).
-      // The 16 finished items wait in the registers the accumulators and the items left free.
-#pragma unroll
-      for (int s = 0; s < PF; ++s) { ld_b(rb[s][0], b_next, s, 0); ld_b(rb[s][1], b_next, s, 1); }
-      for_seq<0, 16>([&](auto qtag) __attribute__((always_inline)) {
-        constexpr int q = decltype(qtag)::value;
-        const uint32_t coff = c_off0 + (uint32_t)((q >> 2) * 32 + (q & 3) * 8) * ldc2;
-        if (p.nt & 2) __builtin_amdgcn_raw_buffer_store_b128(outv[q], rc_rs, coff, 0, 2);
-        else __builtin_amdgcn_raw_buffer_store_b128(outv[q], rc_rs, coff, 0, 0);
-      });
-    }
-    sprev = nst;
     SMX_PSTAMP(3 + 2 * (ch >> 3));
   }
 #undef SMX_PSTAMP

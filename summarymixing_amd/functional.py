@@ -70,6 +70,8 @@ def weights_changed():
 def wpacked(param, dtype, transposed=False, bias=None):
     """Packed image (ops.weight_pack) of a Linear's weight parameter [+ fp32 bias parameter] in the compute dtype."""
     W = wcast(param, dtype)
+    if W.dim() != 2:
+        W = W.view(W.shape[0], -1)               # (a Conv1d(k = 1) weight (out, in, 1) seen as a Linear's)
     ent = _shadow.get(id(param))
     if ent is not None and ent[0]() is param and ent[1] == "managed":
         stamp = ("m", _WEPOCH[0])
@@ -449,6 +451,10 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
             e = ops.epilogue(act=act_up, act_grad_z=z_up, row_mask=mask_up, alpha=alpha_up, drop=drop_up, colsum=gb_up)
         else:
             assert dx_drop is None or res_grad is None
+            # plain (or dropout-backward) dgrad with a short reduction and a wide output: the panel-resident kernel, W packed transposed
+            if wparam is not None and res_grad is None and dx.dtype == dz.dtype and panel_ok(dz, K, M, L.ACT_NONE) and _vec_ok(dx):
+                ops.gemm_panel(dz, wpacked(wparam, dz.dtype, True), dx, N, K, M, ops.epilogue(drop=dx_drop))
+                return dx, dz
             e = ops.epilogue(res=res_grad, drop=dx_drop)
         ops.gemm(L.GEMM_NN, dz, W, dx, N, K, M, e)
     return dx, dz
@@ -1105,7 +1111,7 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
         return r + (None,) if ln_next is not None else r
     h, ln1_b = ln_fwd(x, P["ln1_w"], P["ln1_b"], 1e-5, need_bwd, pre=pre_ln, out_dtype=dtype)
     Wp = wcast(P["Wp"], dtype).view(2 * d, d)                    # Conv1d(d,2d,1) weight viewed as a Linear
-    p_, _ = linear_fwd(h, Wp, P["bp"])
+    p_, _ = linear_fwd(h, Wp, P["bp"], wparam=P["Wp"])
     k = P["wd"].shape[-1]
     wd = P["wd"].detach().reshape(d, k)
     c = ops.dwconv_fwd(p_, wd, P["bd"].detach() if P["bd"] is not None else None, B, T, d, k, True, L.PAD_ZERO, chunk)

@@ -74,7 +74,7 @@ class ConvolutionBranch(nn.Module):
             dtype = x3.dtype
             xr = ops.rows2d(x3 if x3.is_contiguous() else x3.contiguous())
             Wpre, Wpost = F.wcast(Pb["Wpre"], dtype), F.wcast(Pb["Wpost"], dtype)
-            u, zu = F.linear_fwd(xr, Wpre, Pb["bpre"], act, None, save_z=need)       # (N, linear_units)
+            u, zu = F.linear_fwd(xr, Wpre, Pb["bpre"], act, None, save_z=need, wparam=Pb["Wpre"])       # (N, linear_units)
             n = u.shape[1] // 2
             u1, u2 = u[:, :n], u[:, n:]
             v, bnv = F.ln_fwd(u2, Pb["ln_w"], Pb["ln_b"], 1e-5, need)
@@ -170,7 +170,7 @@ class BranchformerEncoderLayer(nn.Module):
             # branch 2: cgMLP(LN(x))
             h2, bn2 = F.ln_fwd(x, nc.weight, nc.bias, nc.eps, need, out_dtype=dtype)
             Wpre, Wpost = F.wcast(Pb["Wpre"], dtype), F.wcast(Pb["Wpost"], dtype)
-            u, zu = F.linear_fwd(h2, Wpre, Pb["bpre"], act, None, save_z=need)           # (N, csgu)
+            u, zu = F.linear_fwd(h2, Wpre, Pb["bpre"], act, None, save_z=need, wparam=Pb["Wpre"])           # (N, csgu)
             n = u.shape[1] // 2
             u1, u2 = u[:, :n], u[:, n:]
             v, bnv = F.ln_fwd(u2, Pb["ln_w"], Pb["ln_b"], 1e-5, need)
@@ -242,7 +242,7 @@ class BranchformerEncoderLayer(nn.Module):
                     e2 = dict(drop=(pd, sd2)) if pd > 0.0 else None
                     d1z, dgz = F.mlp_bwd(dy, merge, act, sv_m, dtype, last_drop=mdrop, dx_split=[(0, c1, e1), (c1, c1 + d, e2)])
                     dg, _ = F.linear_bwd(dgz, g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
-                                         dz_ready=True, dx_drop=(pd, sd4) if pd > 0.0 else None)
+                                         dz_ready=True, dx_drop=(pd, sd4) if pd > 0.0 else None, wparam=Pb["Wpost"])
                 else:
                     if merge[-1]["kind"] == "linear":
                         dcat = F.mlp_bwd(dy, merge, act, sv_m, dtype, last_drop=mdrop)
@@ -252,7 +252,7 @@ class BranchformerEncoderLayer(nn.Module):
                     d1 = dcat[:, :c1] if fuse_y1 else (ops.dropout(dcat[:, :c1], pd, sd1) if pd > 0.0 else dcat[:, :c1].contiguous())
                     # branch 2 backward (the dropout backward of its half rides in linear_bwd's activation/mask pass)
                     dg, _ = F.linear_bwd(dcat[:, c1:], g, Wpost, None, L.ACT_NONE, None, 1.0, F.gacc(Pb["Wpost"]), F.gacc(Pb["bpost"]),
-                                         drop=(pd, sd2) if pd > 0.0 else None, dx_drop=(pd, sd4) if pd > 0.0 else None)
+                                         drop=(pd, sd2) if pd > 0.0 else None, dx_drop=(pd, sd4) if pd > 0.0 else None, wparam=Pb["Wpost"])
                 du = torch.empty_like(u)                   # [d gate | d LN input]: both kernels write their half directly
                 if sp:
                     # the transposed exchange: gradients of the halo rows go back to the ranks that own those frames, gradients
