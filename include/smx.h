@@ -159,6 +159,14 @@ size_t smx_weight_pack_bytes(int M, int K);
 int smx_weight_pack(int dtype, const void* W, int64_t ldw, int transposed, const float* bias, int M, int K, void* packed, void* stream);
 int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void* Wpacked, void* C, int64_t ldc, int N, int M, int K,
                    const smx_epilogue* epi, void* stream);
+/* Many smx_weight_pack calls in ONE launch (every packed image of a model, right after the optimizer rewrote the weights): a
+ * table of jobs in DEVICE memory with the same per-job requirements as smx_weight_pack; block_start = the prefix sum of
+ * smx_weight_pack_job_blocks(M, K) over the jobs before this one, total_blocks = the sum over all of them. */
+typedef struct smx_pack_job {
+  const void* W; int64_t ldw; const float* bias; void* packed; int32_t M, K, transposed, block_start;
+} smx_pack_job;
+int smx_weight_pack_job_blocks(int M, int K);
+int smx_weight_pack_jobs(int dtype, const smx_pack_job* jobs_dev, int njobs, int total_blocks, void* stream);
 
 /* Weight gradient of a (batched) Linear: dW[b] (M x K) += alpha * dZ[b]^T X[b], reducing over `rows` frames
  * (dZ (rows, M), X (rows, K), both row-major).  Split-K over the frame dimension into fp32 slabs in `workspace`

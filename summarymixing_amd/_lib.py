@@ -65,6 +65,12 @@ class Epilogue(ctypes.Structure):
                 ("lnf2_eps", c_f), ("pad2_", ctypes.c_int32)]
 
 
+class PackJob(ctypes.Structure):
+    """smx_pack_job of include/smx.h (one entry of smx_weight_pack_jobs' device table)."""
+    _fields_ = [("W", c_vp), ("ldw", c_i64), ("bias", c_vp), ("packed", c_vp), ("M", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("transposed", ctypes.c_int32), ("block_start", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/smx.h one to one (tests/test_abi.py checks the export list)
 SIGNATURES = {
     "smx_version": (c_i, []),
@@ -77,6 +83,8 @@ SIGNATURES = {
     "smx_gemm_panel_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "smx_weight_pack_bytes": (c_sz, [c_i, c_i]),
     "smx_weight_pack": (c_i, [c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_vp, c_vp]),
+    "smx_weight_pack_job_blocks": (c_i, [c_i, c_i]),
+    "smx_weight_pack_jobs": (c_i, [c_i, c_vp, c_i, c_i, c_vp]),
     "smx_gemm_panel": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_i64, c_i, c_i, c_i, ctypes.POINTER(Epilogue), c_vp]),
     "smx_gemm_ln_fused_ok": (c_i, [c_i, c_i, c_i, c_i]),
     "smx_gemm_ln_pair_ok": (c_i, [c_i, c_i, c_i, c_i]),

@@ -36,6 +36,41 @@ __global__ __launch_bounds__(256) void weight_pack_kernel(const uint16_t* __rest
   out[frag * 64 + lane] = v;
 }
 
+// the same for a table of weights in ONE launch (every packed image of a model after an optimizer step): block b belongs to the
+// last job whose block_start <= b
+__global__ __launch_bounds__(256) void weight_pack_jobs_kernel(const smx_pack_job* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const smx_pack_job j = jobs[lo];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, hi_ = lane >> 5;
+  const int KS = j.K >> 4;
+  const long frag = (long)((int)blockIdx.x - j.block_start) * 4 + wave;
+  if (frag >= (long)(j.M >> 5) * (KS + 1)) return;
+  const int cb = (int)(frag / (KS + 1)), kk = (int)(frag % (KS + 1));
+  const int m = cb * 32 + c, k0 = kk * 16 + hi_ * 8;
+  const uint16_t* W = reinterpret_cast<const uint16_t*>(j.W);
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (kk == KS) {
+    if (j.bias && hi_ == 0) {
+      const float b = j.bias[m];
+      const uint32_t bh = f32_to_bf16_bits(b);
+      v.x = bh | (f32_to_bf16_bits(b - bf16_bits_to_f32(bh)) << 16);
+    }
+  } else if (!j.transposed) {
+    v = *reinterpret_cast<const uint4*>(W + (long)m * j.ldw + k0);
+  } else {
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      w[q] = (uint32_t)W[(long)(k0 + 2 * q) * j.ldw + m] | ((uint32_t)W[(long)(k0 + 2 * q + 1) * j.ldw + m] << 16);
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  reinterpret_cast<uint4*>(j.packed)[frag * 64 + lane] = v;
+}
+
 int launch_panel_fwd(const PanelParams& p, int K, int act, hipStream_t s) { return launch_panel_mode<0>(p, K, act, s); }
 
 }  // namespace smx
@@ -62,6 +97,19 @@ extern "C" int smx_weight_pack(int dtype, const void* W, int64_t ldw, int transp
   hipLaunchKernelGGL(weight_pack_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const uint16_t*>(W), (long)ldw, transposed, bias, M, K, reinterpret_cast<uint4*>(packed));
   return check_launch("smx_weight_pack");
+}
+
+extern "C" int smx_weight_pack_job_blocks(int M, int K) {
+  return (M > 0 && K > 0) ? (int)(((long)(M / 32) * (K / 16 + 1) + 3) / 4) : 0;
+}
+
+extern "C" int smx_weight_pack_jobs(int dtype, const smx_pack_job* jobs_dev, int njobs, int total_blocks, void* stream) {
+  SMX_REQUIRE(dtype == SMX_BF16, "smx_weight_pack_jobs: bf16 only");
+  SMX_REQUIRE(njobs >= 0 && total_blocks >= 0, "smx_weight_pack_jobs: bad sizes");
+  if (njobs == 0 || total_blocks == 0) return SMX_OK;
+  SMX_REQUIRE(jobs_dev, "smx_weight_pack_jobs: null pointer");
+  hipLaunchKernelGGL(weight_pack_jobs_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev, njobs);
+  return check_launch("smx_weight_pack_jobs");
 }
 
 extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void* Wpacked, void* C, int64_t ldc, int N, int M, int K,

@@ -67,13 +67,37 @@ def weights_changed():
     _WEPOCH[0] += 1
 
 
+_pack_table = {"sig": None, "dev": None, "blocks": 0}   # device job table of every trainer-managed packed image
+
+
+def _repack_managed():
+    """ONE launch re-packs every trainer-managed image (they all went stale together: the optimizer rewrote every shadow)."""
+    ents = [v for v in _packed.values() if v[1][0] == "m" and v[0]() is not None]
+    sig = tuple((e[3].data_ptr(), e[3].stride(0), 0 if e[4] is None else e[4].data_ptr(), e[2].data_ptr(), e[5], e[6], e[7]) for e in ents)
+    if _pack_table["sig"] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            return False                                 # (no host-to-device table upload inside a capture: the caller packs singly)
+        lib, arr, nb = L.lib(), (L.PackJob * len(ents))(), 0
+        for j, (W_, ldw, bias_, out_, M, K, tr) in zip(arr, sig):
+            j.W, j.ldw, j.bias, j.packed, j.M, j.K, j.transposed, j.block_start = W_, ldw, bias_ or None, out_, M, K, tr, nb
+            nb += lib.smx_weight_pack_job_blocks(M, K)
+        _pack_table.update(sig=sig, dev=torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(ents[0][2].device), blocks=nb)
+    ops.weight_pack_jobs(_pack_table["dev"], len(ents), _pack_table["blocks"], sum(e[5] * e[6] for e in ents))
+    stamp = ("m", _WEPOCH[0])
+    for k, v in list(_packed.items()):
+        if v[1][0] == "m" and v[0]() is not None:
+            _packed[k] = (v[0], stamp) + v[2:]
+    return True
+
+
 def wpacked(param, dtype, transposed=False, bias=None):
     """Packed image (ops.weight_pack) of a Linear's weight parameter [+ fp32 bias parameter] in the compute dtype."""
     W = wcast(param, dtype)
     if W.dim() != 2:
         W = W.view(W.shape[0], -1)               # (a Conv1d(k = 1) weight (out, in, 1) seen as a Linear's)
     ent = _shadow.get(id(param))
-    if ent is not None and ent[0]() is param and ent[1] == "managed":
+    managed = ent is not None and ent[0]() is param and ent[1] == "managed"
+    if managed:
         stamp = ("m", _WEPOCH[0])
     else:
         stamp = ("v", param._version, param.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()))
@@ -81,12 +105,16 @@ def wpacked(param, dtype, transposed=False, bias=None):
     c = _packed.get(key)
     if c is not None and c[0]() is param and c[1] == stamp:
         return c[2]
+    if c is not None and c[0]() is param and managed and c[1][0] == "m" and _repack_managed():
+        return c[2]                                # (stale with every other managed image: one grouped launch re-packed them all)
     if len(_packed) > 4096:
         for k in [k for k, v in _packed.items() if v[0]() is None]:
             del _packed[k]
     out = c[2] if (c is not None and c[0]() is param) else None
-    out = ops.weight_pack(W, transposed, None if bias is None else bias.detach(), out)
-    _packed[key] = (weakref.ref(param), stamp, out)
+    bt = None if bias is None else bias.detach()
+    out = ops.weight_pack(W, transposed, bt, out)
+    M, K = (W.shape[1], W.shape[0]) if transposed else (W.shape[0], W.shape[1])
+    _packed[key] = (weakref.ref(param), stamp, out, W, bt, M, K, int(transposed))
     return out
 
 

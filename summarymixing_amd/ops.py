@@ -236,6 +236,13 @@ def weight_pack(W, transposed=False, bias=None, out=None):
     return out
 
 
+def weight_pack_jobs(jobs_dev, njobs, total_blocks, nelem=0):
+    """Every job of a device table of smx_pack_job in one launch (smx_weight_pack_jobs)."""
+    tok = _pb(f"weight_pack_jobs ({njobs} weights)", 4.0 * nelem)
+    L.check(L.lib().smx_weight_pack_jobs(L.BF16, _p(jobs_dev), njobs, total_blocks, _stream()), "smx_weight_pack_jobs")
+    _pe(tok)
+
+
 def gemm_panel_ok(a, M, K):
     return a.dtype == torch.bfloat16 and L.lib().smx_gemm_panel_ok(L.BF16, a.shape[0], M, K) == 1
 

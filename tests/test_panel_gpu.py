@@ -136,3 +136,25 @@ def test_panel_is_deterministic_at_full_chip_sizes(K, M):
             o1, z1 = torch.full_like(o0, 3.0), torch.full_like(o0, 3.0)
             fp(o1, z1)
             assert torch.equal(o1, o0)
+
+
+def test_weight_pack_jobs_equals_single_packs():
+    """The grouped re-pack (one launch for a table of weights) writes what the single calls write."""
+    import ctypes
+    torch.manual_seed(5)
+    specs = [(1024, 256, False, True), (256, 1024, True, False), (512, 256, False, True), (2048, 512, False, False), (512, 1536, True, False)]
+    ws, outs, refs, biases = [], [], [], []
+    arr, nb = (L.PackJob * len(specs))(), 0
+    for j, (r, c, tr, hb) in zip(arr, specs):
+        W = (torch.rand(r, c, device="cuda") - 0.5).bfloat16()
+        b = torch.rand(c if tr else r, device="cuda") if hb else None
+        M, K = (c, r) if tr else (r, c)
+        ref = ops.weight_pack(W, transposed=tr, bias=b)
+        out = torch.zeros_like(ref)
+        j.W, j.ldw, j.bias, j.packed, j.M, j.K, j.transposed, j.block_start = W.data_ptr(), W.stride(0), (b.data_ptr() if hb else None), out.data_ptr(), M, K, int(tr), nb
+        nb += L.lib().smx_weight_pack_job_blocks(M, K)
+        ws.append(W); outs.append(out); refs.append(ref); biases.append(b)
+    dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    ops.weight_pack_jobs(dev, len(specs), nb)
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)

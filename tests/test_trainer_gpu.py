@@ -347,3 +347,74 @@ def test_non_finite_gradient_norm_skips_the_update():
     assert opt.skipped_steps() == 2 and torch.equal(opt.flat_p, p0)
     opt.zero_grad(); enc(x)[0].backward(r); opt.step()    # a clean step still updates
     assert opt.skipped_steps() == 2 and not torch.equal(opt.flat_p, p0) and torch.isfinite(opt.flat_p).all()
+
+
+def test_packed_weight_images_follow_the_optimizer():
+    """The panel GEMM's packed images (functional.wpacked) are re-packed after EVERY optimizer step and checkpoint load - eagerly
+    and inside a captured hipGraph (whose replays must contain the pack launches): after each step's forward every cached image
+    equals a fresh pack of the current bf16 shadow, and graph replays equal eager steps."""
+    from summarymixing_amd import functional as F, ops
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    from summarymixing_amd.trainer import FlatAdamW
+    dtype, d = torch.bfloat16, 256
+    old_rows = F._PANEL_MIN_ROWS
+    F._PANEL_MIN_ROWS = 128                       # (the panel path from 128 rows: a small batch exercises it)
+
+    def run(panel, graph):
+        F._PANEL = panel
+        torch.manual_seed(5)
+        enc = ConformerEncoder(1, d, 1024, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                               local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast").cuda()
+        opt = FlatAdamW(enc, lr=3e-2, max_grad_norm=5.0, compute_dtype=dtype)
+        x = torch.randn(4, 200, d, device="cuda").to(dtype)
+        r = torch.randn(4, 200, d, device="cuda").to(dtype)
+
+        def step():
+            opt.zero_grad()
+            y, _ = enc(x)
+            (y.float() * r.float()).sum().backward()
+            opt.step()
+
+        def check_images():
+            n = 0
+            for (pid, tr), ent in list(F._packed.items()):
+                prm = ent[0]()
+                if prm is None or not any(prm is q for q in enc.parameters()):
+                    continue
+                W = F.wcast(prm, dtype)
+                W = W.view(W.shape[0], -1) if W.dim() != 2 else W
+                assert torch.equal(ent[2], ops.weight_pack(W, bool(tr), ent[4])), "stale packed image"
+                n += 1
+            return n
+
+        step(); step()                             # eager: images packed singly, then by the grouped launch
+        if panel:
+            with torch.no_grad():
+                enc(x)                             # (a forward after the update: the forward images are current again)
+            assert check_images() >= 3
+        if graph:
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+                with torch.cuda.graph(g, stream=s):
+                    step()
+            torch.cuda.current_stream().wait_stream(s)
+            for _ in range(3):
+                g.replay()
+        else:
+            for _ in range(5):
+                step()
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().float().flatten() for p in enc.parameters()])
+
+    try:
+        eager = run(True, False)
+        graphed = run(True, True)
+        tiled_eager, tiled_graphed = run(False, False), run(False, True)
+    finally:
+        F._PANEL, F._PANEL_MIN_ROWS = True, old_rows
+    # replays whose graph lacked the pack launches would run steps 4-7 on the images of step 3: far outside this bar at lr 3e-2
+    # (the tiled path sets the bar: graph replay against eager steps of the same kernels)
+    assert float((graphed - eager).abs().max()) <= max(1e-6, 2.0 * float((tiled_graphed - tiled_eager).abs().max()))
