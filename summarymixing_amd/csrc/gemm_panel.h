@@ -35,6 +35,7 @@ struct PanelParams {
   int N, M;
   unsigned dthresh; float dscale; uint64_t seed; const uint64_t* epoch;
   int nt;                             // 2: stream C past the caches
+  int csplit;                         // workgroups per panel: workgroup (panel, s) takes the chunk rounds s, s + csplit, ... (small N: fill the chip)
   long long* dbg;                     // -DSMX_DIAG only: per-wave clock stamps (tools/panel_stamps.py)
 };
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   __shared__ __attribute__((aligned(16))) char smem[A_BYTES + 8 * SCR];
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (wave-uniform for the compiler: scalar ring offsets, no waterfall loops)
-  const int n0 = blockIdx.x * 128;
+  const int n0 = (int)(blockIdx.x / (unsigned)p.csplit) * 128, csi = (int)(blockIdx.x % (unsigned)p.csplit);
 #ifdef SMX_DIAG   // per-wave clock stamps: [0] start, [1] panel in LDS, [2 + 2 r] main loop of chunk round r done, [3 + 2 r] its epilogue
   long long* dbgp = p.dbg ? p.dbg + ((long)blockIdx.x * 8 + (t >> 6)) * 16 : nullptr;
 #define SMX_PSTAMP(k) do { if (dbgp && lane == 0 && (k) < 16) dbgp[k] = clock64(); } while (0)
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   const int nch = p.M >> 6;
 
 #pragma unroll 1
-  for (int ch = wave; ch < nch; ch += 8) {
+  for (int ch = wave + 8 * csi; ch < nch; ch += 8 * p.csplit) {
     // ---- this chunk's weight ring (first PF steps) and bias fragments ----
     uint32_t b_cur = chunk_voff(ch);
     asm volatile("" : "+v"(b_cur));
@@ -282,7 +283,7 @@ int launch_panel_actgrad(const PanelParams& p, int K, int act, hipStream_t s);
 
 template <int MODE>
 static int launch_panel_mode(const PanelParams& p, int K, int act, hipStream_t s) {
-  const dim3 grid((p.N + 127) / 128), block(512);
+  const dim3 grid(((p.N + 127) / 128) * p.csplit), block(512);
 #define SMX_PANEL_CASE(KK, AA) \
   if (K == KK && act == AA) { hipLaunchKernelGGL((gemm_panel_kernel<KK, MODE, AA>), grid, block, 0, s, p); return check_launch("smx_gemm_panel"); }
   SMX_PANEL_CASE(256, SMX_ACT_NONE) SMX_PANEL_CASE(256, SMX_ACT_SWISH) SMX_PANEL_CASE(256, SMX_ACT_GELU) SMX_PANEL_CASE(256, SMX_ACT_RELU)

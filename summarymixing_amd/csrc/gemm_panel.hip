@@ -146,6 +146,12 @@ extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void*
   p.seed = e.drop_seed; p.epoch = e.epoch;
   // store policy of smx_gemm: the output is streamed once it cannot survive in the Infinity Cache anyway
   p.nt = ((long)N * M * 2 >= (96L << 20)) ? 2 : 0;
+  // one workgroup per CU: with fewer panels than ~3/4 of the CUs a panel's chunk rounds (M / 512 of them) are dealt to 2 or 4 workgroups
+  {
+    const int panels = (N + 127) / 128, rounds = (M / 64 + 7) / 8;
+    p.csplit = 1;
+    while (p.csplit < 4 && panels * p.csplit < 192 && rounds % (p.csplit * 2) == 0) p.csplit *= 2;
+  }
 #ifdef SMX_DIAG
   p.dbg = g_dbg_stamps;
 #endif

@@ -118,10 +118,12 @@ def wpacked(param, dtype, transposed=False, bias=None):
     return out
 
 
-# The panel-resident GEMM takes the output-bound Linears with a short reduction (K = 256 / 512: FFN up-projection and the act-grad
-# dgrad of the down-projection) from this many rows on (one 128-row panel per CU: below ~half the chip the tiled kernels win).
+# The panel-resident GEMM takes the output-bound Linears with a short reduction (K = 256 / 512: FFN up-projection, the act-grad
+# dgrad of the down-projection, the conv module's pointwise Linear, the cgMLP projections) from this many rows on.  One 128-row
+# panel per CU; below ~190 panels the kernel deals a panel's chunk rounds to 2 or 4 workgroups.  Same-box A/B of the steps
+# (tools/experiments/ab_panel_rows.sh): 16 000 rows C2b 8.17 -> 7.83 ms, C2a 16.42 -> 15.81; 8 000 rows a tie; 32 000 rows -3 %.
 _PANEL = os.environ.get("SMX_PANEL", "1") != "0"
-_PANEL_MIN_ROWS = int(os.environ.get("SMX_PANEL_MIN_ROWS", "24576"))
+_PANEL_MIN_ROWS = int(os.environ.get("SMX_PANEL_MIN_ROWS", "12288"))
 _PANEL_ACTS = (L.ACT_NONE, L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU)
 
 

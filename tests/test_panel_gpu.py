@@ -19,7 +19,9 @@ def _mk(N, M, K, seed=0):
     return rnd(N, K).bfloat16(), (rnd(M, K) * (2.0 / K ** 0.5)).bfloat16(), rnd(M) * 0.3
 
 
-@pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (128, 512, 256), (1, 64, 256), (700, 2048, 512), (391, 1536, 512), (2500, 3072, 512)])
+# (N < 24 576 with M >= 1024: the chunk rounds of a panel are dealt to 2 or 4 workgroups; 16 000 x 1024 and 8 000 x 2048 fill the chip that way)
+@pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (128, 512, 256), (1, 64, 256), (700, 2048, 512), (391, 1536, 512), (2500, 3072, 512),
+                                   (16000 + 5, 1024, 256), (8000 + 9, 2048, 512)])
 @pytest.mark.parametrize("act", [L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU, L.ACT_NONE])
 def test_panel_forward_matches_float64(N, M, K, act):
     x, W, b = _mk(N, M, K)
@@ -43,7 +45,7 @@ def test_panel_forward_matches_float64(N, M, K, act):
     assert rel_err(o3, ACTS[act](x.double() @ W.double().t())) < 1e-2
 
 
-@pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (5, 128, 256), (700, 2048, 512), (2500, 3072, 512)])
+@pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (5, 128, 256), (700, 2048, 512), (2500, 3072, 512), (16000 + 5, 1024, 256)])
 @pytest.mark.parametrize("act", [L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU])
 def test_panel_actgrad_matches_float64(N, M, K, act):
     dy, Wt, _ = _mk(N, M, K, seed=1)           # Wt (M, K) = W2^T
