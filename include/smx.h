@@ -139,8 +139,8 @@ int smx_gemm_plan_query(int layout, int dtype, const void* A, int64_t lda, int64
                         const smx_epilogue* epi, smx_gemm_plan* plan);
 
 /* Panel-resident GEMM for the SHORT reductions with WIDE outputs of an encoder layer (bf16, K = 256 or 512, M % 64 == 0):
- *   forward      C = D(act(A Wp + bias)), optionally saving the pre-activation Z      (epi: act, z, drop_*; bias: packed, below)
- *   act-grad     C = D((A Wp) * act'(Z))                                             (epi: SMX_EPI_ACT_GRAD, z = input, act, drop_*)
+ *   forward      C = alpha * D(act(A Wp + bias)) * row_mask, optionally saving the pre-activation Z   (epi: act, z, drop_*, row_mask, alpha; bias: packed, below)
+ *   act-grad     C = alpha * D((A Wp) * act'(Z)) * row_mask                                       (epi: SMX_EPI_ACT_GRAD, z = input, act, drop_*, row_mask, alpha)
  * i.e. the FFN up-projection  nn.Linear(d_model, d_ffn) + activation + dropout  (Conformer.py:458-472, Branchformer.py:142-157)
  * and the first half of the autograd backward of the down-projection that follows it (dH = dY W2, then the activation / dropout
  * backward), the two output-bound GEMMs of every encoder layer.  A 128-row panel of A stays in LDS for all M columns and
@@ -152,7 +152,7 @@ int smx_gemm_plan_query(int layout, int dtype, const void* A, int64_t lda, int64
  * must be re-packed whenever W or the bias change.
  * Same arithmetic as smx_gemm with the same epilogue fields (fp32 accumulation, the same dropout mask for the same seed), except
  * that the activation / its gradient is evaluated on the bf16-ROUNDED pre-activation / product (torch autocast semantics: the
- * Linear's output is a bf16 tensor).  Any other epilogue field (bias, residual, C0, row mask, alpha != 1, LayerNorm, fp32 output,
+ * Linear's output is a bf16 tensor).  Any other epilogue field (bias, residual, C0, LayerNorm, fp32 output,
  * column sums) returns SMX_EUNSUPPORTED: use smx_gemm.  smx_gemm_panel_ok: can these sizes take the panel path at all? */
 int smx_gemm_panel_ok(int dtype, int N, int M, int K);
 size_t smx_weight_pack_bytes(int M, int K);

@@ -35,6 +35,7 @@ struct PanelParams {
   int N, M;
   unsigned dthresh; float dscale; uint64_t seed; const uint64_t* epoch;
   int nt;                             // 2: stream C past the caches
+  const uint8_t* row_mask; float alpha;   // per-row keep mask [N] or null; output scale (folded into the dropout scale)
   int csplit;                         // workgroups per panel: workgroup (panel, s) takes the chunk rounds s, s + csplit, ... (small N: fill the chip)
   long long* dbg;                     // -DSMX_DIAG only: per-wave clock stamps (tools/panel_stamps.py)
 };
@@ -124,7 +125,10 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
       const int v = t + 512 * i, row = v / CPR, c = v % CPR, n = min(n0 + row, p.N - 1);   // (rows beyond N: row N - 1 again, their outputs are dropped)
       const uint32_t off = (uint32_t)(((long)n * p.lda + c * 8) * 2);
       const pg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ra_rs, off, 0, 0);
-      ra[i] = make_uint4(r.x, r.y, r.z, r.w);
+      // row mask: a masked row enters the panel as zeros, so its accumulators hold nothing but the bias - which MODE 0 withholds
+      // from it as well (the ones fragment below): act(0) = 0 for every activation here, act-grad and dropout keep the zero
+      const bool keep = p.row_mask ? p.row_mask[n] != 0 : true;
+      ra[i] = keep ? make_uint4(r.x, r.y, r.z, r.w) : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   // dropout: the seed / high-word part of the hash is a kernel constant (pair indices < 2^32), the scale is folded into the values
   const uint64_t dseed = p.dthresh ? epoch_seed(p.seed, p.epoch) : 0;
   const uint32_t hm0 = mix32((uint32_t)dseed) ^ (uint32_t)(dseed >> 32), t16 = p.dthresh >> 16;
-  const float dsc = p.dthresh ? p.dscale : 1.f, dinv = p.dthresh ? 1.f / p.dscale : 1.f;
+  const float dsc = (p.dthresh ? p.dscale : 1.f) * p.alpha, dinv = 1.f / dsc;   // (the output scale alpha rides in the same factor)
   const int nch = p.M >> 6;
 
 #pragma unroll 1
@@ -161,26 +165,30 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     // MODE 1 lets the first step's MFMAs write them (C = 0): no zero fill, no bias load ----
     f32x16 acc[4][2];
     if constexpr (MODE == 0) {
-      uint32_t one0 = hi ? 0u : 0x3f803f80u, zr = 0u;                      // reduce slots 0 and 1 = 1.0, the rest 0
-      asm volatile("" : "+v"(one0), "+v"(zr));                          // (rebuilt per chunk: four registers that would otherwise be spilled across the loop)
-      const uint4 ones = make_uint4(one0, zr, zr, zr);
+      // reduce slots 0 and 1 = 1.0, the rest 0 - per 32-row block, and 0 for a masked row (its bias stays out: see the panel load);
+      // rebuilt per chunk (the four mask bytes come with the ring's requests) rather than kept in registers across the loop
+      const uint8_t* mkp = p.row_mask;
+      asm volatile("" : "+s"(mkp));
+      uint32_t zr = 0u;
+      asm volatile("" : "+v"(zr));
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < 4; ++i) {
+        const bool keep = !hi && (mkp ? mkp[min(n0 + i * 32 + l31, p.N - 1)] != 0 : true);
+        const uint4 ones = make_uint4(keep ? 0x3f803f80u : 0u, zr, zr, zr);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfrag[j]), __builtin_bit_cast(bf16x8, ones), zero, 0, 0, 0);
+      }
     }
-    // this lane's byte offsets of (row n0 + (lane >> 3), columns ch * 64 + (lane & 7) * 8 ..) in C / Z, its dropout pair index there
-    uint32_t c_off0 = (uint32_t)(((long)(n0 + (lane >> 3)) * p.ldc + ch * 64 + (lane & 7) * 8) * 2);
+    // this lane's byte offset of (row n0 + (lane >> 3), columns ch * 64 + (lane & 7) * 8 ..) in Z (the tail's requests need it; the
+    // offsets the epilogue alone needs are built behind the main loop: two registers fewer across it)
     uint32_t z_off0 = (uint32_t)(((long)(n0 + (lane >> 3)) * p.ldz + ch * 64 + (lane & 7) * 8) * 2);
-    uint32_t d_p0 = ((uint32_t)(n0 + (lane >> 3)) * (uint32_t)p.M + (uint32_t)(ch * 64 + (lane & 7) * 8)) >> 1;   // (N * M < 2^30)
-    // (opaque: else the loop-invariant part of all 16 item offsets of the epilogue is hoisted out of the chunk loop - 50 registers)
-    asm volatile("" : "+v"(c_off0), "+v"(z_off0), "+v"(d_p0));
+    // (opaque: else the loop-invariant part of all 16 item offsets is hoisted out of the chunk loop - 50 registers)
+    asm volatile("" : "+v"(z_off0));
     // MODE 1: item q (0..15) of the chunk's saved pre-activation: rows i * 32 + pp * 8 + (lane >> 3) (q = i * 4 + pp), 8 columns
-    const uint32_t z_last = (uint32_t)(((long)(p.N - 1) * p.ldz + ch * 64 + (lane & 7) * 8) * 2);   // (rows beyond N read row N - 1 again: their outputs are dropped)
     auto ld_z = [&](uint4& dst, int q) __attribute__((always_inline)) {
-      panel_ld(dst, min(z_off0 + (uint32_t)((q >> 2) * 32 + (q & 3) * 8) * ldz2, z_last), rz_rs, 0u);
+      panel_ld(dst, z_off0 + (uint32_t)((q >> 2) * 32 + (q & 3) * 8) * ldz2, rz_rs, 0u);   // (rows beyond N: outside the resource, zeros)
     };
 
     // ---- main loop: KS steps of 16 reduce elements, 8 MFMAs each; the ring holds this chunk's first PF steps already ----
@@ -221,6 +229,9 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     });
 
     // ---- epilogue, 32 rows at a time through the wave's own scratch ----
+    uint32_t c_off0 = (uint32_t)(((long)(n0 + (lane >> 3)) * p.ldc + ch * 64 + (lane & 7) * 8) * 2);
+    uint32_t d_p0 = ((uint32_t)(n0 + (lane >> 3)) * (uint32_t)p.M + (uint32_t)(ch * 64 + (lane & 7) * 8)) >> 1;   // dropout pair index (N * M < 2^30)
+    asm volatile("" : "+v"(c_off0), "+v"(d_p0));
     // (scratch addresses rebuilt here, per chunk: hoisted out of the chunk loop they are 12 registers live across the main loop)
     uint32_t s_wr = (uint32_t)(l31 * 128 + hi * 8), s_x = (uint32_t)(l31 & 7), s_rd = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4));
     asm volatile("" : "+v"(s_wr), "+v"(s_x), "+v"(s_rd));

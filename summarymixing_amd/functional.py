@@ -364,9 +364,9 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
         out = torch.empty((N, M), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
     # wparam = the fp32 parameter behind W: bias / activation / saved Z / dropout only -> the panel-resident kernel on its packed image
-    if (wparam is not None and mask is None and res is None and c0 is None and alpha == 1.0 and not out_f32 and ln_next is None and
+    if (wparam is not None and res is None and c0 is None and not out_f32 and ln_next is None and
             drop_cols == 0 and out.dtype == x.dtype and panel_ok(x, M, K, act) and _vec_ok(out, z)):
-        ops.gemm_panel(x, wpacked(wparam, x.dtype, False, bias), out, N, M, K, ops.epilogue(act=act, z=z, drop=drop))
+        ops.gemm_panel(x, wpacked(wparam, x.dtype, False, bias), out, N, M, K, ops.epilogue(act=act, z=z, drop=drop, row_mask=mask, alpha=alpha))
         return out, z
     lnf = lnf2 = None
     if ln_next is not None:
@@ -474,9 +474,9 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
             assert res_grad is None
             z_up, act_up, mask_up, alpha_up, drop_up, gb_up = up
             # wparam = the fp32 parameter behind W (M, K): the act-grad dgrad on the panel-resident kernel, W packed transposed
-            if (wparam is not None and mask_up is None and alpha_up == 1.0 and gb_up is None and dx.dtype == dz.dtype and
-                    panel_ok(dz, K, M, act_up) and _vec_ok(dx, z_up)):
-                ops.gemm_panel(dz, wpacked(wparam, dz.dtype, True), dx, N, K, M, ops.epilogue(act=act_up, act_grad_z=z_up, drop=drop_up))
+            if (wparam is not None and gb_up is None and dx.dtype == dz.dtype and panel_ok(dz, K, M, act_up) and _vec_ok(dx, z_up)):
+                ops.gemm_panel(dz, wpacked(wparam, dz.dtype, True), dx, N, K, M,
+                               ops.epilogue(act=act_up, act_grad_z=z_up, drop=drop_up, row_mask=mask_up, alpha=alpha_up))
                 return dx, dz
             e = ops.epilogue(act=act_up, act_grad_z=z_up, row_mask=mask_up, alpha=alpha_up, drop=drop_up, colsum=gb_up)
         else:
@@ -506,7 +506,7 @@ def mlp_fwd(x, layers, act, mask, need_bwd, dtype, last_res=None, last_drop=None
             Wc = wcast(ly["W"], dtype)
             y, z = linear_fwd(x, Wc, ly["b"], act, mk, save_z=need_bwd, res=last_res if last else None,
                               drop=last_drop if last else None, out=last_out if last else None,
-                              drop_cols=last_drop_cols if last else 0)
+                              drop_cols=last_drop_cols if last else 0, wparam=ly["W"])
         else:
             Wc = wcast(ly["W"], dtype)                     # (H, f, h)
             H, f, h = Wc.shape
@@ -542,7 +542,7 @@ def mlp_bwd(dy, layers, act, saved, dtype, need_dx=True, res_grad=None, dx_out=N
             dy, _ = linear_bwd(dy, x, Wc, z, act, mk, 1.0, gacc(ly["W"]), gacc(ly["b"]), want_dx,
                                res_grad if first else None, dx_out=dx_out if first else None, dz_ready=dz_ready, up=up,
                                drop=last_drop if i == n - 1 else None, ln=ln if first else None,
-                               ln_second=ln_second if first else None, dx_split=dx_split if first else None)
+                               ln_second=ln_second if first else None, dx_split=dx_split if first else None, wparam=ly["W"])
             dz_ready = up is not None
         else:
             Wc = wcast(ly["W"], dtype)

@@ -111,7 +111,7 @@ def test_panel_refuses_what_it_cannot_do():
     with pytest.raises(RuntimeError):
         ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(bias=b))
     with pytest.raises(RuntimeError):
-        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(alpha=0.5))
+        ops.gemm_panel(x, wp, out, N, M, K, ops.epilogue(out_mode=L.OUT_F32))
     assert not ops.gemm_panel_ok(x, M, 384) and not ops.gemm_panel_ok(x, 96, K) and not ops.gemm_panel_ok(x.float(), M, K)
 
 
@@ -160,3 +160,22 @@ def test_weight_pack_jobs_equals_single_packs():
     ops.weight_pack_jobs(dev, len(specs), nb)
     for o, r in zip(outs, refs):
         assert torch.equal(o, r)
+
+
+@pytest.mark.parametrize("N,M,K", [(1000 + 37, 512, 256), (3000, 1024, 256), (700, 512, 512), (20000 + 3, 1536, 512)])
+def test_panel_row_mask_and_alpha(N, M, K):
+    """C = alpha * D(act(.)) * row_mask in both forms (the VanillaNN layers of the cell, summary_mixing.py:207-210): masked rows
+    are exact zeros (they enter the panel as zeros and get no bias), the others equal the tiled kernel's."""
+    x, W, b = _mk(N, M, K, seed=6)
+    mask = (torch.rand(N, device="cuda") > 0.3).to(torch.uint8)
+    mask[-5:] = 0
+    z = (torch.rand(N, M, device="cuda") * 6 - 3).bfloat16()
+    Wt = W.t().contiguous()
+    o1, o2, z1, z2 = (torch.full((N, M), 5.0, device="cuda").bfloat16() for _ in range(4))
+    ops.gemm_panel(x, ops.weight_pack(W, bias=b), o1, N, M, K, ops.epilogue(act=L.ACT_SWISH, z=z1, row_mask=mask, alpha=0.5, drop=(0.15, 9)))
+    ops.gemm(L.GEMM_NT, x, W, o2, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, z=z2, row_mask=mask, alpha=0.5, drop=(0.15, 9)))
+    assert bool((o1[mask == 0] == 0).all()) and rel_err(o1, o2) < 1.2e-2
+    assert rel_err(z1[mask != 0], z2[mask != 0]) < 8e-3          # (the saved pre-activation of a masked row is never used: its gradient is masked too)
+    ops.gemm_panel(x, ops.weight_pack(Wt, transposed=True), o1, N, M, K, ops.epilogue(act=L.ACT_GELU, act_grad_z=z, row_mask=mask, alpha=0.5, drop=(0.15, 9)))
+    ops.gemm(L.GEMM_NN, x, Wt, o2, N, M, K, ops.epilogue(act=L.ACT_GELU, act_grad_z=z, row_mask=mask, alpha=0.5, drop=(0.15, 9)))
+    assert bool((o1[mask == 0] == 0).all()) and rel_err(o1, o2) < 1.2e-2
