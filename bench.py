@@ -239,22 +239,29 @@ def roofline_wgrad(cfg, dtype):
 
 
 def roofline_gemm(cfg, dtype):
-    """The FFN up-projection GEMM (gemm_kernel<bf16, NT, 128x128> +bias+Swish+Z) in isolation, back to back."""
+    """The FFN up-projection GEMM (+bias+Swish+Z) in isolation, back to back: the panel-resident kernel where the product uses it
+    (bf16, K = 256 / 512), else gemm_kernel<NT, 128x128>."""
     from summarymixing_amd import _lib as L, ops
     N, K, M = cfg["B"] * cfg["T"], cfg["d"], cfg["f"] or 4 * cfg["d"]
     x = torch.randn(N, K, device="cuda").to(dtype)
     w = (torch.randn(M, K, device="cuda") * 0.05).to(dtype)
     b = torch.randn(M, device="cuda")
     y, z = torch.empty(N, M, device="cuda", dtype=dtype), torch.empty(N, M, device="cuda", dtype=dtype)
-    e = ops.epilogue(bias=b, act=L.ACT_SWISH, z=z)
-    t = time_kernel(lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e))
+    panel = dtype == torch.bfloat16 and ops.gemm_panel_ok(x, M, K)       # what the product launches for this Linear (functional.linear_fwd)
+    if panel:
+        wp, e = ops.weight_pack(w, bias=b), ops.epilogue(act=L.ACT_SWISH, z=z)
+        t = time_kernel(lambda: ops.gemm_panel(x, wp, y, N, M, K, e))
+    else:
+        e = ops.epilogue(bias=b, act=L.ACT_SWISH, z=z)
+        t = time_kernel(lambda: ops.gemm(L.GEMM_NT, x, w, y, N, M, K, e))
     flops = 2.0 * N * K * M
     es = 2 if dtype == torch.bfloat16 else 4
     mfma_peak = 2500.0 if dtype == torch.bfloat16 else 157.3
     alg_bytes = (N * K + M * K + 2 * N * M) * es + 4 * M      # X + W + Y + Z + bias (SURVEY §8d per-unit figures)
     intensity = flops / alg_bytes                              # flop per algorithmic byte
     ridge = mfma_peak * 1e12 / 8000e9                          # ~312 flop/B (bf16): below it the kernel is HBM-bound
-    name = (f"gemm_kernel<{'bf16' if es == 2 else 'f32'},NT,128x128> FFN up-proj ({N}x{K})x({K}x{M}) +bias+swish+Z")
+    name = ((f"gemm_panel_kernel<{K}, 0, {L.ACT_SWISH}>" if panel else f"gemm_kernel<{'bf16' if es == 2 else 'f32'},NT,128x128>") +
+            f" FFN up-proj ({N}x{K})x({K}x{M}) +bias+swish+Z")
     common = {"kernel": name, "launch_us": t * 1e6, "arithmetic_intensity_flop_per_byte": intensity,
               "mfma_TFLOPs": flops / t / 1e12, "mfma_frac": flops / t / 1e12 / mfma_peak,
               "hbm_GBps_algorithmic": alg_bytes / t / 1e9,

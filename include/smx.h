@@ -139,7 +139,7 @@ int smx_gemm_plan_query(int layout, int dtype, const void* A, int64_t lda, int64
                         const smx_epilogue* epi, smx_gemm_plan* plan);
 
 /* Panel-resident GEMM for the SHORT reductions with WIDE outputs of an encoder layer (bf16, K = 256 or 512, M % 64 == 0):
- *   forward      C = alpha * D(act(A Wp + bias)) * row_mask, optionally saving the pre-activation Z   (epi: act, z, drop_*, row_mask, alpha; bias: packed, below)
+ *   forward      C = alpha * D(act(A Wp + bias)) * row_mask, optionally saving the pre-activation Z   (epi: act, z, drop_* [drop_cols % 64 == 0], row_mask, alpha; bias: packed, below)
  *   act-grad     C = alpha * D((A Wp) * act'(Z)) * row_mask                                       (epi: SMX_EPI_ACT_GRAD, z = input, act, drop_*, row_mask, alpha)
  * i.e. the FFN up-projection  nn.Linear(d_model, d_ffn) + activation + dropout  (Conformer.py:458-472, Branchformer.py:142-157)
  * and the first half of the autograd backward of the down-projection that follows it (dH = dY W2, then the activation / dropout

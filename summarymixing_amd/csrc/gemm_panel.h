@@ -35,6 +35,7 @@ struct PanelParams {
   int N, M;
   unsigned dthresh; float dscale; uint64_t seed; const uint64_t* epoch;
   int nt;                             // 2: stream C past the caches
+  int drop_cols;                      // dropout on the first drop_cols output columns only (a multiple of 64), mask index n * drop_cols + m
   const uint8_t* row_mask; float alpha;   // per-row keep mask [N] or null; output scale (folded into the dropout scale)
   int csplit;                         // workgroups per panel: workgroup (panel, s) takes the chunk rounds s, s + csplit, ... (small N: fill the chip)
   long long* dbg;                     // -DSMX_DIAG only: per-wave clock stamps (tools/panel_stamps.py)
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   // dropout: the seed / high-word part of the hash is a kernel constant (pair indices < 2^32), the scale is folded into the values
   const uint64_t dseed = p.dthresh ? epoch_seed(p.seed, p.epoch) : 0;
   const uint32_t hm0 = mix32((uint32_t)dseed) ^ (uint32_t)(dseed >> 32), t16 = p.dthresh >> 16;
-  const float dsc = (p.dthresh ? p.dscale : 1.f) * p.alpha, dinv = 1.f / dsc;   // (the output scale alpha rides in the same factor)
+  const float dsc_d = (p.dthresh ? p.dscale : 1.f) * p.alpha, dsc_n = p.alpha;   // (the output scale alpha rides in the same factor)
   const int nch = p.M >> 6;
 
 #pragma unroll 1
@@ -230,7 +231,9 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
 
     // ---- epilogue, 32 rows at a time through the wave's own scratch ----
     uint32_t c_off0 = (uint32_t)(((long)(n0 + (lane >> 3)) * p.ldc + ch * 64 + (lane & 7) * 8) * 2);
-    uint32_t d_p0 = ((uint32_t)(n0 + (lane >> 3)) * (uint32_t)p.M + (uint32_t)(ch * 64 + (lane & 7) * 8)) >> 1;   // dropout pair index (N * M < 2^30)
+    uint32_t d_p0 = ((uint32_t)(n0 + (lane >> 3)) * (uint32_t)p.drop_cols + (uint32_t)(ch * 64 + (lane & 7) * 8)) >> 1;   // dropout pair index (N * M < 2^30)
+    const bool dchunk = p.dthresh != 0 && ch * 64 < p.drop_cols;      // (uniform: this chunk's columns are dropped out)
+    const float dsc = dchunk ? dsc_d : dsc_n, dinv = 1.f / dsc;
     asm volatile("" : "+v"(c_off0), "+v"(d_p0));
     // (scratch addresses rebuilt here, per chunk: hoisted out of the chunk loop they are 12 registers live across the main loop)
     uint32_t s_wr = (uint32_t)(l31 * 128 + hi * 8), s_x = (uint32_t)(l31 & 7), s_rd = (uint32_t)((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4));
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= act_grad_c<ACT>(zf[e]) * dsc;
         }
-        if (p.dthresh) panel_dropout8(v, hm0, d_p0 + (uint32_t)(rstep / 2) * (uint32_t)p.M, t16);
+        if (dchunk) panel_dropout8(v, hm0, d_p0 + (uint32_t)(rstep / 2) * (uint32_t)p.drop_cols, t16);
         const pg_u32x4 cu = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         if (p.nt & 2) __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 2);
         else __builtin_amdgcn_raw_buffer_store_b128(cu, rc_rs, coff, 0, 0);

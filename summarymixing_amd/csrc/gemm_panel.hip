@@ -125,7 +125,7 @@ extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void*
   if (e.c0 || e.c0_mode != SMX_C0_NONE || e.res || e.colsum || e.out_mode != SMX_OUT_T ||
       (e.flags & ~SMX_EPI_ACT_GRAD) || e.io_flags || e.lnf2_y || e.bias ||
       !(e.act == SMX_ACT_NONE || e.act == SMX_ACT_SWISH || e.act == SMX_ACT_GELU || e.act == SMX_ACT_RELU) ||
-      (e.drop_cols != 0 && e.drop_cols != M))
+      e.drop_cols < 0 || e.drop_cols > M || e.drop_cols % 64 != 0)
     return fail(SMX_EUNSUPPORTED, "smx_gemm_panel: epilogue = activation (none / Swish / GELU / ReLU), saved Z, dropout, row mask, alpha, or SMX_EPI_ACT_GRAD (the bias belongs to smx_weight_pack); use smx_gemm");
   SMX_REQUIRE(!ag || e.z, "smx_gemm_panel: SMX_EPI_ACT_GRAD needs z (input)");
   SMX_REQUIRE(e.drop_p >= 0.f && e.drop_p < 1.f, "smx_gemm_panel: 0 <= drop_p < 1");
@@ -145,6 +145,7 @@ extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void*
   p.dscale = 1.f / (1.f - e.drop_p);
   p.seed = e.drop_seed; p.epoch = e.epoch;
   p.row_mask = e.row_mask; p.alpha = e.alpha;
+  p.drop_cols = e.drop_cols > 0 ? e.drop_cols : M;
   // store policy of smx_gemm: the output is streamed once it cannot survive in the Infinity Cache anyway
   p.nt = ((long)N * M * 2 >= (96L << 20)) ? 2 : 0;
   // one workgroup per CU: with fewer panels than ~3/4 of the CUs a panel's chunk rounds (M / 512 of them) are dealt to 2 or 4 workgroups

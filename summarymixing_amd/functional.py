@@ -365,8 +365,9 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
     z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
     # wparam = the fp32 parameter behind W: bias / activation / saved Z / dropout only -> the panel-resident kernel on its packed image
     if (wparam is not None and res is None and c0 is None and not out_f32 and ln_next is None and
-            drop_cols == 0 and out.dtype == x.dtype and panel_ok(x, M, K, act) and _vec_ok(out, z)):
-        ops.gemm_panel(x, wpacked(wparam, x.dtype, False, bias), out, N, M, K, ops.epilogue(act=act, z=z, drop=drop, row_mask=mask, alpha=alpha))
+            drop_cols % 64 == 0 and out.dtype == x.dtype and panel_ok(x, M, K, act) and _vec_ok(out, z)):
+        ops.gemm_panel(x, wpacked(wparam, x.dtype, False, bias), out, N, M, K,
+                       ops.epilogue(act=act, z=z, drop=drop, row_mask=mask, alpha=alpha, drop_cols=drop_cols))
         return out, z
     lnf = lnf2 = None
     if ln_next is not None:

@@ -179,3 +179,14 @@ def test_panel_row_mask_and_alpha(N, M, K):
     ops.gemm_panel(x, ops.weight_pack(Wt, transposed=True), o1, N, M, K, ops.epilogue(act=L.ACT_GELU, act_grad_z=z, row_mask=mask, alpha=0.5, drop=(0.15, 9)))
     ops.gemm(L.GEMM_NN, x, Wt, o2, N, M, K, ops.epilogue(act=L.ACT_GELU, act_grad_z=z, row_mask=mask, alpha=0.5, drop=(0.15, 9)))
     assert bool((o1[mask == 0] == 0).all()) and rel_err(o1, o2) < 1.2e-2
+
+
+def test_panel_dropout_on_leading_columns_only():
+    """drop_cols: dropout on the first drop_cols output columns, mask index n * drop_cols + m (the cell's local | summary projection)."""
+    N, M, K, dc = 2000, 512, 256, 256
+    x, W, b = _mk(N, M, K, seed=7)
+    o1, o2 = torch.empty(N, M, device="cuda", dtype=torch.bfloat16), torch.empty(N, M, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_panel(x, ops.weight_pack(W, bias=b), o1, N, M, K, ops.epilogue(act=L.ACT_SWISH, drop=(0.25, 77), drop_cols=dc))
+    ops.gemm(L.GEMM_NT, x, W, o2, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, drop=(0.25, 77), drop_cols=dc))
+    assert torch.equal(o1[:, :dc] == 0, o2[:, :dc] == 0) and 0.2 < float((o1[:, :dc] == 0).float().mean()) < 0.3
+    assert float((o1[:, dc:] == 0).float().mean()) < 0.01 and rel_err(o1, o2) < 1.2e-2
