@@ -39,7 +39,7 @@ _wa, _wb = torch.randn(8192, 8192, device=dev).bfloat16(), torch.randn(8192, 819
 for _ in range(60):                                            # ~0.1 s of matrix work: the chip at its loaded clocks before the first row
     torch.matmul(_wa, _wb)
 del _wa, _wb
-print(f"# hipBLASLt + unfused pass vs the fused smx_gemm launch, N = {N} frames, d = {d}, d_ffn = {f}, bf16, dropout 0.15 (us)")
+print(f"# hipBLASLt + unfused pass vs the fused launch of this library (rows 1-2: smx_gemm_panel from round 5 on; rows 3-4: smx_gemm), N = {N} frames, d = {d}, d_ffn = {f}, bf16, dropout 0.15 (us)")
 print(f"# {'kernel':66s} {'hipBLASLt':>9s} {'+ pass':>8s} {'= sum':>8s} {'fused':>8s} {'fused/sum':>9s}")
 
 # 1) FFN up-projection: z = x W1^T + b1 (saved), a = D(Swish(z))
@@ -55,7 +55,12 @@ def up_pass():
 
 p1 = T(up_pass)
 zb, ab = torch.empty(N, f, device=dev, dtype=torch.bfloat16), torch.empty(N, f, device=dev, dtype=torch.bfloat16)
-fu = T(lambda: ops.gemm(L.GEMM_NT, x, W1, ab, N, f, d, ops.epilogue(bias=b1, act=L.ACT_SWISH, z=zb, drop=(0.15, 7))))
+PANEL = ops.gemm_panel_ok(x, f, d) and os.environ.get("SMX_PANEL", "1") != "0"     # what functional.linear_fwd / linear_bwd launch for these two rows
+if PANEL:
+    wp1, wp2t = ops.weight_pack(W1, bias=b1), ops.weight_pack(W2, transposed=True)
+    fu = T(lambda: ops.gemm_panel(x, wp1, ab, N, f, d, ops.epilogue(act=L.ACT_SWISH, z=zb, drop=(0.15, 7))))
+else:
+    fu = T(lambda: ops.gemm(L.GEMM_NT, x, W1, ab, N, f, d, ops.epilogue(bias=b1, act=L.ACT_SWISH, z=zb, drop=(0.15, 7))))
 print(f"  {f'NT {d}->{f} + bias + Swish + Z + dropout':66s} {lin:9.1f} {p1:8.1f} {lin + p1:8.1f} {fu:8.1f} {fu / (lin + p1):9.2f}")
 
 # 2) act-grad dgrad: dz = D(g * Swish'(z)), g = dy W2
@@ -64,7 +69,10 @@ g = torch.matmul(dy, W2)
 dz = torch.empty_like(g)
 p2 = T(lambda: ops.act_mask_bwd(g, z, None, L.ACT_SWISH, 1.0, dz, None, None, 0, (0.15, 7)))
 dzb = torch.empty(N, f, device=dev, dtype=torch.bfloat16)
-fu = T(lambda: ops.gemm(L.GEMM_NN, dy, W2, dzb, N, f, d, ops.epilogue(act=L.ACT_SWISH, act_grad_z=z, drop=(0.15, 7))))
+if PANEL:
+    fu = T(lambda: ops.gemm_panel(dy, wp2t, dzb, N, f, d, ops.epilogue(act=L.ACT_SWISH, act_grad_z=z, drop=(0.15, 7))))
+else:
+    fu = T(lambda: ops.gemm(L.GEMM_NN, dy, W2, dzb, N, f, d, ops.epilogue(act=L.ACT_SWISH, act_grad_z=z, drop=(0.15, 7))))
 print(f"  {f'NN {d}->{f} + act-grad(z) + dropout':66s} {mm:9.1f} {p2:8.1f} {mm + p2:8.1f} {fu:8.1f} {fu / (mm + p2):9.2f}")
 
 # 3) FFN down-projection + residual (float32 stream) + dropout + LayerNorm of the new stream tensor
