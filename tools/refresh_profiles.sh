@@ -36,11 +36,17 @@ python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline 
 python bench.py --config c2a --batch 10 --frames 375 --grad-accum 4 --accum fused --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/${R}_bench_c2a_recipe_accum4_fused.json"
 python tools/blaslt_plus_epilogue.py > "$OUT/${R}_blaslt_plus_epilogue.txt" 2>/dev/null
 D=512 F=2048 python tools/blaslt_plus_epilogue.py > "$OUT/${R}_blaslt_plus_epilogue_d512.txt" 2>/dev/null
+# the panel-resident GEMM: isolated against the tiled kernel, and the steps with it off / on (same box)
+D=256 F=1024 python tools/panel_bench.py 2>/dev/null | grep -v amdgpu > "$OUT/${R}_panel_bench_d256.txt"
+D=512 F=2048 python tools/panel_bench.py 2>/dev/null | grep -v amdgpu > "$OUT/${R}_panel_bench_d512.txt"
+D=512 F=3072 python tools/panel_bench.py 2>/dev/null | grep -v amdgpu > "$OUT/${R}_panel_bench_d512_f3072.txt"
+bash tools/experiments/ab_panel.sh > "$OUT/${R}_ab_panel.txt" 2>&1
 STEPS=8 prof "${R}_wgrad_group_isolated.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 layer   (8 launches: the 8 weight gradients of a C2b layer, 64000 frames, isolated back to back; algorithmic 983 + 1.4 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 layer
 STEPS=8 prof "${R}_wgrad_group_one_1024x256.txt" "rocprofv3 --kernel-trace --stats -- python tools/one_wgroup.py 64000 one   (8 launches: dW(1024x256) alone over 64000 frames; algorithmic 164.9 MB per launch)" python "$ROOT/tools/one_wgroup.py" 64000 one
 # counter passes last and only on request (PMC=1): after them the box has been seen to lose its device for the next process
 if [[ "${PMC:-0}" == "1" ]]; then
   bash tools/pmc_traffic.sh > "$OUT/${R}_pmc_traffic.txt" 2>&1
   bash tools/pmc_wgroup.sh layer > "$OUT/${R}_pmc_wgrad_group.txt" 2>&1
+  bash tools/pmc_panel.sh > "$OUT/${R}_pmc_panel.txt" 2>&1
 fi
 ls -la "$OUT"
