@@ -132,8 +132,10 @@ extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void*
   SMX_REQUIRE(aligned16(A) && lda % 8 == 0 && lda >= K && aligned16(Wpacked) && aligned16(C) && ldc % 8 == 0 && ldc >= M &&
                   (!e.z || (aligned16(e.z) && e.ldz % 8 == 0 && e.ldz >= M)),
               "smx_gemm_panel: operands must be 16-byte aligned with leading dimensions %% 8 == 0");
-  SMX_REQUIRE(((long)N - 1) * lda * 2 + (long)K * 2 < (1L << 31) && (!e.z || (long)N * e.ldz * 2 < (1L << 31)),
-              "smx_gemm_panel: operand spans must stay below 2 GB");
+  // (32-bit buffer offsets: every operand - with ITS leading dimension, a column slice of a wider buffer counts in full - below 2 GB)
+  if (((long)N - 1) * lda * 2 + (long)K * 2 >= (1L << 31) || ((long)N - 1) * ldc * 2 + (long)M * 2 >= (1L << 31) ||
+      (e.z && ((long)N - 1) * e.ldz * 2 + (long)M * 2 >= (1L << 31)))
+    return fail(SMX_EUNSUPPORTED, "smx_gemm_panel: operand spans (rows x leading dimension) must stay below 2 GB; use smx_gemm");
   PanelParams p;
   memset(&p, 0, sizeof(p));
   p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda;

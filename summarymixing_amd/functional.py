@@ -127,9 +127,14 @@ _PANEL_MIN_ROWS = int(os.environ.get("SMX_PANEL_MIN_ROWS", "12288"))
 _PANEL_ACTS = (L.ACT_NONE, L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU)
 
 
+def _span_ok(*ts):
+    """Every 2-D view spans less than 2 GB WITH its leading dimension (the panel kernel addresses with 32-bit buffer offsets)."""
+    return all(t is None or ((t.shape[0] - 1) * t.stride(0) + t.shape[1]) * t.element_size() < (1 << 31) for t in ts)
+
+
 def panel_ok(x, M, K, act):
     return (_PANEL and x.dtype == torch.bfloat16 and act in _PANEL_ACTS and x.shape[0] >= _PANEL_MIN_ROWS and _vec_ok(x) and
-            ops.gemm_panel_ok(x, M, K))
+            _span_ok(x) and ops.gemm_panel_ok(x, M, K))
 
 
 _WGRAD_BIAS = True   # (round 4: the SMX_NO_WGRAD_BIAS A/B knob is gone)     # A/B knob: bias gradients as a by-product of the wgrad GEMM
@@ -365,7 +370,7 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
     z = torch.empty((N, M), dtype=x.dtype, device=x.device) if (save_z and act != L.ACT_NONE) else None
     # wparam = the fp32 parameter behind W: bias / activation / saved Z / dropout only -> the panel-resident kernel on its packed image
     if (wparam is not None and res is None and c0 is None and not out_f32 and ln_next is None and
-            drop_cols % 64 == 0 and out.dtype == x.dtype and panel_ok(x, M, K, act) and _vec_ok(out, z)):
+            drop_cols % 64 == 0 and out.dtype == x.dtype and panel_ok(x, M, K, act) and _vec_ok(out, z) and _span_ok(out, z)):
         ops.gemm_panel(x, wpacked(wparam, x.dtype, False, bias), out, N, M, K,
                        ops.epilogue(act=act, z=z, drop=drop, row_mask=mask, alpha=alpha, drop_cols=drop_cols))
         return out, z
@@ -475,7 +480,8 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
             assert res_grad is None
             z_up, act_up, mask_up, alpha_up, drop_up, gb_up = up
             # wparam = the fp32 parameter behind W (M, K): the act-grad dgrad on the panel-resident kernel, W packed transposed
-            if (wparam is not None and gb_up is None and dx.dtype == dz.dtype and panel_ok(dz, K, M, act_up) and _vec_ok(dx, z_up)):
+            if (wparam is not None and gb_up is None and dx.dtype == dz.dtype and panel_ok(dz, K, M, act_up) and _vec_ok(dx, z_up) and
+                    _span_ok(dx, z_up)):
                 ops.gemm_panel(dz, wpacked(wparam, dz.dtype, True), dx, N, K, M,
                                ops.epilogue(act=act_up, act_grad_z=z_up, drop=drop_up, row_mask=mask_up, alpha=alpha_up))
                 return dx, dz
@@ -483,7 +489,8 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
         else:
             assert dx_drop is None or res_grad is None
             # plain (or dropout-backward) dgrad with a short reduction and a wide output: the panel-resident kernel, W packed transposed
-            if wparam is not None and res_grad is None and dx.dtype == dz.dtype and panel_ok(dz, K, M, L.ACT_NONE) and _vec_ok(dx):
+            if (wparam is not None and res_grad is None and dx.dtype == dz.dtype and panel_ok(dz, K, M, L.ACT_NONE) and _vec_ok(dx) and
+                    _span_ok(dx)):
                 ops.gemm_panel(dz, wpacked(wparam, dz.dtype, True), dx, N, K, M, ops.epilogue(drop=dx_drop))
                 return dx, dz
             e = ops.epilogue(res=res_grad, drop=dx_drop)
