@@ -295,19 +295,11 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
 int launch_panel_fwd(const PanelParams& p, int K, int act, hipStream_t s);
 int launch_panel_actgrad(const PanelParams& p, int K, int act, hipStream_t s);
 
-#ifdef SMX_PANEL_W32
-template <int K, int MODE, int ACT> __global__ void gemm_panel_w32_kernel(PanelParams p);   // tools/experiments/panel_w32 (experiment)
-#define SMX_PANEL_KERNEL gemm_panel_w32_kernel
-#define SMX_PANEL_THREADS 768
-#else
-#define SMX_PANEL_KERNEL gemm_panel_kernel
-#define SMX_PANEL_THREADS 512
-#endif
 template <int MODE>
 static int launch_panel_mode(const PanelParams& p, int K, int act, hipStream_t s) {
-  const dim3 grid(((p.N + 127) / 128) * p.csplit), block(SMX_PANEL_THREADS);
+  const dim3 grid(((p.N + 127) / 128) * p.csplit), block(512);
 #define SMX_PANEL_CASE(KK, AA) \
-  if (K == KK && act == AA) { hipLaunchKernelGGL((SMX_PANEL_KERNEL<KK, MODE, AA>), grid, block, 0, s, p); return check_launch("smx_gemm_panel"); }
+  if (K == KK && act == AA) { hipLaunchKernelGGL((gemm_panel_kernel<KK, MODE, AA>), grid, block, 0, s, p); return check_launch("smx_gemm_panel"); }
   SMX_PANEL_CASE(256, SMX_ACT_NONE) SMX_PANEL_CASE(256, SMX_ACT_SWISH) SMX_PANEL_CASE(256, SMX_ACT_GELU) SMX_PANEL_CASE(256, SMX_ACT_RELU)
   SMX_PANEL_CASE(512, SMX_ACT_NONE) SMX_PANEL_CASE(512, SMX_ACT_SWISH) SMX_PANEL_CASE(512, SMX_ACT_GELU) SMX_PANEL_CASE(512, SMX_ACT_RELU)
 #undef SMX_PANEL_CASE

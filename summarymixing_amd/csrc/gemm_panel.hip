@@ -1,9 +1,6 @@
 // gemm_panel.hip — C-ABI of the panel-resident GEMM (gemm_panel.h): smx_weight_pack, smx_gemm_panel, the forward instantiations.
 // (The act-grad instantiations live in gemm_panel_bwd.hip: a translation unit of its own, compiled next to this one.)
 #include "gemm_panel.h"
-#ifdef SMX_PANEL_W32
-#include "../../tools/experiments/panel_w32/gemm_panel_w32.h"
-#endif
 
 namespace smx {
 

@@ -1,9 +1,6 @@
 // gemm_panel_bwd.hip — the act-grad instantiations of the panel-resident GEMM (gemm_panel.h): dZ = D(dY W * act'(Z)).
 // A translation unit of its own so that it compiles next to gemm_panel.hip.
 #include "gemm_panel.h"
-#ifdef SMX_PANEL_W32
-#include "../../tools/experiments/panel_w32/gemm_panel_w32.h"
-#endif
 
 namespace smx {
 
