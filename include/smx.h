@@ -485,6 +485,10 @@ int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, const int32
  * itself a captured kernel).  NULL = the plain by-value behaviour.  The library holds no process-global state besides
  * the read-once smx_config and the per-thread error string. */
 int smx_step_counter_add(uint64_t* dev_counter, uint64_t inc, void* stream);
+/* id[0] = the id of the hipGraph capture `stream` is recording into (hipStreamGetCaptureInfo), 0 when it is not capturing.  Host
+ * bookkeeping only (no launch): the host side stamps cached packed weight images (smx_weight_pack) with it, so that EVERY capture
+ * contains its own pack launches and the first eager call after a capture re-packs (round-5 advisor finding). */
+int smx_stream_capture_id(void* stream, uint64_t* id);
 /* out[0] += sum(x^2) — global grad-norm for clipping (zero out[0] first).  Fixed summation order (per-block partials in
  * `workspace`, smx_sumsq_workspace() bytes, folded by one block; no atomics): data-parallel ranks holding the same
  * all-reduced gradients get bit-identical norms, clip factors and weights. */

@@ -166,6 +166,7 @@ SIGNATURES = {
     "smx_get_config": (c_i, [c_vp]),
     "smx_gemm_ln_tile_rows": (c_i, []),
     "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
+    "smx_stream_capture_id": (c_i, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "smx_sumsq_workspace": (c_sz, []),
     "smx_sumsq": (c_i, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "smx_clip_factor": (c_i, [c_vp, c_f, c_f, c_vp, c_vp]),

@@ -55,6 +55,16 @@ extern "C" int smx_step_counter_add(uint64_t* dev_counter, uint64_t inc, void* s
   return smx::check_launch("smx_step_counter_add");
 }
 
+extern "C" int smx_stream_capture_id(void* stream, uint64_t* id) {
+  SMX_REQUIRE(id, "smx_stream_capture_id: null pointer");
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long cid = 0;
+  const hipError_t err = hipStreamGetCaptureInfo(reinterpret_cast<hipStream_t>(stream), &st, &cid);
+  if (err != hipSuccess) return smx::fail(SMX_ELAUNCH, "smx_stream_capture_id: %s", hipGetErrorString(err));
+  *id = st == hipStreamCaptureStatusActive ? (uint64_t)cid : 0;
+  return SMX_OK;
+}
+
 extern "C" int smx_get_config(smx_config* out) {
   SMX_REQUIRE(out, "smx_get_config: null pointer");
   *out = smx::cfg();

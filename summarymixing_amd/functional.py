@@ -33,8 +33,12 @@ _shadow = {}   # id(param) -> (weakref(param), version | "managed", data_ptr, sh
 
 
 def register_shadow(param, shadow):
-    """Trainer hook: `shadow` (bf16 view of a flat buffer) is kept up to date by smx_adamw_step."""
+    """Trainer hook: `shadow` (bf16 view of a flat buffer) is kept up to date by smx_adamw_step.  A parameter that changes hands
+    (a second FlatAdamW over the same module) gets new shadow / flat buffers: its packed images point at the old ones - drop them."""
     _shadow[id(param)] = (weakref.ref(param), "managed", None, shadow)
+    for key in [k for k in _packed if k[0] == id(param)]:
+        del _packed[key]
+    weights_changed()
 
 
 def wcast(param, dtype):
@@ -56,37 +60,54 @@ def wcast(param, dtype):
 # ---- packed weight images of the panel-resident GEMM (ops.gemm_panel / smx_weight_pack): per (parameter, orientation), re-packed
 # when the weight changed.  Unmanaged parameters: torch's version counter (+ the bias's).  Trainer-managed bf16 shadows are rewritten
 # behind torch's back by smx_adamw_step, so the trainer bumps an epoch (weights_changed) after every update / checkpoint load.
-# The image is re-packed INTO THE SAME BUFFER: its address stays valid for captured hipGraphs (whose captured step contains the
-# pack launches - the epoch differs at capture time because the step before ended with an optimizer update).
+# The image is re-packed INTO THE SAME BUFFER: its address stays valid for captured hipGraphs.
+# hipGraph rules (round-5 advisor findings): a managed image's stamp carries the id of the capture it was packed in (0 = eager), so
+#  * EVERY capture contains its own pack launches, whatever the epoch was when it began (a second capture, or one taken right after
+#    a forward-only warm-up, used to contain none and its replays trained against frozen images);
+#  * the first eager use after a capture re-packs.  Replays advance the shadows without running this Python code: whoever replays a
+#    graph that contains an optimizer update calls weights_changed() before the next EAGER forward (FlatAdamW.replay does).
 _WEPOCH = [0]
-_packed = {}   # (id(param), transposed) -> (weakref(param), stamp, packed image)
+# (id(param), transposed) -> (weakref(param), stamp, packed image, W (compute-dtype view), bias tensor | None, M, K, transposed)
+_packed = {}
 
 
 def weights_changed():
-    """Trainer hook: the managed bf16 shadows / fp32 biases were rewritten in place (optimizer step, checkpoint load)."""
+    """Trainer hook: the managed bf16 shadows / fp32 biases were rewritten in place (optimizer step, checkpoint load, graph replay)."""
     _WEPOCH[0] += 1
 
 
-_pack_table = {"sig": None, "dev": None, "blocks": 0}   # device job table of every trainer-managed packed image
+# device job tables of the trainer-managed packed images, per device and per signature.  A table whose launch was captured stays
+# alive for the life of the process (the graph holds its raw pointer); the others are dropped when the set of images changes.
+_pack_tables = {}   # (device, signature) -> [device table, blocks, captured?]
 
 
-def _repack_managed():
-    """ONE launch re-packs every trainer-managed image (they all went stale together: the optimizer rewrote every shadow)."""
-    ents = [v for v in _packed.values() if v[1][0] == "m" and v[0]() is not None]
+def _purge_packed():
+    for k in [k for k, v in _packed.items() if v[0]() is None]:
+        del _packed[k]
+
+
+def _repack_managed(device, stamp):
+    """ONE launch re-packs every trainer-managed image of `device` (they all went stale together: the optimizer rewrote every shadow)."""
+    _purge_packed()
+    keys = [k for k, v in _packed.items() if v[1][0] == "m" and v[2].device == device]
+    ents = [_packed[k] for k in keys]
     sig = tuple((e[3].data_ptr(), e[3].stride(0), 0 if e[4] is None else e[4].data_ptr(), e[2].data_ptr(), e[5], e[6], e[7]) for e in ents)
-    if _pack_table["sig"] != sig:
-        if torch.cuda.is_current_stream_capturing():
+    capturing = torch.cuda.is_current_stream_capturing()
+    tab = _pack_tables.get((device, sig))
+    if tab is None:
+        if capturing:
             return False                                 # (no host-to-device table upload inside a capture: the caller packs singly)
+        for k in [k for k, t in _pack_tables.items() if k[0] == device and not t[2]]:
+            del _pack_tables[k]
         lib, arr, nb = L.lib(), (L.PackJob * len(ents))(), 0
         for j, (W_, ldw, bias_, out_, M, K, tr) in zip(arr, sig):
             j.W, j.ldw, j.bias, j.packed, j.M, j.K, j.transposed, j.block_start = W_, ldw, bias_ or None, out_, M, K, tr, nb
             nb += lib.smx_weight_pack_job_blocks(M, K)
-        _pack_table.update(sig=sig, dev=torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(ents[0][2].device), blocks=nb)
-    ops.weight_pack_jobs(_pack_table["dev"], len(ents), _pack_table["blocks"], sum(e[5] * e[6] for e in ents))
-    stamp = ("m", _WEPOCH[0])
-    for k, v in list(_packed.items()):
-        if v[1][0] == "m" and v[0]() is not None:
-            _packed[k] = (v[0], stamp) + v[2:]
+        tab = _pack_tables[(device, sig)] = [torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), nb, False]
+    tab[2] = tab[2] or capturing
+    ops.weight_pack_jobs(tab[0], len(ents), tab[1], sum(e[5] * e[6] for e in ents))
+    for k, v in zip(keys, ents):
+        _packed[k] = (v[0], stamp) + v[2:]
     return True
 
 
@@ -97,21 +118,26 @@ def wpacked(param, dtype, transposed=False, bias=None):
         W = W.view(W.shape[0], -1)               # (a Conv1d(k = 1) weight (out, in, 1) seen as a Linear's)
     ent = _shadow.get(id(param))
     managed = ent is not None and ent[0]() is param and ent[1] == "managed"
+    bt = None if bias is None else bias.detach()
     if managed:
-        stamp = ("m", _WEPOCH[0])
+        stamp = ("m", _WEPOCH[0], ops.capture_id())
     else:
         stamp = ("v", param._version, param.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()))
     key = (id(param), transposed)
     c = _packed.get(key)
-    if c is not None and c[0]() is param and c[1] == stamp:
+    if c is not None and c[0]() is not param:
+        del _packed[key]                           # (a dead parameter's id re-used)
+        c = None
+    # the image was packed FROM these tensors: another shadow view (a new optimizer), another bias or none (tied weights) -> pack anew
+    same_src = c is not None and c[3].data_ptr() == W.data_ptr() and c[3].stride() == W.stride() and \
+        (None if c[4] is None else c[4].data_ptr()) == (None if bt is None else bt.data_ptr())
+    if same_src and c[1] == stamp:
         return c[2]
-    if c is not None and c[0]() is param and managed and c[1][0] == "m" and _repack_managed():
+    if same_src and managed and c[1][0] == "m" and _repack_managed(c[2].device, stamp):
         return c[2]                                # (stale with every other managed image: one grouped launch re-packed them all)
-    if len(_packed) > 4096:
-        for k in [k for k, v in _packed.items() if v[0]() is None]:
-            del _packed[k]
-    out = c[2] if (c is not None and c[0]() is param) else None
-    bt = None if bias is None else bias.detach()
+    if len(_packed) > 256:
+        _purge_packed()
+    out = c[2] if c is not None else None          # (same parameter and orientation = same shape: the buffer is re-used)
     out = ops.weight_pack(W, transposed, bt, out)
     M, K = (W.shape[1], W.shape[0]) if transposed else (W.shape[0], W.shape[1])
     _packed[key] = (weakref.ref(param), stamp, out, W, bt, M, K, int(transposed))

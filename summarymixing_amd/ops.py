@@ -689,6 +689,15 @@ def step_counter_add(counter, inc=1):
     L.check(L.lib().smx_step_counter_add(_p(counter), inc, _stream()), "smx_step_counter_add")
 
 
+def capture_id():
+    """Id of the hipGraph capture the current stream records into; 0 when it is not capturing (smx_stream_capture_id)."""
+    if not torch.cuda.is_current_stream_capturing():
+        return 0
+    cid = ctypes.c_uint64(0)
+    L.check(L.lib().smx_stream_capture_id(_stream(), ctypes.byref(cid)), "smx_stream_capture_id")
+    return int(cid.value) or -1
+
+
 def sumsq(x, out):
     ws = _workspace(L.lib().smx_sumsq_workspace(), x.device, slot=6)
     L.check(L.lib().smx_sumsq(_p(x), x.numel(), _p(out), _p(ws), _stream()), "smx_sumsq")

@@ -371,6 +371,12 @@ class FlatAdamW:
             self.reduce_bucket_async(0, self.total)
             self._finish_reduce()
 
+    def replay(self, graph):
+        """Replay a captured step that contains this optimizer's update.  The replay rewrites the bf16 shadows without running any
+        Python: the packed weight images of the panel GEMM (functional.wpacked) must be re-packed by the next EAGER forward."""
+        graph.replay()
+        F.weights_changed()
+
     def update_only(self):
         """The part of step() behind the collective (capturable: device step counter, clip, AdamW, shadows)."""
         assert self._dev_step is not None, "call use_device_step_counter(True) before capturing"

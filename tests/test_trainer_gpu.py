@@ -418,3 +418,112 @@ def test_packed_weight_images_follow_the_optimizer():
     # replays whose graph lacked the pack launches would run steps 4-7 on the images of step 3: far outside this bar at lr 3e-2
     # (the tiled path sets the bar: graph replay against eager steps of the same kernels)
     assert float((graphed - eager).abs().max()) <= max(1e-6, 2.0 * float((tiled_graphed - tiled_eager).abs().max()))
+
+
+def _packed_images_current(enc, dtype):
+    """Every cached packed image of `enc`'s parameters equals a fresh pack of the CURRENT bf16 shadow and bias."""
+    from summarymixing_amd import functional as F, ops
+    n = 0
+    for (pid, tr), ent in list(F._packed.items()):
+        prm = ent[0]()
+        if prm is None or not any(prm is q for q in enc.parameters()):
+            continue
+        W = F.wcast(prm, dtype)
+        W = W.view(W.shape[0], -1) if W.dim() != 2 else W
+        assert torch.equal(ent[2], ops.weight_pack(W, bool(tr), ent[4])), "stale packed image"
+        n += 1
+    return n
+
+
+def _small_panel_encoder(d=256):
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(5)
+    return ConformerEncoder(1, d, 4 * d, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                            local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast").cuda()
+
+
+def test_packed_images_follow_a_second_optimizer_over_the_same_module():
+    """Round-5 advisor finding: a second FlatAdamW over one module installs NEW shadow / flat buffers; the cached images must be
+    packed from those, not from the first optimizer's frozen buffers."""
+    from summarymixing_amd import functional as F
+    from summarymixing_amd.trainer import FlatAdamW
+    dtype, d = torch.bfloat16, 256
+    old_rows, F._PANEL_MIN_ROWS = F._PANEL_MIN_ROWS, 128
+    try:
+        enc = _small_panel_encoder(d)
+        x = torch.randn(4, 200, d, device="cuda").to(dtype)
+        r = torch.randn(4, 200, d, device="cuda").to(dtype)
+
+        def step(opt):
+            opt.zero_grad()
+            (enc(x)[0].float() * r.float()).sum().backward()
+            opt.step()
+
+        opt1 = FlatAdamW(enc, lr=3e-2, compute_dtype=dtype)
+        step(opt1); step(opt1)
+        opt2 = FlatAdamW(enc, lr=3e-2, compute_dtype=dtype)
+        step(opt2); step(opt2)
+        with torch.no_grad():
+            enc(x)
+        assert _packed_images_current(enc, dtype) >= 3
+        for ent in F._packed.values():                 # nothing keeps the first optimizer's shadow alive through the cache
+            assert ent[0]() is None or ent[3].untyped_storage().data_ptr() != opt1.shadow.untyped_storage().data_ptr()
+    finally:
+        F._PANEL_MIN_ROWS = old_rows
+
+
+def test_packed_images_in_graphs_captured_after_a_forward_only_warm_up_and_captured_twice():
+    """Round-5 advisor finding: the pack launches must be INSIDE every capture (also one whose epoch stamp happened to be current
+    when it began, and a second capture of the same step), and the first eager forward after replays must re-pack."""
+    from summarymixing_amd import functional as F
+    from summarymixing_amd.trainer import FlatAdamW
+    dtype, d = torch.bfloat16, 256
+    old_rows, F._PANEL_MIN_ROWS = F._PANEL_MIN_ROWS, 128
+    try:
+        def run(graphs):
+            enc = _small_panel_encoder(d)
+            opt = FlatAdamW(enc, lr=3e-2, compute_dtype=dtype)
+            opt.use_device_step_counter(True)
+            x = torch.randn(4, 200, d, device="cuda").to(dtype)
+            r = torch.randn(4, 200, d, device="cuda").to(dtype)
+
+            def step():
+                opt.zero_grad()
+                (enc(x)[0].float() * r.float()).sum().backward()
+                opt.step()
+
+            step()
+            if not graphs:
+                for _ in range(6):
+                    step()
+            else:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    with torch.no_grad():
+                        enc(x)                         # forward-only warm-up: every forward image carries the CURRENT epoch now
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, stream=s):
+                        step()
+                    for _ in range(2):
+                        opt.replay(g1)
+                    with torch.no_grad():
+                        enc(x)                         # eager forward after replays: re-packs
+                    assert _packed_images_current(enc, dtype) >= 3
+                    g2 = torch.cuda.CUDAGraph()        # a second capture of the same step
+                    with torch.cuda.graph(g2, stream=s):
+                        step()
+                    for _ in range(4):
+                        opt.replay(g2)
+                torch.cuda.current_stream().wait_stream(s)
+            opt.use_device_step_counter(False)
+            torch.cuda.synchronize()
+            return torch.cat([p.detach().float().flatten() for p in enc.parameters()])
+
+        eager, graphed = run(False), run(True)
+        F._PANEL = False
+        tiled_eager, tiled_graphed = run(False), run(True)
+    finally:
+        F._PANEL, F._PANEL_MIN_ROWS = True, old_rows
+    # replays of a graph without pack launches run on frozen images: far outside this bar at lr 3e-2
+    assert float((graphed - eager).abs().max()) <= max(1e-6, 2.0 * float((tiled_graphed - tiled_eager).abs().max()))

@@ -163,3 +163,95 @@ def test_c2b_twelve_layers_bf16_forward_error_report():
     report("c2b_12layers_forward_33000frames", e)
     assert e["fp32_maxrel"] <= 1e-3 and e["fp32_rmsrel"] <= 1e-3, e
     assert e["bf16_maxrel"] <= 1e-2 and e["bf16_rmsrel"] <= 1e-2, e          # north_star bar at the benchmarked depth (2.1e-2 with a bf16 stream)
+
+
+def test_c4_eighteen_layers_bf16_forward_error_report():
+    """BASELINE config 4 at its REAL depth and width (…CommonVoice…branchformer_summarymixing.yaml:79-94: 18 layers, d = 512, nhead 1, full
+    mode, csgu 3072, GELU) on 8 250 ragged frames against the fp64 oracle, forward.  The error of the k-layer prefix stacks is recorded
+    too, so that a failing bar says WHERE the precision goes."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd.lobes.models.transformer.Branchformer import BranchformerEncoder
+    d, B, T, L = 512, 33, 250, 18
+    enc = BranchformerEncoder(L, d, 1, kernel_size=31, activation=torch.nn.GELU, dropout=0.0, attention_type="SummaryMixing",
+                              csgu_linear_units=3072, local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d],
+                              summary_out_dim=d, mode="SummaryMixing")
+    _init(enc, 13)
+    x, pad, _ = _batch(B, T, d, 25)
+    sd = {k: v.double() for k, v in enc.state_dict().items()}
+    with torch.no_grad():
+        refs, h = [], x.double()
+        for i in range(L):                                  # the oracle's layer loop (Branchformer.py:447-491), prefixes kept
+            h = O.branchformer_layer(h, sd, f"layers.{i}.", "gelu", "SummaryMixing", d, None, pad)
+            refs.append(h)
+        ref = O.layer_norm(h, sd, "norm.norm.weight", "norm.norm.bias", eps=1e-6)
+        assert float((ref - O.branchformer_encoder(x.double(), sd, "", "gelu", "SummaryMixing", d, None, pad)).abs().max()) == 0.0
+        enc = enc.cuda().eval()
+        y32, _ = enc(x.cuda(), src_key_padding_mask=pad.cuda())
+        y16, _ = enc(x.cuda().bfloat16(), src_key_padding_mask=pad.cuda())
+        # the error as it accumulates: the k-layer prefix encoders (same weights, the final LayerNorm behind layer k) against the
+        # oracle's own prefix - the full stack keeps its float32 stream across layers, so prefixes are run as stacks, not layer by layer
+        per_depth = {}
+        full_sd = enc.state_dict()
+        for k in (1, 3, 6, 9, 12, 15):
+            sub = BranchformerEncoder(k, d, 1, kernel_size=31, activation=torch.nn.GELU, dropout=0.0, attention_type="SummaryMixing",
+                                      csgu_linear_units=3072, local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d],
+                                      summary_out_dim=d, mode="SummaryMixing").cuda().eval()
+            sub.load_state_dict({n: v for n, v in full_sd.items() if not n.startswith("layers.") or int(n.split(".")[1]) < k}, strict=True)
+            rk = O.layer_norm(refs[k - 1], sd, "norm.norm.weight", "norm.norm.bias", eps=1e-6)
+            yk, _ = sub(x.cuda().bfloat16(), src_key_padding_mask=pad.cuda())
+            per_depth[k] = (round(rel_err(yk, rk), 5), round(rms_rel(yk, rk), 5))
+    e = {"fp32_maxrel": rel_err(y32, ref), "fp32_rmsrel": rms_rel(y32, ref), "bf16_maxrel": rel_err(y16, ref),
+         "bf16_rmsrel": rms_rel(y16, ref), "bf16_maxrel_rmsrel_of_the_k_layer_prefix": per_depth}
+    report("c4_18layers_d512_csgu3072_forward_8250frames", e)
+    assert e["fp32_maxrel"] <= 1e-3 and e["fp32_rmsrel"] <= 1e-3, e
+    assert e["bf16_maxrel"] <= 1e-2 and e["bf16_rmsrel"] <= 1e-2, e          # north_star bar at config 4's depth and width
+
+
+@pytest.mark.parametrize("mode", ["SummaryMixing-fast", "SummaryMixing"])
+def test_c5_long_utterance_cell_vs_oracle(mode):
+    """BASELINE config 5's length through the cell: ONE utterance of T = 30 000 frames at d = 512 (plus a ragged second one, so that the
+    padding mask is live) against the fp64 oracle - the O(T) pool at a length 12 x the reference's positional-encoding limit
+    (Transformer.py:306,335).  north_star bars: fp32 1e-3, bf16 1e-2 (max-rel and RMS-rel)."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd.nnet.summary_mixing import SummaryMixing
+    d, B, T = 512, 2, 30000
+    torch.manual_seed(31)
+    cell = SummaryMixing(enc_dim=d, nhead=1, local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], summary_out_dim=d,
+                         activation=torch.nn.GELU, global_dropout=0.0, mode=mode)
+    _init(cell, 14)
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(B, T, d, generator=g)
+    pad = torch.arange(T)[None] < torch.tensor([T, 17321])[:, None]
+    sd = {k: v.double() for k, v in cell.state_dict().items()}
+    with torch.no_grad():
+        ref = O.summary_mixing(x.double(), sd, "", mode, "gelu", d, None, pad)
+        cell = cell.cuda().eval()
+        y32 = cell(x.cuda(), src_padding_mask=pad.cuda())
+        y16 = cell(x.cuda().bfloat16(), src_padding_mask=pad.cuda())
+    valid = pad[:, :, None].expand_as(ref)                   # (padded frames of the fast / full modes are defined too: compared as well)
+    e = {"fp32_maxrel": rel_err(y32, ref), "fp32_rmsrel": rms_rel(y32, ref), "bf16_maxrel": rel_err(y16, ref),
+         "bf16_rmsrel": rms_rel(y16, ref), "bf16_maxrel_valid": rel_err(y16.cpu().float()[valid], ref[valid])}
+    report(f"c5_cell_{mode}_d512_T30000", e)
+    assert e["fp32_maxrel"] <= 1e-3 and e["fp32_rmsrel"] <= 1e-3, e
+    assert e["bf16_maxrel"] <= 1e-2 and e["bf16_rmsrel"] <= 1e-2, e
+
+
+def test_c5_long_utterance_conformer_layer_vs_oracle():
+    """One Conformer-SummaryMixing layer (LS-yaml widths d = 512, d_ffn = 2048, k = 31) on one utterance of T = 30 000 frames + a ragged
+    second one against the fp64 oracle: depthwise conv, LayerNorms and the cell at config 5's length (Conformer.py:479-537)."""
+    from oracle import smx_oracle as O
+    d, f, B, T = 512, 2048, 2, 30000
+    enc = _conformer(1, d, f)
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, T, d, generator=g)
+    pad = torch.arange(T)[None] < torch.tensor([T, 21007])[:, None]
+    sd = {k: v.double() for k, v in enc.state_dict().items()}
+    with torch.no_grad():
+        ref = O.conformer_encoder(x.double(), sd, "", "swish", "SummaryMixing-fast", d, None, pad)
+        enc = enc.cuda().eval()
+        y32, _ = enc(x.cuda(), src_key_padding_mask=pad.cuda())
+        y16, _ = enc(x.cuda().bfloat16(), src_key_padding_mask=pad.cuda())
+    e = {"fp32_maxrel": rel_err(y32, ref), "fp32_rmsrel": rms_rel(y32, ref), "bf16_maxrel": rel_err(y16, ref), "bf16_rmsrel": rms_rel(y16, ref)}
+    report("c5_conformer_layer_d512_f2048_T30000", e)
+    assert e["fp32_maxrel"] <= 1e-3 and e["fp32_rmsrel"] <= 1e-3, e
+    assert e["bf16_maxrel"] <= 1e-2 and e["bf16_rmsrel"] <= 1e-2, e
