@@ -53,6 +53,8 @@ typedef struct smx_config {
   int32_t diag_build;       /* 1 when the library was compiled with -DSMX_DIAG                               */
   int32_t t256;             /* SMX_T256: 256 x 256 GEMM tile (one workgroup per CU, software-pipelined K loop)
                                0 off, 1 for K >= 2048 (1), 2 for every eligible shape (tests)                  */
+  int32_t panel_rows;       /* SMX_PANEL_ROWS: rows per panel of smx_gemm_panel (128 / 64 / 32); 0 = by frame count  */
+  int32_t pad_;
 } smx_config;
 int smx_get_config(smx_config* out);
 /* rows per tile of the LayerNorm-fused GEMMs (SMX_EPI_LN_BWD writes ceil(N / rows) partial row pairs into ln_partial) */
@@ -255,6 +257,19 @@ int smx_masked_mean_fwd(int dtype, const void* S, int64_t lds, const uint8_t* ma
  * smx_dropout indexing; summary_mixing.py:237-239). */
 int smx_masked_mean_bwd(int dtype, const float* g, const float* inv_count, void* dS, int64_t ldds, int B, int T,
                         int D, float drop_p, uint64_t drop_seed, const uint64_t* epoch, void* stream);
+
+/* Small batches (round 6): the masked mean over time AND its broadcast in ONE launch, fixed summation order (no atomics), for
+ * smx_pool_bcast_ok(B, T, D) shapes (B * T <= 16 384 frames, T <= 4096):
+ *   sum[b,:] = sum_t S[b,t,:] * mask_in[b,t];  mean_out[b,:] (optional) = sum (* 1 / count[b] when scale_by_count);
+ *   inv_out[b] (optional) = 1 / count[b];
+ *   dS[b,t,:] (optional) = D( value[b,:] * (inv_in ? inv_in[b] : 1) ) [* act'(Z[b,t,:]) * mask_out[b,t] when Z / mask_out are given]
+ * i.e. smx_masked_mean_fwd followed by smx_masked_mean_bwd (forward `repeat` + the merge input's dropout, summary_mixing.py:218-222,
+ * 237-239,264-267) or by smx_masked_mean_bwd_act (the backward of the same lines), without the workspace round trip and two of
+ * the three launches.  Dropout (drop_p > 0) and the act / mask backward exclude each other. */
+int smx_pool_bcast_ok(int B, int T, int D);
+int smx_pool_bcast(int dtype, const void* S, int64_t lds, const uint8_t* mask_in, float* mean_out, const float* inv_in, float* inv_out,
+                   void* dS, int64_t ldds, int B, int T, int D, int scale_by_count, float drop_p, uint64_t drop_seed,
+                   const uint64_t* epoch, const void* Z, int64_t ldz, const uint8_t* mask_out, int act, void* stream);
 
 /* Same broadcast with the activation / mask backward of the projection that produced the summary columns fused in:
  *   dS[b,t,:] = g[b,:] * inv_count[b] * act'(Z[b,t,:]) * row_mask[b,t]      (Z and/or row_mask given)

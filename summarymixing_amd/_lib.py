@@ -107,6 +107,9 @@ SIGNATURES = {
     "smx_masked_mean_workspace": (c_sz, [c_i, c_i, c_i]),
     "smx_masked_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp]),
     "smx_masked_mean_bwd": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_f, ctypes.c_uint64, c_vp, c_vp]),
+    "smx_pool_bcast_ok": (c_i, [c_i, c_i, c_i]),
+    "smx_pool_bcast": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_i, c_f, ctypes.c_uint64, c_vp, c_vp, c_i64,
+                             c_vp, c_i, c_vp]),
     "smx_masked_mean_bwd_act": (c_i, [c_i, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "smx_chunk_mean_workspace": (c_sz, [c_i, c_i, c_i, c_i]),
     "smx_chunk_mean_fwd": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp]),
@@ -199,7 +202,7 @@ class Config(ctypes.Structure):
     """smx_config of include/smx.h: the knobs the library read from the environment once."""
     _fields_ = [("ln_tile_rows", ctypes.c_int32),
                 ("gemm_ablate", ctypes.c_int32), ("wgroup_ablate", ctypes.c_int32), ("dwroll_ablate", ctypes.c_int32),
-                ("diag_build", ctypes.c_int32), ("t256", ctypes.c_int32)]
+                ("diag_build", ctypes.c_int32), ("t256", ctypes.c_int32), ("panel_rows", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 def get_config():

@@ -10,9 +10,15 @@ namespace smx {
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
 // tuning constants of the register-staged tiles (swept in rounds 1-4)
-constexpr int kOcc = 3;        // workgroups per CU of the 128 x 128 / 64 x 64 tiles (168-register budget)
+#ifndef SMX_KOCC
+#define SMX_KOCC 3
+#endif
+#ifndef SMX_NS_KC
+#define SMX_NS_KC 1
+#endif
+constexpr int kOcc = SMX_KOCC;        // workgroups per CU of the 128 x 128 / 64 x 64 tiles (168-register budget)
 constexpr int kNsSmall = 4;    // register stages in flight of the 64 x 64 tile (latency-bound small grids: see the main loop)
-constexpr int kNsKc = 1;       // ... of the 128 x 128 tile
+constexpr int kNsKc = SMX_NS_KC;       // ... of the 128 x 128 tile
 
 // wgrad (TN) runs exactly two workgroups per CU (wgrad_splits), so it takes the 256-register budget: no spills with
 // the bias-gradient column sums and two register stages of both operands; the LDS-DMA variant's ring is 64 KB.

@@ -37,6 +37,7 @@ struct PanelParams {
   int nt;                             // 2: stream C past the caches
   int drop_cols;                      // dropout on the first drop_cols output columns only (a multiple of 64), mask index n * drop_cols + m
   const uint8_t* row_mask; float alpha;   // per-row keep mask [N] or null; output scale (folded into the dropout scale)
+  int rows;                           // rows per panel: 128, 64 or 32 (the kernel's ROWS)
   int csplit;                         // workgroups per panel: workgroup (panel, s) takes the chunk rounds s, s + csplit, ... (small N: fill the chip)
   long long* dbg;                     // -DSMX_DIAG only: per-wave clock stamps (tools/panel_stamps.py)
 };
@@ -88,15 +89,22 @@ __device__ __forceinline__ void panel_dropout8(float (&v)[8], uint32_t hm0, uint
   }
 }
 
-template <int K, int MODE, int ACT>
+// ROWS (round 6): rows of the resident panel.  128 = the kernel as described above.  64 / 32: the SMALL-N forms - a batch of a few
+// thousand frames has too few 128-row panels for 256 CUs (the recipe's 3750 frames: 30), and on the tiled kernels those launches are
+// LDS-bound at one or two workgroups per CU (tools/experiments/r06_smalln/README.md); a 64-row panel gives 59 workgroups per chunk
+// round, each wave a 64 x 64 (32 x 64) output chunk: the activation fragments still cross the LDS once per 64 output columns and
+// the weights not at all.
+template <int K, int MODE, int ACT, int ROWS = 128>
 __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   static_assert(K == 256 || K == 512, "panel GEMM: K = 256 or 512");
-  constexpr int KS = K / 16, ROWB = K * 2, A_BYTES = 128 * ROWB, SCR = 4096, PF = 8;
+  static_assert(ROWS == 128 || ROWS == 64 || ROWS == 32, "panel GEMM: 128 / 64 / 32 rows per panel");
+  constexpr int RB = ROWS / 32;                         // 32-row accumulator blocks per wave
+  constexpr int KS = K / 16, ROWB = K * 2, A_BYTES = ROWS * ROWB, SCR = 4096, PF = 8;
   static_assert(KS % PF == 0, "whole ring turns");
   __shared__ __attribute__((aligned(16))) char smem[A_BYTES + 8 * SCR];
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (wave-uniform for the compiler: scalar ring offsets, no waterfall loops)
-  const int n0 = (int)(blockIdx.x / (unsigned)p.csplit) * 128, csi = (int)(blockIdx.x % (unsigned)p.csplit);
+  const int n0 = (int)(blockIdx.x / (unsigned)p.csplit) * ROWS, csi = (int)(blockIdx.x % (unsigned)p.csplit);
 #ifdef SMX_DIAG   // per-wave clock stamps: [0] start, [1] panel in LDS, [2 + 2 r] main loop of chunk round r done, [3 + 2 r] its epilogue
   long long* dbgp = p.dbg ? p.dbg + ((long)blockIdx.x * 8 + (t >> 6)) * 16 : nullptr;
 #define SMX_PSTAMP(k) do { if (dbgp && lane == 0 && (k) < 16) dbgp[k] = clock64(); } while (0)
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
 
   // ---- the panel: 128 rows x K -> LDS, 16-byte chunk c of row r at chunk position c ^ (r & 15) ----
   {
-    constexpr int CPR = K / 8, NA = 128 * CPR / 512;
+    constexpr int CPR = K / 8, NA = ROWS * CPR / 512;
     const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), (short)0,
                                                                             (int)((((long)p.N - 1) * p.lda + K) * 2), 0x00020000);
     uint4 ra[NA];
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     if constexpr (MODE == 0) { ld_b(bfrag[0], b_cur, KS, 0); ld_b(bfrag[1], b_cur, KS, 1); }
     // ---- accumulators: MODE 0 starts them at the bias (8 MFMAs of the packed bias fragment against the ones fragment, C = 0),
     // MODE 1 lets the first step's MFMAs write them (C = 0): no zero fill, no bias load ----
-    f32x16 acc[4][2];
+    f32x16 acc[RB][2];
     if constexpr (MODE == 0) {
       // reduce slots 0 and 1 = 1.0, the rest 0 - per 32-row block, and 0 for a masked row (its bias stays out: see the panel load);
       // rebuilt per chunk (the four mask bytes come with the ring's requests) rather than kept in registers across the loop
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
       asm volatile("" : "+v"(zr));
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RB; ++i) {
         const bool keep = !hi && (mkp ? mkp[min(n0 + i * 32 + l31, p.N - 1)] != 0 : true);
         const uint4 ones = make_uint4(keep ? 0x3f803f80u : 0u, zr, zr, zr);
 #pragma unroll
@@ -193,12 +201,12 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     };
 
     // ---- main loop: KS steps of 16 reduce elements, 8 MFMAs each; the ring holds this chunk's first PF steps already ----
-    uint4 fa[4];
+    uint4 fa[RB];
     // (opaque per chunk: otherwise every step's fragment address - loop invariant - is hoisted out of the chunk loop, 64 live registers)
     uint32_t a_cur = a_base;
     asm volatile("" : "+v"(a_cur));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 32 * ROWB);
+    for (int i = 0; i < RB; ++i) fa[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 32 * ROWB);
     __builtin_amdgcn_sched_barrier(0);
     // The instruction order IS the source order (sched_barrier(0) after every MFMA; left to itself the scheduler hoists the fragment
     // reads and ring refills of many steps to the top and spills 90-150 registers).  Activation-fragment major: MFMA 2 i + j
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     for_seq<0, KS>([&](auto ktag) __attribute__((always_inline)) {
       constexpr int kk = decltype(ktag)::value, slot = kk % PF;
       const uint32_t an = a_cur ^ (uint32_t)((kk + 1) << 5);
-      for_seq<0, 8>([&](auto mtag) __attribute__((always_inline)) {
+      for_seq<0, 2 * RB>([&](auto mtag) __attribute__((always_inline)) {
         constexpr int mm = decltype(mtag)::value, i = mm >> 1, j = mm & 1;
         if constexpr ((SMX_PANEL_ABL & 2) != 0) {
           if constexpr (MODE == 1 && kk == 0) { for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f; }
@@ -220,10 +228,10 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb[slot][j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
         }
         if constexpr (kk + 1 < KS && j == 1 && (SMX_PANEL_ABL & 8) == 0) fa[i] = *reinterpret_cast<const uint4*>(smem + an + i * 32 * ROWB);
-        if constexpr (mm >= 6) {
-          constexpr int jj = mm - 6;
+        if constexpr (mm >= 2 * RB - 2) {                    // (behind the step's last two MFMAs)
+          constexpr int jj = mm - (2 * RB - 2);
           if constexpr (kk + PF < KS) ld_b(rb[slot][jj], b_cur, kk + PF, jj);
-          else if constexpr (MODE == 1) ld_z(rb[slot][jj], 2 * slot + jj);
+          else if constexpr (MODE == 1 && 2 * slot + jj < 4 * RB) ld_z(rb[slot][jj], 2 * slot + jj);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -241,12 +249,12 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
     SMX_PSTAMP(2 + 2 * (ch >> 3));
     if constexpr ((SMX_PANEL_ABL & 1) != 0) {
       float sabl = 0.f;
-      for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sabl += acc[i][j][e];
+      for (int i = 0; i < RB; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sabl += acc[i][j][e];
       if (sabl == 123.456f) p.C[0].v = 1;
       if constexpr (MODE == 1) { for (int s = 0; s < PF; ++s) if (rb[s][0].x == 0x12345u) p.C[1].v = 1; }
       continue;
     }
-    for_seq<0, 4>([&](auto itag) __attribute__((always_inline)) {
+    for_seq<0, RB>([&](auto itag) __attribute__((always_inline)) {
       constexpr int i = decltype(itag)::value;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -297,9 +305,14 @@ int launch_panel_actgrad(const PanelParams& p, int K, int act, hipStream_t s);
 
 template <int MODE>
 static int launch_panel_mode(const PanelParams& p, int K, int act, hipStream_t s) {
-  const dim3 grid(((p.N + 127) / 128) * p.csplit), block(512);
+  const int rows = p.rows;
+  const dim3 grid(((p.N + rows - 1) / rows) * p.csplit), block(512);
 #define SMX_PANEL_CASE(KK, AA) \
-  if (K == KK && act == AA) { hipLaunchKernelGGL((gemm_panel_kernel<KK, MODE, AA>), grid, block, 0, s, p); return check_launch("smx_gemm_panel"); }
+  if (K == KK && act == AA) { \
+    if (rows == 128) hipLaunchKernelGGL((gemm_panel_kernel<KK, MODE, AA, 128>), grid, block, 0, s, p); \
+    else if (rows == 64) hipLaunchKernelGGL((gemm_panel_kernel<KK, MODE, AA, 64>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((gemm_panel_kernel<KK, MODE, AA, 32>), grid, block, 0, s, p); \
+    return check_launch("smx_gemm_panel"); }
   SMX_PANEL_CASE(256, SMX_ACT_NONE) SMX_PANEL_CASE(256, SMX_ACT_SWISH) SMX_PANEL_CASE(256, SMX_ACT_GELU) SMX_PANEL_CASE(256, SMX_ACT_RELU)
   SMX_PANEL_CASE(512, SMX_ACT_NONE) SMX_PANEL_CASE(512, SMX_ACT_SWISH) SMX_PANEL_CASE(512, SMX_ACT_GELU) SMX_PANEL_CASE(512, SMX_ACT_RELU)
 #undef SMX_PANEL_CASE

@@ -1560,6 +1560,174 @@ extern "C" int smx_masked_mean_bwd_act(int dtype, const float* g, const float* i
                     "smx_masked_mean_bwd_act");
 }
 
+// =================================================================================================
+// Round 6, small batches: the masked mean AND its broadcast in ONE launch.  The per-utterance summary is three launches on the big
+// path (split-T partial sums, their fixed-order fold, the broadcast back over t) because 64 000 frames want thousands of
+// workgroups; the recipe's 10 x 375 frames or one utterance want neither - every launch of a replayed step costs >= 4.5 us
+// whatever it does (profiles/r06_seq_c2a_recipe_batch_v0_baseline.txt: 6.6 + 4.8 + 6.3 us for 3.8 MB in, 3.8 MB out).
+// One workgroup owns (utterance b, a group of 8 lanes x VT::N columns): its 32 row slots walk the T frames (4 rows in flight each),
+// fold through LDS in a FIXED order (bit-reproducible, no atomics), then the same threads write the broadcast with the options of
+// bcast_rows_kernel: inverted dropout (forward `repeat`, summary_mixing.py:222,237-239,267) or the act / mask backward of the
+// projection that produced the summary columns (backward of summary_mixing.py:210,257).
+// =================================================================================================
+// CL lanes x VT::N columns per row and workgroup, RS = 256 / CL row slots (chosen at launch: narrower groups = more workgroups
+// and more rows in flight for the 10-utterance recipe batch or a single utterance - the first version, 8 lanes and 4 rows in flight
+// on 80 workgroups, took 10-15 us: three dependent round trips per slot).
+template <typename T, bool VEC, int CL>
+__global__ __launch_bounds__(256) void pool_bcast_kernel(const T* __restrict__ S, long lds, const uint8_t* __restrict__ mask_in,
+                                                         float* mean_out, const float* __restrict__ inv_in, float* inv_out,
+                                                         T* dS, long ldds, int T_, int D, int scale, uint32_t dthresh, float dscale,
+                                                         uint64_t dseed_, const uint64_t* ep, const T* __restrict__ Z, long ldz,
+                                                         const uint8_t* __restrict__ mask_out, int act) {
+  constexpr int N = VT<T>::N, RS = 256 / CL, U = 8, G = 8, RG = RS / G;   // columns per lane, row slots, rows in flight, fold groups
+  __shared__ float red[RS][CL * N + 1];
+  __shared__ float cred[RS];
+  const uint64_t dseed = dthresh ? epoch_seed(dseed_, ep) : 0;
+  const int cl = threadIdx.x % CL, rs = threadIdx.x / CL, b = blockIdx.y;
+  const int col = (blockIdx.x * CL + cl) * N;
+  const int nvalid = D - col;                              // (<= 0: an idle lane of the last column group - it still joins the barriers)
+  const T* base = S + (long)b * T_ * lds + (nvalid > 0 ? col : 0);
+  const uint8_t* mrow = mask_in ? mask_in + (long)b * T_ : nullptr;
+  float acc[N], cnt = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0.f;
+  const int tlast = T_ - 1;
+  for (int t = rs; t < T_; t += U * RS) {                  // U rows in flight per slot; rows past the end: the last row, weight 0
+    float f[U][N], m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) loadv<T, VEC>(base + (long)min(t + RS * u, tlast) * lds, nvalid > 0 ? nvalid : 1, f[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tt = t + RS * u;
+      m[u] = tt < T_ ? (mrow ? (mrow[tt] ? 1.f : 0.f) : 1.f) : 0.f;
+      cnt += m[u];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      acc[i] += ((f[0][i] * m[0] + f[1][i] * m[1]) + (f[2][i] * m[2] + f[3][i] * m[3])) +
+                ((f[4][i] * m[4] + f[5][i] * m[5]) + (f[6][i] * m[6] + f[7][i] * m[7]));
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) red[rs][cl * N + i] = acc[i];
+  if (cl == 0) cred[rs] = cnt;
+  __syncthreads();
+  // fixed-order fold in two levels: slot g of the first G folds slots g * RG .. g * RG + RG - 1, then everybody folds the G results
+  if (rs < G) {
+    float c0 = 0.f, w[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = 0.f;
+    for (int k = rs * RG; k < rs * RG + RG; ++k) {
+      c0 += cred[k];
+#pragma unroll
+      for (int i = 0; i < N; ++i) w[i] += red[k][cl * N + i];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // (lgkmcnt(0): the reads above are done before the slot is overwritten)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < N; ++i) red[rs * RG][cl * N + i] = w[i];
+    if (cl == 0) cred[rs * RG] = c0;
+  }
+  __syncthreads();
+  float v[N], c = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = 0.f;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    c += cred[g * RG];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += red[g * RG][cl * N + i];
+  }
+  const float inv = 1.f / c;   // zero valid frames -> inf, 0 * inf = NaN, as the reference (summary_mixing.py:264-266)
+  if (inv_out && blockIdx.x == 0 && threadIdx.x == 0) inv_out[b] = inv;
+  const float sc = (scale ? inv : 1.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] *= sc;
+  if (nvalid <= 0) return;
+  if (mean_out && rs == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i < nvalid) mean_out[(long)b * D + col + i] = v[i];
+  }
+  if (!dS) return;
+  if (inv_in) {
+    const float si = inv_in[b];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] *= si;
+  }
+  if (Z || mask_out) {                                     // backward through act(.) * mask of the producing projection
+    dispatch_act(Z ? act : SMX_ACT_NONE, [&](auto act_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+      for (int t = rs; t < T_; t += 2 * RS) {               // (two rows in flight)
+        const long n0 = (long)b * T_ + t, n1 = n0 + RS;
+        const bool two = t + RS < T_;
+        const float mk0 = mask_out ? (mask_out[n0] ? 1.f : 0.f) : 1.f;
+        const float mk1 = (two && mask_out) ? (mask_out[n1] ? 1.f : 0.f) : 1.f;
+        float o0[N], o1[N];
+        if (ACT != SMX_ACT_NONE) {
+          float z0[N], z1[N];
+          loadv<T, VEC>(Z + n0 * ldz + col, nvalid, z0);
+          loadv<T, VEC>(Z + (two ? n1 : n0) * ldz + col, nvalid, z1);
+#pragma unroll
+          for (int i = 0; i < N; ++i) { o0[i] = v[i] * mk0 * act_grad_c<ACT>(z0[i]); o1[i] = v[i] * mk1 * act_grad_c<ACT>(z1[i]); }
+        } else {
+#pragma unroll
+          for (int i = 0; i < N; ++i) { o0[i] = v[i] * mk0; o1[i] = v[i] * mk1; }
+        }
+        storev<T, VEC>(dS + n0 * ldds + col, nvalid, o0);
+        if (two) storev<T, VEC>(dS + n1 * ldds + col, nvalid, o1);
+      }
+    });
+  } else if (dthresh == 0) {
+    for (int t = rs; t < T_; t += RS) storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, v);
+  } else {                                                 // fused inverted dropout, mask = f(seed, row * D + col)
+    for (int t = rs; t < T_; t += RS) {
+      const uint64_t ix = ((uint64_t)b * T_ + t) * (uint64_t)D + col;
+      float o[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) o[i] = v[i];
+      dropout_apply_any<N>(o, dseed, ix, dthresh, dscale);
+      storev<T, VEC>(dS + ((long)b * T_ + t) * ldds + col, nvalid, o);
+    }
+  }
+}
+
+extern "C" int smx_pool_bcast_ok(int B, int T, int D) {
+  // a workgroup per (utterance, 64 bf16 / 32 fp32 columns) walks all T frames: the small-batch form (long utterances and big batches
+  // keep the split-T kernels, whose thousands of workgroups stream at 0.72 of the HBM roof)
+  return B >= 1 && T >= 1 && D >= 1 && T <= 4096 && (long)B * T <= 16384;
+}
+
+extern "C" int smx_pool_bcast(int dtype, const void* S, int64_t lds, const uint8_t* mask_in, float* mean_out, const float* inv_in,
+                              float* inv_out, void* dS, int64_t ldds, int B, int T, int D, int scale_by_count, float drop_p,
+                              uint64_t drop_seed, const uint64_t* epoch, const void* Z, int64_t ldz, const uint8_t* mask_out, int act,
+                              void* stream) {
+  SMX_REQUIRE(S && (mean_out || dS), "smx_pool_bcast: null pointer");
+  SMX_REQUIRE(B > 0 && T > 0 && D > 0, "smx_pool_bcast: bad sizes");
+  SMX_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "smx_pool_bcast: 0 <= drop_p < 1");
+  SMX_REQUIRE(!(drop_p > 0.f && (Z || mask_out)), "smx_pool_bcast: dropout (forward) and the act / mask backward exclude each other");
+  if (!smx_pool_bcast_ok(B, T, D)) return fail(SMX_EUNSUPPORTED, "smx_pool_bcast: built for small batches (smx_pool_bcast_ok); use smx_masked_mean_fwd + smx_masked_mean_bwd");
+  const uint32_t dthresh = (uint32_t)((double)drop_p * 4294967296.0);
+  const float dscale = 1.f / (1.f - drop_p);
+  const int nvec = dtype == SMX_BF16 ? 8 : 4;
+  const size_t es = dtype == SMX_BF16 ? 2 : 4;
+  const bool vec = vec_ok(S, lds, D, nvec, es) && (dS == nullptr || vec_ok(dS, ldds, D, nvec, es)) && (Z == nullptr || vec_ok(Z, ldz, D, nvec, es));
+  const int a = Z ? act : SMX_ACT_NONE;
+  // lanes per row: the widest group (whole 128-byte row segments) that still gives ~half a workgroup per CU
+  int CL = 8;
+  while (CL > 2 && (long)B * ((D + CL * nvec - 1) / (CL * nvec)) < 128) CL >>= 1;
+  dim3 grid((D + CL * nvec - 1) / (CL * nvec), B);
+#define SMX_PB_LAUNCH(TT, VV, CC) hipLaunchKernelGGL((pool_bcast_kernel<TT, VV, CC>), grid, dim3(256), 0, STREAM, (const TT*)S, lds, mask_in, mean_out, inv_in, inv_out, (TT*)dS, ldds, T, D, scale_by_count, dthresh, dscale, drop_seed, epoch, (const TT*)Z, ldz, mask_out, a)
+#define SMX_PB_CL(TT, VV) do { if (CL == 8) SMX_PB_LAUNCH(TT, VV, 8); else if (CL == 4) SMX_PB_LAUNCH(TT, VV, 4); else SMX_PB_LAUNCH(TT, VV, 2); } while (0)
+  if (dtype == SMX_BF16) {
+    if (vec) SMX_PB_CL(bf16_t, true); else SMX_PB_CL(bf16_t, false);
+  } else if (dtype == SMX_F32) {
+    if (vec) SMX_PB_CL(float, true); else SMX_PB_CL(float, false);
+  } else return fail(SMX_EINVAL, "smx_pool_bcast: bad dtype");
+#undef SMX_PB_CL
+#undef SMX_PB_LAUNCH
+  return check_launch("smx_pool_bcast");
+}
+
 extern "C" size_t smx_chunk_mean_workspace(int B, int T, int D, int chunk) {
   int NC = (T + chunk - 1) / chunk;
   return (size_t)B * NC * D * sizeof(float);

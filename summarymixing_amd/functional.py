@@ -149,7 +149,7 @@ def wpacked(param, dtype, transposed=False, bias=None):
 # panel per CU; below ~190 panels the kernel deals a panel's chunk rounds to 2 or 4 workgroups.  Same-box A/B of the steps
 # (tools/experiments/ab_panel_rows.sh): 16 000 rows C2b 8.17 -> 7.83 ms, C2a 16.42 -> 15.81; 8 000 rows a tie; 32 000 rows -3 %.
 _PANEL = os.environ.get("SMX_PANEL", "1") != "0"
-_PANEL_MIN_ROWS = int(os.environ.get("SMX_PANEL_MIN_ROWS", "12288"))
+_PANEL_MIN_ROWS = int(os.environ.get("SMX_PANEL_MIN_ROWS", "2048"))   # (round 6: 64- / 32-row panels below 12 288 rows, chosen by the library)
 _PANEL_ACTS = (L.ACT_NONE, L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU)
 
 
@@ -163,6 +163,7 @@ def panel_ok(x, M, K, act):
             _span_ok(x) and ops.gemm_panel_ok(x, M, K))
 
 
+_POOL_FUSE = os.environ.get("SMX_POOL_FUSE", "1") != "0"   # small batches: smx_pool_bcast instead of masked mean + broadcast (3 launches)
 _WGRAD_BIAS = True   # (round 4: the SMX_NO_WGRAD_BIAS A/B knob is gone)     # A/B knob: bias gradients as a by-product of the wgrad GEMM
 
 # Residual-stream dtype of a bf16 model.  "fp32" (default) = torch autocast semantics, what the reference's `precision: bf16`
@@ -822,6 +823,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
 
         # ---- summary ------------------------------------------------------------------------------
         inv = None
+        pool_fused = False
         sp = SP.enabled()
         if sp and pool_kind not in ("mean", "expdecay", "chunk"):
             raise NotImplementedError("sequence-parallel mode supports the per-utterance mean, the Dynamic Chunk Training mask and "
@@ -844,6 +846,14 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             SP.all_reduce_sum(buf)
             inv = (1.0 / buf[:, sdim]).contiguous()
             sbar = (buf[:, :sdim] * inv[:, None]).contiguous()
+        elif pool_kind == "mean" and p_drop > 0.0 and cat_has_local and _POOL_FUSE and ops.pool_bcast_ok(B, T, sdim):
+            # small batches (round 6): mean over time + repeat + the merge input's dropout in ONE launch, straight into the summary
+            # half of cat (fast mode: in place - a workgroup reads all T rows of its columns before it writes any)
+            s2 = ops.new_dropout_seed()
+            sbar = None
+            _, inv = ops.pool_bcast(s, mask, B, T, ds=cat[:, cat.shape[1] - sdim:], scale=True, want_mean=False, want_inv=True,
+                                    drop=(p_drop, s2))
+            pool_fused = True
         elif pool_kind == "mean":
             sbar, inv = ops.masked_mean(s, mask, B, T, scale=True, want_inv=True)   # (B, sdim) fp32
         elif pool_kind == "chunk":
@@ -883,13 +893,17 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         if p_drop > 0.0:
             # training: dropout acts on cat[local, repeat(sbar)] per FRAME (summary_mixing.py:237-239,282-284), which
             # breaks the per-utterance factorisation -> materialise the dropped concatenation once and run K = l + s
-            if cat_has_local:
+            if pool_fused:
+                pass                                       # (cat is complete: smx_pool_bcast wrote the dropped broadcast)
+            elif cat_has_local:
                 s2 = ops.new_dropout_seed()
             else:
                 s1, s2 = ops.new_dropout_seed(), ops.new_dropout_seed()
                 cat = torch.empty((N, lw + sdim), dtype=dtype, device=dev)
                 ops.dropout(local, p_drop, s1, out=cat[:, :lw])
-            if pool_kind == "mean":
+            if pool_fused:
+                pass
+            elif pool_kind == "mean":
                 ops.bcast_rows(sbar, None, cat[:, lw:], B, T, drop=(p_drop, s2))   # repeat + dropout in one pass
             else:
                 ops.dropout(sbar, p_drop, s2, out=cat[:, lw:])
@@ -947,23 +961,42 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             # summary columns of global_proj itself (smx_masked_mean_bwd_act) - no separate act_mask_bwd pass over ds
             sum_done = False
 
-            def bcast_ds(dsbar_):
-                nonlocal sum_done
-                SP.all_reduce_sum(dsbar_)                  # sequence-parallel: the mean's gradient sums over every shard
+            def bcast_side():
+                """(z, mask, act) of the projection that produced the summary columns when its act / mask backward can ride in the
+                broadcast of the summary gradient, else None."""
                 if mode == "SummaryMixing-fast" and fuse_local:
                     z_g, mk_g = sv_g[-1][1], sv_g[-1][2]
                     if z_g is not None or mk_g is not None:
-                        ops.bcast_rows_act_bwd(dsbar_, inv, ds_out, B, T, z_g[:, l:] if z_g is not None else None, mk_g, act)
-                        sum_done = True
-                        return
+                        return (z_g[:, l:] if z_g is not None else None, mk_g, act)
                 elif mode != "SummaryMixing-fast" and P["summary_proj"][-1]["kind"] == "linear":
                     # full / expdecay modes: the same for the last layer of summary_proj (its mlp_bwd then starts from dZ)
                     z_s, mk_s = sv_s[-1][1], sv_s[-1][2]
                     if z_s is not None or mk_s is not None:
-                        ops.bcast_rows_act_bwd(dsbar_, inv, ds_out, B, T, z_s, mk_s, act if z_s is not None else L.ACT_NONE)
-                        sum_done = True
-                        return
+                        return (z_s, mk_s, act if z_s is not None else L.ACT_NONE)
+                return None
+
+            def bcast_ds(dsbar_):
+                nonlocal sum_done
+                SP.all_reduce_sum(dsbar_)                  # sequence-parallel: the mean's gradient sums over every shard
+                side = bcast_side()
+                if side is not None:
+                    ops.bcast_rows_act_bwd(dsbar_, inv, ds_out, B, T, side[0], side[1], side[2])
+                    sum_done = True
+                    return
                 ops.bcast_rows(dsbar_, inv, ds_out, B, T)
+
+            def sum_bcast_ds(dsd_):
+                """ds_out = broadcast over t of (sum_t dsd_) * inv [* act'(z) * mask]: one launch for small batches (smx_pool_bcast)."""
+                nonlocal sum_done
+                if _POOL_FUSE and not SP.enabled() and ops.pool_bcast_ok(B, T, dsd_.shape[1]):
+                    side = bcast_side()
+                    z_, mk_, a_ = side if side is not None else (None, None, L.ACT_NONE)
+                    ops.pool_bcast(dsd_, None, B, T, ds=ds_out, scale=False, want_mean=False, inv_in=inv, z=z_, mask_out=mk_,
+                                   act=a_ if z_ is not None else L.ACT_NONE)
+                    sum_done = side is not None
+                    return
+                dsbar_, _ = ops.masked_mean(dsd_, None, B, T, scale=False)               # sum over time
+                bcast_ds(dsbar_)
             if p_drop > 0.0:
                 # dgrad of the K = l + s merge as two GEMMs over the column halves of W: the dropout backward of each half
                 # (and the local half's act/mask backward) rides in the epilogue instead of separate passes
@@ -987,8 +1020,7 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
                 dsd = torch.empty((N, sdim), dtype=dtype, device=dev)
                 ops.gemm(L.GEMM_NN, dzm, Wm[:, lw:], dsd, N, sdim, s_out, ops.epilogue(drop=(p_drop, s2)))
                 if pool_kind == "mean":
-                    dsbar, _ = ops.masked_mean(dsd, None, B, T, scale=False)               # sum over time
-                    bcast_ds(dsbar)
+                    sum_bcast_ds(dsd)
                 elif pool_kind == "chunk":
                     (_chunk_mean_seqpar if SP.enabled() else ops.chunk_mean)(dsd, ds_out, B, T, sm.chunk_size, sm.left_context, reverse=True)
                 elif pool_kind == "expdecay":

@@ -369,6 +369,29 @@ def bcast_rows(g, inv, ds, B, T, drop=None):
     return ds
 
 
+def pool_bcast_ok(B, T, D):
+    return L.lib().smx_pool_bcast_ok(B, T, D) == 1
+
+
+def pool_bcast(s, mask_in, B, T, ds=None, scale=True, want_mean=True, want_inv=False, inv_in=None, drop=None, z=None, mask_out=None,
+               act=L.ACT_NONE):
+    """The masked mean over time and its broadcast in ONE launch (smx_pool_bcast; small batches: pool_bcast_ok).
+    -> (mean (B, D) fp32 | None, inv_count (B) fp32 | None); ds (B*T, D) receives D(value * inv_in) [* act'(z) * mask_out]."""
+    D = s.shape[1]
+    ps, lds_ = _mat(s)
+    mean = torch.empty((B, D), dtype=torch.float32, device=s.device) if want_mean else None
+    inv = torch.empty((B,), dtype=torch.float32, device=s.device) if want_inv else None
+    pds, ldds = _mat(ds) if ds is not None else (None, 0)
+    pz, ldz = _mat(z) if z is not None else (None, 0)
+    dp, dseed = drop if drop is not None else (0.0, 0)
+    nb = B * T * D * _es(s) * (1 + (ds is not None) + (z is not None)) + B * T
+    tok = _pb(f"pool+bcast ({B},{T},{D})", nb)
+    L.check(L.lib().smx_pool_bcast(dt(s), ps, lds_, _p(mask_in), _p(mean), _p(inv_in), _p(inv), pds, ldds, B, T, D, 1 if scale else 0,
+                                   dp, dseed, _epoch() if dp > 0 else None, pz, ldz, _p(mask_out), act, _stream()), "smx_pool_bcast")
+    _pe(tok)
+    return mean, inv
+
+
 def bcast_rows_act_bwd(g, inv, ds, B, T, z, mask, act):
     """ds[b*T+t, :] = g[b,:] * inv[b] * act'(z[b*T+t, :]) * mask[b*T+t]   (z and / or mask may be None)"""
     pds, ldds = _mat(ds)

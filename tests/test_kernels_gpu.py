@@ -915,3 +915,76 @@ print("OK")
     p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SMX_T256=mode, SMX_ROOT=root), capture_output=True,
                        text=True, timeout=300)
     assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,D", [(10, 375, 512), (1, 500, 256), (3, 17, 40), (7, 1300, 192), (2, 4096, 64)])
+def test_pool_bcast_equals_masked_mean_then_broadcast(dtype, B, T, D):
+    """smx_pool_bcast (round 6, small batches: one launch) against the three-launch path it replaces: the masked mean, its inverse
+    count, the dropped broadcast (bit-identical keep decisions: the mask is a function of the element index) and the act / mask
+    backward form - forward also IN PLACE on a column slice (the fast mode's cat buffer, summary_mixing.py:257-267,282-284)."""
+    L, ops = _ops()
+    assert ops.pool_bcast_ok(B, T, D)
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
+    big = (torch.rand(B * T, D + 24, device="cuda", generator=g) * 2 - 1).to(dtype)
+    s = big[:, 24:] if D % 8 == 0 else big[:, 3:3 + D]
+    mask = (torch.rand(B * T, device="cuda", generator=g) > 0.3).to(torch.uint8)
+    mask.view(B, T)[:, 0] = 1
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    # the mean and the inverse count
+    m_ref, inv_ref = ops.masked_mean(s, mask, B, T, scale=True, want_inv=True)
+    m1, inv1 = ops.pool_bcast(s, mask, B, T, ds=None, scale=True, want_mean=True, want_inv=True)
+    ref64 = (s.double().view(B, T, D) * mask.view(B, T, 1)).sum(1) / mask.view(B, T).sum(1, keepdim=True).double()
+    assert rel_err(m1, ref64) < 2e-6 and rel_err(m1, m_ref) < 2e-6 and torch.equal(inv1, inv_ref)
+    # forward: repeat + dropout, out of place and in place
+    out_ref = torch.empty(B * T, D, device="cuda", dtype=dtype)
+    ops.bcast_rows(m_ref, None, out_ref, B, T, drop=(0.2, 4242))
+    out = torch.full((B * T, D), 9.0, device="cuda", dtype=dtype)
+    ops.pool_bcast(s, mask, B, T, ds=out, scale=True, want_mean=False, drop=(0.2, 4242))
+    assert torch.equal(out == 0, out_ref == 0) and rel_err(out, out_ref) < tol
+    if D % 8 == 0:
+        keep = s.clone()
+        ops.pool_bcast(s, mask, B, T, ds=s, scale=True, want_mean=False, drop=(0.2, 4242))
+        assert torch.equal(s, out), "in place differs from out of place"
+        s.copy_(keep)
+    # backward: sum over time, * inv, * act'(z) * mask
+    z = (torch.rand(B * T, D, device="cuda", generator=g) * 6 - 3).to(dtype)
+    dsum, _ = ops.masked_mean(s, None, B, T, scale=False)
+    d_ref = torch.empty(B * T, D, device="cuda", dtype=dtype)
+    ops.bcast_rows_act_bwd(dsum, inv_ref, d_ref, B, T, z, mask, L.ACT_SWISH)
+    d1 = torch.full((B * T, D), 9.0, device="cuda", dtype=dtype)
+    ops.pool_bcast(s, None, B, T, ds=d1, scale=False, want_mean=False, inv_in=inv_ref, z=z, mask_out=mask, act=L.ACT_SWISH)
+    assert rel_err(d1, d_ref) < tol and bool((d1.view(B, T, D)[mask.view(B, T) == 0] == 0).all())
+    d2 = torch.empty_like(d1)
+    ops.bcast_rows(dsum, inv_ref, d_ref, B, T)
+    ops.pool_bcast(s, None, B, T, ds=d2, scale=False, want_mean=False, inv_in=inv_ref)
+    assert rel_err(d2, d_ref) < tol
+    # deterministic
+    d3 = torch.empty_like(d1)
+    ops.pool_bcast(s, None, B, T, ds=d3, scale=False, want_mean=False, inv_in=inv_ref)
+    assert torch.equal(d2, d3)
+    assert not ops.pool_bcast_ok(128, 500, 256)
+
+
+def test_reduce_jobs_many_jobs_and_ragged_tails():
+    """smx_reduce_jobs after the round-6 rewrite (4 groups per thread, ballot job lookup): more than 64 jobs, vector and scalar
+    jobs, source counts on every lane-sharing branch (1, 2, 7, 20), sizes that do not fill the last workgroup."""
+    import ctypes
+    L, ops = _ops()
+    torch.manual_seed(11)
+    specs = [(2, 256, 512), (1, 1, 512), (7, 300, 64), (20, 33, 128), (2, 5, 7), (3, 1, 5), (16, 1, 1024)] + [(2, 64, 64)] * 70
+    arr = (L.ReduceJob * len(specs))()
+    srcs, dsts, refs, starts = [], [], [], [0]
+    for i, (ns, rows, cols) in enumerate(specs):
+        src = torch.randn(ns, rows, cols, device="cuda")
+        dst = torch.randn(rows, cols, device="cuda")
+        refs.append(dst.double() + 0.5 * src.double().sum(0))
+        vec = int(cols % 4 == 0)
+        arr[i] = L.ReduceJob(src.data_ptr(), dst.data_ptr(), rows * cols, cols, ns, rows, cols, 0.5, vec, 0)
+        starts.append(starts[-1] + L.lib().smx_reduce_job_blocks(ctypes.byref(arr[i])))
+        srcs.append(src); dsts.append(dst)
+    jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    starts_dev = torch.tensor(starts, dtype=torch.int32).cuda()
+    ops.reduce_jobs(jobs_dev, starts_dev, len(specs), starts[-1])
+    for d, r in zip(dsts, refs):
+        assert rel_err(d, r) < 1e-6

@@ -21,7 +21,8 @@ def _mk(N, M, K, seed=0):
 
 # (N < 24 576 with M >= 1024: the chunk rounds of a panel are dealt to 2 or 4 workgroups; 16 000 x 1024 and 8 000 x 2048 fill the chip that way)
 @pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (128, 512, 256), (1, 64, 256), (700, 2048, 512), (391, 1536, 512), (2500, 3072, 512),
-                                   (16000 + 5, 1024, 256), (8000 + 9, 2048, 512)])
+                                   (16000 + 5, 1024, 256), (8000 + 9, 2048, 512),
+                                   (3750, 2048, 512), (6000 + 1, 1024, 256), (3750, 1024, 512)])   # (round 6: 64- and 32-row panels, the recipe batch)
 @pytest.mark.parametrize("act", [L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU, L.ACT_NONE])
 def test_panel_forward_matches_float64(N, M, K, act):
     x, W, b = _mk(N, M, K)
@@ -45,7 +46,8 @@ def test_panel_forward_matches_float64(N, M, K, act):
     assert rel_err(o3, ACTS[act](x.double() @ W.double().t())) < 1e-2
 
 
-@pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (5, 128, 256), (700, 2048, 512), (2500, 3072, 512), (16000 + 5, 1024, 256)])
+@pytest.mark.parametrize("N,M,K", [(1000 + 37, 1024, 256), (5, 128, 256), (700, 2048, 512), (2500, 3072, 512), (16000 + 5, 1024, 256),
+                                   (3750, 2048, 512), (6000 + 1, 1024, 256)])
 @pytest.mark.parametrize("act", [L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU])
 def test_panel_actgrad_matches_float64(N, M, K, act):
     dy, Wt, _ = _mk(N, M, K, seed=1)           # Wt (M, K) = W2^T
@@ -190,3 +192,38 @@ def test_panel_dropout_on_leading_columns_only():
     ops.gemm(L.GEMM_NT, x, W, o2, N, M, K, ops.epilogue(bias=b, act=L.ACT_SWISH, drop=(0.25, 77), drop_cols=dc))
     assert torch.equal(o1[:, :dc] == 0, o2[:, :dc] == 0) and 0.2 < float((o1[:, :dc] == 0).float().mean()) < 0.3
     assert float((o1[:, dc:] == 0).float().mean()) < 0.01 and rel_err(o1, o2) < 1.2e-2
+
+
+@pytest.mark.parametrize("rows", [128, 64, 32])
+def test_panel_every_panel_height_in_a_subprocess(rows):
+    """SMX_PANEL_ROWS forces the panel height (read once per process): both forms, with row mask, dropout and a ragged last panel, against
+    the tiled kernel - bit-identical dropout masks, values within a bf16 ulp - and run twice for determinism."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from summarymixing_amd import _lib as L, ops
+from tests._util import rel_err
+assert L.get_config()["panel_rows"] == %d
+g = torch.Generator(device="cuda").manual_seed(3)
+rnd = lambda *s: torch.rand(*s, device="cuda", generator=g) * 2 - 1
+for N, M, K in ((1000 + 37, 1024, 256), (3750, 2048, 512), (333, 512, 512), (70, 192, 256)):
+    x, W, b = rnd(N, K).bfloat16(), (rnd(M, K) * (2.0 / K ** 0.5)).bfloat16(), rnd(M) * 0.3
+    mask = (torch.rand(N, device="cuda", generator=g) > 0.3).to(torch.uint8)
+    z = (rnd(N, M) * 3).bfloat16()
+    Wt = W.t().contiguous()
+    o1, o2, o3, z1, z2 = (torch.full((N, M), 5.0, device="cuda").bfloat16() for _ in range(5))
+    ep = lambda **kw: ops.epilogue(row_mask=mask, alpha=0.5, drop=(0.15, 9), **kw)
+    ops.gemm_panel(x, ops.weight_pack(W, bias=b), o1, N, M, K, ep(act=L.ACT_SWISH, z=z1))
+    ops.gemm_panel(x, ops.weight_pack(W, bias=b), o3, N, M, K, ep(act=L.ACT_SWISH, z=z2))
+    ops.gemm(L.GEMM_NT, x, W, o2, N, M, K, ep(bias=b, act=L.ACT_SWISH, z=z2))
+    assert torch.equal(o1, o3) and torch.equal(o1 == 0, o2 == 0) and rel_err(o1, o2) < 1.2e-2, (N, M, K, rel_err(o1, o2))
+    assert rel_err(z1[mask != 0], z2[mask != 0]) < 8e-3
+    ops.gemm_panel(x, ops.weight_pack(Wt, transposed=True), o1, N, M, K, ep(act=L.ACT_GELU, act_grad_z=z))
+    ops.gemm(L.GEMM_NN, x, Wt, o2, N, M, K, ep(act=L.ACT_GELU, act_grad_z=z))
+    assert bool((o1[mask == 0] == 0).all()) and rel_err(o1, o2) < 1.2e-2, (N, M, K, rel_err(o1, o2))
+print("ok")
+""" % (root, rows)
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, SMX_PANEL_ROWS=str(rows)), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
