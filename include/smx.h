@@ -491,6 +491,34 @@ int smx_ctc_loss_bwd(int dtype, const void* log_probs, int64_t ldlp, const int32
                      const int32_t* tgt_len, int B, int T, int V, int Smax, int blank, const float* nll, const float* gscale,
                      void* grad, int64_t ldg, void* workspace, void* stream);
 
+/* ---- Split-K over WORKGROUPS for the long reductions of a small batch (round 6; the recipe's 10 x 375 frames) -------------------
+ * smx_gemm_panel_slabs: slab[s] (N x M, float32) = A[:, s K : (s + 1) K] . W_s^T for s < nslice on the panel-resident kernel
+ *   (A (N, nslice K) bf16; Wpacked = nslice consecutive smx_weight_pack images, image s = the weight's K-slice s, packed WITHOUT a bias;
+ *   K = 256 or 512 per slice, M %% 64 == 0, M <= 512).  slabs: nslice * N * M floats, caller-owned.
+ * smx_slab_epilogue: C = epilogue(sum_s slab[s]) with the slabs added in a fixed order (bit-reproducible, no atomics) and the
+ *   smx_gemm epilogue fields bias, act (+ z saved), drop_*, alpha, row_mask, res (SMX_IO_RES_F32), out_mode (SMX_OUT_T / SMX_OUT_F32)
+ *   and SMX_EPI_LN_FWD (lnf_*, SMX_IO_LNFY_F32, lnf2_*) - the LayerNorm(s) that follow the Linear (Conformer.py:458-476,507,530-536)
+ *   run on the row in registers: one launch instead of GEMM epilogue + standalone LayerNorm.  Other fields: SMX_EUNSUPPORTED. */
+int smx_gemm_panel_slabs_ok(int dtype, int N, int M, int K, int nslice);
+int smx_gemm_panel_slabs(int dtype, const void* A, int64_t lda, const void* Wpacked, float* slabs, int N, int M, int K, int nslice,
+                         void* stream);
+int smx_slab_epilogue_ok(int dtype, int N, int M, int nslab);
+int smx_slab_epilogue(int dtype, const float* slabs, int nslab, int64_t slab_stride, void* C, int64_t ldc, int N, int M,
+                      const smx_epilogue* epi, void* stream);
+
+/* ---- Sequence-parallel shards (summarymixing_amd/sequence_parallel.py): the boundary arithmetic of the two O(T) summaries inside the
+ * kernels (round 6; it ran as float32 elementwise passes over the activations on the host side before).
+ * smx_chunk_mean_sharded: the shard holds the whole chunks [c_off, c_off + T / chunk).  phase 1: chunk sums into `workspace`
+ *   ((B, T / chunk, D) float32; reverse: scaled by 1 / the GLOBAL window length; left < 0: running sums) - rows of it are what the
+ *   shards exchange.  phase 2: window combine + carry[b][c - carry_c0] for carry_c0 <= c < carry_c0 + carry_n (carry_n == 0: one
+ *   (B, D) row for every chunk), forward divided by the GLOBAL window length.
+ * smx_expdecay_mean_sharded: frames [t_off, t_off + T) of T_glob.  phase 1: ends (2, B, D) <- the states leaving the shard; phase 2:
+ *   ends = the states ENTERING it (folded by the caller from the gathered ones), out = the operator with global denominators. */
+int smx_chunk_mean_sharded(int dtype, const void* X, int64_t ldx, void* out, int64_t ldo, int B, int T, int D, int chunk, int left,
+                           int reverse, int c_off, int phase, const float* carry, int carry_c0, int carry_n, void* workspace, void* stream);
+int smx_expdecay_mean_sharded(int dtype, const void* S, int64_t lds, void* out, int64_t ldo, int B, int T, int D, float decay, int mode,
+                              int t_off, int T_glob, int phase, float* ends, void* workspace, void* stream);
+
 /* Device step counter (one uint64 in device memory) - an explicit ARGUMENT of every call that uses it, never library
  * state: `epoch` of smx_dropout / smx_masked_mean_bwd(_act) / smx_act_mask_bwd / smx_layernorm_bwd2 /
  * smx_dwconv1d_glu_fwd_drop, smx_epilogue.epoch of the GEMMs, `step_dev` of smx_adamw_step.  With a non-NULL counter a

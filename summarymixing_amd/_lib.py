@@ -168,6 +168,12 @@ SIGNATURES = {
                                c_vp]),
     "smx_get_config": (c_i, [c_vp]),
     "smx_gemm_ln_tile_rows": (c_i, []),
+    "smx_gemm_panel_slabs_ok": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "smx_gemm_panel_slabs": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
+    "smx_slab_epilogue_ok": (c_i, [c_i, c_i, c_i, c_i]),
+    "smx_slab_epilogue": (c_i, [c_i, c_vp, c_i, c_i64, c_vp, c_i64, c_i, c_i, ctypes.POINTER(Epilogue), c_vp]),
+    "smx_chunk_mean_sharded": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_i, c_vp, c_vp]),
+    "smx_expdecay_mean_sharded": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
     "smx_stream_capture_id": (c_i, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "smx_sumsq_workspace": (c_sz, []),

@@ -278,8 +278,11 @@ static int launch_layout(GemmParams& p, bool vec, hipStream_t s) {
       return check_launch("smx_gemm");
     }
   }
+#ifndef SMX_WIDE_MIN_TILES
+#define SMX_WIDE_MIN_TILES 256
+#endif
   if (wide && !force_small && p.N >= 128 && p.M >= 256 && p.M % 256 == 0 && p.splits == 1 &&
-      (long)((p.N + 127) / 128) * (p.M / 256) * p.batch >= 256)
+      (long)((p.N + 127) / 128) * (p.M / 256) * p.batch >= SMX_WIDE_MIN_TILES)
     return launch_tile<T, A_KC, B_KC, 128, 256>(p, vec, s);
   if (!force_small && big >= 256 && p.N >= 128 && p.M >= 128) return launch_tile<T, A_KC, B_KC, 128, 128>(p, vec, s);
   return launch_tile<T, A_KC, B_KC, 64, 64>(p, vec, s);

@@ -38,6 +38,11 @@ struct PanelParams {
   int drop_cols;                      // dropout on the first drop_cols output columns only (a multiple of 64), mask index n * drop_cols + m
   const uint8_t* row_mask; float alpha;   // per-row keep mask [N] or null; output scale (folded into the dropout scale)
   int rows;                           // rows per panel: 128, 64 or 32 (the kernel's ROWS)
+  // MODE 2 (split-K slabs, round 6): workgroup (x, y) multiplies K-slice y - columns [y K, (y + 1) K) of A, packed image y of Bp -
+  // and stores its float32 partial products to slab y: no bias, no activation, no mask (smx_slab_epilogue applies them to the sum)
+  float* slab; long slab_stride;      // [nslice][N][M] float32, elements between slabs
+  int nslice;
+  long b_slice_bytes;                 // bytes between the packed images of consecutive K-slices
   int csplit;                         // workgroups per panel: workgroup (panel, s) takes the chunk rounds s, s + csplit, ... (small N: fill the chip)
   long long* dbg;                     // -DSMX_DIAG only: per-wave clock stamps (tools/panel_stamps.py)
 };
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   static_assert(K == 256 || K == 512, "panel GEMM: K = 256 or 512");
   static_assert(ROWS == 128 || ROWS == 64 || ROWS == 32, "panel GEMM: 128 / 64 / 32 rows per panel");
   constexpr int RB = ROWS / 32;                         // 32-row accumulator blocks per wave
-  constexpr int KS = K / 16, ROWB = K * 2, A_BYTES = ROWS * ROWB, SCR = 4096, PF = 8;
+  constexpr int KS = K / 16, ROWB = K * 2, A_BYTES = ROWS * ROWB, SCR = MODE == 2 ? 8192 : 4096, PF = 8;
   static_assert(KS % PF == 0, "whole ring turns");
   __shared__ __attribute__((aligned(16))) char smem[A_BYTES + 8 * SCR];
   const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
@@ -113,7 +118,9 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
 #endif
   SMX_PSTAMP(0);
 
-  const __amdgpu_buffer_rsrc_t rb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Bp), (short)0, (int)((long)p.M * (K + 16) * 2), 0x00020000);
+  const int slice = MODE == 2 ? (int)blockIdx.y : 0;
+  const __amdgpu_buffer_rsrc_t rb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.Bp)) + (long)slice * p.b_slice_bytes,
+                                                                          (short)0, (int)((long)p.M * (K + 16) * 2), 0x00020000);
   const uint32_t lane16 = (uint32_t)lane * 16u;
   // ---- B ring: fragment (column block c * 2 + j, step kk) = 1 KB at ((c * 2 + j) * (KS + 1) + kk) * 1024, lane-major; step KS = the bias.  The chunk's base
   // rides in the VECTOR offset (range-checked: a chunk beyond the last one reads zeros, no memory touched), step and j are constants.
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
   // ---- the panel: 128 rows x K -> LDS, 16-byte chunk c of row r at chunk position c ^ (r & 15) ----
   {
     constexpr int CPR = K / 8, NA = ROWS * CPR / 512;
-    const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), (short)0,
+    const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A) + (long)slice * K, (short)0,
                                                                             (int)((((long)p.N - 1) * p.lda + K) * 2), 0x00020000);
     uint4 ra[NA];
 #pragma unroll
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
       const pg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(ra_rs, off, 0, 0);
       // row mask: a masked row enters the panel as zeros, so its accumulators hold nothing but the bias - which MODE 0 withholds
       // from it as well (the ones fragment below): act(0) = 0 for every activation here, act-grad and dropout keep the zero
-      const bool keep = p.row_mask ? p.row_mask[n] != 0 : true;
+      const bool keep = (MODE != 2 && p.row_mask) ? p.row_mask[n] != 0 : true;
       ra[i] = keep ? make_uint4(r.x, r.y, r.z, r.w) : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
@@ -219,9 +226,9 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
       for_seq<0, 2 * RB>([&](auto mtag) __attribute__((always_inline)) {
         constexpr int mm = decltype(mtag)::value, i = mm >> 1, j = mm & 1;
         if constexpr ((SMX_PANEL_ABL & 2) != 0) {
-          if constexpr (MODE == 1 && kk == 0) { for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f; }
+          if constexpr (MODE != 0 && kk == 0) { for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f; }
           asm volatile("" : "+v"(rb[slot][j].x), "+v"(fa[i].x), "+v"(acc[i][j]));
-        } else if constexpr (MODE == 1 && kk == 0) {
+        } else if constexpr (MODE != 0 && kk == 0) {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb[slot][j]), __builtin_bit_cast(bf16x8, fa[i]), zero, 0, 0, 0);
         } else {
@@ -252,6 +259,36 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
       for (int i = 0; i < RB; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sabl += acc[i][j][e];
       if (sabl == 123.456f) p.C[0].v = 1;
       if constexpr (MODE == 1) { for (int s = 0; s < PF; ++s) if (rb[s][0].x == 0x12345u) p.C[1].v = 1; }
+      continue;
+    }
+    if constexpr (MODE == 2) {
+      // ---- float32 slab: 32 rows x 64 columns at a time through the wave's 8 KB scratch (row r = 256 B, 16-byte granule q at
+      // q ^ (r & 15): conflict-free both ways), out as whole 256-byte row segments, four rows per store instruction ----
+      const __amdgpu_buffer_rsrc_t rs_rs = __builtin_amdgcn_make_buffer_rsrc(p.slab + (long)slice * p.slab_stride, (short)0,
+                                                                              (int)((long)p.N * p.M * 4), 0x00020000);
+      uint32_t f_wr = (uint32_t)(l31 * 256), f_x = (uint32_t)(l31 & 15);
+      uint32_t f_rd = (uint32_t)((lane >> 4) * 256 + (((lane & 15) ^ (lane >> 4)) << 4));        // row lane >> 4 (+ 4 per pass), granule lane & 15
+      uint32_t f_off = (uint32_t)(((long)(n0 + (lane >> 4)) * p.M + ch * 64 + (lane & 15) * 4) * 4);
+      asm volatile("" : "+v"(f_wr), "+v"(f_x), "+v"(f_rd), "+v"(f_off));
+      for_seq<0, RB>([&](auto itag) __attribute__((always_inline)) {
+        constexpr int i = decltype(itag)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(scr + f_wr + (((uint32_t)(j * 8 + g * 2 + hi) ^ f_x) << 4)) =
+                make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+          // (row pp * 4 + (lane >> 4): its swizzle key is (row & 15) = ((pp & 3) * 4 + (lane >> 4)): fold pp's part into the address)
+          const uint4 v = *reinterpret_cast<const uint4*>(scr + ((f_rd + (uint32_t)(pp * 4 * 256)) ^ (uint32_t)(((pp & 3) * 4) << 4)));
+          const pg_u32x4 vu = {v.x, v.y, v.z, v.w};
+          __builtin_amdgcn_raw_buffer_store_b128(vu, rs_rs, f_off + (uint32_t)((i * 32 + pp * 4) * p.M * 4), 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the scratch is rewritten by the next 32-row block)
+      });
+      SMX_PSTAMP(3 + 2 * (ch >> 3));
       continue;
     }
     for_seq<0, RB>([&](auto itag) __attribute__((always_inline)) {
@@ -302,11 +339,12 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelParams p) {
 // host side: one launcher per mode (gemm_panel.hip: forward, gemm_panel_bwd.hip: act-grad), K and the activation by switch
 int launch_panel_fwd(const PanelParams& p, int K, int act, hipStream_t s);
 int launch_panel_actgrad(const PanelParams& p, int K, int act, hipStream_t s);
+int launch_panel_slabs(const PanelParams& p, int K, hipStream_t s);
 
 template <int MODE>
 static int launch_panel_mode(const PanelParams& p, int K, int act, hipStream_t s) {
   const int rows = p.rows;
-  const dim3 grid(((p.N + rows - 1) / rows) * p.csplit), block(512);
+  const dim3 grid(((p.N + rows - 1) / rows) * p.csplit, MODE == 2 ? p.nslice : 1), block(512);
 #define SMX_PANEL_CASE(KK, AA) \
   if (K == KK && act == AA) { \
     if (rows == 128) hipLaunchKernelGGL((gemm_panel_kernel<KK, MODE, AA, 128>), grid, block, 0, s, p); \

@@ -177,3 +177,45 @@ extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void*
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return ag ? launch_panel_actgrad(p, K, e.act, s) : launch_panel_fwd(p, K, e.act, s);
 }
+
+// ---- split-K over workgroups for the LONG reductions of a small batch (round 6) -----------------------------------------------------
+// C (N x M) = A (N x nslice K) W^T with the reduction cut into nslice panel-sized slices: workgroup (panel, slice) multiplies its
+// K-slice on the panel-resident kernel (MODE 2) and stores float32 partial products to slab[slice]; smx_slab_epilogue (rowwise.hip)
+// adds the slabs in a fixed order and applies the Linear's epilogue - and the LayerNorm that follows it.  For the recipe's 3750
+// frames the 64 x 64 tiles of smx_gemm walk K = 2048 on 472 LDS-bound workgroups (21-25 us); 59 panels x 4 slices = 236 workgroups of
+// 8 waves do the same work with the weights never in LDS.
+extern "C" int smx_gemm_panel_slabs_ok(int dtype, int N, int M, int K, int nslice) {
+  return dtype == SMX_BF16 && (K == 256 || K == 512) && N >= 1 && M >= 64 && M % 64 == 0 && M <= 512 && nslice >= 1 && nslice <= 16 &&
+         (long)N * M * 4 < (1L << 31) && (long)N * nslice * K * 2 < (1L << 31);
+}
+
+extern "C" int smx_gemm_panel_slabs(int dtype, const void* A, int64_t lda, const void* Wpacked, float* slabs, int N, int M, int K, int nslice,
+                                    void* stream) {
+  SMX_REQUIRE(A && Wpacked && slabs, "smx_gemm_panel_slabs: null operand");
+  if (N <= 0) return SMX_OK;
+  if (!smx_gemm_panel_slabs_ok(dtype, N, M, K, nslice)) return fail(SMX_EUNSUPPORTED, "smx_gemm_panel_slabs: bf16, K = 256 / 512 per slice, M %% 64 == 0, M <= 512 (smx_gemm_panel_slabs_ok)");
+  SMX_REQUIRE(aligned16(A) && lda % 8 == 0 && lda >= (int64_t)nslice * K && aligned16(Wpacked) && aligned16(slabs),
+              "smx_gemm_panel_slabs: operands must be 16-byte aligned with lda %% 8 == 0 and lda >= nslice * K");
+  if (((long)N - 1) * lda * 2 + (long)nslice * K * 2 >= (1L << 31)) return fail(SMX_EUNSUPPORTED, "smx_gemm_panel_slabs: operand span must stay below 2 GB");
+  PanelParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda;
+  p.Bp = Wpacked;
+  p.N = N; p.M = M;
+  p.alpha = 1.f; p.dscale = 1.f; p.drop_cols = M;
+  p.slab = slabs; p.slab_stride = (long)N * M; p.nslice = nslice;
+  p.b_slice_bytes = (long)smx_weight_pack_bytes(M, K);
+  {
+    // panel height: the largest with ~3/4 of a workgroup per CU (cf. smx_gemm_panel); M <= 512 is at most one chunk round: csplit = 1
+    int rows = K == 512 ? 64 : 128;                        // (K = 512: the float32 scratch leaves room for 64 rows)
+    const int forced = cfg().panel_rows;
+    if (forced == 64 || forced == 32 || (forced == 128 && K == 256)) rows = forced;
+    else while (rows > 32 && (long)((N + rows - 1) / rows) * nslice < 180) rows >>= 1;
+    p.rows = rows;
+    p.csplit = 1;
+  }
+#ifdef SMX_DIAG
+  p.dbg = g_dbg_stamps;
+#endif
+  return launch_panel_slabs(p, K, reinterpret_cast<hipStream_t>(stream));
+}

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(const float* g, const f
 // csum[b,c,:] = scale_c * sum_{t in chunk c} X[b,t,:]   (scale_c = 1 or 1/wlen(c)).  grid (DC, NC, B)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const T* X, long ldx, float* csum, int T_, int D, int chunk,
-                                                        int NC, int left, int scale_by_wlen) {
+                                                        int NC, int left, int scale_by_wlen, int c_off) {
   constexpr int N = VT<T>::N;
   __shared__ float red[3][64 * N];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z, c = blockIdx.y;
@@ -231,9 +231,9 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const T* X, long ldx, fl
   __syncthreads();
   if (w == 0 && nvalid > 0) {
     float sc = 1.f;
-    if (scale_by_wlen) {
-      int lo = left < 0 ? 0 : max(0, (c - left) * chunk);
-      sc = 1.f / (float)(t1 - lo);
+    if (scale_by_wlen) {                                  // (c_off: chunks of earlier sequence-parallel shards in front of this one)
+      const int lo = left < 0 ? 0 : max(0, (c + c_off - left) * chunk);
+      sc = 1.f / (float)(t1 + c_off * chunk - lo);
     }
     float* o = csum + ((long)b * NC + c) * D + col;
 #pragma unroll
@@ -260,9 +260,13 @@ __global__ __launch_bounds__(256) void chunk_prefix_kernel(float* csum, int D, i
 }
 // fwd: out rows of chunk c = (sum_{c'=lo..c} csum[c']) / wlen(c);  bwd (reverse=1): rows of chunk c =
 // sum_{c'=c..hi} csum[c'] (csum already scaled by 1/wlen).  grid (DC, NC, B)
+// Sequence-parallel shards (c_off chunks in front of this one; carry): the window sums that reach into other shards arrive as
+// `carry` rows - chunk c adds carry[b][c - carry_c0] for carry_c0 <= c < carry_c0 + carry_n (carry_n == 0 with a non-null carry: ONE
+// row per utterance for every chunk: the totals of all earlier / later shards with unlimited left context).
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void chunk_window_kernel(const float* csum, T* out, long ldo, int T_, int D,
-                                                           int chunk, int NC, int left, int reverse) {
+                                                           int chunk, int NC, int left, int reverse, int c_off,
+                                                           const float* __restrict__ carry, int carry_c0, int carry_n) {
   constexpr int N = VT<T>::N;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z, c = blockIdx.y;
   const int col = (blockIdx.x * 64 + lane) * N;
@@ -281,10 +285,20 @@ __global__ __launch_bounds__(256) void chunk_window_kernel(const float* csum, T*
     for (int i = 0; i < N; ++i)
       if (i < nvalid) acc[i] += p[i];
   }
+  if (carry) {
+    const float* cp = nullptr;
+    if (carry_n == 0) cp = carry + (long)b * D + col;
+    else if (c >= carry_c0 && c < carry_c0 + carry_n) cp = carry + ((long)b * carry_n + (c - carry_c0)) * D + col;
+    if (cp) {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (i < nvalid) acc[i] += cp[i];
+    }
+  }
   const int t0 = c * chunk, t1 = min(T_, t0 + chunk);
   if (!reverse) {
-    int lo = left < 0 ? 0 : max(0, (c - left) * chunk);
-    float sc = 1.f / (float)(t1 - lo);
+    const int lo = left < 0 ? 0 : max(0, (c + c_off - left) * chunk);
+    float sc = 1.f / (float)(t1 + c_off * chunk - lo);
 #pragma unroll
     for (int i = 0; i < N; ++i) acc[i] *= sc;
   }
@@ -310,7 +324,7 @@ __device__ __forceinline__ float ed_inv_den(int t, int T_, float lng, float inv1
 // grid (DC, ceil(NC/4), B); a wave owns one chunk; lane owns 4 columns.  ws[b][c][0][D] = F_c, ws[b][c][1][D] = G_c
 template <typename T>
 __global__ __launch_bounds__(256) void expdecay_chunk_kernel(const T* __restrict__ X, long ldx, float* __restrict__ ws,
-                                                             int T_, int D, int NC, float gamma, int mode) {
+                                                             int T_, int D, int NC, float gamma, int mode, int t_off, int T_glob) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
   const int c = blockIdx.y * 4 + w, col = (blockIdx.x * 64 + lane) * 4;
   if (c >= NC || col >= D) return;
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(256) void expdecay_chunk_kernel(const T* __restrict
 #pragma unroll
   for (int i = 0; i < ED_CH; ++i) {
     const int t = t0 + i;
-    const float sc = (mode == 1 && t < T_) ? ed_inv_den(t, T_, lng, inv1mg) : 1.f;
+    const float sc = (mode == 1 && t < T_) ? ed_inv_den(t + t_off, T_glob, lng, inv1mg) : 1.f;   // (t_off / T_glob: a sequence-parallel shard)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float x = v[i][q] * sc;
@@ -344,14 +358,19 @@ __global__ __launch_bounds__(256) void expdecay_chunk_kernel(const T* __restrict
 
 // in place: ws[b][c][0] <- f entering chunk c from the left, ws[b][c][1] <- g entering chunk c from the right.
 // One thread per (b, column); the chunk values are independent of the recurrence, so 8 are fetched ahead.
-__global__ __launch_bounds__(256) void expdecay_carry_kernel(float* __restrict__ ws, int D, int NC, int B, float gamma) {
+// f_in / g_in (B, D; sequence-parallel shards): the states entering the shard from its left / right neighbours, else zero.
+// ends (2, B, D; optional, then NOTHING is written to ws): the states LEAVING the shard - f at its last frame, g at its first -
+// with zero entering states: what the shards exchange before the second call.
+__global__ __launch_bounds__(256) void expdecay_carry_kernel(float* __restrict__ ws, int D, int NC, int B, float gamma,
+                                                             const float* __restrict__ f_in, const float* __restrict__ g_in,
+                                                             float* __restrict__ ends, int T_) {
   const long idx = blockIdx.x * 256L + threadIdx.x;
   if (idx >= (long)B * D) return;
   const int b = (int)(idx / D), col = (int)(idx % D);
   float* base = ws + (long)b * NC * 2 * D + col;
   const float gch = expf((float)ED_CH * logf(gamma));    // every chunk is ED_CH rows long (the tail is zero padded)
   // both directions advance in the same loop (two independent chains), 16 chunk values of each fetched ahead
-  float cf = 0.f, cg = 0.f;
+  float cf = f_in ? f_in[idx] : 0.f, cg = g_in ? g_in[idx] : 0.f;
   for (int c0 = 0; c0 < NC; c0 += 16) {
     float f[16], g[16];
 #pragma unroll
@@ -364,19 +383,25 @@ __global__ __launch_bounds__(256) void expdecay_carry_kernel(float* __restrict__
     for (int u = 0; u < 16; ++u) {
       const int c = c0 + u;
       if (c < NC) {
-        base[(long)c * 2 * D] = cf;
+        if (!ends) base[(long)c * 2 * D] = cf;
         cf = f[u] + gch * cf;
-        base[(long)(NC - 1 - c) * 2 * D + D] = cg;
+        if (!ends) base[(long)(NC - 1 - c) * 2 * D + D] = cg;
         cg = g[u] + gch * cg;
       }
     }
+  }
+  if (ends) {
+    // the last chunk is zero padded to ED_CH rows: its end value is gamma^pad times f at the shard's last frame
+    const int pad = NC * ED_CH - T_;
+    ends[idx] = cf * expf(-(float)pad * logf(gamma));
+    ends[(long)B * D + idx] = cg;
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void expdecay_apply_kernel(const T* __restrict__ X, long ldx, const float* __restrict__ ws,
                                                              T* __restrict__ Y, long ldy, int T_, int D, int NC, float gamma,
-                                                             int mode) {
+                                                             int mode, int t_off, int T_glob) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.z;
   const int c = blockIdx.y * 4 + w, col = (blockIdx.x * 64 + lane) * 4;
   if (c >= NC || col >= D) return;
@@ -395,7 +420,7 @@ __global__ __launch_bounds__(256) void expdecay_apply_kernel(const T* __restrict
 #pragma unroll
   for (int i = 0; i < ED_CH; ++i) {                      // ascending: a_t = gamma f_{t-1}  (= f_t - x_t)
     const int t = t0 + i;
-    const float sc = (mode == 1 && t < T_) ? ed_inv_den(t, T_, lng, inv1mg) : 1.f;
+    const float sc = (mode == 1 && t < T_) ? ed_inv_den(t + t_off, T_glob, lng, inv1mg) : 1.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       v[i][q] *= sc;
@@ -414,7 +439,7 @@ __global__ __launch_bounds__(256) void expdecay_apply_kernel(const T* __restrict
     }
     if (t < T_) {
       if (mode == 0) {
-        const float sc = ed_inv_den(t, T_, lng, inv1mg);
+        const float sc = ed_inv_den(t + t_off, T_glob, lng, inv1mg);
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] *= sc;
       }
@@ -1733,19 +1758,26 @@ extern "C" size_t smx_chunk_mean_workspace(int B, int T, int D, int chunk) {
   return (size_t)B * NC * D * sizeof(float);
 }
 
+// phase: 3 = the whole operator (one shard = the whole sequence); 1 = chunk sums (+ running sums) only - the shard's exchange
+// values are then rows of the workspace; 2 = the window combine, with the other shards' contributions in `carry`
 template <typename T>
 static int chunk_mean_impl(const void* X, int64_t ldx, void* out, int64_t ldo, int B, int T_, int D, int chunk, int left,
-                           int reverse, void* ws, hipStream_t s) {
+                           int reverse, void* ws, hipStream_t s, int phase = 3, int c_off = 0, const float* carry = nullptr,
+                           int carry_c0 = 0, int carry_n = 0) {
   const int nvec = VT<T>::N;
   const int NC = (T_ + chunk - 1) / chunk, DC = (D + 64 * nvec - 1) / (64 * nvec);
   dim3 grid(DC, NC, B);
   float* csum = reinterpret_cast<float*>(ws);
   const bool v1 = vec_ok(X, ldx, D, nvec, sizeof(T)), v2 = vec_ok(out, ldo, D, nvec, sizeof(T));
-  if (v1) hipLaunchKernelGGL((chunk_sum_kernel<T, true>), grid, dim3(256), 0, s, (const T*)X, ldx, csum, T_, D, chunk, NC, left, reverse);
-  else hipLaunchKernelGGL((chunk_sum_kernel<T, false>), grid, dim3(256), 0, s, (const T*)X, ldx, csum, T_, D, chunk, NC, left, reverse);
-  if (left < 0) hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)B), dim3(256), 0, s, csum, D, NC, reverse);
-  if (v2) hipLaunchKernelGGL((chunk_window_kernel<T, true>), grid, dim3(256), 0, s, csum, (T*)out, ldo, T_, D, chunk, NC, left, reverse);
-  else hipLaunchKernelGGL((chunk_window_kernel<T, false>), grid, dim3(256), 0, s, csum, (T*)out, ldo, T_, D, chunk, NC, left, reverse);
+  if (phase & 1) {
+    if (v1) hipLaunchKernelGGL((chunk_sum_kernel<T, true>), grid, dim3(256), 0, s, (const T*)X, ldx, csum, T_, D, chunk, NC, left, reverse, c_off);
+    else hipLaunchKernelGGL((chunk_sum_kernel<T, false>), grid, dim3(256), 0, s, (const T*)X, ldx, csum, T_, D, chunk, NC, left, reverse, c_off);
+    if (left < 0) hipLaunchKernelGGL(chunk_prefix_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)B), dim3(256), 0, s, csum, D, NC, reverse);
+  }
+  if (phase & 2) {
+    if (v2) hipLaunchKernelGGL((chunk_window_kernel<T, true>), grid, dim3(256), 0, s, csum, (T*)out, ldo, T_, D, chunk, NC, left, reverse, c_off, carry, carry_c0, carry_n);
+    else hipLaunchKernelGGL((chunk_window_kernel<T, false>), grid, dim3(256), 0, s, csum, (T*)out, ldo, T_, D, chunk, NC, left, reverse, c_off, carry, carry_c0, carry_n);
+  }
   return check_launch("smx_chunk_mean");
 }
 
@@ -1762,19 +1794,44 @@ extern "C" int smx_chunk_mean_bwd(int dtype, const void* dOut, int64_t ldo, void
   return chunk_mean_impl<float>(dOut, ldo, dS, lds, B, T, D, chunk, left, 1, workspace, STREAM);
 }
 
+// Sequence-parallel shards of whole chunks (sequence_parallel.py; summary_mixing.py:224-235 with the mask of TransformerASR.py:85-110):
+// the shard holds chunks [c_off, c_off + T / chunk) of the sequence.  phase 1: chunk sums into the workspace (B, T / chunk, D) float32
+// - reverse: scaled by 1 / window length of the GLOBAL chunk; left < 0: turned into running sums - whose rows are what the shards
+// exchange (the last `left` rows / the last running sum forward, the first ones in reverse).  phase 2: the window combine; chunk c
+// adds carry[b][c - carry_c0] (float32 (B, carry_n, D); carry_n == 0: one (B, D) row for every chunk), forward divides by the
+// GLOBAL window length.  No elementwise pass over the activations happens outside these kernels.
+extern "C" int smx_chunk_mean_sharded(int dtype, const void* X, int64_t ldx, void* out, int64_t ldo, int B, int T, int D, int chunk,
+                                      int left, int reverse, int c_off, int phase, const float* carry, int carry_c0, int carry_n,
+                                      void* workspace, void* stream) {
+  SMX_REQUIRE(workspace && chunk > 0 && T % chunk == 0 && c_off >= 0 && (phase == 1 || phase == 2) && carry_n >= 0 && carry_c0 >= 0,
+              "smx_chunk_mean_sharded: shards hold whole chunks; phase 1 or 2");
+  SMX_REQUIRE(phase == 1 ? X != nullptr : out != nullptr, "smx_chunk_mean_sharded: null pointer");
+  if (B <= 0 || T <= 0 || D <= 0) return SMX_OK;
+  if (dtype == SMX_BF16) return chunk_mean_impl<bf16_t>(X, ldx, out, ldo, B, T, D, chunk, left, reverse, workspace, STREAM, phase, c_off, carry, carry_c0, carry_n);
+  return chunk_mean_impl<float>(X, ldx, out, ldo, B, T, D, chunk, left, reverse, workspace, STREAM, phase, c_off, carry, carry_c0, carry_n);
+}
+
 extern "C" size_t smx_expdecay_mean_workspace(int B, int T, int D) {
   return (size_t)B * ((T + ED_CH - 1) / ED_CH) * 2 * D * sizeof(float);
 }
 
+// phase 3: the whole operator; 1: chunk states + the shard's LEAVING states into `ends` (2, B, D); 2: carries (from the ENTERING states
+// in `ends`) + both scans out (the workspace of phase 1 must still hold the chunk states)
 template <typename T>
 static int expdecay_impl(const void* X, int64_t ldx, void* Y, int64_t ldy, int B, int T_, int D, float gamma, int mode,
-                         void* ws, hipStream_t s) {
+                         void* ws, hipStream_t s, int phase = 3, int t_off = 0, int T_glob = 0, float* ends = nullptr) {
   const int NC = (T_ + ED_CH - 1) / ED_CH;
+  if (T_glob <= 0) T_glob = T_;
   dim3 grid((D + 255) / 256, (NC + 3) / 4, B);
+  const dim3 gc((unsigned)(((long)B * D + 255) / 256));
   float* w = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL((expdecay_chunk_kernel<T>), grid, dim3(256), 0, s, (const T*)X, ldx, w, T_, D, NC, gamma, mode);
-  hipLaunchKernelGGL(expdecay_carry_kernel, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, s, w, D, NC, B, gamma);
-  hipLaunchKernelGGL((expdecay_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)X, ldx, w, (T*)Y, ldy, T_, D, NC, gamma, mode);
+  if (phase & 1) hipLaunchKernelGGL((expdecay_chunk_kernel<T>), grid, dim3(256), 0, s, (const T*)X, ldx, w, T_, D, NC, gamma, mode, t_off, T_glob);
+  if (phase == 1) hipLaunchKernelGGL(expdecay_carry_kernel, gc, dim3(256), 0, s, w, D, NC, B, gamma, (const float*)nullptr, (const float*)nullptr, ends, T_);
+  if (phase & 2) {
+    const float* fin = phase == 2 ? ends : nullptr;
+    hipLaunchKernelGGL(expdecay_carry_kernel, gc, dim3(256), 0, s, w, D, NC, B, gamma, fin, fin ? fin + (long)B * D : nullptr, (float*)nullptr, T_);
+    hipLaunchKernelGGL((expdecay_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)X, ldx, w, (T*)Y, ldy, T_, D, NC, gamma, mode, t_off, T_glob);
+  }
   return check_launch("smx_expdecay_mean");
 }
 
@@ -1803,6 +1860,26 @@ extern "C" int smx_expdecay_mean_bwd(int dtype, const void* dOut, int64_t ldo, v
   if (dtype == SMX_BF16) return expdecay_impl<bf16_t>(dOut, ldo, dS, lds, B, T, D, decay, 1, workspace, STREAM);
   return expdecay_impl<float>(dOut, ldo, dS, lds, B, T, D, decay, 1, workspace, STREAM);
 }
+
+// The expdecay summary on a sequence-parallel shard (frames [t_off, t_off + T) of T_glob): the filter crosses the boundary through ONE
+// (B, D) state per direction.  phase 1: ends (2, B, D) <- the states LEAVING the shard (f at its last frame, g at its first) for zero
+// entering states; the caller gathers them and folds f_in = ends_q[0] + decay^T f_in over the earlier shards (g_in over the later
+// ones) - (B, D) arithmetic - into `ends`; phase 2 (same workspace): out = the operator with those ENTERING states and the
+// denominators of the GLOBAL frame index (summary_mixing.py:316-365; mode 0 forward, 1 the transposed operator M (s / rowsum(M))).
+extern "C" int smx_expdecay_mean_sharded(int dtype, const void* S, int64_t lds, void* out, int64_t ldo, int B, int T, int D, float decay,
+                                         int mode, int t_off, int T_glob, int phase, float* ends, void* workspace, void* stream) {
+  SMX_REQUIRE(S && workspace && ends && (phase == 1 || phase == 2) && (mode == 0 || mode == 1) && t_off >= 0 && T_glob >= t_off + T,
+              "smx_expdecay_mean_sharded: bad arguments");
+  SMX_REQUIRE(decay > 0.f && decay < 1.f, "smx_expdecay_mean_sharded: 0 < decay < 1");
+  const size_t es = dtype == SMX_BF16 ? 2 : 4;
+  SMX_REQUIRE(D % 4 == 0 && lds % 4 == 0 && (reinterpret_cast<uintptr_t>(S) % (4 * es)) == 0 && aligned16(workspace) && aligned16(ends) &&
+                  (phase == 1 || (out && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) % (4 * es)) == 0)),
+              "smx_expdecay_mean_sharded: needs D, leading dimensions multiples of 4 and aligned pointers");
+  if (B <= 0 || T <= 0 || D <= 0) return SMX_OK;
+  if (dtype == SMX_BF16) return expdecay_impl<bf16_t>(S, lds, out, ldo, B, T, D, decay, mode, workspace, STREAM, phase, t_off, T_glob, ends);
+  return expdecay_impl<float>(S, lds, out, ldo, B, T, D, decay, mode, workspace, STREAM, phase, t_off, T_glob, ends);
+}
+
 
 extern "C" int smx_layernorm_fwd(int dtype, const void* X, int64_t ldx, const float* gamma, const float* beta, void* Y,
                                  int64_t ldy, float* stats, int N, int D, float eps, int act, void* stream) {

@@ -633,89 +633,59 @@ class DynChunkMask:
 def _chunk_mean_seqpar(x, out, B, T, chunk, left, reverse=False):
     """The Dynamic Chunk Training summary (chunk c averages the chunks [c - left, c], all earlier ones with left = None:
     summary_mixing.py:224-235 with the mask of TransformerASR.py:85-110) with the time axis sharded over the sequence group.
-    Shards hold whole chunks (T % chunk == 0), so a window reaches into other shards only through chunk SUMS: the local kernel
-    (fp32, its local window sizes multiplied back out) gives the local part of every window sum; left = None adds the totals of
-    all earlier shards (one all-gather of (B, D)), a finite left the last `left` chunk sums of the previous shard ((B, left, D);
-    needs left <= chunks per shard); the denominators count the chunks of the GLOBAL window.
-    reverse: the transposed operator M^T (x / rowsum(M)) - the same exchange towards the LATER shards."""
+    Shards hold whole chunks (T % chunk == 0), so a window reaches into other shards only through chunk SUMS.  Round 6: the
+    arithmetic is two launches of the chunk kernels themselves (smx_chunk_mean_sharded: global chunk indices and window lengths,
+    an additive carry per chunk) around ONE all-gather of small tensors - left = None: the (B, D) totals of the shards, a finite
+    left: the (B, left, D) chunk sums at the shard's edge (needs left <= chunks per shard); nothing of activation size is touched
+    outside the kernels.  reverse: the transposed operator M^T (x / rowsum(M)) - the same exchange towards the LATER shards."""
     W, r = SP.world(), SP.rank()
     if T % chunk != 0:
         raise ValueError(f"sequence-parallel Dynamic Chunk Training: the frames per rank ({T}) must be a multiple of the chunk size ({chunk})")
     C = T // chunk
     if left is not None and left > C:
         raise NotImplementedError(f"sequence-parallel Dynamic Chunk Training: left context {left} chunks > {C} chunks per rank")
-    dev = x.device
     D = x.shape[1]
-    c_loc = torch.arange(C, device=dev)
-    c_glob = c_loc + r * C
-
-    def win(c):                                               # frames in the window of chunk c
-        return ((c if left is None else c.clamp(max=left)) + 1).float() * chunk
-    den_loc, den_glob = win(c_loc)[None, :, None, None], win(c_glob)[None, :, None, None]
-    x4 = x.float().view(B, C, chunk, D)
-    if reverse:
-        x4 = x4 / den_glob * den_loc                          # (the kernel divides by its local window sizes)
-    num = torch.empty((B * T, D), dtype=torch.float32, device=dev)
-    ops.chunk_mean(x4.reshape(B * T, D), num, B, T, chunk, left, reverse=reverse)
-    num = num.view(B, C, chunk, D)
-    if not reverse:
-        num *= den_loc
-    # chunk sums that cross the shard boundary (forward: from earlier shards; transposed: from later ones)
-    src = x4 / den_loc if reverse else x4                     # (transposed: sums of g / den_glob)
+    ws = torch.empty((B, C, D), dtype=torch.float32, device=x.device)
+    ops.chunk_mean_sharded(x, None, B, T, D, chunk, left, reverse, r * C, 1, ws)
+    carry, c0, cn = None, 0, 0
     if left is None:
-        tot = SP.all_gather(src.sum((1, 2)))                 # (B, D) per rank
+        # running sums: the shard's total is the last row (forward) / the first (transposed operator)
+        tot = SP.all_gather((ws[:, 0] if reverse else ws[:, C - 1]).contiguous())
         others = range(r + 1, W) if reverse else range(r)
-        add = sum((tot[q] for q in others), torch.zeros_like(tot[0]))
-        num += add[:, None, None, :]
+        if len(others) > 0:
+            carry = sum((tot[q] for q in others), torch.zeros_like(tot[0])).contiguous()
     elif left > 0:
-        edge = src[:, :left].sum(2) if reverse else src[:, C - left:].sum(2)      # (B, left, D): what the neighbour's windows reach
-        edges = SP.all_gather(edge.contiguous())
+        edges = SP.all_gather((ws[:, :left] if reverse else ws[:, C - left:]).contiguous())     # (B, left, D): what the neighbour's windows reach
         if reverse and r < W - 1:
-            pre = edges[r + 1].cumsum(1)                      # chunks [0, i] of the next shard
-            num[:, C - left:] += pre[:, :, None, :]           # local chunk C - left + i reaches the next shard's chunks [0, i]
+            carry, c0, cn = edges[r + 1].cumsum(1).contiguous(), C - left, left    # local chunk C - left + i reaches the next shard's chunks [0, i]
         elif not reverse and r > 0:
-            suf = edges[r - 1].flip(1).cumsum(1).flip(1)      # chunks [C - left + i, C) of the previous shard
-            num[:, :left] += suf[:, :, None, :]               # local chunk i reaches back to the previous shard's chunk C - left + i
-    if not reverse:
-        num /= den_glob
-    out.view(B, C, chunk, D).copy_(num)
+            carry, c0, cn = edges[r - 1].flip(1).cumsum(1).flip(1).contiguous(), 0, left   # local chunk i reaches back to chunk C - left + i
+    ops.chunk_mean_sharded(None, out, B, T, D, chunk, left, reverse, r * C, 2, ws, carry, c0, cn)
     return out
 
 
 def _expdecay_seqpar(x, out, B, T, decay, reverse=False):
     """The expdecay summary with the time axis sharded over the sequence group: x / out are this rank's (B*T, D) rows of
     a (B, world*T, D) sequence.  (M x)_t = f_t + g_t - x_t is two recurrences, so the rows of a shard see the other shards
-    only through ONE (B, D) state per direction: the local O(T) kernel (fp32, its LOCAL denominators multiplied back out)
-    gives the local numerators; their first / last rows are the states leaving the shard (g at row 0, f at row T-1), one
-    all-gather of (2, B, D) per rank carries them, and the states entering add decay^(t+1) f_in + decay^(T-t) g_in.
-    The denominators rowsum(M) are closed forms of the GLOBAL frame index (rowwise.hip ed_inv_den, float64 here).
+    only through ONE (B, D) state per direction.  Round 6: smx_expdecay_mean_sharded runs the O(T) kernels with the GLOBAL frame
+    index in the denominators (rowwise.hip ed_inv_den) and the entering states as the scans' initial values; between its two
+    phases ONE all-gather of (2, B, D) per rank carries the leaving states and a (B, D) fold turns them into the entering ones.
     reverse: M (x / rowsum(M)), the transposed operator (M is symmetric)."""
     W, r = SP.world(), SP.rank()
     g = float(decay)
-    t = torch.arange(T, device=x.device, dtype=torch.float64)
-
-    def den(tt, TT):
-        return (2.0 - g ** (tt + 1.0) - g ** (TT - tt)) / (1.0 - g) - 1.0
-    den_loc, den_glob = den(t, float(T)).float()[None, :, None], den(t + r * T, float(W * T)).float()[None, :, None]
-    x3 = x.float().view(B, T, -1)
-    if reverse:
-        x3 = x3 / den_glob
-    num = torch.empty_like(x3)
-    ops.expdecay_mean(x3.view(B * T, -1), num.view(B * T, -1), B, T, decay)
-    num *= den_loc
-    ends = SP.all_gather(torch.stack([num[:, T - 1], num[:, 0]]))             # per rank: (f leaving right, g leaving left)
+    D = x.shape[1]
+    ws = torch.empty((L.lib().smx_expdecay_mean_workspace(B, T, D) + 3) // 4, dtype=torch.float32, device=x.device)
+    ends = torch.empty((2, B, D), dtype=torch.float32, device=x.device)
+    ops.expdecay_mean_sharded(x, None, B, T, g, reverse, r * T, W * T, 1, ends, ws)
+    allends = SP.all_gather(ends)                                               # per rank: (f leaving right, g leaving left)
     gT = g ** T
-    f_in = torch.zeros_like(ends[0][0])
+    f_in = torch.zeros_like(ends[0])
     for q in range(r):                                                          # f entering = f_{q} + decay^T f entering q
-        f_in = ends[q][0] + gT * f_in
+        f_in = allends[q][0] + gT * f_in
     g_in = torch.zeros_like(f_in)
     for q in range(W - 1, r, -1):
-        g_in = ends[q][1] + gT * g_in
-    wf, wg = (g ** (t + 1.0)).float()[None, :, None], (g ** (T - t)).float()[None, :, None]
-    num += wf * f_in[:, None, :] + wg * g_in[:, None, :]
-    if not reverse:
-        num /= den_glob
-    out.view(B, T, -1).copy_(num)
+        g_in = allends[q][1] + gT * g_in
+    ops.expdecay_mean_sharded(x, out, B, T, g, reverse, r * T, W * T, 2, torch.stack([f_in, g_in]).contiguous(), ws)
     return out
 
 
@@ -828,9 +798,6 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
         if sp and pool_kind not in ("mean", "expdecay", "chunk"):
             raise NotImplementedError("sequence-parallel mode supports the per-utterance mean, the Dynamic Chunk Training mask and "
                                       "the mask-free expdecay summary (no dense sum_mask)")
-        if sp and p_drop > 0.0:
-            raise NotImplementedError("sequence-parallel mode is dropout-free: the fused dropout masks are indexed by the "
-                                      "LOCAL frame row, every shard would draw the same mask")
         if sp and pool_kind == "expdecay":
             sbar = torch.empty((N, sdim), dtype=dtype, device=dev)
             _expdecay_seqpar(s, sbar, B, T, decay)

@@ -135,9 +135,6 @@ class BranchformerEncoderLayer(nn.Module):
 
     def make_run(self, B, T, m8, src_mask, compute_dtype=None):
         sp = SP.enabled()       # time axis sharded over the ranks: the CSGU's depthwise conv gets halos (below), the cell its all-reduce
-        if sp and self.training and self.p_drop > 0.0:
-            raise NotImplementedError("sequence-parallel mode is dropout-free: the fused dropout masks are indexed by the LOCAL "
-                                      "frame row, every shard would draw the same mask")
         act = self.act
         pd = self.p_drop if self.training else 0.0
         cell = F.cell_run(self.mha_layer._params(), self.mha_layer._cfg(), B, T, m8, src_mask,

@@ -266,6 +266,49 @@ def gemm_panel(a, wp, c, N, M, K, epi=None):
     return c
 
 
+def panel_slabs_ok(a, M, K, nslice):
+    return a.dtype == torch.bfloat16 and L.lib().smx_gemm_panel_slabs_ok(L.BF16, a.shape[0], M, K, nslice) == 1
+
+
+def gemm_panel_slabs(a, wp, slabs, N, M, K, nslice):
+    """slabs[s] (N x M, fp32) = A[:, s K:(s + 1) K] W_s^T (smx_gemm_panel_slabs): A (N, nslice K) bf16, wp = nslice consecutive
+    weight_pack images (weight_pack_slices)."""
+    pa, la = _mat(a)
+    tok = _pb(f"gemm panel slabs bf16 ({N}x{nslice * K})x({nslice * K}x{M}) S={nslice}", (N * nslice * K + M * nslice * K) * 2 + nslice * N * M * 4,
+              2.0 * N * M * K * nslice, f"gemm_panel_kernel<{K}, 2, 0>")
+    L.check(L.lib().smx_gemm_panel_slabs(L.BF16, pa, la, _p(wp), _p(slabs), N, M, K, nslice, _stream()), "smx_gemm_panel_slabs")
+    _pe(tok)
+    return slabs
+
+
+def weight_pack_slices(W, K, transposed=False, out=None):
+    """The K-slices of a bf16 weight packed one after the other (no bias) for gemm_panel_slabs.  W (M, nslice K) [transposed=False:
+    a forward Linear's weight, slices = column ranges] or (nslice K, M) [transposed=True: the same weight seen from its dgrad,
+    slices = row ranges]."""
+    Ktot, M = (W.shape[0], W.shape[1]) if transposed else (W.shape[1], W.shape[0])
+    ns = Ktot // K
+    assert ns * K == Ktot
+    per = L.lib().smx_weight_pack_bytes(M, K) // 2
+    if out is None:
+        out = torch.empty((ns * per,), dtype=torch.bfloat16, device=W.device)
+    for s_ in range(ns):
+        Ws = W[s_ * K:(s_ + 1) * K] if transposed else W[:, s_ * K:(s_ + 1) * K]
+        L.check(L.lib().smx_weight_pack(L.BF16, _p(Ws), Ws.stride(0), 1 if transposed else 0, None, M, K,
+                                        ctypes.c_void_p(out.data_ptr() + 2 * s_ * per), _stream()), "smx_weight_pack")
+    return out
+
+
+def slab_epilogue(slabs, nslab, c, N, M, epi):
+    """c = epilogue(sum of the float32 slabs) + the LayerNorm(s) the epilogue names (smx_slab_epilogue)."""
+    pc, lc = _mat(c)
+    tok = _pb(f"slab epilogue ({N}x{M}) S={nslab}{'+LNfwd' if epi.flags & L.EPI_LN_FWD else ''}",
+              N * M * (4 * nslab + c.element_size() + (4 if epi.io_flags & L.IO_RES_F32 else 2) * (1 if epi.res else 0) + 2 * (1 if epi.z else 0) +
+                       ((4 if epi.io_flags & L.IO_LNFY_F32 else 2) if epi.flags & L.EPI_LN_FWD else 0) + (2 if epi.lnf2_y else 0)))
+    L.check(L.lib().smx_slab_epilogue(L.BF16, _p(slabs), nslab, N * M, pc, lc, N, M, ctypes.byref(epi), _stream()), "smx_slab_epilogue")
+    _pe(tok)
+    return c
+
+
 def wgrad(dz, x, gW, rows, M, K, batch=1, sz=0, sx=0, sw=0, lddz=None, ldx=None, lddw=None, alpha=1.0, dbias=None):
     """gW[b] (M x K) += alpha * dz[b]^T x[b]  (slab split-K + fixed-order reduction; see smx_linear_wgrad).
     dbias (fp32 (batch, M), contiguous): += alpha * column sums of dz from the same launch (needs K % 4 == 0)."""
@@ -423,6 +466,26 @@ def expdecay_mean(s, out, B, T, decay, reverse=False):
     fn = L.lib().smx_expdecay_mean_bwd if reverse else L.lib().smx_expdecay_mean_fwd
     L.check(fn(dt(s), ps, lds, po, ldo, B, T, D, float(decay), _p(ws), _stream()), "smx_expdecay_mean")
     return out
+
+
+def chunk_mean_sharded(x, out, B, T, D, chunk, left, reverse, c_off, phase, ws, carry=None, carry_c0=0, carry_n=0):
+    """One phase of the DynChunk window mean on a sequence-parallel shard (smx_chunk_mean_sharded): phase 1 = chunk sums of x into ws
+    ((B, T // chunk, D) float32), phase 2 = window combine (+ carry) into out."""
+    px, ldx = _mat(x) if x is not None else (None, 0)
+    po, ldo = _mat(out) if out is not None else (None, 0)
+    t = x if x is not None else out
+    L.check(L.lib().smx_chunk_mean_sharded(dt(t), px, ldx, po, ldo, B, T, D, chunk, -1 if left is None else left, 1 if reverse else 0, c_off,
+                                           phase, _p(carry), carry_c0, carry_n, _p(ws), _stream()), "smx_chunk_mean_sharded")
+
+
+def expdecay_mean_sharded(x, out, B, T, decay, reverse, t_off, T_glob, phase, ends, ws):
+    """One phase of the expdecay summary on a sequence-parallel shard (smx_expdecay_mean_sharded): phase 1 fills ends (2, B, D) with the
+    states leaving the shard, phase 2 takes the states entering it from `ends` and writes out."""
+    D = x.shape[1]
+    px, ldx = _mat(x)
+    po, ldo = _mat(out) if out is not None else (None, 0)
+    L.check(L.lib().smx_expdecay_mean_sharded(dt(x), px, ldx, po, ldo, B, T, D, float(decay), 1 if reverse else 0, t_off, T_glob, phase,
+                                              _p(ends), _p(ws), _stream()), "smx_expdecay_mean_sharded")
 
 
 def layernorm_fwd(x, gamma, beta, eps, want_stats, act=L.ACT_NONE, out_dtype=None):
@@ -585,7 +648,17 @@ def new_dropout_seed():
     """A fresh 64-bit seed per dropout site and call, derived from torch's global seed and a call counter (no
     device sync)."""
     _drop_state["counter"] += 1
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _drop_state["counter"] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    # salt: 0, or rank + 1 of a sequence-parallel shard (set_seed_salt) - the fused masks are indexed by the LOCAL frame row, so every
+    # shard must draw from a seed of its own; forward and backward of a site use the same returned value either way
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _drop_state["counter"] * 0xD1B54A32D192ED03 +
+            _drop_state.get("salt", 0) * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
+
+
+def set_seed_salt(salt):
+    """Per-process salt of every dropout seed drawn from now on (sequence_parallel: rank + 1 inside the context, 0 outside)."""
+    prev = _drop_state.get("salt", 0)
+    _drop_state["salt"] = int(salt)
+    return prev
 
 
 def dropout(x, p, seed, out=None):

@@ -33,8 +33,8 @@ reduce them with reduce_gradients() (SUM over the group) before the optimizer.
     context (functional._chunk_mean_seqpar; the transposed operator sends the same sums the other way).
 
 Supported: ConformerEncoder(Layer) and BranchformerEncoder(Layer) with the per-utterance mean (modes SummaryMixing, -fast,
--lite), the mask-free expdecay summary or a DynChunk mask (Conformer), dropout-free.  A dense (T, T) sum_mask raises
-NotImplementedError.  Host-side plumbing only: the
+-lite), the mask-free expdecay summary or a DynChunk mask (Conformer), with or without dropout (per-rank seeds: round 6).  A dense
+(T, T) sum_mask raises NotImplementedError.  Host-side plumbing only: the
 arithmetic stays in libsmx.
 """
 import contextlib
@@ -67,12 +67,17 @@ def sequence_parallel(group=None):
     """with sequence_parallel(group): out, _ = encoder(x_local, src_key_padding_mask=mask_local); loss.backward()"""
     if not dist.is_initialized():
         raise RuntimeError("sequence_parallel needs an initialised torch.distributed process group")
+    from . import ops
     prev = (_State.group, _State.active, _State.rank, _State.world)
     _State.group, _State.active = group, True
     _State.rank, _State.world = dist.get_rank(group), dist.get_world_size(group)
+    # dropout (round 6): the fused masks are functions of (seed, LOCAL frame row, column); every shard salts the seeds it draws with
+    # its rank, so the shards' masks are independent - forward and backward of a site share the drawn seed as everywhere else
+    prev_salt = ops.set_seed_salt(_State.rank + 1)
     try:
         yield
     finally:
+        ops.set_seed_salt(prev_salt)
         _State.group, _State.active, _State.rank, _State.world = prev
 
 

@@ -151,3 +151,110 @@ def test_sequence_parallel_dynchunk(dynchunk):
 
 def test_sequence_parallel_dynchunk_full_mode_no_mask():
     _run("SummaryMixing", nomask=True, dynchunk="16,1")
+
+
+DROP_WORKER = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["SMX_ROOT"])
+from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+from summarymixing_amd import sequence_parallel as SP, ops
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+mode = os.environ["SMX_MODE"]
+d, B, T = 64, 3, 96
+torch.manual_seed(5)
+if os.environ.get("SMX_ENC") == "branchformer":
+    from summarymixing_amd.lobes.models.transformer.Branchformer import BranchformerEncoder
+    enc = BranchformerEncoder(2, d, 1, kernel_size=31, activation=torch.nn.GELU, dropout=0.2, attention_type="SummaryMixing",
+                              csgu_linear_units=128, local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d],
+                              summary_out_dim=d, mode=mode)
+else:
+    enc = ConformerEncoder(2, d, 128, 4, kernel_size=31, activation="swish", dropout=0.2, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode=mode)
+with torch.no_grad():
+    for n, p in enc.named_parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_normal_(p)
+enc = enc.cuda().train()
+x = torch.randn(B, T, d).cuda()
+r = torch.randn(B, T, d).cuda()
+v = torch.randn(B, T, d).cuda()
+lens = torch.tensor([T, 70, 40])
+pad = (torch.arange(T)[None] < lens[:, None]).cuda()
+kw = {}
+if os.environ.get("SMX_DYNCHUNK"):
+    from summarymixing_amd import functional as F
+    from summarymixing_amd.utils.dynamic_chunk_training import DynChunkTrainConfig
+    cs, lc = os.environ["SMX_DYNCHUNK"].split(",")
+    cs, lc = int(cs), (None if lc == "all" else int(lc))
+    kw = dict(src_mask=F.DynChunkMask(T // world, cs, lc), dynchunktrain_config=DynChunkTrainConfig(cs, lc))
+
+def loss_of(xl, pl, rl, want_grad):
+    """Local loss of this shard with the SAME dropout masks at every call (the seed counter is rewound)."""
+    ops._drop_state["counter"] = 1000
+    xin = xl.clone().requires_grad_(want_grad)
+    yl, _ = enc(xin, src_key_padding_mask=pl, **kw)
+    loss = (yl * rl).sum()
+    if want_grad:
+        loss.backward()
+    return loss.detach(), yl.detach(), (xin.grad if want_grad else None)
+
+with SP.sequence_parallel():
+    xl, pl, rl, vl = SP.shard(x), SP.shard(pad), SP.shard(r), SP.shard(v)
+    l0, y0, dx = loss_of(xl, pl, rl, True)
+    l1, y1, _ = loss_of(xl, pl, rl, False)
+    assert torch.equal(y0, y1), "same seeds, different outputs"
+    assert torch.isfinite(y0).all() and torch.isfinite(dx).all()
+    # the masks are live (training mode) ...
+    enc.eval(); _, ye, _ = loss_of(xl, pl, rl, False); enc.train()
+    assert (ye - y0).abs().max() > 1e-3
+    # ... and the backward uses the forward's masks: directional derivative of the GLOBAL loss along v (every shard its slice)
+    eps = 2e-3
+    lp, _, _ = loss_of(xl + eps * vl, pl, rl, False)
+    lm, _, _ = loss_of(xl - eps * vl, pl, rl, False)
+    num = (lp - lm).double() / (2 * eps)
+    ana = (dx * vl).sum().double()
+    both = torch.stack([num, ana]).cpu()
+    dist.all_reduce(both)
+    rel = abs(float(both[0] - both[1])) / max(abs(float(both[1])), 1e-6)
+    assert rel < 3e-2, f"directional derivative {float(both[0]):.6f} vs <dx, v> {float(both[1]):.6f}"
+    # the shards draw DIFFERENT masks: the seed a site would draw next differs by rank
+    seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(seeds, torch.tensor([ops.new_dropout_seed() & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64))
+    assert len({int(t) for t in seeds}) == world
+dist.barrier()
+print(f"rank {rank} OK")
+'''
+
+
+def _run_drop(mode, enc="conformer", dynchunk=""):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SMX_ROOT=ROOT, SMX_MODE=mode, SMX_ENC=enc, SMX_DYNCHUNK=dynchunk, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", DROP_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+            out += "\n[timeout]"
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {rank} OK" in out, f"rank {rank} failed:\n{out[-3000:]}"
+
+
+@pytest.mark.parametrize("mode,enc,dynchunk", [("SummaryMixing-fast", "conformer", ""), ("SummaryMixing", "branchformer", ""),
+                                               ("SummaryMixing-fast", "conformer", "8,2"), ("SummaryMixing-expdecay", "conformer", "")])
+def test_sequence_parallel_trains_with_dropout(mode, enc, dynchunk):
+    """Round 6: the sharded mode with dropout 0.2 in train() (it refused before: every shard would have drawn the same mask from a
+    seed indexed by LOCAL rows; now each rank salts the seeds it draws).  Same seeds -> bit-identical outputs; train != eval; the
+    backward reuses the forward's masks (directional derivative of the global loss against <dx, v>); the ranks' seeds differ."""
+    _run_drop(mode, enc, dynchunk)
