@@ -210,6 +210,20 @@ int smx_wgrad_group_splits(int rows, const smx_wgrad_item* items, int nitems);
 size_t smx_wgrad_group_workspace(int M, int K, int splits);
 int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items, int nitems, int splits, void* stream);
 
+/* Small batches (round 6): the same weight gradients WITHOUT split-K slabs - every 128 x 128 tile of every weight walks all `rows`
+ * frames and adds its product INTO the gradient, dW[i] (M x K, float32, row stride lddw) += dZ_i^T X_i, dbias[i] (M) += column sums of
+ * dZ_i (NULL: none).  No workspace, no smx_reduce_jobs pass; each gradient element has exactly one writer (bit-reproducible).  M, K
+ * multiples of 128.  The slab form above is the one for long batches (its K-slices fill the chip; this one would not). */
+typedef struct smx_wgrad_direct_item {
+  const void* dZ; int64_t lddz;
+  const void* X;  int64_t ldx;
+  float* dW; int64_t lddw;
+  float* dbias;
+  int32_t M, K;
+} smx_wgrad_direct_item;
+int smx_wgrad_group_direct_ok(int rows, int M, int K);
+int smx_wgrad_group_direct(int dtype, int rows, const smx_wgrad_direct_item* items, int nitems, void* stream);
+
 /* One launch for many small fixed-order reductions
  *   dst[i*ldd + j] += alpha * sum_{s < nsrc} src[s*src_stride + i*src_ld + j]      (i < rows, j < cols; src_ld 0 = cols)
  * : weight-gradient slabs, bias partials, LayerNorm dgamma/dbeta partial rows.  `vec` = 1

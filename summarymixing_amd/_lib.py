@@ -36,6 +36,12 @@ class WgradItem(ctypes.Structure):
                 ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("want_bias", ctypes.c_int32), ("pad", ctypes.c_int32)]
 
 
+class WgradDirectItem(ctypes.Structure):
+    """smx_wgrad_direct_item of include/smx.h."""
+    _fields_ = [("dZ", c_vp), ("lddz", c_i64), ("X", c_vp), ("ldx", c_i64), ("dW", c_vp), ("lddw", c_i64), ("dbias", c_vp),
+                ("M", ctypes.c_int32), ("K", ctypes.c_int32)]
+
+
 WGRAD_GROUP_MAX = 16
 
 
@@ -174,6 +180,8 @@ SIGNATURES = {
     "smx_slab_epilogue": (c_i, [c_i, c_vp, c_i, c_i64, c_vp, c_i64, c_i, c_i, ctypes.POINTER(Epilogue), c_vp]),
     "smx_chunk_mean_sharded": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_i, c_vp, c_vp]),
     "smx_expdecay_mean_sharded": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
+    "smx_wgrad_group_direct_ok": (c_i, [c_i, c_i, c_i]),
+    "smx_wgrad_group_direct": (c_i, [c_i, c_i, ctypes.POINTER(WgradDirectItem), c_i, c_vp]),
     "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
     "smx_stream_capture_id": (c_i, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "smx_sumsq_workspace": (c_sz, []),

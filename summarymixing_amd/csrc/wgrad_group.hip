@@ -21,12 +21,9 @@
 // gradients by smx_reduce_jobs in a fixed order (bit-reproducible, no atomics).
 #include <stdlib.h>
 
-#include "smx_common.h"
+#include "gemm_common.h"
 
 namespace smx {
-
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 constexpr int WG_MAX_ITEMS = SMX_WGRAD_GROUP_MAX;
 constexpr int WG_TILE = 256;
@@ -304,6 +301,168 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const WgGroupParams
   }
 }
 
+// =================================================================================================================================
+// Round 6, small batches: the weight gradients of a layer in ONE launch WITHOUT split-K slabs.  A few thousand frames are a short
+// reduction: the 256 x 256 kernel above needs 2 K-slices per tile to occupy 184 of 256 CUs (recipe batch, 3750 frames: 65 us), writes
+// 47 MB of float32 slabs and leaves smx_reduce_jobs 100 MB to fold (25-33 us).  Here every 128 x 128 tile of every weight walks ALL
+// the frames (368 tiles at d_model 512: two workgroups per CU, one round) on the LDS-DMA ring of gemm_tn_dma_kernel (gemm.hip: both
+// operands reduce-strided, 64-frame stages, ring of two, no operand VGPRs) and adds its tile INTO the gradient (float32
+// read-modify-write, each element owned by exactly one workgroup: fixed order, bit-reproducible, no atomics, no workspace).
+// Bias gradient: one extra MFMA per fragment against a ones fragment in the waves of the first X column tile, added into dbias.
+// =================================================================================================================================
+struct WgDirectItem {
+  const bf16_t* A; const bf16_t* B;     // dZ (rows x M), X (rows x K)
+  float* dW; float* dbias;              // (M x K) float32, row stride lddw; (M) or null
+  long lda, ldb, lddw;
+  int M, K, tile0, tiles_m;             // first global tile of this weight, K / 128
+};
+struct WgDirectParams {
+  WgDirectItem it[WG_MAX_ITEMS];
+  int nitems, total_tiles, rows;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_group_direct_kernel(const WgDirectParams p) {
+  typedef bf16_t T;
+  constexpr int BK = 64, NST = 2, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
+  constexpr int OP_BYTES = BK * TILE * 2, STAGE_BYTES = 2 * OP_BYTES, NPC = BK / 16;
+  constexpr int PH_ROWS = 64, STG_LD = TILE * 4 + 16;
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE_BYTES];      // the ring (64 KB); the epilogue rows alias it
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave >> 1, wm = wave & 1, l31 = lane & 31, hi = lane >> 5;
+  // each XCD (workgroup id % 8) takes a contiguous run of tiles: the tiles of one weight that share operand columns meet in one L2
+  const int per = (p.total_tiles + 7) >> 3;
+  const int tg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || tg >= p.total_tiles) return;
+  int w = 0;
+#pragma unroll 1
+  for (int i = 1; i < p.nitems; ++i)
+    if (tg >= p.it[i].tile0) w = i;
+  const WgDirectItem& it = p.it[w];
+  const int tl = tg - it.tile0, tile_n = tl / it.tiles_m, tile_m = tl % it.tiles_m;
+  const int n0 = tile_n * TILE, m0 = tile_m * TILE;
+  const int rows_main = p.rows - p.rows % BK, niter = rows_main / BK;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)smem;
+  const int prow = lane >> 4, gsrc = ((lane & 15) ^ (prow << 2)) * 8;      // this lane's k row in a piece, source column
+  const T* pa[NPC];
+  const T* pb[NPC];
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const long kr = 4 * (wave + 4 * j) + prow;
+    pa[j] = it.A + kr * it.lda + n0 + gsrc;
+    pb[j] = it.B + kr * it.ldb + m0 + gsrc;
+  }
+  const long stepa = (long)BK * it.lda, stepb = (long)BK * it.ldb;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
+  auto issue = [&](int itn) {
+    const uint32_t dst = wave_lds + (itn % NST) * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      glds16(pa[j], dst + j * 4096);
+      glds16(pb[j], dst + OP_BYTES + j * 4096);
+      pa[j] += stepa;
+      pb[j] += stepb;
+    }
+  };
+  f32x16 acc[FN][FM], accb[FN];
+#pragma unroll
+  for (int i = 0; i < FN; ++i) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accb[i][q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FM; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  }
+  const bool do_cs = it.dbias != nullptr && tile_m == 0 && wm == 0;          // (uniform per wave)
+  const uint32_t one2 = 0x3F803F80u;
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2));
+  auto multiply = [&](const char* As, const char* Bs) __attribute__((always_inline)) {
+    bf16x8 fa[2][FN], fb[2][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i) fa[0][i] = frag_tr_swz(As, wn * WN + i * 32 + l31, 0, hi);
+#pragma unroll
+    for (int j = 0; j < FM; ++j) fb[0][j] = frag_tr_swz(Bs, wm * WM + j * 32 + l31, 0, hi);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 16) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) fa[nxt][i] = frag_tr_swz(As, wn * WN + i * 32 + l31, kk + 1, hi);
+#pragma unroll
+        for (int j = 0; j < FM; ++j) fb[nxt][j] = frag_tr_swz(Bs, wm * WM + j * 32 + l31, kk + 1, hi);
+      }
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0);
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fa[cur][i], accb[i], 0, 0, 0);
+      }
+    }
+  };
+  if (niter > 0) issue(0);
+  for (int itn = 0; itn < niter; ++itn) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage itn have landed (ring of two: nothing younger in flight)
+    lds_barrier();                                       // ... and everybody's; the stage read last step is free again
+    if (itn + 1 < niter) issue(itn + 1);
+    const char* As = smem + (itn % NST) * STAGE_BYTES;
+    multiply(As, As + OP_BYTES);
+  }
+  // ---- ragged tail (rows % 64 frames): guarded 16-byte loads - zeros behind the last frame - into the image the DMA writes ----
+  if (p.rows > rows_main) {
+    lds_barrier();                                       // every wave is done with the stage it read last
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int kr = rows_main + 4 * (wave + 4 * j) + prow;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+      if (kr < p.rows) {
+        va = *reinterpret_cast<const uint4*>(it.A + (long)kr * it.lda + n0 + gsrc);
+        vb = *reinterpret_cast<const uint4*>(it.B + (long)kr * it.ldb + m0 + gsrc);
+      }
+      char* d = smem + wave * 1024 + j * 4096 + lane * 16;
+      *reinterpret_cast<uint4*>(d) = va;
+      *reinterpret_cast<uint4*>(d + OP_BYTES) = vb;
+    }
+    __syncthreads();
+    multiply(smem, smem + OP_BYTES);
+  }
+  if (do_cs && hi == 0) {
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0 + wn * WN + i * 32 + l31;
+      it.dbias[n] += accb[i][0];                         // (this wave is the only writer of these 32 entries)
+    }
+  }
+  // ---- epilogue: 64 staged rows at a time, dW += tile (float4 read-modify-write, whole 512-byte row segments) ----
+#pragma unroll 1
+  for (int ph = 0; ph < 2; ++ph) {
+    lds_barrier();
+    if (wn == ph) {
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(smem + (i * 32 + l31) * STG_LD + (wm * WM + j * 32 + g * 8 + hi * 4) * 4) =
+                make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+    }
+    lds_barrier();
+    // thread t: column group (t & 31) * 4, rows (t >> 5) + 8 k
+    float* gp = it.dW + (long)(n0 + ph * PH_ROWS + (t >> 5)) * it.lddw + m0 + (t & 31) * 4;
+    float4 old[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) old[k] = *reinterpret_cast<const float4*>(gp + (long)(8 * k) * it.lddw);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(smem + ((t >> 5) + 8 * k) * STG_LD + (t & 31) * 16);
+      *reinterpret_cast<float4*>(gp + (long)(8 * k) * it.lddw) = make_float4(old[k].x + a.x, old[k].y + a.y, old[k].z + a.z, old[k].w + a.w);
+    }
+  }
+}
+
 static int wg_splits(int rows, int total_tiles) {
   // K slices per tile: tiles * s workgroups run in rounds of one per CU, so the choice is a quantisation problem: 23 tiles
   // (C2b layer) x 11 = 253 fills one round; 92 tiles (d_model 512) x 2 = 184 leaves 28 % of the chip idle, x 3 = 276 needs a
@@ -391,4 +550,35 @@ extern "C" int smx_wgrad_group(int dtype, int rows, const smx_wgrad_item* items,
   // 32-frame ring stages (ring of four) with the ping-pong refill order: the measured best of {32, 64} x {none, ping-pong, + mid-step barrier}
   hipLaunchKernelGGL(wgrad_group_kernel<32>, dim3(8 * per), dim3(512), 131072, s, p);
   return check_launch("smx_wgrad_group");
+}
+
+extern "C" int smx_wgrad_group_direct_ok(int rows, int M, int K) {
+  return rows >= 1 && M > 0 && K > 0 && M % 128 == 0 && K % 128 == 0;
+}
+
+extern "C" int smx_wgrad_group_direct(int dtype, int rows, const smx_wgrad_direct_item* items, int nitems, void* stream) {
+  SMX_REQUIRE(dtype == SMX_BF16, "smx_wgrad_group_direct: bf16 only");
+  SMX_REQUIRE(items && nitems >= 1 && nitems <= WG_MAX_ITEMS, "smx_wgrad_group_direct: 1..%d items per launch", WG_MAX_ITEMS);
+  SMX_REQUIRE(rows >= 1, "smx_wgrad_group_direct: no rows");
+  WgDirectParams p;
+  memset(&p, 0, sizeof(p));
+  int tiles = 0;
+  for (int i = 0; i < nitems; ++i) {
+    const smx_wgrad_direct_item& s = items[i];
+    SMX_REQUIRE(s.dZ && s.X && s.dW, "smx_wgrad_group_direct: null pointer in item %d", i);
+    SMX_REQUIRE(smx_wgrad_group_direct_ok(rows, s.M, s.K), "smx_wgrad_group_direct: item %d: M, K must be multiples of 128", i);
+    SMX_REQUIRE(aligned16(s.dZ) && aligned16(s.X) && aligned16(s.dW) && s.lddz % 8 == 0 && s.ldx % 8 == 0 && s.lddw % 4 == 0 &&
+                    s.lddz >= s.M && s.ldx >= s.K && s.lddw >= s.K,
+                "smx_wgrad_group_direct: item %d: operands must be 16-byte aligned (lddz, ldx %% 8 == 0, lddw %% 4 == 0)", i);
+    WgDirectItem& d = p.it[i];
+    d.A = reinterpret_cast<const bf16_t*>(s.dZ); d.B = reinterpret_cast<const bf16_t*>(s.X);
+    d.dW = s.dW; d.dbias = s.dbias;
+    d.lda = s.lddz; d.ldb = s.ldx; d.lddw = s.lddw; d.M = s.M; d.K = s.K;
+    d.tile0 = tiles; d.tiles_m = s.K / 128;
+    tiles += (s.M / 128) * (s.K / 128);
+  }
+  p.nitems = nitems; p.total_tiles = tiles; p.rows = rows;
+  const int per = (tiles + 7) / 8;
+  hipLaunchKernelGGL(wgrad_group_direct_kernel, dim3(8 * per), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("smx_wgrad_group_direct");
 }

@@ -217,6 +217,9 @@ class _Deferred:
     # (from the kernel's minimum of 64 frames: below 2048 the eight slab GEMMs + reductions it replaces are eight latency-bound
     #  launches - C2b training step at B = 1 x 500: 5.36 -> 4.00 ms, C2a at 2 x 375: 7.11 -> 5.43 ms)
     group_min_rows = 64
+    # up to this many frames the grouped wgrad runs WITHOUT split-K slabs (smx_wgrad_group_direct: 128 x 128 tiles over all the frames,
+    # added into the gradients; SMX_WGRAD_DIRECT_MAX_ROWS=0 switches it off): measured in tools/experiments/r06_smalln/wgrad_direct_bench.py
+    group_direct_max_rows = int(os.environ.get("SMX_WGRAD_DIRECT_MAX_ROWS", "8192"))
 
 
 def _evict_workspaces():
@@ -262,6 +265,16 @@ def _launch_groups():
     lib = L.lib()
     for N, rs in by_n.items():
         n64 = N                                 # (the kernel stages the N % 64 tail frames itself)
+        # (measured, us per layer, slabs + reduce_jobs | direct: d_model 512 - 368 tiles of 128 x 128 - 500 frames 42 | 20, 3750: 83 | 70,
+        #  8000: 146 | 135, 12000: 201 | 222; d_model 256 - 100 tiles, less than half a workgroup per CU - 500: 30 | 12, 2000: 38 | 29,
+        #  3750: 44 | 46, 8000: 55 | 87)
+        tiles128 = sum((M // 128) * (K // 128) for _, _, _, _, _, M, K in rs)
+        if (N <= _Deferred.group_direct_max_rows and (tiles128 >= 256 or N <= 2560) and
+                all(g.stride(1) == 1 and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 for _, _, g, _, _, _, _ in rs)):
+            # small batches (round 6): no K-slices, no slabs, no reduction job - every tile adds its product into the gradient
+            for c0 in range(0, len(rs), L.WGRAD_GROUP_MAX):
+                ops.wgrad_group_direct([(dz, x, gW, dbias, M, K) for dz, x, gW, dbias, _, M, K in rs[c0:c0 + L.WGRAD_GROUP_MAX]], N)
+            continue
         for c0 in range(0, len(rs), L.WGRAD_GROUP_MAX):
             chunk = rs[c0:c0 + L.WGRAD_GROUP_MAX]
             items = (L.WgradItem * len(chunk))()

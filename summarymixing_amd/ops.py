@@ -354,6 +354,24 @@ def wgrad_group(items, nitems, rows, splits):
     _pe(tok)
 
 
+def wgrad_group_direct(recs, rows):
+    """All the weight gradients of a layer in one launch, added INTO the gradients (smx_wgrad_group_direct, small batches):
+    recs = [(dz, x, gW, dbias | None, M, K), ...] with gW (M, K) float32 views."""
+    n = len(recs)
+    items = (L.WgradDirectItem * n)()
+    for it, (dz, x, gW, dbias, M, K) in zip(items, recs):
+        it.dZ, it.lddz, it.X, it.ldx = dz.data_ptr(), dz.stride(0), x.data_ptr(), x.stride(0)
+        it.dW, it.lddw, it.dbias, it.M, it.K = gW.data_ptr(), gW.stride(0), (dbias.data_ptr() if dbias is not None else None), M, K
+    tok = None
+    if _PROF is not None:
+        nb = sum((M + K) * rows * 2 + 8 * M * K for _, _, _, _, M, K in recs)
+        fl = sum(2.0 * rows * M * K for _, _, _, _, M, K in recs)
+        tok = _pb(f"wgrad_group direct bf16 ({n} weights: " + " ".join(f"{M}x{K}" for _, _, _, _, M, K in recs) + f") over {rows} frames", nb, fl,
+                  "wgrad_group_direct_kernel")
+    L.check(L.lib().smx_wgrad_group_direct(L.BF16, rows, items, n, _stream()), "smx_wgrad_group_direct")
+    _pe(tok)
+
+
 def reduce_jobs(jobs_dev, starts_dev, njobs, total_blocks, nbytes=0):
     tok = _pb(f"reduce_jobs ({njobs} jobs)", nbytes)
     L.check(L.lib().smx_reduce_jobs(_p(jobs_dev), _p(starts_dev), njobs, total_blocks, _stream()), "smx_reduce_jobs")

@@ -988,3 +988,37 @@ def test_reduce_jobs_many_jobs_and_ragged_tails():
     ops.reduce_jobs(jobs_dev, starts_dev, len(specs), starts[-1])
     for d, r in zip(dsts, refs):
         assert rel_err(d, r) < 1e-6
+
+
+@pytest.mark.parametrize("rows", [3750, 500, 64, 1, 129, 8192 + 17])
+def test_wgrad_group_direct_matches_float64(rows):
+    """smx_wgrad_group_direct (round 6: the weight gradients of a layer without split-K slabs, added INTO the gradients): against
+    float64, accumulation on top of what the gradient buffers hold, the bias gradients, a ragged frame count, strided views, and
+    bit-identical repeats."""
+    L, ops = _ops()
+    torch.manual_seed(rows)
+    shapes = [(512, 256), (256, 512), (128, 128), (256, 256), (1024, 128)]
+    big_z = (torch.randn(rows, 2304, device="cuda") * 0.5).bfloat16()
+    recs, refs, off = [], [], 0
+    for i, (M, K) in enumerate(shapes):
+        dz = big_z[:, off:off + M]; off += M                      # column slices of one buffer: leading dimension > width
+        x = torch.randn(rows, K, device="cuda").bfloat16()
+        gbuf = torch.randn(M, K + 64, device="cuda")
+        gW = gbuf[:, 32:32 + K]                                    # (a strided float32 gradient view, 16-byte aligned)
+        gb = torch.randn(M, device="cuda") if i != 2 else None
+        refs.append((gW.double() + dz.double().t() @ x.double(), (gb.double() + dz.double().sum(0)) if gb is not None else None, gbuf.clone()))
+        recs.append((dz, x, gW, gb, M, K))
+    ops.wgrad_group_direct(recs, rows)
+    for (dz, x, gW, gb, M, K), (rw, rb, g0) in zip(recs, refs):
+        assert rel_err(gW, rw) < 2e-6, (M, K, rel_err(gW, rw))
+        if gb is not None:
+            assert rel_err(gb, rb) < 2e-6
+        big = gW._base if gW._base is not None else gW
+        assert torch.equal(big[:, :32], g0[:, :32]) and torch.equal(big[:, 32 + K:], g0[:, 32 + K:])    # nothing outside the view is touched
+    # bit-identical when repeated from the same starting point
+    outs = []
+    for _ in range(2):
+        fresh = [(dz, x, torch.zeros(M, K, device="cuda"), torch.zeros(M, device="cuda"), M, K) for dz, x, _, _, M, K in recs]
+        ops.wgrad_group_direct(fresh, rows)
+        outs.append([f[2] for f in fresh] + [f[3] for f in fresh])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
