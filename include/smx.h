@@ -350,6 +350,13 @@ int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, const float*
                            const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
                            int64_t lddx, float* dgamma, float* dbeta, int N, int D, void* workspace, void* dX2, int64_t lddx2,
                            float alpha2, const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, const uint64_t* epoch, void* stream);
+/* The same with the incoming gradient given as `nslab` float32 split-K slabs ((N, D) each, slab_stride elements apart; added in slab
+ * order) - the dgrad of the Linear behind the LayerNorm computed by smx_gemm_panel_slabs: reducer and LayerNorm backward in one launch.
+ * x_f32: X is the float32 residual stream.  dgamma / dbeta partial rows stay in `workspace` (smx_reduce_jobs). */
+int smx_layernorm_bwd2_slabs(int dtype, const float* slabs, int nslab, int64_t slab_stride, const void* X, int64_t ldx, int x_f32,
+                             const float* gamma, const float* beta, int act, const float* stats, const void* R, int64_t ldr, void* dX,
+                             int64_t lddx, int N, int D, void* workspace, void* dX2, int64_t lddx2, float alpha2, const uint8_t* row_mask2,
+                             float drop_p2, uint64_t drop_seed2, const uint64_t* epoch, void* stream);
 /* LayerNorm backward THROUGH the activation that produced the LayerNorm's input: X = zact(Z) (Z the saved pre-activation),
  *   dZ = zact'(Z) * LNbwd(dY)                      (act must be SMX_ACT_NONE: a LayerNorm without a fused activation of its own)
  * - the CSGU of the Branchformer's cgMLP normalises the gate half of GELU(channel_proj1(x)) (Branchformer.py:84-96 via the

@@ -182,6 +182,8 @@ SIGNATURES = {
     "smx_expdecay_mean_sharded": (c_i, [c_i, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp]),
     "smx_wgrad_group_direct_ok": (c_i, [c_i, c_i, c_i]),
     "smx_wgrad_group_direct": (c_i, [c_i, c_i, ctypes.POINTER(WgradDirectItem), c_i, c_vp]),
+    "smx_layernorm_bwd2_slabs": (c_i, [c_i, c_vp, c_i, c_i64, c_vp, c_i64, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp,
+                                       c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp, c_vp]),
     "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
     "smx_stream_capture_id": (c_i, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "smx_sumsq_workspace": (c_sz, []),

@@ -695,6 +695,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_pair_fast(const float* __re
 // that hold dX anyway, it replaces a separate elementwise pass (one more read and one more launch per module).
 struct LnSecond {
   void* dX2; long ld; float alpha; const uint8_t* mask; uint32_t thresh; float scale; uint64_t seed; const uint64_t* epoch;
+  // round 6 (split-K dgrads of a small batch, smx_gemm_panel_slabs): the incoming gradient dY = the sum of `nslab` float32 slabs
+  // ((N, D) each, `slab_stride` elements apart, added in slab order) instead of a dtype-T tensor; null: dY as given
+  const float* slabs; int nslab; long slab_stride;
 };
 
 template <typename T, int VW, int CH, int U, typename TX = T>
@@ -730,7 +733,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int i = 0; i < CH; ++i) {
           const int c = (lane + 64 * i) * VW;
           const int cc = c < D ? c : 0;                  // idle lanes re-read column 0
-          if constexpr (VW == 4) { load4<T>(dY + (long)row * lddy + cc, fdy[u][i]); load4<TX>(X + (long)row * ldx + cc, fx[u][i]); }
+          if constexpr (VW == 4) {
+            if (sec.slabs) {                               // (uniform)
+              const float* sp = sec.slabs + (long)row * D + cc;
+              fdy[u][i][0] = fdy[u][i][1] = fdy[u][i][2] = fdy[u][i][3] = 0.f;
+              for (int s0 = 0; s0 < sec.nslab; s0 += 4) {  // four slabs in flight, summed in slab order
+                float4 a4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a4[k] = *reinterpret_cast<const float4*>(sp + (long)min(s0 + k, sec.nslab - 1) * sec.slab_stride);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  if (s0 + k < sec.nslab) { fdy[u][i][0] += a4[k].x; fdy[u][i][1] += a4[k].y; fdy[u][i][2] += a4[k].z; fdy[u][i][3] += a4[k].w; }
+              }
+            } else {
+              load4<T>(dY + (long)row * lddy + cc, fdy[u][i]);
+            }
+            load4<TX>(X + (long)row * ldx + cc, fx[u][i]);
+          }
           else { fdy[u][i][0] = to_f32(dY[(long)row * lddy + cc]); fx[u][i][0] = to_f32(X[(long)row * ldx + cc]); }
           // the residual gradient is requested with the operands: loaded after the reductions it was a second dependent
           // round trip per row group
@@ -2023,6 +2042,7 @@ extern "C" int smx_layernorm_bwd2(int dtype, const void* dY, int64_t lddy, const
   SMX_REQUIRE(drop_p2 >= 0.f && drop_p2 < 1.f, "smx_layernorm_bwd2: 0 <= drop_p < 1");
   if (N == 0) return SMX_OK;
   LnSecond sec;
+  sec.slabs = nullptr; sec.nslab = 0; sec.slab_stride = 0;
   sec.dX2 = dX2; sec.ld = lddx2; sec.alpha = alpha2; sec.mask = row_mask2;
   sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = epoch;
   if (dtype == SMX_BF16) return ln_bwd_impl<bf16_t>(dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, (float*)workspace, STREAM, sec);
@@ -2044,6 +2064,7 @@ extern "C" int smx_layernorm_bwd2_x32(int dtype, const void* dY, int64_t lddy, c
   const bool vec = D % 4 == 0 && D <= 2048 && ok(dY, lddy) && aligned16(X) && ldx % 4 == 0 && ok(R, ldr) && ok(dX, lddx) && ok(dX2, lddx2);
   if (!vec) return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd2_x32: needs D %% 4 == 0, D <= 2048 and aligned rows");
   LnSecond sec;
+  sec.slabs = nullptr; sec.nslab = 0; sec.slab_stride = 0;
   sec.dX2 = dX2; sec.ld = lddx2; sec.alpha = alpha2; sec.mask = row_mask2;
   sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = epoch;
   const int blocks = ln_bwd_blocks(N);
@@ -2070,6 +2091,37 @@ extern "C" int smx_layernorm_bwd(int dtype, const void* dY, int64_t lddy, const 
                                  float* dbeta, int N, int D, void* workspace, void* stream) {
   return smx_layernorm_bwd2(dtype, dY, lddy, X, ldx, gamma, beta, act, stats, R, ldr, dX, lddx, dgamma, dbeta, N, D, workspace, nullptr, 0,
                             1.f, nullptr, 0.f, 0, nullptr, stream);
+}
+
+// The LayerNorm backward whose incoming gradient is the SUM of float32 split-K slabs (smx_gemm_panel_slabs: the dgrad of the Linear
+// behind the LayerNorm, K cut into nslab slices): one launch instead of reducer + LayerNorm backward.  x_f32: the LayerNorm input is
+// the float32 residual stream (else dtype T).  Everything else as smx_layernorm_bwd2 (res, second output, fused activation).
+extern "C" int smx_layernorm_bwd2_slabs(int dtype, const float* slabs, int nslab, int64_t slab_stride, const void* X, int64_t ldx, int x_f32,
+                                        const float* gamma, const float* beta, int act, const float* stats, const void* R, int64_t ldr,
+                                        void* dX, int64_t lddx, int N, int D, void* workspace, void* dX2, int64_t lddx2, float alpha2,
+                                        const uint8_t* row_mask2, float drop_p2, uint64_t drop_seed2, const uint64_t* epoch, void* stream) {
+  SMX_REQUIRE(dtype == SMX_BF16 && slabs && nslab >= 1 && nslab <= 16 && X && gamma && beta && stats && dX && workspace && D > 0,
+              "smx_layernorm_bwd2_slabs: bad arguments");
+  SMX_REQUIRE(drop_p2 >= 0.f && drop_p2 < 1.f, "smx_layernorm_bwd2_slabs: 0 <= drop_p < 1");
+  if (N == 0) return SMX_OK;
+  typedef bf16_t T;
+  auto ok = [&](const void* p, int64_t ld) { return p == nullptr || ((reinterpret_cast<uintptr_t>(p) % 8) == 0 && ld % 4 == 0); };
+  const bool vec = D % 4 == 0 && D <= 2048 && aligned16(slabs) && slab_stride % 4 == 0 && (x_f32 ? aligned16(X) : ok(X, ldx)) && ldx % 4 == 0 &&
+                   ok(R, ldr) && ok(dX, lddx) && ok(dX2, lddx2);
+  if (!vec) return fail(SMX_EUNSUPPORTED, "smx_layernorm_bwd2_slabs: needs D %% 4 == 0, D <= 2048 and aligned rows");
+  LnSecond sec;
+  sec.slabs = slabs; sec.nslab = nslab; sec.slab_stride = slab_stride;
+  sec.dX2 = dX2; sec.ld = lddx2; sec.alpha = alpha2; sec.mask = row_mask2;
+  sec.thresh = (uint32_t)((double)drop_p2 * 4294967296.0); sec.scale = 1.f / (1.f - drop_p2); sec.seed = drop_seed2; sec.epoch = epoch;
+  const int blocks = ln_bwd_blocks(N);
+  dim3 grid(blocks);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipStream_t s = STREAM;
+#define LN_BWDS(CH, TXX) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4, CH, 1, TXX>), grid, dim3(256), 0, s, (const T*)nullptr, 0, (const TXX*)X, ldx, gamma, beta, act, stats, (const T*)R, ldr, (T*)dX, lddx, partial, N, D, sec)
+  if (x_f32) { if (D <= 256) LN_BWDS(1, float); else if (D <= 512) LN_BWDS(2, float); else if (D <= 1024) LN_BWDS(4, float); else LN_BWDS(8, float); }
+  else { if (D <= 256) LN_BWDS(1, T); else if (D <= 512) LN_BWDS(2, T); else if (D <= 1024) LN_BWDS(4, T); else LN_BWDS(8, T); }
+#undef LN_BWDS
+  return check_launch("smx_layernorm_bwd2_slabs");
 }
 
 // dZ = zact'(Z) * (LayerNorm backward of dY), for a LayerNorm whose input is X = zact(Z) (the CSGU norm of the cgMLP: X = the gate

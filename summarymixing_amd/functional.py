@@ -86,12 +86,24 @@ def _purge_packed():
         del _packed[k]
 
 
+def _pack_jobs_of(e):
+    """(W ptr, ldw, bias ptr, image ptr, M, K, transposed) per pack job of a cache entry: one, or one per K-slice (entry[8] slices of
+    K = entry[6] reduce elements each: column ranges of a forward weight, row ranges of the same weight seen from its dgrad)."""
+    W, img, M, K, tr = e[3], e[2], e[5], e[6], e[7]
+    ns = e[8] if len(e) > 8 else 1
+    if ns == 1:
+        return [(W.data_ptr(), W.stride(0), 0 if e[4] is None else e[4].data_ptr(), img.data_ptr(), M, K, tr)]
+    per = L.lib().smx_weight_pack_bytes(M, K)
+    step = K * W.stride(0) * 2 if tr else K * 2
+    return [(W.data_ptr() + s_ * step, W.stride(0), 0, img.data_ptr() + s_ * per, M, K, tr) for s_ in range(ns)]
+
+
 def _repack_managed(device, stamp):
     """ONE launch re-packs every trainer-managed image of `device` (they all went stale together: the optimizer rewrote every shadow)."""
     _purge_packed()
     keys = [k for k, v in _packed.items() if v[1][0] == "m" and v[2].device == device]
     ents = [_packed[k] for k in keys]
-    sig = tuple((e[3].data_ptr(), e[3].stride(0), 0 if e[4] is None else e[4].data_ptr(), e[2].data_ptr(), e[5], e[6], e[7]) for e in ents)
+    sig = tuple(j for e in ents for j in _pack_jobs_of(e))
     capturing = torch.cuda.is_current_stream_capturing()
     tab = _pack_tables.get((device, sig))
     if tab is None:
@@ -99,23 +111,26 @@ def _repack_managed(device, stamp):
             return False                                 # (no host-to-device table upload inside a capture: the caller packs singly)
         for k in [k for k, t in _pack_tables.items() if k[0] == device and not t[2]]:
             del _pack_tables[k]
-        lib, arr, nb = L.lib(), (L.PackJob * len(ents))(), 0
+        lib, arr, nb = L.lib(), (L.PackJob * len(sig))(), 0
         for j, (W_, ldw, bias_, out_, M, K, tr) in zip(arr, sig):
             j.W, j.ldw, j.bias, j.packed, j.M, j.K, j.transposed, j.block_start = W_, ldw, bias_ or None, out_, M, K, tr, nb
             nb += lib.smx_weight_pack_job_blocks(M, K)
         tab = _pack_tables[(device, sig)] = [torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device), nb, False]
     tab[2] = tab[2] or capturing
-    ops.weight_pack_jobs(tab[0], len(ents), tab[1], sum(e[5] * e[6] for e in ents))
+    ops.weight_pack_jobs(tab[0], len(sig), tab[1], sum(j[4] * j[5] for j in sig))
     for k, v in zip(keys, ents):
         _packed[k] = (v[0], stamp) + v[2:]
     return True
 
 
-def wpacked(param, dtype, transposed=False, bias=None):
-    """Packed image (ops.weight_pack) of a Linear's weight parameter [+ fp32 bias parameter] in the compute dtype."""
+def wpacked(param, dtype, transposed=False, bias=None, kslice=0):
+    """Packed image (ops.weight_pack) of a Linear's weight parameter [+ fp32 bias parameter] in the compute dtype.
+    kslice > 0: the image of gemm_panel_slabs instead - the weight's K-slices of `kslice` reduce elements packed one after the other,
+    no bias (ops.weight_pack_slices)."""
     W = wcast(param, dtype)
     if W.dim() != 2:
         W = W.view(W.shape[0], -1)               # (a Conv1d(k = 1) weight (out, in, 1) seen as a Linear's)
+    assert kslice == 0 or bias is None
     ent = _shadow.get(id(param))
     managed = ent is not None and ent[0]() is param and ent[1] == "managed"
     bt = None if bias is None else bias.detach()
@@ -123,7 +138,7 @@ def wpacked(param, dtype, transposed=False, bias=None):
         stamp = ("m", _WEPOCH[0], ops.capture_id())
     else:
         stamp = ("v", param._version, param.data_ptr(), None if bias is None else (bias._version, bias.data_ptr()))
-    key = (id(param), transposed)
+    key = (id(param), transposed) if kslice == 0 else (id(param), transposed, kslice)
     c = _packed.get(key)
     if c is not None and c[0]() is not param:
         del _packed[key]                           # (a dead parameter's id re-used)
@@ -138,9 +153,13 @@ def wpacked(param, dtype, transposed=False, bias=None):
     if len(_packed) > 256:
         _purge_packed()
     out = c[2] if c is not None else None          # (same parameter and orientation = same shape: the buffer is re-used)
-    out = ops.weight_pack(W, transposed, bt, out)
     M, K = (W.shape[1], W.shape[0]) if transposed else (W.shape[0], W.shape[1])
-    _packed[key] = (weakref.ref(param), stamp, out, W, bt, M, K, int(transposed))
+    if kslice:
+        out = ops.weight_pack_slices(W, kslice, transposed, out)
+        _packed[key] = (weakref.ref(param), stamp, out, W, None, M, kslice, int(transposed), K // kslice)
+    else:
+        out = ops.weight_pack(W, transposed, bt, out)
+        _packed[key] = (weakref.ref(param), stamp, out, W, bt, M, K, int(transposed))
     return out
 
 
@@ -151,6 +170,26 @@ def wpacked(param, dtype, transposed=False, bias=None):
 _PANEL = os.environ.get("SMX_PANEL", "1") != "0"
 _PANEL_MIN_ROWS = int(os.environ.get("SMX_PANEL_MIN_ROWS", "2048"))   # (round 6: 64- / 32-row panels below 12 288 rows, chosen by the library)
 _PANEL_ACTS = (L.ACT_NONE, L.ACT_SWISH, L.ACT_GELU, L.ACT_RELU)
+
+
+# Split-K over workgroups for the Linears of a SMALL batch (smx_gemm_panel_slabs + smx_slab_epilogue / smx_layernorm_bwd2_slabs; round 6):
+# the reduction is cut into panel-sized K-slices, the slabs are summed by the row kernel that follows the Linear anyway (its epilogue +
+# the LayerNorm, or the LayerNorm backward behind a dgrad).  Measured (tools/experiments/r06_smalln/splitk_bench.py, us, GEMM + LayerNorm
+# pair, tiled | split-K): d_model 256 at 500 frames K = 1024: 13.2 | 10.2, 512: 10.8 | 9.3, 256: 9.5 | 8.8; 2000 frames: 14.1 | 13.8, 11.6 | 11.2;
+# d_model 512 at 500 frames: 18.4 | 14.3, 13.3 | 12.6; 2000 frames 21.9 | 20.8; at 3750 frames the slab traffic (S x N x M x 4 bytes
+# written and read back) eats the gain (27.5 | 26.1 at K = 2048, a loss below) - hence up to 2048 frames only.
+_SPLITK = os.environ.get("SMX_SPLITK", "1") != "0"
+_SPLITK_MAX_ROWS = int(os.environ.get("SMX_SPLITK_MAX_ROWS", "2048"))
+
+
+def splitk_cfg(N, M, K, dtype):
+    """(K-slice, number of slices) when the Linear (N x K) -> (N x M) should run as split-K slabs, else None."""
+    if not (_SPLITK and _PANEL and dtype == torch.bfloat16 and 64 <= N <= _SPLITK_MAX_ROWS and M % 64 == 0 and 64 <= M <= 512 and not SP.enabled()):
+        return None
+    ks = 256 if (M <= 256 or K % 512 != 0) else 512
+    if K % ks != 0 or K // ks > 16 or (K // ks == 1 and N > 1024):
+        return None
+    return (ks, K // ks) if L.lib().smx_gemm_panel_slabs_ok(L.BF16, N, M, ks, K // ks) == 1 else None
 
 
 def _span_ok(*ts):
@@ -380,7 +419,7 @@ _LN_FUSE_FWD = os.environ.get("SMX_LN_FUSE", "1").lower() != "bwd"
 _LN_FUSE_BWD = os.environ.get("SMX_LN_FUSE", "1").lower() != "fwd"
 
 
-def ln_next_ok(x, M, ln_next, W=None, res=None, training=True):
+def ln_next_ok(x, M, ln_next, W=None, res=None, training=True, wparam=None):
     """Can - and should - the LayerNorm that follows a Linear (its output: N x M) ride in that GEMM's epilogue (SMX_EPI_LN_FWD)?
     W / res: the weight (view) and residual the GEMM will be given - a column slice with an odd offset is not 16-byte aligned
     and the fused instantiation has no scalar path.
@@ -388,6 +427,9 @@ def ln_next_ok(x, M, ln_next, W=None, res=None, training=True):
     fusion still wins (C2a 49.2 -> 48.4 ms, each direction ~0.75 ms), in a forward-only pass the standalone LayerNorm (a pure
     stream at 5.9 TB/s, paired with the next layer's) is faster (C5 forward 60.2 vs 62.0 ms fused, C2a forward 16.97 vs 17.25;
     tools/experiments/ab_lnfuse_d512.sh): not fused there."""
+    if (wparam is not None and ln_next is not None and _LN_FUSE and _LN_FUSE_FWD and x.dtype == torch.bfloat16 and _vec_ok(x, res) and
+            splitk_cfg(x.shape[0], M, x.shape[1], x.dtype) is not None):
+        return True                                        # small batch: split-K slabs, the LayerNorm rides in the reducer (linear_fwd)
     if M > 256 and not training:
         return False
     return (_LN_FUSE and _LN_FUSE_FWD and ln_next is not None and x.dtype == torch.bfloat16 and x.shape[0] >= _LN_FUSE_MIN_ROWS and _vec_ok(x, W, res) and
@@ -431,6 +473,14 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
     e = ops.epilogue(bias=bias, c0=c0, c0_mode=c0_mode, c0_div=c0_div, act=act, z=z, row_mask=mask, res=res,
                      alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post, ln_fwd=lnf,
                      drop_cols=drop_cols, ln_fwd2=lnf2)
+    sk = splitk_cfg(N, M, K, x.dtype) if (wparam is not None and c0 is None and drop_cols % 4 == 0) else None
+    if sk is not None and _vec_ok(x, out, z, res) and out.stride(0) % 4 == 0 and (res is None or res.stride(0) % 4 == 0):
+        # small batch: K-slices on the panel kernel -> float32 slabs; the reducer applies this epilogue (and the LayerNorms) to their sum
+        slabs = torch.empty((sk[1], N, M), dtype=torch.float32, device=x.device)
+        ops.gemm_panel_slabs(x, wpacked(wparam, x.dtype, False, None, kslice=sk[0]), slabs, N, M, sk[0], sk[1])
+        ops.slab_epilogue(slabs, sk[1], out, N, M, e)
+        return out, z
+    assert ln_next is None or L.lib().smx_gemm_ln_fused_ok(L.BF16, N, M, K) == 1, "ln_next given for a shape only the split-K path fuses"
     ops.gemm(L.GEMM_NT, x, W, out, N, M, K, e)
     return out, z
 
@@ -459,7 +509,7 @@ def ln_fusable(ln_spec, N, K_out, dtype, reduce, W=None):
 
 
 def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=None, dgroup=None, gdiv=0, dx_out=None,
-               drop=None, dz_ready=False, up=None, dx_drop=None, ln=None, ln_second=None, dx_split=None, wparam=None):
+               drop=None, dz_ready=False, up=None, dx_drop=None, ln=None, ln_second=None, dx_split=None, wparam=None, slabs_ok=False):
     """Backward of y = res + alpha*D(act(x W^T + b + c0))*mask (D = the forward's fused dropout, regenerated from its
     seed).  Returns (dx, dz).  gW (M,K) / gb (M) fp32 accumulate.
     dz_ready: dy already IS dZ (a downstream dgrad epilogue fused this layer's act/dropout/mask backward, see `up`).
@@ -501,6 +551,13 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
                 ops.gemm(L.GEMM_NN, dz, W[:, lo:hi], o, N, hi - lo, M, ops.epilogue(**ekw) if ekw else None)
                 outs.append(o)
             return outs, dz
+        if (slabs_ok and wparam is not None and ln is None and up is None and dx_drop is None and res_grad is None and dx_out is None and
+                _vec_ok(dz) and splitk_cfg(N, K, M, dz.dtype) is not None):
+            # small batch, the caller's next step is a LayerNorm backward: the dgrad as float32 split-K slabs, summed inside that kernel
+            ks, ns = splitk_cfg(N, K, M, dz.dtype)
+            slabs = torch.empty((ns, N, K), dtype=torch.float32, device=dy.device)
+            ops.gemm_panel_slabs(dz, wpacked(wparam, dz.dtype, True, None, kslice=ks), slabs, N, K, ks, ns)
+            return ops.Slabs(slabs), dz
         dx = dx_out if dx_out is not None else torch.empty((N, K), dtype=dy.dtype, device=dy.device)
         if ln is not None:
             assert up is None and dx_drop is None and K % 64 == 0
@@ -888,9 +945,9 @@ def cell_run(P, cfg, B, T, mask, sum_mask, p_drop=0.0):
             else:
                 ops.dropout(sbar, p_drop, s2, out=cat[:, lw:])
             sbar_t = None
-            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(cat, Wm.shape[0], ln_next, Wm, res, need_bwd)) else None
+            lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(cat, Wm.shape[0], ln_next, Wm, res, need_bwd, wparam=mg["W"])) else None
             y, zm = linear_fwd(cat, Wm, mg["b"], act, None, res=res, save_z=need_bwd, ln_next=lnn, ln_post=post, out=out,
-                               drop=out_drop)
+                               drop=out_drop, wparam=mg["W"])
         elif pool_kind == "mean":
             sbar_t = ops.cast(sbar, dtype)                                         # (B, sdim) in compute dtype
             c0, _ = linear_fwd(sbar_t, Ws, None, out_f32=True)                     # (B, s_out) fp32
@@ -1091,6 +1148,8 @@ def ln_fwd(x, w, b, eps, need_bwd, act=L.ACT_NONE, wp=None, bp=None, pre=None, o
         wide2 = None
         if second is not None and x.shape[1] > 2048:       # the fused second output exists for D <= 2048: do it in separate
             wide2, second = second, None                   # passes, but ALWAYS return the pair the caller unpacks
+        if isinstance(dy, ops.Slabs) and not (_Deferred.enabled and gw is not None and gb is not None and wide2 is None):
+            dy = dy.sum(x.dtype if x.dtype != torch.float32 else torch.bfloat16)      # (not reached by the encoder layers: plain torch)
         if _Deferred.enabled and gw is not None and gb is not None:
             N, D = x.shape
             ws = deferred_ws(gw.data_ptr(), L.lib().smx_layernorm_bwd_workspace(N, D), x.device)
@@ -1128,9 +1187,12 @@ def dwconv_bwd_deferred(dy, p_, wd, bd, gwd, gbd, B, T, D, k, glu, pad_mode, chu
     return dp, dg
 
 
-def ln_pair_ok(x, M, res, affine):
+def ln_pair_ok(x, M, res, affine, wparam=None):
     """Can the epilogue that runs a LayerNorm behind this Linear (ln_next_ok holds) also run a SECOND LayerNorm on its output
     (smx_gemm_ln_pair_ok: the 128 x 512 tile, float32 residual stream)?"""
+    if (wparam is not None and _LN_PAIR and res is not None and res.dtype == torch.float32 and x.dtype == torch.bfloat16 and
+            splitk_cfg(x.shape[0], M, x.shape[1], x.dtype) is not None and all(v.is_contiguous() and v.data_ptr() % 16 == 0 for v in affine)):
+        return True                                        # (the split-K reducer runs both LayerNorms on the row in registers)
     return (_LN_PAIR and res is not None and res.dtype == torch.float32 and x.dtype == torch.bfloat16 and
             L.lib().smx_gemm_ln_pair_ok(L.BF16, x.shape[0], M, x.shape[1]) == 1 and
             all(v.is_contiguous() and v.data_ptr() % 16 == 0 for v in affine))
@@ -1149,10 +1211,10 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
     d2 = (p, ops.new_dropout_seed()) if p > 0.0 else None
     a, z1 = linear_fwd(h, W1, P["b1"], act, None, save_z=need_bwd, drop=d1, wparam=P["W1"])
     post = []
-    lnn = ((ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) + tuple(ln_next[3:4])) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x, need_bwd)) else None
-    if lnn is not None and ln_pair and len(lnn) > 5 and ln_pair_ok(a, W2.shape[0], x, ln_pair[:2]):
+    lnn = ((ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) + tuple(ln_next[3:4])) if (ln_next is not None and ln_next_ok(a, W2.shape[0], ln_next, W2, x, need_bwd, wparam=P["W2"])) else None
+    if lnn is not None and ln_pair and len(lnn) > 5 and ln_pair_ok(a, W2.shape[0], x, ln_pair[:2], wparam=P["W2"]):
         lnn = lnn + (ln_pair,)
-    y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2, ln_next=lnn, ln_post=post)
+    y, _ = linear_fwd(a, W2, P["b2"], L.ACT_NONE, None, res=x, alpha=alpha, drop=d2, ln_next=lnn, ln_post=post, wparam=P["W2"])
     post, post2 = (post[0] if post else None), (post[1] if len(post) > 1 else None)
     ret = lambda b: ((y, b, post, post2) if ln_pair is not None else (y, b, post)) if ln_next is not None else (y, b)
     if not need_bwd:
@@ -1172,7 +1234,7 @@ def ffn_module_fwd(x, P, act, need_bwd, dtype, alpha=0.5, p=0.0, pre_ln=None, ln
             out, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True, res_grad=dy,
                                 ln=ln_b.spec, ln_second=second)
             return out
-        dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True)
+        dh, _ = linear_bwd(dz1, h, W1, z1, act, None, 1.0, gacc(P["W1"]), gacc(P["b1"]), dz_ready=True, wparam=P["W1"], slabs_ok=True)
         return ln_b(dh, res=dy, second=second)
     bwd.pre = (alpha, None, d2)          # what this block does first to its incoming gradient: alpha * D2(dy)
     return ret(bwd)
@@ -1195,8 +1257,8 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
     Wo = wcast(P["Wo"], dtype)
     dr = (p, ops.new_dropout_seed()) if p > 0.0 else None   # Linear -> Dropout -> * mask (+ x): one epilogue
     post = []
-    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, Wo.shape[0], ln_next, Wo, x if residual else None, need_bwd)) else None
-    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None, drop=dr, ln_next=lnn, ln_post=post)
+    lnn = (ln_next[0], ln_next[1], ln_next[2], L.ACT_NONE, need_bwd) if (ln_next is not None and ln_next_ok(a, Wo.shape[0], ln_next, Wo, x if residual else None, need_bwd, wparam=P["Wo"])) else None
+    y, _ = linear_fwd(a, Wo, P["bo"], L.ACT_NONE, mask, res=x if residual else None, drop=dr, ln_next=lnn, ln_post=post, wparam=P["Wo"])
     post = post[0] if post else None
     if not need_bwd:
         return (y, None, post) if ln_next is not None else (y, None)
@@ -1216,7 +1278,7 @@ def conv_module_fwd(x, P, act, mask, B, T, need_bwd, dtype, chunk=0, residual=Tr
             out, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]),
                                 res_grad=dy if residual else None, ln=ln1_b.spec, ln_second=second)
             return out
-        dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]))
+        dh, _ = linear_bwd(dp, h, Wp, None, L.ACT_NONE, None, 1.0, gacc(P["Wp"]).view(2 * d, d), gacc(P["bp"]), wparam=P["Wp"], slabs_ok=True)
         return ln1_b(dh, res=dy if residual else None, second=second)
     # what this block does first to its incoming gradient: D(dy) * mask (nothing to precompute without mask and dropout)
     bwd.pre = (1.0, mask, dr) if (mask is not None or dr is not None) else None

@@ -551,6 +551,18 @@ def layernorm_fwd_pair(x, gamma1, beta1, eps1, gamma2, beta2, eps2, want_stats, 
     return y1, st1, y2, st2
 
 
+class Slabs:
+    """The float32 split-K partial products of a Linear (gemm_panel_slabs): `t` (S, N, M), to be summed by the consumer -
+    slab_epilogue (forward) or layernorm_bwd (the dgrad of the Linear behind a LayerNorm)."""
+    def __init__(self, t):
+        self.t, self.S, self.N, self.M = t, t.shape[0], t.shape[1], t.shape[2]
+        self.shape, self.dtype, self.device = (self.N, self.M), torch.bfloat16, t.device
+
+    def sum(self, dtype=torch.bfloat16):
+        """The reduced tensor by plain torch (tests / fallbacks only: the product path fuses the sum into its consumer)."""
+        return self.t.sum(0).to(dtype)
+
+
 def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_NONE, ws=None, dx_out=None, second=None):
     """ws: caller-owned workspace; with dgamma = dbeta = None the partial rows stay in it for a deferred reduce_jobs.
     dx_out: optional (N, D) destination view (e.g. a column slice of a wider buffer).
@@ -558,6 +570,23 @@ def layernorm_bwd(dy, x, gamma, beta, stats, dgamma, dbeta, res=None, act=L.ACT_
     N, D = x.shape
     gdt = dy.dtype                                       # gradient dtype; x may be float32 next to bf16 gradients (fp32 residual stream)
     dx = dx_out if dx_out is not None else torch.empty((N, D), dtype=gdt, device=x.device)
+    if isinstance(dy, Slabs):
+        # the incoming gradient is the sum of float32 split-K slabs: reducer + LayerNorm backward in one launch (smx_layernorm_bwd2_slabs)
+        assert dgamma is None and dbeta is None and ws is not None and dy.N == N and dy.M == D
+        px, ldx = _mat(x)
+        pr, ldr = (_mat(res) if res is not None else (None, 0))
+        dx2, a2, m2, dp2, ds2 = None, 1.0, None, 0.0, 0
+        if second is not None:
+            a2, m2, drop2 = second
+            dp2, ds2 = drop2 if (drop2 is not None and drop2[0] > 0.0) else (0.0, 0)
+            dx2 = torch.empty((N, D), dtype=gdt, device=x.device)
+        tok = _pb(f"layernorm_bwd from slabs ({N}x{D}) S={dy.S}{'+res' if res is not None else ''}{'+2nd' if second is not None else ''}",
+                  ((1 + (res is not None) + (second is not None)) * 2 + _es(x) + 4 * dy.S) * N * D)
+        L.check(L.lib().smx_layernorm_bwd2_slabs(L.BF16, _p(dy.t), dy.S, N * D, px, ldx, 1 if x.dtype == torch.float32 else 0, _p(gamma), _p(beta), act,
+                                                 _p(stats), pr, ldr, _p(dx), _mat(dx)[1], N, D, _p(ws), _p(dx2), D if dx2 is not None else 0, a2, _p(m2),
+                                                 dp2, ds2, _epoch(), _stream()), "smx_layernorm_bwd2_slabs")
+        _pe(tok)
+        return dx if second is None else (dx, dx2)
     pdy, lddy = _mat(dy)
     px, ldx = _mat(x)
     pr, ldr = (_mat(res) if res is not None else (None, 0))

@@ -326,11 +326,11 @@ def test_layernorm_fusion_threshold_paths_agree():
     x0 = torch.randn(B, T, d, device="cuda").bfloat16()
     r = torch.randn(B, T, d, device="cuda")
     pad = torch.arange(T, device="cuda")[None] < torch.tensor([T, 211, 150, 287], device="cuda")[:, None]
-    saved = F._LN_FUSE_MIN_ROWS
+    saved, saved_sk = F._LN_FUSE_MIN_ROWS, F._SPLITK
     runs = []
     try:
-        for thr in (0, 1 << 30):
-            F._LN_FUSE_MIN_ROWS = thr
+        for thr, sk in ((0, False), (1 << 30, False), (1 << 30, True)):
+            F._LN_FUSE_MIN_ROWS, F._SPLITK = thr, sk      # (third run, round 6: the small-batch split-K path - slabs + reducer with the LayerNorm)
             enc.zero_grad()
             x = x0.clone().requires_grad_(True)
             ops.prof_start()
@@ -339,13 +339,16 @@ def test_layernorm_fusion_threshold_paths_agree():
             names = [rec[0] for rec in ops.prof_stop()]
             runs.append((y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in enc.named_parameters()},
                          sum("+LN" in n for n in names), sum(n.startswith("layernorm") for n in names)))
+            runs[-1] = runs[-1] + (sum(n.startswith("slab epilogue") or "from slabs" in n for n in names),)
     finally:
-        F._LN_FUSE_MIN_ROWS = saved
-    (ya, ga, pa, fused_a, alone_a), (yb, gb, pb, fused_b, alone_b) = runs
-    assert fused_a > 0 and fused_b == 0 and alone_b > alone_a
-    assert rel_err(ya, yb) <= 1e-2 and rel_err(ga, gb) <= 3e-2
+        F._LN_FUSE_MIN_ROWS, F._SPLITK = saved, saved_sk
+    (ya, ga, pa, fused_a, alone_a, slab_a), (yb, gb, pb, fused_b, alone_b, slab_b), (yc, gc, pc, fused_c, alone_c, slab_c) = runs
+    assert fused_a > 0 and fused_b == 0 and alone_b > alone_a and slab_a == 0 and slab_b == 0
+    assert slab_c >= 8 and alone_c < alone_b              # two layers x (3 forward reducers + 2 LayerNorm backwards from slabs) at least
+    assert rel_err(ya, yb) <= 1e-2 and rel_err(ga, gb) <= 3e-2 and rel_err(yc, yb) <= 1e-2 and rel_err(gc, gb) <= 3e-2
     for n in pa:
         assert rel_err(pa[n], pb[n]) <= 3e-2, n
+        assert rel_err(pc[n], pb[n]) <= 3e-2, n
 
 
 def test_recipe_batch_path_every_parameter_gradient_vs_oracle(monkeypatch):
@@ -434,7 +437,9 @@ def test_layernorm_pair_in_the_stack_equals_two_launches(d, monkeypatch, ln_fuse
         torch.cuda.synchronize()
         return y.detach().float(), xg.grad.float(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
     y1, g1, p1 = run(True)
-    expect = 0 if (ln_fuse_mode == "lnfuse_always" and d == 512) else 2
+    # (round 6: a small batch runs the down-projection as split-K slabs whose reducer does norm2 AND the next layer's LayerNorm)
+    splitk = F.splitk_cfg(B * T, d, 2 * d, torch.bfloat16) is not None
+    expect = 0 if ((ln_fuse_mode == "lnfuse_always" and d == 512) or splitk) else 2
     assert len(calls) == expect, "two layer boundaries of a 3-layer stack take the pair kernel (unless norm2 is fused into the GEMM)"
     y0, g0, p0 = run(False)
     assert len(calls) == expect

@@ -104,3 +104,41 @@ def test_slab_epilogue_equals_the_gemm_epilogue(N, M, K, ks, variant):
     # deterministic
     cs2 = run("slab")[0]
     assert torch.equal(cs, cs2)
+
+
+@pytest.mark.parametrize("xf32", [True, False])
+@pytest.mark.parametrize("N,D,K,ks", [(500, 256, 1024, 256), (1000 + 37, 512, 2048, 512), (333, 256, 512, 256)])
+def test_layernorm_bwd_from_slabs_equals_the_two_launch_path(N, D, K, ks, xf32):
+    """smx_layernorm_bwd2_slabs: the LayerNorm backward with its incoming gradient given as the split-K slabs of the dgrad behind it,
+    against (tiled dgrad GEMM -> bf16 gradient -> smx_layernorm_bwd2): dX, the second output (alpha * D(dX) * mask, same keep
+    decisions), the dgamma / dbeta partial rows.  The slab path never rounds the gradient to bf16, so it is compared at bf16 tolerance
+    with the two-launch path and at float32 tolerance with float64 math."""
+    g = torch.Generator(device="cuda").manual_seed(N + D)
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g) * 2 - 1
+    dz, W = rnd(N, K).bfloat16(), (rnd(K, D) * (2.0 / K ** 0.5)).bfloat16()          # dgrad: dh (N, D) = dz (N, K) W (K, D)
+    x = rnd(N, D) * 2 if xf32 else (rnd(N, D) * 2).bfloat16()
+    gam, bet = rnd(D) + 1.5, rnd(D) * 0.1
+    st = torch.stack([x.float().mean(1), (x.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    res = rnd(N, D).bfloat16()
+    mask = (torch.rand(N, device="cuda", generator=g) > 0.3).to(torch.uint8)
+    ns = K // ks
+    slabs = torch.empty(ns, N, D, device="cuda")
+    ops.gemm_panel_slabs(dz, ops.weight_pack_slices(W, ks, transposed=True), slabs, N, D, ks, ns)
+    nb = L.lib().smx_layernorm_bwd_blocks(N)
+    ws1, ws2 = torch.zeros(nb * 2 * D, device="cuda"), torch.zeros(nb * 2 * D, device="cuda")
+    second = (0.5, mask, (0.15, 4321))
+    dx1, dx1b = ops.layernorm_bwd(ops.Slabs(slabs), x, gam, bet, st, None, None, res=res, ws=ws1, second=second)
+    dh = torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(L.GEMM_NN, dz, W, dh, N, D, K)
+    dx2, dx2b = ops.layernorm_bwd(dh, x, gam, bet, st, None, None, res=res, ws=ws2, second=second)
+    assert rel_err(dx1, dx2) < 1.2e-2 and rel_err(dx1b, dx2b) < 1.2e-2
+    assert float(((dx1b == 0) != (dx2b == 0)).float().mean()) < 2e-3                 # the same keep decisions (tiny values that round to 0 aside)
+    assert rel_err(ws1.view(nb, 2, D).sum(0), ws2.view(nb, 2, D).sum(0)) < 1e-2
+    # float64 reference of dX from the exact gradient
+    gy = (dz.double() @ W.double()) * gam.double()
+    xh = (x.double() - st[:, :1].double()) * st[:, 1:].double()
+    ref = st[:, 1:].double() * (gy - gy.mean(1, keepdim=True) - xh * (gy * xh).mean(1, keepdim=True)) + res.double()
+    assert rel_err(dx1, ref) < 8e-3
+    # bit-identical when repeated
+    dx3, _ = ops.layernorm_bwd(ops.Slabs(slabs), x, gam, bet, st, None, None, res=res, ws=ws1, second=second)
+    assert torch.equal(dx1, dx3)

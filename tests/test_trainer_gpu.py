@@ -377,13 +377,14 @@ def test_packed_weight_images_follow_the_optimizer():
 
         def check_images():
             n = 0
-            for (pid, tr), ent in list(F._packed.items()):
-                prm = ent[0]()
+            for key, ent in list(F._packed.items()):
+                prm, tr = ent[0](), key[1]
                 if prm is None or not any(prm is q for q in enc.parameters()):
                     continue
                 W = F.wcast(prm, dtype)
                 W = W.view(W.shape[0], -1) if W.dim() != 2 else W
-                assert torch.equal(ent[2], ops.weight_pack(W, bool(tr), ent[4])), "stale packed image"
+                fresh = ops.weight_pack_slices(W, key[2], bool(tr)) if len(key) > 2 else ops.weight_pack(W, bool(tr), ent[4])
+                assert torch.equal(ent[2], fresh), "stale packed image"
                 n += 1
             return n
 
@@ -424,13 +425,14 @@ def _packed_images_current(enc, dtype):
     """Every cached packed image of `enc`'s parameters equals a fresh pack of the CURRENT bf16 shadow and bias."""
     from summarymixing_amd import functional as F, ops
     n = 0
-    for (pid, tr), ent in list(F._packed.items()):
-        prm = ent[0]()
+    for key, ent in list(F._packed.items()):
+        prm, tr = ent[0](), key[1]
         if prm is None or not any(prm is q for q in enc.parameters()):
             continue
         W = F.wcast(prm, dtype)
         W = W.view(W.shape[0], -1) if W.dim() != 2 else W
-        assert torch.equal(ent[2], ops.weight_pack(W, bool(tr), ent[4])), "stale packed image"
+        fresh = ops.weight_pack_slices(W, key[2], bool(tr)) if len(key) > 2 else ops.weight_pack(W, bool(tr), ent[4])   # (key[2]: K-slice images)
+        assert torch.equal(ent[2], fresh), "stale packed image"
         n += 1
     return n
 
