@@ -481,6 +481,9 @@ def main():
                     help="skip the extra_points of the default line (SURVEY 8d batches: C2b B=64 x 500, C2a B=10 x 375, and the bf16 "
                          "residual stream), each a short child run of this script")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-step-only", action="store_true",
+                    help="(the extra_points child runs) only roofline_step - the step's algorithmic bytes / flops over the timed step - "
+                         "instead of the per-kernel roofline objects")
     ap.add_argument("--dry-run-ranks", type=int, default=0, metavar="N",
                     help="no GPU needed: build the model on the CPU, print the N-rank data-parallel plan (gradient buckets in "
                          "launch order, the rs_ag shard map, bytes on the wire, the hipGraph split decision, the RCCL environment) "
@@ -750,7 +753,9 @@ def main():
             out["comm"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None
             out["comm"]["topology"] = gpu_topology()
     if rank == 0:
-        if not args.no_roofline:
+        if args.roofline_step_only and train and world == 1 and not force_dist:
+            out["roofline_step"] = roofline_step_kernels(step, dtype, dt / args.steps * 1e3)[4]
+        elif not args.no_roofline:
             if train and world == 1 and not force_dist:
                 (out["roofline"], out["roofline_kernels"], out["roofline_symbols"], out["roofline_family"],
                  out["roofline_step"]) = roofline_step_kernels(step, dtype, dt / args.steps * 1e3)
@@ -785,15 +790,17 @@ def extra_points():
             ("C2a recipe OPTIMIZER step: 4 micro-batches of 10 x 375 (grad_accumulation_factor 4, ...transducer.yaml:65-66) as one fused "
              "batch (trainer.fuse_microbatches); ms_per_step is per optimizer step",
              ["--config", "c2a", "--batch", "10", "--frames", "375", "--grad-accum", "4", "--accum", "fused"], {}),
+            ("C2b ONE utterance B=1 x T=500 (hipGraph replay of the whole step)", ["--config", "c2b", "--batch", "1", "--steps", "30"], {}),
             ("C2b B=128 x T=500 on the bf16 residual stream (SMX_RESIDUAL=bf16, rounds 1-2)", ["--config", "c2b"], {"SMX_RESIDUAL": "bf16"}))
     for label, extra, env in runs:
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "4", "--no-cpu-baseline", "--no-roofline",
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "4", "--no-cpu-baseline", "--roofline-step-only",
                "--no-extra-points"] + extra
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, **env))
             d = json.loads(r.stdout.strip().splitlines()[-1])
             pts.append({"point": label, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                        "launch": d["config"]["launch"], "residual_stream": d["config"]["residual_stream"]})
+                        "launch": d["config"]["launch"], "residual_stream": d["config"]["residual_stream"],
+                        "roofline_step": d.get("roofline_step")})
         except Exception as ex:                          # noqa: BLE001
             pts.append({"point": label, "error": f"{type(ex).__name__}: {ex}"[:200]})
     return pts

@@ -54,7 +54,7 @@ typedef struct smx_config {
   int32_t t256;             /* SMX_T256: 256 x 256 GEMM tile (one workgroup per CU, software-pipelined K loop)
                                0 off, 1 for K >= 2048 (1), 2 for every eligible shape (tests)                  */
   int32_t panel_rows;       /* SMX_PANEL_ROWS: rows per panel of smx_gemm_panel (128 / 64 / 32); 0 = by frame count  */
-  int32_t pad_;
+  int32_t pool_fuse_max_rows;  /* SMX_POOL_FUSE_MAX_ROWS: smx_pool_bcast_ok up to this many frames (B * T)            */
 } smx_config;
 int smx_get_config(smx_config* out);
 /* rows per tile of the LayerNorm-fused GEMMs (SMX_EPI_LN_BWD writes ceil(N / rows) partial row pairs into ln_partial) */

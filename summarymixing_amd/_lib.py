@@ -218,7 +218,7 @@ class Config(ctypes.Structure):
     """smx_config of include/smx.h: the knobs the library read from the environment once."""
     _fields_ = [("ln_tile_rows", ctypes.c_int32),
                 ("gemm_ablate", ctypes.c_int32), ("wgroup_ablate", ctypes.c_int32), ("dwroll_ablate", ctypes.c_int32),
-                ("diag_build", ctypes.c_int32), ("t256", ctypes.c_int32), ("panel_rows", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("diag_build", ctypes.c_int32), ("t256", ctypes.c_int32), ("panel_rows", ctypes.c_int32), ("pool_fuse_max_rows", ctypes.c_int32)]
 
 
 def get_config():

@@ -37,6 +37,7 @@ const smx_config& cfg() {
     k.ln_tile_rows = 128;
     k.t256 = env_i("SMX_T256", 1);
     k.panel_rows = env_i("SMX_PANEL_ROWS", 0);
+    k.pool_fuse_max_rows = env_i("SMX_POOL_FUSE_MAX_ROWS", 16384);
 #ifdef SMX_DIAG
     k.gemm_ablate = env_i("SMX_GEMM_ABLATE", 0);
     k.wgroup_ablate = env_i("SMX_WGROUP_ABLATE", 0);

@@ -1736,9 +1736,12 @@ __global__ __launch_bounds__(256) void pool_bcast_kernel(const T* __restrict__ S
 }
 
 extern "C" int smx_pool_bcast_ok(int B, int T, int D) {
-  // a workgroup per (utterance, 64 bf16 / 32 fp32 columns) walks all T frames: the small-batch form (long utterances and big batches
-  // keep the split-T kernels, whose thousands of workgroups stream at 0.72 of the HBM roof)
-  return B >= 1 && T >= 1 && D >= 1 && T <= 4096 && (long)B * T <= 16384;
+  // a workgroup per (utterance, 64 bf16 / 32 fp32 columns) walks all T frames: small batches - and big ones of ordinary utterances whose
+  // (utterance, column group) pairs alone fill the chip (same-box A/B of the steps with it on: C2b B = 128 18.02 -> 17.90 ms, B = 64
+  // 12.00 -> 11.88, C2a 45.36 -> 45.16, C4 38.51 -> 38.00).  Long utterances (config 5: T = 30 000) keep the split-T kernels, whose
+  // thousands of workgroups stream at 0.72 of the HBM roof.  SMX_POOL_FUSE_MAX_ROWS: the frame count up to which few pairs are enough.
+  if (!(B >= 1 && T >= 1 && D >= 1 && T <= 4096)) return 0;
+  return (long)B * T <= (long)cfg().pool_fuse_max_rows || (long)B * ((D + 63) / 64) >= 256;
 }
 
 extern "C" int smx_pool_bcast(int dtype, const void* S, int64_t lds, const uint8_t* mask_in, float* mean_out, const float* inv_in,

@@ -474,6 +474,8 @@ def linear_fwd(x, W, bias=None, act=L.ACT_NONE, mask=None, res=None, alpha=1.0, 
                      alpha=alpha, out_mode=L.OUT_F32 if out_f32 else L.OUT_T, drop=drop, c0_post=c0_post, ln_fwd=lnf,
                      drop_cols=drop_cols, ln_fwd2=lnf2)
     sk = splitk_cfg(N, M, K, x.dtype) if (wparam is not None and c0 is None and drop_cols % 4 == 0) else None
+    if sk is not None and sk[1] == 1 and ln_next is None:
+        sk = None                                          # (one slice and no LayerNorm to absorb: the reducer would be a launch more, not less)
     if sk is not None and _vec_ok(x, out, z, res) and out.stride(0) % 4 == 0 and (res is None or res.stride(0) % 4 == 0):
         # small batch: K-slices on the panel kernel -> float32 slabs; the reducer applies this epilogue (and the LayerNorms) to their sum
         slabs = torch.empty((sk[1], N, M), dtype=torch.float32, device=x.device)

@@ -918,7 +918,7 @@ print("OK")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,T,D", [(10, 375, 512), (1, 500, 256), (3, 17, 40), (7, 1300, 192), (2, 4096, 64)])
+@pytest.mark.parametrize("B,T,D", [(10, 375, 512), (1, 500, 256), (3, 17, 40), (7, 1300, 192), (2, 4096, 64), (128, 500, 256)])
 def test_pool_bcast_equals_masked_mean_then_broadcast(dtype, B, T, D):
     """smx_pool_bcast (round 6, small batches: one launch) against the three-launch path it replaces: the masked mean, its inverse
     count, the dropped broadcast (bit-identical keep decisions: the mask is a function of the element index) and the act / mask
@@ -963,7 +963,7 @@ def test_pool_bcast_equals_masked_mean_then_broadcast(dtype, B, T, D):
     d3 = torch.empty_like(d1)
     ops.pool_bcast(s, None, B, T, ds=d3, scale=False, want_mean=False, inv_in=inv_ref)
     assert torch.equal(d2, d3)
-    assert not ops.pool_bcast_ok(128, 500, 256)
+    assert ops.pool_bcast_ok(128, 500, 256) and not ops.pool_bcast_ok(8, 30000, 512) and not ops.pool_bcast_ok(20, 2000, 256)
 
 
 def test_reduce_jobs_many_jobs_and_ragged_tails():
