@@ -157,6 +157,8 @@ int smx_gemm_plan_query(int layout, int dtype, const void* A, int64_t lda, int64
  * Linear's output is a bf16 tensor).  Any other epilogue field (bias, residual, C0, LayerNorm, fp32 output,
  * column sums) returns SMX_EUNSUPPORTED: use smx_gemm.  smx_gemm_panel_ok: can these sizes take the panel path at all? */
 int smx_gemm_panel_ok(int dtype, int N, int M, int K);
+/* rows per panel the launch for (N, M) would use: 128, or 64 / 32 when a small batch has too few 128-row panels for the chip (round 6) */
+int smx_gemm_panel_rows(int N, int M);
 size_t smx_weight_pack_bytes(int M, int K);
 int smx_weight_pack(int dtype, const void* W, int64_t ldw, int transposed, const float* bias, int M, int K, void* packed, void* stream);
 int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void* Wpacked, void* C, int64_t ldc, int N, int M, int K,

@@ -184,6 +184,7 @@ SIGNATURES = {
     "smx_wgrad_group_direct": (c_i, [c_i, c_i, ctypes.POINTER(WgradDirectItem), c_i, c_vp]),
     "smx_layernorm_bwd2_slabs": (c_i, [c_i, c_vp, c_i, c_i64, c_vp, c_i64, c_i, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp,
                                        c_vp, c_i64, c_f, c_vp, c_f, ctypes.c_uint64, c_vp, c_vp]),
+    "smx_gemm_panel_rows": (c_i, [c_i, c_i]),
     "smx_step_counter_add": (c_i, [c_vp, ctypes.c_uint64, c_vp]),
     "smx_stream_capture_id": (c_i, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "smx_sumsq_workspace": (c_sz, []),

@@ -80,6 +80,34 @@ using namespace smx;
 extern long long* g_dbg_stamps;   // gemm.hip (smx_debug_set_timing_buffer)
 #endif
 
+// one workgroup per CU: with fewer panels than ~3/4 of the CUs a panel's chunk rounds (M / 512 of them) are dealt to 2 or 4 workgroups,
+// and when that still leaves most of the chip idle (a few thousand frames) the panels shrink to 64 or 32 rows (SMX_PANEL_ROWS=<n>: that size)
+static void panel_geometry(int N, int M, int* rows_out, int* csplit_out) {
+  const int rounds = (M / 64 + 7) / 8;
+  auto split_for = [&](int rows) {
+    const int panels = (N + rows - 1) / rows;
+    int cs = 1;
+    while (cs < 4 && panels * cs < 192 && rounds % (cs * 2) == 0) cs *= 2;
+    return cs;
+  };
+  int rows = 128;
+  const int forced = cfg().panel_rows;
+  if (forced == 128 || forced == 64 || forced == 32) rows = forced;
+  else {
+    // the LARGEST panel height whose launch still has ~3/4 of a workgroup per CU (tools/experiments/r06_smalln: one round of
+    // 188-256 workgroups is the best point of every (frames, M) cell between 2 000 and 12 000 frames)
+    while (rows > 32 && ((N + rows - 1) / rows) * split_for(rows) < 180) rows >>= 1;
+  }
+  *rows_out = rows;
+  *csplit_out = split_for(rows);
+}
+
+extern "C" int smx_gemm_panel_rows(int N, int M) {
+  int rows = 128, cs = 1;
+  if (N > 0 && M > 0) panel_geometry(N, M, &rows, &cs);
+  return rows;
+}
+
 extern "C" int smx_gemm_panel_ok(int dtype, int N, int M, int K) {
   return dtype == SMX_BF16 && (K == 256 || K == 512) && N >= 1 && M >= 64 && M % 64 == 0 && (long)N * M * 2 < (1L << 31);
 }
@@ -150,27 +178,7 @@ extern "C" int smx_gemm_panel(int dtype, const void* A, int64_t lda, const void*
   p.drop_cols = e.drop_cols > 0 ? e.drop_cols : M;
   // store policy of smx_gemm: the output is streamed once it cannot survive in the Infinity Cache anyway
   p.nt = ((long)N * M * 2 >= (96L << 20)) ? 2 : 0;
-  // one workgroup per CU: with fewer panels than ~3/4 of the CUs a panel's chunk rounds (M / 512 of them) are dealt to 2 or 4 workgroups,
-  // and when that still leaves most of the chip idle (a few thousand frames) the panels shrink to 64 or 32 rows (SMX_PANEL_ROWS=<n>: that size)
-  {
-    const int rounds = (M / 64 + 7) / 8;
-    auto split_for = [&](int rows) {
-      const int panels = (N + rows - 1) / rows;
-      int cs = 1;
-      while (cs < 4 && panels * cs < 192 && rounds % (cs * 2) == 0) cs *= 2;
-      return cs;
-    };
-    int rows = 128;
-    const int forced = cfg().panel_rows;
-    if (forced == 128 || forced == 64 || forced == 32) rows = forced;
-    else {
-      // the LARGEST panel height whose launch still has ~3/4 of a workgroup per CU (tools/experiments/r06_smalln: one round of
-      // 188-256 workgroups is the best point of every (frames, M) cell between 2 000 and 12 000 frames)
-      while (rows > 32 && ((N + rows - 1) / rows) * split_for(rows) < 180) rows >>= 1;
-    }
-    p.rows = rows;
-    p.csplit = split_for(rows);
-  }
+  panel_geometry(N, M, &p.rows, &p.csplit);
 #ifdef SMX_DIAG
   p.dbg = g_dbg_stamps;
 #endif

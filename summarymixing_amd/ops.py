@@ -260,7 +260,7 @@ def gemm_panel(a, wp, c, N, M, K, epi=None):
         tag = "".join(t for t, on in (("+act", epi.act != L.ACT_NONE and not ag), ("+Z", epi.z and not ag),
                                       ("+actgrad(z)", ag), ("+drop", epi.drop_p > 0)) if on)
         tok = _pb(f"gemm panel bf16 ({N}x{K})x({K}x{M}) {tag}", nb, 2.0 * N * M * K,
-                  f"gemm_panel_kernel<{K}, {1 if ag else 0}, {epi.act}>")
+                  f"gemm_panel_kernel<{K}, {1 if ag else 0}, {epi.act}, {L.lib().smx_gemm_panel_rows(N, M)}>")
     L.check(L.lib().smx_gemm_panel(L.BF16, pa, la, _p(wp), pc, lc, N, M, K, ctypes.byref(epi), _stream()), "smx_gemm_panel")
     _pe(tok)
     return c
@@ -275,7 +275,7 @@ def gemm_panel_slabs(a, wp, slabs, N, M, K, nslice):
     weight_pack images (weight_pack_slices)."""
     pa, la = _mat(a)
     tok = _pb(f"gemm panel slabs bf16 ({N}x{nslice * K})x({nslice * K}x{M}) S={nslice}", (N * nslice * K + M * nslice * K) * 2 + nslice * N * M * 4,
-              2.0 * N * M * K * nslice, f"gemm_panel_kernel<{K}, 2, 0>")
+              2.0 * N * M * K * nslice, f"gemm_panel_kernel<{K}, 2, 0, *>")
     L.check(L.lib().smx_gemm_panel_slabs(L.BF16, pa, la, _p(wp), _p(slabs), N, M, K, nslice, _stream()), "smx_gemm_panel_slabs")
     _pe(tok)
     return slabs
