@@ -492,7 +492,11 @@ _LN_FUSE = os.environ.get("SMX_LN_FUSE", "1") != "0"   # A/B knob: LayerNorm bac
 # CUs idle and each workgroup's serial chain (K loop, four epilogue phases) IS the kernel's duration - 64 us at 16 000 frames
 # against 76 us at 64 000.  Measured on the C2b step (fused / separate kernels, ms): B = 16: 8.30 / 5.97, 32: 9.77 / 8.15,
 # 48: 11.33 / 10.63, 64: 12.97 / 12.56, 80: 15.20 / 15.74, 96: 16.52 / 17.49, 128: 19.11 / 20.24 -> fuse from 36 864 rows.
-_LN_FUSE_MIN_ROWS = int(os.environ.get("SMX_LN_FUSE_MIN_ROWS", "36864"))
+# Round 6, re-measured on the round-5/6 kernels (one-pass LayerNorm epilogue, DPP row sums; tools/experiments/r06_smalln/ab_lnfuse_mid*.sh,
+# same box, separate | fused, ms): C2b B = 32 (16 000 rows) 7.66 | 8.28, B = 36 9.81 | 9.64, 40: 10.13 | 9.91, 48: 10.66 | 10.45, 56: 11.34 | 10.99,
+# 64: 12.00 | 11.53; C2a (d_model 512) B = 32 15.87 | 17.13, 40: 20.70 | 20.55, 48: 22.26 | 21.91, 56: 24.79 | 23.49, 64: 26.85 | 25.31; the recipe's
+# 4 fused micro-batches (15 000 rows) 15.40 | 16.73; C4 at 16 000 / 24 000 rows: ties -> fuse from 17 500 rows (was 36 864).
+_LN_FUSE_MIN_ROWS = int(os.environ.get("SMX_LN_FUSE_MIN_ROWS", "17500"))
 # norm2 of a Conformer layer + the first LayerNorm of the next layer in ONE pass over the float32 stream (smx_layernorm_fwd_pair_x32;
 # tests switch it off to compare with the two-launch path)
 _LN_PAIR = True

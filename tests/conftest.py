@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-# The product fuses a d_model = 256 LayerNorm into its neighbouring GEMM only from 36 864 frames up (functional._LN_FUSE_MIN_ROWS:
+# The product fuses a d_model = 256 LayerNorm into its neighbouring GEMM only from 17 500 frames up (36 864 until round 6) (functional._LN_FUSE_MIN_ROWS:
 # below that the 128-row LayerNorm tile underfills the chip).  The parity tests run at a few hundred to ~16 000 frames, so the
 # encoder-level modules below run TWICE (fixture `ln_fuse_mode`, requested through their `pytestmark`):
 #   lnfuse_default - the shipped dispatch (separate LayerNorm kernels at these sizes: what a user gets at the recipe batch),
