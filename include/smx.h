@@ -55,10 +55,14 @@ typedef struct smx_config {
                                0 off, 1 for K >= 2048 (1), 2 for every eligible shape (tests)                  */
   int32_t panel_rows;       /* SMX_PANEL_ROWS: rows per panel of smx_gemm_panel (128 / 64 / 32); 0 = by frame count  */
   int32_t pool_fuse_max_rows;  /* SMX_POOL_FUSE_MAX_ROWS: smx_pool_bcast_ok up to this many frames (B * T)            */
+  int32_t ln_tile64;        /* SMX_LN_TILE64: the 64 x 256 LayerNorm-fused tile: 0 never, 1 where it fills its rounds better (default), 2 always */
+  int32_t pad_;
 } smx_config;
 int smx_get_config(smx_config* out);
 /* rows per tile of the LayerNorm-fused GEMMs (SMX_EPI_LN_BWD writes ceil(N / rows) partial row pairs into ln_partial) */
 int smx_gemm_ln_tile_rows(void);
+/* ... for a given launch: 64 (d_model = 256 at mid-size batches, round 6) or 128 */
+int smx_gemm_ln_tile_rows_for(int N, int M);
 
 /* Epilogue of the fused projection GEMM:
  *   v      = acc + bias[m] + C0[map(n), m]

@@ -174,6 +174,7 @@ SIGNATURES = {
                                c_vp]),
     "smx_get_config": (c_i, [c_vp]),
     "smx_gemm_ln_tile_rows": (c_i, []),
+    "smx_gemm_ln_tile_rows_for": (c_i, [c_i, c_i]),
     "smx_gemm_panel_slabs_ok": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "smx_gemm_panel_slabs": (c_i, [c_i, c_vp, c_i64, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp]),
     "smx_slab_epilogue_ok": (c_i, [c_i, c_i, c_i, c_i]),
@@ -219,7 +220,7 @@ class Config(ctypes.Structure):
     """smx_config of include/smx.h: the knobs the library read from the environment once."""
     _fields_ = [("ln_tile_rows", ctypes.c_int32),
                 ("gemm_ablate", ctypes.c_int32), ("wgroup_ablate", ctypes.c_int32), ("dwroll_ablate", ctypes.c_int32),
-                ("diag_build", ctypes.c_int32), ("t256", ctypes.c_int32), ("panel_rows", ctypes.c_int32), ("pool_fuse_max_rows", ctypes.c_int32)]
+                ("diag_build", ctypes.c_int32), ("t256", ctypes.c_int32), ("panel_rows", ctypes.c_int32), ("pool_fuse_max_rows", ctypes.c_int32), ("ln_tile64", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 def get_config():

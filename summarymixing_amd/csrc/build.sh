@@ -20,7 +20,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-o
 [[ -n "${SMX_CXXFLAGS:-}" ]] && FLAGS+=(${SMX_CXXFLAGS})
 mkdir -p "$OBJ"
 pids=()
-for f in capi gemm gemm_ln256 gemm_ln512 gemm_panel gemm_panel_bwd rowwise slab_epilogue dwconv frontend ctc reduce wgrad_group; do
+for f in capi gemm gemm_ln256 gemm_ln256r64 gemm_ln512 gemm_panel gemm_panel_bwd rowwise slab_epilogue dwconv frontend ctc reduce wgrad_group; do
   src="${HERE}/${f}.hip"; obj="${OBJ}/${f}.o"
   if [[ ! -f "$obj" || "$src" -nt "$obj" || "${HERE}/smx_common.h" -nt "$obj" || "${HERE}/gemm_common.h" -nt "$obj" || "${HERE}/gemm_kernel.h" -nt "$obj" || "${HERE}/gemm_panel.h" -nt "$obj" || "${HERE}/dwconv_roll.h" -nt "$obj" || "${HERE}/build.sh" -nt "$obj" || "${HERE}/../../include/smx.h" -nt "$obj" ]]; then
     extra=()
@@ -29,5 +29,5 @@ for f in capi gemm gemm_ln256 gemm_ln512 gemm_panel gemm_panel_bwd rowwise slab_
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJ}"/{capi,gemm,gemm_ln256,gemm_ln512,gemm_panel,gemm_panel_bwd,rowwise,slab_epilogue,dwconv,frontend,ctc,reduce,wgrad_group}.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${OBJ}"/{capi,gemm,gemm_ln256,gemm_ln256r64,gemm_ln512,gemm_panel,gemm_panel_bwd,rowwise,slab_epilogue,dwconv,frontend,ctc,reduce,wgrad_group}.o
 echo "built $OUT"

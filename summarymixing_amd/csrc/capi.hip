@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "smx_common.h"
+#include "gemm_common.h"
 
 namespace smx {
 
@@ -38,6 +39,7 @@ const smx_config& cfg() {
     k.t256 = env_i("SMX_T256", 1);
     k.panel_rows = env_i("SMX_PANEL_ROWS", 0);
     k.pool_fuse_max_rows = env_i("SMX_POOL_FUSE_MAX_ROWS", 16384);
+    k.ln_tile64 = env_i("SMX_LN_TILE64", 1);
 #ifdef SMX_DIAG
     k.gemm_ablate = env_i("SMX_GEMM_ABLATE", 0);
     k.wgroup_ablate = env_i("SMX_WGROUP_ABLATE", 0);
@@ -73,5 +75,6 @@ extern "C" int smx_get_config(smx_config* out) {
   return SMX_OK;
 }
 extern "C" int smx_gemm_ln_tile_rows(void) { return smx::cfg().ln_tile_rows; }
+extern "C" int smx_gemm_ln_tile_rows_for(int N, int M) { return smx::ln_tile_rows_for(N, M); }
 extern "C" int smx_version(void) { return SMX_VERSION; }
 extern "C" const char* smx_last_error(void) { return smx::last_error_buf(); }

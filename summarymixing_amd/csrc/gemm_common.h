@@ -38,6 +38,21 @@ struct GemmParams {
 };
 
 // every launch site of the GEMM dispatch: `if (plan_only(p, ...)) return SMX_OK;` in front of its hipLaunchKernelGGL
+// rows per tile of the LayerNorm-fused GEMMs of width M for N frames (= rows per dgamma / dbeta partial row pair).  d_model = 256 has a
+// 64-row tile (round 6): two workgroups per CU = rounds of 512, and a mostly empty last round costs a whole one, so the choice is a
+// quantisation problem: cost = rounds x rows, a workgroup that has its CU to itself (<= 256 of them) runs ~1/4 faster.  Same-box
+// A/B of the C2b step (128 | 64 rows, ms): B = 36: 9.42 | 8.90, 48: 10.08 | 9.51, 64: 11.28 | 10.76, 72: 14.58 | 14.68, 80: 14.65 | 14.94,
+// 96: 15.49 | 16.30, 128: 17.72 | 18.58.  SMX_LN_TILE64: 0 never, 1 this rule, 2 always.
+inline int ln_tile_rows_for(int N, int M) {
+  const int mode = cfg().ln_tile64;
+  if (M != 256 || mode == 0 || N <= 0) return 128;
+  if (mode == 2) return 64;
+  auto cost = [&](int rows) {
+    const long w = (N + rows - 1) / rows;
+    return (double)((w + 511) / 512) * rows * (w <= 256 ? 0.75 : 1.0);
+  };
+  return cost(64) < cost(128) - 1e-9 ? 64 : 128;
+}
 inline bool plan_only(GemmParams& p, int kernel, bool a_kc, bool b_kc, int tn, int tm, bool vec, int lnf, int gather) {
   if (!p.plan) return false;
   *p.plan = smx_gemm_plan{kernel, a_kc, b_kc, tn, tm, vec, lnf, gather};
@@ -1286,10 +1301,10 @@ __device__ __forceinline__ void epilogue_phase_ln1p(const GemmParams& p, const c
   }
 }
 // the tile's statistics: rows [n0, n0 + 128) as one contiguous block (call after a barrier behind the last phase)
-__device__ __forceinline__ void ln1p_store_stats(const GemmParams& p, const float* lnst, int n0, int t) {
-  if (p.e.lnf_stats && t < 128 && n0 + t < p.N)
+__device__ __forceinline__ void ln1p_store_stats(const GemmParams& p, const float* lnst, int n0, int t, int rows = 128) {
+  if (p.e.lnf_stats && t < rows && n0 + t < p.N)
     *reinterpret_cast<float2*>(p.e.lnf_stats + 2 * (long)(n0 + t)) = *reinterpret_cast<const float2*>(lnst + 2 * t);
-  if (p.e.lnf2_y && p.e.lnf2_stats && t >= 128 && n0 + t - 128 < p.N)
+  if (p.e.lnf2_y && p.e.lnf2_stats && t >= 128 && t - 128 < rows && n0 + t - 128 < p.N)
     *reinterpret_cast<float2*>(p.e.lnf2_stats + 2 * (long)(n0 + t - 128)) = *reinterpret_cast<const float2*>(lnst + 2 * t);
 }
 

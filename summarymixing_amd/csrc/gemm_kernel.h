@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
   static_assert(GATHER < 3 || (sizeof(T) == 4 && A_KC && B_KC && LNF == 0), "GATHER 3 / 4 (folded DFT frames): float32 NT");
   static_assert(GATHER != 1 || (A_KC && B_KC), "GATHER 1: NT");
   static_assert(GATHER != 2 || (!A_KC && !B_KC), "GATHER 2: TN");
-  static_assert(LNF == 0 || (sizeof(T) == 2 && VEC && (TILE_M == 256 || TILE_M == 512) && TILE_N == 128), "fused LayerNorm: bf16 128 x 256 / 128 x 512 tile");
+  static_assert(LNF == 0 || (sizeof(T) == 2 && VEC && (TILE_M == 256 || TILE_M == 512) && (TILE_N == 128 || (TILE_N == 64 && TILE_M == 256))),
+                "fused LayerNorm: bf16 128 x 256 / 128 x 512 / 64 x 256 tile");
   static_assert(LNF <= 3 || LNF == 5 || LNF == 7, "LNF: 1 / 3 LayerNorm backward (3: extended), 2 forward, +4 = float32 ln_x");
   // ROW512: the row-complete tile of d_model = 512 (128 rows x 512 columns = 64 K outputs, ONE workgroup per CU, the four waves side
   // by side: 128 x 128 outputs = 256 accumulator registers each, the wave tile of the 256 x 256 kernel) on the same explicit
@@ -41,7 +42,12 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
   constexpr bool ROW512 = TILE_M == 512;
   static_assert(!ROW512 || (sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && GATHER == 0), "128 x 512 tile: bf16, aligned, NT / NN");
   constexpr int BK = ElemTraits<T>::BK;
-  constexpr int WAVES_M = ROW512 ? 4 : 2, WAVES_N = 4 / WAVES_M;
+  // ROW64 (round 6): the row-complete 64 x 256 tile of d_model = 256 for 17 500 - 37 000 frames, where 128-row tiles are fewer than the
+  // chip's 512 workgroup slots (B = 64 x 500: 250): twice the workgroups, the four waves side by side (64 x 64 outputs each: as many
+  // fragment reads per MFMA as the 128 x 256 tile's 64 x 128), the same software pipeline with ONE activation piece per step
+  constexpr bool ROW64 = TILE_N == 64 && TILE_M == 256;
+  static_assert(!ROW64 || (sizeof(T) == 2 && VEC && A_KC && GATHER == 0), "64 x 256 tile: bf16, aligned, NT / NN");
+  constexpr int WAVES_M = (ROW512 || ROW64) ? 4 : 2, WAVES_N = 4 / WAVES_M;
   constexpr int WN = TILE_N / WAVES_N, WM = TILE_M / WAVES_M;
   constexpr int FN = WN / 32, FM = WM / 32;
   constexpr int A_BYTES = lds_bytes<T, TILE_N, A_KC>();
@@ -57,13 +63,13 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
   constexpr bool T256P = (sizeof(T) == 2 && VEC && A_KC && TILE_N == 256 && TILE_M == 256 && GATHER == 0 && LNF == 0) || ROW512;
   // W128P: the 128 x 256 tile (two workgroups per CU, every LayerNorm-fused epilogue) with the same explicit software pipeline
   // in 32-element steps: both operands double-buffered in LDS (2 x 24 KB = the one 48 KB stage of the serial loop)
-  constexpr bool W128P = sizeof(T) == 2 && VEC && A_KC && TILE_N == 128 && TILE_M == 256 && GATHER == 0;
+  constexpr bool W128P = sizeof(T) == 2 && VEC && A_KC && (TILE_N == 128 || TILE_N == 64) && TILE_M == 256 && GATHER == 0;
   constexpr int AB_BYTES = T256P ? 2 * (A_BYTES + B_BYTES) : A_BYTES + B_BYTES;
   constexpr int SMEM_BYTES = AB_BYTES > EPI_BYTES ? AB_BYTES : EPI_BYTES;
   constexpr int RED_BYTES = TILE_M * 4;                          // colsum: phase-0 column sums
   // bias[TILE_M] | row factors[TILE_N] (mask * alpha) [| LN gamma | beta [LN forward: | the tile's (mean, rstd) pairs of both
   // LayerNorms | gamma | beta of the second LayerNorm]]
-  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0) + (LNF == 2 ? 4 * TILE_N + 2 * TILE_M : 0)) * 4;
+  constexpr int SIDE_BYTES = (TILE_M + TILE_N + (LNF ? 2 * TILE_M : 0) + (LNF == 2 ? 4 * 128 + 2 * TILE_M : 0)) * 4;   // (statistics block: [2][128][2] whatever TILE_N)
   // when the block would pass the 64 KB static LDS limit its small epilogue arrays live behind the epilogue staging rows
   // inside the (by then dead) operand stage, fenced by one extra barrier
   constexpr bool ALIAS_SIDE = SMEM_BYTES + RED_BYTES + SIDE_BYTES > 65536;
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
       // (its own loop, chosen ONCE: with both paths inside one loop their hoisted row pointers and constants are live together and
       //  hipcc spills - every reload then sits behind the stores of the previous item, s_waitcnt vmcnt(0))
       float* lnst = lng + 2 * TILE_M;                      // [2][128][2]: statistics of the LayerNorm and of the optional second one
-      float* lng2 = lnst + 4 * TILE_N;                     // gamma | beta of the second LayerNorm
+      float* lng2 = lnst + 4 * 128;                        // gamma | beta of the second LayerNorm
       if (e.lnf2_y) {                                      // (uniform; visible behind the first barrier of the loop)
 #pragma unroll
         for (int cc = t; cc < TILE_M; cc += 256) { lng2[cc] = e.lnf2_gamma[cc]; lng2[TILE_M + cc] = e.lnf2_beta[cc]; }
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE
       }
       lds_barrier();
       asm volatile("" :: "v"(st_touch));
-      ln1p_store_stats(p, lnst, n0, t);
+      ln1p_store_stats(p, lnst, n0, t, TILE_N);
       SMX_STAMP(7);
       return;
     }

@@ -5,9 +5,12 @@
 
 namespace smx {
 
+int launch_ln_fused_256_r64(GemmParams& p, bool b_kc, hipStream_t s);      // gemm_ln256r64.hip: the 64 x 256 tile
+
 template <bool B_KC>
 static int launch_ln(GemmParams& p, hipStream_t s) {
   typedef bf16_t T;
+  if (ln_tile_rows_for(p.N, 256) == 64) return launch_ln_fused_256_r64(p, B_KC, s);
   p.tiles_n = (p.N + 127) / 128;
   p.tiles_m = 1;
   const dim3 grid(p.tiles_n), block(256);

@@ -98,8 +98,28 @@ static void panel_geometry(int N, int M, int* rows_out, int* csplit_out) {
     // 188-256 workgroups is the best point of every (frames, M) cell between 2 000 and 12 000 frames)
     while (rows > 32 && ((N + rows - 1) / rows) * split_for(rows) < 180) rows >>= 1;
   }
+  int cs = split_for(rows);
+  // One panel per CU at a time, so the launch runs in rounds of 256 workgroups and a mostly empty last round costs a whole one: C2b
+  // B = 72 x 500 is 282 panels of 128 rows - the up-projection took 54 us against 33 us at B = 64 (250 panels).  Among 128- / 64-row panels
+  // with the chunk rounds dealt to 1, 2 or 4 workgroups, take the geometry that fills its rounds best (a 64-row panel streams the
+  // weights twice per 128 rows: -5 %; every doubling of the split stages the panel once more: -2 %).
+  if (forced == 0 && rows == 128 && (long)((N + 127) / 128) * cs > 256) {
+    double best = -1.0;
+    int brows = 128, bcs = cs;
+    for (int r = 128; r >= 64; r >>= 1) {
+      for (int c = cs; c <= 4; c *= 2) {
+        if (rounds % c != 0) break;
+        const long wgs = (long)((N + r - 1) / r) * c;
+        double score = (double)wgs / (256.0 * (double)((wgs + 255) / 256));
+        if (r == 64) score *= 0.95;
+        for (int q = cs; q < c; q *= 2) score *= 0.98;
+        if (score > best + 1e-9) { best = score; brows = r; bcs = c; }
+      }
+    }
+    rows = brows; cs = bcs;
+  }
   *rows_out = rows;
-  *csplit_out = split_for(rows);
+  *csplit_out = cs;
 }
 
 extern "C" int smx_gemm_panel_rows(int N, int M) {

@@ -568,7 +568,7 @@ def linear_bwd(dy, x, W, z, act, mask, alpha, gW, gb, need_dx=True, res_grad=Non
         if ln is not None:
             assert up is None and dx_drop is None and K % 64 == 0
             gw_ln, gb_ln = gacc(ln["gw_param"]).view(-1), gacc(ln["gb_param"]).view(-1)
-            tr = L.lib().smx_gemm_ln_tile_rows()              # rows per LayerNorm-fused tile = per partial row pair
+            tr = L.lib().smx_gemm_ln_tile_rows_for(N, K)      # rows per LayerNorm-fused tile = per partial row pair (64 or 128)
             ntile = (N + tr - 1) // tr
             ws = deferred_ws(gw_ln.data_ptr(), ntile * 2 * K * 4, dy.device)
             dx2 = torch.empty((N, K), dtype=dy.dtype, device=dy.device) if ln_second is not None else None

@@ -643,7 +643,7 @@ def test_wgrad_tied_weight_across_flushes():
 # ---- LayerNorm fused into the row-complete GEMM epilogues (SMX_EPI_LN_BWD / SMX_EPI_LN_FWD): 128 x 256 tile (d_model = 256, two
 # workgroups per CU) and 128 x 512 tile (d_model = 512, one workgroup per CU on the software-pipelined main loop) ------------------
 @pytest.mark.parametrize("D", [256, 512])
-@pytest.mark.parametrize("N,K", [(4096, 1024), (33000 + 77, 512), (200, 256), (2000 + 13, 2048)])
+@pytest.mark.parametrize("N,K", [(4096, 1024), (33000 + 77, 512), (200, 256), (2000 + 13, 2048), (50000 + 5, 256)])
 def test_gemm_epilogue_layernorm_backward(N, K, D):
     """dgrad GEMM whose epilogue runs the LayerNorm backward (rows complete in the tile): dX, the second output
     alpha * D(dX) * mask, and the per-tile dgamma / dbeta partial rows against fp64 torch math."""
@@ -659,7 +659,7 @@ def test_gemm_epilogue_layernorm_backward(N, K, D):
     mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
     rstd = (var + 1e-5).rsqrt()
     stats = torch.cat([mean, rstd], 1).float().contiguous()
-    tr = L.lib().smx_gemm_ln_tile_rows()
+    tr = L.lib().smx_gemm_ln_tile_rows_for(N, D)      # (64-row tiles at d_model 256 up to ~38 000 frames: round 6)
     ntile = (N + tr - 1) // tr
     partial = torch.zeros(ntile, 2, D, device="cuda")
     dx, dx2 = torch.empty(N, D, device="cuda", dtype=torch.bfloat16), torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
@@ -706,7 +706,7 @@ def test_gemm_epilogue_layernorm_forward(N, K, act, D):
 
 
 @pytest.mark.parametrize("D", [256, 512])
-@pytest.mark.parametrize("N,K", [(4096 + 9, 1024), (300, 2048)])
+@pytest.mark.parametrize("N,K", [(4096 + 9, 1024), (300, 2048), (45000 + 3, 512)])
 @pytest.mark.parametrize("layout", ["NT", "NN"])
 def test_gemm_epilogue_layernorm_float32_stream(N, K, layout, D):
     """The autocast forms (float32 residual stream next to bf16 operands), both weight layouts: forward = Linear + bias +
@@ -738,7 +738,7 @@ def test_gemm_epilogue_layernorm_float32_stream(N, K, layout, D):
     rstd = (var + 1e-5).rsqrt()
     st = torch.cat([mean, rstd], 1).float().contiguous()
     rg = torch.randn(N, D, device="cuda").bfloat16()
-    tr = L.lib().smx_gemm_ln_tile_rows()
+    tr = L.lib().smx_gemm_ln_tile_rows_for(N, D)      # (64-row tiles at d_model 256 up to ~38 000 frames: round 6)
     partial = torch.zeros((N + tr - 1) // tr, 2, D, device="cuda")
     dx = torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
     ops.gemm(lay, a, Wop, dx, N, D, K, ops.epilogue(res=rg, ln_bwd=(x32, st, gamma, partial, None, None, None, True)))
@@ -801,7 +801,7 @@ def test_gemm_epilogue_layernorm_backward_with_activations(D):
     mean, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
     rstd = (var + 1e-5).rsqrt()
     stats = torch.cat([mean, rstd], 1).float().contiguous()
-    tr = L.lib().smx_gemm_ln_tile_rows()
+    tr = L.lib().smx_gemm_ln_tile_rows_for(N, D)      # (64-row tiles at d_model 256 up to ~38 000 frames: round 6)
     partial = torch.zeros((N + tr - 1) // tr, 2, D, device="cuda")
     dx, dx2 = torch.empty(N, D, device="cuda", dtype=torch.bfloat16), torch.empty(N, D, device="cuda", dtype=torch.bfloat16)
     e = ops.epilogue(ln_bwd=(x, stats, gamma, partial, dx2, (1.0, None, None, z2, L.ACT_SWISH), (beta, L.ACT_SWISH)))

@@ -108,7 +108,7 @@ xs = rnd(N, d)
 _, stats = ops.layernorm_fwd(xs, gam, bet, 1e-5, True, L.ACT_NONE, out_dtype=torch.bfloat16)
 dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
 p4 = T(lambda: ops.layernorm_bwd(gh, xs, gam, bet, stats, dg, db, dy, L.ACT_NONE))
-tr = L.lib().smx_gemm_ln_tile_rows()
+tr = L.lib().smx_gemm_ln_tile_rows_for(N, d)
 ws = torch.zeros(((N + tr - 1) // tr) * 2 * d, device=dev)
 dxo = torch.empty(N, d, device=dev, dtype=torch.bfloat16)
 if LNF:

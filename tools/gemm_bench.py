@@ -82,7 +82,7 @@ def build(N, K, M, layout, dtype=torch.bfloat16, epi="swishz"):
         g_, b_ = torch.ones(M, device="cuda"), torch.zeros(M, device="cuda")
         rg = torch.randn(N, M, device="cuda").to(dtype)
         dx2 = torch.empty(N, M, device="cuda", dtype=dtype)
-        tr = L.lib().smx_gemm_ln_tile_rows()
+        tr = L.lib().smx_gemm_ln_tile_rows_for(N, M)
         ws = torch.empty(((N + tr - 1) // tr) * 2 * M, device="cuda")
         if layout == "NNlnb3":   # + the consumer's activation gradient in the second output (the cell's dy * act'(z_m))
             z2 = torch.randn(N, M, device="cuda").to(dtype)
