@@ -43,13 +43,17 @@ struct GemmParams {
 // quantisation problem: cost = rounds x rows, a workgroup that has its CU to itself (<= 256 of them) runs ~1/4 faster.  Same-box
 // A/B of the C2b step (128 | 64 rows, ms): B = 36: 9.42 | 8.90, 48: 10.08 | 9.51, 64: 11.28 | 10.76, 72: 14.58 | 14.68, 80: 14.65 | 14.94,
 // 96: 15.49 | 16.30, 128: 17.72 | 18.58.  SMX_LN_TILE64: 0 never, 1 this rule, 2 always.
+#ifndef SMX_R64_OCC
+#define SMX_R64_OCC 2
+#endif
 inline int ln_tile_rows_for(int N, int M) {
   const int mode = cfg().ln_tile64;
   if (M != 256 || mode == 0 || N <= 0) return 128;
   if (mode == 2) return 64;
   auto cost = [&](int rows) {
     const long w = (N + rows - 1) / rows;
-    return (double)((w + 511) / 512) * rows * (w <= 256 ? 0.75 : 1.0);
+    const long slots = rows == 64 ? 256L * SMX_R64_OCC : 512L;
+    return (double)((w + slots - 1) / slots) * rows * (w <= 256 ? 0.75 : 1.0);
   };
   return cost(64) < cost(128) - 1e-9 ? 64 : 128;
 }

@@ -13,6 +13,9 @@ namespace smx {
 #ifndef SMX_KOCC
 #define SMX_KOCC 3
 #endif
+#ifndef SMX_R64_OCC
+#define SMX_R64_OCC 2      // workgroups per CU of the 64 x 256 LayerNorm-fused tile (3: 168 registers)
+#endif
 #ifndef SMX_NS_KC
 #define SMX_NS_KC 1
 #endif
@@ -28,7 +31,7 @@ constexpr int kNsKc = SMX_NS_KC;       // ... of the 128 x 128 tile
 // GATHER (bf16, 64 x 64 tile): 1 = the A operand of an NT GEMM, 2 = the B operand of a TN GEMM is the implicit patch matrix of a
 // 3 x 3 / stride 2 convolution over 64 channels (GemmParams::g_*): the front-end's second block without im2col.
 template <typename T, bool A_KC, bool B_KC, int TILE_N, int TILE_M, bool VEC, int LNF = 0, int GATHER = 0>
-__global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE_M > 128 || !A_KC) ? 2 : kOcc))) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, ((TILE_N == 256 || TILE_M == 512) ? 1 : ((TILE_N == 64 && TILE_M == 256) ? SMX_R64_OCC : ((TILE_M > 128 || !A_KC) ? 2 : kOcc)))) void gemm_kernel(GemmParams p) {
   static_assert(GATHER == 0 || GATHER >= 3 || (sizeof(T) == 2 && VEC && TILE_N == 64 && TILE_M == 64 && LNF == 0), "GATHER 1 / 2: bf16 64 x 64 tile");
   static_assert(GATHER < 3 || (sizeof(T) == 4 && A_KC && B_KC && LNF == 0), "GATHER 3 / 4 (folded DFT frames): float32 NT");
   static_assert(GATHER != 1 || (A_KC && B_KC), "GATHER 1: NT");
