@@ -447,3 +447,54 @@ def test_layernorm_pair_in_the_stack_equals_two_launches(d, monkeypatch, ln_fuse
     assert rel_err(y1, y0) < 8e-3 and rel_err(g1, g0) < 1.6e-2
     for n in p0:
         assert rel_err(p1[n], p0[n]) < 1.6e-2, n
+
+
+@pytest.mark.parametrize("B,T,d,f", [(1, 500, 256, 1024), (2, 375, 512, 2048)])
+def test_small_batch_split_k_path_every_parameter_gradient_vs_oracle(B, T, d, f, monkeypatch):
+    """Round 6, the dispatch of a batch below 2048 frames (one utterance of 500 frames at d_model 256; two recipe utterances at d_model
+    512): the long reductions as split-K slabs whose reducer applies the Linear's epilogue and the LayerNorm behind it (smx_gemm_panel_slabs
+    + smx_slab_epilogue), the LayerNorm backward fed from the slabs of the dgrad behind it (smx_layernorm_bwd2_slabs), the weight
+    gradients of a layer in one slab-free launch (smx_wgrad_group_direct), 32-row panels.  Output, dL/dx and EVERY parameter gradient of
+    two layers against the fp64 oracle's autograd (Conformer.py:479-537), and the record that those kernels really ran."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd import functional as F
+    from summarymixing_amd import ops
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(17)
+    enc = ConformerEncoder(2, d, f, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast")
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+            elif "bias" in n:
+                p.normal_(0, 0.05)
+    sd = {k: v.double().requires_grad_(True) for k, v in enc.state_dict().items()}
+    x = torch.randn(B, T, d)
+    lens = torch.tensor([T] + [T - 97] * (B - 1))
+    pad = torch.arange(T)[None] < lens[:, None]
+    r = torch.randn(B, T, d) * pad[..., None]
+    xr = x.double().requires_grad_(True)
+    ref = O.conformer_encoder(xr, sd, "", "swish", "SummaryMixing-fast", d, None, pad)
+    (ref * r.double()).sum().backward()
+    enc = enc.cuda().train()
+    xg = x.cuda().bfloat16().requires_grad_(True)
+    ops.prof_start()
+    y, _ = enc(xg, src_key_padding_mask=pad.cuda())
+    (y.float() * r.cuda()).sum().backward()
+    F.flush_deferred()
+    names = [rec[0] for rec in ops.prof_stop()]
+    torch.cuda.synchronize()
+    shipped = F._LN_FUSE_MIN_ROWS > 0      # (the lnfuse_always fixture sends the dgrads through the LayerNorm-fused GEMM epilogues instead)
+    assert sum(n.startswith("gemm panel slabs") for n in names) >= (12 if shipped else 6), names   # per layer: 2 down-projections + conv out forward, 2 + 1 dgrads
+    assert sum(n.startswith("slab epilogue") and "+LNfwd" in n for n in names) >= 6
+    assert sum("layernorm_bwd from slabs" in n for n in names) >= (6 if shipped else 0)
+    assert sum(n.startswith("wgrad_group direct") for n in names) == 2
+    assert rel_err(y, ref) <= 1e-2, rel_err(y, ref)
+    assert rel_err(xg.grad, xr.grad) <= 3e-2, rel_err(xg.grad, xr.grad)
+    worst = ("", 0.0)
+    for n, p in enc.named_parameters():
+        e = rel_err(p.grad, sd[n].grad)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] <= 3e-2, worst
