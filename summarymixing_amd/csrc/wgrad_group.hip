@@ -321,9 +321,12 @@ struct WgDirectParams {
   int nitems, total_tiles, rows;
 };
 
+#ifndef SMX_WGD_BK
+#define SMX_WGD_BK 64     // frames per ring stage of the slab-free grouped wgrad: 64 = ring of two, 32 = ring of four (the same 64 KB)
+#endif
 __global__ __launch_bounds__(256, 2) void wgrad_group_direct_kernel(const WgDirectParams p) {
   typedef bf16_t T;
-  constexpr int BK = 64, NST = 2, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
+  constexpr int BK = SMX_WGD_BK, NST = 128 / BK, TILE = 128, WN = 64, WM = 64, FN = 2, FM = 2;
   constexpr int OP_BYTES = BK * TILE * 2, STAGE_BYTES = 2 * OP_BYTES, NPC = BK / 16;
   constexpr int PH_ROWS = 64, STG_LD = TILE * 4 + 16;
   __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE_BYTES];      // the ring (64 KB); the epilogue rows alias it
@@ -402,11 +405,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_group_direct_kernel(const WgDire
       }
     }
   };
-  if (niter > 0) issue(0);
+  for (int s_ = 0; s_ < NST - 1 && s_ < niter; ++s_) issue(s_);
   for (int itn = 0; itn < niter; ++itn) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage itn have landed (ring of two: nothing younger in flight)
+    // this wave's pieces of stage itn have landed when at most the (2 NPC each) DMA instructions of the younger stages in flight are
+    // outstanding (vmcnt retires in order; nothing else uses vector memory in this loop)
+    const int ahead = min(NST - 2, niter - 1 - itn);
+    if (ahead >= 2 && NST >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
+    else if (ahead >= 1 && NST >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();                                       // ... and everybody's; the stage read last step is free again
-    if (itn + 1 < niter) issue(itn + 1);
+    if (itn + NST - 1 < niter) issue(itn + NST - 1);
     const char* As = smem + (itn % NST) * STAGE_BYTES;
     multiply(As, As + OP_BYTES);
   }
