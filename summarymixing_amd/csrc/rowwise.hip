@@ -1617,6 +1617,9 @@ extern "C" int smx_masked_mean_bwd_act(int dtype, const float* g, const float* i
 // CL lanes x VT::N columns per row and workgroup, RS = 256 / CL row slots (chosen at launch: narrower groups = more workgroups
 // and more rows in flight for the 10-utterance recipe batch or a single utterance - the first version, 8 lanes and 4 rows in flight
 // on 80 workgroups, took 10-15 us: three dependent round trips per slot).
+#ifndef SMX_PB_UB
+#define SMX_PB_UB 4      // rows in flight of the backward's write phase
+#endif
 template <typename T, bool VEC, int CL>
 __global__ __launch_bounds__(256) void pool_bcast_kernel(const T* __restrict__ S, long lds, const uint8_t* __restrict__ mask_in,
                                                          float* mean_out, const float* __restrict__ inv_in, float* inv_out,
@@ -1701,24 +1704,23 @@ __global__ __launch_bounds__(256) void pool_bcast_kernel(const T* __restrict__ S
   if (Z || mask_out) {                                     // backward through act(.) * mask of the producing projection
     dispatch_act(Z ? act : SMX_ACT_NONE, [&](auto act_tag) {
       constexpr int ACT = decltype(act_tag)::value;
-      for (int t = rs; t < T_; t += 2 * RS) {               // (two rows in flight)
-        const long n0 = (long)b * T_ + t, n1 = n0 + RS;
-        const bool two = t + RS < T_;
-        const float mk0 = mask_out ? (mask_out[n0] ? 1.f : 0.f) : 1.f;
-        const float mk1 = (two && mask_out) ? (mask_out[n1] ? 1.f : 0.f) : 1.f;
-        float o0[N], o1[N];
-        if (ACT != SMX_ACT_NONE) {
-          float z0[N], z1[N];
-          loadv<T, VEC>(Z + n0 * ldz + col, nvalid, z0);
-          loadv<T, VEC>(Z + (two ? n1 : n0) * ldz + col, nvalid, z1);
+      constexpr int UB = SMX_PB_UB;                         // rows in flight
+      for (int t = rs; t < T_; t += UB * RS) {
+        float z[UB][N], mk[UB];
 #pragma unroll
-          for (int i = 0; i < N; ++i) { o0[i] = v[i] * mk0 * act_grad_c<ACT>(z0[i]); o1[i] = v[i] * mk1 * act_grad_c<ACT>(z1[i]); }
-        } else {
-#pragma unroll
-          for (int i = 0; i < N; ++i) { o0[i] = v[i] * mk0; o1[i] = v[i] * mk1; }
+        for (int u = 0; u < UB; ++u) {
+          const long n = (long)b * T_ + min(t + u * RS, tlast);
+          mk[u] = mask_out ? (mask_out[n] ? 1.f : 0.f) : 1.f;
+          if (ACT != SMX_ACT_NONE) loadv<T, VEC>(Z + n * ldz + col, nvalid, z[u]);
         }
-        storev<T, VEC>(dS + n0 * ldds + col, nvalid, o0);
-        if (two) storev<T, VEC>(dS + n1 * ldds + col, nvalid, o1);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (t + u * RS >= T_) break;
+          float o[N];
+#pragma unroll
+          for (int i = 0; i < N; ++i) o[i] = ACT != SMX_ACT_NONE ? v[i] * mk[u] * act_grad_c<ACT>(z[u][i]) : v[i] * mk[u];
+          storev<T, VEC>(dS + ((long)b * T_ + t + u * RS) * ldds + col, nvalid, o);
+        }
       }
     });
   } else if (dthresh == 0) {
