@@ -2,7 +2,7 @@
 # Re-measure everything profiles/ holds for this round (run on the GPU box through gpurun; outputs land in
 # gpurun_out/refresh/, copy them into profiles/ afterwards):  gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03 v2'
 set -uo pipefail
-R="${1:-r05}"; TAG="${2:-vX}"
+R="${1:-r06}"; TAG="${2:-vX}"
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/refresh"; mkdir -p "$OUT"
 cd "$ROOT"
@@ -33,6 +33,9 @@ STEPS=7 prof "${R}_step_c2b_dynchunk_8_2_${TAG}.txt" "rocprofv3 --kernel-trace -
 STEPS=1 prof "${R}_frontend_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python tools/frontend_bench.py   (waveform -> fbank -> InputNormalization -> CNN fwd / fwd+bwd at B = 128 x 20 s; per-call averages are the figures, the 'step' total covers all timed repetitions)" python "$ROOT/tools/frontend_bench.py"
 STEPS=25 prof "${R}_step_c2b_b1_${TAG}.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --batch 1 --steps 20 --warmup 5   (25 steps; C2b, ONE utterance of 500 frames, hipGraph replay)" python "$ROOT/bench.py" --batch 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra-points
 python bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-extra-points 2>/dev/null | tail -1 > "$OUT/${R}_bench_b1.json"
+STEPS=9 prof "${R}_step_c2b_b64_v2.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --batch 64 --steps 6 --warmup 2   (9 steps incl. the capture; C2b, B = 64 x T = 500: every launch a whole round)" python "$ROOT/bench.py" --batch 64 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-extra-points
+STEPS=9 prof "${R}_step_c2b_b72_v1.txt" "rocprofv3 --kernel-trace --stats -- python bench.py --batch 72 --steps 6 --warmup 2   (9 steps incl. the capture; C2b, B = 72 x T = 500: just behind the whole-round sweet spot)" python "$ROOT/bench.py" --batch 72 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-extra-points
+{ for b in 48 56 64 68 72 80 96 112 128 136 160; do python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-extra-points 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C2b B = %3d x T = 500  %8.3f ms  %10.0f frames/s' % ($b, d['ms_per_step'], d['value']))"; done; } > "$OUT/${R}_batch_curve.txt"
 python bench.py --config c2a --batch 10 --frames 375 --grad-accum 4 --accum fused --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > "$OUT/${R}_bench_c2a_recipe_accum4_fused.json"
 python tools/blaslt_plus_epilogue.py > "$OUT/${R}_blaslt_plus_epilogue.txt" 2>/dev/null
 D=512 F=2048 python tools/blaslt_plus_epilogue.py > "$OUT/${R}_blaslt_plus_epilogue_d512.txt" 2>/dev/null
