@@ -103,7 +103,9 @@ static void panel_geometry(int N, int M, int* rows_out, int* csplit_out) {
   // B = 72 x 500 is 282 panels of 128 rows - the up-projection took 54 us against 33 us at B = 64 (250 panels).  Among 128- / 64-row panels
   // with the chunk rounds dealt to 1, 2 or 4 workgroups, take the geometry that fills its rounds best (a 64-row panel streams the
   // weights twice per 128 rows: -5 %; every doubling of the split stages the panel once more: -2 %).
-  if (forced == 0 && rows == 128 && (long)((N + 127) / 128) * cs > 256) {
+  // Up to four rounds only: beyond, the last round is a small part of the launch and the panel staged twice comes from HBM, not L2
+  // (config 5, 240 000 rows = 1875 panels: 484 -> 534 us and 308 -> 363 us with the chunk rounds dealt to two workgroups).
+  if (forced == 0 && rows == 128 && (long)((N + 127) / 128) * cs > 256 && (long)((N + 127) / 128) * cs <= 1024) {
     double best = -1.0;
     int brows = 128, bcs = cs;
     for (int r = 128; r >= 64; r >>= 1) {
