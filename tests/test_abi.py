@@ -109,3 +109,26 @@ def test_grouped_wgrad_slice_plan_is_size_aware():
     for rows in (64, 700, 3750, 16000, 64000, 240000):
         s = plan(rows, c2a)
         assert 1 <= s <= max(1, rows // 64 // 8) or s == 1    # at least 8 steps of 64 frames per slice
+
+
+def test_launch_geometry_rules_need_no_gpu_and_hold_their_measured_cells():
+    """The library's geometry choices are host arithmetic (no GPU): the panel height (smx_gemm_panel_rows) and the row-complete
+    LayerNorm tile (smx_gemm_ln_tile_rows_for) at the sizes whose A/B tables are in tools/experiments/r06_smalln/README.md."""
+    import subprocess
+    import sys
+    # (a fresh process with the knobs unset: the library reads SMX_PANEL_ROWS / SMX_LN_TILE64 once)
+    code = ("import ctypes;from summarymixing_amd import _lib;L=_lib.lib();"
+            "print([L.smx_gemm_panel_rows(n,m) for n,m in ((3750,2048),(3750,1024),(500,1024),(12000,512),(32000,1024),(36000,1024),(64000,1024),(240000,2048),(240000,512))]);"
+            "print([L.smx_gemm_ln_tile_rows_for(n,m) for n,m in ((17500,256),(32000,256),(36000,256),(64000,256),(32000,512),(0,256))]);"
+            "print([L.smx_pool_bcast_ok(b,t,d) for b,t,d in ((10,375,512),(1,500,256),(128,500,256),(8,30000,512),(2,4096,64),(2,4097,64))])")
+    env = {k: v for k, v in os.environ.items() if k not in ("SMX_PANEL_ROWS", "SMX_LN_TILE64", "SMX_POOL_FUSE_MAX_ROWS")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, cwd=ROOT, env=env).stdout.splitlines()
+    rows, tiles, pools = eval(out[-3]), eval(out[-2]), eval(out[-1])
+    # 3750 frames: 64-row panels for the 2048-wide up-projection, 32 rows at 1024 (one round of 188-256 workgroups); one utterance: 32 rows;
+    # 12 000 x 512: 64 rows; 32 000 rows = 250 panels of 128; 36 000 rows (282 panels) takes the geometry that fills its rounds; config 5's
+    # 1875 panels stay on 128 rows (the round-efficiency rule stops at four rounds)
+    assert rows[0] == 64 and rows[1] == 32 and rows[2] == 32 and rows[3] == 64 and rows[4] == 128 and rows[6] == 128
+    assert rows[5] in (64, 128) and rows[7] == 128 and rows[8] == 128
+    # the 64-row LayerNorm tile where 128-row tiles leave one workgroup per CU (<= 32 768 rows at d_model 256), never at d_model 512
+    assert tiles == [64, 64, 128, 128, 128, 128]
+    assert pools == [1, 1, 1, 0, 1, 0]
