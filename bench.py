@@ -121,7 +121,7 @@ def time_kernel(fn, iters=30, warm=5):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-PMC_FILES = ("r05_pmc_panel.txt", "r05_pmc_traffic.txt", "r05_pmc_wgrad_group.txt", "r04_pmc_traffic.txt", "r04_pmc_wgrad_group.txt", "r03_pmc_traffic.txt", "r03_pmc_wgrad_group.txt", "r02_pmc_traffic.txt", "r02_pmc_wgrad_group.txt", "r01_pmc_traffic.txt")
+PMC_FILES = ("r06_pmc_traffic.txt", "r05_pmc_panel.txt", "r05_pmc_traffic.txt", "r05_pmc_wgrad_group.txt", "r04_pmc_traffic.txt", "r04_pmc_wgrad_group.txt", "r03_pmc_traffic.txt", "r03_pmc_wgrad_group.txt", "r02_pmc_traffic.txt", "r02_pmc_wgrad_group.txt", "r01_pmc_traffic.txt")
 PMC_NOTE = ("HBM bytes per launch read from the COMMITTED PMC passes under profiles/ (TCC FETCH_SIZE x2-corrected + "
             "WRITE_SIZE, separate --pmc passes of tools/pmc_traffic.sh / pmc_panel.sh / pmc_wgroup.sh on this exact shape) - a constant of the build, "
             "not measured in this run; null when no pass exists for the shape")
