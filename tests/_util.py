@@ -53,7 +53,7 @@ def rms_rel(a, b):
 
 
 def report(name, entries):
-    """Append measured errors to gpurun_out/parity_errors.jsonl (copied into DESIGN.md §2 / profiles/ by hand)."""
+    """Append measured errors to gpurun_out/parity_errors.jsonl (copied into DESIGN.md §I.1 / profiles/ by hand)."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

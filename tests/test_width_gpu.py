@@ -10,7 +10,7 @@ defaults):
 
 Tolerances: fp32 1e-3 (north_star) on outputs and every gradient, both as max|a-b|/max|b| and as RMS-relative error.
 bf16: activations are STORED in bf16 between kernels, so the error grows with depth; asserted per test below and the
-measured values are written to gpurun_out/parity_errors.jsonl (quoted in DESIGN.md §2)."""
+measured values are written to gpurun_out/parity_errors.jsonl (quoted in DESIGN.md §I.1)."""
 import pytest
 import torch
 

@@ -1,6 +1,6 @@
 // pcgemm2.hip — EXPERIMENT (not part of libsmx.so): producer / consumer GEMM for the output-heavy K = 256 shapes.
 //
-// Question: a 128 x 128 workgroup of gemm.hip lives 25.5 K cycles for 2 K cycles of MFMA work; its four
+// Question (DESIGN_APPENDIX.md §5 / §7): a 128 x 128 workgroup of gemm.hip lives 25.5 K cycles for 2 K cycles of MFMA work; its four
 // waves load, multiply, stage and run the epilogue one after the other, and the three workgroups of a CU do it in phase.
 // Does it pay to give the two halves to DIFFERENT waves of one persistent workgroup?
 //

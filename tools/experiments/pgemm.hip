@@ -1,6 +1,6 @@
 // pgemm.hip — persistent LDS-DMA GEMM for the long-K bf16 NT / NN shapes of the encoder (gfx950).
 //
-// Why: the tiled kernels of gemm.hip run 2-3 workgroups of 4 waves per CU; each fetches its operands
+// Why (DESIGN_APPENDIX.md §4/§5): the tiled kernels of gemm.hip run 2-3 workgroups of 4 waves per CU; each fetches its operands
 // through registers (one 48 KB stage in flight per workgroup), multiplies, stages its epilogue and retires.  On the
 // K >= 512 shapes that structure is bound by (operand bytes in flight per CU) / (L2 -> CU latency): a 128 x 256 tile
 // needs 96 B of operands per output-tile row per K element, and prefetching across the epilogue needs VGPRs it does not
