@@ -498,3 +498,46 @@ def test_small_batch_split_k_path_every_parameter_gradient_vs_oracle(B, T, d, f,
         if e > worst[1]:
             worst = (n, e)
     assert worst[1] <= 3e-2, worst
+
+
+@pytest.mark.parametrize("B,T,d,f", [(6, 350, 256, 1024), (10, 375, 512, 2048), (18, 500, 256, 1024), (36, 500, 256, 1024), (20, 450, 512, 2048)])
+def test_dispatch_regimes_every_parameter_gradient_vs_oracle(B, T, d, f):
+    """The batch sizes between one utterance and the headline batch each take a different set of kernels (functional.py's rules, round 6):
+    2100 frames: 32- / 64-row panels, tiled 64 x 64 GEMMs, the slab-free grouped wgrad; the recipe's 10 x 375 frames at d_model 512; 9000
+    frames: above the slab-free wgrad's limit (slabs + reduce_jobs), 128-row panels dealt to several workgroups; 18 000 frames at d_model
+    256: the LayerNorm-fused epilogues on the 64 x 256 row-complete tile; 9000 frames at d_model 512.  Output, dL/dx and EVERY parameter
+    gradient of two layers against the fp64 oracle's autograd (Conformer.py:479-537; summary_mixing.py:241-284), ragged lengths."""
+    from oracle import smx_oracle as O
+    from summarymixing_amd import functional as F
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(B * 1000 + T)
+    enc = ConformerEncoder(2, d, f, 4, kernel_size=31, activation="swish", dropout=0.0, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast")
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_normal_(p)
+            elif "bias" in n:
+                p.normal_(0, 0.05)
+    sd = {k: v.double().requires_grad_(True) for k, v in enc.state_dict().items()}
+    x = torch.randn(B, T, d)
+    lens = torch.randint(T // 2, T + 1, (B,)); lens[0] = T
+    pad = torch.arange(T)[None] < lens[:, None]
+    r = torch.randn(B, T, d) * pad[..., None]
+    xr = x.double().requires_grad_(True)
+    ref = O.conformer_encoder(xr, sd, "", "swish", "SummaryMixing-fast", d, None, pad)
+    (ref * r.double()).sum().backward()
+    enc = enc.cuda().train()
+    xg = x.cuda().bfloat16().requires_grad_(True)
+    y, _ = enc(xg, src_key_padding_mask=pad.cuda())
+    (y.float() * r.cuda()).sum().backward()
+    F.flush_deferred()
+    torch.cuda.synchronize()
+    assert rel_err(y, ref) <= 1e-2, rel_err(y, ref)
+    assert rel_err(xg.grad, xr.grad) <= 3e-2, rel_err(xg.grad, xr.grad)
+    worst = ("", 0.0)
+    for n, p in enc.named_parameters():
+        e = rel_err(p.grad, sd[n].grad)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] <= 3e-2, worst
