@@ -147,3 +147,35 @@ def test_c5_twelve_layer_stack_at_full_size_properties():
     t_full = timed(x, pad)
     t_half = timed(x[:, :T // 2].contiguous(), pad[:, :T // 2].contiguous())
     assert 1.6 <= t_full / t_half <= 2.4, (t_full, t_half)
+
+
+@pytest.mark.parametrize("B,T,d,f", [(1, 500, 256, 1024), (10, 375, 512, 2048), (6, 350, 256, 1024)])
+def test_small_batch_training_step_is_bit_reproducible(B, T, d, f):
+    """The round-6 small-batch kernels reduce in a FIXED order (split-K slabs summed by the row reducer in slab order, the slab-free
+    grouped wgrad with one writer per gradient element, the pool's two-level fold, smx_reduce_jobs): the same training-mode step -
+    dropout 0.15, the same seeds - twice from the same state gives bit-identical outputs, dL/dx and parameter gradients (one
+    utterance, the recipe's 10 x 375 frames at d_model 512, 2100 frames).  No float atomics anywhere on these paths."""
+    from summarymixing_amd import functional as F, ops
+    from summarymixing_amd.lobes.models.transformer.Conformer import ConformerEncoder
+    torch.manual_seed(B * 100 + T)
+    enc = ConformerEncoder(2, d, f, 4, kernel_size=31, activation="swish", dropout=0.15, attention_type="SummaryMixing",
+                           local_proj_hid_dim=[d], local_proj_out_dim=d, summary_hid_dim=[d], mode="SummaryMixing-fast").cuda().train()
+    x0 = torch.randn(B, T, d, device="cuda").bfloat16()
+    lens = torch.randint(T // 2, T + 1, (B,), device="cuda"); lens[0] = T
+    pad = torch.arange(T, device="cuda")[None] < lens[:, None]
+    r = torch.randn(B, T, d, device="cuda")
+    runs = []
+    for _ in range(2):
+        ops._drop_state["counter"] = 1000                  # the same dropout seeds in both runs
+        enc.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        y, _ = enc(x, src_key_padding_mask=pad)
+        (y.float() * r).sum().backward()
+        F.flush_deferred()
+        torch.cuda.synchronize()
+        runs.append((y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in enc.named_parameters()}))
+    (y1, g1, p1), (y2, g2, p2) = runs
+    assert torch.isfinite(y1.float()).all() and (y1 != 0).any()
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)
+    for n in p1:
+        assert torch.equal(p1[n], p2[n]), n
